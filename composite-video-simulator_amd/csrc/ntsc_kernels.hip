@@ -1,0 +1,699 @@
+// ntsc_kernels.hip -- CDNA4 (gfx950) kernels for the per-field NTSC composite / VHS chain
+// (reference: composite_layer(), ffmpeg_ntsc.cpp:1570-1921).
+//
+// Execution model.  Every filter in the reference is a SERIAL fp64 recurrence along a scanline
+// whose result is truncated to int between stages, so bit-exactness forbids any re-association
+// inside a row.  Parallelism therefore comes from scanlines: ONE LANE = ONE SCANLINE, a wavefront
+// carries 64 scanlines in lock-step along x, and a batch of fields supplies tens of thousands of
+// independent rows.  All lanes of a wave are always at the same x, which gives
+//   * coalesced access to the transposed composite plane comp[x][row] (256 B per wave access),
+//   * the VHS vertical chroma blend as a one-lane wave shift (__shfl_up), no line buffer,
+//   * wave-uniform control flow for every pipeline guard.
+// The whole stage chain is streamed in x with bounded look-ahead, so no intermediate plane ever
+// touches HBM except the composite signal itself (the encoder|decoder interface, which the head
+// switching stage needs random access to).
+//
+//   k_field_setup : 1 lane / field   head-switch geometry, per-row phase noise + dropout draws
+//   k_row_states  : 1 lane / (row, noise stream)  rand() state + noise accumulator at row start
+//   k_encode      : 1 lane / row     BGRA -> YIQ -> chroma LP -> QAM -> pre-emphasis -> luma noise
+//   k_decode      : 1 lane / row     head switch -> Y/C split -> noise -> VHS -> TV LP -> BGRA
+//
+// fp contract: this file MUST be compiled with -ffp-contract=off (an FMA changes the results).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ntsc_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ntscsim {
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------ integer helpers
+DEV int sdiv2(int n) { return (n + (int)((unsigned)n >> 31)) >> 1; }   // C `/ 2` (truncating)
+DEV int sdiv4(int n) { return (n + ((n >> 31) & 3)) >> 2; }             // C `/ 4`
+DEV unsigned udiv31(unsigned n, const Magic31 &m) { return __umulhi(n, m.mul) >> m.shift; }
+DEV unsigned umod31(unsigned n, const Magic31 &m) { return n - udiv31(n, m) * m.div; }
+DEV int sdivm(int n, const Magic31 &m)                                   // C `/ d`, d > 0
+{
+    const unsigned a = (unsigned)(n < 0 ? -n : n);
+    const int q = (int)udiv31(a, m);
+    return n < 0 ? -q : q;
+}
+
+// scanline subcarrier phase, ffmpeg_ntsc.cpp:1473-1480 / :1529-1536
+DEV unsigned scan_phase(const DevParams &P, unsigned y, uint64_t fieldno)
+{
+    const unsigned off = (unsigned)P.phase_off;
+    if (P.phase_mode == 90)  return (unsigned)((fieldno + off + (y >> 1)) & 3);
+    if (P.phase_mode == 180) return (unsigned)((((fieldno + y) & 2) + off) & 3);
+    if (P.phase_mode == 270) return (unsigned)((fieldno + off - (y >> 1)) & 3);
+    return off & 3;
+}
+
+// ------------------------------------------------------------------------------ one-pole IIR
+// LowpassFilter::lowpass / highpass, ffmpeg_ntsc.cpp:90-99 (operation order is the contract)
+struct OnePole {
+    double p;
+    DEV double lp(double s, double a)
+    {
+        const double s1 = s * a;
+        const double s2 = p - (p * a);
+        p = s1 + s2;
+        return p;
+    }
+    DEV double hp(double s, double a)
+    {
+        const double s1 = s * a;
+        const double s2 = p - (p * a);
+        p = s1 + s2;
+        return s - p;
+    }
+};
+struct Lp3 {
+    OnePole f0, f1, f2;
+    DEV void reset(double v) { f0.p = v; f1.p = v; f2.p = v; }
+    DEV double push(double s, double a) { return f2.lp(f1.lp(f0.lp(s, a), a), a); }
+};
+
+// ------------------------------------------------------------------------------ rand() in LDS
+// Per-lane glibc TYPE_3 generator: the 31-word window lives in LDS as ring[slot][lane]
+// (conflict-free: bank = lane), the three newest words in registers.
+struct LaneRand {
+    uint32_t p3, p2, p1;   // s[i-3], s[i-2], s[i-1]
+    int slot;              // wave-uniform
+    DEV void init(uint32_t *ring, const uint32_t *state, int stride, int lane)
+    {
+        for (int j = 0; j < 31; j++) ring[j * 64 + lane] = state[(size_t)j * stride];
+        p3 = ring[28 * 64 + lane];
+        p2 = ring[29 * 64 + lane];
+        p1 = ring[30 * 64 + lane];
+        slot = 0;
+    }
+    DEV uint32_t next(uint32_t *ring, int lane)
+    {
+        const uint32_t v = ring[slot * 64 + lane] + p3;   // s[i-31] + s[i-3]
+        ring[slot * 64 + lane] = v;
+        p3 = p2; p2 = p1; p1 = v;
+        slot = (slot == 30) ? 0 : slot + 1;
+        return v >> 1;
+    }
+};
+
+// generator over a private array (setup kernels only; tiny amount of work)
+struct LocalRand {
+    uint32_t r[31];
+    int i;
+    DEV void load(const uint32_t *s) { for (int j = 0; j < 31; j++) r[j] = s[j]; i = 0; }
+    DEV uint32_t next()
+    {
+        int j = i + 28; if (j >= 31) j -= 31;
+        const uint32_t v = r[i] + r[j];
+        r[i] = v;
+        i = (i == 30) ? 0 : i + 1;
+        return v >> 1;
+    }
+    // advance by the jump polynomial c (x^n mod x^31 - x^28 - 1): new w[j] = sum_k c[k] w[j+k]
+    DEV void jump(const uint32_t *c)
+    {
+        uint32_t w[61], o[31];
+        for (int j = 0; j < 31; j++) { int q = i + j; if (q >= 31) q -= 31; w[j] = r[q]; }
+        for (int j = 31; j < 61; j++) w[j] = w[j - 31] + w[j - 3];
+        for (int j = 0; j < 31; j++) {
+            uint32_t acc = 0;
+            for (int k = 0; k < 31; k++) acc += c[k] * w[j + k];
+            o[j] = acc;
+        }
+        for (int j = 0; j < 31; j++) r[j] = o[j];
+        i = 0;
+    }
+};
+
+DEV int field_rows(const DevParams &P, unsigned field) { return (P.H - (int)field + 1) / 2; }
+
+// =============================================================================== k_field_setup
+// Per field: the draws that are not per-pixel.  Order of draws inside one composite_layer call
+// (SURVEY A.10): [W*L luma] [4 head switch] [2*W*L chroma] [L phase noise] [L dropout].
+__global__ void k_field_setup(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
+                              int *__restrict__ hs_shift, int *__restrict__ pn_noise,
+                              int *__restrict__ dropout)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= P.nfields) return;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const int L = field_rows(P, field);
+    int *hs_row = hs_shift + (size_t)f * P.Lslot;
+
+    LocalRand g;
+    g.load(fd.rng);
+    if (P.noise_k) g.jump(G.lskip + field * 31);
+
+    // VHS head switching geometry, ffmpeg_ntsc.cpp:1647-1713
+    if (P.hs) {
+        const unsigned twidth = (unsigned)P.W + ((unsigned)P.W / 10u);
+        double noise = 0;
+        if (P.hs_noise_on) {
+            unsigned u = g.next();
+            u *= g.next(); u *= g.next(); u *= g.next();
+            u %= 2000000000U;
+            noise = ((double)u / 1000000000U) - 1.0;
+            noise *= P.hs_pn;
+        }
+        const double t = P.ntsc ? twidth * 262.5 : twidth * 312.5;
+        // fmod(a, 1.0) == a - trunc(a) exactly (params are validated non-negative)
+        double a = P.hs_point + noise;
+        unsigned pp = (unsigned)((a - trunc(a)) * t);
+        int y = (int)((pp / twidth) * 2u) + (int)field;
+        a = P.hs_phase + noise;
+        pp = (unsigned)((a - trunc(a)) * t);
+        const unsigned hx = pp % twidth;
+        y -= P.ntsc ? (262 - 240) * 2 : (312 - 288) * 2;
+        const int ishif = (hx >= twidth / 2) ? (int)(hx - twidth) : (int)hx;
+        // the first row (shif = 0) is a no-op; later rows always start at tx = 0
+        int shif = 0;
+        unsigned shy = 0;
+        while (y < P.H) {
+            if (y >= 0 && shif != 0) hs_row[(y - (int)field) >> 1] = shif;
+            shif = (shy == 0) ? ishif : (shif * 7) / 8;
+            y += 2;
+            shy++;
+        }
+    }
+
+    if (P.cnoise_k) g.jump(G.cskip + field * 31);
+
+    // chroma phase noise accumulator, one draw per row, carried down the field (:1736-1746)
+    if (P.pnoise_k) {
+        int n = 0;
+        for (int k = 0; k < L; k++) {
+            n += (int)umod31(g.next(), P.m_pnoise) - P.pnoise_k;
+            n = sdiv2(n);
+            pn_noise[(size_t)f * P.Lslot + k] = n;
+        }
+    }
+    // chroma dropout, one draw per row (:1891-1901)
+    if (P.loss) {
+        for (int k = 0; k < L; k++)
+            dropout[(size_t)f * P.Lslot + k] = (g.next() % 100000U) < (unsigned)P.loss;
+    }
+}
+
+// =============================================================================== k_row_states
+// rand() state and noise accumulator(s) at the first pixel of every scanline.
+// The accumulators are carried across rows in the reference (noise = (noise + d - k) / 2, C
+// truncation), but the map is monotone in `noise` and halves the distance, so running it from
+// both extremes (-k and +k) over a short warm-up pins the exact value as soon as the two
+// trajectories meet.  If they have not met after the warm-up (probability ~2^-warm) the lane
+// recomputes serially from the start of the field -- exact by construction either way.
+__global__ void k_row_states(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
+                             uint32_t *__restrict__ rs_luma, int *__restrict__ n0_luma,
+                             uint32_t *__restrict__ rs_chroma, int *__restrict__ n0_u,
+                             int *__restrict__ n0_v)
+{
+    const int rho = blockIdx.x * blockDim.x + threadIdx.x;
+    const int stream = blockIdx.y;                 // 0 luma, 1 chroma
+    if (rho >= P.R) return;
+    if (stream == 0 ? !P.noise_k : !P.cnoise_k) return;
+    const int f = rho / P.Lslot, k = rho - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned par = fd.field & 1u;
+    if (k >= field_rows(P, par)) return;
+
+    const size_t jidx = ((size_t)(stream * 2 + par) * P.Lslot + k);
+    const int warm = G.jwarm[jidx];
+    const int K = stream == 0 ? P.noise_k : P.cnoise_k;
+    const Magic31 M = stream == 0 ? P.m_noise : P.m_cnoise;
+    const long long start = stream == 0 ? (long long)k * P.W : 2ll * k * P.W;  // draws before row
+    const bool exact = (long long)warm == start;   // warm-up reaches the start of the stream
+
+    LocalRand g;
+    g.load(fd.rng);
+    g.jump(G.jrow + jidx * 31);
+
+    int lo0 = exact ? 0 : -K, hi0 = exact ? 0 : K;   // luma / U
+    int lo1 = lo0, hi1 = hi0;                         // V
+    if (stream == 0) {
+        for (int i = 0; i < warm; i++) {
+            const int d = (int)umod31(g.next(), M) - K;
+            lo0 = sdiv2(lo0 + d); hi0 = sdiv2(hi0 + d);
+        }
+    } else {
+        for (int i = 0; i < warm; i += 2) {
+            int d = (int)umod31(g.next(), M) - K;
+            lo0 = sdiv2(lo0 + d); hi0 = sdiv2(hi0 + d);
+            d = (int)umod31(g.next(), M) - K;
+            lo1 = sdiv2(lo1 + d); hi1 = sdiv2(hi1 + d);
+        }
+    }
+    if (lo0 != hi0 || lo1 != hi1) {
+        // not pinned: serial replay from the first draw of this stream in this field
+        g.load(fd.rng);
+        g.jump(G.sstart + (size_t)(stream * 2 + par) * 31);
+        lo0 = lo1 = 0;
+        if (stream == 0) {
+            for (long long i = 0; i < start; i++)
+                lo0 = sdiv2(lo0 + (int)umod31(g.next(), M) - K);
+        } else {
+            for (long long i = 0; i < start; i += 2) {
+                lo0 = sdiv2(lo0 + (int)umod31(g.next(), M) - K);
+                lo1 = sdiv2(lo1 + (int)umod31(g.next(), M) - K);
+            }
+        }
+    }
+
+    uint32_t *rs = stream == 0 ? rs_luma : rs_chroma;
+    for (int j = 0; j < 31; j++) {
+        int q = g.i + j; if (q >= 31) q -= 31;
+        rs[(size_t)j * P.Rpad + rho] = g.r[q];
+    }
+    if (stream == 0) n0_luma[rho] = lo0;
+    else { n0_u[rho] = lo0; n0_v[rho] = lo1; }
+}
+
+// =============================================================================== k_encode
+// BGRA row -> composite signal (int32, Y*256 with the chroma subcarrier riding on it).
+// Stream position t reads pixel t; output sample x = t - 4 (the Q low-pass looks 4 ahead).
+
+DEV void load_px16(const uint8_t *srow, int x0, int W, bool al16, uint32_t (&px)[16])
+{
+    if (al16 && x0 + 16 <= W) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(srow + 4 * (size_t)x0);
+        const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w;
+        px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+        px[8] = c.x; px[9] = c.y; px[10] = c.z; px[11] = c.w;
+        px[12] = d.x; px[13] = d.y; px[14] = d.z; px[15] = d.w;
+    } else {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(srow);
+#pragma unroll
+        for (int j = 0; j < 16; j++) px[j] = (x0 + j < W) ? p[x0 + j] : 0u;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__restrict__ fields,
+                                               const uint32_t *__restrict__ rs_luma,
+                                               const int *__restrict__ n0_luma,
+                                               int *__restrict__ comp)
+{
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int rho = blockIdx.x * 64 + lane;
+    const int rc = rho < P.R ? rho : P.R - 1;
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool valid = rho < P.R && (int)(field + 2u * k) < P.H;
+    const unsigned y = valid ? field + 2u * (unsigned)k : field;
+    // source row: min(y + opposite, H-1), ffmpeg_ntsc.cpp:1585-1588, :1599
+    const unsigned opposite = (fd.flags & 1u) ? ((fd.flags & 2u) ? 1u : 0u) : 0u;
+    unsigned sy = y + opposite;
+    if (sy > (unsigned)P.H - 1u) sy = (unsigned)P.H - 1u;
+    const uint8_t *srow = fd.src + (size_t)fd.src_ls * sy;
+    const unsigned xi = scan_phase(P, y, fd.fieldno);
+    const int W = P.W;
+
+    LaneRand rng;
+    int noise = 0;
+    if (P.noise_k) {
+        rng.init(ring, rs_luma + rc, P.Rpad, lane);
+        noise = n0_luma[rc];
+    }
+
+    Lp3 lpI, lpQ;
+    lpI.reset(0); lpQ.reset(0);
+    OnePole pre; pre.p = 16;
+    // delay windows: element 0 is the oldest (sample t-4), element 4 the newest (sample t)
+    int Yw[5] = {0, 0, 0, 0, 0}, Iw[5] = {0, 0, 0, 0, 0}, Qw[5] = {0, 0, 0, 0, 0};
+    int fI[3] = {0, 0, 0};
+    int *cdst = comp + rho;
+
+    uint32_t cur[16], nxt[16];
+    load_px16(srow, 0, W, P.src_al16 != 0, cur);
+    for (int t0 = 0; t0 < W + 4; t0 += 16) {
+        if (t0 + 16 < W) load_px16(srow, t0 + 16, W, P.src_al16 != 0, nxt);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int t = t0 + j;
+            if (t >= W + 4) break;
+            // ---- RGB -> YIQ, ffmpeg_ntsc.cpp:1375-1383 (pixels past the row end feed zeros
+            //      into filters whose outputs are never used)
+            const uint32_t px = (t < W) ? cur[j] : 0u;
+            const int r = (int)((px >> 16) & 0xFF), g = (int)((px >> 8) & 0xFF), b = (int)(px & 0xFF);
+            const double dY = (0.30 * r) + (0.59 * g) + (0.11 * b);
+            const int Yn = (int)(256 * dY);
+            const int In = (int)(256 * ((-0.27 * (b - dY)) + (0.74 * (r - dY))));
+            const int Qn = (int)(256 * ((0.41 * (b - dY)) + (0.48 * (r - dY))));
+#pragma unroll
+            for (int q = 0; q < 4; q++) { Yw[q] = Yw[q + 1]; Iw[q] = Iw[q + 1]; Qw[q] = Qw[q + 1]; }
+            Yw[4] = Yn; Iw[4] = In; Qw[4] = Qn;
+            // ---- input chroma low-pass, composite_lowpass :1429-1458 (I: 1.3 MHz delay 2,
+            //      Q: 0.6 MHz delay 4; the last `delay` samples keep their input)
+            fI[0] = fI[1]; fI[1] = fI[2];
+            fI[2] = (int)lpI.push((double)In, P.a_in_i);
+            const int fQ = (int)lpQ.push((double)Qn, P.a_in_q);
+
+            const int x = t - 4;
+            if (x < 0) continue;
+            int I1 = Iw[0], Q1 = Qw[0];
+            if (P.in_lp) {
+                if (x < W - 2) I1 = fI[0];
+                if (x < W - 4) Q1 = fQ;
+            }
+            // ---- chroma_into_luma :1460-1495
+            const unsigned s = (xi + (unsigned)x) & 3u;
+            int chroma = ((s & 1u) ? Q1 : I1) * P.amp;
+            if (s & 2u) chroma = -chroma;
+            int Y = Yw[0] + chroma / 50;
+            // ---- composite pre-emphasis :1614-1629
+            if (P.pre_on) {
+                double sd = Y;
+                sd += pre.hp(sd, P.a_pre) * P.pre_gain;
+                Y = (int)sd;
+            }
+            // ---- luma noise :1632-1644
+            if (P.noise_k) {
+                Y += noise;
+                noise += (int)umod31(rng.next(ring, lane), P.m_noise) - P.noise_k;
+                noise = sdiv2(noise);
+            }
+            if (valid) cdst[(size_t)x * P.Rpad] = Y;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) cur[j] = nxt[j];
+    }
+}
+
+// =============================================================================== k_decode
+// streaming chroma_from_luma (ffmpeg_ntsc.cpp:1497-1567).  push(t) takes composite sample t and
+// returns Y/I/Q for x = t - 7.
+struct Demod {
+    int c0, c1, c2;               // cs(t-3), cs(t-2), cs(t-1)
+    int w0, w1, w2, w3, w4, w5;   // scaled chroma at q-5 .. q   (q = t-2)
+    int y0, y1, y2, y3, y4;       // box-filtered luma at q-5 .. q-1
+    int ie_prev, qe_prev, ie_next, qe_next;
+    DEV void init()
+    {
+        c0 = c1 = c2 = 0;
+        w0 = w1 = w2 = w3 = w4 = w5 = 0;
+        y0 = y1 = y2 = y3 = y4 = 0;
+        ie_prev = qe_prev = ie_next = qe_next = 0;
+    }
+    DEV static int sel4(unsigned xi, int a0, int a1, int a2, int a3)
+    {
+        const int lo = (xi & 1u) ? a1 : a0;
+        const int hi = (xi & 1u) ? a3 : a2;
+        return (xi & 2u) ? hi : lo;
+    }
+    DEV void push(int ct, int t, unsigned xi, int W, int xe, const Magic31 &mA, bool nocolor,
+                  int &Yo, int &Io, int &Qo)
+    {
+        const int q = t - 2;
+        // 4-tap box with zero extension (:1507-1525)
+        const int yb = nocolor ? c1 : sdiv4(c0 + c1 + c2 + ct);
+        int ch = ct - yb;
+        // un-flip the negative half cycles (:1539-1542): positions x+2, x+3 for
+        // x = (4-xi)&3 + 4m while x+3 < W
+        const unsigned g = (unsigned)(q - 2 + (int)xi) & 3u;
+        const bool neg = (g == 0u && q >= 2 && q + 1 < W) || (g == 1u && q >= 3);
+        if (neg) ch = -ch;
+        ch = sdivm(ch * 50, mA);                                         // :1544-1546
+        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
+        c0 = c1; c1 = c2; c2 = ct;
+        Yo = y0;
+        y0 = y1; y1 = y2; y2 = y3; y3 = y4; y4 = yb;
+        const int x = q - 5;
+        int I, Q;
+        if (x & 1) {
+            // odd x (and x = -1): fetch the even sample at x+1, interpolate (:1549-1561)
+            const bool m = (x + 1 + (int)xi + 1) < W;
+            ie_next = m ? -sel4(xi, w1, w2, w3, w4) : 0;
+            qe_next = m ? -sel4(xi, w2, w3, w4, w5) : 0;
+            I = (ie_prev + ie_next) >> 1;
+            Q = (qe_prev + qe_next) >> 1;
+        } else {
+            I = ie_next; Q = qe_next;
+            ie_prev = ie_next; qe_prev = qe_next;
+        }
+        if (x >= xe || nocolor) { I = 0; Q = 0; }                        // :1553-1556, :1562-1565
+        Io = I; Qo = Q;
+    }
+};
+
+template <bool VHS, bool COMPOUT>
+__global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
+                                               const FieldDev *__restrict__ fields,
+                                               const int *__restrict__ comp,
+                                               const uint32_t *__restrict__ rs_chroma,
+                                               const int *__restrict__ n0_u,
+                                               const int *__restrict__ n0_v,
+                                               const int *__restrict__ hs_shift,
+                                               const int *__restrict__ pn_noise,
+                                               const int *__restrict__ dropout)
+{
+    __shared__ uint32_t ring[31 * 64];
+    __shared__ int tailU[16 * 64], tailV[16 * 64];
+    __shared__ uint32_t ostage[64 * 17];
+
+    const int lane = threadIdx.x;
+    // 63 output rows per wave; lane 0 recomputes the row above (halo for the vertical blend)
+    const int gidx = blockIdx.x * 63 + lane - 1;
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok;
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const unsigned xi = scan_phase(P, y, fd.fieldno);
+    const int W = P.W;
+    const int xe = (W & 1) ? W - 1 : W - 2;      // first even x with x+2 >= W
+    const int tw = W + W / 10;
+    const int hs = P.hs ? hs_shift[rc] : 0;
+    const bool drop = P.loss ? dropout[rc] != 0 : false;
+    double cosv = 1, sinv = 0;
+    if (P.pnoise_k) {
+        const int n = pn_noise[rc] + P.pnoise_k;
+        cosv = G.ptab[2 * n]; sinv = G.ptab[2 * n + 1];
+    }
+    uint32_t *drow = reinterpret_cast<uint32_t *>(fd.dst + (size_t)fd.dst_ls * y);
+    const int *cbase = comp + rc;
+    const bool vb = VHS && P.vblend && P.ntsc;
+
+    LaneRand rng;
+    int nU = 0, nV = 0;
+    if (P.cnoise_k) {
+        rng.init(ring, rs_chroma + rc, P.Rpad, lane);
+        nU = n0_u[rc]; nV = n0_v[rc];
+    }
+
+    // composite sample after head switching (:1687-1697): Y[x] = tmp[(x + shif) mod twidth],
+    // tmp = the row followed by zeros up to twidth; zero outside the row.
+    auto cs = [&](int x) -> int {
+        if (x < 0 || x >= W) return 0;
+        int idx = x;
+        if (hs != 0) {
+            idx = x + hs;
+            if (idx < 0) idx += tw; else if (idx >= tw) idx -= tw;
+            if (idx >= W) return 0;
+        }
+        return cbase[(size_t)idx * P.Rpad];
+    };
+
+    const int d = VHS ? P.cdelay : 0;             // VHS chroma delay (9/12/14)
+    const int SK1 = 7;                            // demodulator latency
+    const int SK2 = COMPOUT ? 7 : 0;              // second demodulator
+    const int dI = P.out_lp == 2 ? 2 : (P.out_lp == 1 ? 1 : 0);
+    const int dQ = P.out_lp == 2 ? 4 : (P.out_lp == 1 ? 1 : 0);
+    const int SKO = dQ;                           // output low-pass look-ahead
+    const int total = W + SK1 + d + SK2 + SKO;
+
+    Demod D1, D2;
+    D1.init(); D2.init();
+    int l0 = 0, l1 = 0, l2 = 0;                   // luma stream window (VHS)
+    Lp3 vl, vcU, vcV, sh, oU, oV;
+    OnePole vpre;
+    vl.reset(16); vpre.p = 16; vcU.reset(0); vcV.reset(0); sh.reset(0); oU.reset(0); oV.reset(0);
+    // output stage windows: element 0 oldest
+    int Yd[5] = {0, 0, 0, 0, 0};                  // luma delayed to the output position
+    int Ur[5] = {0, 0, 0, 0, 0}, Vr[5] = {0, 0, 0, 0, 0};   // raw chroma (row tails)
+    int Uf[3] = {0, 0, 0};                        // filtered U waiting for V (full LP only)
+
+    int pc[4], pl[4];                             // prefetched composite samples
+#pragma unroll
+    for (int j = 0; j < 4; j++) { pc[j] = cs(j); pl[j] = VHS ? cs(j - 5 - d) : 0; }
+
+    for (int t0 = 0; t0 < total; t0 += 4) {
+        int nc[4], nl[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            nc[j] = cs(t0 + 4 + j);
+            nl[j] = VHS ? cs(t0 + 4 + j - 5 - d) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = t0 + j;
+            if (t >= total) break;
+            // ================= Y/C separation #1 at x1 = t - 7 (:1716, amplitude_back)
+            int Y, U, V;
+            D1.push(pc[j], t, xi, W, xe, P.m_amp_back, P.nocolor != 0, Y, U, V);
+            const int x1 = t - SK1;
+            if (x1 >= 0 && x1 < W) {
+                // chroma noise :1719-1735
+                if (P.cnoise_k) {
+                    U += nU; V += nV;
+                    nU = sdiv2(nU + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+                    nV = sdiv2(nV + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+                }
+                // chroma phase noise :1748-1762
+                if (P.pnoise_k) {
+                    const double u = U, v = V;
+                    const double u_ = (u * cosv) - (v * sinv);
+                    const double v_ = (u * sinv) + (v * cosv);
+                    U = (int)u_; V = (int)v_;
+                }
+            }
+            int x2 = x1;           // position after the VHS block
+            if (VHS) {
+                // ---- VHS chroma low-pass :1814-1836: value for input x1 lands at x1 - d
+                int fU = 0, fV = 0;
+                if (x1 >= 0 && x1 < W) {
+                    fU = (int)vcU.push((double)U, P.a_vc);
+                    fV = (int)vcV.push((double)V, P.a_vc);
+                    if (x1 >= W - 16) { tailU[(x1 & 15) * 64 + lane] = U; tailV[(x1 & 15) * 64 + lane] = V; }
+                }
+                x2 = x1 - d;
+                // ---- luma path at x2: box (or pass-through) -> low-pass + emphasis -> sharpen
+                const int lc = pl[j];              // cs(x2 + 2)
+                const int yb = P.nocolor ? l1 : sdiv4(l0 + l1 + l2 + lc);
+                l0 = l1; l1 = l2; l2 = lc;
+                if (x2 >= 0 && x2 < W) {
+                    if (x2 >= W - d) { fU = tailU[(x2 & 15) * 64 + lane]; fV = tailV[(x2 & 15) * 64 + lane]; }
+                    U = fU; V = fV;
+                    // luma low-pass + emphasis :1793-1812
+                    double s = yb;
+                    s = vl.push(s, P.a_vl);
+                    s += vpre.hp(s, P.a_vl) * 1.6;
+                    Y = (int)s;
+                    // sharpen :1866-1883
+                    {
+                        const double s0 = Y;
+                        const double ts = sh.push(s0, P.a_sh);
+                        Y = (int)(s0 + ((s0 - ts) * P.sharpen * 2));
+                    }
+                }
+                // ---- vertical chroma blend :1843-1863 (wave shift: lane-1 is the row above)
+                {
+                    const int upU = __shfl_up(U, 1), upV = __shfl_up(V, 1);
+                    if (vb && k >= 1) {
+                        const int pu = k >= 2 ? upU : 0, pv = k >= 2 ? upV : 0;
+                        U = (pu + U + 1) >> 1;
+                        V = (pv + V + 1) >> 1;
+                    }
+                }
+            }
+            int x3 = x2;
+            if (COMPOUT) {
+                // ---- composite out of the VCR :1885-1888: modulate, then separate again
+                int c2 = 0;
+                if (x2 >= 0 && x2 < W) {
+                    const unsigned s = (xi + (unsigned)x2) & 3u;
+                    int chroma = ((s & 1u) ? V : U) * P.amp;
+                    if (s & 2u) chroma = -chroma;
+                    c2 = Y + chroma / 50;
+                }
+                D2.push(c2, x2, xi, W, xe, P.m_amp, false, Y, U, V);
+                x3 = x2 - 7;
+            }
+            if (x3 < 0 || x3 >= W + SKO) continue;
+            // ================= dropout :1891-1901, output low-pass :1903-1908 at x3
+            const bool in3 = x3 < W;
+            if (drop || !in3) { U = 0; V = 0; }
+            if (!in3) Y = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { Yd[q] = Yd[q + 1]; Ur[q] = Ur[q + 1]; Vr[q] = Vr[q + 1]; }
+            Yd[4] = Y; Ur[4] = U; Vr[4] = V;
+            int fU = 0, fV = 0;
+            if (P.out_lp && in3) {
+                const double a_u = P.out_lp == 1 ? P.a_tv : P.a_in_i;
+                const double a_v = P.out_lp == 1 ? P.a_tv : P.a_in_q;
+                fU = (int)oU.push((double)U, a_u);
+                fV = (int)oV.push((double)V, a_v);
+            }
+            Uf[0] = Uf[1]; Uf[1] = Uf[2]; Uf[2] = fU;
+            const int xo = x3 - SKO;
+            if (xo < 0) continue;
+            int Yo = Yd[4 - SKO], Uo, Vo;
+            if (P.out_lp == 0) { Uo = U; Vo = V; }
+            else {
+                // U value for xo was produced dI steps after xo entered, V value dQ steps after
+                Uo = (xo < W - dI) ? Uf[2 - (dQ - dI)] : Ur[4 - SKO];
+                Vo = (xo < W - dQ) ? fV : Vr[4 - SKO];
+            }
+            // ================= YIQ -> RGB :1385-1396, pack :1914 (alpha = 0)
+            int r = (int)(((1.000 * Yo) + (0.956 * Uo) + (0.621 * Vo)) / 256);
+            int g = (int)(((1.000 * Yo) + (-0.272 * Uo) + (-0.647 * Vo)) / 256);
+            int b = (int)(((1.000 * Yo) + (-1.106 * Uo) + (1.703 * Vo)) / 256);
+            r = r < 0 ? 0 : (r > 255 ? 255 : r);
+            g = g < 0 ? 0 : (g > 255 ? 255 : g);
+            b = b < 0 ? 0 : (b > 255 ? 255 : b);
+            ostage[lane * 17 + (xo & 15)] = ((uint32_t)r << 16) + ((uint32_t)g << 8) + (uint32_t)b;
+            if ((xo & 15) == 15 || xo == W - 1) {
+                const int xb = xo & ~15;
+                const int n = xo - xb + 1;
+                if (is_out) {
+                    if (n == 16 && P.dst_al16) {
+                        uint4 *o = reinterpret_cast<uint4 *>(drow + xb);
+                        const uint32_t *s = &ostage[lane * 17];
+                        o[0] = make_uint4(s[0], s[1], s[2], s[3]);
+                        o[1] = make_uint4(s[4], s[5], s[6], s[7]);
+                        o[2] = make_uint4(s[8], s[9], s[10], s[11]);
+                        o[3] = make_uint4(s[12], s[13], s[14], s[15]);
+                    } else {
+                        for (int q = 0; q < n; q++) drow[xb + q] = ostage[lane * 17 + q];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
+    }
+}
+
+// explicit instantiations used by the launcher
+template __global__ void k_decode<false, false>(DevParams, GeomDev, const FieldDev *, const int *,
+                                                const uint32_t *, const int *, const int *,
+                                                const int *, const int *, const int *);
+template __global__ void k_decode<true, false>(DevParams, GeomDev, const FieldDev *, const int *,
+                                               const uint32_t *, const int *, const int *,
+                                               const int *, const int *, const int *);
+template __global__ void k_decode<true, true>(DevParams, GeomDev, const FieldDev *, const int *,
+                                              const uint32_t *, const int *, const int *,
+                                              const int *, const int *, const int *);
+
+// =============================================================================== k_bob
+// Line doubling done by the field loop after composite_layer (ffmpeg_ntsc.cpp:2233-2257):
+// field 1: row y (odd) is copied onto row y-1; field 0: row y+1 is copied onto odd row y while
+// y+1 < H.  One workgroup per (field slot, destination row); 16-byte coalesced copies.
+__global__ void k_bob(DevParams P, const FieldDev *__restrict__ fields)
+{
+    const int f = blockIdx.y;
+    const FieldDev &fd = fields[f];
+    if (!(fd.flags & 0x100u)) return;
+    const unsigned field = fd.field & 1u;
+    const int yo = 2 * blockIdx.x + 1;            // odd row index
+    int ysrc, ydst;
+    if (field) { ysrc = yo; ydst = yo - 1; if (ysrc >= P.H) return; }
+    else       { ysrc = yo + 1; ydst = yo; if (ysrc >= P.H) return; }
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(fd.dst + (size_t)fd.dst_ls * ysrc);
+    uint32_t *o = reinterpret_cast<uint32_t *>(fd.dst + (size_t)fd.dst_ls * ydst);
+    if (P.dst_al16 && (P.W & 3) == 0) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+        uint4 *o4 = reinterpret_cast<uint4 *>(o);
+        for (int i = threadIdx.x; i < P.W / 4; i += blockDim.x) o4[i] = s4[i];
+    } else {
+        for (int i = threadIdx.x; i < P.W; i += blockDim.x) o[i] = s[i];
+    }
+}
+
+} // namespace ntscsim

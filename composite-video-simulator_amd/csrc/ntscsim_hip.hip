@@ -1,0 +1,497 @@
+// ntscsim_hip.hip -- context, scratch management and kernel launches behind include/ntscsim.h.
+// Replaces the call site `composite_layer(dst, src, input, field, fieldno)` of the reference's
+// field loop (ffmpeg_ntsc.cpp:2229) and the per-call heap planes it allocates (:1590-1592).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ntscsim.h"
+#include "ntsc_device.hpp"
+
+// single translation unit: the kernels are compiled together with their launcher
+#include "ntsc_kernels.hip"
+
+using namespace ntscsim;
+
+namespace {
+
+// LowpassFilter::setFilter, ffmpeg_ntsc.cpp:78-86, at the video sample rate used by every call
+double alpha_for(double hz)
+{
+    const double rate = (315000000.00 * 4) / 88;
+    const double timeInterval = 1.0 / rate;
+    const double tau = 1 / (hz * 2 * M_PI);
+    return timeInterval / (tau + timeInterval);
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Geometry {
+    int W = 0, H = 0;
+    bool valid = false;
+    DevBuf<uint32_t> lskip, cskip, jrow, sstart;
+    DevBuf<int32_t> jwarm;
+    uint64_t calls[2] = {0, 0};
+};
+
+} // namespace
+
+struct ntscsim_ctx {
+    ntscsim_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    uint64_t rng_pos = 0;
+
+    // rand() position cache for O(1) advance between consecutive fields
+    bool have_state = false;
+    uint64_t state_pos = 0;
+    RandState state;
+    struct Delta { uint64_t n; RandPoly p; };
+    std::vector<Delta> deltas;
+
+    Geometry geom;
+    DevBuf<double> ptab;
+    bool ptab_ready = false;
+
+    // per-batch scratch
+    DevBuf<FieldDev> fields;
+    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp;
+    DevBuf<uint32_t> rs_luma, rs_chroma;
+    FieldDev *stage[2] = {nullptr, nullptr};
+    size_t stage_cap[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    int stage_idx = 0;
+
+    // last batch (debug tap)
+    int last_n = 0, last_W = 0, last_H = 0, last_Rpad = 0, last_Lslot = 0;
+
+    // host-frame path
+    DevBuf<uint8_t> fsrc, fdst;
+
+    bool profiling = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+#define HIPCHK(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);           \
+            return NTSCSIM_E_HIP;                                                      \
+        }                                                                              \
+    } while (0)
+
+static RandState ctx_state_at(ntscsim_ctx *c, uint64_t pos)
+{
+    if (c->have_state) {
+        if (pos == c->state_pos) return c->state;
+        if (pos > c->state_pos) {
+            const uint64_t d = pos - c->state_pos;
+            for (auto &e : c->deltas)
+                if (e.n == d) {
+                    c->state = rand_state_apply(e.p, c->state);
+                    c->state_pos = pos;
+                    return c->state;
+                }
+            if (c->deltas.size() < 8) {
+                c->deltas.push_back({d, rand_poly_pow(d)});
+                c->state = rand_state_apply(c->deltas.back().p, c->state);
+                c->state_pos = pos;
+                return c->state;
+            }
+        }
+    }
+    c->state = rand_state_at(pos);
+    c->state_pos = pos;
+    c->have_state = true;
+    return c->state;
+}
+
+static void fill_dev_params(const ntscsim_params &p, DevParams &D)
+{
+    std::memset(&D, 0, sizeof(D));
+    D.ntsc = p.tv_standard == NTSCSIM_TV_NTSC;
+    D.phase_mode = p.video_scanline_phase_shift;
+    D.phase_off = p.video_scanline_phase_shift_offset;
+    D.in_lp = p.composite_in_chroma_lowpass != 0;
+    D.out_lp = p.composite_out_chroma_lowpass ? (p.composite_out_chroma_lowpass_lite ? 1 : 2) : 0;
+    D.amp = p.subcarrier_amplitude;
+    D.amp_back = p.subcarrier_amplitude_back;
+    D.m_amp = magic31((uint32_t)D.amp);
+    D.m_amp_back = magic31((uint32_t)D.amp_back);
+    D.noise_k = p.video_noise;
+    D.m_noise = magic31((uint32_t)(2 * p.video_noise + 1));
+    D.cnoise_k = p.video_chroma_noise;
+    D.m_cnoise = magic31((uint32_t)(2 * p.video_chroma_noise + 1));
+    D.pnoise_k = p.video_chroma_phase_noise;
+    D.m_pnoise = magic31((uint32_t)(2 * p.video_chroma_phase_noise + 1));
+    D.loss = p.video_chroma_loss;
+    D.hs = p.vhs_head_switching != 0;
+    D.hs_noise_on = p.vhs_head_switching_phase_noise != 0;
+    D.hs_point = p.vhs_head_switching_point;
+    D.hs_phase = p.vhs_head_switching_phase;
+    D.hs_pn = p.vhs_head_switching_phase_noise;
+    D.nocolor = p.nocolor_subcarrier != 0;
+    D.vhs = p.emulating_vhs != 0;
+    D.vblend = p.vhs_chroma_vert_blend != 0;
+    D.svideo = p.vhs_svideo_out != 0;
+    double luma_cut = 2400000, chroma_cut = 320000;          // :1773-1791
+    D.cdelay = 9;
+    if (p.output_vhs_tape_speed == NTSCSIM_VHS_LP) { luma_cut = 1900000; chroma_cut = 300000; D.cdelay = 12; }
+    if (p.output_vhs_tape_speed == NTSCSIM_VHS_EP) { luma_cut = 1400000; chroma_cut = 280000; D.cdelay = 14; }
+    D.pre_on = (p.composite_preemphasis != 0 && p.composite_preemphasis_cut > 0);
+    D.pre_gain = p.composite_preemphasis;
+    D.a_pre = D.pre_on ? alpha_for(p.composite_preemphasis_cut) : 0;
+    D.a_in_i = alpha_for(1300000);
+    D.a_in_q = alpha_for(600000);
+    D.a_tv = alpha_for(2600000);
+    D.a_vl = alpha_for(luma_cut);
+    D.a_vc = alpha_for(chroma_cut);
+    D.a_sh = alpha_for(luma_cut * 4);
+    D.sharpen = p.vhs_out_sharpen;
+    D.warm_luma = 64;
+    D.warm_chroma = 128;
+}
+
+// stream layout of one composite_layer() call
+static uint64_t chroma_stream_offset(const ntscsim_params &p, int W, int L)
+{
+    uint64_t o = 0;
+    if (p.video_noise != 0) o += (uint64_t)W * L;
+    if (p.vhs_head_switching && p.vhs_head_switching_phase_noise != 0) o += 4;
+    return o;
+}
+
+static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
+{
+    Geometry &g = c->geom;
+    if (g.valid && g.W == W && g.H == H) return NTSCSIM_OK;
+    g.valid = false;
+    const int Lslot = (H + 1) / 2;
+    const int Lp[2] = {(H + 1) / 2, H / 2};
+    std::vector<uint32_t> lskip(2 * 31), cskip(2 * 31), sstart(4 * 31), jrow((size_t)4 * Lslot * 31);
+    std::vector<int32_t> jwarm((size_t)4 * Lslot);
+    const RandPoly xW = rand_poly_pow((uint64_t)W), x2W = rand_poly_pow(2ull * W);
+    for (int par = 0; par < 2; par++) {
+        const RandPoly a = rand_poly_pow((uint64_t)W * Lp[par]);
+        const RandPoly b = rand_poly_pow(2ull * W * Lp[par]);
+        std::memcpy(&lskip[par * 31], a.c, sizeof(a.c));
+        std::memcpy(&cskip[par * 31], b.c, sizeof(b.c));
+        g.calls[par] = ntscsim_rng_calls_per_field(&c->prm, W, H, (unsigned)par);
+        for (int s = 0; s < 2; s++) {
+            const uint64_t off = s == 0 ? 0 : chroma_stream_offset(c->prm, W, Lp[par]);
+            const RandPoly so = rand_poly_pow(off);
+            std::memcpy(&sstart[(size_t)(s * 2 + par) * 31], so.c, sizeof(so.c));
+            const uint64_t warm_max = s == 0 ? (uint64_t)D.warm_luma : (uint64_t)D.warm_chroma;
+            const uint64_t per_row = s == 0 ? (uint64_t)W : 2ull * W;
+            const RandPoly &step = s == 0 ? xW : x2W;
+            RandPoly cur = so;
+            uint64_t cur_e = off;
+            for (int k = 0; k < Lslot; k++) {
+                const uint64_t start = per_row * (uint64_t)k;
+                const uint64_t warm = start < warm_max ? start : warm_max;
+                const uint64_t e = off + start - warm;
+                if (e != cur_e) {
+                    cur = (e - cur_e == per_row) ? rand_poly_mul(cur, step) : rand_poly_pow(e);
+                    cur_e = e;
+                }
+                const size_t idx = (size_t)(s * 2 + par) * Lslot + k;
+                std::memcpy(&jrow[idx * 31], cur.c, sizeof(cur.c));
+                jwarm[idx] = (int32_t)warm;
+            }
+        }
+    }
+    HIPCHK(c, g.lskip.ensure(lskip.size()));
+    HIPCHK(c, g.cskip.ensure(cskip.size()));
+    HIPCHK(c, g.sstart.ensure(sstart.size()));
+    HIPCHK(c, g.jrow.ensure(jrow.size()));
+    HIPCHK(c, g.jwarm.ensure(jwarm.size()));
+    HIPCHK(c, hipMemcpy(g.lskip.p, lskip.data(), lskip.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g.cskip.p, cskip.data(), cskip.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g.sstart.p, sstart.data(), sstart.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g.jrow.p, jrow.data(), jrow.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g.jwarm.p, jwarm.data(), jwarm.size() * 4, hipMemcpyHostToDevice));
+    g.W = W; g.H = H; g.valid = true;
+    return NTSCSIM_OK;
+}
+
+static int build_ptab(ntscsim_ctx *c)
+{
+    if (c->ptab_ready) return NTSCSIM_OK;
+    const int K = c->prm.video_chroma_phase_noise;
+    std::vector<double> t((size_t)(2 * K + 1) * 2);
+    for (int n = -K; n <= K; n++) {
+        const double pi = ((double)n * M_PI) / 100;        // ffmpeg_ntsc.cpp:1746
+        t[(size_t)(n + K) * 2] = std::cos(pi);              // host libm, as the reference
+        t[(size_t)(n + K) * 2 + 1] = std::sin(pi);
+    }
+    HIPCHK(c, c->ptab.ensure(t.size()));
+    HIPCHK(c, hipMemcpy(c->ptab.p, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->ptab_ready = true;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx **out)
+{
+    if (!p || !out) return NTSCSIM_E_ARG;
+    *out = nullptr;
+    int rc = ntscsim_params_validate(p);
+    if (rc != NTSCSIM_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NTSCSIM_E_NODEV;
+    if (device < 0 || device >= ndev) return NTSCSIM_E_NODEV;
+    ntscsim_ctx *c = new (std::nothrow) ntscsim_ctx();
+    if (!c) return NTSCSIM_E_NOMEM;
+    c->prm = *p;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return NTSCSIM_E_HIP;
+    }
+    for (int i = 0; i < 5; i++) (void)hipEventCreate(&c->ev[i]);
+    for (int i = 0; i < 2; i++) (void)hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
+    *out = c;
+    return NTSCSIM_OK;
+}
+
+extern "C" void ntscsim_destroy(ntscsim_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    c->geom.lskip.release(); c->geom.cskip.release(); c->geom.jrow.release();
+    c->geom.sstart.release(); c->geom.jwarm.release();
+    c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
+    c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
+    c->comp.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->fsrc.release(); c->fdst.release();
+    for (int i = 0; i < 2; i++) {
+        if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+        if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+    }
+    for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *ntscsim_last_error(const ntscsim_ctx *c) { return c ? c->err.c_str() : ""; }
+extern "C" uint64_t ntscsim_get_rng_pos(const ntscsim_ctx *c) { return c ? c->rng_pos : 0; }
+extern "C" void ntscsim_set_rng_pos(ntscsim_ctx *c, uint64_t pos) { if (c) c->rng_pos = pos; }
+extern "C" void ntscsim_set_profiling(ntscsim_ctx *c, int on) { if (c) c->profiling = on != 0; }
+
+extern "C" int ntscsim_sync(ntscsim_ctx *c)
+{
+    if (!c) return NTSCSIM_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4])
+{
+    if (!c || !out_ms) return NTSCSIM_E_ARG;
+    if (!c->ev_valid) return NTSCSIM_E_ARG;
+    HIPCHK(c, hipEventSynchronize(c->ev[4]));
+    HIPCHK(c, hipEventElapsedTime(&out_ms[0], c->ev[0], c->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&out_ms[1], c->ev[1], c->ev[2]));
+    HIPCHK(c, hipEventElapsedTime(&out_ms[2], c->ev[2], c->ev[3]));
+    HIPCHK(c, hipEventElapsedTime(&out_ms[3], c->ev[0], c->ev[4]));
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n,
+                                     int W, int H, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0) return NTSCSIM_E_ARG;
+    if (W < 16 || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+
+    DevParams D;
+    fill_dev_params(c->prm, D);
+    D.W = W; D.H = H;
+    D.Lslot = (H + 1) / 2;
+    D.nfields = n;
+    const long long R = (long long)n * D.Lslot;
+    if (R > (1ll << 30)) return NTSCSIM_E_SIZE;
+    D.R = (int)R;
+    D.Rpad = (int)(((R + 63) / 64) * 64 + 64);
+    if ((long long)D.Rpad * W > (1ll << 31) - 1) {
+        // comp is indexed with size_t, but keep the plane under 8 GiB per batch
+        if ((long long)D.Rpad * W > (1ll << 31)) return NTSCSIM_E_SIZE;
+    }
+
+    int rc = build_geometry(c, W, H, D);
+    if (rc != NTSCSIM_OK) return rc;
+    if (D.pnoise_k) { rc = build_ptab(c); if (rc != NTSCSIM_OK) return rc; }
+
+    // ---- descriptors -> device records (rand() state per field on the host: one 31x31
+    //      multiply-accumulate per consecutive field)
+    const int si = c->stage_idx;
+    c->stage_idx ^= 1;
+    if (c->stage_used[si]) HIPCHK(c, hipEventSynchronize(c->stage_ev[si]));
+    if (c->stage_cap[si] < (size_t)n) {
+        if (c->stage[si]) (void)hipHostFree(c->stage[si]);
+        c->stage[si] = nullptr; c->stage_cap[si] = 0;
+        const size_t want = (size_t)n + (size_t)n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->stage[si], want * sizeof(FieldDev), hipHostMallocDefault));
+        c->stage_cap[si] = want;
+    }
+    FieldDev *fh = c->stage[si];
+    bool al_src = true, al_dst = true, any_bob = false;
+    uint64_t pos = c->rng_pos;
+    for (int i = 0; i < n; i++) {
+        const ntscsim_field_desc &d = descs[i];
+        if (!d.src_dev || !d.dst_dev) return NTSCSIM_E_ARG;
+        if (d.src_linesize < 4 * W || d.dst_linesize < 4 * W) return NTSCSIM_E_SIZE;  // :1580-1581
+        if ((d.src_linesize & 3) || (d.dst_linesize & 3)) return NTSCSIM_E_SIZE;
+        if (((uintptr_t)d.src_dev & 3) || ((uintptr_t)d.dst_dev & 3)) return NTSCSIM_E_ARG;
+        if (d.field > 1) return NTSCSIM_E_ARG;
+        if (d.rng_pos != NTSCSIM_RNG_AUTO) pos = d.rng_pos;
+        FieldDev &o = fh[i];
+        o.src = (const uint8_t *)d.src_dev;
+        o.dst = (uint8_t *)d.dst_dev;
+        o.src_ls = d.src_linesize; o.dst_ls = d.dst_linesize;
+        o.field = d.field; o.flags = d.flags; o.fieldno = d.fieldno; o._pad = 0;
+        const RandState s = ctx_state_at(c, pos);
+        std::memcpy(o.rng, s.w, sizeof(o.rng));
+        pos += c->geom.calls[d.field & 1];
+        al_src = al_src && !(((uintptr_t)d.src_dev | (uintptr_t)d.src_linesize) & 15);
+        al_dst = al_dst && !(((uintptr_t)d.dst_dev | (uintptr_t)d.dst_linesize) & 15);
+        any_bob = any_bob || (d.flags & NTSCSIM_DESC_BOB);
+    }
+    c->rng_pos = pos;
+    D.src_al16 = al_src; D.dst_al16 = al_dst;
+
+    // ---- scratch
+    HIPCHK(c, c->fields.ensure((size_t)n));
+    HIPCHK(c, c->comp.ensure((size_t)D.Rpad * W));
+    if (D.hs) HIPCHK(c, c->hs_shift.ensure((size_t)D.R));
+    if (D.pnoise_k) HIPCHK(c, c->pn_noise.ensure((size_t)D.R));
+    if (D.loss) HIPCHK(c, c->dropout.ensure((size_t)D.R));
+    if (D.noise_k) { HIPCHK(c, c->rs_luma.ensure((size_t)31 * D.Rpad)); HIPCHK(c, c->n0_luma.ensure((size_t)D.Rpad)); }
+    if (D.cnoise_k) {
+        HIPCHK(c, c->rs_chroma.ensure((size_t)31 * D.Rpad));
+        HIPCHK(c, c->n0_u.ensure((size_t)D.Rpad));
+        HIPCHK(c, c->n0_v.ensure((size_t)D.Rpad));
+    }
+
+    GeomDev G;
+    G.lskip = c->geom.lskip.p; G.cskip = c->geom.cskip.p; G.jrow = c->geom.jrow.p;
+    G.jwarm = c->geom.jwarm.p; G.sstart = c->geom.sstart.p; G.ptab = c->ptab.p;
+
+    const bool prof = c->profiling;
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    HIPCHK(c, hipMemcpyAsync(c->fields.p, fh, (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
+    c->stage_used[si] = true;
+    if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
+
+    if (D.hs || D.pnoise_k || D.loss)
+        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, c->fields.p,
+                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
+    if (D.noise_k || D.cnoise_k)
+        hipLaunchKernelGGL(k_row_states, dim3((D.R + 127) / 128, 2), dim3(128), 0, st, D, G,
+                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
+                           c->n0_v.p);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    hipLaunchKernelGGL(k_encode, dim3((D.R + 63) / 64), dim3(64), 0, st, D, c->fields.p,
+                       c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    const dim3 dgrid((D.R + 62) / 63);
+    if (!D.vhs)
+        hipLaunchKernelGGL((k_decode<false, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
+                           c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p);
+    else if (D.svideo)
+        hipLaunchKernelGGL((k_decode<true, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
+                           c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p);
+    else
+        hipLaunchKernelGGL((k_decode<true, true>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
+                           c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p);
+    if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+    if (any_bob)
+        hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, c->fields.p);
+    if (prof) { HIPCHK(c, hipEventRecord(c->ev[4], st)); c->ev_valid = true; }
+    HIPCHK(c, hipGetLastError());
+
+    c->last_n = n; c->last_W = W; c->last_H = H; c->last_Rpad = D.Rpad; c->last_Lslot = D.Lslot;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int src_interlaced,
+                             int src_tff, uint8_t *dst, int dst_ls, int W, int H, unsigned field,
+                             uint64_t fieldno)
+{
+    if (!c || !src || !dst) return NTSCSIM_E_ARG;          // :1578-1579
+    if (src_ls < 4 * W || dst_ls < 4 * W) return NTSCSIM_E_SIZE;   // :1580-1581
+    if (field > 1) return NTSCSIM_E_ARG;
+    if (W < 16 || H < 2) return NTSCSIM_E_SIZE;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t pitch = (((size_t)W * 4 + 255) / 256) * 256;
+    HIPCHK(c, c->fsrc.ensure(pitch * H));
+    HIPCHK(c, c->fdst.ensure(pitch * H));
+    HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p, pitch, src, (size_t)src_ls, (size_t)W * 4, (size_t)H,
+                               hipMemcpyHostToDevice, c->stream));
+    ntscsim_field_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.src_dev = c->fsrc.p; d.dst_dev = c->fdst.p;
+    d.src_linesize = (int)pitch; d.dst_linesize = (int)pitch;
+    d.field = field;
+    d.flags = (src_interlaced ? NTSCSIM_DESC_INTERLACED : 0u) | (src_tff ? NTSCSIM_DESC_TFF : 0u);
+    d.fieldno = fieldno;
+    d.rng_pos = NTSCSIM_RNG_AUTO;
+    int rc = ntscsim_fields_device(c, &d, 1, W, H, c->stream);
+    if (rc != NTSCSIM_OK) return rc;
+    // only the rows of this field are written back (:1910-1916)
+    const int L = (H - (int)field + 1) / 2;
+    if (L > 0)
+        HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)dst_ls * field, (size_t)dst_ls * 2,
+                                   c->fdst.p + pitch * field, pitch * 2, (size_t)W * 4, (size_t)L,
+                                   hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_debug_read_composite(ntscsim_ctx *c, int32_t *out, size_t out_elems)
+{
+    if (!c || !out) return NTSCSIM_E_ARG;
+    if (c->last_n <= 0) return NTSCSIM_E_ARG;
+    const size_t W = (size_t)c->last_W, Rpad = (size_t)c->last_Rpad;
+    const size_t R = (size_t)c->last_n * c->last_Lslot;
+    if (out_elems < R * W) return NTSCSIM_E_SIZE;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    std::vector<int32_t> tmp(W * Rpad);
+    HIPCHK(c, hipMemcpy(tmp.data(), c->comp.p, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < R; r++)
+        for (size_t x = 0; x < W; x++) out[r * W + x] = tmp[x * Rpad + r];
+    return NTSCSIM_OK;
+}

@@ -1,0 +1,137 @@
+"""ntscsim -- host-side Python mirror of the reference's per-field interface
+(composite_layer(), ffmpeg_ntsc.cpp:1570, and the field loop around it, :2202-2282), calling the
+hand-written HIP kernels through the C-ABI of include/ntscsim.h.
+
+torch is used only for device memory, streams and torch.distributed plumbing.
+"""
+import ctypes as C
+
+from . import _capi
+from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, FieldDesc, NtscsimError,
+                    Params, lib, make_params)
+
+__all__ = ["FieldSimulator", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
+           "field_rows", "calls_per_field", "field_schedule"]
+
+
+def field_rows(height, field):
+    """Rows composite_layer touches: y = field, field+2, ... < height."""
+    return (height - field + 1) // 2 if height > field else 0
+
+
+def calls_per_field(params, width, height, field):
+    return int(lib().ntscsim_rng_calls_per_field(C.byref(params), width, height, field))
+
+
+def field_schedule(n_fields, first=0):
+    """The reference's field loop (ffmpeg_ntsc.cpp:2202-2229): output field `current` uses
+    field parity (current & 1) ^ 1 and fieldno = current."""
+    return [((cur & 1) ^ 1, cur) for cur in range(first, first + n_fields)]
+
+
+class FieldSimulator:
+    """One GPU context.  `flags` are the reference's CLI switches, e.g. ("-vhs",)."""
+
+    def __init__(self, flags=(), device=0, params=None):
+        self.params = params if params is not None else make_params(flags)
+        self._lib = lib()
+        h = C.c_void_p()
+        rc = self._lib.ntscsim_create(C.byref(self.params), int(device), C.byref(h))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_create(device=%d)" % device)
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ntscsim_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "%s: %s" % (what, self._lib.ntscsim_last_error(self._h).decode()))
+
+    # ---- rand() stream position -----------------------------------------------------------
+    @property
+    def rng_pos(self):
+        return int(self._lib.ntscsim_get_rng_pos(self._h))
+
+    @rng_pos.setter
+    def rng_pos(self, pos):
+        self._lib.ntscsim_set_rng_pos(self._h, int(pos))
+
+    # ---- drop-in for composite_layer(): host (numpy) frames ---------------------------------
+    def field_host(self, dst, src, field, fieldno, interlaced=0, tff=0):
+        """dst, src: numpy uint8 [H, W, 4] BGRA (C-contiguous).  Writes rows field, field+2, ..."""
+        h, w = src.shape[:2]
+        assert src.shape == dst.shape and src.shape[2] == 4
+        u8p = C.POINTER(C.c_uint8)
+        rc = self._lib.ntscsim_field(self._h, src.ctypes.data_as(u8p), src.strides[0],
+                                     int(interlaced), int(tff), dst.ctypes.data_as(u8p),
+                                     dst.strides[0], w, h, int(field), int(fieldno))
+        self._chk(rc, "ntscsim_field")
+
+    # ---- batched, device-resident -----------------------------------------------------------
+    def build_descs(self, src, dst, jobs, bob=False, interlaced=0, tff=0, rng_pos=None):
+        """src, dst: torch uint8 CUDA tensors [N, H, W, 4].  jobs: iterable of
+        (src_index, dst_index, field, fieldno).  rng_pos: None (sequential from the ctx
+        position) or a list of absolute rand() stream positions."""
+        assert src.is_cuda and dst.is_cuda and src.dim() == 4 and dst.dim() == 4
+        assert src.stride(2) == 4 and src.stride(3) == 1 and dst.stride(2) == 4 and dst.stride(3) == 1
+        jobs = list(jobs)
+        arr = (FieldDesc * len(jobs))()
+        sbase, dbase = src.data_ptr(), dst.data_ptr()
+        sfs, dfs = src.stride(0), dst.stride(0)
+        flags = (DESC_INTERLACED if interlaced else 0) | (DESC_TFF if tff else 0) | \
+                (DESC_BOB if bob else 0)
+        for i, (si, di, field, fieldno) in enumerate(jobs):
+            d = arr[i]
+            d.src_dev = sbase + si * sfs
+            d.dst_dev = dbase + di * dfs
+            d.src_linesize = src.stride(1)
+            d.dst_linesize = dst.stride(1)
+            d.field = field
+            d.flags = flags
+            d.fieldno = fieldno
+            d.rng_pos = RNG_AUTO if rng_pos is None else int(rng_pos[i])
+        return arr
+
+    def run_descs(self, descs, width, height, stream=None):
+        """Enqueue; does not synchronise."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.ntscsim_fields_device(self._h, descs, len(descs), int(width), int(height),
+                                             C.c_void_p(stream))
+        self._chk(rc, "ntscsim_fields_device")
+
+    def fields(self, src, dst, jobs, **kw):
+        descs = self.build_descs(src, dst, jobs, **kw)
+        self.run_descs(descs, src.shape[2], src.shape[1])
+        return descs
+
+    def sync(self):
+        self._chk(self._lib.ntscsim_sync(self._h), "ntscsim_sync")
+
+    def set_profiling(self, on=True):
+        self._lib.ntscsim_set_profiling(self._h, 1 if on else 0)
+
+    def timings_ms(self):
+        out = (C.c_float * 4)()
+        self._chk(self._lib.ntscsim_get_timings_ms(self._h, out), "ntscsim_get_timings_ms")
+        return {"setup": out[0], "encode": out[1], "decode": out[2], "total": out[3]}
+
+    def debug_composite(self, n_fields, width, height):
+        import numpy as np
+        lslot = (height + 1) // 2
+        a = np.zeros((n_fields, lslot, width), dtype=np.int32)
+        rc = self._lib.ntscsim_debug_read_composite(
+            self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size)
+        self._chk(rc, "ntscsim_debug_read_composite")
+        return a

@@ -1,0 +1,159 @@
+"""ctypes binding of include/ntscsim.h (the product C-ABI, libntscsim.so).
+
+The shared object loads without a GPU (so the CPU test-suite can check the exported symbols and
+use the host-side parse_argv mirror); ntscsim_create() then fails with NTSCSIM_E_NODEV.  There is
+no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRODUCT_SO = os.path.join(PKG_DIR, "libntscsim.so")
+
+OK, E_ARG, E_SIZE, E_NODEV, E_HIP, E_NOMEM, E_PARAM, E_FLAG, E_HELP, E_INTERNAL = \
+    0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+RNG_AUTO = 0xFFFFFFFFFFFFFFFF
+DESC_INTERLACED, DESC_TFF, DESC_BOB = 1, 2, 0x100
+
+# every symbol include/ntscsim.h declares
+EXPORTS = (
+    "ntscsim_params_init", "ntscsim_cli_init", "ntscsim_params_parse_argv",
+    "ntscsim_params_validate", "ntscsim_rng_calls_per_field", "ntscsim_rng_draw",
+    "ntscsim_create", "ntscsim_destroy", "ntscsim_strerror", "ntscsim_last_error",
+    "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_fields_device",
+    "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
+    "ntscsim_debug_read_composite",
+)
+
+
+class Params(C.Structure):
+    """struct ntscsim_params -- keep in lock-step with include/ntscsim.h."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("tv_standard", C.c_int32),
+        ("output_width", C.c_int32),
+        ("output_height", C.c_int32),
+        ("video_scanline_phase_shift", C.c_int32),
+        ("video_scanline_phase_shift_offset", C.c_int32),
+        ("composite_preemphasis", C.c_double),
+        ("composite_preemphasis_cut", C.c_double),
+        ("vhs_out_sharpen", C.c_double),
+        ("vhs_head_switching", C.c_int32),
+        ("_pad0", C.c_int32),
+        ("vhs_head_switching_point", C.c_double),
+        ("vhs_head_switching_phase", C.c_double),
+        ("vhs_head_switching_phase_noise", C.c_double),
+        ("composite_in_chroma_lowpass", C.c_int32),
+        ("composite_out_chroma_lowpass", C.c_int32),
+        ("composite_out_chroma_lowpass_lite", C.c_int32),
+        ("video_yc_recombine", C.c_int32),
+        ("video_chroma_noise", C.c_int32),
+        ("video_chroma_phase_noise", C.c_int32),
+        ("video_chroma_loss", C.c_int32),
+        ("video_noise", C.c_int32),
+        ("subcarrier_amplitude", C.c_int32),
+        ("subcarrier_amplitude_back", C.c_int32),
+        ("emulating_vhs", C.c_int32),
+        ("nocolor_subcarrier", C.c_int32),
+        ("nocolor_subcarrier_after_yc_sep", C.c_int32),
+        ("vhs_chroma_vert_blend", C.c_int32),
+        ("vhs_svideo_out", C.c_int32),
+        ("enable_composite_emulation", C.c_int32),
+        ("output_vhs_tape_speed", C.c_int32),
+        ("_pad1", C.c_int32),
+    ]
+
+
+class FieldDesc(C.Structure):
+    """struct ntscsim_field_desc"""
+    _fields_ = [
+        ("src_dev", C.c_void_p),
+        ("dst_dev", C.c_void_p),
+        ("src_linesize", C.c_int32),
+        ("dst_linesize", C.c_int32),
+        ("field", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("fieldno", C.c_uint64),
+        ("rng_pos", C.c_uint64),
+    ]
+
+
+_u8p = C.POINTER(C.c_uint8)
+_lib = None
+
+
+def lib():
+    """Load libntscsim.so; fail loudly if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(PRODUCT_SO):
+        raise RuntimeError(
+            "%s is missing -- build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+            "(or `make -C composite-video-simulator_amd/csrc`)" % PRODUCT_SO)
+    L = C.CDLL(PRODUCT_SO)
+    L.ntscsim_params_init.argtypes = [C.POINTER(Params)]
+    L.ntscsim_params_init.restype = None
+    L.ntscsim_cli_init.argtypes = [C.c_void_p]
+    L.ntscsim_cli_init.restype = None
+    L.ntscsim_params_parse_argv.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int,
+                                            C.POINTER(C.c_char_p), C.c_int]
+    L.ntscsim_params_parse_argv.restype = C.c_int
+    L.ntscsim_params_validate.argtypes = [C.POINTER(Params)]
+    L.ntscsim_params_validate.restype = C.c_int
+    L.ntscsim_rng_calls_per_field.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_uint]
+    L.ntscsim_rng_calls_per_field.restype = C.c_uint64
+    L.ntscsim_rng_draw.argtypes = [C.c_uint64, C.c_size_t, C.POINTER(C.c_uint32)]
+    L.ntscsim_rng_draw.restype = None
+    L.ntscsim_create.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+    L.ntscsim_create.restype = C.c_int
+    L.ntscsim_destroy.argtypes = [C.c_void_p]
+    L.ntscsim_destroy.restype = None
+    L.ntscsim_strerror.argtypes = [C.c_int]
+    L.ntscsim_strerror.restype = C.c_char_p
+    L.ntscsim_last_error.argtypes = [C.c_void_p]
+    L.ntscsim_last_error.restype = C.c_char_p
+    L.ntscsim_get_rng_pos.argtypes = [C.c_void_p]
+    L.ntscsim_get_rng_pos.restype = C.c_uint64
+    L.ntscsim_set_rng_pos.argtypes = [C.c_void_p, C.c_uint64]
+    L.ntscsim_set_rng_pos.restype = None
+    L.ntscsim_field.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int,
+                                C.c_int, C.c_int, C.c_uint, C.c_uint64]
+    L.ntscsim_field.restype = C.c_int
+    L.ntscsim_fields_device.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p]
+    L.ntscsim_fields_device.restype = C.c_int
+    L.ntscsim_sync.argtypes = [C.c_void_p]
+    L.ntscsim_sync.restype = C.c_int
+    L.ntscsim_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_set_profiling.restype = None
+    L.ntscsim_get_timings_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.ntscsim_get_timings_ms.restype = C.c_int
+    L.ntscsim_debug_read_composite.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t]
+    L.ntscsim_debug_read_composite.restype = C.c_int
+    _lib = L
+    return L
+
+
+class NtscsimError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = lib().ntscsim_strerror(code).decode()
+        super().__init__("ntscsim error %d: %s%s" % (code, msg, (" -- " + detail) if detail else ""))
+
+
+def make_params(flags=(), **overrides):
+    """ntscsim_params from the reference's CLI switches (ffmpeg_ntsc.cpp parse_argv :972)."""
+    L = lib()
+    p = Params()
+    L.ntscsim_params_init(C.byref(p))
+    argv = [b"ffmpeg_ntsc"] + [str(f).encode() for f in flags]
+    arr = (C.c_char_p * len(argv))(*argv)
+    rc = L.ntscsim_params_parse_argv(C.byref(p), None, len(argv), arr, 0)
+    if rc != OK:
+        raise NtscsimError(rc, "parse_argv(%r)" % (list(flags),))
+    for k, v in overrides.items():
+        if k not in dict(Params._fields_):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p

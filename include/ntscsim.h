@@ -1,0 +1,219 @@
+/*
+ * ntscsim.h -- C ABI of the MI355X-native NTSC composite / VHS field simulator.
+ *
+ * This is the drop-in boundary for ONE hot path of joncampbell123/composite-video-simulator:
+ * the per-field function
+ *
+ *     void composite_layer(AVFrame *dst, AVFrame *src, InputFile&, unsigned field,
+ *                          unsigned long long fieldno)          ffmpeg_ntsc.cpp:1570-1921
+ *
+ * called once per output field from the field loop at ffmpeg_ntsc.cpp:2229, together with the
+ * ~35 process-wide globals it reads (ffmpeg_ntsc.cpp:205-214, :756-809) and the libc rand()
+ * stream it consumes.  Everything here is plain C: pointers, sizes, PODs.  No torch / HIP types
+ * appear in any signature; a HIP stream is passed as an opaque void*.
+ *
+ * The reference has no plugin API -- the "interface" is the function signature above plus the
+ * globals -- so the mapping is:
+ *
+ *   reference                                   | this header
+ *   --------------------------------------------+------------------------------------------
+ *   globals set by parse_argv() :972-1282       | struct ntscsim_params + ntscsim_params_parse_argv()
+ *   preset_NTSC()/preset_PAL() :815-831         | ntscsim_params_init() / "-tvstd" flag
+ *   composite_layer(dst,src,_,field,fieldno)    | ntscsim_field()            (host AVFrame planes)
+ *   N calls of composite_layer in the loop :2202 | ntscsim_fields_device()   (batched, HBM resident)
+ *   process-wide rand() state (never seeded)    | explicit 64-bit stream position per field
+ *   bob line doubling :2233-2257                | ntscsim_bob_device() / NTSCSIM_FIELD_BOB
+ *   silent `return` on bad frames :1578-1583    | negative error codes
+ */
+#ifndef NTSCSIM_H
+#define NTSCSIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTSCSIM_ABI_VERSION 1
+
+/* ---- error codes (the reference returns silently, ffmpeg_ntsc.cpp:1578-1583) ---- */
+enum {
+    NTSCSIM_OK          = 0,
+    NTSCSIM_E_ARG       = -1,  /* NULL pointer / bad argument                              */
+    NTSCSIM_E_SIZE      = -2,  /* linesize < 4*width, size mismatch, width/height too small */
+    NTSCSIM_E_NODEV     = -3,  /* no HIP device / HIP runtime unavailable                   */
+    NTSCSIM_E_HIP       = -4,  /* a HIP call failed (see ntscsim_last_error)                */
+    NTSCSIM_E_NOMEM     = -5,
+    NTSCSIM_E_PARAM     = -6,  /* params outside the supported domain                       */
+    NTSCSIM_E_FLAG      = -7,  /* unknown switch / bad value (reference: "return 1")        */
+    NTSCSIM_E_HELP      = -8,  /* -h / -help was given                                      */
+    NTSCSIM_E_INTERNAL  = -9
+};
+
+enum { NTSCSIM_TV_NTSC = 0, NTSCSIM_TV_PAL = 1 };
+enum { NTSCSIM_VHS_SP = 0, NTSCSIM_VHS_LP = 1, NTSCSIM_VHS_EP = 2 }; /* ffmpeg_ntsc.cpp:801-805 */
+
+/*
+ * Immutable snapshot of the globals composite_layer() reads.  Field names follow the
+ * reference's global names; the comment gives file:line of the global and its default.
+ */
+typedef struct ntscsim_params {
+    uint32_t struct_size;                 /* = sizeof(ntscsim_params); versions the struct      */
+    int32_t  tv_standard;                 /* output_ntsc/output_pal :209-210; NTSCSIM_TV_NTSC    */
+    int32_t  output_width;                /* :207  720                                          */
+    int32_t  output_height;               /* :208  480 (576 PAL)                                */
+    int32_t  video_scanline_phase_shift;        /* :213  180 (0|90|180|270)                     */
+    int32_t  video_scanline_phase_shift_offset; /* :214  0                                      */
+    double   composite_preemphasis;       /* :756  0                                            */
+    double   composite_preemphasis_cut;   /* :757  1000000                                      */
+    double   vhs_out_sharpen;             /* :759  1.5                                          */
+    int32_t  vhs_head_switching;          /* :761  false (true with -vhs)                       */
+    int32_t  _pad0;
+    double   vhs_head_switching_point;    /* :762  1 - 4.51/262.5                               */
+    double   vhs_head_switching_phase;    /* :763  0.99/262.5                                   */
+    double   vhs_head_switching_phase_noise; /* :764 (1/500)/262.5                              */
+    int32_t  composite_in_chroma_lowpass;       /* :766  true                                   */
+    int32_t  composite_out_chroma_lowpass;      /* :767  true                                   */
+    int32_t  composite_out_chroma_lowpass_lite; /* :768  true                                   */
+    int32_t  video_yc_recombine;          /* :770  0  (parsed, unused by ffmpeg_ntsc L1)        */
+    int32_t  video_chroma_noise;          /* :772  0                                            */
+    int32_t  video_chroma_phase_noise;    /* :773  0                                            */
+    int32_t  video_chroma_loss;           /* :774  0                                            */
+    int32_t  video_noise;                 /* :775  2                                            */
+    int32_t  subcarrier_amplitude;        /* :776  50                                           */
+    int32_t  subcarrier_amplitude_back;   /* :777  50                                           */
+    int32_t  emulating_vhs;               /* :791  false                                        */
+    int32_t  nocolor_subcarrier;          /* :794  false                                        */
+    int32_t  nocolor_subcarrier_after_yc_sep; /* :795 false (parsed, unused by ffmpeg_ntsc L1)  */
+    int32_t  vhs_chroma_vert_blend;       /* :796  true                                         */
+    int32_t  vhs_svideo_out;              /* :797  false                                        */
+    int32_t  enable_composite_emulation;  /* :798  true (-nocomp clears it; L1 never tests it)  */
+    int32_t  output_vhs_tape_speed;       /* :809  NTSCSIM_VHS_SP                               */
+    int32_t  _pad1;
+} ntscsim_params;
+
+/* Host-side (L4/L2) settings parse_argv() also fills; not read by the field DSP. */
+#define NTSCSIM_MAX_INPUTS 16
+typedef struct ntscsim_cli {
+    const char *input_paths[NTSCSIM_MAX_INPUTS]; /* -i (repeatable) :1012                       */
+    int32_t     n_inputs;
+    int32_t     frame_delay;                     /* -d :1003, 1..256, default 1                 */
+    const char *output_path;                     /* -o :1017                                    */
+    int32_t     use_422_colorspace;              /* -422 / -420 :1022-1027                      */
+    /* audio-only flags are accepted for CLI compatibility and recorded, never used here */
+    int32_t     emulating_preemphasis, emulating_deemphasis, output_vhs_hifi;
+    double      output_audio_hiss_db, output_audio_linear_buzz, vhs_linear_high_boost;
+} ntscsim_cli;
+
+/* preset_NTSC() + the global initialisers (ffmpeg_ntsc.cpp:205-214, :756-809, :824-831). */
+void ntscsim_params_init(ntscsim_params *p);
+void ntscsim_cli_init(ntscsim_cli *c);
+
+/*
+ * Mirror of parse_argv() (ffmpeg_ntsc.cpp:972-1282): same switch names (any number of leading
+ * '-'), same defaults, same preset side effects (-vhs :1141, -vhs-speed :1160, -comp-catv* :1077)
+ * and the same post-parse derivation of subcarrier_amplitude_back (:1264-1265).
+ * argv[0] is the program name, as in main().  `cli` may be NULL.  If `require_io` is non-zero the
+ * "No output file / No input files specified" checks (:1271-1278) apply.
+ * Returns NTSCSIM_OK, NTSCSIM_E_HELP (-h), or NTSCSIM_E_FLAG (reference: return 1).
+ */
+int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, int argc,
+                              const char *const *argv, int require_io);
+
+/* Rejects parameter values for which the reference's own behaviour is undefined
+ * (negative noise levels, subcarrier amplitude 0 -> division by zero at :1545, ...). */
+int ntscsim_params_validate(const ntscsim_params *p);
+
+/*
+ * Number of libc rand() draws one composite_layer() call makes:
+ *   [W*L if video_noise] + [4 if head switching with phase noise] + [2*W*L if chroma noise]
+ *   + [L if chroma phase noise] + [L if chroma loss],   L = rows of this field.
+ */
+uint64_t ntscsim_rng_calls_per_field(const ntscsim_params *p, int width, int height,
+                                     unsigned field);
+
+/* glibc TYPE_3 rand() clone (stdlib/random_r.c, seed 1): draw `n` values starting at stream
+ * position `pos` (0 = first rand() of the process) using O(log pos) jump-ahead. */
+void ntscsim_rng_draw(uint64_t pos, size_t n, uint32_t *out);
+
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct ntscsim_ctx ntscsim_ctx;
+
+/* Bind to HIP device `device` (ordinal), snapshot `p`.  Fails with NTSCSIM_E_NODEV when no
+ * GPU is present: there is NO CPU fallback in this library. */
+int  ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx **out);
+void ntscsim_destroy(ntscsim_ctx *ctx);
+const char *ntscsim_strerror(int code);
+const char *ntscsim_last_error(const ntscsim_ctx *ctx); /* text of the last HIP failure */
+
+/* Stream position of the next field processed through ntscsim_field() (starts at 0, advances
+ * by ntscsim_rng_calls_per_field per call -- exactly the reference's process-wide rand()). */
+uint64_t ntscsim_get_rng_pos(const ntscsim_ctx *ctx);
+void     ntscsim_set_rng_pos(ntscsim_ctx *ctx, uint64_t pos);
+
+/*
+ * Drop-in for composite_layer() (ffmpeg_ntsc.cpp:1570).  HOST buffers, as an AVFrame holds them:
+ *   src_bgra/src_linesize/src_interlaced/src_tff = srcframe->data[0], ->linesize[0],
+ *                                                  ->interlaced_frame, ->top_field_first
+ *   dst_bgra/dst_linesize/width/height           = dstframe->data[0], ->linesize[0], ->width, ->height
+ * Only rows y = field, field+2, ... of dst are written (alpha byte 0, :1914); other rows are
+ * untouched.  Synchronous.  Uses and advances the ctx's rand() stream position.
+ */
+int ntscsim_field(ntscsim_ctx *ctx,
+                  const uint8_t *src_bgra, int src_linesize, int src_interlaced, int src_tff,
+                  uint8_t *dst_bgra, int dst_linesize,
+                  int width, int height, unsigned field, uint64_t fieldno);
+
+/* ---- batched, device-resident form (what the field loop :2202-2282 becomes) -------------- */
+
+#define NTSCSIM_RNG_AUTO  UINT64_MAX   /* rng_pos: continue after the previous descriptor      */
+#define NTSCSIM_FIELD_BOB 1u           /* flags: also line-double into the other field's rows
+                                          (ffmpeg_ntsc.cpp:2233-2257)                          */
+
+typedef struct ntscsim_field_desc {
+    const void *src_dev;      /* device pointer, BGRA frame, width x height                    */
+    void       *dst_dev;      /* device pointer, BGRA frame, width x height                    */
+    int32_t     src_linesize; /* bytes, >= 4*width, multiple of 4                              */
+    int32_t     dst_linesize;
+    uint32_t    field;        /* 0 | 1 : rows field, field+2, ...                              */
+    uint32_t    flags;        /* bit0 src_interlaced, bit1 src_top_field_first, bit8 bob       */
+    uint64_t    fieldno;      /* `current` in the reference's loop                             */
+    uint64_t    rng_pos;      /* rand() stream position at entry, or NTSCSIM_RNG_AUTO          */
+} ntscsim_field_desc;
+
+#define NTSCSIM_DESC_INTERLACED 1u
+#define NTSCSIM_DESC_TFF        2u
+#define NTSCSIM_DESC_BOB        0x100u
+
+/*
+ * Process `n` independent fields of one geometry.  All pointers in `descs` are DEVICE pointers
+ * on the ctx's device; the descriptor array itself is host memory.  Work is enqueued on
+ * `hip_stream` (a hipStream_t passed as void*, NULL = the ctx's own stream) and the call returns
+ * without synchronising; scratch owned by the ctx is reused by the next call on the same ctx,
+ * which is stream-ordered after this one.  descs[0].rng_pos == NTSCSIM_RNG_AUTO continues from
+ * the ctx position; on return the ctx position is the end of the last descriptor.
+ */
+int ntscsim_fields_device(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int n,
+                          int width, int height, void *hip_stream);
+
+/* Block until everything enqueued by this ctx has finished. */
+int ntscsim_sync(ntscsim_ctx *ctx);
+
+/* Kernel timing of the LAST ntscsim_fields_device() call, from hipEvents recorded on the
+ * launch stream (valid after ntscsim_sync).  Index: 0 setup kernels, 1 encode kernel,
+ * 2 decode kernel, 3 whole call.  Enable with ntscsim_set_profiling(ctx, 1). */
+void ntscsim_set_profiling(ntscsim_ctx *ctx, int on);
+int  ntscsim_get_timings_ms(ntscsim_ctx *ctx, float out_ms[4]);
+
+/* Debug tap used by the stage-level parity tests: copy the composite-signal plane (int32, one
+ * value per pixel, row-major [n][L][W]) that the last ntscsim_fields_device() call left in
+ * scratch -- the signal after chroma_into_luma + pre-emphasis + luma noise (ffmpeg_ntsc.cpp:1611-1644),
+ * before head switching -- into host memory. */
+int ntscsim_debug_read_composite(ntscsim_ctx *ctx, int32_t *out, size_t out_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTSCSIM_H */
