@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the per-field NTSC composite / VHS path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8(d) "Config 2"): a 720x486, 30 fps, 10-second
+synthetic colour-bars clip (300 frames -> 600 output fields; frame k = the 8-bar table rotated by
+k pixels), full `-vhs` preset (head switching, luma noise 4, chroma noise 16, chroma phase noise
+4, chroma dropout 4, SP tape speed).  One "step" = one pass of the hot path over one such clip
+per GPU, frames resident in HBM.  With N GPUs the clip is N x 300 frames, dealt frame-round-robin
+to the ranks (weak scaling; no data-path collective -- fields are independent once their rand()
+stream positions are fixed).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "composite-video-simulator_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 (FMA-counted); the exact path cannot use FMA
+
+
+def make_bars_clip(torch, n_frames, w, h, first_frame, stride, device):
+    """Frames first_frame, first_frame+stride, ...: BGRA 8-bar 75% bars rotated by the frame
+    index; alpha 0.  uint8 [n, h, w, 4] in HBM."""
+    table = torch.tensor([0xC0C0C0, 0xC0C000, 0x00C0C0, 0x00C000,
+                          0xC000C0, 0xC00000, 0x0000C0, 0x000000], dtype=torch.int64, device=device)
+    x = torch.arange(w, device=device, dtype=torch.int64)
+    rot = (first_frame + stride * torch.arange(n_frames, device=device, dtype=torch.int64))
+    sx = (x[None, :] + rot[:, None]) % w
+    px = table[(8 * sx) // w]                                   # [n, w] 0xRRGGBB
+    row = torch.stack([px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF, torch.zeros_like(px)],
+                      dim=-1).to(torch.uint8)                   # B, G, R, A
+    return row[:, None, :, :].expand(n_frames, h, w, 4).contiguous()
+
+
+def cpu_baseline(params, w, h, n_fields, check_against=None):
+    """Oracle (our CPU restatement of the reference, 1 thread like the reference) on the first
+    n_fields of the same clip.  Returns (fields_per_s, n_checked_ok)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import _libs as L
+    o = L.OracleStream(params)
+    dst = np.zeros((h, w, 4), np.uint8)
+    frames = {}
+    t = 0.0
+    ok = 0
+    for cur in range(n_fields):
+        fr = cur // 2
+        if fr not in frames:
+            frames = {fr: L.bars(w, h, fr)}
+        t0 = time.perf_counter()
+        o.field(dst, frames[fr], (cur & 1) ^ 1, cur)
+        t += time.perf_counter() - t0
+        if check_against is not None and cur in check_against:
+            field = (cur & 1) ^ 1
+            if np.array_equal(dst[field::2], check_against[cur]):
+                ok += 1
+            else:
+                raise AssertionError("bench: HIP output of field %d differs from the oracle" % cur)
+    return n_fields / t, ok
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=720)
+    ap.add_argument("--height", type=int, default=486)
+    ap.add_argument("--frames", type=int, default=300, help="frames per GPU per step")
+    ap.add_argument("--preset", default="-vhs", help="reference CLI switches, space separated")
+    ap.add_argument("--cpu-fields", type=int, default=600,
+                    help="fields of the clip timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import ntscsim
+    from ntscsim import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h = args.width, args.height
+    flags = args.preset.split()
+    params = ntscsim.make_params(flags)
+    n_frames_local = args.frames
+    n_fields_global = 2 * n_frames_local * world
+    jobs = shard.jobs_for_rank(params, w, h, n_fields_global, rank, world)
+    assert len(jobs) == 2 * n_frames_local
+
+    # inputs resident in HBM: this rank's frames rank, rank+world, ...
+    src = make_bars_clip(torch, n_frames_local, w, h, rank, world, dev)
+    dst = torch.zeros((n_frames_local, h, w, 4), dtype=torch.uint8, device=dev)
+    sim = ntscsim.FieldSimulator(params=params, device=local_rank)
+    # job -> (local src frame, local dst frame, field, fieldno), explicit rand() positions
+    loc = [((cur // 2 - rank) // world, (cur // 2 - rank) // world, field, fieldno)
+           for (cur, field, fieldno, _) in jobs]
+    descs = sim.build_descs(src, dst, loc, rng_pos=[j[3] for j in jobs])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        sim.run_descs(descs, w, h, stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    sim.set_profiling(True)       # hipEvents on the launch stream around each kernel
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    tm = sim.timings_ms()
+    sim.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # gather a checksum per rank (the only exchange the path needs)
+        cs = torch.tensor([int(dst.to(torch.int64).sum().item())], dtype=torch.int64, device=dev)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+
+    fields_per_step_local = len(jobs)
+    total_fields = fields_per_step_local * world * args.steps
+    value = total_fields / elapsed
+    L_rows = (h + 1) // 2  # both parities have ceil/floor; 486 -> 243
+    alg_bytes_field = 8 * w * ((ntscsim.field_rows(h, 0) + ntscsim.field_rows(h, 1)) / 2.0)
+    alg_bytes_launch = alg_bytes_field * fields_per_step_local
+
+    out = None
+    if rank == 0:
+        calls = max(1, tm["calls"])
+        dec_ms = tm["decode"] / calls
+        enc_ms = tm["encode"] / calls
+        set_ms = tm["setup"] / calls
+        chain_ms = dec_ms + enc_ms + set_ms
+        achieved = alg_bytes_launch / (dec_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%dx%d %s" % (w, h, args.preset)
+                if key in tj:
+                    traffic = tj[key]["k_decode_hbm_bytes_per_launch"] * (
+                        fields_per_step_local / float(tj[key]["fields_per_launch"]))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "frames/sec (output frames = fields; 720x486 NTSC, full VHS preset)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d 30fps 10s colour-bars clip (%d frames -> %d fields per GPU per "
+                            "step), preset '%s', frame-round-robin over %d GPU(s)" % (
+                                w, h, n_frames_local, fields_per_step_local, args.preset, world),
+                "fields_per_step_per_gpu": fields_per_step_local,
+                "input_frames_per_sec": value / 2.0,
+                "mode": "exact (bit-identical to the reference: fp64, no FMA contraction)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_decode",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "kernel_ms": dec_ms,
+                "note": "exact mode is fp64-VALU/latency bound, not HBM bound (DESIGN.md); "
+                        "path_achieved uses encode+decode+setup time",
+                "path_achieved": alg_bytes_launch / (chain_ms * 1e-3) / 1e9,
+                "kernel_ms_all": {"setup": set_ms, "encode": enc_ms, "decode": dec_ms},
+            },
+        }
+        if world == 1 and args.cpu_fields > 0:
+            import numpy as np
+            ncpu = min(args.cpu_fields, fields_per_step_local)
+            # parity spot check on the fields the oracle produces anyway
+            host = dst.cpu().numpy()
+            chk = {}
+            for cur in (0, 1, 2, 3, ncpu - 2, ncpu - 1):
+                if 0 <= cur < ncpu:
+                    field = (cur & 1) ^ 1
+                    chk[cur] = host[cur // 2][field::2].copy()
+            # note: field pairs share a dst frame, so each field's rows are intact
+            cpu_fps, ok = cpu_baseline(params, w, h, ncpu, chk)
+            out["cpu_baseline"] = {
+                "value": cpu_fps,
+                "unit": "frames/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "first %d fields of the same clip, oracle/ntsc_oracle.c (bit-exact "
+                          "restatement of the single-threaded reference), gcc -O2 "
+                          "-ffp-contract=off; %d fields compared byte-for-byte with the HIP "
+                          "output" % (ncpu, ok),
+                "host_cpus": os.cpu_count(),
+            }
+            out["speedup_vs_cpu_1core"] = value / cpu_fps
+        print(json.dumps(out), flush=True)
+    sim.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

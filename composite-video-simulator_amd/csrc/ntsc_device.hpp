@@ -42,15 +42,15 @@ struct FieldDev {
     int32_t src_ls, dst_ls;
     uint32_t field, flags;
     uint64_t fieldno;
-    uint32_t rng[31];   // rand() state at the field's first draw
+    uint32_t rng[61];   // rand() window at the field's first draw, extended by 30 words
     uint32_t _pad;
 };
-static_assert(sizeof(FieldDev) == 168, "FieldDev layout");
+static_assert(sizeof(FieldDev) == 288, "FieldDev layout");
 
 // per-geometry jump tables (device memory), see ntscsim_hip.hip: Geometry
 struct GeomDev {
-    const uint32_t *lskip;    // [2][31]        x^(W*L_par)           (luma stage skip)
-    const uint32_t *cskip;    // [2][31]        x^(2*W*L_par)         (chroma stage skip)
+    const uint32_t *lskip;    // [2 par][31]  x^(draws before the head-switch draws)
+    const uint32_t *pskip;    // [2 par][31]  x^(draws before the phase-noise / dropout draws)
     const uint32_t *jrow;     // [2 stream][2 par][Lslot][31]  x^(row start - warm-up)
     const int32_t  *jwarm;    // [2 stream][2 par][Lslot]      warm-up draws (== start -> exact)
     const uint32_t *sstart;   // [2 stream][2 par][31]         x^(stream start within the field)

@@ -100,32 +100,44 @@ struct LaneRand {
     }
 };
 
-// generator over a private array (setup kernels only; tiny amount of work)
-struct LocalRand {
-    uint32_t r[31];
-    int i;
-    DEV void load(const uint32_t *s) { for (int j = 0; j < 31; j++) r[j] = s[j]; i = 0; }
-    DEV uint32_t next()
-    {
-        int j = i + 28; if (j >= 31) j -= 31;
-        const uint32_t v = r[i] + r[j];
-        r[i] = v;
-        i = (i == 30) ? 0 : i + 1;
-        return v >> 1;
+// Jump-ahead: state advanced by the polynomial c (x^n mod x^31 - x^28 - 1) given the 61-word
+// extension w of the starting window:  out[j] = sum_k c[k] * w[j+k].  Fully unrolled so that
+// everything stays in registers (private arrays with dynamic indices would live in scratch).
+DEV void jump61(const uint32_t *__restrict__ c, const uint32_t *__restrict__ w, uint32_t (&o)[31])
+{
+    uint32_t cc[31], ww[61];
+#pragma unroll
+    for (int k = 0; k < 31; k++) cc[k] = c[k];
+#pragma unroll
+    for (int i = 0; i < 61; i++) ww[i] = w[i];
+#pragma unroll
+    for (int j = 0; j < 31; j++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 31; k++) acc += cc[k] * ww[j + k];
+        o[j] = acc;
     }
-    // advance by the jump polynomial c (x^n mod x^31 - x^28 - 1): new w[j] = sum_k c[k] w[j+k]
-    DEV void jump(const uint32_t *c)
+}
+
+// Per-lane generator for the setup kernels: same LDS ring as LaneRand but the slot is a per-lane
+// value (lanes run different numbers of draws).
+struct SetupRand {
+    uint32_t p3, p2, p1;
+    int slot;
+    DEV void init(uint32_t *ring, const uint32_t (&st)[31], int lane)
     {
-        uint32_t w[61], o[31];
-        for (int j = 0; j < 31; j++) { int q = i + j; if (q >= 31) q -= 31; w[j] = r[q]; }
-        for (int j = 31; j < 61; j++) w[j] = w[j - 31] + w[j - 3];
-        for (int j = 0; j < 31; j++) {
-            uint32_t acc = 0;
-            for (int k = 0; k < 31; k++) acc += c[k] * w[j + k];
-            o[j] = acc;
-        }
-        for (int j = 0; j < 31; j++) r[j] = o[j];
-        i = 0;
+#pragma unroll
+        for (int j = 0; j < 31; j++) ring[j * 64 + lane] = st[j];
+        p3 = st[28]; p2 = st[29]; p1 = st[30];
+        slot = 0;
+    }
+    DEV uint32_t next(uint32_t *ring, int lane)
+    {
+        const uint32_t v = ring[slot * 64 + lane] + p3;
+        ring[slot * 64 + lane] = v;
+        p3 = p2; p2 = p1; p1 = v;
+        slot = (slot == 30) ? 0 : slot + 1;
+        return v >> 1;
     }
 };
 
@@ -134,28 +146,32 @@ DEV int field_rows(const DevParams &P, unsigned field) { return (P.H - (int)fiel
 // =============================================================================== k_field_setup
 // Per field: the draws that are not per-pixel.  Order of draws inside one composite_layer call
 // (SURVEY A.10): [W*L luma] [4 head switch] [2*W*L chroma] [L phase noise] [L dropout].
-__global__ void k_field_setup(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
-                              int *__restrict__ hs_shift, int *__restrict__ pn_noise,
-                              int *__restrict__ dropout)
+__global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
+                                                    const FieldDev *__restrict__ fields,
+                                                    int *__restrict__ hs_shift,
+                                                    int *__restrict__ pn_noise,
+                                                    int *__restrict__ dropout)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int f = blockIdx.x * 64 + lane;
     if (f >= P.nfields) return;
     const FieldDev &fd = fields[f];
     const unsigned field = fd.field & 1u;
     const int L = field_rows(P, field);
     int *hs_row = hs_shift + (size_t)f * P.Lslot;
-
-    LocalRand g;
-    g.load(fd.rng);
-    if (P.noise_k) g.jump(G.lskip + field * 31);
+    uint32_t st[31];
+    SetupRand g;
 
     // VHS head switching geometry, ffmpeg_ntsc.cpp:1647-1713
     if (P.hs) {
         const unsigned twidth = (unsigned)P.W + ((unsigned)P.W / 10u);
         double noise = 0;
         if (P.hs_noise_on) {
-            unsigned u = g.next();
-            u *= g.next(); u *= g.next(); u *= g.next();
+            jump61(G.lskip + field * 31, fd.rng, st);      // skip the luma-noise draws
+            g.init(ring, st, lane);
+            unsigned u = g.next(ring, lane);
+            u *= g.next(ring, lane); u *= g.next(ring, lane); u *= g.next(ring, lane);
             u %= 2000000000U;
             noise = ((double)u / 1000000000U) - 1.0;
             noise *= P.hs_pn;
@@ -181,21 +197,23 @@ __global__ void k_field_setup(DevParams P, GeomDev G, const FieldDev *__restrict
         }
     }
 
-    if (P.cnoise_k) g.jump(G.cskip + field * 31);
-
-    // chroma phase noise accumulator, one draw per row, carried down the field (:1736-1746)
-    if (P.pnoise_k) {
-        int n = 0;
-        for (int k = 0; k < L; k++) {
-            n += (int)umod31(g.next(), P.m_pnoise) - P.pnoise_k;
-            n = sdiv2(n);
-            pn_noise[(size_t)f * P.Lslot + k] = n;
+    if (P.pnoise_k || P.loss) {
+        jump61(G.pskip + field * 31, fd.rng, st);          // skip luma + head switch + chroma
+        g.init(ring, st, lane);
+        // chroma phase noise accumulator, one draw per row, carried down the field (:1736-1746)
+        if (P.pnoise_k) {
+            int n = 0;
+            for (int k = 0; k < L; k++) {
+                n += (int)umod31(g.next(ring, lane), P.m_pnoise) - P.pnoise_k;
+                n = sdiv2(n);
+                pn_noise[(size_t)f * P.Lslot + k] = n;
+            }
         }
-    }
-    // chroma dropout, one draw per row (:1891-1901)
-    if (P.loss) {
-        for (int k = 0; k < L; k++)
-            dropout[(size_t)f * P.Lslot + k] = (g.next() % 100000U) < (unsigned)P.loss;
+        // chroma dropout, one draw per row (:1891-1901)
+        if (P.loss) {
+            for (int k = 0; k < L; k++)
+                dropout[(size_t)f * P.Lslot + k] = (g.next(ring, lane) % 100000U) < (unsigned)P.loss;
+        }
     }
 }
 
@@ -206,12 +224,16 @@ __global__ void k_field_setup(DevParams P, GeomDev G, const FieldDev *__restrict
 // both extremes (-k and +k) over a short warm-up pins the exact value as soon as the two
 // trajectories meet.  If they have not met after the warm-up (probability ~2^-warm) the lane
 // recomputes serially from the start of the field -- exact by construction either way.
-__global__ void k_row_states(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
-                             uint32_t *__restrict__ rs_luma, int *__restrict__ n0_luma,
-                             uint32_t *__restrict__ rs_chroma, int *__restrict__ n0_u,
-                             int *__restrict__ n0_v)
+__global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
+                                                   const FieldDev *__restrict__ fields,
+                                                   uint32_t *__restrict__ rs_luma,
+                                                   int *__restrict__ n0_luma,
+                                                   uint32_t *__restrict__ rs_chroma,
+                                                   int *__restrict__ n0_u, int *__restrict__ n0_v)
 {
-    const int rho = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int rho = blockIdx.x * 64 + lane;
     const int stream = blockIdx.y;                 // 0 luma, 1 chroma
     if (rho >= P.R) return;
     if (stream == 0 ? !P.noise_k : !P.cnoise_k) return;
@@ -227,45 +249,47 @@ __global__ void k_row_states(DevParams P, GeomDev G, const FieldDev *__restrict_
     const long long start = stream == 0 ? (long long)k * P.W : 2ll * k * P.W;  // draws before row
     const bool exact = (long long)warm == start;   // warm-up reaches the start of the stream
 
-    LocalRand g;
-    g.load(fd.rng);
-    g.jump(G.jrow + jidx * 31);
+    uint32_t st[31];
+    SetupRand g;
+    jump61(G.jrow + jidx * 31, fd.rng, st);
+    g.init(ring, st, lane);
 
     int lo0 = exact ? 0 : -K, hi0 = exact ? 0 : K;   // luma / U
     int lo1 = lo0, hi1 = hi0;                         // V
     if (stream == 0) {
         for (int i = 0; i < warm; i++) {
-            const int d = (int)umod31(g.next(), M) - K;
+            const int d = (int)umod31(g.next(ring, lane), M) - K;
             lo0 = sdiv2(lo0 + d); hi0 = sdiv2(hi0 + d);
         }
     } else {
         for (int i = 0; i < warm; i += 2) {
-            int d = (int)umod31(g.next(), M) - K;
+            int d = (int)umod31(g.next(ring, lane), M) - K;
             lo0 = sdiv2(lo0 + d); hi0 = sdiv2(hi0 + d);
-            d = (int)umod31(g.next(), M) - K;
+            d = (int)umod31(g.next(ring, lane), M) - K;
             lo1 = sdiv2(lo1 + d); hi1 = sdiv2(hi1 + d);
         }
     }
     if (lo0 != hi0 || lo1 != hi1) {
         // not pinned: serial replay from the first draw of this stream in this field
-        g.load(fd.rng);
-        g.jump(G.sstart + (size_t)(stream * 2 + par) * 31);
+        jump61(G.sstart + (size_t)(stream * 2 + par) * 31, fd.rng, st);
+        g.init(ring, st, lane);
         lo0 = lo1 = 0;
         if (stream == 0) {
             for (long long i = 0; i < start; i++)
-                lo0 = sdiv2(lo0 + (int)umod31(g.next(), M) - K);
+                lo0 = sdiv2(lo0 + (int)umod31(g.next(ring, lane), M) - K);
         } else {
             for (long long i = 0; i < start; i += 2) {
-                lo0 = sdiv2(lo0 + (int)umod31(g.next(), M) - K);
-                lo1 = sdiv2(lo1 + (int)umod31(g.next(), M) - K);
+                lo0 = sdiv2(lo0 + (int)umod31(g.next(ring, lane), M) - K);
+                lo1 = sdiv2(lo1 + (int)umod31(g.next(ring, lane), M) - K);
             }
         }
     }
 
     uint32_t *rs = stream == 0 ? rs_luma : rs_chroma;
+    int q = g.slot;
     for (int j = 0; j < 31; j++) {
-        int q = g.i + j; if (q >= 31) q -= 31;
-        rs[(size_t)j * P.Rpad + rho] = g.r[q];
+        rs[(size_t)j * P.Rpad + rho] = ring[q * 64 + lane];
+        q = (q == 30) ? 0 : q + 1;
     }
     if (stream == 0) n0_luma[rho] = lo0;
     else { n0_u[rho] = lo0; n0_v[rho] = lo1; }
@@ -623,12 +647,17 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
             Uf[0] = Uf[1]; Uf[1] = Uf[2]; Uf[2] = fU;
             const int xo = x3 - SKO;
             if (xo < 0) continue;
-            int Yo = Yd[4 - SKO], Uo, Vo;
+            // (static selects instead of Yd[4 - SKO]: dynamic register indexing would go to scratch)
+            const int Yo = SKO == 0 ? Yd[4] : (SKO == 1 ? Yd[3] : Yd[0]);
+            int Uo, Vo;
             if (P.out_lp == 0) { Uo = U; Vo = V; }
             else {
                 // U value for xo was produced dI steps after xo entered, V value dQ steps after
-                Uo = (xo < W - dI) ? Uf[2 - (dQ - dI)] : Ur[4 - SKO];
-                Vo = (xo < W - dQ) ? fV : Vr[4 - SKO];
+                const int Uraw = SKO == 1 ? Ur[3] : Ur[0];
+                const int Vraw = SKO == 1 ? Vr[3] : Vr[0];
+                const int Ufil = (dQ - dI) == 0 ? Uf[2] : Uf[0];
+                Uo = (xo < W - dI) ? Ufil : Uraw;
+                Vo = (xo < W - dQ) ? fV : Vraw;
             }
             // ================= YIQ -> RGB :1385-1396, pack :1914 (alpha = 0)
             int r = (int)(((1.000 * Yo) + (0.956 * Uo) + (0.621 * Vo)) / 256);

@@ -48,7 +48,7 @@ struct DevBuf {
 struct Geometry {
     int W = 0, H = 0;
     bool valid = false;
-    DevBuf<uint32_t> lskip, cskip, jrow, sstart;
+    DevBuf<uint32_t> lskip, pskip, jrow, sstart;
     DevBuf<int32_t> jwarm;
     uint64_t calls[2] = {0, 0};
 };
@@ -89,9 +89,12 @@ struct ntscsim_ctx {
     // host-frame path
     DevBuf<uint8_t> fsrc, fdst;
 
+    // profiling: five events per call (start | setup done | encode done | decode done | end),
+    // recorded on the launch stream; summed and recycled by ntscsim_get_timings_ms()
     bool profiling = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    struct EvSet { hipEvent_t e[5]; };
+    std::vector<EvSet> ev_live, ev_free;
+    int warm_override[2] = {0, 0};
 };
 
 #define HIPCHK(ctx, call)                                                              \
@@ -191,14 +194,18 @@ static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
     g.valid = false;
     const int Lslot = (H + 1) / 2;
     const int Lp[2] = {(H + 1) / 2, H / 2};
-    std::vector<uint32_t> lskip(2 * 31), cskip(2 * 31), sstart(4 * 31), jrow((size_t)4 * Lslot * 31);
+    std::vector<uint32_t> lskip(2 * 31), pskip(2 * 31), sstart(4 * 31), jrow((size_t)4 * Lslot * 31);
     std::vector<int32_t> jwarm((size_t)4 * Lslot);
     const RandPoly xW = rand_poly_pow((uint64_t)W), x2W = rand_poly_pow(2ull * W);
     for (int par = 0; par < 2; par++) {
-        const RandPoly a = rand_poly_pow((uint64_t)W * Lp[par]);
-        const RandPoly b = rand_poly_pow(2ull * W * Lp[par]);
+        // draws before the 4 head-switch draws, and before the per-row phase-noise draws
+        const uint64_t off_hs = c->prm.video_noise != 0 ? (uint64_t)W * Lp[par] : 0;
+        const uint64_t off_pn = chroma_stream_offset(c->prm, W, Lp[par]) +
+                                (c->prm.video_chroma_noise != 0 ? 2ull * W * Lp[par] : 0);
+        const RandPoly a = rand_poly_pow(off_hs);
+        const RandPoly b = rand_poly_pow(off_pn);
         std::memcpy(&lskip[par * 31], a.c, sizeof(a.c));
-        std::memcpy(&cskip[par * 31], b.c, sizeof(b.c));
+        std::memcpy(&pskip[par * 31], b.c, sizeof(b.c));
         g.calls[par] = ntscsim_rng_calls_per_field(&c->prm, W, H, (unsigned)par);
         for (int s = 0; s < 2; s++) {
             const uint64_t off = s == 0 ? 0 : chroma_stream_offset(c->prm, W, Lp[par]);
@@ -224,12 +231,12 @@ static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
         }
     }
     HIPCHK(c, g.lskip.ensure(lskip.size()));
-    HIPCHK(c, g.cskip.ensure(cskip.size()));
+    HIPCHK(c, g.pskip.ensure(pskip.size()));
     HIPCHK(c, g.sstart.ensure(sstart.size()));
     HIPCHK(c, g.jrow.ensure(jrow.size()));
     HIPCHK(c, g.jwarm.ensure(jwarm.size()));
     HIPCHK(c, hipMemcpy(g.lskip.p, lskip.data(), lskip.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g.cskip.p, cskip.data(), cskip.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(g.pskip.p, pskip.data(), pskip.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(g.sstart.p, sstart.data(), sstart.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(g.jrow.p, jrow.data(), jrow.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(g.jwarm.p, jwarm.data(), jwarm.size() * 4, hipMemcpyHostToDevice));
@@ -271,7 +278,6 @@ extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx *
         delete c;
         return NTSCSIM_E_HIP;
     }
-    for (int i = 0; i < 5; i++) (void)hipEventCreate(&c->ev[i]);
     for (int i = 0; i < 2; i++) (void)hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
     *out = c;
     return NTSCSIM_OK;
@@ -282,7 +288,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    c->geom.lskip.release(); c->geom.cskip.release(); c->geom.jrow.release();
+    c->geom.lskip.release(); c->geom.pskip.release(); c->geom.jrow.release();
     c->geom.sstart.release(); c->geom.jwarm.release();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
@@ -292,7 +298,8 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
     }
-    for (int i = 0; i < 5; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (auto &s : c->ev_live) for (int i = 0; i < 5; i++) (void)hipEventDestroy(s.e[i]);
+    for (auto &s : c->ev_free) for (int i = 0; i < 5; i++) (void)hipEventDestroy(s.e[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -310,16 +317,34 @@ extern "C" int ntscsim_sync(ntscsim_ctx *c)
     return NTSCSIM_OK;
 }
 
-extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4])
+extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4], int *n_calls)
 {
     if (!c || !out_ms) return NTSCSIM_E_ARG;
-    if (!c->ev_valid) return NTSCSIM_E_ARG;
-    HIPCHK(c, hipEventSynchronize(c->ev[4]));
-    HIPCHK(c, hipEventElapsedTime(&out_ms[0], c->ev[0], c->ev[1]));
-    HIPCHK(c, hipEventElapsedTime(&out_ms[1], c->ev[1], c->ev[2]));
-    HIPCHK(c, hipEventElapsedTime(&out_ms[2], c->ev[2], c->ev[3]));
-    HIPCHK(c, hipEventElapsedTime(&out_ms[3], c->ev[0], c->ev[4]));
+    HIPCHK(c, hipSetDevice(c->device));
+    out_ms[0] = out_ms[1] = out_ms[2] = out_ms[3] = 0.f;
+    int n = 0;
+    for (auto &s : c->ev_live) {
+        float t[4];
+        HIPCHK(c, hipEventSynchronize(s.e[4]));
+        HIPCHK(c, hipEventElapsedTime(&t[0], s.e[0], s.e[1]));
+        HIPCHK(c, hipEventElapsedTime(&t[1], s.e[1], s.e[2]));
+        HIPCHK(c, hipEventElapsedTime(&t[2], s.e[2], s.e[3]));
+        HIPCHK(c, hipEventElapsedTime(&t[3], s.e[0], s.e[4]));
+        for (int i = 0; i < 4; i++) out_ms[i] += t[i];
+        c->ev_free.push_back(s);
+        n++;
+    }
+    c->ev_live.clear();
+    if (n_calls) *n_calls = n;
     return NTSCSIM_OK;
+}
+
+extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chroma_draws)
+{
+    if (!c) return;
+    c->warm_override[0] = luma_draws;
+    c->warm_override[1] = chroma_draws & ~1;
+    c->geom.valid = false;
 }
 
 extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n,
@@ -334,6 +359,8 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
 
     DevParams D;
     fill_dev_params(c->prm, D);
+    if (c->warm_override[0] > 0) D.warm_luma = c->warm_override[0];
+    if (c->warm_override[1] > 0) D.warm_chroma = c->warm_override[1];
     D.W = W; D.H = H;
     D.Lslot = (H + 1) / 2;
     D.nfields = n;
@@ -379,7 +406,8 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         o.src_ls = d.src_linesize; o.dst_ls = d.dst_linesize;
         o.field = d.field; o.flags = d.flags; o.fieldno = d.fieldno; o._pad = 0;
         const RandState s = ctx_state_at(c, pos);
-        std::memcpy(o.rng, s.w, sizeof(o.rng));
+        std::memcpy(o.rng, s.w, sizeof(s.w));
+        for (int j = 31; j < 61; j++) o.rng[j] = o.rng[j - 31] + o.rng[j - 3];
         pos += c->geom.calls[d.field & 1];
         al_src = al_src && !(((uintptr_t)d.src_dev | (uintptr_t)d.src_linesize) & 15);
         al_dst = al_dst && !(((uintptr_t)d.dst_dev | (uintptr_t)d.dst_linesize) & 15);
@@ -402,11 +430,16 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     }
 
     GeomDev G;
-    G.lskip = c->geom.lskip.p; G.cskip = c->geom.cskip.p; G.jrow = c->geom.jrow.p;
+    G.lskip = c->geom.lskip.p; G.pskip = c->geom.pskip.p; G.jrow = c->geom.jrow.p;
     G.jwarm = c->geom.jwarm.p; G.sstart = c->geom.sstart.p; G.ptab = c->ptab.p;
 
     const bool prof = c->profiling;
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[0], st));
+    ntscsim_ctx::EvSet evs;
+    if (prof) {
+        if (!c->ev_free.empty()) { evs = c->ev_free.back(); c->ev_free.pop_back(); }
+        else for (int i = 0; i < 5; i++) HIPCHK(c, hipEventCreate(&evs.e[i]));
+        HIPCHK(c, hipEventRecord(evs.e[0], st));
+    }
     HIPCHK(c, hipMemcpyAsync(c->fields.p, fh, (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
     c->stage_used[si] = true;
@@ -416,13 +449,13 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, c->fields.p,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p);
     if (D.noise_k || D.cnoise_k)
-        hipLaunchKernelGGL(k_row_states, dim3((D.R + 127) / 128, 2), dim3(128), 0, st, D, G,
+        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
                            c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (prof) HIPCHK(c, hipEventRecord(evs.e[1], st));
     hipLaunchKernelGGL(k_encode, dim3((D.R + 63) / 64), dim3(64), 0, st, D, c->fields.p,
                        c->rs_luma.p, c->n0_luma.p, c->comp.p);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    if (prof) HIPCHK(c, hipEventRecord(evs.e[2], st));
     const dim3 dgrid((D.R + 62) / 63);
     if (!D.vhs)
         hipLaunchKernelGGL((k_decode<false, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
@@ -436,10 +469,10 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         hipLaunchKernelGGL((k_decode<true, true>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
                            c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                            c->pn_noise.p, c->dropout.p);
-    if (prof) HIPCHK(c, hipEventRecord(c->ev[3], st));
+    if (prof) HIPCHK(c, hipEventRecord(evs.e[3], st));
     if (any_bob)
         hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, c->fields.p);
-    if (prof) { HIPCHK(c, hipEventRecord(c->ev[4], st)); c->ev_valid = true; }
+    if (prof) { HIPCHK(c, hipEventRecord(evs.e[4], st)); c->ev_live.push_back(evs); }
     HIPCHK(c, hipGetLastError());
 
     c->last_n = n; c->last_W = W; c->last_H = H; c->last_Rpad = D.Rpad; c->last_Lslot = D.Lslot;

@@ -321,10 +321,10 @@ extern "C" int ntscsim_params_validate(const ntscsim_params *p)
     if (p->video_chroma_noise < 0 || p->video_chroma_noise > kmax) return NTSCSIM_E_PARAM;
     if (p->video_chroma_phase_noise < 0 || p->video_chroma_phase_noise > 4096) return NTSCSIM_E_PARAM;
     if (p->video_chroma_loss < 0) return NTSCSIM_E_PARAM;
-    // division by subcarrier_amplitude(_back) at :1545; 0 is a SIGFPE in the reference
-    if (p->subcarrier_amplitude_back == 0 || p->subcarrier_amplitude == 0) return NTSCSIM_E_PARAM;
-    if (p->subcarrier_amplitude < -100000 || p->subcarrier_amplitude > 100000) return NTSCSIM_E_PARAM;
-    if (p->subcarrier_amplitude_back < -100000 || p->subcarrier_amplitude_back > 100000)
+    // division by subcarrier_amplitude(_back) at :1545 (0 is a SIGFPE in the reference);
+    // I*amplitude at :1487 overflows int beyond a few thousand.  Documented range is 0..100.
+    if (p->subcarrier_amplitude < 1 || p->subcarrier_amplitude > 1000) return NTSCSIM_E_PARAM;
+    if (p->subcarrier_amplitude_back < 1 || p->subcarrier_amplitude_back > 1000)
         return NTSCSIM_E_PARAM;
     if (p->output_vhs_tape_speed < NTSCSIM_VHS_SP || p->output_vhs_tape_speed > NTSCSIM_VHS_EP)
         return NTSCSIM_E_PARAM;                                          // reference: abort() :1789

@@ -123,9 +123,16 @@ class FieldSimulator:
         self._lib.ntscsim_set_profiling(self._h, 1 if on else 0)
 
     def timings_ms(self):
+        """Summed hipEvent timings (ms) of the calls made since the last query."""
         out = (C.c_float * 4)()
-        self._chk(self._lib.ntscsim_get_timings_ms(self._h, out), "ntscsim_get_timings_ms")
-        return {"setup": out[0], "encode": out[1], "decode": out[2], "total": out[3]}
+        n = C.c_int(0)
+        self._chk(self._lib.ntscsim_get_timings_ms(self._h, out, C.byref(n)),
+                  "ntscsim_get_timings_ms")
+        return {"setup": out[0], "encode": out[1], "decode": out[2], "total": out[3],
+                "calls": n.value}
+
+    def debug_set_warmup(self, luma_draws, chroma_draws):
+        self._lib.ntscsim_debug_set_warmup(self._h, int(luma_draws), int(chroma_draws))
 
     def debug_composite(self, n_fields, width, height):
         import numpy as np

@@ -22,7 +22,7 @@ EXPORTS = (
     "ntscsim_create", "ntscsim_destroy", "ntscsim_strerror", "ntscsim_last_error",
     "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_fields_device",
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
-    "ntscsim_debug_read_composite",
+    "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
 )
 
 
@@ -127,10 +127,12 @@ def lib():
     L.ntscsim_sync.restype = C.c_int
     L.ntscsim_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.ntscsim_set_profiling.restype = None
-    L.ntscsim_get_timings_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.ntscsim_get_timings_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.ntscsim_get_timings_ms.restype = C.c_int
     L.ntscsim_debug_read_composite.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t]
     L.ntscsim_debug_read_composite.restype = C.c_int
+    L.ntscsim_debug_set_warmup.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ntscsim_debug_set_warmup.restype = None
     _lib = L
     return L
 

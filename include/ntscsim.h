@@ -22,7 +22,7 @@
  *   composite_layer(dst,src,_,field,fieldno)    | ntscsim_field()            (host AVFrame planes)
  *   N calls of composite_layer in the loop :2202 | ntscsim_fields_device()   (batched, HBM resident)
  *   process-wide rand() state (never seeded)    | explicit 64-bit stream position per field
- *   bob line doubling :2233-2257                | ntscsim_bob_device() / NTSCSIM_FIELD_BOB
+ *   bob line doubling :2233-2257                | NTSCSIM_DESC_BOB flag of ntscsim_field_desc
  *   silent `return` on bad frames :1578-1583    | negative error codes
  */
 #ifndef NTSCSIM_H
@@ -169,8 +169,6 @@ int ntscsim_field(ntscsim_ctx *ctx,
 /* ---- batched, device-resident form (what the field loop :2202-2282 becomes) -------------- */
 
 #define NTSCSIM_RNG_AUTO  UINT64_MAX   /* rng_pos: continue after the previous descriptor      */
-#define NTSCSIM_FIELD_BOB 1u           /* flags: also line-double into the other field's rows
-                                          (ffmpeg_ntsc.cpp:2233-2257)                          */
 
 typedef struct ntscsim_field_desc {
     const void *src_dev;      /* device pointer, BGRA frame, width x height                    */
@@ -178,7 +176,8 @@ typedef struct ntscsim_field_desc {
     int32_t     src_linesize; /* bytes, >= 4*width, multiple of 4                              */
     int32_t     dst_linesize;
     uint32_t    field;        /* 0 | 1 : rows field, field+2, ...                              */
-    uint32_t    flags;        /* bit0 src_interlaced, bit1 src_top_field_first, bit8 bob       */
+    uint32_t    flags;        /* NTSCSIM_DESC_* : bit0 src interlaced_frame, bit1 src
+                                 top_field_first, bit8 bob line doubling (:2233-2257)          */
     uint64_t    fieldno;      /* `current` in the reference's loop                             */
     uint64_t    rng_pos;      /* rand() stream position at entry, or NTSCSIM_RNG_AUTO          */
 } ntscsim_field_desc;
@@ -201,17 +200,22 @@ int ntscsim_fields_device(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int
 /* Block until everything enqueued by this ctx has finished. */
 int ntscsim_sync(ntscsim_ctx *ctx);
 
-/* Kernel timing of the LAST ntscsim_fields_device() call, from hipEvents recorded on the
- * launch stream (valid after ntscsim_sync).  Index: 0 setup kernels, 1 encode kernel,
- * 2 decode kernel, 3 whole call.  Enable with ntscsim_set_profiling(ctx, 1). */
+/* Kernel timing from hipEvents recorded on the launch stream around each stage of every
+ * ntscsim_fields_device() call made while profiling is on.  ntscsim_get_timings_ms() waits for
+ * those calls, returns the SUMS since the previous query (index 0 setup kernels, 1 encode
+ * kernel, 2 decode kernel, 3 whole call incl. descriptor upload and bob) and the number of calls. */
 void ntscsim_set_profiling(ntscsim_ctx *ctx, int on);
-int  ntscsim_get_timings_ms(ntscsim_ctx *ctx, float out_ms[4]);
+int  ntscsim_get_timings_ms(ntscsim_ctx *ctx, float out_ms[4], int *n_calls);
 
 /* Debug tap used by the stage-level parity tests: copy the composite-signal plane (int32, one
  * value per pixel, row-major [n][L][W]) that the last ntscsim_fields_device() call left in
  * scratch -- the signal after chroma_into_luma + pre-emphasis + luma noise (ffmpeg_ntsc.cpp:1611-1644),
  * before head switching -- into host memory. */
 int ntscsim_debug_read_composite(ntscsim_ctx *ctx, int32_t *out, size_t out_elems);
+
+/* Test hook: shorten the noise-accumulator warm-up of k_row_states (default 64 / 128 draws) so
+ * that the exact serial-replay fallback is exercised.  Results must not change. */
+void ntscsim_debug_set_warmup(ntscsim_ctx *ctx, int luma_draws, int chroma_draws);
 
 #ifdef __cplusplus
 }

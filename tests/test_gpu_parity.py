@@ -1,0 +1,296 @@
+"""GPU parity tests: the HIP path, called through the C-ABI (ctypes), against the CPU oracle and
+the committed golden vectors.  Bit-exact everywhere -- the whole path is integer pixels in/out
+with fp64 filters evaluated in the reference's operation order (tolerance: 0)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _libs as L
+import cases
+import ntscsim
+from ntscsim import _capi, shard
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "ntsc_golden.npz"))
+MANIFEST = json.load(open(os.path.join(HERE, "golden", "ntsc_golden.json")))["cases"]
+FULL = json.load(open(os.path.join(HERE, "golden", "ntsc_fullsize_hashes.json")))["cases"]
+
+
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def run_hip(p, srcs, jobs, h, w, il=0, tff=0, bob=False, dst_init=0, per_field_dst=False,
+            rng_pos=None, sim=None):
+    """jobs: (src index, field, fieldno).  Default: all fields land in ONE dst frame, like the
+    reference's 1-frame delay ring.  Returns the dst frames as numpy."""
+    torch = torch_mod()
+    own = sim is None
+    sim = sim or ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    nd = len(jobs) if per_field_dst else 1
+    dst = torch.full((nd, h, w, 4), dst_init, dtype=torch.uint8, device="cuda")
+    j4 = [(si, (k if per_field_dst else 0), field, fieldno) for k, (si, field, fieldno) in enumerate(jobs)]
+    if per_field_dst or len(jobs) == 1:
+        sim.fields(src, dst, j4, interlaced=il, tff=tff, bob=bob, rng_pos=rng_pos)
+    else:
+        # same dst frame: fields of opposite parity touch disjoint rows, same parity must be ordered
+        # -> one call per field pair keeps the reference's overwrite order
+        for i in range(0, len(j4), 2):
+            sim.fields(src, dst, j4[i:i + 2], interlaced=il, tff=tff, bob=bob,
+                       rng_pos=None if rng_pos is None else rng_pos[i:i + 2])
+    sim.sync()
+    out = dst.cpu().numpy()
+    if own:
+        sim.close()
+    return out
+
+
+@pytest.mark.parametrize("m", MANIFEST, ids=[m["name"] for m in MANIFEST])
+def test_golden_vectors(m):
+    name, w, h, n = m["name"], m["w"], m["h"], m["n"]
+    p = L.make_params(m["flags"])
+    srcs = [np.ascontiguousarray(a) for a in GOLD["%s__src" % name]]
+    jobs = cases.case_jobs(n)
+    per = run_hip(p, srcs, jobs, h, w, m["interlaced"], m["tff"], per_field_dst=True)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        assert np.array_equal(per[k][field::2], GOLD["%s__field%d" % (name, k)]), "field %d" % k
+        assert not per[k][1 - field::2].any(), "rows of the other field were written"
+    one = run_hip(p, srcs, jobs, h, w, m["interlaced"], m["tff"])
+    assert np.array_equal(one[0], GOLD["%s__final" % name])
+
+
+@pytest.mark.parametrize("c", cases.CASES, ids=[c[0] for c in cases.CASES])
+def test_case_matrix_vs_oracle_other_seeds(c):
+    name, flags, w, h, n, kind, il, tff = c
+    n += 3
+    p = L.make_params(flags)
+    srcs = [cases.make_source(kind, w, h, j + 11) for j in range((n + 1) // 2)]
+    jobs = cases.case_jobs(n)
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno, il, tff)
+    got = run_hip(p, srcs, jobs, h, w, il, tff, per_field_dst=True)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("flags", [[], ["-vhs"], ["-vhs", "-comp-catv2"]])
+def test_composite_signal_stage_tap(flags):
+    """Stage-level parity: the composite plane between encoder and decoder."""
+    torch = torch_mod()
+    w, h, n = 96, 34, 4
+    p = L.make_params(flags)
+    srcs = [L.noise_frame(w, h, 5 + j) for j in range(2)]
+    jobs = cases.case_jobs(n)
+    o = L.OracleStream(p)
+    taps = []
+    for (si, field, fieldno) in jobs:
+        taps.append(o.field(np.zeros((h, w, 4), np.uint8), srcs[si], field, fieldno,
+                            taps=["composite_y"])["composite_y"])
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, dst, [(si, k, f, fn) for k, (si, f, fn) in enumerate(jobs)])
+    comp = sim.debug_composite(n, w, h)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        assert np.array_equal(comp[k, :L.field_rows(h, field)], taps[k])
+    sim.close()
+
+
+@pytest.mark.parametrize("w,h,flags,nf", [(720, 480, [], 4), (720, 480, ["-vhs"], 6),
+                                          (720, 486, ["-vhs"], 6), (1920, 1080, ["-vhs"], 3)])
+def test_full_size_vs_oracle(w, h, flags, nf):
+    p = L.make_params(flags)
+    srcs = [L.bars(w, h, j) if j % 2 == 0 else L.noise_frame(w, h, 77 + j) for j in range((nf + 1) // 2)]
+    jobs = cases.case_jobs(nf)
+    o = L.OracleStream(p)
+    exp = np.zeros((nf, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    got = run_hip(p, srcs, jobs, h, w, per_field_dst=True)
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("c", FULL, ids=lambda c: "%dx%d%s" % (c["w"], c["h"], "".join(c["flags"])))
+def test_full_size_reference_hashes(c):
+    """Hashes recorded from the reference extract at the BASELINE sizes (incl. 3840x2160)."""
+    w, h, n = c["w"], c["h"], c["n"]
+    p = L.make_params(c["flags"])
+    srcs = [L.bars(w, h, j) for j in range((n + 1) // 2)]
+    torch = torch_mod()
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.zeros((1, h, w, 4), dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        sim.fields(src, dst, [(k // 2, 0, (k & 1) ^ 1, k)])
+        sim.sync()
+        assert "%016x" % L.fnv1a(dst[0].cpu().numpy()) == c["fnv1a_after_each_field"][k], "field %d" % k
+    sim.close()
+
+
+def test_host_frame_dropin_sequence():
+    """ntscsim_field(): the composite_layer() drop-in on host buffers with linesize padding,
+    rand() stream carried across calls like the reference's process-wide generator."""
+    w, h = 96, 32
+    p = L.make_params(["-vhs"])
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    pad = 24
+    src_p = np.zeros((h, w + pad, 4), np.uint8)
+    dst_p = np.full((h, w + pad, 4), 0x5A, np.uint8)
+    exp = np.full((h, w, 4), 0x5A, np.uint8)
+    for k in range(5):
+        s = L.noise_frame(w, h, 40 + k // 2)
+        src_p[:, :w] = s
+        field = (k & 1) ^ 1
+        sim.field_host(dst_p[:, :w], src_p[:, :w], field, k)
+        o.field(exp, s, field, k)
+        assert np.array_equal(dst_p[:, :w], exp), "call %d" % k
+        assert (dst_p[:, w:] == 0x5A).all(), "padding bytes were written"
+        assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+def test_batch_split_and_order_invariance():
+    """Size-independent property at the BASELINE size: a 64-field batch == 64 single-field
+    calls == two half batches issued in reverse order (explicit rand() positions)."""
+    torch = torch_mod()
+    w, h, nf = 720, 486, 64
+    p = L.make_params(["-vhs"])
+    src = torch.from_numpy(np.stack([L.bars(w, h, j) for j in range(nf // 2)])).cuda()
+    jobs = [(k // 2, k, (k & 1) ^ 1, k) for k in range(nf)]
+    pos = [shard.rng_pos_of_field(p, w, h, k) for k in range(nf)]
+    sim = ntscsim.FieldSimulator(params=p)
+    a = torch.zeros((nf, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, a, jobs, rng_pos=pos)
+    b = torch.zeros_like(a)
+    sim.fields(src, b, jobs[nf // 2:], rng_pos=pos[nf // 2:])
+    sim.fields(src, b, jobs[:nf // 2], rng_pos=pos[:nf // 2])
+    c = torch.zeros_like(a)
+    sim.rng_pos = 0
+    for j in jobs:
+        sim.fields(src, c, [j])            # RNG_AUTO continues from the ctx position
+    sim.sync()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # spot-check three fields of the batch against the oracle
+    o = L.OracleStream(p)
+    for k in (0, 1, 2):
+        e = np.zeros((h, w, 4), np.uint8)
+        o.field(e, src[k // 2].cpu().numpy(), (k & 1) ^ 1, k)
+        assert np.array_equal(a[k].cpu().numpy(), e)
+    sim.close()
+
+
+def test_bench_clip_checksum_of_checksums():
+    """The bench workload itself (600 fields, 720x486, -vhs): every 37th field vs the oracle at
+    its closed-form stream position, plus determinism of the whole batch."""
+    torch = torch_mod()
+    w, h, nf = 720, 486, 600
+    p = L.make_params(["-vhs"])
+    frames = np.stack([L.bars(w, h, j) for j in range(nf // 2)])
+    src = torch.from_numpy(frames).cuda()
+    jobs = [(k // 2, k // 2, (k & 1) ^ 1, k) for k in range(nf)]
+    pos = [shard.rng_pos_of_field(p, w, h, k) for k in range(nf)]
+    sim = ntscsim.FieldSimulator(params=p)
+    d1 = torch.zeros((nf // 2, h, w, 4), dtype=torch.uint8, device="cuda")
+    d2 = torch.zeros_like(d1)
+    sim.fields(src, d1, jobs, rng_pos=pos)
+    sim.fields(src, d2, jobs, rng_pos=pos)
+    sim.sync()
+    assert torch.equal(d1, d2)
+    got = d1.cpu().numpy()
+    for k in range(0, nf, 37):
+        o = L.OracleStream(p)
+        o.skip(pos[k])
+        e = np.zeros((h, w, 4), np.uint8)
+        field = (k & 1) ^ 1
+        o.field(e, frames[k // 2], field, k)
+        assert np.array_equal(got[k // 2][field::2], e[field::2]), "field %d" % k
+    sim.close()
+
+
+def test_warmup_fallback_path_is_exact():
+    """Force the noise-accumulator warm-up to be too short so lanes take the serial-replay
+    fallback; results must not change."""
+    w, h, n = 96, 32, 4
+    p = L.make_params(["-vhs", "-noise", "40", "-chroma-noise", "60"])
+    srcs = [L.noise_frame(w, h, 9 + j) for j in range(2)]
+    jobs = cases.case_jobs(n)
+    ref = run_hip(p, srcs, jobs, h, w, per_field_dst=True)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.debug_set_warmup(1, 2)
+    got = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+    sim.close()
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    assert np.array_equal(ref, exp) and np.array_equal(got, exp)
+
+
+def test_bob_line_doubling():
+    w, h = 96, 32
+    for hh in (h, h + 1):
+        p = L.make_params(["-vhs"])
+        srcs = [L.noise_frame(w, hh, 3)]
+        for field in (0, 1):
+            o = L.OracleStream(p)
+            e = np.full((hh, w, 4), 0x33, np.uint8)
+            o.field(e, srcs[0], field, 0)
+            L.oracle().ntsc_oracle_bob(L._ptr(e), w * 4, w, hh, field)
+            g = run_hip(p, srcs, [(0, field, 0)], hh, w, bob=True, dst_init=0x33)
+            assert np.array_equal(g[0], e), (hh, field)
+
+
+def test_error_codes():
+    torch = torch_mod()
+    p = L.make_params([])
+    sim = ntscsim.FieldSimulator(params=p)
+    lib = L.product()
+    src = torch.zeros((1, 32, 96, 4), dtype=torch.uint8, device="cuda")
+    d = sim.build_descs(src, src.clone(), [(0, 0, 0, 0)])
+    assert lib.ntscsim_fields_device(sim._h, d, 1, 8, 32, None) == _capi.E_SIZE      # width < 16
+    d[0].src_linesize = 4 * 96 - 4
+    assert lib.ntscsim_fields_device(sim._h, d, 1, 96, 32, None) == _capi.E_SIZE     # :1580
+    d[0].src_linesize = 4 * 96
+    d[0].field = 2
+    assert lib.ntscsim_fields_device(sim._h, d, 1, 96, 32, None) == _capi.E_ARG
+    d[0].field = 0
+    d[0].src_dev = None
+    assert lib.ntscsim_fields_device(sim._h, d, 1, 96, 32, None) == _capi.E_ARG      # :1578
+    assert lib.ntscsim_fields_device(sim._h, d, 0, 96, 32, None) == 0
+    h = C.c_void_p()
+    bad = L.make_params([], video_noise=-2)
+    assert lib.ntscsim_create(C.byref(bad), 0, C.byref(h)) == _capi.E_PARAM
+    assert lib.ntscsim_create(C.byref(p), 99, C.byref(h)) == _capi.E_NODEV
+    sim.close()
+
+
+def test_unaligned_rows_take_the_scalar_path():
+    """src/dst rows that are not 16-byte aligned (odd width, offset base) stay exact."""
+    torch = torch_mod()
+    w, h = 99, 20
+    p = L.make_params(["-vhs"])
+    s = L.noise_frame(w, h, 21)
+    o = L.OracleStream(p)
+    e = np.zeros((h, w, 4), np.uint8)
+    o.field(e, s, 1, 0)
+    sim = ntscsim.FieldSimulator(params=p)
+    big = torch.zeros((1, h, w + 3, 4), dtype=torch.uint8, device="cuda")
+    big[0, :, 1:w + 1] = torch.from_numpy(s).cuda()
+    out = torch.zeros_like(big)
+    src_v = big[:, :, 1:w + 1]
+    dst_v = out[:, :, 1:w + 1]
+    sim.fields(src_v, dst_v, [(0, 0, 1, 0)])
+    sim.sync()
+    assert np.array_equal(dst_v[0].cpu().numpy(), e)
+    assert not out[0, :, 0].any() and not out[0, :, w + 1:].any()
+    sim.close()

@@ -1,0 +1,117 @@
+"""Host-side mirror of parse_argv() and the C-ABI surface (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import _libs as L
+import ntscsim
+from ntscsim import _capi
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(L.ROOT, "include", "ntscsim.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ntscsim_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "header parse failed"
+    lib = C.CDLL(L.PRODUCT_SO)
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "missing export: " + sym
+    assert declared == set(_capi.EXPORTS)
+
+
+def test_struct_layout_matches_c():
+    p = L.make_params([])
+    assert p.struct_size == C.sizeof(_capi.Params)
+
+
+def test_defaults_are_the_reference_globals():
+    p = L.make_params([])
+    assert (p.output_width, p.output_height, p.tv_standard) == (720, 480, 0)
+    assert (p.video_scanline_phase_shift, p.video_scanline_phase_shift_offset) == (180, 0)
+    assert (p.video_noise, p.video_chroma_noise, p.video_chroma_phase_noise, p.video_chroma_loss) == (2, 0, 0, 0)
+    assert (p.subcarrier_amplitude, p.subcarrier_amplitude_back) == (50, 50)
+    assert p.composite_in_chroma_lowpass and p.composite_out_chroma_lowpass and p.composite_out_chroma_lowpass_lite
+    assert not p.emulating_vhs and not p.vhs_head_switching and p.vhs_chroma_vert_blend
+    assert p.vhs_out_sharpen == 1.5 and p.composite_preemphasis == 0 and p.composite_preemphasis_cut == 1000000
+    assert p.vhs_head_switching_point == 1.0 - ((4.5 + 0.01) / 262.5)
+    assert p.vhs_head_switching_phase == (1.0 - 0.01) / 262.5
+    assert p.vhs_head_switching_phase_noise == (1.0 / 500) / 262.5
+
+
+def test_vhs_preset_side_effects():
+    p = L.make_params(["-vhs"])                       # ffmpeg_ntsc.cpp:1141-1151
+    assert p.emulating_vhs and p.vhs_head_switching
+    assert (p.video_chroma_phase_noise, p.video_chroma_noise, p.video_chroma_loss, p.video_noise) == (4, 16, 4, 4)
+    p = L.make_params(["-vhs-speed", "ep"])           # :1160-1189: VHS but NOT head switching
+    assert p.emulating_vhs and not p.vhs_head_switching and p.output_vhs_tape_speed == 2
+    assert (p.video_chroma_phase_noise, p.video_chroma_noise, p.video_chroma_loss, p.video_noise) == (6, 22, 8, 6)
+    p = L.make_params(["--vhs-speed", "lp"])          # any number of leading dashes :979-980
+    assert p.output_vhs_tape_speed == 1 and p.video_noise == 5
+    p = L.make_params(["-vhs-hifi", "0"])
+    assert p.emulating_vhs
+
+
+def test_catv_presets_and_amplitude_back_derivation():
+    # :1077-1096 and :1264-1265: back += (50*pre*(315000000/88)) / (2*cut), truncated on store
+    for flag, pre, cut, pn in (("-comp-catv", 7, 3579545, 2), ("-comp-catv2", 15, 3579545, 4),
+                               ("-comp-catv3", 25, 7159090, 6), ("-comp-catv4", 40, 14318181, 6)):
+        p = L.make_params([flag])
+        assert (p.composite_preemphasis, p.composite_preemphasis_cut, p.video_chroma_phase_noise) == (pre, cut, pn)
+        assert p.subcarrier_amplitude_back == int(50 + (50 * pre * 3579545) / (2 * cut))
+    p = L.make_params(["-subcarrier-amp", "30"])
+    assert (p.subcarrier_amplitude, p.subcarrier_amplitude_back) == (30, 30)
+
+
+def test_pal_and_width():
+    p = L.make_params(["-tvstd", "pal"])
+    assert (p.tv_standard, p.output_width, p.output_height) == (1, 720, 576)
+    p = L.make_params(["-width", "960"])
+    assert p.output_width == 960
+
+
+@pytest.mark.parametrize("flags", [["-comp-phase", "45"], ["-width", "16"], ["-d", "0"], ["-d", "257"],
+                                   ["-tvstd", "secam"], ["-vhs-speed", "slp"], ["-bogus"], ["stray"],
+                                   ["-noise"], ["-ss", "3"], ["-bkey-feedback", "2"]])
+def test_rejected_like_the_reference(flags):
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        L.make_params(flags)
+    assert e.value.code == _capi.E_FLAG
+
+
+def test_help():
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        L.make_params(["-h"])
+    assert e.value.code == _capi.E_HELP
+
+
+def test_validate_rejects_undefined_domain():
+    lib = L.product()
+    for ov in ({"video_noise": -1}, {"subcarrier_amplitude_back": 0}, {"subcarrier_amplitude": 0},
+               {"output_vhs_tape_speed": 7}, {"struct_size": 12}, {"video_chroma_noise": -3}):
+        p = L.make_params(["-vhs"], **ov)
+        assert lib.ntscsim_params_validate(C.byref(p)) == _capi.E_PARAM, ov
+    assert lib.ntscsim_params_validate(C.byref(L.make_params(["-vhs"]))) == 0
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product must fail loudly, never compute on the CPU."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        ntscsim.FieldSimulator(["-vhs"])
+    assert e.value.code == _capi.E_NODEV
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not import / link / call anything under oracle/."""
+    for root, _, files in os.walk(L.PKG):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "ntsc_oracle" not in txt and "oracle/" not in txt, os.path.join(root, f)
