@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
     g.init(ring, st, lane);
 
     int lo0 = exact ? 0 : -K, hi0 = exact ? 0 : K;   // luma / U
-    int lo1 = lo0, hi1 = hi0;                         // V
+    int lo1 = stream == 0 ? 0 : lo0, hi1 = stream == 0 ? 0 : hi0;   // V (chroma stream only)
     if (stream == 0) {
         for (int i = 0; i < warm; i++) {
             const int d = (int)umod31(g.next(ring, lane), M) - K;
@@ -410,7 +410,8 @@ __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__re
 
 // =============================================================================== k_decode
 // streaming chroma_from_luma (ffmpeg_ntsc.cpp:1497-1567).  push(t) takes composite sample t and
-// returns Y/I/Q for x = t - 7.
+// returns Y/I/Q for x = t - 7.  EDGE=false is the steady-state specialisation: every row-boundary
+// predicate is known (2 <= q, q+1 < W, x+xi+2 < W, x < xe), so they compile away.
 struct Demod {
     int c0, c1, c2;               // cs(t-3), cs(t-2), cs(t-1)
     int w0, w1, w2, w3, w4, w5;   // scaled chroma at q-5 .. q   (q = t-2)
@@ -429,6 +430,7 @@ struct Demod {
         const int hi = (xi & 1u) ? a3 : a2;
         return (xi & 2u) ? hi : lo;
     }
+    template <bool EDGE>
     DEV void push(int ct, int t, unsigned xi, int W, int xe, const Magic31 &mA, bool nocolor,
                   int &Yo, int &Io, int &Qo)
     {
@@ -439,7 +441,9 @@ struct Demod {
         // un-flip the negative half cycles (:1539-1542): positions x+2, x+3 for
         // x = (4-xi)&3 + 4m while x+3 < W
         const unsigned g = (unsigned)(q - 2 + (int)xi) & 3u;
-        const bool neg = (g == 0u && q >= 2 && q + 1 < W) || (g == 1u && q >= 3);
+        bool neg;
+        if (EDGE) neg = (g == 0u && q >= 2 && q + 1 < W) || (g == 1u && q >= 3);
+        else neg = g < 2u;
         if (neg) ch = -ch;
         ch = sdivm(ch * 50, mA);                                         // :1544-1546
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
@@ -450,7 +454,7 @@ struct Demod {
         int I, Q;
         if (x & 1) {
             // odd x (and x = -1): fetch the even sample at x+1, interpolate (:1549-1561)
-            const bool m = (x + 1 + (int)xi + 1) < W;
+            const bool m = EDGE ? (x + 1 + (int)xi + 1) < W : true;
             ie_next = m ? -sel4(xi, w1, w2, w3, w4) : 0;
             qe_next = m ? -sel4(xi, w2, w3, w4, w5) : 0;
             I = (ie_prev + ie_next) >> 1;
@@ -459,10 +463,164 @@ struct Demod {
             I = ie_next; Q = qe_next;
             ie_prev = ie_next; qe_prev = qe_next;
         }
-        if (x >= xe || nocolor) { I = 0; Q = 0; }                        // :1553-1556, :1562-1565
+        if ((EDGE && x >= xe) || nocolor) { I = 0; Q = 0; }              // :1553-1556, :1562-1565
         Io = I; Qo = Q;
     }
 };
+
+// per-lane state of the decode pipeline
+struct DecState {
+    Demod D1, D2;
+    int l0, l1, l2;               // luma stream window (VHS)
+    Lp3 vl, vcU, vcV, sh, oU, oV;
+    OnePole vpre;
+    int Yd[5];                    // luma delayed to the output position (0 oldest)
+    int Ur[5], Vr[5];             // raw chroma at the output stage (row tails)
+    int Uf[3];                    // filtered U waiting for V (full output low-pass only)
+    LaneRand rng;
+    int nU, nV;
+};
+
+// per-lane / per-launch constants of the decode pipeline
+struct DecConst {
+    unsigned xi;
+    int W, xe, k, lane;
+    int d, SKO, dI, dQ;
+    bool vb, drop;
+    double cosv, sinv;
+    int *tailU, *tailV;           // [16][Rpad] global scratch, this lane's column
+    size_t rstride;
+};
+
+// One pipeline step at stream position t.  Returns true when a pixel for x = *xo was produced.
+template <bool VHS, bool COMPOUT, bool EDGE>
+DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *ring, int t,
+                  int pc, int pl, uint32_t &px, int &xo_out)
+{
+    const int W = C.W;
+    const int lane = C.lane;
+    // ================= Y/C separation #1 at x1 = t - 7 (:1716, amplitude_back)
+    int Y, U, V;
+    S.D1.template push<EDGE>(pc, t, C.xi, W, C.xe, P.m_amp_back, P.nocolor != 0, Y, U, V);
+    const int x1 = t - 7;
+    const bool in1 = EDGE ? (x1 >= 0 && x1 < W) : true;
+    if (in1) {
+        // chroma noise :1719-1735
+        if (P.cnoise_k) {
+            U += S.nU; V += S.nV;
+            S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+            S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+        }
+        // chroma phase noise :1748-1762
+        if (P.pnoise_k) {
+            const double u = U, v = V;
+            const double u_ = (u * C.cosv) - (v * C.sinv);
+            const double v_ = (u * C.sinv) + (v * C.cosv);
+            U = (int)u_; V = (int)v_;
+        }
+    }
+    int x2 = x1;           // position after the VHS block
+    if (VHS) {
+        const int d = C.d;
+        // ---- VHS chroma low-pass :1814-1836: value for input x1 lands at x1 - d
+        int fU = 0, fV = 0;
+        if (in1) {
+            fU = (int)S.vcU.push((double)U, P.a_vc);
+            fV = (int)S.vcV.push((double)V, P.a_vc);
+            if (EDGE && x1 >= W - 16) {
+                C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
+                C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
+            }
+        }
+        x2 = x1 - d;
+        // ---- luma path at x2: box (or pass-through) -> low-pass + emphasis -> sharpen
+        const int lc = pl;                 // cs(x2 + 2)
+        const int yb = P.nocolor ? S.l1 : sdiv4(S.l0 + S.l1 + S.l2 + lc);
+        S.l0 = S.l1; S.l1 = S.l2; S.l2 = lc;
+        const bool in2 = EDGE ? (x2 >= 0 && x2 < W) : true;
+        if (in2) {
+            if (EDGE && x2 >= W - d) {
+                fU = C.tailU[(size_t)(x2 & 15) * C.rstride];
+                fV = C.tailV[(size_t)(x2 & 15) * C.rstride];
+            }
+            U = fU; V = fV;
+            // luma low-pass + emphasis :1793-1812
+            double s = yb;
+            s = S.vl.push(s, P.a_vl);
+            s += S.vpre.hp(s, P.a_vl) * 1.6;
+            Y = (int)s;
+            // sharpen :1866-1883
+            {
+                const double s0 = Y;
+                const double ts = S.sh.push(s0, P.a_sh);
+                Y = (int)(s0 + ((s0 - ts) * P.sharpen * 2));
+            }
+        }
+        // ---- vertical chroma blend :1843-1863 (wave shift: lane-1 is the row above)
+        {
+            const int upU = __shfl_up(U, 1), upV = __shfl_up(V, 1);
+            if (C.vb && C.k >= 1) {
+                const int pu = C.k >= 2 ? upU : 0, pv = C.k >= 2 ? upV : 0;
+                U = (pu + U + 1) >> 1;
+                V = (pv + V + 1) >> 1;
+            }
+        }
+    }
+    int x3 = x2;
+    if (COMPOUT) {
+        // ---- composite out of the VCR :1885-1888: modulate, then separate again
+        int c2 = 0;
+        if (!EDGE || (x2 >= 0 && x2 < W)) {
+            const unsigned s = (C.xi + (unsigned)x2) & 3u;
+            int chroma = ((s & 1u) ? V : U) * P.amp;
+            if (s & 2u) chroma = -chroma;
+            c2 = Y + chroma / 50;
+        }
+        S.D2.template push<EDGE>(c2, x2, C.xi, W, C.xe, P.m_amp, false, Y, U, V);
+        x3 = x2 - 7;
+    }
+    const int SKO = C.SKO;
+    if (EDGE && (x3 < 0 || x3 >= W + SKO)) return false;
+    // ================= dropout :1891-1901, output low-pass :1903-1908 at x3
+    const bool in3 = EDGE ? x3 < W : true;
+    if (C.drop || !in3) { U = 0; V = 0; }
+    if (!in3) Y = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { S.Yd[q] = S.Yd[q + 1]; S.Ur[q] = S.Ur[q + 1]; S.Vr[q] = S.Vr[q + 1]; }
+    S.Yd[4] = Y; S.Ur[4] = U; S.Vr[4] = V;
+    int fU = 0, fV = 0;
+    if (P.out_lp && in3) {
+        const double a_u = P.out_lp == 1 ? P.a_tv : P.a_in_i;
+        const double a_v = P.out_lp == 1 ? P.a_tv : P.a_in_q;
+        fU = (int)S.oU.push((double)U, a_u);
+        fV = (int)S.oV.push((double)V, a_v);
+    }
+    S.Uf[0] = S.Uf[1]; S.Uf[1] = S.Uf[2]; S.Uf[2] = fU;
+    const int xo = x3 - SKO;
+    if (EDGE && xo < 0) return false;
+    // (static selects instead of Yd[4 - SKO]: dynamic register indexing would go to scratch)
+    const int Yo = SKO == 0 ? S.Yd[4] : (SKO == 1 ? S.Yd[3] : S.Yd[0]);
+    int Uo, Vo;
+    if (P.out_lp == 0) { Uo = U; Vo = V; }
+    else {
+        // U value for xo was produced dI steps after xo entered, V value dQ steps after
+        const int Uraw = SKO == 1 ? S.Ur[3] : S.Ur[0];
+        const int Vraw = SKO == 1 ? S.Vr[3] : S.Vr[0];
+        const int Ufil = (C.dQ - C.dI) == 0 ? S.Uf[2] : S.Uf[0];
+        Uo = (!EDGE || xo < W - C.dI) ? Ufil : Uraw;
+        Vo = (!EDGE || xo < W - C.dQ) ? fV : Vraw;
+    }
+    // ================= YIQ -> RGB :1385-1396, pack :1914 (alpha = 0)
+    int r = (int)(((1.000 * Yo) + (0.956 * Uo) + (0.621 * Vo)) / 256);
+    int g = (int)(((1.000 * Yo) + (-0.272 * Uo) + (-0.647 * Vo)) / 256);
+    int b = (int)(((1.000 * Yo) + (-1.106 * Uo) + (1.703 * Vo)) / 256);
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    px = ((uint32_t)r << 16) + ((uint32_t)g << 8) + (uint32_t)b;
+    xo_out = xo;
+    return true;
+}
 
 template <bool VHS, bool COMPOUT>
 __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
@@ -473,11 +631,10 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
                                                const int *__restrict__ n0_v,
                                                const int *__restrict__ hs_shift,
                                                const int *__restrict__ pn_noise,
-                                               const int *__restrict__ dropout)
+                                               const int *__restrict__ dropout,
+                                               int *__restrict__ tails)
 {
     __shared__ uint32_t ring[31 * 64];
-    __shared__ int tailU[16 * 64], tailV[16 * 64];
-    __shared__ uint32_t ostage[64 * 17];
 
     const int lane = threadIdx.x;
     // 63 output rows per wave; lane 0 recomputes the row above (halo for the vertical blend)
@@ -489,26 +646,48 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
     const bool rowok = (int)(field + 2u * k) < P.H;
     const bool is_out = lane >= 1 && gidx < P.R && rowok;
     const unsigned y = rowok ? field + 2u * (unsigned)k : field;
-    const unsigned xi = scan_phase(P, y, fd.fieldno);
     const int W = P.W;
-    const int xe = (W & 1) ? W - 1 : W - 2;      // first even x with x+2 >= W
     const int tw = W + W / 10;
     const int hs = P.hs ? hs_shift[rc] : 0;
-    const bool drop = P.loss ? dropout[rc] != 0 : false;
-    double cosv = 1, sinv = 0;
-    if (P.pnoise_k) {
-        const int n = pn_noise[rc] + P.pnoise_k;
-        cosv = G.ptab[2 * n]; sinv = G.ptab[2 * n + 1];
-    }
     uint32_t *drow = reinterpret_cast<uint32_t *>(fd.dst + (size_t)fd.dst_ls * y);
     const int *cbase = comp + rc;
-    const bool vb = VHS && P.vblend && P.ntsc;
+    // every lane of a wave owns a distinct column of the tails scratch (halo lanes included)
+    const size_t tcol = (size_t)blockIdx.x * 64 + lane;
+    const size_t tstride = (size_t)gridDim.x * 64;
 
-    LaneRand rng;
-    int nU = 0, nV = 0;
+    DecConst C;
+    C.xi = scan_phase(P, y, fd.fieldno);
+    C.W = W;
+    C.xe = (W & 1) ? W - 1 : W - 2;      // first even x with x+2 >= W
+    C.k = k;
+    C.lane = lane;
+    C.d = VHS ? P.cdelay : 0;            // VHS chroma delay (9/12/14)
+    C.dI = P.out_lp == 2 ? 2 : (P.out_lp == 1 ? 1 : 0);
+    C.dQ = P.out_lp == 2 ? 4 : (P.out_lp == 1 ? 1 : 0);
+    C.SKO = C.dQ;                        // output low-pass look-ahead
+    C.vb = VHS && P.vblend && P.ntsc;
+    C.drop = P.loss ? dropout[rc] != 0 : false;
+    C.cosv = 1; C.sinv = 0;
+    if (P.pnoise_k) {
+        const int n = pn_noise[rc] + P.pnoise_k;
+        C.cosv = G.ptab[2 * n]; C.sinv = G.ptab[2 * n + 1];
+    }
+    C.tailU = tails + tcol;
+    C.tailV = tails + 16 * tstride + tcol;
+    C.rstride = tstride;
+
+    DecState S;
+    S.D1.init(); S.D2.init();
+    S.l0 = S.l1 = S.l2 = 0;
+    S.vl.reset(16); S.vpre.p = 16; S.vcU.reset(0); S.vcV.reset(0); S.sh.reset(0);
+    S.oU.reset(0); S.oV.reset(0);
+#pragma unroll
+    for (int q = 0; q < 5; q++) { S.Yd[q] = 0; S.Ur[q] = 0; S.Vr[q] = 0; }
+    S.Uf[0] = S.Uf[1] = S.Uf[2] = 0;
+    S.nU = S.nV = 0;
     if (P.cnoise_k) {
-        rng.init(ring, rs_chroma + rc, P.Rpad, lane);
-        nU = n0_u[rc]; nV = n0_v[rc];
+        S.rng.init(ring, rs_chroma + rc, P.Rpad, lane);
+        S.nU = n0_u[rc]; S.nV = n0_v[rc];
     }
 
     // composite sample after head switching (:1687-1697): Y[x] = tmp[(x + shif) mod twidth],
@@ -523,182 +702,69 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
         }
         return cbase[(size_t)idx * P.Rpad];
     };
+    const bool any_hs = __any(hs != 0);
 
-    const int d = VHS ? P.cdelay : 0;             // VHS chroma delay (9/12/14)
-    const int SK1 = 7;                            // demodulator latency
-    const int SK2 = COMPOUT ? 7 : 0;              // second demodulator
-    const int dI = P.out_lp == 2 ? 2 : (P.out_lp == 1 ? 1 : 0);
-    const int dQ = P.out_lp == 2 ? 4 : (P.out_lp == 1 ? 1 : 0);
-    const int SKO = dQ;                           // output low-pass look-ahead
-    const int total = W + SK1 + d + SK2 + SKO;
+    const int d = C.d;
+    const int SKT = 7 + d + (COMPOUT ? 7 : 0) + C.SKO;   // pipeline depth: xo = t - SKT
+    const int total = W + SKT;
+    const int LOFF = 5 + d;                                // luma stream reads cs(t - LOFF)
 
-    Demod D1, D2;
-    D1.init(); D2.init();
-    int l0 = 0, l1 = 0, l2 = 0;                   // luma stream window (VHS)
-    Lp3 vl, vcU, vcV, sh, oU, oV;
-    OnePole vpre;
-    vl.reset(16); vpre.p = 16; vcU.reset(0); vcV.reset(0); sh.reset(0); oU.reset(0); oV.reset(0);
-    // output stage windows: element 0 oldest
-    int Yd[5] = {0, 0, 0, 0, 0};                  // luma delayed to the output position
-    int Ur[5] = {0, 0, 0, 0, 0}, Vr[5] = {0, 0, 0, 0, 0};   // raw chroma (row tails)
-    int Uf[3] = {0, 0, 0};                        // filtered U waiting for V (full LP only)
-
-    int pc[4], pl[4];                             // prefetched composite samples
+    int t = 0;
+    // ---------------- prologue: fill the pipeline (guarded steps)
+    for (; t < SKT && t < total; t++) {
+        uint32_t px; int xo;
+        (void)dec_step<VHS, COMPOUT, true>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo);
+    }
+    // ---------------- steady state: every stage is strictly inside the row, 4 pixels per
+    // iteration, one 16-byte store per lane.  Ends 16 samples before the row end.
+    {
+        int pc[4], pl[4];
+        const int t_end = W - 16;
+        if (t + 4 <= t_end) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) { pc[j] = cs(j); pl[j] = VHS ? cs(j - 5 - d) : 0; }
-
-    for (int t0 = 0; t0 < total; t0 += 4) {
-        int nc[4], nl[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            nc[j] = cs(t0 + 4 + j);
-            nl[j] = VHS ? cs(t0 + 4 + j - 5 - d) : 0;
+            for (int j = 0; j < 4; j++) { pc[j] = cs(t + j); pl[j] = VHS ? cs(t + j - LOFF) : 0; }
         }
+        for (; t + 4 <= t_end; t += 4) {
+            int nc[4], nl[4];
+            if (any_hs) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int t = t0 + j;
-            if (t >= total) break;
-            // ================= Y/C separation #1 at x1 = t - 7 (:1716, amplitude_back)
-            int Y, U, V;
-            D1.push(pc[j], t, xi, W, xe, P.m_amp_back, P.nocolor != 0, Y, U, V);
-            const int x1 = t - SK1;
-            if (x1 >= 0 && x1 < W) {
-                // chroma noise :1719-1735
-                if (P.cnoise_k) {
-                    U += nU; V += nV;
-                    nU = sdiv2(nU + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
-                    nV = sdiv2(nV + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+                for (int j = 0; j < 4; j++) {
+                    nc[j] = cs(t + 4 + j);
+                    nl[j] = VHS ? cs(t + 4 + j - LOFF) : 0;
                 }
-                // chroma phase noise :1748-1762
-                if (P.pnoise_k) {
-                    const double u = U, v = V;
-                    const double u_ = (u * cosv) - (v * sinv);
-                    const double v_ = (u * sinv) + (v * cosv);
-                    U = (int)u_; V = (int)v_;
-                }
-            }
-            int x2 = x1;           // position after the VHS block
-            if (VHS) {
-                // ---- VHS chroma low-pass :1814-1836: value for input x1 lands at x1 - d
-                int fU = 0, fV = 0;
-                if (x1 >= 0 && x1 < W) {
-                    fU = (int)vcU.push((double)U, P.a_vc);
-                    fV = (int)vcV.push((double)V, P.a_vc);
-                    if (x1 >= W - 16) { tailU[(x1 & 15) * 64 + lane] = U; tailV[(x1 & 15) * 64 + lane] = V; }
-                }
-                x2 = x1 - d;
-                // ---- luma path at x2: box (or pass-through) -> low-pass + emphasis -> sharpen
-                const int lc = pl[j];              // cs(x2 + 2)
-                const int yb = P.nocolor ? l1 : sdiv4(l0 + l1 + l2 + lc);
-                l0 = l1; l1 = l2; l2 = lc;
-                if (x2 >= 0 && x2 < W) {
-                    if (x2 >= W - d) { fU = tailU[(x2 & 15) * 64 + lane]; fV = tailV[(x2 & 15) * 64 + lane]; }
-                    U = fU; V = fV;
-                    // luma low-pass + emphasis :1793-1812
-                    double s = yb;
-                    s = vl.push(s, P.a_vl);
-                    s += vpre.hp(s, P.a_vl) * 1.6;
-                    Y = (int)s;
-                    // sharpen :1866-1883
-                    {
-                        const double s0 = Y;
-                        const double ts = sh.push(s0, P.a_sh);
-                        Y = (int)(s0 + ((s0 - ts) * P.sharpen * 2));
-                    }
-                }
-                // ---- vertical chroma blend :1843-1863 (wave shift: lane-1 is the row above)
-                {
-                    const int upU = __shfl_up(U, 1), upV = __shfl_up(V, 1);
-                    if (vb && k >= 1) {
-                        const int pu = k >= 2 ? upU : 0, pv = k >= 2 ? upV : 0;
-                        U = (pu + U + 1) >> 1;
-                        V = (pv + V + 1) >> 1;
-                    }
-                }
-            }
-            int x3 = x2;
-            if (COMPOUT) {
-                // ---- composite out of the VCR :1885-1888: modulate, then separate again
-                int c2 = 0;
-                if (x2 >= 0 && x2 < W) {
-                    const unsigned s = (xi + (unsigned)x2) & 3u;
-                    int chroma = ((s & 1u) ? V : U) * P.amp;
-                    if (s & 2u) chroma = -chroma;
-                    c2 = Y + chroma / 50;
-                }
-                D2.push(c2, x2, xi, W, xe, P.m_amp, false, Y, U, V);
-                x3 = x2 - 7;
-            }
-            if (x3 < 0 || x3 >= W + SKO) continue;
-            // ================= dropout :1891-1901, output low-pass :1903-1908 at x3
-            const bool in3 = x3 < W;
-            if (drop || !in3) { U = 0; V = 0; }
-            if (!in3) Y = 0;
+            } else {
+                // t + 7 < W and t + 4 - LOFF >= 0: plain coalesced loads
 #pragma unroll
-            for (int q = 0; q < 4; q++) { Yd[q] = Yd[q + 1]; Ur[q] = Ur[q + 1]; Vr[q] = Vr[q + 1]; }
-            Yd[4] = Y; Ur[4] = U; Vr[4] = V;
-            int fU = 0, fV = 0;
-            if (P.out_lp && in3) {
-                const double a_u = P.out_lp == 1 ? P.a_tv : P.a_in_i;
-                const double a_v = P.out_lp == 1 ? P.a_tv : P.a_in_q;
-                fU = (int)oU.push((double)U, a_u);
-                fV = (int)oV.push((double)V, a_v);
-            }
-            Uf[0] = Uf[1]; Uf[1] = Uf[2]; Uf[2] = fU;
-            const int xo = x3 - SKO;
-            if (xo < 0) continue;
-            // (static selects instead of Yd[4 - SKO]: dynamic register indexing would go to scratch)
-            const int Yo = SKO == 0 ? Yd[4] : (SKO == 1 ? Yd[3] : Yd[0]);
-            int Uo, Vo;
-            if (P.out_lp == 0) { Uo = U; Vo = V; }
-            else {
-                // U value for xo was produced dI steps after xo entered, V value dQ steps after
-                const int Uraw = SKO == 1 ? Ur[3] : Ur[0];
-                const int Vraw = SKO == 1 ? Vr[3] : Vr[0];
-                const int Ufil = (dQ - dI) == 0 ? Uf[2] : Uf[0];
-                Uo = (xo < W - dI) ? Ufil : Uraw;
-                Vo = (xo < W - dQ) ? fV : Vraw;
-            }
-            // ================= YIQ -> RGB :1385-1396, pack :1914 (alpha = 0)
-            int r = (int)(((1.000 * Yo) + (0.956 * Uo) + (0.621 * Vo)) / 256);
-            int g = (int)(((1.000 * Yo) + (-0.272 * Uo) + (-0.647 * Vo)) / 256);
-            int b = (int)(((1.000 * Yo) + (-1.106 * Uo) + (1.703 * Vo)) / 256);
-            r = r < 0 ? 0 : (r > 255 ? 255 : r);
-            g = g < 0 ? 0 : (g > 255 ? 255 : g);
-            b = b < 0 ? 0 : (b > 255 ? 255 : b);
-            ostage[lane * 17 + (xo & 15)] = ((uint32_t)r << 16) + ((uint32_t)g << 8) + (uint32_t)b;
-            if ((xo & 15) == 15 || xo == W - 1) {
-                const int xb = xo & ~15;
-                const int n = xo - xb + 1;
-                if (is_out) {
-                    if (n == 16 && P.dst_al16) {
-                        uint4 *o = reinterpret_cast<uint4 *>(drow + xb);
-                        const uint32_t *s = &ostage[lane * 17];
-                        o[0] = make_uint4(s[0], s[1], s[2], s[3]);
-                        o[1] = make_uint4(s[4], s[5], s[6], s[7]);
-                        o[2] = make_uint4(s[8], s[9], s[10], s[11]);
-                        o[3] = make_uint4(s[12], s[13], s[14], s[15]);
-                    } else {
-                        for (int q = 0; q < n; q++) drow[xb + q] = ostage[lane * 17 + q];
-                    }
+                for (int j = 0; j < 4; j++) {
+                    nc[j] = cbase[(size_t)(t + 4 + j) * P.Rpad];
+                    nl[j] = VHS ? cbase[(size_t)(t + 4 + j - LOFF) * P.Rpad] : 0;
                 }
             }
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int xo;
+                (void)dec_step<VHS, COMPOUT, false>(P, S, C, ring, t + j, pc[j], pl[j], o[j], xo);
+            }
+            if (is_out) {
+                const int xo0 = t - SKT;                   // multiple of 4
+                if (P.dst_al16) {
+                    *reinterpret_cast<uint4 *>(drow + xo0) = make_uint4(o[0], o[1], o[2], o[3]);
+                } else {
+                    drow[xo0] = o[0]; drow[xo0 + 1] = o[1]; drow[xo0 + 2] = o[2]; drow[xo0 + 3] = o[3];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
+    }
+    // ---------------- epilogue: row end, filter tails, pipeline drain (guarded steps)
+    for (; t < total; t++) {
+        uint32_t px; int xo;
+        if (dec_step<VHS, COMPOUT, true>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
+            if (is_out) drow[xo] = px;
     }
 }
-
-// explicit instantiations used by the launcher
-template __global__ void k_decode<false, false>(DevParams, GeomDev, const FieldDev *, const int *,
-                                                const uint32_t *, const int *, const int *,
-                                                const int *, const int *, const int *);
-template __global__ void k_decode<true, false>(DevParams, GeomDev, const FieldDev *, const int *,
-                                               const uint32_t *, const int *, const int *,
-                                               const int *, const int *, const int *);
-template __global__ void k_decode<true, true>(DevParams, GeomDev, const FieldDev *, const int *,
-                                              const uint32_t *, const int *, const int *,
-                                              const int *, const int *, const int *);
 
 // =============================================================================== k_bob
 // Line doubling done by the field loop after composite_layer (ffmpeg_ntsc.cpp:2233-2257):

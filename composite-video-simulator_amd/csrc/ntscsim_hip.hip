@@ -75,7 +75,7 @@ struct ntscsim_ctx {
 
     // per-batch scratch
     DevBuf<FieldDev> fields;
-    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp;
+    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, tails;
     DevBuf<uint32_t> rs_luma, rs_chroma;
     FieldDev *stage[2] = {nullptr, nullptr};
     size_t stage_cap[2] = {0, 0};
@@ -292,7 +292,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geom.sstart.release(); c->geom.jwarm.release();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->tails.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
@@ -457,18 +457,19 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
                        c->rs_luma.p, c->n0_luma.p, c->comp.p);
     if (prof) HIPCHK(c, hipEventRecord(evs.e[2], st));
     const dim3 dgrid((D.R + 62) / 63);
+    if (D.vhs) HIPCHK(c, c->tails.ensure((size_t)32 * 64 * dgrid.x));
     if (!D.vhs)
         hipLaunchKernelGGL((k_decode<false, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
                            c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p);
+                           c->pn_noise.p, c->dropout.p, c->tails.p);
     else if (D.svideo)
         hipLaunchKernelGGL((k_decode<true, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
                            c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p);
+                           c->pn_noise.p, c->dropout.p, c->tails.p);
     else
         hipLaunchKernelGGL((k_decode<true, true>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
                            c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p);
+                           c->pn_noise.p, c->dropout.p, c->tails.p);
     if (prof) HIPCHK(c, hipEventRecord(evs.e[3], st));
     if (any_bob)
         hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, c->fields.p);
