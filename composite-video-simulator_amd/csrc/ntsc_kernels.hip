@@ -51,6 +51,34 @@ DEV unsigned scan_phase(const DevParams &P, unsigned y, uint64_t fieldno)
     return off & 3;
 }
 
+// ------------------------------------------------------------------------------ option policy
+// The hot kernels are instantiated twice: a GENERIC form that reads every option from DevParams
+// (wave-uniform branches inside the loop), and a PRESET form in which the options of the two
+// configurations that matter for throughput -- the default preset and the full `-vhs` preset --
+// are compile-time constants, so the steady-state loop is one straight-line block.  The launcher
+// picks the PRESET form only when the parameters match it exactly; results are identical.
+enum : unsigned {
+    F_GENERIC = 1u,     // read options at run time
+    F_CNOISE  = 2u,     // chroma noise on
+    F_PNOISE  = 4u,     // chroma phase noise on
+    F_LNOISE  = 8u,     // luma noise on
+};
+template <unsigned F>
+struct Opt {
+    static constexpr bool generic = (F & F_GENERIC) != 0;
+    DEV static bool cnoise(const DevParams &P) { return generic ? P.cnoise_k != 0 : (F & F_CNOISE) != 0; }
+    DEV static bool pnoise(const DevParams &P) { return generic ? P.pnoise_k != 0 : (F & F_PNOISE) != 0; }
+    DEV static bool lnoise(const DevParams &P) { return generic ? P.noise_k != 0 : (F & F_LNOISE) != 0; }
+    DEV static bool nocolor(const DevParams &P) { return generic ? P.nocolor != 0 : false; }
+    DEV static int  outlp(const DevParams &P) { return generic ? P.out_lp : 1; }      // preset: lite
+    DEV static bool inlp(const DevParams &P) { return generic ? P.in_lp != 0 : true; }
+    DEV static bool pre(const DevParams &P) { return generic ? P.pre_on != 0 : false; }
+    // subcarrier amplitude 50 both ways: (c*50)/50 == c and (v*50)/50 == v exactly
+    DEV static int scale_back(const DevParams &P, int c, const Magic31 &m)
+    { return generic ? sdivm(c * 50, m) : c; }
+    DEV static int modulate(const DevParams &P, int v) { return generic ? (v * P.amp) / 50 : v; }
+};
+
 // ------------------------------------------------------------------------------ one-pole IIR
 // LowpassFilter::lowpass / highpass, ffmpeg_ntsc.cpp:90-99 (operation order is the contract)
 struct OnePole {
@@ -315,11 +343,75 @@ DEV void load_px16(const uint8_t *srow, int x0, int W, bool al16, uint32_t (&px)
     }
 }
 
+struct EncState {
+    Lp3 lpI, lpQ;
+    OnePole pre;
+    // delay windows: element 0 is the oldest (sample t-4), element 4 the newest (sample t)
+    int Yw[5], Iw[5], Qw[5];
+    int fI[3];
+    LaneRand rng;
+    int noise;
+};
+
+// One encoder step: consumes pixel t, emits composite sample x = t - 4.  EDGE=false is the
+// steady state (4 <= t < W): no row-boundary predicate survives.
+template <bool EDGE, class O>
+DEV void enc_step(const DevParams &P, EncState &S, unsigned xi, int W, uint32_t *ring, int lane,
+                  int t, uint32_t px_in, int *cdst, bool valid)
+{
+    // ---- RGB -> YIQ, ffmpeg_ntsc.cpp:1375-1383 (pixels past the row end feed zeros into
+    //      filters whose outputs are never used)
+    const uint32_t px = (!EDGE || t < W) ? px_in : 0u;
+    const int r = (int)((px >> 16) & 0xFF), g = (int)((px >> 8) & 0xFF), b = (int)(px & 0xFF);
+    const double dY = (0.30 * r) + (0.59 * g) + (0.11 * b);
+    const int Yn = (int)(256 * dY);
+    const int In = (int)(256 * ((-0.27 * (b - dY)) + (0.74 * (r - dY))));
+    const int Qn = (int)(256 * ((0.41 * (b - dY)) + (0.48 * (r - dY))));
+#pragma unroll
+    for (int q = 0; q < 4; q++) { S.Yw[q] = S.Yw[q + 1]; S.Iw[q] = S.Iw[q + 1]; S.Qw[q] = S.Qw[q + 1]; }
+    S.Yw[4] = Yn; S.Iw[4] = In; S.Qw[4] = Qn;
+    // ---- input chroma low-pass, composite_lowpass :1429-1458 (I: 1.3 MHz delay 2,
+    //      Q: 0.6 MHz delay 4; the last `delay` samples keep their input)
+    int fQ = 0;
+    if (O::inlp(P)) {
+        S.fI[0] = S.fI[1]; S.fI[1] = S.fI[2];
+        S.fI[2] = (int)S.lpI.push((double)In, P.a_in_i);
+        fQ = (int)S.lpQ.push((double)Qn, P.a_in_q);
+    }
+    const int x = t - 4;
+    if (EDGE && x < 0) return;
+    int I1 = S.Iw[0], Q1 = S.Qw[0];
+    if (O::inlp(P)) {
+        if (!EDGE || x < W - 2) I1 = S.fI[0];
+        if (!EDGE || x < W - 4) Q1 = fQ;
+    }
+    // ---- chroma_into_luma :1460-1495
+    const unsigned s = (xi + (unsigned)x) & 3u;
+    int chroma = O::modulate(P, (s & 1u) ? Q1 : I1);
+    if (s & 2u) chroma = -chroma;
+    int Y = S.Yw[0] + chroma;
+    // ---- composite pre-emphasis :1614-1629
+    if (O::pre(P)) {
+        double sd = Y;
+        sd += S.pre.hp(sd, P.a_pre) * P.pre_gain;
+        Y = (int)sd;
+    }
+    // ---- luma noise :1632-1644
+    if (O::lnoise(P)) {
+        Y += S.noise;
+        S.noise += (int)umod31(S.rng.next(ring, lane), P.m_noise) - P.noise_k;
+        S.noise = sdiv2(S.noise);
+    }
+    if (valid) cdst[(size_t)x * P.Rpad] = Y;
+}
+
+template <unsigned F>
 __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__restrict__ fields,
                                                const uint32_t *__restrict__ rs_luma,
                                                const int *__restrict__ n0_luma,
                                                int *__restrict__ comp)
 {
+    using O = Opt<F>;
     __shared__ uint32_t ring[31 * 64];
     const int lane = threadIdx.x;
     const int rho = blockIdx.x * 64 + lane;
@@ -336,73 +428,49 @@ __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__re
     const uint8_t *srow = fd.src + (size_t)fd.src_ls * sy;
     const unsigned xi = scan_phase(P, y, fd.fieldno);
     const int W = P.W;
+    const bool al = P.src_al16 != 0;
 
-    LaneRand rng;
-    int noise = 0;
-    if (P.noise_k) {
-        rng.init(ring, rs_luma + rc, P.Rpad, lane);
-        noise = n0_luma[rc];
+    EncState S;
+    S.noise = 0;
+    if (O::lnoise(P)) {
+        S.rng.init(ring, rs_luma + rc, P.Rpad, lane);
+        S.noise = n0_luma[rc];
     }
-
-    Lp3 lpI, lpQ;
-    lpI.reset(0); lpQ.reset(0);
-    OnePole pre; pre.p = 16;
-    // delay windows: element 0 is the oldest (sample t-4), element 4 the newest (sample t)
-    int Yw[5] = {0, 0, 0, 0, 0}, Iw[5] = {0, 0, 0, 0, 0}, Qw[5] = {0, 0, 0, 0, 0};
-    int fI[3] = {0, 0, 0};
+    S.lpI.reset(0); S.lpQ.reset(0);
+    S.pre.p = 16;
+#pragma unroll
+    for (int q = 0; q < 5; q++) { S.Yw[q] = 0; S.Iw[q] = 0; S.Qw[q] = 0; }
+    S.fI[0] = S.fI[1] = S.fI[2] = 0;
     int *cdst = comp + rho;
 
     uint32_t cur[16], nxt[16];
-    load_px16(srow, 0, W, P.src_al16 != 0, cur);
-    for (int t0 = 0; t0 < W + 4; t0 += 16) {
-        if (t0 + 16 < W) load_px16(srow, t0 + 16, W, P.src_al16 != 0, nxt);
+    load_px16(srow, 0, W, al, cur);
+    int t0 = 0;
+    // first chunk: pipeline fill (guarded)
+    {
+        if (16 < W) load_px16(srow, 16, W, al, nxt);
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int t = t0 + j;
-            if (t >= W + 4) break;
-            // ---- RGB -> YIQ, ffmpeg_ntsc.cpp:1375-1383 (pixels past the row end feed zeros
-            //      into filters whose outputs are never used)
-            const uint32_t px = (t < W) ? cur[j] : 0u;
-            const int r = (int)((px >> 16) & 0xFF), g = (int)((px >> 8) & 0xFF), b = (int)(px & 0xFF);
-            const double dY = (0.30 * r) + (0.59 * g) + (0.11 * b);
-            const int Yn = (int)(256 * dY);
-            const int In = (int)(256 * ((-0.27 * (b - dY)) + (0.74 * (r - dY))));
-            const int Qn = (int)(256 * ((0.41 * (b - dY)) + (0.48 * (r - dY))));
+        for (int j = 0; j < 16; j++)
+            if (j < W + 4) enc_step<true, O>(P, S, xi, W, ring, lane, j, cur[j], cdst, valid);
 #pragma unroll
-            for (int q = 0; q < 4; q++) { Yw[q] = Yw[q + 1]; Iw[q] = Iw[q + 1]; Qw[q] = Qw[q + 1]; }
-            Yw[4] = Yn; Iw[4] = In; Qw[4] = Qn;
-            // ---- input chroma low-pass, composite_lowpass :1429-1458 (I: 1.3 MHz delay 2,
-            //      Q: 0.6 MHz delay 4; the last `delay` samples keep their input)
-            fI[0] = fI[1]; fI[1] = fI[2];
-            fI[2] = (int)lpI.push((double)In, P.a_in_i);
-            const int fQ = (int)lpQ.push((double)Qn, P.a_in_q);
-
-            const int x = t - 4;
-            if (x < 0) continue;
-            int I1 = Iw[0], Q1 = Qw[0];
-            if (P.in_lp) {
-                if (x < W - 2) I1 = fI[0];
-                if (x < W - 4) Q1 = fQ;
-            }
-            // ---- chroma_into_luma :1460-1495
-            const unsigned s = (xi + (unsigned)x) & 3u;
-            int chroma = ((s & 1u) ? Q1 : I1) * P.amp;
-            if (s & 2u) chroma = -chroma;
-            int Y = Yw[0] + chroma / 50;
-            // ---- composite pre-emphasis :1614-1629
-            if (P.pre_on) {
-                double sd = Y;
-                sd += pre.hp(sd, P.a_pre) * P.pre_gain;
-                Y = (int)sd;
-            }
-            // ---- luma noise :1632-1644
-            if (P.noise_k) {
-                Y += noise;
-                noise += (int)umod31(rng.next(ring, lane), P.m_noise) - P.noise_k;
-                noise = sdiv2(noise);
-            }
-            if (valid) cdst[(size_t)x * P.Rpad] = Y;
-        }
+        for (int j = 0; j < 16; j++) cur[j] = nxt[j];
+        t0 = 16;
+    }
+    // steady state: whole 16-pixel chunks strictly inside the row
+    for (; t0 + 16 <= W; t0 += 16) {
+        if (t0 + 16 < W) load_px16(srow, t0 + 16, W, al, nxt);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            enc_step<false, O>(P, S, xi, W, ring, lane, t0 + j, cur[j], cdst, valid);
+#pragma unroll
+        for (int j = 0; j < 16; j++) cur[j] = nxt[j];
+    }
+    // row end + pipeline drain (guarded)
+    for (; t0 < W + 4; t0 += 16) {
+        if (t0 + 16 < W) load_px16(srow, t0 + 16, W, al, nxt);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (t0 + j < W + 4) enc_step<true, O>(P, S, xi, W, ring, lane, t0 + j, cur[j], cdst, valid);
 #pragma unroll
         for (int j = 0; j < 16; j++) cur[j] = nxt[j];
     }
@@ -430,9 +498,11 @@ struct Demod {
         const int hi = (xi & 1u) ? a3 : a2;
         return (xi & 2u) ? hi : lo;
     }
-    template <bool EDGE>
-    DEV void push(int ct, int t, unsigned xi, int W, int xe, const Magic31 &mA, bool nocolor,
-                  int &Yo, int &Io, int &Qo)
+    // PAR: parity of the output position x = t - 7 when it is known at compile time (0 even,
+    // 1 odd), -1 to test it at run time.
+    template <bool EDGE, class O, int PAR>
+    DEV void push(const DevParams &P, int ct, int t, unsigned xi, int W, int xe, const Magic31 &mA,
+                  bool nocolor, int &Yo, int &Io, int &Qo)
     {
         const int q = t - 2;
         // 4-tap box with zero extension (:1507-1525)
@@ -445,14 +515,15 @@ struct Demod {
         if (EDGE) neg = (g == 0u && q >= 2 && q + 1 < W) || (g == 1u && q >= 3);
         else neg = g < 2u;
         if (neg) ch = -ch;
-        ch = sdivm(ch * 50, mA);                                         // :1544-1546
+        ch = O::scale_back(P, ch, mA);                                   // :1544-1546
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
         c0 = c1; c1 = c2; c2 = ct;
         Yo = y0;
         y0 = y1; y1 = y2; y2 = y3; y3 = y4; y4 = yb;
         const int x = q - 5;
         int I, Q;
-        if (x & 1) {
+        const bool odd = PAR < 0 ? (x & 1) != 0 : PAR == 1;
+        if (odd) {
             // odd x (and x = -1): fetch the even sample at x+1, interpolate (:1549-1561)
             const bool m = EDGE ? (x + 1 + (int)xi + 1) < W : true;
             ie_next = m ? -sel4(xi, w1, w2, w3, w4) : 0;
@@ -493,7 +564,7 @@ struct DecConst {
 };
 
 // One pipeline step at stream position t.  Returns true when a pixel for x = *xo was produced.
-template <bool VHS, bool COMPOUT, bool EDGE>
+template <bool VHS, bool COMPOUT, bool EDGE, class O, int PAR1, int PAR2>
 DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *ring, int t,
                   int pc, int pl, uint32_t &px, int &xo_out)
 {
@@ -501,18 +572,18 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     const int lane = C.lane;
     // ================= Y/C separation #1 at x1 = t - 7 (:1716, amplitude_back)
     int Y, U, V;
-    S.D1.template push<EDGE>(pc, t, C.xi, W, C.xe, P.m_amp_back, P.nocolor != 0, Y, U, V);
+    S.D1.template push<EDGE, O, PAR1>(P, pc, t, C.xi, W, C.xe, P.m_amp_back, O::nocolor(P), Y, U, V);
     const int x1 = t - 7;
     const bool in1 = EDGE ? (x1 >= 0 && x1 < W) : true;
     if (in1) {
         // chroma noise :1719-1735
-        if (P.cnoise_k) {
+        if (O::cnoise(P)) {
             U += S.nU; V += S.nV;
             S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
             S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
         }
         // chroma phase noise :1748-1762
-        if (P.pnoise_k) {
+        if (O::pnoise(P)) {
             const double u = U, v = V;
             const double u_ = (u * C.cosv) - (v * C.sinv);
             const double v_ = (u * C.sinv) + (v * C.cosv);
@@ -535,7 +606,7 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         x2 = x1 - d;
         // ---- luma path at x2: box (or pass-through) -> low-pass + emphasis -> sharpen
         const int lc = pl;                 // cs(x2 + 2)
-        const int yb = P.nocolor ? S.l1 : sdiv4(S.l0 + S.l1 + S.l2 + lc);
+        const int yb = O::nocolor(P) ? S.l1 : sdiv4(S.l0 + S.l1 + S.l2 + lc);
         S.l0 = S.l1; S.l1 = S.l2; S.l2 = lc;
         const bool in2 = EDGE ? (x2 >= 0 && x2 < W) : true;
         if (in2) {
@@ -572,11 +643,11 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         int c2 = 0;
         if (!EDGE || (x2 >= 0 && x2 < W)) {
             const unsigned s = (C.xi + (unsigned)x2) & 3u;
-            int chroma = ((s & 1u) ? V : U) * P.amp;
-            if (s & 2u) chroma = -chroma;
-            c2 = Y + chroma / 50;
+            int chroma = O::modulate(P, (s & 1u) ? V : U);      // (v*amp)/50, sign applied after:
+            if (s & 2u) chroma = -chroma;                        // truncation is symmetric
+            c2 = Y + chroma;
         }
-        S.D2.template push<EDGE>(c2, x2, C.xi, W, C.xe, P.m_amp, false, Y, U, V);
+        S.D2.template push<EDGE, O, PAR2>(P, c2, x2, C.xi, W, C.xe, P.m_amp, false, Y, U, V);
         x3 = x2 - 7;
     }
     const int SKO = C.SKO;
@@ -589,9 +660,10 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     for (int q = 0; q < 4; q++) { S.Yd[q] = S.Yd[q + 1]; S.Ur[q] = S.Ur[q + 1]; S.Vr[q] = S.Vr[q + 1]; }
     S.Yd[4] = Y; S.Ur[4] = U; S.Vr[4] = V;
     int fU = 0, fV = 0;
-    if (P.out_lp && in3) {
-        const double a_u = P.out_lp == 1 ? P.a_tv : P.a_in_i;
-        const double a_v = P.out_lp == 1 ? P.a_tv : P.a_in_q;
+    const int out_lp = O::outlp(P);
+    if (out_lp && in3) {
+        const double a_u = out_lp == 1 ? P.a_tv : P.a_in_i;
+        const double a_v = out_lp == 1 ? P.a_tv : P.a_in_q;
         fU = (int)S.oU.push((double)U, a_u);
         fV = (int)S.oV.push((double)V, a_v);
     }
@@ -601,7 +673,7 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     // (static selects instead of Yd[4 - SKO]: dynamic register indexing would go to scratch)
     const int Yo = SKO == 0 ? S.Yd[4] : (SKO == 1 ? S.Yd[3] : S.Yd[0]);
     int Uo, Vo;
-    if (P.out_lp == 0) { Uo = U; Vo = V; }
+    if (out_lp == 0) { Uo = U; Vo = V; }
     else {
         // U value for xo was produced dI steps after xo entered, V value dQ steps after
         const int Uraw = SKO == 1 ? S.Ur[3] : S.Ur[0];
@@ -622,8 +694,131 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     return true;
 }
 
-template <bool VHS, bool COMPOUT>
-__global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
+// dec_step for unrolled iteration j of the steady loop (j is a compile-time constant after
+// unrolling, so the switch folds away)
+template <bool VHS, bool COMPOUT, class O, int TP>
+DEV bool dec_step_j(const DevParams &P, DecState &S, const DecConst &C, uint32_t *ring, int t,
+                    int j, int pc, int pl, uint32_t &px, int &xo)
+{
+    if (TP < 0) return dec_step<VHS, COMPOUT, false, O, -1, -1>(P, S, C, ring, t + j, pc, pl, px, xo);
+    // PAR1 = (TP + j + 1) & 1, PAR2 = (j + 1) & 1
+    if (((TP + j + 1) & 1) == 0) {
+        if (((j + 1) & 1) == 0) return dec_step<VHS, COMPOUT, false, O, 0, 0>(P, S, C, ring, t + j, pc, pl, px, xo);
+        return dec_step<VHS, COMPOUT, false, O, 0, 1>(P, S, C, ring, t + j, pc, pl, px, xo);
+    }
+    if (((j + 1) & 1) == 0) return dec_step<VHS, COMPOUT, false, O, 1, 0>(P, S, C, ring, t + j, pc, pl, px, xo);
+    return dec_step<VHS, COMPOUT, false, O, 1, 1>(P, S, C, ring, t + j, pc, pl, px, xo);
+}
+
+// run-time constants of one lane's decode
+struct DecRun {
+    const int *cbase;
+    uint32_t *drow;
+    uint32_t *ostage;
+    bool is_out, any_hs;
+    int hs, tw, SKT, LOFF;
+};
+
+// Steady-state loop of k_decode.  TP = parity of the pipeline depth SKT (-1: unknown).  With the
+// preset options (output low-pass delay 1) position parities are: first demodulator x1 = t - 7
+// -> (TP + j + 1) & 1; second demodulator x = t - 14 - d with d = SKT - 15 -> (j + 1) & 1.
+template <bool VHS, bool COMPOUT, class O, int TP>
+DEV int dec_steady(const DevParams &P, DecState &S, const DecConst &C, const DecRun &Rn,
+                   uint32_t *ring, int t)
+{
+    const int W = C.W;
+    const int lane = C.lane;
+    const int *cbase = Rn.cbase;
+    uint32_t *drow = Rn.drow;
+    uint32_t *ostage = Rn.ostage;
+    const bool is_out = Rn.is_out, any_hs = Rn.any_hs;
+    const int hs = Rn.hs, tw = Rn.tw, SKT = Rn.SKT, LOFF = Rn.LOFF;
+    auto cs = [&](int x) -> int {
+        if (x < 0 || x >= W) return 0;
+        int idx = x;
+        if (hs != 0) {
+            idx = x + hs;
+            if (idx < 0) idx += tw; else if (idx >= tw) idx -= tw;
+            if (idx >= W) return 0;
+        }
+        return cbase[(size_t)idx * P.Rpad];
+    };
+    {
+        int pc[4], pl[4];
+        const int t_end = W - 16;
+        if (t + 4 <= t_end) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j] = cs(t + j); pl[j] = VHS ? cs(t + j - LOFF) : 0; }
+        }
+        for (; t + 4 <= t_end; t += 4) {
+            int nc[4], nl[4];
+            if (any_hs) {
+                // some row of this wave is displaced by the head switch: per-lane index remap,
+                // branch-free (x is inside the row here; |hs| < tw/2 so one wrap suffices)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int i0 = t + 4 + j + hs;
+                    i0 += (i0 >> 31) & tw;
+                    i0 -= (i0 >= tw) ? tw : 0;
+                    const int v0 = cbase[(size_t)(i0 < W ? i0 : W - 1) * P.Rpad];
+                    nc[j] = i0 < W ? v0 : 0;
+                    if (VHS) {
+                        int i1 = t + 4 + j - LOFF + hs;
+                        i1 += (i1 >> 31) & tw;
+                        i1 -= (i1 >= tw) ? tw : 0;
+                        const int v1 = cbase[(size_t)(i1 < W ? i1 : W - 1) * P.Rpad];
+                        nl[j] = i1 < W ? v1 : 0;
+                    } else nl[j] = 0;
+                }
+            } else {
+                // t + 7 < W and t + 4 - LOFF >= 0: plain coalesced loads
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    nc[j] = cbase[(size_t)(t + 4 + j) * P.Rpad];
+                    nl[j] = VHS ? cbase[(size_t)(t + 4 + j - LOFF) * P.Rpad] : 0;
+                }
+            }
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int xo;
+                (void)dec_step_j<VHS, COMPOUT, O, TP>(P, S, C, ring, t, j, pc[j], pl[j], o[j], xo);
+                // keep the scheduler from interleaving whole pipeline steps: one step already has
+                // ~10 independent filter chains, and mixing four of them costs >70 extra VGPRs
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // stage 4 pixels; every 4th iteration write the lane's 16 pixels as one 64-byte burst
+            {
+                const int xo0 = t - SKT;                   // multiple of 4
+                const int sub = (xo0 >> 2) & 3;
+                if (P.dst_al16) {
+                    *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) =
+                        make_uint4(o[0], o[1], o[2], o[3]);
+                    if (sub == 3 && is_out) {
+                        const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
+                        uint4 *dp = reinterpret_cast<uint4 *>(drow + (xo0 - 12));
+                        const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
+                        dp[0] = a; dp[1] = b; dp[2] = c4; dp[3] = d4;
+                    }
+                } else if (is_out) {
+                    drow[xo0] = o[0]; drow[xo0 + 1] = o[1]; drow[xo0 + 2] = o[2]; drow[xo0 + 3] = o[3];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
+        }
+        // pixels still staged when the steady loop ends (fewer than 16)
+        if (P.dst_al16 && is_out) {
+            const int xo_end = t - SKT;                    // first pixel not produced yet
+            const int xb = xo_end & ~15;
+            for (int q = xb; q < xo_end; q++) drow[q] = ostage[lane * 20 + (q - xb)];
+        }
+    }
+    return t;
+}
+
+template <bool VHS, bool COMPOUT, unsigned F>
+__global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
                                                const FieldDev *__restrict__ fields,
                                                const int *__restrict__ comp,
                                                const uint32_t *__restrict__ rs_chroma,
@@ -635,6 +830,8 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
                                                int *__restrict__ tails)
 {
     __shared__ uint32_t ring[31 * 64];
+    // output staging: 16 pixels per lane, row stride 20 dwords (16-byte aligned, b128 accesses)
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
 
     const int lane = threadIdx.x;
     // 63 output rows per wave; lane 0 recomputes the row above (halo for the vertical blend)
@@ -662,13 +859,14 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
     C.k = k;
     C.lane = lane;
     C.d = VHS ? P.cdelay : 0;            // VHS chroma delay (9/12/14)
-    C.dI = P.out_lp == 2 ? 2 : (P.out_lp == 1 ? 1 : 0);
-    C.dQ = P.out_lp == 2 ? 4 : (P.out_lp == 1 ? 1 : 0);
+    using O = Opt<F>;
+    C.dI = O::outlp(P) == 2 ? 2 : (O::outlp(P) == 1 ? 1 : 0);
+    C.dQ = O::outlp(P) == 2 ? 4 : (O::outlp(P) == 1 ? 1 : 0);
     C.SKO = C.dQ;                        // output low-pass look-ahead
     C.vb = VHS && P.vblend && P.ntsc;
     C.drop = P.loss ? dropout[rc] != 0 : false;
     C.cosv = 1; C.sinv = 0;
-    if (P.pnoise_k) {
+    if (O::pnoise(P)) {
         const int n = pn_noise[rc] + P.pnoise_k;
         C.cosv = G.ptab[2 * n]; C.sinv = G.ptab[2 * n + 1];
     }
@@ -685,7 +883,7 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
     for (int q = 0; q < 5; q++) { S.Yd[q] = 0; S.Ur[q] = 0; S.Vr[q] = 0; }
     S.Uf[0] = S.Uf[1] = S.Uf[2] = 0;
     S.nU = S.nV = 0;
-    if (P.cnoise_k) {
+    if (O::cnoise(P)) {
         S.rng.init(ring, rs_chroma + rc, P.Rpad, lane);
         S.nU = n0_u[rc]; S.nV = n0_v[rc];
     }
@@ -713,55 +911,23 @@ __global__ __launch_bounds__(64) void k_decode(DevParams P, GeomDev G,
     // ---------------- prologue: fill the pipeline (guarded steps)
     for (; t < SKT && t < total; t++) {
         uint32_t px; int xo;
-        (void)dec_step<VHS, COMPOUT, true>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo);
+        (void)dec_step<VHS, COMPOUT, true, O, -1, -1>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo);
     }
     // ---------------- steady state: every stage is strictly inside the row, 4 pixels per
-    // iteration, one 16-byte store per lane.  Ends 16 samples before the row end.
+    // iteration; ends 16 samples before the row end.  The PRESET kernels know the parity of every
+    // demodulator position at compile time (one loop per parity of the pipeline depth).
     {
-        int pc[4], pl[4];
-        const int t_end = W - 16;
-        if (t + 4 <= t_end) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { pc[j] = cs(t + j); pl[j] = VHS ? cs(t + j - LOFF) : 0; }
-        }
-        for (; t + 4 <= t_end; t += 4) {
-            int nc[4], nl[4];
-            if (any_hs) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    nc[j] = cs(t + 4 + j);
-                    nl[j] = VHS ? cs(t + 4 + j - LOFF) : 0;
-                }
-            } else {
-                // t + 7 < W and t + 4 - LOFF >= 0: plain coalesced loads
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    nc[j] = cbase[(size_t)(t + 4 + j) * P.Rpad];
-                    nl[j] = VHS ? cbase[(size_t)(t + 4 + j - LOFF) * P.Rpad] : 0;
-                }
-            }
-            uint32_t o[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                int xo;
-                (void)dec_step<VHS, COMPOUT, false>(P, S, C, ring, t + j, pc[j], pl[j], o[j], xo);
-            }
-            if (is_out) {
-                const int xo0 = t - SKT;                   // multiple of 4
-                if (P.dst_al16) {
-                    *reinterpret_cast<uint4 *>(drow + xo0) = make_uint4(o[0], o[1], o[2], o[3]);
-                } else {
-                    drow[xo0] = o[0]; drow[xo0 + 1] = o[1]; drow[xo0 + 2] = o[2]; drow[xo0 + 3] = o[3];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
-        }
+        DecRun Rn;
+        Rn.cbase = cbase; Rn.drow = drow; Rn.ostage = ostage; Rn.is_out = is_out; Rn.hs = hs;
+        Rn.tw = tw; Rn.SKT = SKT; Rn.LOFF = LOFF; Rn.any_hs = any_hs;
+        if (O::generic) t = dec_steady<VHS, COMPOUT, O, -1>(P, S, C, Rn, ring, t);
+        else if (SKT & 1) t = dec_steady<VHS, COMPOUT, O, 1>(P, S, C, Rn, ring, t);
+        else t = dec_steady<VHS, COMPOUT, O, 0>(P, S, C, Rn, ring, t);
     }
     // ---------------- epilogue: row end, filter tails, pipeline drain (guarded steps)
     for (; t < total; t++) {
         uint32_t px; int xo;
-        if (dec_step<VHS, COMPOUT, true>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
+        if (dec_step<VHS, COMPOUT, true, O, -1, -1>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
             if (is_out) drow[xo] = px;
     }
 }

@@ -95,6 +95,7 @@ struct ntscsim_ctx {
     struct EvSet { hipEvent_t e[5]; };
     std::vector<EvSet> ev_live, ev_free;
     int warm_override[2] = {0, 0};
+    bool force_generic = false;
 };
 
 #define HIPCHK(ctx, call)                                                              \
@@ -339,6 +340,11 @@ extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4], int *n_ca
     return NTSCSIM_OK;
 }
 
+extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
+{
+    if (c) c->force_generic = on != 0;
+}
+
 extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chroma_draws)
 {
     if (!c) return;
@@ -453,23 +459,34 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
                            c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
     if (prof) HIPCHK(c, hipEventRecord(evs.e[1], st));
-    hipLaunchKernelGGL(k_encode, dim3((D.R + 63) / 64), dim3(64), 0, st, D, c->fields.p,
-                       c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    // PRESET kernels (options folded at compile time) when the parameters match the default
+    // preset or the full -vhs preset exactly; otherwise the GENERIC kernels.  Same results.
+    const bool enc_preset = !c->force_generic && D.in_lp && !D.pre_on && D.noise_k != 0 && D.amp == 50;
+    if (enc_preset)
+        hipLaunchKernelGGL((k_encode<F_LNOISE>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    else
+        hipLaunchKernelGGL((k_encode<F_GENERIC>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->comp.p);
     if (prof) HIPCHK(c, hipEventRecord(evs.e[2], st));
     const dim3 dgrid((D.R + 62) / 63);
     if (D.vhs) HIPCHK(c, c->tails.ensure((size_t)32 * 64 * dgrid.x));
-    if (!D.vhs)
-        hipLaunchKernelGGL((k_decode<false, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
-                           c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p, c->tails.p);
-    else if (D.svideo)
-        hipLaunchKernelGGL((k_decode<true, false>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
-                           c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p, c->tails.p);
-    else
-        hipLaunchKernelGGL((k_decode<true, true>), dgrid, dim3(64), 0, st, D, G, c->fields.p,
-                           c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p, c->tails.p);
+    const bool dec_common = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50 &&
+                            D.amp_back == 50;
+#define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
+    hipLaunchKernelGGL((k_decode<VHS, CO, F>), dgrid, dim3(64), 0, st, D, G, c->fields.p,        \
+                       c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,           \
+                       c->pn_noise.p, c->dropout.p, c->tails.p)
+    if (!D.vhs) {
+        if (dec_common && !D.cnoise_k && !D.pnoise_k) NTSC_LAUNCH_DECODE(false, false, 0u);
+        else NTSC_LAUNCH_DECODE(false, false, F_GENERIC);
+    } else if (D.svideo) {
+        NTSC_LAUNCH_DECODE(true, false, F_GENERIC);
+    } else {
+        if (dec_common && D.cnoise_k && D.pnoise_k) NTSC_LAUNCH_DECODE(true, true, (F_CNOISE | F_PNOISE));
+        else NTSC_LAUNCH_DECODE(true, true, F_GENERIC);
+    }
+#undef NTSC_LAUNCH_DECODE
     if (prof) HIPCHK(c, hipEventRecord(evs.e[3], st));
     if (any_bob)
         hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, c->fields.p);

@@ -131,6 +131,9 @@ class FieldSimulator:
         return {"setup": out[0], "encode": out[1], "decode": out[2], "total": out[3],
                 "calls": n.value}
 
+    def debug_force_generic(self, on=True):
+        self._lib.ntscsim_debug_force_generic(self._h, 1 if on else 0)
+
     def debug_set_warmup(self, luma_draws, chroma_draws):
         self._lib.ntscsim_debug_set_warmup(self._h, int(luma_draws), int(chroma_draws))
 

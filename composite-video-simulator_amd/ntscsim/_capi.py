@@ -23,6 +23,7 @@ EXPORTS = (
     "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_fields_device",
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
+    "ntscsim_debug_force_generic",
 )
 
 
@@ -133,6 +134,8 @@ def lib():
     L.ntscsim_debug_read_composite.restype = C.c_int
     L.ntscsim_debug_set_warmup.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ntscsim_debug_set_warmup.restype = None
+    L.ntscsim_debug_force_generic.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_debug_force_generic.restype = None
     _lib = L
     return L
 

@@ -217,6 +217,10 @@ int ntscsim_debug_read_composite(ntscsim_ctx *ctx, int32_t *out, size_t out_elem
  * that the exact serial-replay fallback is exercised.  Results must not change. */
 void ntscsim_debug_set_warmup(ntscsim_ctx *ctx, int luma_draws, int chroma_draws);
 
+/* Test hook: always launch the GENERIC kernels (options read at run time) instead of the PRESET
+ * specialisations chosen for the default / -vhs parameter sets.  Results must not change. */
+void ntscsim_debug_force_generic(ntscsim_ctx *ctx, int on);
+
 #ifdef __cplusplus
 }
 #endif

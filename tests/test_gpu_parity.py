@@ -236,6 +236,27 @@ def test_warmup_fallback_path_is_exact():
     assert np.array_equal(ref, exp) and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("flags,w,h", [([], 96, 32), (["-vhs"], 96, 32), (["-vhs"], 720, 486),
+                                       (["-vhs", "-vhs-speed", "lp"], 100, 33)])
+def test_preset_and_generic_kernels_agree(flags, w, h):
+    """The compile-time specialised kernels and the run-time-option kernels are the same function."""
+    n = 4
+    p = L.make_params(flags)
+    srcs = [L.noise_frame(w, h, 31 + j) for j in range(2)]
+    jobs = cases.case_jobs(n)
+    a = run_hip(p, srcs, jobs, h, w, per_field_dst=True)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.debug_force_generic(True)
+    b = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+    sim.close()
+    assert np.array_equal(a, b)
+    o = L.OracleStream(p)
+    e = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(e[k], srcs[si], field, fieldno)
+    assert np.array_equal(a, e)
+
+
 def test_bob_line_doubling():
     w, h = 96, 32
     for hh in (h, h + 1):
