@@ -353,17 +353,12 @@ extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chr
     c->geom.valid = false;
 }
 
-extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n,
-                                     int W, int H, void *hip_stream)
+// ---- step 1: descriptors -> device records.  The rand() window of every field is computed on
+// the host (one 31x31 multiply-accumulate per consecutive field).
+static int prepare_records(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n, int W, int H,
+                           DevParams &D, FieldDev *fh, bool &any_bob)
 {
-    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
-    if (n == 0) return NTSCSIM_OK;
-    if (n < 0) return NTSCSIM_E_ARG;
     if (W < 16 || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
-
-    DevParams D;
     fill_dev_params(c->prm, D);
     if (c->warm_override[0] > 0) D.warm_luma = c->warm_override[0];
     if (c->warm_override[1] > 0) D.warm_chroma = c->warm_override[1];
@@ -374,29 +369,14 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     if (R > (1ll << 30)) return NTSCSIM_E_SIZE;
     D.R = (int)R;
     D.Rpad = (int)(((R + 63) / 64) * 64 + 64);
-    if ((long long)D.Rpad * W > (1ll << 31) - 1) {
-        // comp is indexed with size_t, but keep the plane under 8 GiB per batch
-        if ((long long)D.Rpad * W > (1ll << 31)) return NTSCSIM_E_SIZE;
-    }
+    if ((long long)D.Rpad * W > (1ll << 31)) return NTSCSIM_E_SIZE;   // keep comp under 8 GiB
 
     int rc = build_geometry(c, W, H, D);
     if (rc != NTSCSIM_OK) return rc;
     if (D.pnoise_k) { rc = build_ptab(c); if (rc != NTSCSIM_OK) return rc; }
 
-    // ---- descriptors -> device records (rand() state per field on the host: one 31x31
-    //      multiply-accumulate per consecutive field)
-    const int si = c->stage_idx;
-    c->stage_idx ^= 1;
-    if (c->stage_used[si]) HIPCHK(c, hipEventSynchronize(c->stage_ev[si]));
-    if (c->stage_cap[si] < (size_t)n) {
-        if (c->stage[si]) (void)hipHostFree(c->stage[si]);
-        c->stage[si] = nullptr; c->stage_cap[si] = 0;
-        const size_t want = (size_t)n + (size_t)n / 4 + 16;
-        HIPCHK(c, hipHostMalloc((void **)&c->stage[si], want * sizeof(FieldDev), hipHostMallocDefault));
-        c->stage_cap[si] = want;
-    }
-    FieldDev *fh = c->stage[si];
-    bool al_src = true, al_dst = true, any_bob = false;
+    bool al_src = true, al_dst = true;
+    any_bob = false;
     uint64_t pos = c->rng_pos;
     for (int i = 0; i < n; i++) {
         const ntscsim_field_desc &d = descs[i];
@@ -421,9 +401,18 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     }
     c->rng_pos = pos;
     D.src_al16 = al_src; D.dst_al16 = al_dst;
+    return NTSCSIM_OK;
+}
 
-    // ---- scratch
-    HIPCHK(c, c->fields.ensure((size_t)n));
+// ---- step 2: scratch + the kernel chain over device-resident records
+static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fields_dev,
+                          bool any_bob, hipStream_t st, const ntscsim_ctx::EvSet *evs)
+{
+    const int n = D.nfields, W = D.W, H = D.H;
+    // (no-ops unless another geometry was used on this ctx since the records were prepared)
+    int grc = build_geometry(c, W, H, D);
+    if (grc != NTSCSIM_OK) return grc;
+    if (D.pnoise_k) { grc = build_ptab(c); if (grc != NTSCSIM_OK) return grc; }
     HIPCHK(c, c->comp.ensure((size_t)D.Rpad * W));
     if (D.hs) HIPCHK(c, c->hs_shift.ensure((size_t)D.R));
     if (D.pnoise_k) HIPCHK(c, c->pn_noise.ensure((size_t)D.R));
@@ -434,47 +423,36 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         HIPCHK(c, c->n0_u.ensure((size_t)D.Rpad));
         HIPCHK(c, c->n0_v.ensure((size_t)D.Rpad));
     }
+    const dim3 dgrid((D.R + 62) / 63);
+    if (D.vhs) HIPCHK(c, c->tails.ensure((size_t)32 * 64 * dgrid.x));
 
     GeomDev G;
     G.lskip = c->geom.lskip.p; G.pskip = c->geom.pskip.p; G.jrow = c->geom.jrow.p;
     G.jwarm = c->geom.jwarm.p; G.sstart = c->geom.sstart.p; G.ptab = c->ptab.p;
 
-    const bool prof = c->profiling;
-    ntscsim_ctx::EvSet evs;
-    if (prof) {
-        if (!c->ev_free.empty()) { evs = c->ev_free.back(); c->ev_free.pop_back(); }
-        else for (int i = 0; i < 5; i++) HIPCHK(c, hipEventCreate(&evs.e[i]));
-        HIPCHK(c, hipEventRecord(evs.e[0], st));
-    }
-    HIPCHK(c, hipMemcpyAsync(c->fields.p, fh, (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
-    c->stage_used[si] = true;
     if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
-
     if (D.hs || D.pnoise_k || D.loss)
-        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, c->fields.p,
+        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p);
     if (D.noise_k || D.cnoise_k)
         hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
-                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
+                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
-    if (prof) HIPCHK(c, hipEventRecord(evs.e[1], st));
+    if (evs) HIPCHK(c, hipEventRecord(evs->e[1], st));
     // PRESET kernels (options folded at compile time) when the parameters match the default
     // preset or the full -vhs preset exactly; otherwise the GENERIC kernels.  Same results.
     const bool enc_preset = !c->force_generic && D.in_lp && !D.pre_on && D.noise_k != 0 && D.amp == 50;
     if (enc_preset)
         hipLaunchKernelGGL((k_encode<F_LNOISE>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
-                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
     else
         hipLaunchKernelGGL((k_encode<F_GENERIC>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
-                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->comp.p);
-    if (prof) HIPCHK(c, hipEventRecord(evs.e[2], st));
-    const dim3 dgrid((D.R + 62) / 63);
-    if (D.vhs) HIPCHK(c, c->tails.ensure((size_t)32 * 64 * dgrid.x));
+                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    if (evs) HIPCHK(c, hipEventRecord(evs->e[2], st));
     const bool dec_common = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50 &&
                             D.amp_back == 50;
 #define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
-    hipLaunchKernelGGL((k_decode<VHS, CO, F>), dgrid, dim3(64), 0, st, D, G, c->fields.p,        \
+    hipLaunchKernelGGL((k_decode<VHS, CO, F>), dgrid, dim3(64), 0, st, D, G, fields_dev,         \
                        c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,           \
                        c->pn_noise.p, c->dropout.p, c->tails.p)
     if (!D.vhs) {
@@ -487,14 +465,126 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         else NTSC_LAUNCH_DECODE(true, true, F_GENERIC);
     }
 #undef NTSC_LAUNCH_DECODE
-    if (prof) HIPCHK(c, hipEventRecord(evs.e[3], st));
+    if (evs) HIPCHK(c, hipEventRecord(evs->e[3], st));
     if (any_bob)
-        hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, c->fields.p);
-    if (prof) { HIPCHK(c, hipEventRecord(evs.e[4], st)); c->ev_live.push_back(evs); }
+        hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, fields_dev);
+    if (evs) HIPCHK(c, hipEventRecord(evs->e[4], st));
     HIPCHK(c, hipGetLastError());
-
     c->last_n = n; c->last_W = W; c->last_H = H; c->last_Rpad = D.Rpad; c->last_Lslot = D.Lslot;
     return NTSCSIM_OK;
+}
+
+static int take_events(ntscsim_ctx *c, ntscsim_ctx::EvSet &evs)
+{
+    if (!c->ev_free.empty()) { evs = c->ev_free.back(); c->ev_free.pop_back(); }
+    else for (int i = 0; i < 5; i++) HIPCHK(c, hipEventCreate(&evs.e[i]));
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n,
+                                     int W, int H, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0) return NTSCSIM_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+
+    // pinned staging for the records, double-buffered against the asynchronous upload
+    const int si = c->stage_idx;
+    c->stage_idx ^= 1;
+    if (c->stage_used[si]) HIPCHK(c, hipEventSynchronize(c->stage_ev[si]));
+    if (c->stage_cap[si] < (size_t)n) {
+        if (c->stage[si]) (void)hipHostFree(c->stage[si]);
+        c->stage[si] = nullptr; c->stage_cap[si] = 0;
+        const size_t want = (size_t)n + (size_t)n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->stage[si], want * sizeof(FieldDev), hipHostMallocDefault));
+        c->stage_cap[si] = want;
+    }
+    DevParams D;
+    bool any_bob = false;
+    int rc = prepare_records(c, descs, n, W, H, D, c->stage[si], any_bob);
+    if (rc != NTSCSIM_OK) return rc;
+    HIPCHK(c, c->fields.ensure((size_t)n));
+
+    ntscsim_ctx::EvSet evs;
+    const bool prof = c->profiling;
+    if (prof) {
+        rc = take_events(c, evs);
+        if (rc != NTSCSIM_OK) return rc;
+        HIPCHK(c, hipEventRecord(evs.e[0], st));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->fields.p, c->stage[si], (size_t)n * sizeof(FieldDev),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
+    c->stage_used[si] = true;
+    rc = launch_records(c, D, c->fields.p, any_bob, st, prof ? &evs : nullptr);
+    if (rc != NTSCSIM_OK) return rc;
+    if (prof) c->ev_live.push_back(evs);
+    return NTSCSIM_OK;
+}
+
+// ---- prepared batches: validate + derive + upload once, launch many times ------------------
+struct ntscsim_batch {
+    ntscsim_ctx *ctx;
+    DevParams D;
+    DevBuf<FieldDev> records;
+    bool any_bob;
+    uint64_t rng_end;
+};
+
+extern "C" int ntscsim_batch_create(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n, int W,
+                                    int H, ntscsim_batch **out)
+{
+    if (!c || !descs || !out || n <= 0) return NTSCSIM_E_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FieldDev> host((size_t)n);
+    ntscsim_batch *b = new (std::nothrow) ntscsim_batch();
+    if (!b) return NTSCSIM_E_NOMEM;
+    b->ctx = c;
+    int rc = prepare_records(c, descs, n, W, H, b->D, host.data(), b->any_bob);
+    if (rc != NTSCSIM_OK) { delete b; return rc; }
+    b->rng_end = c->rng_pos;
+    if (b->records.ensure((size_t)n) != hipSuccess ||
+        hipMemcpy(b->records.p, host.data(), (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice) !=
+            hipSuccess) {
+        b->records.release();
+        delete b;
+        c->err = "ntscsim_batch_create: device allocation / upload failed";
+        return NTSCSIM_E_HIP;
+    }
+    *out = b;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_batch_run(ntscsim_batch *b, void *hip_stream)
+{
+    if (!b) return NTSCSIM_E_ARG;
+    ntscsim_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    ntscsim_ctx::EvSet evs;
+    const bool prof = c->profiling;
+    if (prof) {
+        int rc = take_events(c, evs);
+        if (rc != NTSCSIM_OK) return rc;
+        HIPCHK(c, hipEventRecord(evs.e[0], st));
+    }
+    int rc = launch_records(c, b->D, b->records.p, b->any_bob, st, prof ? &evs : nullptr);
+    if (rc != NTSCSIM_OK) return rc;
+    if (prof) c->ev_live.push_back(evs);
+    c->rng_pos = b->rng_end;
+    return NTSCSIM_OK;
+}
+
+extern "C" void ntscsim_batch_destroy(ntscsim_batch *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipDeviceSynchronize();
+    b->records.release();
+    delete b;
 }
 
 extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int src_interlaced,

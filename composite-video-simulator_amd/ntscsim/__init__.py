@@ -111,6 +111,23 @@ class FieldSimulator:
                                              C.c_void_p(stream))
         self._chk(rc, "ntscsim_fields_device")
 
+    def prepare(self, descs, width, height):
+        """Prepared batch (ntscsim_batch_create): returns a handle for run_prepared()."""
+        h = C.c_void_p()
+        rc = self._lib.ntscsim_batch_create(self._h, descs, len(descs), int(width), int(height),
+                                            C.byref(h))
+        self._chk(rc, "ntscsim_batch_create")
+        return h
+
+    def run_prepared(self, batch, stream=None):
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._chk(self._lib.ntscsim_batch_run(batch, C.c_void_p(stream)), "ntscsim_batch_run")
+
+    def free_prepared(self, batch):
+        self._lib.ntscsim_batch_destroy(batch)
+
     def fields(self, src, dst, jobs, **kw):
         descs = self.build_descs(src, dst, jobs, **kw)
         self.run_descs(descs, src.shape[2], src.shape[1])

@@ -21,6 +21,7 @@ EXPORTS = (
     "ntscsim_params_validate", "ntscsim_rng_calls_per_field", "ntscsim_rng_draw",
     "ntscsim_create", "ntscsim_destroy", "ntscsim_strerror", "ntscsim_last_error",
     "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_fields_device",
+    "ntscsim_batch_create", "ntscsim_batch_run", "ntscsim_batch_destroy",
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
     "ntscsim_debug_force_generic",
@@ -124,6 +125,13 @@ def lib():
     L.ntscsim_fields_device.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]
     L.ntscsim_fields_device.restype = C.c_int
+    L.ntscsim_batch_create.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p)]
+    L.ntscsim_batch_create.restype = C.c_int
+    L.ntscsim_batch_run.argtypes = [C.c_void_p, C.c_void_p]
+    L.ntscsim_batch_run.restype = C.c_int
+    L.ntscsim_batch_destroy.argtypes = [C.c_void_p]
+    L.ntscsim_batch_destroy.restype = None
     L.ntscsim_sync.argtypes = [C.c_void_p]
     L.ntscsim_sync.restype = C.c_int
     L.ntscsim_set_profiling.argtypes = [C.c_void_p, C.c_int]

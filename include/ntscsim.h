@@ -197,6 +197,19 @@ typedef struct ntscsim_field_desc {
 int ntscsim_fields_device(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int n,
                           int width, int height, void *hip_stream);
 
+/*
+ * Prepared batch: the same work as ntscsim_fields_device(), split into "validate the descriptors,
+ * derive each field's rand() window, upload the records" (once) and "enqueue the kernel chain"
+ * (any number of times, e.g. a clip that is re-rendered, or a ring of frame buffers that is
+ * refilled in place).  The descriptors' pointers must stay valid.  A batch uses its ctx's scratch:
+ * runs on one ctx are stream-ordered by the caller; use one ctx per stream to overlap batches.
+ */
+typedef struct ntscsim_batch ntscsim_batch;
+int  ntscsim_batch_create(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int n,
+                          int width, int height, ntscsim_batch **out);
+int  ntscsim_batch_run(ntscsim_batch *batch, void *hip_stream);
+void ntscsim_batch_destroy(ntscsim_batch *batch);
+
 /* Block until everything enqueued by this ctx has finished. */
 int ntscsim_sync(ntscsim_ctx *ctx);
 

@@ -217,6 +217,35 @@ def test_bench_clip_checksum_of_checksums():
     sim.close()
 
 
+def test_prepared_batch_equals_direct_call():
+    """ntscsim_batch_create/run: same bytes as ntscsim_fields_device, re-runnable, and two
+    geometries can alternate on one ctx."""
+    torch = torch_mod()
+    p = L.make_params(["-vhs"])
+    sim = ntscsim.FieldSimulator(params=p)
+    outs = {}
+    plans = {}
+    for (w, h) in ((96, 32), (100, 35)):
+        n = 6
+        src = torch.from_numpy(np.stack([L.noise_frame(w, h, 50 + j) for j in range(3)])).cuda()
+        jobs = [(k // 2, k, (k & 1) ^ 1, k) for k in range(n)]
+        pos = [shard.rng_pos_of_field(p, w, h, k) for k in range(n)]
+        a = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        b = torch.zeros_like(a)
+        sim.fields(src, a, jobs, rng_pos=pos)
+        d = sim.build_descs(src, b, jobs, rng_pos=pos)
+        plans[(w, h)] = (sim.prepare(d, w, h), d, src, a, b)
+    for _ in range(2):
+        for key, (pl, d, src, a, b) in plans.items():
+            b.zero_()
+            sim.run_prepared(pl)
+            sim.sync()
+            assert torch.equal(a, b), key
+    for pl, *_ in plans.values():
+        sim.free_prepared(pl)
+    sim.close()
+
+
 def test_warmup_fallback_path_is_exact():
     """Force the noise-accumulator warm-up to be too short so lanes take the serial-replay
     fallback; results must not change."""
