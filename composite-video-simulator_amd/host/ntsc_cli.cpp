@@ -1,0 +1,249 @@
+// ntsc_cli.cpp -- `ffmpeg_ntsc`-compatible command line host for the GPU field simulator.
+//
+// Mirrors the reference's L4 + L2 layers (ffmpeg_ntsc.cpp: parse_argv :972-1282, the field loop
+// of main() :2146-2283) around the C ABI of include/ntscsim.h.  The L3 media layer (libav* 3.x
+// demux/decode/sws_scale/encode, :229-714, :1940-2023) is NOT rebuilt: frames enter and leave as
+// raw BGRA (`ffmpeg -i in.mp4 -vf scale=720:480 -pix_fmt bgra -f rawvideo - | ntsc_cli -i - ...`).
+//
+//   ntsc_cli [reference switches] -i <in.bgra | - | bars:N | noise:N> -o <out.bgra | - | null:>
+//
+// Output: one bob-deinterlaced BGRA frame per FIELD (59.94 Hz for NTSC), exactly what the
+// reference hands to its encoder (:2233-2280).  Field `current` uses source frame current/2,
+// field parity (current&1)^1 and fieldno = current (:2229), the frame-delay ring of `-d` frames
+// (:2070-2092, :2277) is honoured (it only affects the one row bob does not overwrite).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ntscsim.h"
+
+namespace {
+
+void usage(const char *arg0)
+{
+    // same switch list as help() ffmpeg_ntsc.cpp:833-887 (media/audio-only ones are accepted
+    // and ignored where the reference's parser accepts them)
+    std::fprintf(stderr,
+        "%s [options]\n"
+        " -i <raw BGRA file | - | bars:N | noise:N>   (more than one: layered, last one wins)\n"
+        " -o <raw BGRA file | - | null:>\n"
+        " -d <n>                        Video delay buffer (n frames)\n"
+        " -width <n>  -tvstd <pal|ntsc>\n"
+        " -vhs  -vhs-hifi <0|1>  -vhs-speed <ep|lp|sp>  -vhs-svideo <0|1>  -vhs-chroma-vblend <0|1>\n"
+        " -vhs-head-switching <0|1>  -vhs-head-switching-point <x>  -vhs-head-switching-phase <x>\n"
+        " -vhs-head-switching-noise-level <x>\n"
+        " -noise <0..100>  -chroma-noise <0..100>  -chroma-phase-noise <x>  -chroma-dropout <x>\n"
+        " -subcarrier-amp <0...100>  -nocolor-subcarrier  -nocolor-subcarrier-after-yc-sep\n"
+        " -comp-pre <s>  -comp-cut <f>  -comp-catv  -comp-catv2  -comp-catv3  -comp-catv4\n"
+        " -comp-phase <0|90|180|270>  -comp-phase-offset <n>\n"
+        " -in-composite-lowpass <n>  -out-composite-lowpass <n>  -out-composite-lowpass-lite <n>\n"
+        " -yc-recomb <n>  -nocomp  -422  -420\n"
+        " (audio only, accepted: -preemphasis -deemphasis -audio-hiss -vhs-linear-video-crosstalk\n"
+        "  -vhs-linear-high-boost)\n"
+        " extra (not in the reference): --batch <fields per GPU batch, default 256> --height <n>\n",
+        arg0);
+}
+
+struct Source {
+    std::string spec;
+    FILE *fp = nullptr;
+    long synth_frames = -1;   // >= 0: synthetic
+    int synth_kind = 0;       // 0 bars, 1 noise
+    long next = 0;
+};
+
+void make_bars(uint8_t *f, int W, int H, long rot)
+{
+    static const uint32_t table[8] = {0xC0C0C0, 0xC0C000, 0x00C0C0, 0x00C000,
+                                      0xC000C0, 0xC00000, 0x0000C0, 0x000000};
+    for (int y = 0; y < H; y++) {
+        uint32_t *row = reinterpret_cast<uint32_t *>(f + (size_t)y * W * 4);
+        for (int x = 0; x < W; x++) row[x] = table[(8 * (int)((x + rot) % W)) / W];
+    }
+}
+
+void make_noise(uint8_t *f, int W, int H, uint32_t seed)
+{
+    uint32_t s = seed ? seed : 0x1234567u;
+    uint32_t *p = reinterpret_cast<uint32_t *>(f);
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        s ^= s << 13; s ^= s >> 17; s ^= s << 5;
+        p[i] = s & 0xFFFFFFu;
+    }
+}
+
+bool open_source(Source &s)
+{
+    if (!s.spec.compare(0, 5, "bars:")) { s.synth_frames = std::atol(s.spec.c_str() + 5); s.synth_kind = 0; return true; }
+    if (!s.spec.compare(0, 6, "noise:")) { s.synth_frames = std::atol(s.spec.c_str() + 6); s.synth_kind = 1; return true; }
+    if (s.spec == "-") { s.fp = stdin; return true; }
+    s.fp = std::fopen(s.spec.c_str(), "rb");
+    return s.fp != nullptr;
+}
+
+// false at end of input
+bool read_frame(Source &s, uint8_t *dst, int W, int H)
+{
+    if (s.synth_frames >= 0) {
+        if (s.next >= s.synth_frames) return false;
+        if (s.synth_kind == 0) make_bars(dst, W, H, s.next);
+        else make_noise(dst, W, H, 0x1234567u + (uint32_t)s.next);
+        s.next++;
+        return true;
+    }
+    const size_t n = (size_t)W * H * 4;
+    const size_t got = std::fread(dst, 1, n, s.fp);
+    if (got != n) return false;
+    s.next++;
+    return true;
+}
+
+#define HIPOK(call)                                                                         \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            std::fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e__));                \
+            return 1;                                                                       \
+        }                                                                                   \
+    } while (0)
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    // pull out the two switches the reference does not have, pass the rest to the mirror parser
+    int batch_fields = 256, height_override = 0;
+    std::vector<const char *> av;
+    av.push_back(argv[0]);
+    for (int i = 1; i < argc; i++) {
+        if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) { batch_fields = std::atoi(argv[++i]); continue; }
+        if (!std::strcmp(argv[i], "--height") && i + 1 < argc) { height_override = std::atoi(argv[++i]); continue; }
+        av.push_back(argv[i]);
+    }
+    ntscsim_params prm;
+    ntscsim_cli cli;
+    ntscsim_params_init(&prm);          // preset_NTSC(), main() :1924
+    ntscsim_cli_init(&cli);
+    int rc = ntscsim_params_parse_argv(&prm, &cli, (int)av.size(), av.data(), 1);   // :1925
+    if (rc == NTSCSIM_E_HELP) { usage(argv[0]); return 1; }
+    if (rc != NTSCSIM_OK) return 1;
+    if (height_override > 0) prm.output_height = height_override;
+    if (batch_fields < 2) batch_fields = 2;
+    batch_fields &= ~1;
+    const int W = prm.output_width, H = prm.output_height;
+    const size_t fbytes = (size_t)W * H * 4;
+    // as the reference prints after parsing (:1268-1269)
+    std::fprintf(stderr, "VHS head switching point: %.6f\n", prm.vhs_head_switching_phase);
+    std::fprintf(stderr, "VHS head switching noise: %.6f\n", prm.vhs_head_switching_phase_noise);
+
+    std::vector<Source> inputs((size_t)cli.n_inputs);
+    for (int i = 0; i < cli.n_inputs; i++) {
+        inputs[(size_t)i].spec = cli.input_paths[i];
+        if (!open_source(inputs[(size_t)i])) {
+            std::fprintf(stderr, "Failed to open %s\n", cli.input_paths[i]);
+            return 1;
+        }
+    }
+    FILE *out = nullptr;
+    const std::string ospec = cli.output_path;
+    if (ospec == "-") out = stdout;
+    else if (ospec != "null:") {
+        out = std::fopen(ospec.c_str(), "wb");
+        if (!out) { std::fprintf(stderr, "Failed to open %s\n", ospec.c_str()); return 1; }
+    }
+
+    ntscsim_ctx *sim = nullptr;
+    rc = ntscsim_create(&prm, 0, &sim);
+    if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_create: %s\n", ntscsim_strerror(rc)); return 1; }
+
+    const int nframes_batch = batch_fields / 2;
+    uint8_t *d_src = nullptr, *d_dst = nullptr, *h_src = nullptr, *h_dst = nullptr;
+    HIPOK(hipMalloc((void **)&d_src, fbytes * nframes_batch));
+    HIPOK(hipMalloc((void **)&d_dst, fbytes * batch_fields));
+    HIPOK(hipHostMalloc((void **)&h_src, fbytes * nframes_batch, hipHostMallocDefault));
+    HIPOK(hipHostMalloc((void **)&h_dst, fbytes * batch_fields, hipHostMallocDefault));
+    HIPOK(hipMemset(d_dst, 0, fbytes * batch_fields));   // ring frames start zeroed (:2088)
+
+    // frame-delay ring (:2070-2092): only its row H-1 can survive composite_layer + bob
+    const int delay = cli.frame_delay;
+    std::vector<std::vector<uint8_t>> ring_last((size_t)delay, std::vector<uint8_t>((size_t)W * 4, 0));
+    size_t ring_idx = 0;
+
+    std::vector<ntscsim_field_desc> descs((size_t)batch_fields);
+    std::vector<uint8_t> scratch(fbytes);
+    unsigned long long current = 0;     // output field counter (:2140)
+    unsigned long long total_fields = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool eof = false;
+    while (!eof) {
+        // ---- read up to nframes_batch frames from the LAST input (it overwrites the layers
+        //      below it, :2203-2230); lower layers only advance the rand() stream
+        int nf = 0;
+        for (; nf < nframes_batch; nf++) {
+            bool ok = true;
+            for (size_t li = 0; li + 1 < inputs.size(); li++)
+                ok = read_frame(inputs[li], scratch.data(), W, H) && ok;
+            ok = read_frame(inputs.back(), h_src + fbytes * nf, W, H) && ok;
+            if (!ok) { eof = true; break; }
+        }
+        if (nf == 0) break;
+        HIPOK(hipMemcpy(d_src, h_src, fbytes * nf, hipMemcpyHostToDevice));
+        const int nfields = nf * 2;
+        const uint64_t layers = (uint64_t)inputs.size();
+        uint64_t pos = ntscsim_get_rng_pos(sim);
+        for (int k = 0; k < nfields; k++) {
+            const unsigned long long cur = current + (unsigned)k;
+            const unsigned field = (unsigned)((cur & 1) ^ 1);                       // :2229
+            const uint64_t calls = ntscsim_rng_calls_per_field(&prm, W, H, field);
+            pos += calls * (layers - 1);          // draws made by the layers underneath
+            ntscsim_field_desc &d = descs[(size_t)k];
+            std::memset(&d, 0, sizeof(d));
+            d.src_dev = d_src + fbytes * (size_t)(k / 2);
+            d.dst_dev = d_dst + fbytes * (size_t)k;
+            d.src_linesize = W * 4; d.dst_linesize = W * 4;
+            d.field = field;
+            d.flags = NTSCSIM_DESC_BOB;                                             // :2233-2257
+            d.fieldno = cur;
+            d.rng_pos = pos;
+            pos += calls;
+        }
+        rc = ntscsim_fields_device(sim, descs.data(), nfields, W, H, nullptr);
+        if (rc != NTSCSIM_OK) {
+            std::fprintf(stderr, "ntscsim_fields_device: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim));
+            return 1;
+        }
+        rc = ntscsim_sync(sim);
+        if (rc != NTSCSIM_OK) return 1;
+        ntscsim_set_rng_pos(sim, pos);
+        HIPOK(hipMemcpy(h_dst, d_dst, fbytes * nfields, hipMemcpyDeviceToHost));
+        for (int k = 0; k < nfields; k++) {
+            uint8_t *f = h_dst + fbytes * (size_t)k;
+            const unsigned field = descs[(size_t)k].field;
+            uint8_t *last = f + (size_t)(H - 1) * W * 4;
+            // the row neither composite_layer nor bob writes keeps the ring frame's content
+            const bool stale = ((H & 1) == 0 && field == 0) || ((H & 1) == 1 && field == 1);
+            std::vector<uint8_t> &slot = ring_last[ring_idx];
+            if (stale) std::memcpy(last, slot.data(), (size_t)W * 4);
+            std::memcpy(slot.data(), last, (size_t)W * 4);
+            ring_idx = (ring_idx + 1) % (size_t)delay;                              // :2277
+            if (out && std::fwrite(f, 1, fbytes, out) != fbytes) { std::fprintf(stderr, "write failed\n"); return 1; }
+        }
+        // the device frames are reused by the next batch: clear what bob did not overwrite
+        HIPOK(hipMemset(d_dst, 0, fbytes * batch_fields));
+        current += (unsigned)nfields;
+        total_fields += (unsigned)nfields;
+        std::fprintf(stderr, "\rOutput field %llu ", current);                      // :1361
+    }
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "\n%llu fields in %.3f s (%.1f fields/s incl. host I/O)\n", total_fields, dt,
+                 dt > 0 ? total_fields / dt : 0.0);
+    if (out && out != stdout) std::fclose(out);
+    ntscsim_destroy(sim);
+    (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipHostFree(h_src); (void)hipHostFree(h_dst);
+    return 0;
+}
