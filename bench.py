@@ -233,7 +233,9 @@ def main():
                 "path_achieved": alg_bytes_launch / (chain_ms * 1e-3) / 1e9,
                 "kernel_ms_all": {"setup": set_ms, "encode": enc_ms, "decode": dec_ms},
                 "kernel_timing": "hipEvents on the launch stream, %d steps on one context right "
-                                 "after the timed region" % calls,
+                                 "after the timed region (un-shared launches; rocprofv3 of this "
+                                 "command shows them in its Min column, --inflight 1 in its "
+                                 "Average -- profiles/README.md)" % calls,
             },
         }
         if world == 1 and args.cpu_fields > 0:

@@ -807,12 +807,7 @@ DEV int dec_steady(const DevParams &P, DecState &S, const DecConst &C, const Dec
 #pragma unroll
             for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
         }
-        // pixels still staged when the steady loop ends (fewer than 16)
-        if (P.dst_al16 && is_out) {
-            const int xo_end = t - SKT;                    // first pixel not produced yet
-            const int xb = xo_end & ~15;
-            for (int q = xb; q < xo_end; q++) drow[q] = ostage[lane * 20 + (q - xb)];
-        }
+        // (a partly filled 16-pixel group stays staged; the epilogue keeps filling it)
     }
     return t;
 }
@@ -927,8 +922,22 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
     // ---------------- epilogue: row end, filter tails, pipeline drain (guarded steps)
     for (; t < total; t++) {
         uint32_t px; int xo;
-        if (dec_step<VHS, COMPOUT, true, O, -1, -1>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
-            if (is_out) drow[xo] = px;
+        if (!dec_step<VHS, COMPOUT, true, O, -1, -1>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
+            continue;
+        if (!P.dst_al16) { if (is_out) drow[xo] = px; continue; }
+        // same 16-pixel staging as the steady loop: whole 64-byte bursts, then the row's tail
+        ostage[lane * 20 + (xo & 15)] = px;
+        if ((xo & 15) == 15) {
+            if (is_out) {
+                const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
+                uint4 *dp = reinterpret_cast<uint4 *>(drow + (xo - 15));
+                const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
+                dp[0] = a; dp[1] = b; dp[2] = c4; dp[3] = d4;
+            }
+        } else if (xo == W - 1 && is_out) {
+            const int xb = xo & ~15;
+            for (int q = xb; q <= xo; q++) drow[q] = ostage[lane * 20 + (q - xb)];
+        }
     }
 }
 
