@@ -34,6 +34,7 @@ struct DevParams {
     double sharpen;                  // vhs_out_sharpen
     int src_al16, dst_al16;          // all src/dst rows 16-byte aligned
     int warm_luma, warm_chroma;      // warm-up draws used by k_row_states
+    int variant;                     // 0 ffmpeg_ntsc (BGRA), 1 ffmpeg_to_composite (YUV422P)
 };
 
 struct FieldDev {

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
         }
         const double t = P.ntsc ? twidth * 262.5 : twidth * 312.5;
         // fmod(a, 1.0) == a - trunc(a) exactly (params are validated non-negative)
-        double a = P.hs_point + noise;
+        // ffmpeg_ntsc: row from `point`, column from `phase` (:1666-1670);
+        // ffmpeg_to_composite: both from the single `phase` parameter (:691-693)
+        double a = (P.variant ? P.hs_phase : P.hs_point) + noise;
         unsigned pp = (unsigned)((a - trunc(a)) * t);
         int y = (int)((pp / twidth) * 2u) + (int)field;
         a = P.hs_phase + noise;
@@ -274,7 +276,9 @@ __global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
     const int warm = G.jwarm[jidx];
     const int K = stream == 0 ? P.noise_k : P.cnoise_k;
     const Magic31 M = stream == 0 ? P.m_noise : P.m_cnoise;
-    const long long start = stream == 0 ? (long long)k * P.W : 2ll * k * P.W;  // draws before row
+    // draws made before this row: luma 1/pixel; chroma 2/pixel (BGRA path) or 2/chroma sample
+    const long long cpr = P.variant ? 2ll * (P.W / 2) : 2ll * P.W;
+    const long long start = stream == 0 ? (long long)k * P.W : cpr * k;
     const bool exact = (long long)warm == start;   // warm-up reaches the start of the stream
 
     uint32_t st[31];

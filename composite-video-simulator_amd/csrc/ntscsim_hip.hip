@@ -15,6 +15,7 @@
 
 // single translation unit: the kernels are compiled together with their launcher
 #include "ntsc_kernels.hip"
+#include "ntsc422_kernels.hip"
 
 using namespace ntscsim;
 
@@ -46,7 +47,7 @@ struct DevBuf {
 };
 
 struct Geometry {
-    int W = 0, H = 0;
+    int W = 0, H = 0, variant = 0;
     bool valid = false;
     DevBuf<uint32_t> lskip, pskip, jrow, sstart;
     DevBuf<int32_t> jwarm;
@@ -76,6 +77,10 @@ struct ntscsim_ctx {
     // per-batch scratch
     DevBuf<FieldDev> fields;
     DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, tails;
+    DevBuf<Field422Dev> fields422;
+    DevBuf<uint8_t> scratch422;
+    std::vector<FieldDev> host_fields;
+    std::vector<Field422Dev> host_fields422;
     DevBuf<uint32_t> rs_luma, rs_chroma;
     FieldDev *stage[2] = {nullptr, nullptr};
     size_t stage_cap[2] = {0, 0};
@@ -191,29 +196,32 @@ static uint64_t chroma_stream_offset(const ntscsim_params &p, int W, int L)
 static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
 {
     Geometry &g = c->geom;
-    if (g.valid && g.W == W && g.H == H) return NTSCSIM_OK;
+    if (g.valid && g.W == W && g.H == H && g.variant == D.variant) return NTSCSIM_OK;
     g.valid = false;
+    // chroma-noise draws per row: 2 per pixel (BGRA path) / 2 per chroma sample (YUV422P path)
+    const uint64_t cdraws = D.variant ? 2ull * (uint64_t)(W / 2) : 2ull * (uint64_t)W;
     const int Lslot = (H + 1) / 2;
     const int Lp[2] = {(H + 1) / 2, H / 2};
     std::vector<uint32_t> lskip(2 * 31), pskip(2 * 31), sstart(4 * 31), jrow((size_t)4 * Lslot * 31);
     std::vector<int32_t> jwarm((size_t)4 * Lslot);
-    const RandPoly xW = rand_poly_pow((uint64_t)W), x2W = rand_poly_pow(2ull * W);
+    const RandPoly xW = rand_poly_pow((uint64_t)W), x2W = rand_poly_pow(cdraws);
     for (int par = 0; par < 2; par++) {
         // draws before the 4 head-switch draws, and before the per-row phase-noise draws
         const uint64_t off_hs = c->prm.video_noise != 0 ? (uint64_t)W * Lp[par] : 0;
         const uint64_t off_pn = chroma_stream_offset(c->prm, W, Lp[par]) +
-                                (c->prm.video_chroma_noise != 0 ? 2ull * W * Lp[par] : 0);
+                                (c->prm.video_chroma_noise != 0 ? cdraws * Lp[par] : 0);
         const RandPoly a = rand_poly_pow(off_hs);
         const RandPoly b = rand_poly_pow(off_pn);
         std::memcpy(&lskip[par * 31], a.c, sizeof(a.c));
         std::memcpy(&pskip[par * 31], b.c, sizeof(b.c));
-        g.calls[par] = ntscsim_rng_calls_per_field(&c->prm, W, H, (unsigned)par);
+        g.calls[par] = D.variant ? ntscsim_rng_calls_per_field_422(&c->prm, W, H, (unsigned)par)
+                                 : ntscsim_rng_calls_per_field(&c->prm, W, H, (unsigned)par);
         for (int s = 0; s < 2; s++) {
             const uint64_t off = s == 0 ? 0 : chroma_stream_offset(c->prm, W, Lp[par]);
             const RandPoly so = rand_poly_pow(off);
             std::memcpy(&sstart[(size_t)(s * 2 + par) * 31], so.c, sizeof(so.c));
             const uint64_t warm_max = s == 0 ? (uint64_t)D.warm_luma : (uint64_t)D.warm_chroma;
-            const uint64_t per_row = s == 0 ? (uint64_t)W : 2ull * W;
+            const uint64_t per_row = s == 0 ? (uint64_t)W : cdraws;
             const RandPoly &step = s == 0 ? xW : x2W;
             RandPoly cur = so;
             uint64_t cur_e = off;
@@ -241,7 +249,7 @@ static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
     HIPCHK(c, hipMemcpy(g.sstart.p, sstart.data(), sstart.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(g.jrow.p, jrow.data(), jrow.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(g.jwarm.p, jwarm.data(), jwarm.size() * 4, hipMemcpyHostToDevice));
-    g.W = W; g.H = H; g.valid = true;
+    g.W = W; g.H = H; g.variant = D.variant; g.valid = true;
     return NTSCSIM_OK;
 }
 
@@ -293,7 +301,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geom.sstart.release(); c->geom.jwarm.release();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->tails.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->tails.release(); c->fields422.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
@@ -585,6 +593,154 @@ extern "C" void ntscsim_batch_destroy(ntscsim_batch *b)
     (void)hipDeviceSynchronize();
     b->records.release();
     delete b;
+}
+
+// ---- the 8-bit YUV422P sibling (ffmpeg_to_composite.cpp) ------------------------------------
+static double alpha_rate(double rate, double hz)
+{
+    const double timeInterval = 1.0 / rate;
+    const double tau = 1 / (hz * 2 * M_PI);
+    return timeInterval / (tau + timeInterval);
+}
+
+extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
+                                        int W, int H, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0) return NTSCSIM_E_ARG;
+    if (W < 16 || (W & 1) || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;   // 4:2:2
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const ntscsim_params &p = c->prm;
+
+    DevParams D;
+    fill_dev_params(p, D);
+    if (c->warm_override[0] > 0) D.warm_luma = c->warm_override[0];
+    if (c->warm_override[1] > 0) D.warm_chroma = c->warm_override[1];
+    D.variant = 1;
+    D.W = W; D.H = H; D.Lslot = (H + 1) / 2; D.nfields = n;
+    const long long R = (long long)n * D.Lslot;
+    if (R > (1ll << 30)) return NTSCSIM_E_SIZE;
+    D.R = (int)R;
+    D.Rpad = (int)(((R + 63) / 64) * 64 + 64);
+    // filter constants of the 8-bit tool: chroma runs at half the luma sample rate
+    const double rl = (315000000.00 * 4) / 88, rc2 = (315000000.00 * 4) / (88 * 2);
+    double luma_cut = 2400000, chroma_cut = 320000;                     // :793-808
+    D.cdelay = 4;
+    if (p.output_vhs_tape_speed == NTSCSIM_VHS_LP) { luma_cut = 1900000; chroma_cut = 300000; D.cdelay = 5; }
+    if (p.output_vhs_tape_speed == NTSCSIM_VHS_EP) { luma_cut = 1400000; chroma_cut = 280000; D.cdelay = 6; }
+    D.a_in_i = alpha_rate(rc2, 1300000);                                // :366-381
+    D.a_in_q = alpha_rate(rc2, 600000);
+    const double a_hp_i = alpha_rate(rc2, 1300000 / 2.0), a_hp_q = alpha_rate(rc2, 600000 / 2.0);
+    D.a_tv = alpha_rate(rc2, (315000000.00 * 4) / (88 * 2 * 4));        // lite :408
+    D.a_vl = alpha_rate(rl, luma_cut);
+    D.a_vc = alpha_rate(rc2, chroma_cut);
+    D.a_sh = alpha_rate(rl, luma_cut * 2);                              // :893
+    const double a_sh_c = alpha_rate(rc2, chroma_cut * 2);              // :911
+    D.sharpen = p.vhs_out_sharpen;
+    D.out_lp = p.composite_out_chroma_lowpass ? 2 : (p.composite_out_chroma_lowpass_lite ? 1 : 0);  // :948-951
+    if (p.video_yc_recombine < 0 || p.video_yc_recombine > 64) return NTSCSIM_E_PARAM;
+
+    int rc = build_geometry(c, W, H, D);
+    if (rc != NTSCSIM_OK) return rc;
+    if (D.pnoise_k) { rc = build_ptab(c); if (rc != NTSCSIM_OK) return rc; }
+
+    c->host_fields.resize((size_t)n);
+    c->host_fields422.resize((size_t)n);
+    uint64_t pos = c->rng_pos;
+    bool any_render = false, any_flt = false;
+    for (int i = 0; i < n; i++) {
+        const ntscsim_field422_desc &d = descs[i];
+        if (d.field > 1) return NTSCSIM_E_ARG;
+        Field422Dev &o = c->host_fields422[(size_t)i];
+        std::memset(&o, 0, sizeof(o));
+        for (int k = 0; k < 3; k++) {
+            if (!d.dst_dev[k]) return NTSCSIM_E_ARG;
+            const int need = k == 0 ? W : W / 2;
+            if (d.dst_linesize[k] < need) return NTSCSIM_E_SIZE;
+            o.dst[k] = (uint8_t *)d.dst_dev[k]; o.dst_ls[k] = d.dst_linesize[k];
+            if (d.src_dev[0]) {
+                if (!d.src_dev[k] || d.src_linesize[k] < need) return NTSCSIM_E_SIZE;
+                o.src[k] = (const uint8_t *)d.src_dev[k]; o.src_ls[k] = d.src_linesize[k];
+            }
+            if (d.flt_dev[0] && p.black_key_level_feedback >= 0) {
+                if (!d.flt_dev[k] || d.flt_linesize[k] < need) return NTSCSIM_E_SIZE;
+                o.flt[k] = (uint8_t *)d.flt_dev[k]; o.flt_ls[k] = d.flt_linesize[k];
+            }
+        }
+        if (d.src_dev[0]) {
+            const int minh = (d.flags & NTSCSIM_422_INTERLACED) ? 4 : 2;
+            if (d.src_height < minh) return NTSCSIM_E_SIZE;
+            any_render = true;
+        }
+        any_flt = any_flt || o.flt[0] != nullptr;
+        o.src_height = d.src_height;
+        o.field = d.field; o.flags = d.flags; o.fieldno = d.fieldno;
+        if (d.rng_pos != NTSCSIM_RNG_AUTO) pos = d.rng_pos;
+        FieldDev &fo = c->host_fields[(size_t)i];
+        std::memset(&fo, 0, sizeof(fo));
+        fo.field = d.field; fo.fieldno = d.fieldno;
+        const RandState s = ctx_state_at(c, pos);
+        std::memcpy(fo.rng, s.w, sizeof(s.w));
+        for (int j = 31; j < 61; j++) fo.rng[j] = fo.rng[j - 31] + fo.rng[j - 3];
+        if (!(d.flags & NTSCSIM_422_NOCOMP)) pos += c->geom.calls[d.field & 1];
+    }
+    c->rng_pos = pos;
+
+    const dim3 pgrid((D.R + 62) / 63);
+    const size_t S = (size_t)pgrid.x * 64;
+    const size_t W2 = (size_t)W / 2;
+    HIPCHK(c, c->fields.ensure((size_t)n));
+    HIPCHK(c, c->fields422.ensure((size_t)n));
+    HIPCHK(c, c->scratch422.ensure(S * (3 * (size_t)W + 2 * W2) + 256));
+    if (D.hs) HIPCHK(c, c->hs_shift.ensure((size_t)D.R));
+    if (D.pnoise_k) HIPCHK(c, c->pn_noise.ensure((size_t)D.R));
+    if (D.loss) HIPCHK(c, c->dropout.ensure((size_t)D.R));
+    if (D.noise_k) { HIPCHK(c, c->rs_luma.ensure((size_t)31 * D.Rpad)); HIPCHK(c, c->n0_luma.ensure((size_t)D.Rpad)); }
+    if (D.cnoise_k) {
+        HIPCHK(c, c->rs_chroma.ensure((size_t)31 * D.Rpad));
+        HIPCHK(c, c->n0_u.ensure((size_t)D.Rpad));
+        HIPCHK(c, c->n0_v.ensure((size_t)D.Rpad));
+    }
+    // (pageable host staging: the copies below are synchronous with respect to the host buffers)
+    HIPCHK(c, hipMemcpyAsync(c->fields.p, c->host_fields.data(), (size_t)n * sizeof(FieldDev),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->fields422.p, c->host_fields422.data(), (size_t)n * sizeof(Field422Dev),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+
+    GeomDev G;
+    G.lskip = c->geom.lskip.p; G.pskip = c->geom.pskip.p; G.jrow = c->geom.jrow.p;
+    G.jwarm = c->geom.jwarm.p; G.sstart = c->geom.sstart.p; G.ptab = c->ptab.p;
+    Scratch422 Sc;
+    Sc.S = S;
+    Sc.Y = c->scratch422.p;
+    Sc.T = Sc.Y + S * W;
+    Sc.Cc = Sc.T + S * W;
+    Sc.U = Sc.Cc + S * W;
+    Sc.V = Sc.U + S * W2;
+
+    if (any_render)
+        hipLaunchKernelGGL(k422_render, dim3((unsigned)((2 * W + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
+                           dim3(256), 0, st, D, c->fields422.p);
+    if (any_flt)
+        hipLaunchKernelGGL(k422_bkey, dim3((unsigned)((W2 + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
+                           dim3(256), 0, st, D, c->fields422.p, p.black_key_level_feedback);
+    if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
+    if (D.hs || D.pnoise_k || D.loss)
+        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, c->fields.p,
+                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
+    if (D.noise_k || D.cnoise_k)
+        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
+                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
+                           c->n0_v.p);
+    hipLaunchKernelGGL(k422_process, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
+                       c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                       c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma,
+                       p.video_yc_recombine, p.nocolor_subcarrier_after_yc_sep);
+    HIPCHK(c, hipGetLastError());
+    return NTSCSIM_OK;
 }
 
 extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int src_interlaced,

@@ -58,6 +58,18 @@ extern "C" void ntscsim_params_init(ntscsim_params *p)
     p->vhs_svideo_out = 0;                            // :797
     p->enable_composite_emulation = 1;                // :798
     p->output_vhs_tape_speed = NTSCSIM_VHS_SP;        // :809
+    p->black_key_level_feedback = -1;                 // ffmpeg_to_composite.cpp:322
+    p->vhs_out_sharpen_chroma = 0.85;                 // ffmpeg_to_composite.cpp:271
+}
+
+extern "C" void ntscsim_params_init_to_composite(ntscsim_params *p)
+{
+    // ffmpeg_to_composite.cpp:267-333: same as ffmpeg_ntsc except the head-switch model
+    ntscsim_params_init(p);
+    if (!p) return;
+    p->vhs_head_switching_phase = 1.0 - ((4.5 + 0.01) / 262.5);           // :274
+    p->vhs_head_switching_point = p->vhs_head_switching_phase;            // no such global: mirror
+    p->vhs_head_switching_phase_noise = (((1.0 / 300)) / 262.5);          // :275
 }
 
 extern "C" void ntscsim_cli_init(ntscsim_cli *c)
@@ -74,8 +86,24 @@ extern "C" void ntscsim_cli_init(ntscsim_cli *c)
     c->vhs_linear_high_boost = 0.25;      // :782
 }
 
+static int parse_argv_impl(ntscsim_params *p, ntscsim_cli *cli, int argc, const char *const *argv,
+                           int require_io, bool tocomp);
+
 extern "C" int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, int argc,
                                          const char *const *argv, int require_io)
+{
+    return parse_argv_impl(p, cli, argc, argv, require_io, false);
+}
+
+extern "C" int ntscsim_params_parse_argv_to_composite(ntscsim_params *p, ntscsim_cli *cli, int argc,
+                                                      const char *const *argv, int require_io)
+{
+    return parse_argv_impl(p, cli, argc, argv, require_io, true);
+}
+
+// tocomp = false: ffmpeg_ntsc.cpp parse_argv :972-1282; true: ffmpeg_to_composite.cpp :1325-1639
+static int parse_argv_impl(ntscsim_params *p, ntscsim_cli *cli, int argc, const char *const *argv,
+                           int require_io, bool tocomp)
 {
     ntscsim_cli local_cli;
     if (!p || (argc > 0 && !argv)) return NTSCSIM_E_ARG;
@@ -117,7 +145,7 @@ extern "C" int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, in
             if (!next(v)) return NTSCSIM_E_FLAG;
             p->output_width = (int)std::strtoul(v, nullptr, 0);
             if (p->output_width < 32) return NTSCSIM_E_FLAG;            // :1001
-        } else if (!std::strcmp(a, "d")) {
+        } else if (!tocomp && !std::strcmp(a, "d")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
             unsigned long d = std::strtoul(v, nullptr, 0);
             if (d == 0 || d > 256) {
@@ -127,8 +155,20 @@ extern "C" int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, in
             cli->frame_delay = (int)d;
         } else if (!std::strcmp(a, "i")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
-            if (cli->n_inputs >= NTSCSIM_MAX_INPUTS) return NTSCSIM_E_FLAG;
-            cli->input_paths[cli->n_inputs++] = v;
+            if (tocomp) { cli->input_paths[0] = v; cli->n_inputs = 1; }   // single input :1502
+            else {
+                if (cli->n_inputs >= NTSCSIM_MAX_INPUTS) return NTSCSIM_E_FLAG;
+                cli->input_paths[cli->n_inputs++] = v;
+            }
+        } else if (tocomp && !std::strcmp(a, "bkey-feedback")) {          // :1356
+            if (!next(v)) return NTSCSIM_E_FLAG;
+            p->black_key_level_feedback = std::atoi(v);
+        } else if (tocomp && (!std::strcmp(a, "ss") || !std::strcmp(a, "se") || !std::strcmp(a, "t") ||
+                              !std::strcmp(a, "a") || !std::strcmp(a, "v"))) {
+            if (!next(v)) return NTSCSIM_E_FLAG;      // media-layer switches :1368-1392, not DSP
+        } else if (tocomp && (!std::strcmp(a, "an") || !std::strcmp(a, "vn") || !std::strcmp(a, "vi") ||
+                              !std::strcmp(a, "vp"))) {
+            // :1393-1404 stream selection / interlaced-vs-bob output: media layer
         } else if (!std::strcmp(a, "o")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
             cli->output_path = v;
@@ -158,8 +198,12 @@ extern "C" int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, in
             p->enable_composite_emulation = 0;
         } else if (!std::strcmp(a, "vhs-head-switching-point")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
-            p->vhs_head_switching_point = std::atof(v);
-        } else if (!std::strcmp(a, "vhs-head-switching-phase")) {
+            if (tocomp) {                                                 // to_composite :1405-1407
+                p->vhs_head_switching_phase = std::atof(v);
+                p->vhs_head_switching_point = p->vhs_head_switching_phase;
+            }
+            else p->vhs_head_switching_point = std::atof(v);
+        } else if (!tocomp && !std::strcmp(a, "vhs-head-switching-phase")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
             p->vhs_head_switching_phase = std::atof(v);
         } else if (!std::strcmp(a, "vhs-head-switching-noise-level")) {
@@ -177,19 +221,19 @@ extern "C" int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, in
         } else if (!std::strcmp(a, "comp-cut")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
             p->composite_preemphasis_cut = std::atof(v);
-        } else if (!std::strcmp(a, "comp-catv")) {              // :1077-1081
-            p->composite_preemphasis = 7;
-            p->composite_preemphasis_cut = 315000000 / 88;
+        } else if (!std::strcmp(a, "comp-catv")) {              // :1077-1081 | to_composite :1424
+            p->composite_preemphasis = tocomp ? 1.5 : 7;
+            p->composite_preemphasis_cut = tocomp ? 315000000 / 88 / 2 : 315000000 / 88;
             p->video_chroma_phase_noise = 2;
-        } else if (!std::strcmp(a, "comp-catv2")) {             // :1082-1086
-            p->composite_preemphasis = 15;
-            p->composite_preemphasis_cut = 315000000 / 88;
+        } else if (!std::strcmp(a, "comp-catv2")) {             // :1082-1086 | :1429
+            p->composite_preemphasis = tocomp ? 2.5 : 15;
+            p->composite_preemphasis_cut = tocomp ? 315000000 / 88 / 2 : 315000000 / 88;
             p->video_chroma_phase_noise = 4;
-        } else if (!std::strcmp(a, "comp-catv3")) {             // :1087-1091
-            p->composite_preemphasis = 25;
-            p->composite_preemphasis_cut = (315000000 * 2) / 88;
+        } else if (!std::strcmp(a, "comp-catv3")) {             // :1087-1091 | :1434
+            p->composite_preemphasis = tocomp ? 4 : 25;
+            p->composite_preemphasis_cut = tocomp ? 315000000 / 88 / 2 : (315000000 * 2) / 88;
             p->video_chroma_phase_noise = 6;
-        } else if (!std::strcmp(a, "comp-catv4")) {             // :1092-1096
+        } else if (!tocomp && !std::strcmp(a, "comp-catv4")) {  // :1092-1096
             p->composite_preemphasis = 40;
             p->composite_preemphasis_cut = (315000000 * 4) / 88;
             p->video_chroma_phase_noise = 6;
@@ -288,13 +332,23 @@ extern "C" int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, in
     }
 
     // post-parse derivation :1264-1265.  `int += double`: evaluated in double, truncated on store.
-    if (p->composite_preemphasis != 0)
-        p->subcarrier_amplitude_back =
-            (int)(p->subcarrier_amplitude_back +
-                  (50 * p->composite_preemphasis * (315000000 / 88)) /
-                      (2 * p->composite_preemphasis_cut));
+    if (p->composite_preemphasis != 0) {
+        if (tocomp)                                                     // to_composite :1626-1627
+            p->subcarrier_amplitude_back =
+                (int)(p->subcarrier_amplitude_back + (50 * p->composite_preemphasis) / 4);
+        else
+            p->subcarrier_amplitude_back =
+                (int)(p->subcarrier_amplitude_back +
+                      (50 * p->composite_preemphasis * (315000000 / 88)) /
+                          (2 * p->composite_preemphasis_cut));
+    }
 
-    if (require_io) {
+    if (require_io && tocomp) {
+        if (cli->n_inputs == 0 || !cli->output_path || !*cli->output_path) {
+            std::fprintf(stderr, "You must specify an input and output file (-i and -o).\n");  // :1634
+            return NTSCSIM_E_FLAG;
+        }
+    } else if (require_io) {
         if (!cli->output_path || !*cli->output_path) {
             std::fprintf(stderr, "No output file specified\n");        // :1272
             return NTSCSIM_E_FLAG;
@@ -351,6 +405,24 @@ extern "C" uint64_t ntscsim_rng_calls_per_field(const ntscsim_params *p, int wid
     if (p->video_chroma_noise != 0) n += 2 * W * L;                                // :1719
     if (p->video_chroma_phase_noise != 0) n += L;                                  // :1736
     if (p->video_chroma_loss != 0) n += L;                                         // :1891
+    return n;
+}
+
+extern "C" uint64_t ntscsim_rng_calls_per_field_422(const ntscsim_params *p, int width, int height,
+                                                    unsigned field)
+{
+    // composite_video_process(), ffmpeg_to_composite.cpp: luma noise 1/pixel :660, head switch 4
+    // :680, chroma noise 2 per chroma sample (width/2 per row) :747-750, phase noise 1/row :762,
+    // dropout 1/row :937
+    if (!p || width <= 0 || height <= 0 || field > 1 || (unsigned)height <= field) return 0;
+    const uint64_t L = (uint64_t)((height - (int)field + 1) / 2);
+    const uint64_t W = (uint64_t)width, W2 = (uint64_t)(width / 2);
+    uint64_t n = 0;
+    if (p->video_noise != 0) n += W * L;
+    if (p->vhs_head_switching && p->vhs_head_switching_phase_noise != 0) n += 4;
+    if (p->video_chroma_noise != 0) n += 2 * W2 * L;
+    if (p->video_chroma_phase_noise != 0) n += L;
+    if (p->video_chroma_loss != 0) n += L;
     return n;
 }
 

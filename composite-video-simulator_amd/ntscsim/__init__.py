@@ -7,8 +7,8 @@ torch is used only for device memory, streams and torch.distributed plumbing.
 import ctypes as C
 
 from . import _capi
-from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, FieldDesc, NtscsimError,
-                    Params, lib, make_params)
+from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, Field422Desc, FieldDesc,
+                    NtscsimError, Params, lib, make_params, make_params_to_composite)
 
 __all__ = ["FieldSimulator", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
            "field_rows", "calls_per_field", "field_schedule"]
@@ -132,6 +132,33 @@ class FieldSimulator:
         descs = self.build_descs(src, dst, jobs, **kw)
         self.run_descs(descs, src.shape[2], src.shape[1])
         return descs
+
+    # ---- 8-bit YUV422P sibling (ffmpeg_to_composite) ---------------------------------------
+    def fields422(self, jobs, width, height, stream=None):
+        """jobs: list of dicts with keys dst (3 CUDA uint8 tensors [H, ls]), optional src (3
+        tensors) + src_height, optional flt (3 tensors), field, fieldno, flags, rng_pos."""
+        arr = (Field422Desc * len(jobs))()
+        for d, j in zip(arr, jobs):
+            for k in range(3):
+                d.dst_dev[k] = j["dst"][k].data_ptr()
+                d.dst_linesize[k] = j["dst"][k].stride(0)
+                if j.get("src") is not None:
+                    d.src_dev[k] = j["src"][k].data_ptr()
+                    d.src_linesize[k] = j["src"][k].stride(0)
+                if j.get("flt") is not None:
+                    d.flt_dev[k] = j["flt"][k].data_ptr()
+                    d.flt_linesize[k] = j["flt"][k].stride(0)
+            d.src_height = j.get("src_height", 0)
+            d.field = j["field"]
+            d.flags = j.get("flags", 0)
+            d.fieldno = j["fieldno"]
+            d.rng_pos = RNG_AUTO if j.get("rng_pos") is None else int(j["rng_pos"])
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.ntscsim_fields422_device(self._h, arr, len(jobs), int(width), int(height),
+                                                C.c_void_p(stream))
+        self._chk(rc, "ntscsim_fields422_device")
 
     def sync(self):
         self._chk(self._lib.ntscsim_sync(self._h), "ntscsim_sync")

@@ -25,6 +25,8 @@ EXPORTS = (
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
     "ntscsim_debug_force_generic",
+    "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
+    "ntscsim_fields422_device", "ntscsim_rng_calls_per_field_422",
 )
 
 
@@ -62,7 +64,8 @@ class Params(C.Structure):
         ("vhs_svideo_out", C.c_int32),
         ("enable_composite_emulation", C.c_int32),
         ("output_vhs_tape_speed", C.c_int32),
-        ("_pad1", C.c_int32),
+        ("black_key_level_feedback", C.c_int32),
+        ("vhs_out_sharpen_chroma", C.c_double),
     ]
 
 
@@ -79,6 +82,26 @@ class FieldDesc(C.Structure):
         ("rng_pos", C.c_uint64),
     ]
 
+
+class Field422Desc(C.Structure):
+    """struct ntscsim_field422_desc"""
+    _fields_ = [
+        ("dst_dev", C.c_void_p * 3),
+        ("src_dev", C.c_void_p * 3),
+        ("flt_dev", C.c_void_p * 3),
+        ("dst_linesize", C.c_int32 * 3),
+        ("src_linesize", C.c_int32 * 3),
+        ("flt_linesize", C.c_int32 * 3),
+        ("src_height", C.c_int32),
+        ("field", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("_pad", C.c_uint32),
+        ("fieldno", C.c_uint64),
+        ("rng_pos", C.c_uint64),
+    ]
+
+
+F422_INTERLACED, F422_TFF, F422_SRC420, F422_SECOND, F422_NOCOMP = 1, 2, 4, 8, 16
 
 _u8p = C.POINTER(C.c_uint8)
 _lib = None
@@ -142,6 +165,16 @@ def lib():
     L.ntscsim_debug_read_composite.restype = C.c_int
     L.ntscsim_debug_set_warmup.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ntscsim_debug_set_warmup.restype = None
+    L.ntscsim_params_init_to_composite.argtypes = [C.POINTER(Params)]
+    L.ntscsim_params_init_to_composite.restype = None
+    L.ntscsim_params_parse_argv_to_composite.argtypes = [C.POINTER(Params), C.c_void_p, C.c_int,
+                                                         C.POINTER(C.c_char_p), C.c_int]
+    L.ntscsim_params_parse_argv_to_composite.restype = C.c_int
+    L.ntscsim_fields422_device.argtypes = [C.c_void_p, C.POINTER(Field422Desc), C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p]
+    L.ntscsim_fields422_device.restype = C.c_int
+    L.ntscsim_rng_calls_per_field_422.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_uint]
+    L.ntscsim_rng_calls_per_field_422.restype = C.c_uint64
     L.ntscsim_debug_force_generic.argtypes = [C.c_void_p, C.c_int]
     L.ntscsim_debug_force_generic.restype = None
     _lib = L
@@ -153,6 +186,23 @@ class NtscsimError(RuntimeError):
         self.code = code
         msg = lib().ntscsim_strerror(code).decode()
         super().__init__("ntscsim error %d: %s%s" % (code, msg, (" -- " + detail) if detail else ""))
+
+
+def make_params_to_composite(flags=(), **overrides):
+    """ntscsim_params from ffmpeg_to_composite's switches (ffmpeg_to_composite.cpp :1325)."""
+    L = lib()
+    p = Params()
+    L.ntscsim_params_init_to_composite(C.byref(p))
+    argv = [b"ffmpeg_to_composite"] + [str(f).encode() for f in flags]
+    arr = (C.c_char_p * len(argv))(*argv)
+    rc = L.ntscsim_params_parse_argv_to_composite(C.byref(p), None, len(argv), arr, 0)
+    if rc != OK:
+        raise NtscsimError(rc, "parse_argv_to_composite(%r)" % (list(flags),))
+    for k, v in overrides.items():
+        if k not in dict(Params._fields_):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
 
 def make_params(flags=(), **overrides):

@@ -90,7 +90,8 @@ typedef struct ntscsim_params {
     int32_t  vhs_svideo_out;              /* :797  false                                        */
     int32_t  enable_composite_emulation;  /* :798  true (-nocomp clears it; L1 never tests it)  */
     int32_t  output_vhs_tape_speed;       /* :809  NTSCSIM_VHS_SP                               */
-    int32_t  _pad1;
+    int32_t  black_key_level_feedback;    /* ffmpeg_to_composite.cpp:322  -1 (variant only)      */
+    double   vhs_out_sharpen_chroma;      /* ffmpeg_to_composite.cpp:271  0.85 (variant only)    */
 } ntscsim_params;
 
 /* Host-side (L4/L2) settings parse_argv() also fills; not read by the field DSP. */
@@ -120,6 +121,17 @@ void ntscsim_cli_init(ntscsim_cli *c);
  */
 int ntscsim_params_parse_argv(ntscsim_params *p, ntscsim_cli *cli, int argc,
                               const char *const *argv, int require_io);
+
+/*
+ * The 8-bit YUV422P sibling tool, ffmpeg_to_composite.cpp: its global initialisers (:267-333 --
+ * note the different head-switch defaults: one `phase` parameter = 1-4.51/262.5, noise 1/300 line)
+ * and its parse_argv() (:1325-1639: no -d / -comp-catv4 / -vhs-head-switching-phase; adds
+ * -bkey-feedback, -ss/-se/-t, -a/-v/-an/-vn, -vi/-vp; -vhs-head-switching-point sets the phase;
+ * -comp-catv* = 1.5/2.5/4 at fsc/2; amplitude_back += 50*pre/4 (:1627)).
+ */
+void ntscsim_params_init_to_composite(ntscsim_params *p);
+int  ntscsim_params_parse_argv_to_composite(ntscsim_params *p, ntscsim_cli *cli, int argc,
+                                            const char *const *argv, int require_io);
 
 /* Rejects parameter values for which the reference's own behaviour is undefined
  * (negative noise levels, subcarrier amplitude 0 -> division by zero at :1545, ...). */
@@ -209,6 +221,45 @@ int  ntscsim_batch_create(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int
                           int width, int height, ntscsim_batch **out);
 int  ntscsim_batch_run(ntscsim_batch *batch, void *hip_stream);
 void ntscsim_batch_destroy(ntscsim_batch *batch);
+
+/* ---- the 8-bit YUV422P sibling: ffmpeg_to_composite.cpp --------------------------------------
+ * One descriptor == one iteration of the loop at ffmpeg_to_composite.cpp:1783-1800:
+ *   render_field(dst, src, field, ...) :1784   (skipped when src_dev[0] == NULL)
+ *   black_key_feedback(dst, flt, ...)  :1787   (when params.black_key_level_feedback >= 0 and
+ *                                               flt_dev[0] != NULL)
+ *   composite_video_process(dst, field, fieldno) :1790, IN PLACE on the rows of `field` of the
+ *                                               YUV422P frame dst (skipped with NTSCSIM_422_NOCOMP,
+ *                                               the tool's -nocomp :1789)
+ * Create the ctx from ntscsim_params_init_to_composite()/..._parse_argv_to_composite() parameters.
+ * The reference's Y/C separator reads two bytes past each luma row (:496, undefined behaviour);
+ * this implementation reads the value 16 there, so up to ~16 luma / ~12 chroma samples at the
+ * right edge of a row can differ from a particular run of the reference.
+ * Fields that share a feedback frame must not be in the same batch (frame-to-frame recurrence).
+ */
+#define NTSCSIM_422_INTERLACED 1u   /* src->interlaced_frame                                     */
+#define NTSCSIM_422_TFF        2u   /* src->top_field_first                                      */
+#define NTSCSIM_422_SRC420     4u   /* decoder format is YUV420P (:1005): src chroma is H/2 tall */
+#define NTSCSIM_422_SECOND     8u   /* field_number - src_pts >= ticks_per_frame/2 (:1035)       */
+#define NTSCSIM_422_NOCOMP     16u  /* -nocomp: render only                                      */
+
+typedef struct ntscsim_field422_desc {
+    void       *dst_dev[3];         /* Y, U, V of the YUV422P output frame (device pointers)     */
+    const void *src_dev[3];         /* source frame for render_field, or NULL                    */
+    void       *flt_dev[3];         /* black-key feedback frame, or NULL                         */
+    int32_t     dst_linesize[3], src_linesize[3], flt_linesize[3];
+    int32_t     src_height;         /* source frame height (its width is the output width)       */
+    uint32_t    field;
+    uint32_t    flags;              /* NTSCSIM_422_*                                             */
+    uint32_t    _pad;
+    uint64_t    fieldno;
+    uint64_t    rng_pos;            /* or NTSCSIM_RNG_AUTO                                       */
+} ntscsim_field422_desc;
+
+int ntscsim_fields422_device(ntscsim_ctx *ctx, const ntscsim_field422_desc *descs, int n,
+                             int width, int height, void *hip_stream);
+/* draws of one composite_video_process() call (chroma noise runs at width/2 samples per row) */
+uint64_t ntscsim_rng_calls_per_field_422(const ntscsim_params *p, int width, int height,
+                                         unsigned field);
 
 /* Block until everything enqueued by this ctx has finished. */
 int ntscsim_sync(ntscsim_ctx *ctx);

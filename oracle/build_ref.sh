@@ -25,3 +25,20 @@ mkdir -p "$here/_ref"
     cat "$here/ref_shim_post.cpp"
 } | g++ -x c++ -O2 -w -ffp-contract=off -fPIC -shared -I"$here/../include" - -o "$here/_ref/libntsc_ref.so"
 echo "built $here/_ref/libntsc_ref.so"
+
+# ---- the 8-bit YUV422P sibling, ffmpeg_to_composite.cpp:
+# 97-131 LowpassFilter | 261 use_422_colorspace | 267-333 L1 globals | 335-351 clampu8/clips16 |
+# 353-553 chroma low-pass / modulate / demodulate | 629-1129 composite_video_process,
+# black_key_feedback, render_field
+src2="$ref/ffmpeg_to_composite.cpp"
+{
+    cat "$here/ref_tocomp_pre.hpp"
+    sed -n '97,131p' "$src2"
+    sed -n '261,261p' "$src2"
+    sed -n '267,333p' "$src2"
+    sed -n '335,351p' "$src2"
+    sed -n '353,553p' "$src2"
+    sed -n '629,1129p' "$src2"
+    cat "$here/ref_tocomp_post.cpp"
+} | g++ -x c++ -O2 -w -ffp-contract=off -fPIC -shared -I"$here/../include" - -o "$here/_ref/libtocomp_ref.so"
+echo "built $here/_ref/libtocomp_ref.so"

@@ -167,3 +167,165 @@ class RefStream:
         h, w = src.shape[:2]
         ref().ntsc_ref_composite_layer(_ptr(dst), w * 4, _ptr(src), w * 4, interlaced, tff,
                                        w, h, field, fieldno)
+
+
+# ------------------------------------------------------------------ 8-bit YUV422P variant -----
+TOCOMP_REF_SO = os.path.join(ROOT, "oracle", "_ref", "libtocomp_ref.so")
+OOB_DEFINED, OOB_MEMORY = 0, 1
+
+
+class TocompPlanes(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8) * 3), ("linesize", C.c_int * 3),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+class Yuv422:
+    """A YUV422P frame in ONE buffer (Y | U | V + slack), so that the reference's two-byte read
+    past each luma row (ffmpeg_to_composite.cpp:496) lands in memory we own and control."""
+
+    def __init__(self, w, h, pad=0, fill=0):
+        self.w, self.h = w, h
+        self.ls = [w + pad, w // 2 + pad, w // 2 + pad]
+        sizes = [self.ls[0] * h, self.ls[1] * h, self.ls[2] * h]
+        self.buf = np.full(sum(sizes) + 64, fill, np.uint8)
+        self.off = [0, sizes[0], sizes[0] + sizes[1]]
+
+    def plane(self, i):
+        n = self.ls[i] * self.h
+        return self.buf[self.off[i]:self.off[i] + n].reshape(self.h, self.ls[i])
+
+    def pix(self, i):
+        return self.plane(i)[:, :(self.w if i == 0 else self.w // 2)]
+
+    def copy(self):
+        o = Yuv422(self.w, self.h)
+        o.ls, o.off = list(self.ls), list(self.off)
+        o.buf = self.buf.copy()
+        return o
+
+    def cplanes(self):
+        t = TocompPlanes()
+        for i in range(3):
+            t.data[i] = C.cast(self.buf.ctypes.data + self.off[i], C.POINTER(C.c_uint8))
+            t.linesize[i] = self.ls[i]
+        t.width, t.height = self.w, self.h
+        return t
+
+    def ptr_arrays(self):
+        d = (C.POINTER(C.c_uint8) * 3)(*[C.cast(self.buf.ctypes.data + self.off[i], C.POINTER(C.c_uint8))
+                                         for i in range(3)])
+        ls = (C.c_int * 3)(*self.ls)
+        return d, ls
+
+
+def yuv_noise(w, h, seed, pad=0):
+    f = Yuv422(w, h, pad)
+    rng = np.random.RandomState(seed)
+    f.pix(0)[:] = rng.randint(16, 236, size=(h, w), dtype=np.uint8)
+    f.pix(1)[:] = rng.randint(16, 241, size=(h, w // 2), dtype=np.uint8)
+    f.pix(2)[:] = rng.randint(16, 241, size=(h, w // 2), dtype=np.uint8)
+    return f
+
+
+def yuv_bars(w, h, rot=0, pad=0):
+    """BT.601 75% colour bars in YUV422P."""
+    yuv = [(180, 128, 128), (162, 44, 142), (131, 156, 44), (112, 72, 58),
+           (84, 184, 198), (65, 100, 212), (35, 212, 114), (16, 128, 128)]
+    f = Yuv422(w, h, pad)
+    for x in range(w):
+        c = yuv[(8 * ((x + rot) % w)) // w]
+        f.pix(0)[:, x] = c[0]
+        if x % 2 == 0:
+            f.pix(1)[:, x // 2] = c[1]
+            f.pix(2)[:, x // 2] = c[2]
+    return f
+
+
+def _bind_tocomp_oracle():
+    o = oracle()
+    if not hasattr(o, "_tocomp_bound"):
+        o.tocomp_oracle_process.argtypes = [C.POINTER(Params), C.POINTER(OracleRng),
+                                            C.POINTER(TocompPlanes), C.c_uint, C.c_uint64, C.c_int]
+        o.tocomp_oracle_process.restype = C.c_int
+        o.tocomp_oracle_render_field.argtypes = [C.POINTER(TocompPlanes), C.POINTER(TocompPlanes),
+                                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint]
+        o.tocomp_oracle_render_field.restype = None
+        o.tocomp_oracle_black_key_feedback.argtypes = [C.POINTER(TocompPlanes), C.POINTER(TocompPlanes),
+                                                       C.c_uint, C.c_int]
+        o.tocomp_oracle_black_key_feedback.restype = None
+        o._tocomp_bound = True
+    return o
+
+
+def make_params_tocomp(flags=(), **overrides):
+    return ntscsim.make_params_to_composite(flags, **overrides)
+
+
+class TocompOracleStream:
+    def __init__(self, params, oob=OOB_DEFINED):
+        self.p, self.oob = params, oob
+        self.g = OracleRng()
+        oracle().ntsc_oracle_rng_seed(C.byref(self.g), 1)
+        _bind_tocomp_oracle()
+
+    @property
+    def rng_pos(self):
+        return int(self.g.count)
+
+    def skip(self, n):
+        oracle().ntsc_oracle_rng_discard(C.byref(self.g), n)
+
+    def process(self, frame, field, fieldno):
+        t = frame.cplanes()
+        rc = oracle().tocomp_oracle_process(C.byref(self.p), C.byref(self.g), C.byref(t), field,
+                                            fieldno, self.oob)
+        assert rc == 0
+
+
+def tocomp_oracle_render_field(dst, src, is420, interlaced, tff, second, field):
+    o = _bind_tocomp_oracle()
+    d, s = dst.cplanes(), src.cplanes()
+    o.tocomp_oracle_render_field(C.byref(d), C.byref(s), is420, interlaced, tff, second, field)
+
+
+def tocomp_oracle_black_key(dst, flt, field, level):
+    o = _bind_tocomp_oracle()
+    d, f = dst.cplanes(), flt.cplanes()
+    o.tocomp_oracle_black_key_feedback(C.byref(d), C.byref(f), field, level)
+
+
+def have_tocomp_ref():
+    return os.path.exists(TOCOMP_REF_SO)
+
+
+_tocomp_ref = None
+
+
+def tocomp_ref():
+    global _tocomp_ref
+    if _tocomp_ref is None:
+        lib = C.CDLL(TOCOMP_REF_SO)
+        pp = C.POINTER(C.POINTER(C.c_uint8))
+        ip = C.POINTER(C.c_int)
+        lib.tocomp_ref_set_params.argtypes = [C.POINTER(Params)]
+        lib.tocomp_ref_srand.argtypes = [C.c_uint]
+        lib.tocomp_ref_process.argtypes = [pp, ip, C.c_int, C.c_int, C.c_uint, C.c_ulonglong]
+        lib.tocomp_ref_render_field.argtypes = [pp, ip, C.c_int, C.c_int, pp, ip, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_int, C.c_uint]
+        lib.tocomp_ref_black_key_feedback.argtypes = [pp, ip, pp, ip, C.c_int, C.c_int, C.c_uint]
+        for f in (lib.tocomp_ref_set_params, lib.tocomp_ref_srand, lib.tocomp_ref_process,
+                  lib.tocomp_ref_render_field, lib.tocomp_ref_black_key_feedback):
+            f.restype = None
+        _tocomp_ref = lib
+    return _tocomp_ref
+
+
+class TocompRefStream:
+    def __init__(self, params):
+        tocomp_ref().tocomp_ref_set_params(C.byref(params))
+        tocomp_ref().tocomp_ref_srand(1)
+
+    def process(self, frame, field, fieldno):
+        d, ls = frame.ptr_arrays()
+        tocomp_ref().tocomp_ref_process(C.cast(d, C.POINTER(C.POINTER(C.c_uint8))), ls, frame.w,
+                                        frame.h, field, fieldno)

@@ -1,0 +1,216 @@
+"""The 8-bit YUV422P sibling (ffmpeg_to_composite.cpp): oracle pinning (CPU), product parity (GPU).
+
+Chain of evidence:
+  reference extract  ==  oracle in MEMORY mode      (bit for bit, whole buffer; needs /root/reference)
+  oracle MEMORY      ~=  oracle DEFINED             (differs only in a bounded right margin: the
+                                                     reference's two-byte read past each luma row)
+  oracle DEFINED     ==  HIP path                   (bit for bit, GPU tests)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _libs as L
+import cases422
+import ntscsim
+from ntscsim import _capi
+
+MARGIN_Y, MARGIN_C = 24, 14   # samples at the right edge that the out-of-row read can influence
+
+
+def refresh(frame, src, field):
+    """What render_field does for a same-size progressive source: overwrite the field's rows."""
+    for i in range(3):
+        frame.plane(i)[field::2] = src.plane(i)[field::2]
+
+
+@pytest.mark.skipif(not L.have_tocomp_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("c", cases422.CASES422, ids=[c[0] for c in cases422.CASES422])
+@pytest.mark.parametrize("pad", [0, 32])
+def test_oracle_equals_reference_extract(c, pad):
+    name, flags, w, h, n, kind = c
+    p = L.make_params_tocomp(flags)
+    srcs = [cases422.make_source422(kind, w, h, j, pad) for j in range((n + 1) // 2)]
+    a, b, d = srcs[0].copy(), srcs[0].copy(), srcs[0].copy()
+    r, o, od = L.TocompRefStream(p), L.TocompOracleStream(p, L.OOB_MEMORY), L.TocompOracleStream(p, L.OOB_DEFINED)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        for fr in (a, b, d):
+            refresh(fr, srcs[k // 2], field)
+        r.process(a, field, k)
+        o.process(b, field, k)
+        od.process(d, field, k)
+        assert np.array_equal(a.buf, b.buf), "field %d" % k          # incl. padding bytes
+        # the defined-behaviour oracle differs from the reference only inside the right margin
+        assert np.array_equal(b.pix(0)[:, :w - MARGIN_Y], d.pix(0)[:, :w - MARGIN_Y])
+        for i in (1, 2):
+            assert np.array_equal(b.pix(i)[:, :w // 2 - MARGIN_C], d.pix(i)[:, :w // 2 - MARGIN_C])
+        assert o.rng_pos == od.rng_pos
+    lib = L.product()
+    exp = sum(lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, (k & 1) ^ 1) for k in range(n))
+    assert o.rng_pos == exp
+
+
+@pytest.mark.skipif(not L.have_tocomp_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("is420,il,tff,second,sh", [(0, 0, 0, 0, 32), (0, 0, 0, 0, 50), (1, 0, 0, 0, 48),
+                                                     (0, 1, 1, 0, 48), (0, 1, 1, 1, 48), (0, 1, 0, 0, 40),
+                                                     (1, 1, 0, 1, 64), (1, 1, 1, 0, 36)])
+def test_render_field_equals_reference_extract(is420, il, tff, second, sh):
+    w, h = 64, 32
+    rng = np.random.RandomState(sh)
+    src = L.Yuv422(w, sh)
+    src.buf[:] = rng.randint(0, 256, size=src.buf.shape, dtype=np.uint8)
+    for field in (0, 1):
+        a, b = L.Yuv422(w, h, fill=7), L.Yuv422(w, h, fill=7)
+        da, la = a.ptr_arrays()
+        ds, ls = src.ptr_arrays()
+        pp = C.POINTER(C.POINTER(C.c_uint8))
+        L.tocomp_ref().tocomp_ref_render_field(C.cast(da, pp), la, w, h, C.cast(ds, pp), ls, sh, is420,
+                                               il, tff, second, field)
+        L.tocomp_oracle_render_field(b, src, is420, il, tff, second, field)
+        for i in range(3):
+            assert np.array_equal(a.pix(i), b.pix(i)), (field, i)
+
+
+@pytest.mark.skipif(not L.have_tocomp_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_black_key_equals_reference_extract():
+    w, h = 64, 16
+    p = L.make_params_tocomp(["-bkey-feedback", "6"])
+    assert p.black_key_level_feedback == 6
+    L.tocomp_ref().tocomp_ref_set_params(C.byref(p))
+    rng = np.random.RandomState(3)
+    for field in (0, 1):
+        d = L.Yuv422(w, h); f = L.Yuv422(w, h)
+        d.buf[:] = rng.randint(10, 40, size=d.buf.shape, dtype=np.uint8)
+        d.pix(1)[:] = rng.randint(120, 136, size=d.pix(1).shape, dtype=np.uint8)
+        d.pix(2)[:] = rng.randint(120, 136, size=d.pix(2).shape, dtype=np.uint8)
+        f.buf[:] = rng.randint(0, 256, size=f.buf.shape, dtype=np.uint8)
+        d2, f2 = d.copy(), f.copy()
+        pp = C.POINTER(C.POINTER(C.c_uint8))
+        da, la = d.ptr_arrays(); fa, lf = f.ptr_arrays()
+        L.tocomp_ref().tocomp_ref_black_key_feedback(C.cast(da, pp), la, C.cast(fa, pp), lf, w, h, field)
+        L.tocomp_oracle_black_key(d2, f2, field, 6)
+        assert np.array_equal(d.buf, d2.buf) and np.array_equal(f.buf, f2.buf)
+
+
+def test_to_composite_flag_mirror():
+    p = L.make_params_tocomp([])
+    assert p.vhs_head_switching_phase == 1.0 - ((4.5 + 0.01) / 262.5)          # :274
+    assert p.vhs_head_switching_phase_noise == (1.0 / 300) / 262.5             # :275
+    assert p.vhs_out_sharpen_chroma == 0.85 and p.black_key_level_feedback == -1
+    p = L.make_params_tocomp(["-comp-catv2"])                                   # :1429-1433, :1627
+    assert (p.composite_preemphasis, p.composite_preemphasis_cut) == (2.5, 315000000 // 88 // 2)
+    assert p.subcarrier_amplitude_back == int(50 + (50 * 2.5) / 4)
+    p = L.make_params_tocomp(["-vhs-head-switching-point", "0.25"])            # sets the PHASE here
+    assert p.vhs_head_switching_phase == 0.25
+    for bad in (["-d", "2"], ["-comp-catv4"], ["-vhs-head-switching-phase", "0.1"]):
+        with pytest.raises(ntscsim.NtscsimError):
+            L.make_params_tocomp(bad)
+    for ok in (["-ss", "1"], ["-vp"], ["-an"], ["-bkey-feedback", "3"], ["-t", "5"]):
+        L.make_params_tocomp(ok)
+
+
+# ------------------------------------------------------------------------------------- GPU -----
+
+def to_dev(torch, frame):
+    return [torch.from_numpy(np.ascontiguousarray(frame.plane(i))).cuda() for i in range(3)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", cases422.CASES422, ids=[c[0] for c in cases422.CASES422])
+def test_hip_equals_oracle_defined(c):
+    import torch
+    name, flags, w, h, n, kind = c
+    p = L.make_params_tocomp(flags)
+    srcs = [cases422.make_source422(kind, w, h, j + 5) for j in range((n + 1) // 2)]
+    o = L.TocompOracleStream(p, L.OOB_DEFINED)
+    frame = srcs[0].copy()
+    sim = ntscsim.FieldSimulator(params=p)
+    dev = to_dev(torch, frame)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        refresh(frame, srcs[k // 2], field)
+        o.process(frame, field, k)
+        srcd = to_dev(torch, srcs[k // 2])
+        sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
+        sim.sync()
+        for i in range(3):
+            got = dev[i].cpu().numpy()
+            assert np.array_equal(got[:, :frame.pix(i).shape[1]], frame.pix(i)), "field %d plane %d" % (k, i)
+        assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_hip_batch_of_fields_full_size():
+    """720x480 -vhs, 8 fields in ONE batch (each field its own frame), explicit rand() positions."""
+    import torch
+    w, h, n = 720, 480, 8
+    p = L.make_params_tocomp(["-vhs"])
+    lib = L.product()
+    srcs = [L.yuv_bars(w, h, j) if j % 2 == 0 else L.yuv_noise(w, h, 70 + j) for j in range(n // 2)]
+    exp, jobs, devs = [], [], []
+    o = L.TocompOracleStream(p, L.OOB_DEFINED)
+    pos = 0
+    for k in range(n):
+        field = (k & 1) ^ 1
+        fr = srcs[k // 2].copy()
+        o.process(fr, field, k)
+        exp.append(fr)
+        d = to_dev(torch, srcs[k // 2])
+        devs.append(d)
+        jobs.append({"dst": d, "field": field, "fieldno": k, "rng_pos": pos})
+        pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, field)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.fields422(jobs, w, h)
+    sim.sync()
+    for k in range(n):
+        for i in range(3):
+            assert np.array_equal(devs[k][i].cpu().numpy(), exp[k].pix(i)), (k, i)
+    sim.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("is420,il,tff,second,sh", [(0, 0, 0, 0, 50), (1, 0, 0, 0, 48), (0, 1, 1, 1, 48),
+                                                     (1, 1, 0, 1, 64)])
+def test_hip_render_field_and_black_key(is420, il, tff, second, sh):
+    import torch
+    w, h = 64, 32
+    p = L.make_params_tocomp(["-vhs", "-bkey-feedback", "8"])
+    rng = np.random.RandomState(sh)
+    src = L.Yuv422(w, sh)
+    src.buf[:] = rng.randint(0, 60, size=src.buf.shape, dtype=np.uint8)
+    src.pix(1)[:] = rng.randint(118, 138, size=src.pix(1).shape, dtype=np.uint8)
+    src.pix(2)[:] = rng.randint(118, 138, size=src.pix(2).shape, dtype=np.uint8)
+    dst, flt = L.Yuv422(w, h, fill=9), L.Yuv422(w, h)
+    flt.buf[:] = rng.randint(0, 256, size=flt.buf.shape, dtype=np.uint8)
+    o = L.TocompOracleStream(p, L.OOB_DEFINED)
+    sim = ntscsim.FieldSimulator(params=p)
+    dd, fd, sd = to_dev(torch, dst), to_dev(torch, flt), to_dev(torch, src)
+    flags = (_capi.F422_SRC420 if is420 else 0) | (_capi.F422_INTERLACED if il else 0) | \
+            (_capi.F422_TFF if tff else 0) | (_capi.F422_SECOND if second else 0)
+    for k in range(3):
+        field = (k & 1) ^ 1
+        L.tocomp_oracle_render_field(dst, src, is420, il, tff, second, field)
+        L.tocomp_oracle_black_key(dst, flt, field, 8)
+        o.process(dst, field, k)
+        sim.fields422([{"dst": dd, "src": sd, "src_height": sh, "flt": fd, "field": field,
+                        "fieldno": k, "flags": flags}], w, h)
+        sim.sync()
+        for i in range(3):
+            assert np.array_equal(dd[i].cpu().numpy(), dst.pix(i)), (k, i)
+            assert np.array_equal(fd[i].cpu().numpy(), flt.pix(i)), (k, i)
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_hip_422_rejects_odd_width():
+    import torch
+    p = L.make_params_tocomp([])
+    sim = ntscsim.FieldSimulator(params=p)
+    t = [torch.zeros((8, 64), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        sim.fields422([{"dst": t, "field": 0, "fieldno": 0}], 33, 8)
+    assert e.value.code == _capi.E_SIZE
+    sim.close()
