@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="steps in flight: contexts (own HIP stream, scratch and destination "
                          "clip each) the steps rotate over")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the "
+                         "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-fields", type=int, default=600,
                     help="fields of the clip timed on the CPU oracle (0 = skip)")
     args = ap.parse_args()
@@ -97,13 +100,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    red_dev = dev                       # device of the tiny tensors the ranks exchange
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            red_dev = torch.device("cpu")
 
     w, h = args.width, args.height
     flags = args.preset.split()
@@ -162,11 +171,11 @@ def main():
     sims[0].set_profiling(False)
     dst = dsts[0]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # gather a checksum per rank (the only exchange the path needs)
-        cs = torch.tensor([int(dst.to(torch.int64).sum().item())], dtype=torch.int64, device=dev)
+        cs = torch.tensor([int(dst.to(torch.int64).sum().item())], dtype=torch.int64, device=red_dev)
         allcs = [torch.zeros_like(cs) for _ in range(world)]
         dist.all_gather(allcs, cs)
 
@@ -216,6 +225,7 @@ def main():
                 "fields_per_step_per_gpu": fields_per_step_local,
                 "input_frames_per_sec": value / 2.0,
                 "steps_in_flight": nq,
+                "rank_checksums": [int(c_.item()) for c_ in allcs] if dist is not None else None,
                 "mode": "exact (bit-identical to the reference: fp64, no FMA contraction)",
             },
             "roofline": {

@@ -1,0 +1,30 @@
+"""Developer probe: throughput of the YUV422P variant (first-cut multi-sweep kernel)."""
+import os, sys, time, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import torch, ntscsim
+import _libs as L
+w, h, nf = 720, 486, 600
+p = ntscsim.make_params_to_composite(["-vhs"])
+lib = ntscsim.lib()
+sim = ntscsim.FieldSimulator(params=p)
+base = L.yuv_bars(w, h, 0)
+frames = [[torch.from_numpy(base.plane(i).copy()).cuda() for i in range(3)] for _ in range(nf // 2)]
+jobs, pos = [], 0
+for k in range(nf):
+    field = (k & 1) ^ 1
+    jobs.append({"dst": frames[k // 2], "field": field, "fieldno": k, "rng_pos": pos})
+    pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, field)
+sim.fields422(jobs, w, h); sim.sync()
+t0 = time.perf_counter()
+K = 5
+for _ in range(K): sim.fields422(jobs, w, h)
+sim.sync()
+dt = (time.perf_counter() - t0) / K
+print("variant 720x486 -vhs: %.2f ms per 600 fields, %.0f fields/s" % (dt * 1e3, nf / dt))
+# CPU oracle on a few fields
+o = L.TocompOracleStream(p, L.OOB_DEFINED)
+fr = base.copy()
+t0 = time.perf_counter()
+for k in range(20): o.process(fr, (k & 1) ^ 1, k)
+print("oracle: %.2f ms/field" % ((time.perf_counter() - t0) / 20 * 1e3))
