@@ -579,6 +579,8 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     S.D1.template push<EDGE, O, PAR1>(P, pc, t, C.xi, W, C.xe, P.m_amp_back, O::nocolor(P), Y, U, V);
     const int x1 = t - 7;
     const bool in1 = EDGE ? (x1 >= 0 && x1 < W) : true;
+    constexpr bool FAST = !EDGE && !O::generic;   // steady state of a PRESET kernel
+    double Ud = 0, Vd = 0;                         // chroma as doubles (== U, V)
     if (in1) {
         // chroma noise :1719-1735
         if (O::cnoise(P)) {
@@ -591,8 +593,13 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
             const double u = U, v = V;
             const double u_ = (u * C.cosv) - (v * C.sinv);
             const double v_ = (u * C.sinv) + (v * C.cosv);
-            U = (int)u_; V = (int)v_;
-        }
+            if (FAST && VHS) {
+                // (double)(int)d == trunc(d) up to the sign of zero, which no later stage can
+                // observe (filters start from +0/16, results are truncated to int): one v_trunc
+                // instead of a convert pair.  The int copies are only needed for the row tail.
+                Ud = trunc(u_); Vd = trunc(v_);
+            } else { U = (int)u_; V = (int)v_; Ud = U; Vd = V; }
+        } else { Ud = U; Vd = V; }
     }
     int x2 = x1;           // position after the VHS block
     if (VHS) {
@@ -600,8 +607,8 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         // ---- VHS chroma low-pass :1814-1836: value for input x1 lands at x1 - d
         int fU = 0, fV = 0;
         if (in1) {
-            fU = (int)S.vcU.push((double)U, P.a_vc);
-            fV = (int)S.vcV.push((double)V, P.a_vc);
+            fU = (int)S.vcU.push(Ud, P.a_vc);
+            fV = (int)S.vcV.push(Vd, P.a_vc);
             if (EDGE && x1 >= W - 16) {
                 C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
                 C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
@@ -623,10 +630,10 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
             double s = yb;
             s = S.vl.push(s, P.a_vl);
             s += S.vpre.hp(s, P.a_vl) * 1.6;
-            Y = (int)s;
-            // sharpen :1866-1883
+            // Y = (int)s, then sharpen reads it back as a double :1866-1883
             {
-                const double s0 = Y;
+                double s0;
+                if (FAST) s0 = trunc(s); else { Y = (int)s; s0 = Y; }
                 const double ts = S.sh.push(s0, P.a_sh);
                 Y = (int)(s0 + ((s0 - ts) * P.sharpen * 2));
             }
@@ -660,6 +667,24 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     const bool in3 = EDGE ? x3 < W : true;
     if (C.drop || !in3) { U = 0; V = 0; }
     if (!in3) Y = 0;
+    if (FAST) {
+        // PRESET steady state (output low-pass = lite, delay 1): the next step only reads the
+        // previous luma sample; the raw-chroma windows are refilled by the >=16 guarded steps of
+        // the epilogue before anything reads them.  Filter outputs stay doubles (trunc, see above).
+        const double fUd = trunc(S.oU.push((double)U, P.a_tv));
+        const double fVd = trunc(S.oV.push((double)V, P.a_tv));
+        const int Yo = S.Yd[4];                    // luma of the previous step == position xo
+        S.Yd[3] = S.Yd[4]; S.Yd[4] = Y;
+        int r = (int)(((1.000 * Yo) + (0.956 * fUd) + (0.621 * fVd)) / 256);
+        int g = (int)(((1.000 * Yo) + (-0.272 * fUd) + (-0.647 * fVd)) / 256);
+        int b = (int)(((1.000 * Yo) + (-1.106 * fUd) + (1.703 * fVd)) / 256);
+        r = r < 0 ? 0 : (r > 255 ? 255 : r);
+        g = g < 0 ? 0 : (g > 255 ? 255 : g);
+        b = b < 0 ? 0 : (b > 255 ? 255 : b);
+        px = ((uint32_t)r << 16) + ((uint32_t)g << 8) + (uint32_t)b;
+        xo_out = x3 - 1;
+        return true;
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) { S.Yd[q] = S.Yd[q + 1]; S.Ur[q] = S.Ur[q + 1]; S.Vr[q] = S.Vr[q + 1]; }
     S.Yd[4] = Y; S.Ur[4] = U; S.Vr[4] = V;
@@ -716,6 +741,8 @@ DEV bool dec_step_j(const DevParams &P, DecState &S, const DecConst &C, uint32_t
 
 // run-time constants of one lane's decode
 struct DecRun {
+    const int *comp;      // composite plane (uniform) and this lane's column
+    int rc;
     const int *cbase;
     uint32_t *drow;
     uint32_t *ostage;
@@ -778,8 +805,9 @@ DEV int dec_steady(const DevParams &P, DecState &S, const DecConst &C, const Dec
                 // t + 7 < W and t + 4 - LOFF >= 0: plain coalesced loads
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    nc[j] = cbase[(size_t)(t + 4 + j) * P.Rpad];
-                    nl[j] = VHS ? cbase[(size_t)(t + 4 + j - LOFF) * P.Rpad] : 0;
+                    // uniform row base + per-lane column: SGPR base / VGPR offset addressing
+                    nc[j] = (Rn.comp + (size_t)(t + 4 + j) * P.Rpad)[Rn.rc];
+                    nl[j] = VHS ? (Rn.comp + (size_t)(t + 4 + j - LOFF) * P.Rpad)[Rn.rc] : 0;
                 }
             }
             uint32_t o[4];
@@ -917,6 +945,7 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
     // demodulator position at compile time (one loop per parity of the pipeline depth).
     {
         DecRun Rn;
+        Rn.comp = comp; Rn.rc = rc;
         Rn.cbase = cbase; Rn.drow = drow; Rn.ostage = ostage; Rn.is_out = is_out; Rn.hs = hs;
         Rn.tw = tw; Rn.SKT = SKT; Rn.LOFF = LOFF; Rn.any_hs = any_hs;
         if (O::generic) t = dec_steady<VHS, COMPOUT, O, -1>(P, S, C, Rn, ring, t);
