@@ -777,6 +777,108 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     return NTSCSIM_OK;
 }
 
+// ---- host-frame streaming: the field loop for a run of frames in HOST memory ---------------
+// Chunks of frames flow through H2D copy -> kernel chain -> D2H copy on three streams with two
+// chunk slots, so the PCIe transfers of neighbouring chunks overlap the kernels (and each other:
+// the link is full duplex).  The caller's buffers are pinned in place (hipHostRegister) for the
+// duration of the call; if that fails the copies still work, just synchronously.
+extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t src_frame_stride,
+                                   int src_ls, int n_frames, uint8_t *dst, size_t dst_frame_stride,
+                                   int dst_ls, int W, int H, uint64_t first_fieldno, uint32_t flags,
+                                   int chunk_frames)
+{
+    if (!c || !src || !dst || n_frames < 0) return NTSCSIM_E_ARG;
+    if (n_frames == 0) return NTSCSIM_OK;
+    if (src_ls < 4 * W || dst_ls < 4 * W) return NTSCSIM_E_SIZE;
+    if (W < 16 || H < 2) return NTSCSIM_E_SIZE;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (chunk_frames <= 0) chunk_frames = 32;
+    if (chunk_frames > n_frames) chunk_frames = n_frames;
+    const size_t pitch = (((size_t)W * 4 + 255) / 256) * 256;
+    const size_t fbytes = pitch * H;
+    const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (size_t)src_ls * H;
+    const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + (size_t)dst_ls * H;
+    const bool pin_src = hipHostRegister((void *)src, src_span, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_dst = hipHostRegister((void *)dst, dst_span, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+
+    struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr; hipEvent_t up = nullptr, done = nullptr, down = nullptr; bool used = false; };
+    Slot slot[2];
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    int rc = NTSCSIM_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == NTSCSIM_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = NTSCSIM_E_HIP; }
+        return e != hipSuccess;
+    };
+    fail(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate");
+    fail(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking), "hipStreamCreate");
+    for (int i = 0; i < 2 && rc == NTSCSIM_OK; i++) {
+        fail(hipMalloc((void **)&slot[i].dsrc, fbytes * chunk_frames), "hipMalloc");
+        fail(hipMalloc((void **)&slot[i].ddst, fbytes * chunk_frames * 2), "hipMalloc");
+        fail(hipEventCreateWithFlags(&slot[i].up, hipEventDisableTiming), "hipEventCreate");
+        fail(hipEventCreateWithFlags(&slot[i].done, hipEventDisableTiming), "hipEventCreate");
+        fail(hipEventCreateWithFlags(&slot[i].down, hipEventDisableTiming), "hipEventCreate");
+    }
+    std::vector<ntscsim_field_desc> descs((size_t)chunk_frames * 2);
+    uint64_t cur = first_fieldno;
+    int chunk_no = 0;
+    for (int f0 = 0; f0 < n_frames && rc == NTSCSIM_OK; f0 += chunk_frames, chunk_no++) {
+        Slot &sl = slot[chunk_no & 1];
+        const int nf = (n_frames - f0 < chunk_frames) ? n_frames - f0 : chunk_frames;
+        // the slot's previous download must have left the device buffers
+        if (sl.used) { if (fail(hipEventSynchronize(sl.down), "hipEventSynchronize")) break; }
+        // H2D: nf frames, row by row into the device pitch
+        for (int j = 0; j < nf; j++)
+            if (fail(hipMemcpy2DAsync(sl.dsrc + fbytes * j, pitch, src + src_frame_stride * (size_t)(f0 + j),
+                                      (size_t)src_ls, (size_t)W * 4, (size_t)H, hipMemcpyHostToDevice, s_up),
+                     "hipMemcpy2DAsync H2D")) break;
+        if (rc != NTSCSIM_OK) break;
+        fail(hipEventRecord(sl.up, s_up), "hipEventRecord");
+        // kernels on the ctx stream, after the upload
+        fail(hipStreamWaitEvent(c->stream, sl.up, 0), "hipStreamWaitEvent");
+        fail(hipMemsetAsync(sl.ddst, 0, fbytes * nf * 2, c->stream), "hipMemsetAsync");
+        for (int k = 0; k < 2 * nf; k++) {
+            ntscsim_field_desc &d = descs[(size_t)k];
+            std::memset(&d, 0, sizeof(d));
+            d.src_dev = sl.dsrc + fbytes * (size_t)(k / 2);
+            d.dst_dev = sl.ddst + fbytes * (size_t)k;
+            d.src_linesize = (int)pitch; d.dst_linesize = (int)pitch;
+            d.field = (uint32_t)((cur & 1) ^ 1);              // ffmpeg_ntsc.cpp:2229
+            d.flags = flags;
+            d.fieldno = cur++;
+            d.rng_pos = NTSCSIM_RNG_AUTO;
+        }
+        if (rc == NTSCSIM_OK) {
+            const int r2 = ntscsim_fields_device(c, descs.data(), 2 * nf, W, H, c->stream);
+            if (r2 != NTSCSIM_OK) { rc = r2; break; }
+        }
+        fail(hipEventRecord(sl.done, c->stream), "hipEventRecord");
+        // D2H on its own stream, after the kernels
+        fail(hipStreamWaitEvent(s_dn, sl.done, 0), "hipStreamWaitEvent");
+        for (int k = 0; k < 2 * nf && rc == NTSCSIM_OK; k++)
+            fail(hipMemcpy2DAsync(dst + dst_frame_stride * (size_t)(2 * f0 + k), (size_t)dst_ls,
+                                  sl.ddst + fbytes * (size_t)k, pitch, (size_t)W * 4, (size_t)H,
+                                  hipMemcpyDeviceToHost, s_dn), "hipMemcpy2DAsync D2H");
+        fail(hipEventRecord(sl.down, s_dn), "hipEventRecord");
+        sl.used = true;
+    }
+    (void)hipStreamSynchronize(s_up);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(s_dn);
+    for (int i = 0; i < 2; i++) {
+        if (slot[i].dsrc) (void)hipFree(slot[i].dsrc);
+        if (slot[i].ddst) (void)hipFree(slot[i].ddst);
+        if (slot[i].up) (void)hipEventDestroy(slot[i].up);
+        if (slot[i].done) (void)hipEventDestroy(slot[i].done);
+        if (slot[i].down) (void)hipEventDestroy(slot[i].down);
+    }
+    if (s_up) (void)hipStreamDestroy(s_up);
+    if (s_dn) (void)hipStreamDestroy(s_dn);
+    if (pin_src) (void)hipHostUnregister((void *)src);
+    if (pin_dst) (void)hipHostUnregister((void *)dst);
+    return rc;
+}
+
 extern "C" int ntscsim_debug_read_composite(ntscsim_ctx *c, int32_t *out, size_t out_elems)
 {
     if (!c || !out) return NTSCSIM_E_ARG;

@@ -77,6 +77,17 @@ class FieldSimulator:
                                      dst.strides[0], w, h, int(field), int(fieldno))
         self._chk(rc, "ntscsim_field")
 
+    def frames_host(self, dst, src, first_fieldno=0, bob=True, chunk_frames=0):
+        """The field loop over host frames: src numpy uint8 [N, H, W, 4], dst [2N, H, W, 4]."""
+        n, h, w = src.shape[:3]
+        assert dst.shape == (2 * n, h, w, 4) and src.flags.c_contiguous and dst.flags.c_contiguous
+        u8p = C.POINTER(C.c_uint8)
+        rc = self._lib.ntscsim_frames_host(self._h, src.ctypes.data_as(u8p), src.strides[0],
+                                           src.strides[1], n, dst.ctypes.data_as(u8p),
+                                           dst.strides[0], dst.strides[1], w, h, int(first_fieldno),
+                                           DESC_BOB if bob else 0, int(chunk_frames))
+        self._chk(rc, "ntscsim_frames_host")
+
     # ---- batched, device-resident -----------------------------------------------------------
     def build_descs(self, src, dst, jobs, bob=False, interlaced=0, tff=0, rng_pos=None):
         """src, dst: torch uint8 CUDA tensors [N, H, W, 4].  jobs: iterable of

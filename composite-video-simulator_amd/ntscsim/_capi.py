@@ -20,7 +20,8 @@ EXPORTS = (
     "ntscsim_params_init", "ntscsim_cli_init", "ntscsim_params_parse_argv",
     "ntscsim_params_validate", "ntscsim_rng_calls_per_field", "ntscsim_rng_draw",
     "ntscsim_create", "ntscsim_destroy", "ntscsim_strerror", "ntscsim_last_error",
-    "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_fields_device",
+    "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_frames_host",
+    "ntscsim_fields_device",
     "ntscsim_batch_create", "ntscsim_batch_run", "ntscsim_batch_destroy",
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
@@ -145,6 +146,10 @@ def lib():
     L.ntscsim_field.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int,
                                 C.c_int, C.c_int, C.c_uint, C.c_uint64]
     L.ntscsim_field.restype = C.c_int
+    L.ntscsim_frames_host.argtypes = [C.c_void_p, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p,
+                                      C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32,
+                                      C.c_int]
+    L.ntscsim_frames_host.restype = C.c_int
     L.ntscsim_fields_device.argtypes = [C.c_void_p, C.POINTER(FieldDesc), C.c_int, C.c_int,
                                         C.c_int, C.c_void_p]
     L.ntscsim_fields_device.restype = C.c_int

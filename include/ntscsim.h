@@ -178,6 +178,21 @@ int ntscsim_field(ntscsim_ctx *ctx,
                   uint8_t *dst_bgra, int dst_linesize,
                   int width, int height, unsigned field, uint64_t fieldno);
 
+/*
+ * The field loop (ffmpeg_ntsc.cpp:2202-2282) for a run of frames held in HOST memory, pipelined:
+ * source frame j (j = 0..n_frames-1, BGRA, at src + j*src_frame_stride) produces output fields
+ * first_fieldno + 2j and + 2j+1 (field parity (cur&1)^1, :2229), each into its own host frame at
+ * dst + k*dst_frame_stride (k = 0..2*n_frames-1).  Destination frames start zeroed on the device;
+ * with NTSCSIM_DESC_BOB in `flags` every row is then written except the one row bob leaves alone
+ * (the frame-delay ring's, :2248).  Chunks of `chunk_frames` frames (<= 0: default 32) flow
+ * through H2D copy | kernels | D2H copy on three HIP streams; the caller's buffers are pinned for
+ * the duration of the call.  Synchronous; continues the ctx's rand() stream.
+ */
+int ntscsim_frames_host(ntscsim_ctx *ctx, const uint8_t *src, size_t src_frame_stride,
+                        int src_linesize, int n_frames, uint8_t *dst, size_t dst_frame_stride,
+                        int dst_linesize, int width, int height, uint64_t first_fieldno,
+                        uint32_t flags, int chunk_frames);
+
 /* ---- batched, device-resident form (what the field loop :2202-2282 becomes) -------------- */
 
 #define NTSCSIM_RNG_AUTO  UINT64_MAX   /* rng_pos: continue after the previous descriptor      */

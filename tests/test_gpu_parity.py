@@ -344,3 +344,65 @@ def test_unaligned_rows_take_the_scalar_path():
     assert np.array_equal(dst_v[0].cpu().numpy(), e)
     assert not out[0, :, 0].any() and not out[0, :, w + 1:].any()
     sim.close()
+
+
+@pytest.mark.parametrize("flags,w,h,n", [
+    (["-vhs"], 16, 2, 3),            # smallest accepted frame
+    (["-vhs"], 18, 3, 3),            # ragged: width not a multiple of 4, odd height
+    ([], 17, 5, 2),
+    (["-vhs"], 40, 7, 4),            # narrower than the pipeline depth + 16 (no steady state)
+    (["-vhs", "-vhs-speed", "ep", "-out-composite-lowpass-lite", "0"], 52, 6, 2),
+    (["-vhs"], 4096, 6, 2),          # one very long scanline per lane
+    (["-vhs"], 64, 1030, 2),         # more rows than one wave, head switch far inside
+])
+def test_extreme_geometries(flags, w, h, n):
+    p = L.make_params(flags)
+    srcs = [L.noise_frame(w, h, 90 + j) for j in range((n + 1) // 2)]
+    jobs = cases.case_jobs(n)
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    got = run_hip(p, srcs, jobs, h, w, per_field_dst=True)
+    assert np.array_equal(got, exp)
+
+
+def test_many_small_fields_in_one_batch():
+    """Ragged batch: 257 fields of 48x10 (rows of many fields share a wavefront)."""
+    torch = torch_mod()
+    w, h, n = 48, 10, 257
+    p = L.make_params(["-vhs"])
+    frames = np.stack([L.noise_frame(w, h, 500 + j) for j in range((n + 1) // 2)])
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for k in range(n):
+        o.field(exp[k], frames[k // 2], (k & 1) ^ 1, k)
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(frames).cuda()
+    dst = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, dst, [(k // 2, k, (k & 1) ^ 1, k) for k in range(n)])
+    sim.sync()
+    assert np.array_equal(dst.cpu().numpy(), exp)
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+def test_frames_host_streaming_equals_field_loop():
+    """ntscsim_frames_host: pipelined H2D | kernels | D2H over several chunks == the reference's
+    field loop (composite_layer + bob into zeroed frames), rand() stream carried across calls."""
+    w, h, n = 96, 34, 11
+    p = L.make_params(["-vhs"])
+    frames = np.stack([L.noise_frame(w, h, 700 + j) for j in range(n)])
+    o = L.OracleStream(p)
+    exp = np.zeros((2 * n, h, w, 4), np.uint8)
+    for cur in range(2 * n):
+        field = (cur & 1) ^ 1
+        o.field(exp[cur], frames[cur // 2], field, cur)
+        L.oracle().ntsc_oracle_bob(L._ptr(exp[cur]), w * 4, w, h, field)
+    sim = ntscsim.FieldSimulator(params=p)
+    got = np.full((2 * n, h, w, 4), 0xEE, np.uint8)
+    sim.frames_host(got[:8], frames[:4], first_fieldno=0, chunk_frames=3)    # 2 chunks
+    sim.frames_host(got[8:], frames[4:], first_fieldno=8, chunk_frames=2)    # 4 chunks
+    assert np.array_equal(got, exp)
+    assert sim.rng_pos == o.rng_pos
+    sim.close()

@@ -1,0 +1,18 @@
+"""Developer probe: end-to-end (PCIe-inclusive) throughput of ntscsim_frames_host."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import ntscsim, _libs as L
+w, h, n = 720, 486, 300
+p = ntscsim.make_params(["-vhs"])
+src = np.stack([L.bars(w, h, j) for j in range(n)])
+dst = np.zeros((2 * n, h, w, 4), np.uint8)
+sim = ntscsim.FieldSimulator(params=p)
+sim.frames_host(dst[:8], src[:4])
+for ch in (16, 32, 64):
+    t0 = time.perf_counter()
+    sim.frames_host(dst, src, first_fieldno=0, chunk_frames=ch)
+    dt = time.perf_counter() - t0
+    print("chunk %d frames: %d fields in %.3f s = %.0f fields/s (H2D %.1f MB + D2H %.1f MB => %.1f GB/s combined)" % (
+        ch, 2 * n, dt, 2 * n / dt, src.nbytes / 1e6, dst.nbytes / 1e6, (src.nbytes + dst.nbytes) / dt / 1e9))
