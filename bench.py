@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="steps in flight: contexts (own HIP stream, scratch and destination "
                          "clip each) the steps rotate over")
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast32"],
+                    help="exact = bit-identical to the reference (fp64, default); fast32 = fp32 "
+                         "filters within the tolerance of tests/test_gpu_fast_mode.py")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the "
                          "multi-rank path on a box with fewer GPUs than ranks)")
@@ -133,6 +136,9 @@ def main():
     nq = max(1, args.inflight)
     streams = [torch.cuda.Stream(dev) for _ in range(nq)]
     sims = [ntscsim.FieldSimulator(params=params, device=local_rank) for _ in range(nq)]
+    if args.mode == "fast32":
+        for sm in sims:
+            sm.set_mode(ntscsim._capi.MODE_FAST32)
     dsts = [torch.zeros((n_frames_local, h, w, 4), dtype=torch.uint8, device=dev) for _ in range(nq)]
     descs = [sm.build_descs(src, d, loc, rng_pos=[j[3] for j in jobs]) for sm, d in zip(sims, dsts)]
     # prepared batches: descriptor validation, each field's rand() window (a pure function of its
@@ -216,7 +222,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if args.mode == "exact" else "f32",
             "data": "synthetic",
             "config": {
                 "workload": "%dx%d 30fps 10s colour-bars clip (%d frames -> %d fields per GPU per "
@@ -226,7 +232,9 @@ def main():
                 "input_frames_per_sec": value / 2.0,
                 "steps_in_flight": nq,
                 "rank_checksums": [int(c_.item()) for c_ in allcs] if dist is not None else None,
-                "mode": "exact (bit-identical to the reference: fp64, no FMA contraction)",
+                "mode": "exact (bit-identical to the reference: fp64, no FMA contraction)"
+                        if args.mode == "exact" else
+                        "fast32 (fp32 filters; <= 1 LSB per 8-bit channel vs the reference)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -248,7 +256,7 @@ def main():
                                  "Average -- profiles/README.md)" % calls,
             },
         }
-        if world == 1 and args.cpu_fields > 0:
+        if world == 1 and args.cpu_fields > 0 and args.mode == "exact":
             import numpy as np
             ncpu = min(args.cpu_fields, fields_per_step_local)
             # parity spot check on the fields the oracle produces anyway

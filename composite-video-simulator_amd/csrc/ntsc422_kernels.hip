@@ -313,7 +313,8 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     }
     // ---- chroma phase noise :755-781 (u*cos - u*sin, v*cos + v*sin: not a rotation)
     if (P.pnoise_k) {
-        const int n = pn_noise[rc] + P.pnoise_k;
+        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
         const double cosv = G.ptab[2 * n], sinv = G.ptab[2 * n + 1];
         for (int x = 0; x < W2; x++) {
             const double u = (int)R.u(x) - 128, v = (int)R.v(x) - 128;

@@ -81,28 +81,39 @@ struct Opt {
 
 // ------------------------------------------------------------------------------ one-pole IIR
 // LowpassFilter::lowpass / highpass, ffmpeg_ntsc.cpp:90-99 (operation order is the contract)
-struct OnePole {
-    double p;
-    DEV double lp(double s, double a)
+// RT = double: the EXACT mode (bit-identical to the reference).  RT = float: the FAST mode the
+// north star allows for "the filtered signal" (stated tolerance, tests/test_gpu_fast_mode.py):
+// same pipeline, same integer stages and rand() stream, filters in fp32 in the algebraically
+// equal form p += a*(s - p) (one subtract + one FMA per pole instead of two multiplies and two adds).
+template <class RT>
+struct OnePoleT {
+    RT p;
+    DEV RT lp(RT s, RT a)
     {
-        const double s1 = s * a;
-        const double s2 = p - (p * a);
+        const RT s1 = s * a;
+        const RT s2 = p - (p * a);
         p = s1 + s2;
         return p;
     }
-    DEV double hp(double s, double a)
-    {
-        const double s1 = s * a;
-        const double s2 = p - (p * a);
-        p = s1 + s2;
-        return s - p;
-    }
+    DEV RT hp(RT s, RT a) { return s - lp(s, a); }
 };
-struct Lp3 {
-    OnePole f0, f1, f2;
-    DEV void reset(double v) { f0.p = v; f1.p = v; f2.p = v; }
-    DEV double push(double s, double a) { return f2.lp(f1.lp(f0.lp(s, a), a), a); }
+template <>
+struct OnePoleT<float> {
+    float p;
+    DEV float lp(float s, float a) { p = __builtin_fmaf(a, s - p, p); return p; }
+    DEV float hp(float s, float a) { return s - lp(s, a); }
 };
+template <class RT>
+struct Lp3T {
+    OnePoleT<RT> f0, f1, f2;
+    DEV void reset(RT v) { f0.p = v; f1.p = v; f2.p = v; }
+    DEV RT push(RT s, RT a) { return f2.lp(f1.lp(f0.lp(s, a), a), a); }
+};
+using OnePole = OnePoleT<double>;
+using Lp3 = Lp3T<double>;
+template <class RT> DEV RT rtrunc(RT v);
+template <> DEV double rtrunc<double>(double v) { return trunc(v); }
+template <> DEV float rtrunc<float>(float v) { return truncf(v); }
 
 // ------------------------------------------------------------------------------ rand() in LDS
 // Per-lane glibc TYPE_3 generator: the 31-word window lives in LDS as ring[slot][lane]
@@ -347,9 +358,10 @@ DEV void load_px16(const uint8_t *srow, int x0, int W, bool al16, uint32_t (&px)
     }
 }
 
+template <class RT>
 struct EncState {
-    Lp3 lpI, lpQ;
-    OnePole pre;
+    Lp3T<RT> lpI, lpQ;
+    OnePoleT<RT> pre;
     // delay windows: element 0 is the oldest (sample t-4), element 4 the newest (sample t)
     int Yw[5], Iw[5], Qw[5];
     int fI[3];
@@ -359,18 +371,18 @@ struct EncState {
 
 // One encoder step: consumes pixel t, emits composite sample x = t - 4.  EDGE=false is the
 // steady state (4 <= t < W): no row-boundary predicate survives.
-template <bool EDGE, class O>
-DEV void enc_step(const DevParams &P, EncState &S, unsigned xi, int W, uint32_t *ring, int lane,
+template <bool EDGE, class O, class RT>
+DEV void enc_step(const DevParams &P, EncState<RT> &S, unsigned xi, int W, uint32_t *ring, int lane,
                   int t, uint32_t px_in, int *cdst, bool valid)
 {
     // ---- RGB -> YIQ, ffmpeg_ntsc.cpp:1375-1383 (pixels past the row end feed zeros into
     //      filters whose outputs are never used)
     const uint32_t px = (!EDGE || t < W) ? px_in : 0u;
     const int r = (int)((px >> 16) & 0xFF), g = (int)((px >> 8) & 0xFF), b = (int)(px & 0xFF);
-    const double dY = (0.30 * r) + (0.59 * g) + (0.11 * b);
+    const RT dY = (RT(0.30) * r) + (RT(0.59) * g) + (RT(0.11) * b);
     const int Yn = (int)(256 * dY);
-    const int In = (int)(256 * ((-0.27 * (b - dY)) + (0.74 * (r - dY))));
-    const int Qn = (int)(256 * ((0.41 * (b - dY)) + (0.48 * (r - dY))));
+    const int In = (int)(256 * ((RT(-0.27) * (b - dY)) + (RT(0.74) * (r - dY))));
+    const int Qn = (int)(256 * ((RT(0.41) * (b - dY)) + (RT(0.48) * (r - dY))));
 #pragma unroll
     for (int q = 0; q < 4; q++) { S.Yw[q] = S.Yw[q + 1]; S.Iw[q] = S.Iw[q + 1]; S.Qw[q] = S.Qw[q + 1]; }
     S.Yw[4] = Yn; S.Iw[4] = In; S.Qw[4] = Qn;
@@ -379,8 +391,8 @@ DEV void enc_step(const DevParams &P, EncState &S, unsigned xi, int W, uint32_t 
     int fQ = 0;
     if (O::inlp(P)) {
         S.fI[0] = S.fI[1]; S.fI[1] = S.fI[2];
-        S.fI[2] = (int)S.lpI.push((double)In, P.a_in_i);
-        fQ = (int)S.lpQ.push((double)Qn, P.a_in_q);
+        S.fI[2] = (int)S.lpI.push((RT)In, (RT)P.a_in_i);
+        fQ = (int)S.lpQ.push((RT)Qn, (RT)P.a_in_q);
     }
     const int x = t - 4;
     if (EDGE && x < 0) return;
@@ -396,8 +408,8 @@ DEV void enc_step(const DevParams &P, EncState &S, unsigned xi, int W, uint32_t 
     int Y = S.Yw[0] + chroma;
     // ---- composite pre-emphasis :1614-1629
     if (O::pre(P)) {
-        double sd = Y;
-        sd += S.pre.hp(sd, P.a_pre) * P.pre_gain;
+        RT sd = Y;
+        sd += S.pre.hp(sd, (RT)P.a_pre) * (RT)P.pre_gain;
         Y = (int)sd;
     }
     // ---- luma noise :1632-1644
@@ -409,7 +421,7 @@ DEV void enc_step(const DevParams &P, EncState &S, unsigned xi, int W, uint32_t 
     if (valid) cdst[(size_t)x * P.Rpad] = Y;
 }
 
-template <unsigned F>
+template <unsigned F, class RT>
 __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__restrict__ fields,
                                                const uint32_t *__restrict__ rs_luma,
                                                const int *__restrict__ n0_luma,
@@ -434,7 +446,7 @@ __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__re
     const int W = P.W;
     const bool al = P.src_al16 != 0;
 
-    EncState S;
+    EncState<RT> S;
     S.noise = 0;
     if (O::lnoise(P)) {
         S.rng.init(ring, rs_luma + rc, P.Rpad, lane);
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__re
         if (16 < W) load_px16(srow, 16, W, al, nxt);
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            if (j < W + 4) enc_step<true, O>(P, S, xi, W, ring, lane, j, cur[j], cdst, valid);
+            if (j < W + 4) enc_step<true, O, RT>(P, S, xi, W, ring, lane, j, cur[j], cdst, valid);
 #pragma unroll
         for (int j = 0; j < 16; j++) cur[j] = nxt[j];
         t0 = 16;
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__re
         if (t0 + 16 < W) load_px16(srow, t0 + 16, W, al, nxt);
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            enc_step<false, O>(P, S, xi, W, ring, lane, t0 + j, cur[j], cdst, valid);
+            enc_step<false, O, RT>(P, S, xi, W, ring, lane, t0 + j, cur[j], cdst, valid);
 #pragma unroll
         for (int j = 0; j < 16; j++) cur[j] = nxt[j];
     }
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(64) void k_encode(DevParams P, const FieldDev *__re
         if (t0 + 16 < W) load_px16(srow, t0 + 16, W, al, nxt);
 #pragma unroll
         for (int j = 0; j < 16; j++)
-            if (t0 + j < W + 4) enc_step<true, O>(P, S, xi, W, ring, lane, t0 + j, cur[j], cdst, valid);
+            if (t0 + j < W + 4) enc_step<true, O, RT>(P, S, xi, W, ring, lane, t0 + j, cur[j], cdst, valid);
 #pragma unroll
         for (int j = 0; j < 16; j++) cur[j] = nxt[j];
     }
@@ -544,11 +556,12 @@ struct Demod {
 };
 
 // per-lane state of the decode pipeline
+template <class RT>
 struct DecState {
     Demod D1, D2;
     int l0, l1, l2;               // luma stream window (VHS)
-    Lp3 vl, vcU, vcV, sh, oU, oV;
-    OnePole vpre;
+    Lp3T<RT> vl, vcU, vcV, sh, oU, oV;
+    OnePoleT<RT> vpre;
     int Yd[5];                    // luma delayed to the output position (0 oldest)
     int Ur[5], Vr[5];             // raw chroma at the output stage (row tails)
     int Uf[3];                    // filtered U waiting for V (full output low-pass only)
@@ -568,8 +581,8 @@ struct DecConst {
 };
 
 // One pipeline step at stream position t.  Returns true when a pixel for x = *xo was produced.
-template <bool VHS, bool COMPOUT, bool EDGE, class O, int PAR1, int PAR2>
-DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *ring, int t,
+template <bool VHS, bool COMPOUT, bool EDGE, class O, int PAR1, int PAR2, class RT>
+DEV bool dec_step(const DevParams &P, DecState<RT> &S, const DecConst &C, uint32_t *ring, int t,
                   int pc, int pl, uint32_t &px, int &xo_out)
 {
     const int W = C.W;
@@ -580,7 +593,7 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     const int x1 = t - 7;
     const bool in1 = EDGE ? (x1 >= 0 && x1 < W) : true;
     constexpr bool FAST = !EDGE && !O::generic;   // steady state of a PRESET kernel
-    double Ud = 0, Vd = 0;                         // chroma as doubles (== U, V)
+    RT Ud = 0, Vd = 0;                             // chroma as reals (== U, V)
     if (in1) {
         // chroma noise :1719-1735
         if (O::cnoise(P)) {
@@ -590,14 +603,15 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         }
         // chroma phase noise :1748-1762
         if (O::pnoise(P)) {
-            const double u = U, v = V;
-            const double u_ = (u * C.cosv) - (v * C.sinv);
-            const double v_ = (u * C.sinv) + (v * C.cosv);
+            const RT u = U, v = V;
+            const RT cosv = (RT)C.cosv, sinv = (RT)C.sinv;
+            const RT u_ = (u * cosv) - (v * sinv);
+            const RT v_ = (u * sinv) + (v * cosv);
             if (FAST && VHS) {
                 // (double)(int)d == trunc(d) up to the sign of zero, which no later stage can
                 // observe (filters start from +0/16, results are truncated to int): one v_trunc
                 // instead of a convert pair.  The int copies are only needed for the row tail.
-                Ud = trunc(u_); Vd = trunc(v_);
+                Ud = rtrunc<RT>(u_); Vd = rtrunc<RT>(v_);
             } else { U = (int)u_; V = (int)v_; Ud = U; Vd = V; }
         } else { Ud = U; Vd = V; }
     }
@@ -607,8 +621,8 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         // ---- VHS chroma low-pass :1814-1836: value for input x1 lands at x1 - d
         int fU = 0, fV = 0;
         if (in1) {
-            fU = (int)S.vcU.push(Ud, P.a_vc);
-            fV = (int)S.vcV.push(Vd, P.a_vc);
+            fU = (int)S.vcU.push(Ud, (RT)P.a_vc);
+            fV = (int)S.vcV.push(Vd, (RT)P.a_vc);
             if (EDGE && x1 >= W - 16) {
                 C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
                 C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
@@ -627,15 +641,15 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
             }
             U = fU; V = fV;
             // luma low-pass + emphasis :1793-1812
-            double s = yb;
-            s = S.vl.push(s, P.a_vl);
-            s += S.vpre.hp(s, P.a_vl) * 1.6;
+            RT s = yb;
+            s = S.vl.push(s, (RT)P.a_vl);
+            s += S.vpre.hp(s, (RT)P.a_vl) * RT(1.6);
             // Y = (int)s, then sharpen reads it back as a double :1866-1883
             {
-                double s0;
-                if (FAST) s0 = trunc(s); else { Y = (int)s; s0 = Y; }
-                const double ts = S.sh.push(s0, P.a_sh);
-                Y = (int)(s0 + ((s0 - ts) * P.sharpen * 2));
+                RT s0;
+                if (FAST) s0 = rtrunc<RT>(s); else { Y = (int)s; s0 = Y; }
+                const RT ts = S.sh.push(s0, (RT)P.a_sh);
+                Y = (int)(s0 + ((s0 - ts) * (RT)P.sharpen * 2));
             }
         }
         // ---- vertical chroma blend :1843-1863 (wave shift: lane-1 is the row above)
@@ -671,13 +685,13 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         // PRESET steady state (output low-pass = lite, delay 1): the next step only reads the
         // previous luma sample; the raw-chroma windows are refilled by the >=16 guarded steps of
         // the epilogue before anything reads them.  Filter outputs stay doubles (trunc, see above).
-        const double fUd = trunc(S.oU.push((double)U, P.a_tv));
-        const double fVd = trunc(S.oV.push((double)V, P.a_tv));
+        const RT fUd = rtrunc<RT>(S.oU.push((RT)U, (RT)P.a_tv));
+        const RT fVd = rtrunc<RT>(S.oV.push((RT)V, (RT)P.a_tv));
         const int Yo = S.Yd[4];                    // luma of the previous step == position xo
         S.Yd[3] = S.Yd[4]; S.Yd[4] = Y;
-        int r = (int)(((1.000 * Yo) + (0.956 * fUd) + (0.621 * fVd)) / 256);
-        int g = (int)(((1.000 * Yo) + (-0.272 * fUd) + (-0.647 * fVd)) / 256);
-        int b = (int)(((1.000 * Yo) + (-1.106 * fUd) + (1.703 * fVd)) / 256);
+        int r = (int)(((RT(1.000) * Yo) + (RT(0.956) * fUd) + (RT(0.621) * fVd)) / 256);
+        int g = (int)(((RT(1.000) * Yo) + (RT(-0.272) * fUd) + (RT(-0.647) * fVd)) / 256);
+        int b = (int)(((RT(1.000) * Yo) + (RT(-1.106) * fUd) + (RT(1.703) * fVd)) / 256);
         r = r < 0 ? 0 : (r > 255 ? 255 : r);
         g = g < 0 ? 0 : (g > 255 ? 255 : g);
         b = b < 0 ? 0 : (b > 255 ? 255 : b);
@@ -691,10 +705,10 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
     int fU = 0, fV = 0;
     const int out_lp = O::outlp(P);
     if (out_lp && in3) {
-        const double a_u = out_lp == 1 ? P.a_tv : P.a_in_i;
-        const double a_v = out_lp == 1 ? P.a_tv : P.a_in_q;
-        fU = (int)S.oU.push((double)U, a_u);
-        fV = (int)S.oV.push((double)V, a_v);
+        const RT a_u = (RT)(out_lp == 1 ? P.a_tv : P.a_in_i);
+        const RT a_v = (RT)(out_lp == 1 ? P.a_tv : P.a_in_q);
+        fU = (int)S.oU.push((RT)U, a_u);
+        fV = (int)S.oV.push((RT)V, a_v);
     }
     S.Uf[0] = S.Uf[1]; S.Uf[1] = S.Uf[2]; S.Uf[2] = fU;
     const int xo = x3 - SKO;
@@ -712,9 +726,9 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
         Vo = (!EDGE || xo < W - C.dQ) ? fV : Vraw;
     }
     // ================= YIQ -> RGB :1385-1396, pack :1914 (alpha = 0)
-    int r = (int)(((1.000 * Yo) + (0.956 * Uo) + (0.621 * Vo)) / 256);
-    int g = (int)(((1.000 * Yo) + (-0.272 * Uo) + (-0.647 * Vo)) / 256);
-    int b = (int)(((1.000 * Yo) + (-1.106 * Uo) + (1.703 * Vo)) / 256);
+    int r = (int)(((RT(1.000) * Yo) + (RT(0.956) * Uo) + (RT(0.621) * Vo)) / 256);
+    int g = (int)(((RT(1.000) * Yo) + (RT(-0.272) * Uo) + (RT(-0.647) * Vo)) / 256);
+    int b = (int)(((RT(1.000) * Yo) + (RT(-1.106) * Uo) + (RT(1.703) * Vo)) / 256);
     r = r < 0 ? 0 : (r > 255 ? 255 : r);
     g = g < 0 ? 0 : (g > 255 ? 255 : g);
     b = b < 0 ? 0 : (b > 255 ? 255 : b);
@@ -725,18 +739,18 @@ DEV bool dec_step(const DevParams &P, DecState &S, const DecConst &C, uint32_t *
 
 // dec_step for unrolled iteration j of the steady loop (j is a compile-time constant after
 // unrolling, so the switch folds away)
-template <bool VHS, bool COMPOUT, class O, int TP>
-DEV bool dec_step_j(const DevParams &P, DecState &S, const DecConst &C, uint32_t *ring, int t,
+template <bool VHS, bool COMPOUT, class O, int TP, class RT>
+DEV bool dec_step_j(const DevParams &P, DecState<RT> &S, const DecConst &C, uint32_t *ring, int t,
                     int j, int pc, int pl, uint32_t &px, int &xo)
 {
-    if (TP < 0) return dec_step<VHS, COMPOUT, false, O, -1, -1>(P, S, C, ring, t + j, pc, pl, px, xo);
+    if (TP < 0) return dec_step<VHS, COMPOUT, false, O, -1, -1, RT>(P, S, C, ring, t + j, pc, pl, px, xo);
     // PAR1 = (TP + j + 1) & 1, PAR2 = (j + 1) & 1
     if (((TP + j + 1) & 1) == 0) {
-        if (((j + 1) & 1) == 0) return dec_step<VHS, COMPOUT, false, O, 0, 0>(P, S, C, ring, t + j, pc, pl, px, xo);
-        return dec_step<VHS, COMPOUT, false, O, 0, 1>(P, S, C, ring, t + j, pc, pl, px, xo);
+        if (((j + 1) & 1) == 0) return dec_step<VHS, COMPOUT, false, O, 0, 0, RT>(P, S, C, ring, t + j, pc, pl, px, xo);
+        return dec_step<VHS, COMPOUT, false, O, 0, 1, RT>(P, S, C, ring, t + j, pc, pl, px, xo);
     }
-    if (((j + 1) & 1) == 0) return dec_step<VHS, COMPOUT, false, O, 1, 0>(P, S, C, ring, t + j, pc, pl, px, xo);
-    return dec_step<VHS, COMPOUT, false, O, 1, 1>(P, S, C, ring, t + j, pc, pl, px, xo);
+    if (((j + 1) & 1) == 0) return dec_step<VHS, COMPOUT, false, O, 1, 0, RT>(P, S, C, ring, t + j, pc, pl, px, xo);
+    return dec_step<VHS, COMPOUT, false, O, 1, 1, RT>(P, S, C, ring, t + j, pc, pl, px, xo);
 }
 
 // run-time constants of one lane's decode
@@ -753,8 +767,8 @@ struct DecRun {
 // Steady-state loop of k_decode.  TP = parity of the pipeline depth SKT (-1: unknown).  With the
 // preset options (output low-pass delay 1) position parities are: first demodulator x1 = t - 7
 // -> (TP + j + 1) & 1; second demodulator x = t - 14 - d with d = SKT - 15 -> (j + 1) & 1.
-template <bool VHS, bool COMPOUT, class O, int TP>
-DEV int dec_steady(const DevParams &P, DecState &S, const DecConst &C, const DecRun &Rn,
+template <bool VHS, bool COMPOUT, class O, int TP, class RT>
+DEV int dec_steady(const DevParams &P, DecState<RT> &S, const DecConst &C, const DecRun &Rn,
                    uint32_t *ring, int t)
 {
     const int W = C.W;
@@ -814,7 +828,7 @@ DEV int dec_steady(const DevParams &P, DecState &S, const DecConst &C, const Dec
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 int xo;
-                (void)dec_step_j<VHS, COMPOUT, O, TP>(P, S, C, ring, t, j, pc[j], pl[j], o[j], xo);
+                (void)dec_step_j<VHS, COMPOUT, O, TP, RT>(P, S, C, ring, t, j, pc[j], pl[j], o[j], xo);
                 // keep the scheduler from interleaving whole pipeline steps: one step already has
                 // ~10 independent filter chains, and mixing four of them costs >70 extra VGPRs
                 __builtin_amdgcn_sched_barrier(0);
@@ -844,7 +858,7 @@ DEV int dec_steady(const DevParams &P, DecState &S, const DecConst &C, const Dec
     return t;
 }
 
-template <bool VHS, bool COMPOUT, unsigned F>
+template <bool VHS, bool COMPOUT, unsigned F, class RT>
 __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
                                                const FieldDev *__restrict__ fields,
                                                const int *__restrict__ comp,
@@ -894,14 +908,16 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
     C.drop = P.loss ? dropout[rc] != 0 : false;
     C.cosv = 1; C.sinv = 0;
     if (O::pnoise(P)) {
-        const int n = pn_noise[rc] + P.pnoise_k;
+        // (slots past the last row of an odd-height field are never written by k_field_setup)
+        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
         C.cosv = G.ptab[2 * n]; C.sinv = G.ptab[2 * n + 1];
     }
     C.tailU = tails + tcol;
     C.tailV = tails + 16 * tstride + tcol;
     C.rstride = tstride;
 
-    DecState S;
+    DecState<RT> S;
     S.D1.init(); S.D2.init();
     S.l0 = S.l1 = S.l2 = 0;
     S.vl.reset(16); S.vpre.p = 16; S.vcU.reset(0); S.vcV.reset(0); S.sh.reset(0);
@@ -938,7 +954,7 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
     // ---------------- prologue: fill the pipeline (guarded steps)
     for (; t < SKT && t < total; t++) {
         uint32_t px; int xo;
-        (void)dec_step<VHS, COMPOUT, true, O, -1, -1>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo);
+        (void)dec_step<VHS, COMPOUT, true, O, -1, -1, RT>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo);
     }
     // ---------------- steady state: every stage is strictly inside the row, 4 pixels per
     // iteration; ends 16 samples before the row end.  The PRESET kernels know the parity of every
@@ -948,14 +964,14 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
         Rn.comp = comp; Rn.rc = rc;
         Rn.cbase = cbase; Rn.drow = drow; Rn.ostage = ostage; Rn.is_out = is_out; Rn.hs = hs;
         Rn.tw = tw; Rn.SKT = SKT; Rn.LOFF = LOFF; Rn.any_hs = any_hs;
-        if (O::generic) t = dec_steady<VHS, COMPOUT, O, -1>(P, S, C, Rn, ring, t);
-        else if (SKT & 1) t = dec_steady<VHS, COMPOUT, O, 1>(P, S, C, Rn, ring, t);
-        else t = dec_steady<VHS, COMPOUT, O, 0>(P, S, C, Rn, ring, t);
+        if (O::generic) t = dec_steady<VHS, COMPOUT, O, -1, RT>(P, S, C, Rn, ring, t);
+        else if (SKT & 1) t = dec_steady<VHS, COMPOUT, O, 1, RT>(P, S, C, Rn, ring, t);
+        else t = dec_steady<VHS, COMPOUT, O, 0, RT>(P, S, C, Rn, ring, t);
     }
     // ---------------- epilogue: row end, filter tails, pipeline drain (guarded steps)
     for (; t < total; t++) {
         uint32_t px; int xo;
-        if (!dec_step<VHS, COMPOUT, true, O, -1, -1>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
+        if (!dec_step<VHS, COMPOUT, true, O, -1, -1, RT>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
             continue;
         if (!P.dst_al16) { if (is_out) drow[xo] = px; continue; }
         // same 16-pixel staging as the steady loop: whole 64-byte bursts, then the row's tail

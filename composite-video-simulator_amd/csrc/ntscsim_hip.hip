@@ -101,6 +101,7 @@ struct ntscsim_ctx {
     std::vector<EvSet> ev_live, ev_free;
     int warm_override[2] = {0, 0};
     bool force_generic = false;
+    int mode = NTSCSIM_MODE_EXACT;
 };
 
 #define HIPCHK(ctx, call)                                                              \
@@ -348,6 +349,13 @@ extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4], int *n_ca
     return NTSCSIM_OK;
 }
 
+extern "C" int ntscsim_set_mode(ntscsim_ctx *c, int mode)
+{
+    if (!c || (mode != NTSCSIM_MODE_EXACT && mode != NTSCSIM_MODE_FAST32)) return NTSCSIM_E_ARG;
+    c->mode = mode;
+    return NTSCSIM_OK;
+}
+
 extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
 {
     if (c) c->force_generic = on != 0;
@@ -450,19 +458,23 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     // PRESET kernels (options folded at compile time) when the parameters match the default
     // preset or the full -vhs preset exactly; otherwise the GENERIC kernels.  Same results.
     const bool enc_preset = !c->force_generic && D.in_lp && !D.pre_on && D.noise_k != 0 && D.amp == 50;
-    if (enc_preset)
-        hipLaunchKernelGGL((k_encode<F_LNOISE>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
-                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
-    else
-        hipLaunchKernelGGL((k_encode<F_GENERIC>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
-                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    const bool fast = c->mode == NTSCSIM_MODE_FAST32;
+#define NTSC_LAUNCH_ENCODE(F, RT)                                                               \
+    hipLaunchKernelGGL((k_encode<F, RT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,             \
+                       fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p)
+    if (enc_preset) { if (fast) NTSC_LAUNCH_ENCODE(F_LNOISE, float); else NTSC_LAUNCH_ENCODE(F_LNOISE, double); }
+    else { if (fast) NTSC_LAUNCH_ENCODE(F_GENERIC, float); else NTSC_LAUNCH_ENCODE(F_GENERIC, double); }
+#undef NTSC_LAUNCH_ENCODE
     if (evs) HIPCHK(c, hipEventRecord(evs->e[2], st));
     const bool dec_common = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50 &&
                             D.amp_back == 50;
-#define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
-    hipLaunchKernelGGL((k_decode<VHS, CO, F>), dgrid, dim3(64), 0, st, D, G, fields_dev,         \
+#define NTSC_LAUNCH_DECODE_RT(VHS, CO, F, RT)                                                   \
+    hipLaunchKernelGGL((k_decode<VHS, CO, F, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev,     \
                        c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,           \
                        c->pn_noise.p, c->dropout.p, c->tails.p)
+#define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
+    do { if (fast) NTSC_LAUNCH_DECODE_RT(VHS, CO, F, float);                                     \
+         else NTSC_LAUNCH_DECODE_RT(VHS, CO, F, double); } while (0)
     if (!D.vhs) {
         if (dec_common && !D.cnoise_k && !D.pnoise_k) NTSC_LAUNCH_DECODE(false, false, 0u);
         else NTSC_LAUNCH_DECODE(false, false, F_GENERIC);
@@ -473,6 +485,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         else NTSC_LAUNCH_DECODE(true, true, F_GENERIC);
     }
 #undef NTSC_LAUNCH_DECODE
+#undef NTSC_LAUNCH_DECODE_RT
     if (evs) HIPCHK(c, hipEventRecord(evs->e[3], st));
     if (any_bob)
         hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, fields_dev);

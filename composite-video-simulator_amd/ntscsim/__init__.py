@@ -57,6 +57,10 @@ class FieldSimulator:
         if rc != _capi.OK:
             raise NtscsimError(rc, "%s: %s" % (what, self._lib.ntscsim_last_error(self._h).decode()))
 
+    def set_mode(self, mode):
+        """_capi.MODE_EXACT (default, bit-identical to the reference) or _capi.MODE_FAST32."""
+        self._chk(self._lib.ntscsim_set_mode(self._h, int(mode)), "ntscsim_set_mode")
+
     # ---- rand() stream position -----------------------------------------------------------
     @property
     def rng_pos(self):

@@ -13,6 +13,7 @@ PRODUCT_SO = os.path.join(PKG_DIR, "libntscsim.so")
 OK, E_ARG, E_SIZE, E_NODEV, E_HIP, E_NOMEM, E_PARAM, E_FLAG, E_HELP, E_INTERNAL = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 RNG_AUTO = 0xFFFFFFFFFFFFFFFF
+MODE_EXACT, MODE_FAST32 = 0, 1
 DESC_INTERLACED, DESC_TFF, DESC_BOB = 1, 2, 0x100
 
 # every symbol include/ntscsim.h declares
@@ -20,7 +21,7 @@ EXPORTS = (
     "ntscsim_params_init", "ntscsim_cli_init", "ntscsim_params_parse_argv",
     "ntscsim_params_validate", "ntscsim_rng_calls_per_field", "ntscsim_rng_draw",
     "ntscsim_create", "ntscsim_destroy", "ntscsim_strerror", "ntscsim_last_error",
-    "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_frames_host",
+    "ntscsim_set_mode", "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_frames_host",
     "ntscsim_fields_device",
     "ntscsim_batch_create", "ntscsim_batch_run", "ntscsim_batch_destroy",
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
@@ -139,6 +140,8 @@ def lib():
     L.ntscsim_strerror.restype = C.c_char_p
     L.ntscsim_last_error.argtypes = [C.c_void_p]
     L.ntscsim_last_error.restype = C.c_char_p
+    L.ntscsim_set_mode.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_set_mode.restype = C.c_int
     L.ntscsim_get_rng_pos.argtypes = [C.c_void_p]
     L.ntscsim_get_rng_pos.restype = C.c_uint64
     L.ntscsim_set_rng_pos.argtypes = [C.c_void_p, C.c_uint64]

@@ -160,6 +160,18 @@ void ntscsim_destroy(ntscsim_ctx *ctx);
 const char *ntscsim_strerror(int code);
 const char *ntscsim_last_error(const ntscsim_ctx *ctx); /* text of the last HIP failure */
 
+/*
+ * Arithmetic mode of the BGRA path.
+ *   NTSCSIM_MODE_EXACT  (default): fp64 filters in the reference's operation order, no FMA --
+ *                       output bit-identical to composite_layer().
+ *   NTSCSIM_MODE_FAST32: the same pipeline, integer stages and rand() stream, with the filters,
+ *                       the colour matrices and the phase rotation in fp32 (FMA allowed).  Output
+ *                       differs from the reference by at most 1 LSB per 8-bit channel on a small
+ *                       fraction of pixels (bounds in tests/test_gpu_fast_mode.py).
+ */
+enum { NTSCSIM_MODE_EXACT = 0, NTSCSIM_MODE_FAST32 = 1 };
+int ntscsim_set_mode(ntscsim_ctx *ctx, int mode);
+
 /* Stream position of the next field processed through ntscsim_field() (starts at 0, advances
  * by ntscsim_rng_calls_per_field per call -- exactly the reference's process-wide rand()). */
 uint64_t ntscsim_get_rng_pos(const ntscsim_ctx *ctx);
