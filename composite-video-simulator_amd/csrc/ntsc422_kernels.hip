@@ -4,10 +4,11 @@
 //
 // First-cut mapping: same execution model as ntsc_kernels.hip -- ONE LANE =
 // ONE SCANLINE, 63 rows + 1 halo row per wavefront -- but the stage chain is NOT yet fused: every
-// loop of the reference is one sweep of the lane over its row, on byte planes kept TRANSPOSED in
-// HBM scratch (plane[x][slot], slot = wave*64 + lane) so that each wave access is one coalesced
-// 64-byte line.  Every stage clamps to uint8 like the reference (clampu8 :335), so the sweeps
-// communicate through bytes exactly as the reference's in-place frame does.
+// loop of the reference is one sweep of the lane over its row, on byte planes kept TRANSPOSED and
+// PACKED in HBM scratch (four samples per 32-bit word, plane[x>>2][slot], slot = wave*64 + lane),
+// so that each wave access moves two full 128-byte lines.  Every stage clamps to uint8 like the
+// reference (clampu8 :335), so the sweeps communicate through bytes exactly as the reference's
+// in-place frame does.
 //
 // The reference's Y/C separator reads Y[x+2] two bytes past the row (:496, undefined behaviour);
 // here that read returns 16, the box filter's own pre-charge value (oracle: TOCOMP_OOB_DEFINED).
@@ -33,7 +34,7 @@ enum : uint32_t {
 };
 
 struct Scratch422 {
-    uint8_t *Y, *T, *Cc, *U, *V;   // [W][S], [W][S], [W][S], [W/2][S], [W/2][S]
+    uint32_t *Y, *T, *U, *V;       // words of 4 samples: [ceil(W/4)][S] x2, [ceil(W/8)][S] x2
     size_t S;                      // slots = waves * 64
 };
 
@@ -140,81 +141,181 @@ __global__ void k422_bkey(DevParams P, const Field422Dev *__restrict__ fields, i
 }
 
 // ------------------------------------------------------------------------------ the field
-struct Row422 {
-    uint8_t *Y, *T, *Cc, *U, *V;
+// Row planes in HBM scratch: FOUR consecutive samples per 32-bit word, words transposed:
+// plane[x >> 2][slot].  One wave access = 64 lanes x 4 B = two full 128-byte lines.
+struct Plane422 {
+    uint32_t *p;      // this lane's column
     size_t S;
-    DEV uint8_t &y(int x) const { return Y[(size_t)x * S]; }
-    DEV uint8_t &t(int x) const { return T[(size_t)x * S]; }
-    DEV uint8_t &c(int x) const { return Cc[(size_t)x * S]; }
-    DEV uint8_t &u(int x) const { return U[(size_t)x * S]; }
-    DEV uint8_t &v(int x) const { return V[(size_t)x * S]; }
+    DEV uint32_t word(int q) const { return p[(size_t)q * S]; }
+    DEV void set_word(int q, uint32_t w) const { p[(size_t)q * S] = w; }
+    DEV int byte_at(int x) const { return (int)((word(x >> 2) >> (8 * (x & 3))) & 0xFFu); }   // random access
 };
 
-// composite_video_chroma_lowpass :353-393 (full) on one plane of one row
-DEV void chroma_lp_full422(uint8_t *P0, size_t S, int W2, double a_lp, double a_hp, int delay)
+// Sequential byte writer: samples arrive in increasing x, a word is stored when its 4th byte does.
+struct Packer422 {
+    Plane422 pl;
+    uint32_t acc;
+    DEV void begin(const Plane422 &q) { pl = q; acc = 0; }
+    DEV void put(int x, int v)
+    {
+        const uint32_t sh = 8u * (unsigned)(x & 3);
+        acc = (x & 3) ? (acc | ((uint32_t)v << sh)) : (uint32_t)v;
+        if ((x & 3) == 3) pl.set_word(x >> 2, acc);
+    }
+    // n samples were put; positions >= n of the last word keep what the plane holds
+    DEV void finish(int n)
+    {
+        if (n & 3) {
+            const uint32_t mask = (1u << (8 * (n & 3))) - 1u;
+            const uint32_t old = pl.word(n >> 2);
+            pl.set_word(n >> 2, (old & ~mask) | (acc & mask));
+        }
+    }
+};
+
+// Blocks of 8 samples (two words); the next block is requested before the current one is
+// processed, so the memory latency overlaps the filter arithmetic.
+constexpr int BK = 8;
+struct Reader422 {
+    Plane422 pl;
+    int nwords;
+    uint32_t c0, c1, n0, n1;
+    DEV void begin(const Plane422 &q, int n)
+    {
+        pl = q; nwords = (n + 3) >> 2;
+        c0 = nwords > 0 ? pl.word(0) : 0u;
+        c1 = nwords > 1 ? pl.word(1) : 0u;
+        n0 = n1 = 0;
+    }
+    DEV void prefetch(int x0)           // block starting at x0 + 8
+    {
+        const int q = (x0 >> 2) + 2;
+        n0 = q < nwords ? pl.word(q) : 0u;
+        n1 = q + 1 < nwords ? pl.word(q + 1) : 0u;
+    }
+    DEV int get(int j) const { return (int)(((j < 4 ? c0 : c1) >> (8 * (j & 3))) & 0xFFu); }
+    DEV void advance() { c0 = n0; c1 = n1; }
+};
+
+#define SWEEP_BEGIN(PLANE, N)                                                    \
+    {                                                                            \
+        Reader422 rd_; rd_.begin((PLANE), (N));                                  \
+        for (int x0_ = 0; x0_ < (N); x0_ += BK) {                                \
+            rd_.prefetch(x0_);                                                   \
+            _Pragma("unroll") for (int j_ = 0; j_ < BK; j_++) {                  \
+                const int x = x0_ + j_;                                          \
+                if (x >= (N)) break;                                             \
+                const int in = rd_.get(j_);
+#define SWEEP_END                                                                \
+            }                                                                    \
+            rd_.advance();                                                       \
+        }                                                                        \
+    }
+
+struct Row422 {
+    Plane422 Y, T, U, V;
+};
+
+// composite_video_chroma_lowpass :353-393 (full) on one plane of one row: output for input x
+// lands at x - delay; the last `delay` samples keep their input
+DEV void chroma_lp_full422(const Plane422 &P0, int W2, double a_lp, double a_hp, int delay)
 {
     Lp3 lp; lp.reset(128);
     OnePole hp; hp.p = 128;
-    for (int x = 0; x < W2; x++) {
-        double s = P0[(size_t)x * S];
+    Packer422 out; out.begin(P0);
+    SWEEP_BEGIN(P0, W2)
+        double s = in;
         s += hp.hp(s, a_hp);
         s = lp.push(s, a_lp);
-        if (x >= delay) P0[(size_t)(x - delay) * S] = (uint8_t)clampu8((int)s);
-    }
+        if (x >= delay) out.put(x - delay, clampu8((int)s));
+    SWEEP_END
+    out.finish(W2 > delay ? W2 - delay : 0);
 }
 // composite_video_chroma_lowpass_lite :395-431 and the VHS chroma low-pass :834-855
-DEV void chroma_lp_plain422(uint8_t *P0, size_t S, int W2, double a, int delay)
+DEV void chroma_lp_plain422(const Plane422 &P0, int W2, double a, int delay)
 {
     Lp3 lp; lp.reset(128);
-    for (int x = 0; x < W2; x++) {
-        double s = P0[(size_t)x * S];
-        s = lp.push(s, a);
-        if (x >= delay) P0[(size_t)(x - delay) * S] = (uint8_t)clampu8((int)s);
-    }
+    Packer422 out; out.begin(P0);
+    SWEEP_BEGIN(P0, W2)
+        const double s = lp.push((double)in, a);
+        if (x >= delay) out.put(x - delay, clampu8((int)s));
+    SWEEP_END
+    out.finish(W2 > delay ? W2 - delay : 0);
 }
-// composite_video_yuv_to_ntsc :434-477
+// composite_video_yuv_to_ntsc :434-477 (one chroma sample modulates two luma samples)
 DEV void modulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, int amp, bool nocolor)
 {
-    for (int x = 0; x < W; x += 2) {
-        const int cu = (int)R.u(x >> 1) - 128, cv = (int)R.v(x >> 1) - 128;
-        for (int sx = 0; sx < 2 && x + sx < W; sx++) {
-            const unsigned s = (xi + (unsigned)x + (unsigned)sx) & 3u;
-            int chroma = ((s & 1u) ? cv : cu) * amp;
-            if (s & 2u) chroma = -chroma;
-            R.y(x + sx) = (uint8_t)clampu8((int)R.y(x + sx) + chroma / 50);
+    const int W2 = W / 2;
+    Reader422 ru, rv;
+    ru.begin(R.U, W2); rv.begin(R.V, W2);
+    Packer422 oy; oy.begin(R.Y);
+    int cu = 0, cv = 0;
+    // 8 luma samples use 4 chroma samples: the chroma readers advance every other luma block
+    SWEEP_BEGIN(R.Y, W)
+        if (!(x & 1)) {
+            const int cj = (x >> 1) & 7;
+            if (cj == 0 && x > 0) { ru.advance(); rv.advance(); }
+            if (cj == 0) { ru.prefetch(x >> 1); rv.prefetch(x >> 1); }
+            cu = ((x >> 1) < W2 ? ru.get(cj) : 128) - 128;
+            cv = ((x >> 1) < W2 ? rv.get(cj) : 128) - 128;
         }
-        if (nocolor) { R.u(x >> 1) = 128; R.v(x >> 1) = 128; }
+        const unsigned s = (xi + (unsigned)x) & 3u;
+        int chroma = ((s & 1u) ? cv : cu) * amp;
+        if (s & 2u) chroma = -chroma;
+        oy.put(x, clampu8(in + chroma / 50));
+    SWEEP_END
+    oy.finish(W);
+    if (nocolor) {
+        const int nw = (W2 + 3) >> 2;
+        for (int q = 0; q < nw; q++) { R.U.set_word(q, 0x80808080u); R.V.set_word(q, 0x80808080u); }
     }
 }
-// composite_ntsc_to_yuv :480-553 (out-of-row read = 16, out-of-array writes dropped)
+// composite_ntsc_to_yuv :480-553 in ONE sweep (out-of-row read = 16, out-of-array writes dropped).
+// The reference's flip loop (:524-527) negates positions x+2, x+3 for x = (4-xi)&3 + 4m, x < W:
+// position p is flipped iff g = (p-2+xi)&3 is 0 (and p >= 2) or 1 (and p >= 3); flip, rescale
+// (:529-531) and the U/V pick (:535-550) are applied as soon as a pixel pair is complete.
 DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA,
                        bool after_yc_sep)
 {
-    unsigned d0 = 16, d1 = 16, d2 = R.y(0), d3 = R.y(1);
-    unsigned sum = 16 * 2 + d2 + d3;
-    for (int x = 0; x < W; x++) {
-        const unsigned c = (x + 2 < W) ? (unsigned)R.y(x + 2) : 16u;
-        sum -= d0;
-        d0 = d1; d1 = d2; d2 = d3; d3 = c;
-        sum += c;
-        const unsigned yb = (sum / 4u) & 0xFFu;
-        R.y(x) = (uint8_t)yb;
-        const int ch = clampu8((int)c + 128 - (int)yb);
-        R.c(x) = (uint8_t)ch;
-        if (after_yc_sep) { R.y(x) = (uint8_t)ch; R.u(x >> 1) = 128; R.v(x >> 1) = 128; }
-    }
-    if (after_yc_sep) return;
-    for (int x = (int)((4u - xi) & 3u); x < W; x += 4) {
-        if (x + 2 < W) R.c(x + 2) = (uint8_t)(255 - R.c(x + 2));
-        if (x + 3 < W) R.c(x + 3) = (uint8_t)(255 - R.c(x + 3));
-    }
     const int W2 = W / 2;
-    for (int x = 0; x < W2; x++) {
-        const int a = clampu8(sdivm(((int)R.c(2 * x) - 128) * 50, mA) + 128);
-        const int b = clampu8(sdivm(((int)R.c(2 * x + 1) - 128) * 50, mA) + 128);
-        if (xi & 1u) { R.u(x) = (uint8_t)(255 - b); R.v(x) = (uint8_t)(255 - a); }
-        else         { R.u(x) = (uint8_t)(255 - a); R.v(x) = (uint8_t)(255 - b); }
-    }
+    // the reader runs over the row; sample x+2 is needed at step x: keep a 2-sample look-ahead
+    unsigned d0 = 16, d1 = 16, d2 = 0, d3 = 0, sum = 0;
+    int la0 = 16, la1 = 16;            // Y[x], Y[x+1] relative to the reader position
+    int ch_even = 0;
+    Packer422 oy, ou, ov;
+    oy.begin(R.Y); ou.begin(R.U); ov.begin(R.V);
+    // Step the reader position r = x + 2.  Outputs at x = r - 2 go to words the reader has passed.
+    SWEEP_BEGIN(R.Y, W + 2)
+        const int c_in = x < W ? in : 16;          // Y[r] (16 beyond the row)
+        if (x == 0) { d2 = (unsigned)c_in; sum = 32 + d2; }
+        else if (x == 1) { d3 = (unsigned)c_in; sum += d3; }
+        else {
+            const int xo = x - 2;
+            const unsigned c = (unsigned)c_in;
+            sum -= d0;
+            d0 = d1; d1 = d2; d2 = d3; d3 = c;
+            sum += c;
+            const unsigned yb = (sum / 4u) & 0xFFu;
+            int ch = clampu8((int)c + 128 - (int)yb);
+            if (after_yc_sep) {                                  // :503-507
+                oy.put(xo, ch);
+                if (!(xo & 1)) { ou.put(xo >> 1, 128); ov.put(xo >> 1, 128); }
+            } else {
+                oy.put(xo, (int)yb);
+                const unsigned g = (unsigned)(xo - 2 + (int)xi) & 3u;
+                if ((g == 0u && xo >= 2) || (g == 1u && xo >= 3)) ch = 255 - ch;
+                ch = clampu8(sdivm((ch - 128) * 50, mA) + 128);
+                if (!(xo & 1)) ch_even = ch;
+                else {
+                    const int a = ch_even, b = ch;
+                    ou.put(xo >> 1, (xi & 1u) ? 255 - b : 255 - a);
+                    ov.put(xo >> 1, (xi & 1u) ? 255 - a : 255 - b);
+                }
+            }
+        }
+        (void)la0; (void)la1;
+    SWEEP_END
+    oy.finish(W); ou.finish(W2); ov.finish(W2);
 }
 
 __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
@@ -246,55 +347,87 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     const int W = P.W, W2 = P.W / 2;
     const size_t slot = (size_t)blockIdx.x * 64 + lane;
     Row422 R;
-    R.S = Sc.S;
-    R.Y = Sc.Y + slot; R.T = Sc.T + slot; R.Cc = Sc.Cc + slot; R.U = Sc.U + slot; R.V = Sc.V + slot;
+    R.Y.p = Sc.Y + slot; R.T.p = Sc.T + slot; R.U.p = Sc.U + slot; R.V.p = Sc.V + slot;
+    R.Y.S = R.T.S = R.U.S = R.V.S = Sc.S;
     uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
     uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
     uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
 
-    // ---- frame row -> transposed scratch
-    for (int x = 0; x < W; x++) R.y(x) = fy[x];
-    for (int x = 0; x < W2; x++) { R.u(x) = fu[x]; R.v(x) = fv[x]; }
+    // ---- frame row -> packed transposed scratch
+    {
+        Packer422 o; o.begin(R.Y);
+        for (int x0 = 0; x0 < W; x0 += 16) {
+            uint8_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) v[j] = (x0 + j < W) ? fy[x0 + j] : (uint8_t)0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) if (x0 + j < W) o.put(x0 + j, v[j]);
+        }
+        o.finish(W);
+        Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
+        for (int x0 = 0; x0 < W2; x0 += 16) {
+            uint8_t a[16], b[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) { a[j] = (x0 + j < W2) ? fu[x0 + j] : (uint8_t)0; b[j] = (x0 + j < W2) ? fv[x0 + j] : (uint8_t)0; }
+#pragma unroll
+            for (int j = 0; j < 16; j++) if (x0 + j < W2) { ou.put(x0 + j, a[j]); ov.put(x0 + j, b[j]); }
+        }
+        ou.finish(W2); ov.finish(W2);
+    }
 
     // ---- input chroma low-pass :632
     if (P.in_lp) {
-        chroma_lp_full422(R.U, R.S, W2, P.a_in_i, a_hp_i, P.ntsc ? 2 : 2);
-        chroma_lp_full422(R.V, R.S, W2, P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i, P.ntsc ? 4 : 2);
+        chroma_lp_full422(R.U, W2, P.a_in_i, a_hp_i, 2);
+        chroma_lp_full422(R.V, W2, P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i, P.ntsc ? 4 : 2);
     }
     // ---- modulate :633
     modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
     // ---- pre-emphasis :636-651
     if (P.pre_on) {
         OnePole pre; pre.p = 16;
-        for (int x = 0; x < W; x++) {
-            double s = R.y(x);
+        Packer422 o; o.begin(R.Y);
+        SWEEP_BEGIN(R.Y, W)
+            double s = in;
             s += pre.hp(s, P.a_pre) * P.pre_gain;
-            R.y(x) = (uint8_t)clampu8((int)s);
-        }
+            o.put(x, clampu8((int)s));
+        SWEEP_END
+        o.finish(W);
     }
     // ---- luma noise :654-666
     if (P.noise_k) {
         LaneRand rng;
         rng.init(ring, rs_luma + rc, P.Rpad, lane);
         int noise = n0_luma[rc];
-        for (int x = 0; x < W; x++) {
-            R.y(x) = (uint8_t)clampu8((int)R.y(x) + noise);
+        Packer422 o; o.begin(R.Y);
+        SWEEP_BEGIN(R.Y, W)
+            o.put(x, clampu8(in + noise));
             noise = sdiv2(noise + (int)umod31(rng.next(ring, lane), P.m_noise) - P.noise_k);
-        }
+        SWEEP_END
+        o.finish(W);
     }
     // ---- head switching :669-732 (displaced copy, fill value 16)
     if (P.hs) {
         const int hs = hs_shift[rc];
         if (__any(hs != 0)) {
             const int tw = W + W / 10;
-            for (int x = 0; x < W; x++) R.t(x) = R.y(x);
-            for (int x = 0; x < W; x++) {
-                int idx = x + hs;
-                idx += (idx >> 31) & tw;
-                idx -= (idx >= tw) ? tw : 0;
-                const uint8_t v = R.t(idx < W ? idx : W - 1);
-                if (hs != 0) R.y(x) = idx < W ? v : (uint8_t)16;
+            const int nw = (W + 3) >> 2;
+            for (int q = 0; q < nw; q++) R.T.set_word(q, R.Y.word(q));
+            Packer422 o; o.begin(R.Y);
+            for (int x0 = 0; x0 < W; x0 += BK) {
+                int v[BK], ix[BK];
+#pragma unroll
+                for (int j = 0; j < BK; j++) {
+                    int idx = x0 + j + hs;
+                    idx += (idx >> 31) & tw;
+                    idx -= (idx >= tw) ? tw : 0;
+                    ix[j] = idx;
+                    v[j] = R.T.byte_at(idx < W ? idx : W - 1);
+                }
+#pragma unroll
+                for (int j = 0; j < BK; j++)
+                    if (x0 + j < W) o.put(x0 + j, ix[j] < W ? v[j] : 16);
             }
+            o.finish(W);
         }
     }
     // ---- Y/C separation :734
@@ -304,77 +437,106 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
         LaneRand rng;
         rng.init(ring, rs_chroma + rc, P.Rpad, lane);
         int nU = n0_u[rc], nV = n0_v[rc];
-        for (int x = 0; x < W2; x++) {
-            R.u(x) = (uint8_t)clampu8((int)R.u(x) + nU);
-            R.v(x) = (uint8_t)clampu8((int)R.v(x) + nV);
+        Reader422 rv; rv.begin(R.V, W2);
+        Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
+        SWEEP_BEGIN(R.U, W2)
+            if (j_ == 0) rv.prefetch(x0_);
+            ou.put(x, clampu8(in + nU));
+            ov.put(x, clampu8(rv.get(j_) + nV));
             nU = sdiv2(nU + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
             nV = sdiv2(nV + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
-        }
+            if (j_ == BK - 1 || x == W2 - 1) rv.advance();
+        SWEEP_END
+        ou.finish(W2); ov.finish(W2);
     }
     // ---- chroma phase noise :755-781 (u*cos - u*sin, v*cos + v*sin: not a rotation)
     if (P.pnoise_k) {
         int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
         n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
         const double cosv = G.ptab[2 * n], sinv = G.ptab[2 * n + 1];
-        for (int x = 0; x < W2; x++) {
-            const double u = (int)R.u(x) - 128, v = (int)R.v(x) - 128;
+        Reader422 rv; rv.begin(R.V, W2);
+        Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
+        SWEEP_BEGIN(R.U, W2)
+            if (j_ == 0) rv.prefetch(x0_);
+            const double u = in - 128, v = rv.get(j_) - 128;
             const double u_ = (u * cosv) - (u * sinv);
             const double v_ = (v * cosv) + (v * sinv);
-            R.u(x) = (uint8_t)clampu8((int)(u_ + 128));
-            R.v(x) = (uint8_t)clampu8((int)(v_ + 128));
-        }
+            ou.put(x, clampu8((int)(u_ + 128)));
+            ov.put(x, clampu8((int)(v_ + 128)));
+            if (j_ == BK - 1 || x == W2 - 1) rv.advance();
+        SWEEP_END
+        ou.finish(W2); ov.finish(W2);
     }
     // ---- VHS block :786-930
     if (P.vhs) {
         {   // luma low-pass + emphasis :812-831
             Lp3 lp; lp.reset(16);
             OnePole pre; pre.p = 16;
-            for (int x = 0; x < W; x++) {
-                double s = R.y(x);
+            Packer422 o; o.begin(R.Y);
+            SWEEP_BEGIN(R.Y, W)
+                double s = in;
                 s = lp.push(s, P.a_vl);
                 s += pre.hp(s, P.a_vl) * 1.6;
-                R.y(x) = (uint8_t)clampu8((int)s);
-            }
+                o.put(x, clampu8((int)s));
+            SWEEP_END
+            o.finish(W);
         }
-        chroma_lp_plain422(R.U, R.S, W2, P.a_vc, P.cdelay);     // :834-855
-        chroma_lp_plain422(R.V, R.S, W2, P.a_vc, P.cdelay);
-        if (P.vblend && P.ntsc) {                                // :862-882, delay line starts at 128
-            for (int x = 0; x < W2; x++) {
-                const int cU = R.u(x), cV = R.v(x);
-                const int upU = __shfl_up(cU, 1), upV = __shfl_up(cV, 1);
+        chroma_lp_plain422(R.U, W2, P.a_vc, P.cdelay);     // :834-855
+        chroma_lp_plain422(R.V, W2, P.a_vc, P.cdelay);
+        if (P.vblend && P.ntsc) {                            // :862-882, delay line starts at 128
+            // four samples at a time: (a + b + 1) >> 1 per byte, row above via wave shift
+            const int nw = (W2 + 3) >> 2;
+            for (int q = 0; q < nw; q++) {
+                const uint32_t cU = R.U.word(q), cV = R.V.word(q);
+                uint32_t upU = (uint32_t)__shfl_up((int)cU, 1), upV = (uint32_t)__shfl_up((int)cV, 1);
+                if (k < 2) { upU = 0x80808080u; upV = 0x80808080u; }
                 if (k >= 1) {
-                    R.u(x) = (uint8_t)(((k >= 2 ? upU : 128) + cU + 1) >> 1);
-                    R.v(x) = (uint8_t)(((k >= 2 ? upV : 128) + cV + 1) >> 1);
+                    uint32_t oU = 0, oV = 0;
+#pragma unroll
+                    for (int bsel = 0; bsel < 4; bsel++) {
+                        const uint32_t sh = 8u * bsel;
+                        oU |= ((((upU >> sh) & 0xFFu) + ((cU >> sh) & 0xFFu) + 1u) >> 1) << sh;
+                        oV |= ((((upV >> sh) & 0xFFu) + ((cV >> sh) & 0xFFu) + 1u) >> 1) << sh;
+                    }
+                    R.U.set_word(q, oU); R.V.set_word(q, oV);
                 }
             }
         }
         {   // luma sharpen :887-901
             Lp3 lp; lp.reset(16);
-            for (int x = 0; x < W; x++) {
-                const double s = R.y(x);
+            Packer422 o; o.begin(R.Y);
+            SWEEP_BEGIN(R.Y, W)
+                const double s = in;
                 const double ts = lp.push(s, P.a_sh);
-                R.y(x) = (uint8_t)clampu8((int)(s + ((s - ts) * P.sharpen)));
-            }
+                o.put(x, clampu8((int)(s + ((s - ts) * P.sharpen))));
+            SWEEP_END
+            o.finish(W);
         }
         {   // chroma sharpen :904-924
             Lp3 lU, lV; lU.reset(128); lV.reset(128);
-            for (int x = 0; x < W2; x++) {
-                double s = R.u(x);
+            Reader422 rv; rv.begin(R.V, W2);
+            Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
+            SWEEP_BEGIN(R.U, W2)
+                if (j_ == 0) rv.prefetch(x0_);
+                double s = in;
                 double ts = lU.push(s, a_sh_c);
-                R.u(x) = (uint8_t)clampu8((int)(s + ((s - ts) * sharpen_c)));
-                s = R.v(x);
+                ou.put(x, clampu8((int)(s + ((s - ts) * sharpen_c))));
+                s = rv.get(j_);
                 ts = lV.push(s, a_sh_c);
-                R.v(x) = (uint8_t)clampu8((int)(s + ((s - ts) * sharpen_c)));
-            }
+                ov.put(x, clampu8((int)(s + ((s - ts) * sharpen_c))));
+                if (j_ == BK - 1 || x == W2 - 1) rv.advance();
+            SWEEP_END
+            ou.finish(W2); ov.finish(W2);
         }
-        if (!P.svideo) {                                         // :926-929
+        if (!P.svideo) {                                     // :926-929
             modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
             demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0);
         }
     }
     // ---- chroma dropout :932-942
     if (P.loss && dropout[rc]) {
-        for (int x = 0; x < W2; x++) { R.u(x) = 128; R.v(x) = 128; }
+        const int nw = (W2 + 3) >> 2;
+        for (int q = 0; q < nw; q++) { R.U.set_word(q, 0x80808080u); R.V.set_word(q, 0x80808080u); }
     }
     // ---- extra Y/C recombine passes :943-946
     for (int i = 0; i < yc_recombine; i++) {
@@ -383,16 +545,24 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     }
     // ---- output chroma low-pass :948-951 (full if "out", else lite if "lite")
     if (P.out_lp == 2) {
-        chroma_lp_full422(R.U, R.S, W2, P.a_in_i, a_hp_i, 2);
-        chroma_lp_full422(R.V, R.S, W2, P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i, P.ntsc ? 4 : 2);
+        chroma_lp_full422(R.U, W2, P.a_in_i, a_hp_i, 2);
+        chroma_lp_full422(R.V, W2, P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i, P.ntsc ? 4 : 2);
     } else if (P.out_lp == 1) {
-        chroma_lp_plain422(R.U, R.S, W2, P.a_tv, 1);
-        chroma_lp_plain422(R.V, R.S, W2, P.a_tv, 1);
+        chroma_lp_plain422(R.U, W2, P.a_tv, 1);
+        chroma_lp_plain422(R.V, W2, P.a_tv, 1);
     }
-    // ---- transposed scratch -> frame row
+    // ---- packed transposed scratch -> frame row
     if (is_out) {
-        for (int x = 0; x < W; x++) fy[x] = R.y(x);
-        for (int x = 0; x < W2; x++) { fu[x] = R.u(x); fv[x] = R.v(x); }
+        SWEEP_BEGIN(R.Y, W)
+            fy[x] = (uint8_t)in;
+        SWEEP_END
+        Reader422 rv; rv.begin(R.V, W2);
+        SWEEP_BEGIN(R.U, W2)
+            if (j_ == 0) rv.prefetch(x0_);
+            fu[x] = (uint8_t)in;
+            fv[x] = (uint8_t)rv.get(j_);
+            if (j_ == BK - 1 || x == W2 - 1) rv.advance();
+        SWEEP_END
     }
 }
 

@@ -78,7 +78,7 @@ struct ntscsim_ctx {
     DevBuf<FieldDev> fields;
     DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, tails;
     DevBuf<Field422Dev> fields422;
-    DevBuf<uint8_t> scratch422;
+    DevBuf<uint32_t> scratch422;
     std::vector<FieldDev> host_fields;
     std::vector<Field422Dev> host_fields422;
     DevBuf<uint32_t> rs_luma, rs_chroma;
@@ -706,7 +706,8 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     const size_t W2 = (size_t)W / 2;
     HIPCHK(c, c->fields.ensure((size_t)n));
     HIPCHK(c, c->fields422.ensure((size_t)n));
-    HIPCHK(c, c->scratch422.ensure(S * (3 * (size_t)W + 2 * W2) + 256));
+    const size_t Wq = ((size_t)W + 3) / 4 + 2, W2q = (W2 + 3) / 4 + 2;   // words per row (+slack)
+    HIPCHK(c, c->scratch422.ensure(S * (2 * Wq + 2 * W2q) + 256));
     if (D.hs) HIPCHK(c, c->hs_shift.ensure((size_t)D.R));
     if (D.pnoise_k) HIPCHK(c, c->pn_noise.ensure((size_t)D.R));
     if (D.loss) HIPCHK(c, c->dropout.ensure((size_t)D.R));
@@ -729,10 +730,9 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     Scratch422 Sc;
     Sc.S = S;
     Sc.Y = c->scratch422.p;
-    Sc.T = Sc.Y + S * W;
-    Sc.Cc = Sc.T + S * W;
-    Sc.U = Sc.Cc + S * W;
-    Sc.V = Sc.U + S * W2;
+    Sc.T = Sc.Y + S * Wq;
+    Sc.U = Sc.T + S * Wq;
+    Sc.V = Sc.U + S * W2q;
 
     if (any_render)
         hipLaunchKernelGGL(k422_render, dim3((unsigned)((2 * W + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
