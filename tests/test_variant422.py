@@ -94,6 +94,31 @@ def test_black_key_equals_reference_extract():
         assert np.array_equal(d.buf, d2.buf) and np.array_equal(f.buf, f2.buf)
 
 
+import json as _json
+import os as _os
+_G422 = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+_GOLD422 = np.load(_os.path.join(_G422, "tocomp_golden.npz"))
+_MAN422 = _json.load(open(_os.path.join(_G422, "tocomp_golden.json")))["cases"]
+
+
+@pytest.mark.parametrize("m", _MAN422, ids=[m["name"] for m in _MAN422])
+def test_oracle_reproduces_reference_golden(m):
+    """Runs everywhere (also where /root/reference is absent): the oracle in MEMORY mode against
+    whole-buffer snapshots recorded from the reference extract by tests/golden/make_golden422.py."""
+    name, w, h, n = m["name"], m["w"], m["h"], m["n"]
+    p = L.make_params_tocomp(m["flags"])
+    fr = L.Yuv422(w, h)
+    fr.buf[:] = _GOLD422["%s__init" % name]
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        src = L.Yuv422(w, h)
+        src.buf[:] = _GOLD422["%s__src%d" % (name, k // 2)]
+        refresh(fr, src, field)
+        o.process(fr, field, k)
+        assert np.array_equal(fr.buf, _GOLD422["%s__after%d" % (name, k)]), "field %d" % k
+
+
 def test_to_composite_flag_mirror():
     p = L.make_params_tocomp([])
     assert p.vhs_head_switching_phase == 1.0 - ((4.5 + 0.01) / 262.5)          # :274
