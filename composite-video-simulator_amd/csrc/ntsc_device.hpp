@@ -35,6 +35,7 @@ struct DevParams {
     int src_al16, dst_al16;          // all src/dst rows 16-byte aligned
     int warm_luma, warm_chroma;      // warm-up draws used by k_row_states
     int variant;                     // 0 ffmpeg_ntsc (BGRA), 1 ffmpeg_to_composite (YUV422P)
+    int ghost_taps, ghost_delay[4], ghost_gain[4];   // extension (not in the reference)
 };
 
 struct FieldDev {

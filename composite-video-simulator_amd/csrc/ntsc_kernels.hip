@@ -990,6 +990,23 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
     }
 }
 
+// =============================================================================== k_ghost
+// EXTENSION (not in the reference, default off): multipath ghosting of the composite signal,
+// out[x] = in[x] + (sum_k gain_k * in[x - delay_k]) / 256.  Pointwise over the transposed plane:
+// one thread per (x, row), coalesced along rows.
+__global__ void k_ghost(DevParams P, const int *__restrict__ in, int *__restrict__ out)
+{
+    const int rho = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (rho >= P.R) return;
+    int acc = 0;
+    for (int k = 0; k < P.ghost_taps; k++) {
+        const int xs = x - P.ghost_delay[k];
+        if (xs >= 0) acc += P.ghost_gain[k] * in[(size_t)xs * P.Rpad + rho];
+    }
+    out[(size_t)x * P.Rpad + rho] = in[(size_t)x * P.Rpad + rho] + acc / 256;
+}
+
 // =============================================================================== k_bob
 // Line doubling done by the field loop after composite_layer (ffmpeg_ntsc.cpp:2233-2257):
 // field 1: row y (odd) is copied onto row y-1; field 0: row y+1 is copied onto odd row y while

@@ -76,7 +76,7 @@ struct ntscsim_ctx {
 
     // per-batch scratch
     DevBuf<FieldDev> fields;
-    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, tails;
+    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, comp_ghost, tails;
     DevBuf<Field422Dev> fields422;
     DevBuf<uint32_t> scratch422;
     std::vector<FieldDev> host_fields;
@@ -183,6 +183,8 @@ static void fill_dev_params(const ntscsim_params &p, DevParams &D)
     D.sharpen = p.vhs_out_sharpen;
     D.warm_luma = 64;
     D.warm_chroma = 128;
+    D.ghost_taps = p.ghost_taps;
+    for (int k = 0; k < 4; k++) { D.ghost_delay[k] = p.ghost_delay[k]; D.ghost_gain[k] = p.ghost_gain[k]; }
 }
 
 // stream layout of one composite_layer() call
@@ -302,7 +304,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geom.sstart.release(); c->geom.jwarm.release();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->tails.release(); c->fields422.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->tails.release(); c->fields422.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
@@ -465,12 +467,20 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     if (enc_preset) { if (fast) NTSC_LAUNCH_ENCODE(F_LNOISE, float); else NTSC_LAUNCH_ENCODE(F_LNOISE, double); }
     else { if (fast) NTSC_LAUNCH_ENCODE(F_GENERIC, float); else NTSC_LAUNCH_ENCODE(F_GENERIC, double); }
 #undef NTSC_LAUNCH_ENCODE
+    // extension: ghosting between encoder and decoder (reads the raw plane, writes a second one)
+    const int *dec_in = c->comp.p;
+    if (D.ghost_taps > 0) {
+        HIPCHK(c, c->comp_ghost.ensure((size_t)D.Rpad * W));
+        hipLaunchKernelGGL(k_ghost, dim3((D.R + 255) / 256, (unsigned)W), dim3(256), 0, st, D,
+                           c->comp.p, c->comp_ghost.p);
+        dec_in = c->comp_ghost.p;
+    }
     if (evs) HIPCHK(c, hipEventRecord(evs->e[2], st));
     const bool dec_common = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50 &&
                             D.amp_back == 50;
 #define NTSC_LAUNCH_DECODE_RT(VHS, CO, F, RT)                                                   \
     hipLaunchKernelGGL((k_decode<VHS, CO, F, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev,     \
-                       c->comp.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,           \
+                       dec_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,           \
                        c->pn_noise.p, c->dropout.p, c->tails.p)
 #define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
     do { if (fast) NTSC_LAUNCH_DECODE_RT(VHS, CO, F, float);                                     \

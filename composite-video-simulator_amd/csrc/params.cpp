@@ -383,6 +383,11 @@ extern "C" int ntscsim_params_validate(const ntscsim_params *p)
     if (p->output_vhs_tape_speed < NTSCSIM_VHS_SP || p->output_vhs_tape_speed > NTSCSIM_VHS_EP)
         return NTSCSIM_E_PARAM;                                          // reference: abort() :1789
     if (p->tv_standard != NTSCSIM_TV_NTSC && p->tv_standard != NTSCSIM_TV_PAL) return NTSCSIM_E_PARAM;
+    if (p->ghost_taps < 0 || p->ghost_taps > NTSCSIM_MAX_GHOST_TAPS) return NTSCSIM_E_PARAM;
+    for (int k = 0; k < p->ghost_taps; k++) {
+        if (p->ghost_delay[k] < 1 || p->ghost_delay[k] > 4096) return NTSCSIM_E_PARAM;
+        if (p->ghost_gain[k] < -256 || p->ghost_gain[k] > 256) return NTSCSIM_E_PARAM;
+    }
     if (p->vhs_head_switching) {
         // (unsigned)(fmod(x,1.0)*t) with a negative x is UB in the reference
         const double n = p->vhs_head_switching_phase_noise < 0 ? -p->vhs_head_switching_phase_noise

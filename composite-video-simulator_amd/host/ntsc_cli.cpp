@@ -45,7 +45,8 @@ void usage(const char *arg0)
         " -yc-recomb <n>  -nocomp  -422  -420\n"
         " (audio only, accepted: -preemphasis -deemphasis -audio-hiss -vhs-linear-video-crosstalk\n"
         "  -vhs-linear-high-boost)\n"
-        " extra (not in the reference): --batch <fields per GPU batch, default 256> --height <n>\n",
+        " extra (not in the reference): --batch <fields per GPU batch, default 256> --height <n>\n"
+        "                               --ghost <delay px>:<gain/256>  (multipath ghost tap, up to 4)\n",
         arg0);
 }
 
@@ -118,11 +119,18 @@ int main(int argc, char **argv)
 {
     // pull out the two switches the reference does not have, pass the rest to the mirror parser
     int batch_fields = 256, height_override = 0;
+    int ghost_n = 0, ghost_d[4] = {0, 0, 0, 0}, ghost_g[4] = {0, 0, 0, 0};
     std::vector<const char *> av;
     av.push_back(argv[0]);
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) { batch_fields = std::atoi(argv[++i]); continue; }
         if (!std::strcmp(argv[i], "--height") && i + 1 < argc) { height_override = std::atoi(argv[++i]); continue; }
+        if (!std::strcmp(argv[i], "--ghost") && i + 1 < argc) {       // extension: <delay>:<gain/256>
+            int dd = 0, gg = 0;
+            if (std::sscanf(argv[++i], "%d:%d", &dd, &gg) != 2 || ghost_n >= 4) { std::fprintf(stderr, "bad --ghost\n"); return 1; }
+            ghost_d[ghost_n] = dd; ghost_g[ghost_n] = gg; ghost_n++;
+            continue;
+        }
         av.push_back(argv[i]);
     }
     ntscsim_params prm;
@@ -133,6 +141,8 @@ int main(int argc, char **argv)
     if (rc == NTSCSIM_E_HELP) { usage(argv[0]); return 1; }
     if (rc != NTSCSIM_OK) return 1;
     if (height_override > 0) prm.output_height = height_override;
+    prm.ghost_taps = ghost_n;
+    for (int k = 0; k < ghost_n; k++) { prm.ghost_delay[k] = ghost_d[k]; prm.ghost_gain[k] = ghost_g[k]; }
     if (batch_fields < 2) batch_fields = 2;
     batch_fields &= ~1;
     const int W = prm.output_width, H = prm.output_height;

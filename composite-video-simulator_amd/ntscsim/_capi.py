@@ -68,6 +68,10 @@ class Params(C.Structure):
         ("output_vhs_tape_speed", C.c_int32),
         ("black_key_level_feedback", C.c_int32),
         ("vhs_out_sharpen_chroma", C.c_double),
+        ("ghost_taps", C.c_int32),
+        ("ghost_delay", C.c_int32 * 4),
+        ("ghost_gain", C.c_int32 * 4),
+        ("_pad1", C.c_int32),
     ]
 
 

@@ -92,7 +92,17 @@ typedef struct ntscsim_params {
     int32_t  output_vhs_tape_speed;       /* :809  NTSCSIM_VHS_SP                               */
     int32_t  black_key_level_feedback;    /* ffmpeg_to_composite.cpp:322  -1 (variant only)      */
     double   vhs_out_sharpen_chroma;      /* ffmpeg_to_composite.cpp:271  0.85 (variant only)    */
+    /* EXTENSION, not in the reference (SURVEY 0.3 / 8(f) "ext"): multipath ghosting on the
+     * composite signal, between the luma-noise stage (:1644) and head switching (:1647):
+     *   Y'[x] = Y[x] + ( sum_k ghost_gain[k] * Y[x - ghost_delay[k]] ) / 256      (Y[<0] = 0)
+     * taps read the un-ghosted signal (FIR), C integer arithmetic.  ghost_taps = 0 (default)
+     * disables it and leaves the output bit-identical to the reference.  BGRA path only. */
+    int32_t  ghost_taps;                  /* 0..NTSCSIM_MAX_GHOST_TAPS                           */
+    int32_t  ghost_delay[4];              /* samples, 1..4096                                    */
+    int32_t  ghost_gain[4];               /* 1/256 units, -256..256                              */
+    int32_t  _pad1;
 } ntscsim_params;
+#define NTSCSIM_MAX_GHOST_TAPS 4
 
 /* Host-side (L4/L2) settings parse_argv() also fills; not read by the field DSP. */
 #define NTSCSIM_MAX_INPUTS 16

@@ -303,6 +303,23 @@ int ntsc_oracle_field(const ntscsim_params *p, ntsc_oracle_rng *g,
     }
     tap(taps->composite_y, fY, n);
 
+    /* EXTENSION (not in the reference; default off): multipath ghosting, see ntscsim.h */
+    if (p->ghost_taps > 0) {
+        int32_t *raw = (int32_t *)malloc(((size_t)W + 1) * sizeof(int32_t));
+        int gk;
+        for (k = 0; k < L && raw; k++) {
+            int32_t *Y = ROWY(k);
+            memcpy(raw, Y, (size_t)W * sizeof(int32_t));
+            for (x = 0; x < W; x++) {
+                int acc = 0;
+                for (gk = 0; gk < p->ghost_taps; gk++)
+                    if (x - p->ghost_delay[gk] >= 0) acc += p->ghost_gain[gk] * raw[x - p->ghost_delay[gk]];
+                Y[x] = raw[x] + acc / 256;
+            }
+        }
+        free(raw);
+    }
+
     /* VHS head switching :1647-1713 */
     if (p->vhs_head_switching) {
         unsigned twidth = (unsigned)W + ((unsigned)W / 10u);

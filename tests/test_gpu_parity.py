@@ -406,3 +406,33 @@ def test_frames_host_streaming_equals_field_loop():
     assert np.array_equal(got, exp)
     assert sim.rng_pos == o.rng_pos
     sim.close()
+
+
+@pytest.mark.parametrize("flags", [[], ["-vhs"], ["-vhs", "-vhs-head-switching-point", "0.105",
+                                                  "-vhs-head-switching-phase", "0.002"]])
+def test_ghosting_extension(flags):
+    """EXTENSION (absent from the reference): multipath ghost taps on the composite
+    signal.  No reference to pin against -- the oracle's own definition is the spec ("parity
+    unpinned"); with ghost_taps = 0 (default) every other test shows the output is unchanged."""
+    w, h, n = 96, 32, 4
+    p = L.make_params(flags)
+    p.ghost_taps = 3
+    for k, (d, g) in enumerate(((7, 64), (19, -32), (40, 12))):
+        p.ghost_delay[k] = d
+        p.ghost_gain[k] = g
+    srcs = [L.noise_frame(w, h, 61 + j) for j in range(2)]
+    jobs = cases.case_jobs(n)
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    got = run_hip(p, srcs, jobs, h, w, per_field_dst=True)
+    assert np.array_equal(got, exp)
+    # and it does change the picture
+    p0 = L.make_params(flags)
+    base = run_hip(p0, srcs, jobs, h, w, per_field_dst=True)
+    assert not np.array_equal(base, got)
+    bad = L.make_params(flags)
+    bad.ghost_taps = 1
+    bad.ghost_delay[0] = 0
+    assert L.product().ntscsim_params_validate(C.byref(bad)) == _capi.E_PARAM
