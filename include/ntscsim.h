@@ -164,7 +164,10 @@ void ntscsim_rng_draw(uint64_t pos, size_t n, uint32_t *out);
 typedef struct ntscsim_ctx ntscsim_ctx;
 
 /* Bind to HIP device `device` (ordinal), snapshot `p`.  Fails with NTSCSIM_E_NODEV when no
- * GPU is present: there is NO CPU fallback in this library. */
+ * GPU is present: there is NO CPU fallback in this library.
+ * Threading: a ctx (and the batches created from it) is NOT re-entrant -- one thread at a time
+ * per ctx, like the reference's globals + process-wide rand(); use one ctx per thread / stream.
+ * Work enqueued through one ctx is ordered by the caller's stream; its scratch is reused. */
 int  ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx **out);
 void ntscsim_destroy(ntscsim_ctx *ctx);
 const char *ntscsim_strerror(int code);
