@@ -831,7 +831,9 @@ DEV int dec_steady(const DevParams &P, DecState<RT> &S, const DecConst &C, const
                 (void)dec_step_j<VHS, COMPOUT, O, TP, RT>(P, S, C, ring, t, j, pc[j], pl[j], o[j], xo);
                 // keep the scheduler from interleaving whole pipeline steps: one step already has
                 // ~10 independent filter chains, and mixing four of them costs >70 extra VGPRs
+#ifndef NTSC_NO_STEP_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
             // stage 4 pixels; every 4th iteration write the lane's 16 pixels as one 64-byte burst
             {
