@@ -236,7 +236,8 @@ typedef struct ntscsim_field_desc {
 
 #define NTSCSIM_DESC_INTERLACED 1u
 #define NTSCSIM_DESC_TFF        2u
-#define NTSCSIM_DESC_BOB        0x100u
+#define NTSCSIM_DESC_BOB        0x100u   /* bob writes the OTHER field's rows of dst_dev: give every
+                                            descriptor of a batch its own destination frame */
 
 /*
  * Process `n` independent fields of one geometry.  All pointers in `descs` are DEVICE pointers
