@@ -242,8 +242,20 @@ DEV void chroma_lp_plain422(const Plane422 &P0, int W2, double a, int delay)
     SWEEP_END
     out.finish(W2 > delay ? W2 - delay : 0);
 }
+// Post-stages that are pointwise/causal on the freshly modulated luma and can therefore ride in
+// the modulation sweep: pre-emphasis :636-651 and luma noise :654-666 (each with its own clamp).
+struct LumaPost422 {
+    bool pre_on, noise_on;
+    OnePole pre;
+    LaneRand rng;
+    int noise;
+    uint32_t *ring;
+    int lane;
+};
+
 // composite_video_yuv_to_ntsc :434-477 (one chroma sample modulates two luma samples)
-DEV void modulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, int amp, bool nocolor)
+DEV void modulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, int amp, bool nocolor,
+                     LumaPost422 *post = nullptr)
 {
     const int W2 = W / 2;
     Reader422 ru, rv;
@@ -262,7 +274,19 @@ DEV void modulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, in
         const unsigned s = (xi + (unsigned)x) & 3u;
         int chroma = ((s & 1u) ? cv : cu) * amp;
         if (s & 2u) chroma = -chroma;
-        oy.put(x, clampu8(in + chroma / 50));
+        int yv = clampu8(in + chroma / 50);
+        if (post) {
+            if (post->pre_on) {
+                double sd = yv;
+                sd += post->pre.hp(sd, P.a_pre) * P.pre_gain;
+                yv = clampu8((int)sd);
+            }
+            if (post->noise_on) {
+                yv = clampu8(yv + post->noise);
+                post->noise = sdiv2(post->noise + (int)umod31(post->rng.next(post->ring, post->lane), P.m_noise) - P.noise_k);
+            }
+        }
+        oy.put(x, yv);
     SWEEP_END
     oy.finish(W);
     if (nocolor) {
@@ -274,8 +298,36 @@ DEV void modulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, in
 // The reference's flip loop (:524-527) negates positions x+2, x+3 for x = (4-xi)&3 + 4m, x < W:
 // position p is flipped iff g = (p-2+xi)&3 is 0 (and p >= 2) or 1 (and p >= 3); flip, rescale
 // (:529-531) and the U/V pick (:535-550) are applied as soon as a pixel pair is complete.
+// Chroma post-stages riding in the Y/C separation sweep: chroma noise :738-754 and the phase
+// noise :755-781 (pointwise on the samples the separator has just produced, each with its clamp).
+struct ChromaPost422 {
+    bool noise_on, phase_on;
+    LaneRand rng;
+    int nU, nV;
+    double cosv, sinv;
+    uint32_t *ring;
+    int lane;
+};
+DEV void chroma_post422(const DevParams &P, ChromaPost422 *cp, int &u, int &v)
+{
+    if (!cp) return;
+    if (cp->noise_on) {
+        u = clampu8(u + cp->nU);
+        v = clampu8(v + cp->nV);
+        cp->nU = sdiv2(cp->nU + (int)umod31(cp->rng.next(cp->ring, cp->lane), P.m_cnoise) - P.cnoise_k);
+        cp->nV = sdiv2(cp->nV + (int)umod31(cp->rng.next(cp->ring, cp->lane), P.m_cnoise) - P.cnoise_k);
+    }
+    if (cp->phase_on) {
+        const double du = u - 128, dv = v - 128;
+        const double u_ = (du * cp->cosv) - (du * cp->sinv);
+        const double v_ = (dv * cp->cosv) + (dv * cp->sinv);
+        u = clampu8((int)(u_ + 128));
+        v = clampu8((int)(v_ + 128));
+    }
+}
+
 DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA,
-                       bool after_yc_sep)
+                       bool after_yc_sep, ChromaPost422 *cpost = nullptr)
 {
     const int W2 = W / 2;
     // the reader runs over the row; sample x+2 is needed at step x: keep a 2-sample look-ahead
@@ -299,7 +351,7 @@ DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, 
             int ch = clampu8((int)c + 128 - (int)yb);
             if (after_yc_sep) {                                  // :503-507
                 oy.put(xo, ch);
-                if (!(xo & 1)) { ou.put(xo >> 1, 128); ov.put(xo >> 1, 128); }
+                if (!(xo & 1)) { int u = 128, v = 128; chroma_post422(P, cpost, u, v); ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
             } else {
                 oy.put(xo, (int)yb);
                 const unsigned g = (unsigned)(xo - 2 + (int)xi) & 3u;
@@ -308,8 +360,10 @@ DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, 
                 if (!(xo & 1)) ch_even = ch;
                 else {
                     const int a = ch_even, b = ch;
-                    ou.put(xo >> 1, (xi & 1u) ? 255 - b : 255 - a);
-                    ov.put(xo >> 1, (xi & 1u) ? 255 - a : 255 - b);
+                    int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
+                    chroma_post422(P, cpost, u, v);
+                    ou.put(xo >> 1, u);
+                    ov.put(xo >> 1, v);
                 }
             }
         }
@@ -353,25 +407,30 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
     uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
 
-    // ---- frame row -> packed transposed scratch
+    // ---- frame row -> packed transposed scratch.  A scratch word holds 4 consecutive samples in
+    // memory order, so aligned rows are moved 16 (luma) / 8 (chroma) bytes per lane per load.
     {
+        int x0 = 0;
+        if (P.src_al16)
+            for (; x0 + 16 <= W; x0 += 16) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(fy + x0);
+                const int q = x0 >> 2;
+                R.Y.set_word(q, v.x); R.Y.set_word(q + 1, v.y); R.Y.set_word(q + 2, v.z); R.Y.set_word(q + 3, v.w);
+            }
         Packer422 o; o.begin(R.Y);
-        for (int x0 = 0; x0 < W; x0 += 16) {
-            uint8_t v[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) v[j] = (x0 + j < W) ? fy[x0 + j] : (uint8_t)0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) if (x0 + j < W) o.put(x0 + j, v[j]);
-        }
+        for (; x0 < W; x0++) o.put(x0, fy[x0]);
         o.finish(W);
+        int c0 = 0;
+        if (P.dst_al16)
+            for (; c0 + 8 <= W2; c0 += 8) {
+                const uint2 a = *reinterpret_cast<const uint2 *>(fu + c0);
+                const uint2 b = *reinterpret_cast<const uint2 *>(fv + c0);
+                const int q = c0 >> 2;
+                R.U.set_word(q, a.x); R.U.set_word(q + 1, a.y);
+                R.V.set_word(q, b.x); R.V.set_word(q + 1, b.y);
+            }
         Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
-        for (int x0 = 0; x0 < W2; x0 += 16) {
-            uint8_t a[16], b[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) { a[j] = (x0 + j < W2) ? fu[x0 + j] : (uint8_t)0; b[j] = (x0 + j < W2) ? fv[x0 + j] : (uint8_t)0; }
-#pragma unroll
-            for (int j = 0; j < 16; j++) if (x0 + j < W2) { ou.put(x0 + j, a[j]); ov.put(x0 + j, b[j]); }
-        }
+        for (; c0 < W2; c0++) { ou.put(c0, fu[c0]); ov.put(c0, fv[c0]); }
         ou.finish(W2); ov.finish(W2);
     }
 
@@ -380,30 +439,13 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
         chroma_lp_full422(R.U, W2, P.a_in_i, a_hp_i, 2);
         chroma_lp_full422(R.V, W2, P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i, P.ntsc ? 4 : 2);
     }
-    // ---- modulate :633
-    modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
-    // ---- pre-emphasis :636-651
-    if (P.pre_on) {
-        OnePole pre; pre.p = 16;
-        Packer422 o; o.begin(R.Y);
-        SWEEP_BEGIN(R.Y, W)
-            double s = in;
-            s += pre.hp(s, P.a_pre) * P.pre_gain;
-            o.put(x, clampu8((int)s));
-        SWEEP_END
-        o.finish(W);
-    }
-    // ---- luma noise :654-666
-    if (P.noise_k) {
-        LaneRand rng;
-        rng.init(ring, rs_luma + rc, P.Rpad, lane);
-        int noise = n0_luma[rc];
-        Packer422 o; o.begin(R.Y);
-        SWEEP_BEGIN(R.Y, W)
-            o.put(x, clampu8(in + noise));
-            noise = sdiv2(noise + (int)umod31(rng.next(ring, lane), P.m_noise) - P.noise_k);
-        SWEEP_END
-        o.finish(W);
+    // ---- modulate :633 + pre-emphasis :636-651 + luma noise :654-666 in one sweep
+    {
+        LumaPost422 lp_;
+        lp_.pre_on = P.pre_on != 0; lp_.noise_on = P.noise_k != 0;
+        lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
+        if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
+        modulate422(P, R, W, xi, P.amp, P.nocolor != 0, &lp_);
     }
     // ---- head switching :669-732 (displaced copy, fill value 16)
     if (P.hs) {
@@ -430,101 +472,88 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
             o.finish(W);
         }
     }
-    // ---- Y/C separation :734
-    if (!P.nocolor) demodulate422(P, R, W, xi, P.m_amp_back, after_yc_sep != 0);
-    // ---- chroma noise :738-754
-    if (P.cnoise_k) {
-        LaneRand rng;
-        rng.init(ring, rs_chroma + rc, P.Rpad, lane);
-        int nU = n0_u[rc], nV = n0_v[rc];
-        Reader422 rv; rv.begin(R.V, W2);
-        Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
-        SWEEP_BEGIN(R.U, W2)
-            if (j_ == 0) rv.prefetch(x0_);
-            ou.put(x, clampu8(in + nU));
-            ov.put(x, clampu8(rv.get(j_) + nV));
-            nU = sdiv2(nU + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
-            nV = sdiv2(nV + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
-            if (j_ == BK - 1 || x == W2 - 1) rv.advance();
-        SWEEP_END
-        ou.finish(W2); ov.finish(W2);
-    }
-    // ---- chroma phase noise :755-781 (u*cos - u*sin, v*cos + v*sin: not a rotation)
-    if (P.pnoise_k) {
-        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
-        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
-        const double cosv = G.ptab[2 * n], sinv = G.ptab[2 * n + 1];
-        Reader422 rv; rv.begin(R.V, W2);
-        Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
-        SWEEP_BEGIN(R.U, W2)
-            if (j_ == 0) rv.prefetch(x0_);
-            const double u = in - 128, v = rv.get(j_) - 128;
-            const double u_ = (u * cosv) - (u * sinv);
-            const double v_ = (v * cosv) + (v * sinv);
-            ou.put(x, clampu8((int)(u_ + 128)));
-            ov.put(x, clampu8((int)(v_ + 128)));
-            if (j_ == BK - 1 || x == W2 - 1) rv.advance();
-        SWEEP_END
-        ou.finish(W2); ov.finish(W2);
+    // ---- Y/C separation :734 + chroma noise :738-754 + phase noise :755-781
+    {
+        ChromaPost422 cp_;
+        cp_.noise_on = P.cnoise_k != 0; cp_.phase_on = P.pnoise_k != 0;
+        cp_.nU = cp_.nV = 0; cp_.cosv = 1; cp_.sinv = 0; cp_.ring = ring; cp_.lane = lane;
+        if (cp_.noise_on) { cp_.rng.init(ring, rs_chroma + rc, P.Rpad, lane); cp_.nU = n0_u[rc]; cp_.nV = n0_v[rc]; }
+        if (cp_.phase_on) {
+            int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+            n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+            cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
+        }
+        if (!P.nocolor) demodulate422(P, R, W, xi, P.m_amp_back, after_yc_sep != 0, &cp_);
+        else if (cp_.noise_on || cp_.phase_on) {
+            // no separation (-nocolor-subcarrier): the noise stages still run on the stored chroma
+            Reader422 rv; rv.begin(R.V, W2);
+            Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
+            SWEEP_BEGIN(R.U, W2)
+                if (j_ == 0) rv.prefetch(x0_);
+                int u = in, v = rv.get(j_);
+                chroma_post422(P, &cp_, u, v);
+                ou.put(x, u); ov.put(x, v);
+                if (j_ == BK - 1 || x == W2 - 1) rv.advance();
+            SWEEP_END
+            ou.finish(W2); ov.finish(W2);
+        }
     }
     // ---- VHS block :786-930
     if (P.vhs) {
-        {   // luma low-pass + emphasis :812-831
+        {   // luma low-pass + emphasis :812-831, then sharpen :887-901 (both causal: one sweep)
             Lp3 lp; lp.reset(16);
             OnePole pre; pre.p = 16;
+            Lp3 sh; sh.reset(16);
             Packer422 o; o.begin(R.Y);
             SWEEP_BEGIN(R.Y, W)
                 double s = in;
                 s = lp.push(s, P.a_vl);
                 s += pre.hp(s, P.a_vl) * 1.6;
-                o.put(x, clampu8((int)s));
+                const double y1 = clampu8((int)s);
+                const double ts = sh.push(y1, P.a_sh);
+                o.put(x, clampu8((int)(y1 + ((y1 - ts) * P.sharpen))));
             SWEEP_END
             o.finish(W);
         }
-        chroma_lp_plain422(R.U, W2, P.a_vc, P.cdelay);     // :834-855
-        chroma_lp_plain422(R.V, W2, P.a_vc, P.cdelay);
-        if (P.vblend && P.ntsc) {                            // :862-882, delay line starts at 128
-            // four samples at a time: (a + b + 1) >> 1 per byte, row above via wave shift
-            const int nw = (W2 + 3) >> 2;
-            for (int q = 0; q < nw; q++) {
-                const uint32_t cU = R.U.word(q), cV = R.V.word(q);
-                uint32_t upU = (uint32_t)__shfl_up((int)cU, 1), upV = (uint32_t)__shfl_up((int)cV, 1);
-                if (k < 2) { upU = 0x80808080u; upV = 0x80808080u; }
-                if (k >= 1) {
-                    uint32_t oU = 0, oV = 0;
-#pragma unroll
-                    for (int bsel = 0; bsel < 4; bsel++) {
-                        const uint32_t sh = 8u * bsel;
-                        oU |= ((((upU >> sh) & 0xFFu) + ((cU >> sh) & 0xFFu) + 1u) >> 1) << sh;
-                        oV |= ((((upV >> sh) & 0xFFu) + ((cV >> sh) & 0xFFu) + 1u) >> 1) << sh;
-                    }
-                    R.U.set_word(q, oU); R.V.set_word(q, oV);
-                }
-            }
-        }
-        {   // luma sharpen :887-901
-            Lp3 lp; lp.reset(16);
-            Packer422 o; o.begin(R.Y);
-            SWEEP_BEGIN(R.Y, W)
-                const double s = in;
-                const double ts = lp.push(s, P.a_sh);
-                o.put(x, clampu8((int)(s + ((s - ts) * P.sharpen))));
-            SWEEP_END
-            o.finish(W);
-        }
-        {   // chroma sharpen :904-924
-            Lp3 lU, lV; lU.reset(128); lV.reset(128);
+        {   // chroma low-pass :834-855 (output lands d samples back, the last d keep their input)
+            // -> vertical blend :862-882 -> chroma sharpen :904-924, all in output order
+            const int d = P.cdelay;
+            const bool blend = P.vblend && P.ntsc;
+            Lp3 lU, lV, sU, sV;
+            lU.reset(128); lV.reset(128); sU.reset(128); sV.reset(128);
+            int wu[7] = {0, 0, 0, 0, 0, 0, 0}, wv[7] = {0, 0, 0, 0, 0, 0, 0};   // last 7 inputs, [6] newest
             Reader422 rv; rv.begin(R.V, W2);
             Packer422 ou, ov; ou.begin(R.U); ov.begin(R.V);
-            SWEEP_BEGIN(R.U, W2)
+            SWEEP_BEGIN(R.U, W2 + d)
                 if (j_ == 0) rv.prefetch(x0_);
-                double s = in;
-                double ts = lU.push(s, a_sh_c);
-                ou.put(x, clampu8((int)(s + ((s - ts) * sharpen_c))));
-                s = rv.get(j_);
-                ts = lV.push(s, a_sh_c);
-                ov.put(x, clampu8((int)(s + ((s - ts) * sharpen_c))));
-                if (j_ == BK - 1 || x == W2 - 1) rv.advance();
+                const int inV = rv.get(j_);
+                int fU = 0, fV = 0;
+                if (x < W2) {
+                    fU = clampu8((int)lU.push((double)in, P.a_vc));
+                    fV = clampu8((int)lV.push((double)inV, P.a_vc));
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) { wu[q] = wu[q + 1]; wv[q] = wv[q + 1]; }
+                wu[6] = in; wv[6] = inV;
+                const int xo = x - d;
+                if (xo >= 0) {
+                    // raw input at xo = d samples back (d is 4, 5 or 6)
+                    const int rawU = d == 4 ? wu[2] : (d == 5 ? wu[1] : wu[0]);
+                    const int rawV = d == 4 ? wv[2] : (d == 5 ? wv[1] : wv[0]);
+                    int u = xo < W2 - d ? fU : rawU, v = xo < W2 - d ? fV : rawV;
+                    const int upU = __shfl_up(u, 1), upV = __shfl_up(v, 1);
+                    if (blend && k >= 1) {
+                        u = ((k >= 2 ? upU : 128) + u + 1) >> 1;
+                        v = ((k >= 2 ? upV : 128) + v + 1) >> 1;
+                    }
+                    double s = u;
+                    double ts = sU.push(s, a_sh_c);
+                    ou.put(xo, clampu8((int)(s + ((s - ts) * sharpen_c))));
+                    s = v;
+                    ts = sV.push(s, a_sh_c);
+                    ov.put(xo, clampu8((int)(s + ((s - ts) * sharpen_c))));
+                }
+                if (j_ == BK - 1 || x == W2 + d - 1) rv.advance();
             SWEEP_END
             ou.finish(W2); ov.finish(W2);
         }
@@ -551,18 +580,44 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
         chroma_lp_plain422(R.U, W2, P.a_tv, 1);
         chroma_lp_plain422(R.V, W2, P.a_tv, 1);
     }
-    // ---- packed transposed scratch -> frame row
+    // ---- packed transposed scratch -> frame row (64-byte bursts per lane on aligned rows)
     if (is_out) {
-        SWEEP_BEGIN(R.Y, W)
-            fy[x] = (uint8_t)in;
-        SWEEP_END
-        Reader422 rv; rv.begin(R.V, W2);
-        SWEEP_BEGIN(R.U, W2)
-            if (j_ == 0) rv.prefetch(x0_);
-            fu[x] = (uint8_t)in;
-            fv[x] = (uint8_t)rv.get(j_);
-            if (j_ == BK - 1 || x == W2 - 1) rv.advance();
-        SWEEP_END
+        int x0 = 0;
+        if (P.src_al16) {
+            for (; x0 + 64 <= W; x0 += 64) {
+                uint32_t w[16];
+                const int q = x0 >> 2;
+#pragma unroll
+                for (int j = 0; j < 16; j++) w[j] = R.Y.word(q + j);
+                uint4 *o = reinterpret_cast<uint4 *>(fy + x0);
+                o[0] = make_uint4(w[0], w[1], w[2], w[3]);   o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                o[2] = make_uint4(w[8], w[9], w[10], w[11]); o[3] = make_uint4(w[12], w[13], w[14], w[15]);
+            }
+            for (; x0 + 16 <= W; x0 += 16) {
+                const int q = x0 >> 2;
+                *reinterpret_cast<uint4 *>(fy + x0) =
+                    make_uint4(R.Y.word(q), R.Y.word(q + 1), R.Y.word(q + 2), R.Y.word(q + 3));
+            }
+        }
+        for (; x0 < W; x0++) fy[x0] = (uint8_t)R.Y.byte_at(x0);
+        int c0 = 0;
+        if (P.dst_al16) {
+            for (; c0 + 32 <= W2; c0 += 32) {
+                uint32_t a[8], b[8];
+                const int q = c0 >> 2;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { a[j] = R.U.word(q + j); b[j] = R.V.word(q + j); }
+                uint2 *ou2 = reinterpret_cast<uint2 *>(fu + c0), *ov2 = reinterpret_cast<uint2 *>(fv + c0);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { ou2[j] = make_uint2(a[2 * j], a[2 * j + 1]); ov2[j] = make_uint2(b[2 * j], b[2 * j + 1]); }
+            }
+            for (; c0 + 8 <= W2; c0 += 8) {
+                const int q = c0 >> 2;
+                *reinterpret_cast<uint2 *>(fu + c0) = make_uint2(R.U.word(q), R.U.word(q + 1));
+                *reinterpret_cast<uint2 *>(fv + c0) = make_uint2(R.V.word(q), R.V.word(q + 1));
+            }
+        }
+        for (; c0 < W2; c0++) { fu[c0] = (uint8_t)R.U.byte_at(c0); fv[c0] = (uint8_t)R.V.byte_at(c0); }
     }
 }
 

@@ -673,6 +673,7 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     c->host_fields422.resize((size_t)n);
     uint64_t pos = c->rng_pos;
     bool any_render = false, any_flt = false;
+    bool al_y16 = true, al_c8 = true;      // vector copies between frame rows and scratch words
     for (int i = 0; i < n; i++) {
         const ntscsim_field422_desc &d = descs[i];
         if (d.field > 1) return NTSCSIM_E_ARG;
@@ -698,6 +699,9 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
             any_render = true;
         }
         any_flt = any_flt || o.flt[0] != nullptr;
+        al_y16 = al_y16 && !(((uintptr_t)d.dst_dev[0] | (uintptr_t)d.dst_linesize[0]) & 15);
+        al_c8 = al_c8 && !(((uintptr_t)d.dst_dev[1] | (uintptr_t)d.dst_linesize[1] |
+                            (uintptr_t)d.dst_dev[2] | (uintptr_t)d.dst_linesize[2]) & 7);
         o.src_height = d.src_height;
         o.field = d.field; o.flags = d.flags; o.fieldno = d.fieldno;
         if (d.rng_pos != NTSCSIM_RNG_AUTO) pos = d.rng_pos;
@@ -710,6 +714,8 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         if (!(d.flags & NTSCSIM_422_NOCOMP)) pos += c->geom.calls[d.field & 1];
     }
     c->rng_pos = pos;
+    D.src_al16 = al_y16;      // (422 path: luma rows 16-byte aligned)
+    D.dst_al16 = al_c8;       // (422 path: chroma rows 8-byte aligned)
 
     const dim3 pgrid((D.R + 62) / 63);
     const size_t S = (size_t)pgrid.x * 64;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PRODUCT_SO = os.path.join(PKG_DIR, "libntscsim.so")
+# NTSCSIM_LIB: developer override (A/B builds of the same ABI); default = the in-tree library
+PRODUCT_SO = os.environ.get("NTSCSIM_LIB") or os.path.join(PKG_DIR, "libntscsim.so")
 
 OK, E_ARG, E_SIZE, E_NODEV, E_HIP, E_NOMEM, E_PARAM, E_FLAG, E_HELP, E_INTERNAL = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9
