@@ -140,6 +140,51 @@ __global__ void k422_bkey(DevParams P, const Field422Dev *__restrict__ fields, i
     }
 }
 
+// ------------------------------------------------------------------------------ output frame
+// The pixel work of output_frame() ffmpeg_to_composite.cpp:1177-1236: the rows of `field` of a
+// processed YUV422P frame are line-doubled ("bob") into the encoder's frame, which is YUV422P
+// (:1177-1196) or YUV420P (:1197-1236; there the chroma rows are DECIMATED by the copy itself, no
+// swscale involved).  One block per destination luma row.
+struct Out422Dev {
+    const uint8_t *frame[3];
+    uint8_t *bob[3];
+    int32_t frame_ls[3], bob_ls[3];
+    uint32_t field, mode;
+};
+enum : uint32_t { OUT422_BOB422 = 0u, OUT422_BOB420 = 1u, OUT422_INTERLACED420 = 2u };
+
+DEV void copy_row422(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, int nbytes, bool al4)
+{
+    if (al4) {
+        const int nw = nbytes >> 2;
+        for (int i = threadIdx.x; i < nw; i += blockDim.x)
+            ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
+        for (int i = (nw << 2) + threadIdx.x; i < nbytes; i += blockDim.x) d[i] = s[i];
+    } else {
+        for (int i = threadIdx.x; i < nbytes; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+__global__ void k422_output(DevParams P, const Out422Dev *__restrict__ outs, int al4)
+{
+    const Out422Dev &o = outs[blockIdx.y];
+    const unsigned y = blockIdx.x, H = (unsigned)P.H;
+    unsigned sy;
+    if (o.mode == OUT422_INTERLACED420) sy = y;                    // :1202-1203
+    else if (o.field) sy = y | 1u;                                 // 1, 1, 3, 3, ...  :1181-1184
+    else sy = (y + 1u) & ~1u;                                      // 0, 2, 2, 4, 4, ...
+    if (sy >= H) sy -= 2u;                                         // :1186-1187
+    copy_row422(o.bob[0] + (size_t)o.bob_ls[0] * y, o.frame[0] + (size_t)o.frame_ls[0] * sy, P.W, al4);
+    bool chroma = true;
+    unsigned cy = y;
+    if (o.mode == OUT422_BOB420) { chroma = (y & 1u) == 0u; cy = y >> 1; }                   // :1225-1226
+    else if (o.mode == OUT422_INTERLACED420) { chroma = (y & 2u) == 0u; cy = (y & 1u) + ((y & ~3u) >> 1); }  // :1215-1216
+    if (chroma)
+        for (int p = 1; p <= 2; p++)
+            copy_row422(o.bob[p] + (size_t)o.bob_ls[p] * cy, o.frame[p] + (size_t)o.frame_ls[p] * sy,
+                        P.W / 2, al4);
+}
+
 // ------------------------------------------------------------------------------ the field
 // Row planes in HBM scratch: FOUR consecutive samples per 32-bit word, words transposed:
 // plane[x >> 2][slot].  One wave access = 64 lanes x 4 B = two full 128-byte lines.

@@ -81,6 +81,8 @@ struct ntscsim_ctx {
     DevBuf<uint32_t> scratch422;
     std::vector<FieldDev> host_fields;
     std::vector<Field422Dev> host_fields422;
+    std::vector<Out422Dev> host_out422;
+    DevBuf<Out422Dev> out422;
     DevBuf<uint32_t> rs_luma, rs_chroma;
     FieldDev *stage[2] = {nullptr, nullptr};
     size_t stage_cap[2] = {0, 0};
@@ -93,6 +95,10 @@ struct ntscsim_ctx {
 
     // host-frame path
     DevBuf<uint8_t> fsrc, fdst;
+    // ntscsim_frames_host(): two chunk slots, copy streams and events, kept between calls
+    struct HostSlot { DevBuf<uint8_t> dsrc, ddst; hipEvent_t up = nullptr, done = nullptr, down = nullptr; };
+    HostSlot hslot[2];
+    hipStream_t s_up = nullptr, s_dn = nullptr;
 
     // profiling: five events per call (start | setup done | encode done | decode done | end),
     // recorded on the launch stream; summed and recycled by ntscsim_get_timings_ms()
@@ -304,8 +310,16 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geom.sstart.release(); c->geom.jwarm.release();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->comp_ghost.release(); c->tails.release(); c->fields422.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
+    for (auto &h : c->hslot) {
+        h.dsrc.release(); h.ddst.release();
+        if (h.up) (void)hipEventDestroy(h.up);
+        if (h.done) (void)hipEventDestroy(h.done);
+        if (h.down) (void)hipEventDestroy(h.down);
+    }
+    if (c->s_up) (void)hipStreamDestroy(c->s_up);
+    if (c->s_dn) (void)hipStreamDestroy(c->s_dn);
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
@@ -772,6 +786,47 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     return NTSCSIM_OK;
 }
 
+extern "C" int ntscsim_output422_device(ntscsim_ctx *c, const ntscsim_out422_desc *descs, int n,
+                                        int W, int H, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0) return NTSCSIM_E_ARG;
+    if (W < 16 || (W & 1) || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->host_out422.resize((size_t)n);
+    bool al4 = true;
+    for (int i = 0; i < n; i++) {
+        const ntscsim_out422_desc &d = descs[i];
+        if (d.field > 1 || d.mode > NTSCSIM_OUT422_INTERLACED420) return NTSCSIM_E_ARG;
+        Out422Dev &o = c->host_out422[(size_t)i];
+        std::memset(&o, 0, sizeof(o));
+        for (int k = 0; k < 3; k++) {
+            if (!d.frame_dev[k] || !d.bob_dev[k]) return NTSCSIM_E_ARG;
+            const int need = k == 0 ? W : W / 2;
+            if (d.frame_linesize[k] < need || d.bob_linesize[k] < need) return NTSCSIM_E_SIZE;
+            o.frame[k] = (const uint8_t *)d.frame_dev[k]; o.frame_ls[k] = d.frame_linesize[k];
+            o.bob[k] = (uint8_t *)d.bob_dev[k]; o.bob_ls[k] = d.bob_linesize[k];
+            al4 = al4 && !(((uintptr_t)d.frame_dev[k] | (uintptr_t)d.frame_linesize[k] |
+                            (uintptr_t)d.bob_dev[k] | (uintptr_t)d.bob_linesize[k]) & 3);
+        }
+        o.field = d.field; o.mode = d.mode;
+    }
+    DevParams D;
+    std::memset(&D, 0, sizeof(D));
+    D.W = W; D.H = H; D.variant = 1;
+    HIPCHK(c, c->out422.ensure((size_t)n));
+    // (pageable staging: synchronous with respect to the host vector, like ntscsim_fields422_device)
+    HIPCHK(c, hipMemcpyAsync(c->out422.p, c->host_out422.data(), (size_t)n * sizeof(Out422Dev),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)n), dim3(256), 0, st, D, c->out422.p,
+                       al4 ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    return NTSCSIM_OK;
+}
+
 extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int src_interlaced,
                              int src_tff, uint8_t *dst, int dst_ls, int W, int H, unsigned field,
                              uint64_t fieldno)
@@ -823,8 +878,12 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     HIPCHK(c, hipSetDevice(c->device));
     if (chunk_frames <= 0) chunk_frames = 32;
     if (chunk_frames > n_frames) chunk_frames = n_frames;
-    const size_t pitch = (((size_t)W * 4 + 255) / 256) * 256;
+    // device frames are packed at a 16-byte row pitch (the kernels' vector path); when the host
+    // layout is the same, a whole chunk moves as ONE linear copy instead of per-frame 2-D copies
+    const size_t pitch = (((size_t)W * 4 + 15) / 16) * 16;
     const size_t fbytes = pitch * H;
+    const bool lin_src = (size_t)src_ls == pitch && src_frame_stride == fbytes;
+    const bool lin_dst = (size_t)dst_ls == pitch && dst_frame_stride == fbytes;
     const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (size_t)src_ls * H;
     const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + (size_t)dst_ls * H;
     const bool pin_src = hipHostRegister((void *)src, src_span, hipHostRegisterDefault) == hipSuccess;
@@ -833,20 +892,23 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
 
     struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr; hipEvent_t up = nullptr, done = nullptr, down = nullptr; bool used = false; };
     Slot slot[2];
-    hipStream_t s_up = nullptr, s_dn = nullptr;
     int rc = NTSCSIM_OK;
     auto fail = [&](hipError_t e, const char *what) {
         if (e != hipSuccess && rc == NTSCSIM_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = NTSCSIM_E_HIP; }
         return e != hipSuccess;
     };
-    fail(hipStreamCreateWithFlags(&s_up, hipStreamNonBlocking), "hipStreamCreate");
-    fail(hipStreamCreateWithFlags(&s_dn, hipStreamNonBlocking), "hipStreamCreate");
+    if (!c->s_up) fail(hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking), "hipStreamCreate");
+    if (!c->s_dn) fail(hipStreamCreateWithFlags(&c->s_dn, hipStreamNonBlocking), "hipStreamCreate");
+    const hipStream_t s_up = c->s_up, s_dn = c->s_dn;
     for (int i = 0; i < 2 && rc == NTSCSIM_OK; i++) {
-        fail(hipMalloc((void **)&slot[i].dsrc, fbytes * chunk_frames), "hipMalloc");
-        fail(hipMalloc((void **)&slot[i].ddst, fbytes * chunk_frames * 2), "hipMalloc");
-        fail(hipEventCreateWithFlags(&slot[i].up, hipEventDisableTiming), "hipEventCreate");
-        fail(hipEventCreateWithFlags(&slot[i].done, hipEventDisableTiming), "hipEventCreate");
-        fail(hipEventCreateWithFlags(&slot[i].down, hipEventDisableTiming), "hipEventCreate");
+        ntscsim_ctx::HostSlot &h = c->hslot[i];
+        fail(h.dsrc.ensure(fbytes * chunk_frames), "hipMalloc");
+        fail(h.ddst.ensure(fbytes * chunk_frames * 2), "hipMalloc");
+        if (!h.up) fail(hipEventCreateWithFlags(&h.up, hipEventDisableTiming), "hipEventCreate");
+        if (!h.done) fail(hipEventCreateWithFlags(&h.done, hipEventDisableTiming), "hipEventCreate");
+        if (!h.down) fail(hipEventCreateWithFlags(&h.down, hipEventDisableTiming), "hipEventCreate");
+        slot[i].dsrc = h.dsrc.p; slot[i].ddst = h.ddst.p;
+        slot[i].up = h.up; slot[i].done = h.done; slot[i].down = h.down;
     }
     std::vector<ntscsim_field_desc> descs((size_t)chunk_frames * 2);
     uint64_t cur = first_fieldno;
@@ -857,10 +919,14 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
         // the slot's previous download must have left the device buffers
         if (sl.used) { if (fail(hipEventSynchronize(sl.down), "hipEventSynchronize")) break; }
         // H2D: nf frames, row by row into the device pitch
-        for (int j = 0; j < nf; j++)
-            if (fail(hipMemcpy2DAsync(sl.dsrc + fbytes * j, pitch, src + src_frame_stride * (size_t)(f0 + j),
-                                      (size_t)src_ls, (size_t)W * 4, (size_t)H, hipMemcpyHostToDevice, s_up),
-                     "hipMemcpy2DAsync H2D")) break;
+        if (lin_src)
+            fail(hipMemcpyAsync(sl.dsrc, src + fbytes * (size_t)f0, fbytes * (size_t)nf,
+                                hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D");
+        else
+            for (int j = 0; j < nf; j++)
+                if (fail(hipMemcpy2DAsync(sl.dsrc + fbytes * j, pitch, src + src_frame_stride * (size_t)(f0 + j),
+                                          (size_t)src_ls, (size_t)W * 4, (size_t)H, hipMemcpyHostToDevice, s_up),
+                         "hipMemcpy2DAsync H2D")) break;
         if (rc != NTSCSIM_OK) break;
         fail(hipEventRecord(sl.up, s_up), "hipEventRecord");
         // kernels on the ctx stream, after the upload
@@ -884,7 +950,10 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
         fail(hipEventRecord(sl.done, c->stream), "hipEventRecord");
         // D2H on its own stream, after the kernels
         fail(hipStreamWaitEvent(s_dn, sl.done, 0), "hipStreamWaitEvent");
-        for (int k = 0; k < 2 * nf && rc == NTSCSIM_OK; k++)
+        if (lin_dst)
+            fail(hipMemcpyAsync(dst + fbytes * (size_t)(2 * f0), sl.ddst, fbytes * (size_t)(2 * nf),
+                                hipMemcpyDeviceToHost, s_dn), "hipMemcpyAsync D2H");
+        else for (int k = 0; k < 2 * nf && rc == NTSCSIM_OK; k++)
             fail(hipMemcpy2DAsync(dst + dst_frame_stride * (size_t)(2 * f0 + k), (size_t)dst_ls,
                                   sl.ddst + fbytes * (size_t)k, pitch, (size_t)W * 4, (size_t)H,
                                   hipMemcpyDeviceToHost, s_dn), "hipMemcpy2DAsync D2H");
@@ -894,15 +963,6 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     (void)hipStreamSynchronize(s_up);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(s_dn);
-    for (int i = 0; i < 2; i++) {
-        if (slot[i].dsrc) (void)hipFree(slot[i].dsrc);
-        if (slot[i].ddst) (void)hipFree(slot[i].ddst);
-        if (slot[i].up) (void)hipEventDestroy(slot[i].up);
-        if (slot[i].done) (void)hipEventDestroy(slot[i].done);
-        if (slot[i].down) (void)hipEventDestroy(slot[i].down);
-    }
-    if (s_up) (void)hipStreamDestroy(s_up);
-    if (s_dn) (void)hipStreamDestroy(s_dn);
     if (pin_src) (void)hipHostUnregister((void *)src);
     if (pin_dst) (void)hipHostUnregister((void *)dst);
     return rc;

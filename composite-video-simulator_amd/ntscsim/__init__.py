@@ -8,7 +8,7 @@ import ctypes as C
 
 from . import _capi
 from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, Field422Desc, FieldDesc,
-                    NtscsimError, Params, lib, make_params, make_params_to_composite)
+                    NtscsimError, Out422Desc, Params, lib, make_params, make_params_to_composite)
 
 __all__ = ["FieldSimulator", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
            "field_rows", "calls_per_field", "field_schedule"]
@@ -174,6 +174,24 @@ class FieldSimulator:
         rc = self._lib.ntscsim_fields422_device(self._h, arr, len(jobs), int(width), int(height),
                                                 C.c_void_p(stream))
         self._chk(rc, "ntscsim_fields422_device")
+
+    def output422(self, jobs, width, height, stream=None):
+        """jobs: list of dicts {frame: 3 CUDA uint8 tensors, bob: 3 tensors, field, mode}."""
+        arr = (Out422Desc * len(jobs))()
+        for d, j in zip(arr, jobs):
+            for k in range(3):
+                d.frame_dev[k] = j["frame"][k].data_ptr()
+                d.frame_linesize[k] = j["frame"][k].stride(0)
+                d.bob_dev[k] = j["bob"][k].data_ptr()
+                d.bob_linesize[k] = j["bob"][k].stride(0)
+            d.field = j["field"]
+            d.mode = j["mode"]
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.ntscsim_output422_device(self._h, arr, len(jobs), int(width), int(height),
+                                                C.c_void_p(stream))
+        self._chk(rc, "ntscsim_output422_device")
 
     def sync(self):
         self._chk(self._lib.ntscsim_sync(self._h), "ntscsim_sync")

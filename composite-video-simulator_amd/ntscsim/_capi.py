@@ -29,7 +29,7 @@ EXPORTS = (
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
     "ntscsim_debug_force_generic",
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
-    "ntscsim_fields422_device", "ntscsim_rng_calls_per_field_422",
+    "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_rng_calls_per_field_422",
 )
 
 
@@ -110,6 +110,21 @@ class Field422Desc(C.Structure):
 
 F422_INTERLACED, F422_TFF, F422_SRC420, F422_SECOND, F422_NOCOMP = 1, 2, 4, 8, 16
 
+
+class Out422Desc(C.Structure):
+    """struct ntscsim_out422_desc"""
+    _fields_ = [
+        ("frame_dev", C.c_void_p * 3),
+        ("bob_dev", C.c_void_p * 3),
+        ("frame_linesize", C.c_int32 * 3),
+        ("bob_linesize", C.c_int32 * 3),
+        ("field", C.c_uint32),
+        ("mode", C.c_uint32),
+    ]
+
+
+OUT422_BOB422, OUT422_BOB420, OUT422_INTERLACED420 = 0, 1, 2
+
 _u8p = C.POINTER(C.c_uint8)
 _lib = None
 
@@ -186,6 +201,9 @@ def lib():
     L.ntscsim_fields422_device.argtypes = [C.c_void_p, C.POINTER(Field422Desc), C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]
     L.ntscsim_fields422_device.restype = C.c_int
+    L.ntscsim_output422_device.argtypes = [C.c_void_p, C.POINTER(Out422Desc), C.c_int, C.c_int,
+                                           C.c_int, C.c_void_p]
+    L.ntscsim_output422_device.restype = C.c_int
     L.ntscsim_rng_calls_per_field_422.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_uint]
     L.ntscsim_rng_calls_per_field_422.restype = C.c_uint64
     L.ntscsim_debug_force_generic.argtypes = [C.c_void_p, C.c_int]

@@ -298,6 +298,32 @@ typedef struct ntscsim_field422_desc {
 
 int ntscsim_fields422_device(ntscsim_ctx *ctx, const ntscsim_field422_desc *descs, int n,
                              int width, int height, void *hip_stream);
+
+/*
+ * The pixel work of output_frame() ffmpeg_to_composite.cpp:1131, lines :1177-1236: line-double
+ * ("bob") the rows of `field` of a processed YUV422P frame into the frame handed to the encoder.
+ *   NTSCSIM_OUT422_BOB422         use_422_colorspace, field rate (:1177-1196): bob is YUV422P
+ *   NTSCSIM_OUT422_BOB420         4:2:0, field rate (:1197-1236): bob is YUV420P; chroma row y/2 is
+ *                                 the frame's chroma row sy(y) for even y (decimation by copy)
+ *   NTSCSIM_OUT422_INTERLACED420  4:2:0 with -interlaced (:1202, :1215-1223): luma copied 1:1,
+ *                                 chroma rows interleaved per field
+ * (4:2:2 interlaced output encodes the frame as is, :1158 -- nothing to do.)  The bob frame's
+ * chroma planes need (height+1)/2 rows in the 4:2:0 modes.  Stream-ordered like the calls above.
+ */
+#define NTSCSIM_OUT422_BOB422        0u
+#define NTSCSIM_OUT422_BOB420        1u
+#define NTSCSIM_OUT422_INTERLACED420 2u
+
+typedef struct ntscsim_out422_desc {
+    const void *frame_dev[3];       /* processed YUV422P frame (the dst of ntscsim_fields422_device) */
+    void       *bob_dev[3];         /* encoder frame: YUV422P or YUV420P                         */
+    int32_t     frame_linesize[3], bob_linesize[3];
+    uint32_t    field;              /* output_frame()'s `field` argument (:1793, :1796)          */
+    uint32_t    mode;               /* NTSCSIM_OUT422_*                                          */
+} ntscsim_out422_desc;
+
+int ntscsim_output422_device(ntscsim_ctx *ctx, const ntscsim_out422_desc *descs, int n,
+                             int width, int height, void *hip_stream);
 /* draws of one composite_video_process() call (chroma noise runs at width/2 samples per row) */
 uint64_t ntscsim_rng_calls_per_field_422(const ntscsim_params *p, int width, int height,
                                          unsigned field);

@@ -29,7 +29,7 @@ echo "built $here/_ref/libntsc_ref.so"
 # ---- the 8-bit YUV422P sibling, ffmpeg_to_composite.cpp:
 # 97-131 LowpassFilter | 261 use_422_colorspace | 267-333 L1 globals | 335-351 clampu8/clips16 |
 # 353-553 chroma low-pass / modulate / demodulate | 629-1129 composite_video_process,
-# black_key_feedback, render_field
+# black_key_feedback, render_field | 1177-1236 output_frame's bob copy loops
 src2="$ref/ffmpeg_to_composite.cpp"
 {
     cat "$here/ref_tocomp_pre.hpp"
@@ -39,6 +39,11 @@ src2="$ref/ffmpeg_to_composite.cpp"
     sed -n '335,351p' "$src2"
     sed -n '353,553p' "$src2"
     sed -n '629,1129p' "$src2"
+    # the bob copy loops of output_frame() :1177-1236, given a function head/tail of our own
+    echo 'static AVFrame *output_avstream_video_bob_frame;'
+    echo 'static void ref_output_bob(AVFrame *frame, unsigned int field) {'
+    sed -n '1177,1236p' "$src2"
+    echo '}'
     cat "$here/ref_tocomp_post.cpp"
 } | g++ -x c++ -O2 -w -ffp-contract=off -fPIC -shared -I"$here/../include" - -o "$here/_ref/libtocomp_ref.so"
 echo "built $here/_ref/libtocomp_ref.so"

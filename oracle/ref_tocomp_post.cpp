@@ -65,3 +65,13 @@ extern "C" void tocomp_ref_black_key_feedback(uint8_t *const *ddata, const int *
     AVFrame d, f; fill(d, ddata, dls, w, h); fill(f, fdata, fls, w, h);
     black_key_feedback(&d, &f, field, 0);
 }
+extern "C" void tocomp_ref_output_frame(uint8_t *const *bdata, const int *bls,
+                                        uint8_t *const *fdata, const int *fls, int w, int h,
+                                        unsigned field, int mode)
+{
+    AVFrame b, f; fill(b, bdata, bls, w, h); fill(f, fdata, fls, w, h);
+    use_422_colorspace = (mode == 0);
+    output_video_as_interlaced = (mode == 2);
+    output_avstream_video_bob_frame = &b;
+    ref_output_bob(&f, field);
+}

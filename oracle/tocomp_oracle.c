@@ -421,3 +421,29 @@ void tocomp_oracle_render_field(tocomp_planes *d, const tocomp_planes *s, int is
         }
     }
 }
+
+/* output_frame() ffmpeg_to_composite.cpp:1177-1236 -- the row copies only (everything else in
+ * that function is encoder plumbing). */
+void tocomp_oracle_output_frame(tocomp_planes *bob, const tocomp_planes *frame, unsigned field,
+                                int mode)
+{
+    const unsigned H = (unsigned)frame->height;
+    const size_t W = (size_t)frame->width;
+    for (unsigned y = 0; y < H; y++) {
+        unsigned sy;
+        if (mode == 2) sy = y;                                  /* :1202-1203 */
+        else if (field) sy = y | 1u;                            /* :1181-1182, :1204-1205 */
+        else sy = (y + 1u) & ~1u;                               /* :1183-1184, :1206-1207 */
+        if (sy >= H) sy -= 2;                                   /* :1186-1187, :1209-1210 */
+        memcpy(bob->data[0] + (size_t)bob->linesize[0] * y,
+               frame->data[0] + (size_t)frame->linesize[0] * sy, W);
+        int chroma = 1;
+        unsigned cy = y;
+        if (mode == 1) { chroma = (y & 1u) == 0; cy = y >> 1; }                              /* :1225-1226 */
+        else if (mode == 2) { chroma = (y & 2u) == 0; cy = (y & 1u) + ((y & ~3u) >> 1); }    /* :1215-1216 */
+        if (chroma)
+            for (int p = 1; p <= 2; p++)
+                memcpy(bob->data[p] + (size_t)bob->linesize[p] * cy,
+                       frame->data[p] + (size_t)frame->linesize[p] * sy, W / 2);
+    }
+}

@@ -44,6 +44,12 @@ void tocomp_oracle_render_field(tocomp_planes *dst, const tocomp_planes *src, in
 void tocomp_oracle_black_key_feedback(tocomp_planes *dst, tocomp_planes *flt, unsigned field,
                                       int level);
 
+/* the bob copy of output_frame() :1177-1236.  mode: 0 = 4:2:2 field-rate bob (:1177-1196),
+ * 1 = 4:2:0 field-rate bob, 2 = 4:2:0 interlaced (:1197-1236).  `bob` is YUV422P (mode 0) or
+ * YUV420P (modes 1, 2: chroma planes (height+1)/2 rows); bob->width/height are not read. */
+void tocomp_oracle_output_frame(tocomp_planes *bob, const tocomp_planes *frame, unsigned field,
+                                int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,6 +253,9 @@ def _bind_tocomp_oracle():
         o.tocomp_oracle_black_key_feedback.argtypes = [C.POINTER(TocompPlanes), C.POINTER(TocompPlanes),
                                                        C.c_uint, C.c_int]
         o.tocomp_oracle_black_key_feedback.restype = None
+        o.tocomp_oracle_output_frame.argtypes = [C.POINTER(TocompPlanes), C.POINTER(TocompPlanes),
+                                                 C.c_uint, C.c_int]
+        o.tocomp_oracle_output_frame.restype = None
         o._tocomp_bound = True
     return o
 
@@ -294,6 +297,12 @@ def tocomp_oracle_black_key(dst, flt, field, level):
     o.tocomp_oracle_black_key_feedback(C.byref(d), C.byref(f), field, level)
 
 
+def tocomp_oracle_output_frame(bob, frame, field, mode):
+    o = _bind_tocomp_oracle()
+    b, f = bob.cplanes(), frame.cplanes()
+    o.tocomp_oracle_output_frame(C.byref(b), C.byref(f), field, mode)
+
+
 def have_tocomp_ref():
     return os.path.exists(TOCOMP_REF_SO)
 
@@ -313,8 +322,10 @@ def tocomp_ref():
         lib.tocomp_ref_render_field.argtypes = [pp, ip, C.c_int, C.c_int, pp, ip, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_int, C.c_uint]
         lib.tocomp_ref_black_key_feedback.argtypes = [pp, ip, pp, ip, C.c_int, C.c_int, C.c_uint]
+        lib.tocomp_ref_output_frame.argtypes = [pp, ip, pp, ip, C.c_int, C.c_int, C.c_uint, C.c_int]
         for f in (lib.tocomp_ref_set_params, lib.tocomp_ref_srand, lib.tocomp_ref_process,
-                  lib.tocomp_ref_render_field, lib.tocomp_ref_black_key_feedback):
+                  lib.tocomp_ref_render_field, lib.tocomp_ref_black_key_feedback,
+                  lib.tocomp_ref_output_frame):
             f.restype = None
         _tocomp_ref = lib
     return _tocomp_ref

@@ -94,6 +94,60 @@ def test_black_key_equals_reference_extract():
         assert np.array_equal(d.buf, d2.buf) and np.array_equal(f.buf, f2.buf)
 
 
+def _bob_frame(w, h, mode, rng):
+    """An encoder frame for output_frame(): YUV422P for mode 0, else YUV420P ((h+1)//2 chroma
+    rows; held in a Yuv422 of full height so the helpers apply), pre-filled with a pattern."""
+    b = L.Yuv422(w, h, pad=0)
+    b.buf[:] = rng.randint(0, 256, size=b.buf.shape, dtype=np.uint8)
+    return b
+
+
+_OUT_CASES = [(w, h, mode, field) for (w, h) in ((64, 32), (48, 15), (32, 6), (40, 3))
+              for mode in (0, 1, 2) for field in (0, 1)]
+
+
+@pytest.mark.skipif(not L.have_tocomp_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("w,h,mode,field", _OUT_CASES)
+def test_output_frame_equals_reference_extract(w, h, mode, field):
+    rng = np.random.RandomState(w * 100 + h * 7 + mode * 2 + field)
+    frame = L.yuv_noise(w, h, 5)
+    a, b = _bob_frame(w, h, mode, rng), None
+    b = a.copy()
+    pp = C.POINTER(C.POINTER(C.c_uint8))
+    ba, bl = a.ptr_arrays(); fa, fl = frame.ptr_arrays()
+    L.tocomp_ref().tocomp_ref_output_frame(C.cast(ba, pp), bl, C.cast(fa, pp), fl, w, h, field, mode)
+    L.tocomp_oracle_output_frame(b, frame, field, mode)
+    assert np.array_equal(a.buf, b.buf)
+
+
+def test_output_frame_properties():
+    """Size-independent properties of the bob copy: every luma row of the bob frame is a row of
+    the same parity as `field` (or the identity for interlaced 4:2:0); 4:2:0 chroma row j is the
+    frame's chroma row sy(2j)."""
+    w, h = 64, 31
+    frame = L.yuv_noise(w, h, 9)
+    for field in (0, 1):
+        b = L.Yuv422(w, h)
+        L.tocomp_oracle_output_frame(b, frame, field, 0)
+        for y in range(h):
+            sy = (y | 1) if field else ((y + 1) & ~1)
+            if sy >= h:
+                sy -= 2
+            assert sy % 2 == field
+            for i in range(3):
+                assert np.array_equal(b.pix(i)[y], frame.pix(i)[sy])
+        b = L.Yuv422(w, h)
+        L.tocomp_oracle_output_frame(b, frame, field, 1)
+        for j in range((h + 1) // 2):
+            sy = ((2 * j) | 1) if field else ((2 * j + 1) & ~1)
+            if sy >= h:
+                sy -= 2
+            assert np.array_equal(b.pix(1)[j], frame.pix(1)[sy])
+        b = L.Yuv422(w, h)
+        L.tocomp_oracle_output_frame(b, frame, field, 2)
+        assert np.array_equal(b.pix(0), frame.pix(0))
+
+
 import json as _json
 import os as _os
 _G422 = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
@@ -237,5 +291,50 @@ def test_hip_422_rejects_odd_width():
     t = [torch.zeros((8, 64), dtype=torch.uint8, device="cuda") for _ in range(3)]
     with pytest.raises(ntscsim.NtscsimError) as e:
         sim.fields422([{"dst": t, "field": 0, "fieldno": 0}], 33, 8)
+    assert e.value.code == _capi.E_SIZE
+    sim.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,mode,field", _OUT_CASES + [(720, 486, 0, 1), (720, 486, 1, 0), (720, 480, 2, 1)])
+def test_hip_output_frame(w, h, mode, field):
+    import torch
+    rng = np.random.RandomState(w + h + mode + field)
+    frame = L.yuv_noise(w, h, 11)
+    bob = _bob_frame(w, h, mode, rng)
+    sim = ntscsim.FieldSimulator(params=L.make_params_tocomp([]))
+    fd, bd = to_dev(torch, frame), to_dev(torch, bob)
+    L.tocomp_oracle_output_frame(bob, frame, field, mode)
+    sim.output422([{"frame": fd, "bob": bd, "field": field, "mode": mode}], w, h)
+    sim.sync()
+    for i in range(3):
+        assert np.array_equal(bd[i].cpu().numpy(), bob.pix(i)), i
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_hip_output_frame_batch_unaligned():
+    """A batch of descriptors, odd pointers/linesizes (byte path) and error codes."""
+    import torch
+    w, h = 66, 20
+    sim = ntscsim.FieldSimulator(params=L.make_params_tocomp([]))
+    jobs, want = [], []
+    for k in range(5):
+        frame = L.yuv_noise(w, h, 20 + k, pad=3)
+        bob = L.Yuv422(w, h, pad=1, fill=k)
+        fd, bd = to_dev(torch, frame), to_dev(torch, bob)
+        L.tocomp_oracle_output_frame(bob, frame, k & 1, k % 3)
+        jobs.append({"frame": fd, "bob": bd, "field": k & 1, "mode": k % 3})
+        want.append(bob)
+    sim.output422(jobs, w, h)
+    sim.sync()
+    for j, b in zip(jobs, want):
+        for i in range(3):
+            assert np.array_equal(j["bob"][i].cpu().numpy(), b.plane(i)), i
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        sim.output422([dict(jobs[0], mode=3)], w, h)
+    assert e.value.code == _capi.E_ARG
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        sim.output422(jobs[:1], w + 62, h)
     assert e.value.code == _capi.E_SIZE
     sim.close()

@@ -1,6 +1,8 @@
 """Developer probe: end-to-end (PCIe-inclusive) throughput of ntscsim_frames_host."""
 import os, sys, time
 import numpy as np
+import torch
+torch.zeros(1, device='cuda')
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import ntscsim, _libs as L
@@ -10,9 +12,23 @@ src = np.stack([L.bars(w, h, j) for j in range(n)])
 dst = np.zeros((2 * n, h, w, 4), np.uint8)
 sim = ntscsim.FieldSimulator(params=p)
 sim.frames_host(dst[:8], src[:4])
-for ch in (16, 32, 64):
+for ch in (16, 32, 64, 150, 300):
+    sim.rng_pos = 0
     t0 = time.perf_counter()
     sim.frames_host(dst, src, first_fieldno=0, chunk_frames=ch)
     dt = time.perf_counter() - t0
     print("chunk %d frames: %d fields in %.3f s = %.0f fields/s (H2D %.1f MB + D2H %.1f MB => %.1f GB/s combined)" % (
         ch, 2 * n, dt, 2 * n / dt, src.nbytes / 1e6, dst.nbytes / 1e6, (src.nbytes + dst.nbytes) / dt / 1e9))
+
+# same with caller-pinned buffers (hipHostRegister inside the call then fails harmlessly)
+import torch
+tsrc = torch.empty(src.shape, dtype=torch.uint8).pin_memory()
+tdst = torch.empty(dst.shape, dtype=torch.uint8).pin_memory()
+tsrc.numpy()[:] = src
+for ch in (16, 32, 64, 150, 300):
+    sim.rng_pos = 0
+    t0 = time.perf_counter()
+    sim.frames_host(tdst.numpy(), tsrc.numpy(), first_fieldno=0, chunk_frames=ch)
+    dt = time.perf_counter() - t0
+    print("pinned, chunk %d frames: %.0f fields/s (%.1f GB/s combined)" % (ch, 2 * n / dt, (src.nbytes + dst.nbytes) / dt / 1e9))
+assert (tdst.numpy() == dst).all()
