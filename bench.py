@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "composite-video-simulator_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md: 256 CU x 4 SIMD at 2.4 GHz; one wave64 VALU instruction per 4 cycles
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 (FMA-counted); the exact path cannot use FMA
 
 
@@ -42,13 +43,20 @@ def make_bars_clip(torch, n_frames, w, h, first_frame, stride, device):
     return row[:, None, :, :].expand(n_frames, h, w, 4).contiguous()
 
 
-def cpu_baseline(params, w, h, n_fields, check_against=None):
-    """Oracle (our CPU restatement of the reference, 1 thread like the reference) on the first
-    n_fields of the same clip.  Returns (fields_per_s, n_checked_ok)."""
+def _cpu_engine(kind, params):
+    """The single-threaded CPU engines bench.py times beside the GPU: 'reference' = the
+    reference's own composite_layer() text compiled into oracle/_ref/libntsc_ref.so by
+    oracle/build_ref.sh (process-wide libc rand(), like the tool); 'port' = oracle/ntsc_oracle.c."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import _libs as L
-    o = L.OracleStream(params)
+    return L, (L.RefStream(params) if kind == "reference" else L.OracleStream(params))
+
+
+def cpu_baseline(kind, params, w, h, n_fields, check_against=None):
+    """Engine `kind`, 1 thread like the reference, on the first n_fields of the same clip.
+    Returns (fields_per_s, n_checked_ok)."""
+    import numpy as np
+    L, o = _cpu_engine(kind, params)
     dst = np.zeros((h, w, 4), np.uint8)
     frames = {}
     t = 0.0
@@ -65,8 +73,87 @@ def cpu_baseline(params, w, h, n_fields, check_against=None):
             if np.array_equal(dst[field::2], check_against[cur]):
                 ok += 1
             else:
-                raise AssertionError("bench: HIP output of field %d differs from the oracle" % cur)
+                raise AssertionError("bench: HIP output of field %d differs from the %s" % (cur, kind))
     return n_fields / t, ok
+
+
+def cpu_worker(args):
+    """`bench.py --cpu-worker A B`: one process of the all-cores CPU leg.  Prepares fields [A, B)
+    of the clip for the port (rand() stream positioned by jump-ahead, as a multi-threaded CPU
+    implementation would), prints "ready", waits for a line on stdin, runs, prints its end time."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "composite-video-simulator_amd"))
+    from ntscsim import _capi, shard
+    a, b = int(args.cpu_worker[0]), int(args.cpu_worker[1])
+    params = _capi.make_params(args.preset.split())
+    L, o = _cpu_engine("port", params)
+    o.skip(shard.rng_pos_of_field(params, args.width, args.height, a))
+    w, h = args.width, args.height
+    dst = np.zeros((h, w, 4), np.uint8)
+    src = {}
+    for cur in range(a, b):
+        src[cur // 2] = L.bars(w, h, cur // 2)
+    print("ready", flush=True)
+    sys.stdin.readline()
+    for cur in range(a, b):
+        o.field(dst, src[cur // 2], (cur & 1) ^ 1, cur)
+    print("%.6f %d" % (time.time(), int(dst.sum() & 0xFFFF)), flush=True)
+
+
+def usable_cpus():
+    """Logical CPUs this process may actually use: affinity mask, capped by a cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
+def cpu_all_cores(args, n_workers, fields_each):
+    """All host CPUs: n_workers processes x fields_each fields of the port, released together once
+    every process is ready.  Returns fields_per_s."""
+    import subprocess
+    procs = []
+    for i in range(n_workers):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i * fields_each),
+               str((i + 1) * fields_each), "--width", str(args.width), "--height",
+               str(args.height), "--preset=" + args.preset]
+        procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL,
+                                      env=dict(os.environ, OMP_NUM_THREADS="1")))
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != b"ready":
+                raise RuntimeError("bench: CPU worker failed to start")
+        t0 = time.time()
+        for p in procs:
+            p.stdin.write(b"go\n")
+            p.stdin.flush()
+        ends = [float(p.stdout.readline().split()[0]) for p in procs]
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close()
+            except Exception:
+                pass
+            p.wait(timeout=60)
+    return n_workers * fields_each / (max(ends) - t0)
 
 
 def main():
@@ -87,9 +174,15 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the "
                          "multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--cpu-fields", type=int, default=600,
-                    help="fields of the clip timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-fields", type=int, default=300,
+                    help="fields of the clip timed on the single-threaded CPU engines (0 = skip)")
+    ap.add_argument("--cpu-mt-fields", type=int, default=8,
+                    help="fields per process of the all-cores CPU leg (0 = skip that leg)")
+    ap.add_argument("--cpu-worker", nargs=2, metavar=("A", "B"), default=None,
+                    help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        return cpu_worker(args)
 
     import torch
     import ntscsim
@@ -201,14 +294,34 @@ def main():
         chain_ms = dec_ms + enc_ms + set_ms
         achieved = alg_bytes_launch / (dec_ms * 1e-3) / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = "%dx%d %s" % (w, h, args.preset)
                 if key in tj:
-                    traffic = tj[key]["k_decode_hbm_bytes_per_launch"] * (
-                        fields_per_step_local / float(tj[key]["fields_per_launch"]))
+                    scale = fields_per_step_local / float(tj[key]["fields_per_launch"])
+                    traffic = tj[key]["k_decode_hbm_bytes_per_launch"] * scale
+                    if args.mode == "exact" and "valu_wave_insts_per_launch" in tj[key]:
+                        vi = {k_: v_ * scale for k_, v_ in tj[key]["valu_wave_insts_per_launch"].items()}
+                        # every wave64 VALU instruction (fp64 or int32) occupies its SIMD for one
+                        # quad-cycle (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU, profiles/README.md)
+                        vpeak = 256 * 4 * VALU_CLOCK_HZ / 4.0
+                        valu = {
+                            "bound": "valu-issue",
+                            "unit": "wave64 VALU instructions/s",
+                            "peak": vpeak,
+                            "insts_per_step": vi,
+                            "k_decode_achieved": vi["k_decode"] / (dec_ms * 1e-3),
+                            "k_decode_frac": vi["k_decode"] / (dec_ms * 1e-3) / vpeak,
+                            "path_achieved": sum(vi.values()) / (elapsed / args.steps),
+                            "path_frac": sum(vi.values()) / (elapsed / args.steps) / vpeak,
+                            "note": "instruction counts from the SQ_INSTS_VALU PMC pass "
+                                    "(profiles/r01_pmc_summary.txt); peak = 1024 SIMDs x 2.4 GHz / 4 "
+                                    "cycles; k_decode alone = one launch (2,315 waves cannot balance "
+                                    "1,024 SIMDs), path = whole chain with the steps in flight",
+                        }
             except Exception:
                 traffic = None
         out = {
@@ -250,6 +363,7 @@ def main():
                         "path_achieved uses encode+decode+setup time",
                 "path_achieved": alg_bytes_launch / (chain_ms * 1e-3) / 1e9,
                 "kernel_ms_all": {"setup": set_ms, "encode": enc_ms, "decode": dec_ms},
+                "valu": valu,
                 "kernel_timing": "hipEvents on the launch stream, %d steps on one context right "
                                  "after the timed region (un-shared launches; rocprofv3 of this "
                                  "command shows them in its Min column, --inflight 1 in its "
@@ -267,19 +381,38 @@ def main():
                     field = (cur & 1) ^ 1
                     chk[cur] = host[cur // 2][field::2].copy()
             # note: field pairs share a dst frame, so each field's rows are intact
-            cpu_fps, ok = cpu_baseline(params, w, h, ncpu, chk)
+            port_fps, ok = cpu_baseline("port", params, w, h, ncpu, chk)
+            have_ref = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libntsc_ref.so"))
+            if have_ref:
+                cpu_fps, ok_ref = cpu_baseline("reference", params, w, h, ncpu, chk)
+                kind = "reference"
+                what = ("composite_layer() of the reference itself (its ffmpeg_ntsc.cpp text "
+                        "compiled by oracle/build_ref.sh into oracle/_ref/libntsc_ref.so, g++ -O2 "
+                        "-ffp-contract=off, libc rand()), single-threaded like the tool")
+            else:
+                cpu_fps, ok_ref, kind = port_fps, ok, "port"
+                what = ("oracle/ntsc_oracle.c (bit-exact restatement of the single-threaded "
+                        "reference; oracle/_ref not present on this box), gcc -O2 -ffp-contract=off")
             out["cpu_baseline"] = {
                 "value": cpu_fps,
                 "unit": "frames/s",
                 "cores": 1,
-                "kind": "port",
-                "sample": "first %d fields of the same clip, oracle/ntsc_oracle.c (bit-exact "
-                          "restatement of the single-threaded reference), gcc -O2 "
-                          "-ffp-contract=off; %d fields compared byte-for-byte with the HIP "
-                          "output" % (ncpu, ok),
+                "kind": kind,
+                "sample": "first %d fields of the same clip, %s; %d fields compared byte-for-byte "
+                          "with the HIP output" % (ncpu, what, ok_ref),
                 "host_cpus": os.cpu_count(),
+                "port_1core": port_fps,
             }
             out["speedup_vs_cpu_1core"] = value / cpu_fps
+            if args.cpu_mt_fields > 0:
+                nw, quota = usable_cpus()
+                mt_fps = cpu_all_cores(args, nw, args.cpu_mt_fields)
+                out["cpu_baseline"]["port_all_cores"] = {
+                    "value": mt_fps, "cores": nw, "cgroup_cpu_quota": quota,
+                    "sample": "%d processes (one per usable logical CPU: affinity mask capped by "
+                              "the cgroup CPU quota) x %d fields of the port, rand() positions by "
+                              "jump-ahead, released together" % (nw, args.cpu_mt_fields)}
+                out["speedup_vs_cpu_all_cores"] = value / mt_fps
         print(json.dumps(out), flush=True)
     for sm, pl in zip(sims, plans):
         sm.free_prepared(pl)

@@ -4,14 +4,20 @@ and regenerates profiles/traffic.json and profiles/README.md.
 Usage: python tools/make_profiles.py <bench.json> <prof default dir> <prof inflight1 dir> <pmc dir> [fast32 bench.json]"""
 import csv, json, shutil, sys
 
-bench, pdef, psingle, pmc = sys.argv[1:5]
-fast = sys.argv[5] if len(sys.argv) > 5 else None
-shutil.copy(pdef + "/r01_kernel_stats.csv", "profiles/r01_kernel_stats_default_cmd.csv")
-shutil.copy(psingle + "/r01_kernel_stats.csv", "profiles/r01_kernel_stats_inflight1.csv")
-shutil.copy(pmc + "/summary.txt", "profiles/r01_pmc_summary.txt")
-shutil.copy(bench, "profiles/r01_bench.json")
+bench = sys.argv[1]
+fast = None
+if len(sys.argv) >= 5:      # full refresh; with only <bench.json> the committed summaries are kept
+    pdef, psingle, pmc = sys.argv[2:5]
+    fast = sys.argv[5] if len(sys.argv) > 5 else None
+    shutil.copy(pdef + "/r01_kernel_stats.csv", "profiles/r01_kernel_stats_default_cmd.csv")
+    shutil.copy(psingle + "/r01_kernel_stats.csv", "profiles/r01_kernel_stats_inflight1.csv")
+    shutil.copy(pmc + "/summary.txt", "profiles/r01_pmc_summary.txt")
+if bench != "profiles/r01_bench.json":
+    shutil.copy(bench, "profiles/r01_bench.json")
 if fast:
     shutil.copy(fast, "profiles/r01_bench_fast32.json")
+else:
+    fast = "profiles/r01_bench_fast32.json"
 
 
 def top(path):
@@ -47,6 +53,9 @@ traffic = {"720x486 -vhs": {
     "k_encode_fetch_KiB_raw": enc["FETCH_SIZE"],
     "k_encode_fetch_KiB_x2_gfx950_wide_load_correction": 2 * enc["FETCH_SIZE"],
     "k_encode_write_KiB": enc["WRITE_SIZE"],
+    "valu_wave_insts_per_launch": {"k_decode": dec["SQ_INSTS_VALU"], "k_encode": enc["SQ_INSTS_VALU"],
+                                   "setup": sum(v["SQ_INSTS_VALU"] for k, v in pm.items()
+                                                if "k_row_states" in k or "k_field_setup" in k)},
     "note": "rocprofv3 --pmc, one counter per pass (tools/pmc.sh), bench.py --inflight 1; FETCH_SIZE/"
             "WRITE_SIZE are in KiB; WRITE_SIZE is calibrated by k_encode, whose only stores are the "
             "composite plane: 410062 KiB == 720*145800*4 B exactly; k_decode loads are 4 B/lane (no x2 "
@@ -64,9 +73,15 @@ md = ["# profiles/ -- round 1 (MI355X, gfx950, ROCm 7.2)\n",
       "| `r01_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--inflight 1`) | FETCH_SIZE, WRITE_SIZE, SQ instruction counters per kernel (mean per launch) |",
       "| `traffic.json` | derived from the PMC summary | HBM bytes per launch that `bench.py` reports as `roofline.traffic` |\n",
       "## Bench line\n",
-      "`value` = %.0f frames/s (fields/s), %.3f ms per 600-field step, %.0fx the 1-core CPU oracle (%.1f fields/s); "
-      "`roofline.frac` = %.3f (k_decode, HBM).%s\n" % (
-          d["value"], d["ms_per_step"], d["speedup_vs_cpu_1core"], d["cpu_baseline"]["value"], d["roofline"]["frac"],
+      "`value` = %.0f frames/s (fields/s), %.3f ms per 600-field step; `roofline.frac` = %.3f (k_decode, HBM "
+      "algorithmic bytes) and `roofline.valu.path_frac` = %.2f (VALU issue slots, the bound that applies).  CPU beside "
+      "it on the GPU box's host (2x EPYC 9575F, cgroup quota 16 CPUs): the reference's own `composite_layer()` "
+      "(`oracle/_ref`, single-threaded like the tool) %.1f fields/s => %.0fx; our port 1 core %.1f fields/s; our port on "
+      "all %d usable CPUs %.0f fields/s => %.0fx.%s\n" % (
+          d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["valu"]["path_frac"],
+          d["cpu_baseline"]["value"], d["speedup_vs_cpu_1core"], d["cpu_baseline"]["port_1core"],
+          d["cpu_baseline"]["port_all_cores"]["cores"], d["cpu_baseline"]["port_all_cores"]["value"],
+          d["speedup_vs_cpu_all_cores"],
           (" FAST32 mode: %.0f frames/s." % json.load(open(fast))["value"]) if fast else ""),
       "## Kernel durations (us): hipEvents in bench.py vs rocprofv3\n",
       "| kernel | bench.py hipEvents (isolated pass) | rocprofv3 inflight 1 avg | rocprofv3 default cmd min / avg / max |",
