@@ -1034,4 +1034,95 @@ __global__ void k_bob(DevParams P, const FieldDev *__restrict__ fields)
     }
 }
 
+// =============================================================================== k_bgra_to_yuv
+// SURVEY 8(f) row f2, the output side: BGRA -> planar YUV 4:2:0 / 4:2:2 for the encoder (what the
+// tool does with sws_scale at ffmpeg_ntsc.cpp:2266).  libswscale is not part of the reference
+// tree, so this is NOT a bit-clone of it: it is BT.601 limited range in the classic 15-bit
+// fixed-point form (Y = 16 + 219/255 * (0.299 R + 0.587 G + 0.114 B), Cb/Cr = 128 + 224/255 * ...),
+// chroma taken from the rounded mean of the 2x1 (4:2:2) or 2x2 (4:2:0) block.  Parity unpinned.
+struct YuvDev {
+    const uint8_t *bgra;
+    uint8_t *y, *u, *v;
+    int32_t bgra_ls, y_ls, u_ls, v_ls;
+};
+namespace yuvc {
+constexpr int RY = 8414, GY = 16519, BY = 3208;        // (int)(c * 219 / 255 * 32768 + 0.5)
+constexpr int RU = -4864, GU = -9527, BU = 14392;      // (int)(c * 224 / 255 * 32768 + 0.5)
+constexpr int RV = 14392, GV = -12060, BV = -2331;
+}
+DEV uint32_t yuv_luma(uint32_t px)
+{
+    const int b = px & 255u, g = (px >> 8) & 255u, r = (px >> 16) & 255u;
+    return (uint32_t)(yuvc::RY * r + yuvc::GY * g + yuvc::BY * b + (16 << 15) + (1 << 14)) >> 15;
+}
+// chroma of a block of n = 1 << lg pixels whose channel sums are rs, gs, bs
+DEV void yuv_chroma(int rs, int gs, int bs, int lg, uint32_t &u, uint32_t &v)
+{
+    const int sh = 15 + lg;
+    u = (uint32_t)(yuvc::RU * rs + yuvc::GU * gs + yuvc::BU * bs + (128 << sh) + (1 << (sh - 1))) >> sh;
+    v = (uint32_t)(yuvc::RV * rs + yuvc::GV * gs + yuvc::BV * bs + (128 << sh) + (1 << (sh - 1))) >> sh;
+}
+DEV void yuv_acc(uint32_t px, int &rs, int &gs, int &bs)
+{
+    bs += px & 255u; gs += (px >> 8) & 255u; rs += (px >> 16) & 255u;
+}
+
+// One thread = 8 pixels of one row (4:2:2) or of a row pair (4:2:0); v420: 1 = 4:2:0.
+__global__ void k_bgra_to_yuv(DevParams P, const YuvDev *__restrict__ frames, int v420, int vec)
+{
+    const YuvDev &f = frames[blockIdx.z];
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (x0 >= P.W) return;
+    const int y0 = v420 ? 2 * (int)blockIdx.y : (int)blockIdx.y;
+    const int y1 = (v420 && y0 + 1 < P.H) ? y0 + 1 : y0;          // odd height: last row twice
+    const int nrows = v420 ? 2 : 1;
+    const int npx = P.W - x0 < 8 ? P.W - x0 : 8;                  // W is even
+    uint32_t px[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r >= nrows) break;
+        const uint8_t *row = f.bgra + (size_t)f.bgra_ls * (r ? y1 : y0) + (size_t)x0 * 4;
+        if (vec && npx == 8) {
+            const uint4 a = reinterpret_cast<const uint4 *>(row)[0], b = reinterpret_cast<const uint4 *>(row)[1];
+            px[r][0] = a.x; px[r][1] = a.y; px[r][2] = a.z; px[r][3] = a.w;
+            px[r][4] = b.x; px[r][5] = b.y; px[r][6] = b.z; px[r][7] = b.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                px[r][i] = i < npx ? reinterpret_cast<const uint32_t *>(row)[i] : 0u;
+        }
+    }
+    // luma
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (r >= nrows || (r == 1 && y1 == y0)) break;
+        uint8_t *yrow = f.y + (size_t)f.y_ls * (r ? y1 : y0) + x0;
+        uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { w0 |= yuv_luma(px[r][i]) << (8 * i); w1 |= yuv_luma(px[r][4 + i]) << (8 * i); }
+        if (vec && npx == 8) *reinterpret_cast<uint2 *>(yrow) = make_uint2(w0, w1);
+        else
+            for (int i = 0; i < npx; i++) yrow[i] = (uint8_t)((i < 4 ? w0 >> (8 * i) : w1 >> (8 * (i - 4))) & 255u);
+    }
+    // chroma
+    uint32_t uw = 0, vw = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int rs = 0, gs = 0, bs = 0;
+        yuv_acc(px[0][2 * c], rs, gs, bs); yuv_acc(px[0][2 * c + 1], rs, gs, bs);
+        if (v420) { yuv_acc(px[1][2 * c], rs, gs, bs); yuv_acc(px[1][2 * c + 1], rs, gs, bs); }
+        uint32_t u, v;
+        yuv_chroma(rs, gs, bs, v420 ? 2 : 1, u, v);
+        uw |= u << (8 * c); vw |= v << (8 * c);
+    }
+    const int cy = blockIdx.y;
+    uint8_t *urow = f.u + (size_t)f.u_ls * cy + x0 / 2, *vrow = f.v + (size_t)f.v_ls * cy + x0 / 2;
+    if (vec && npx == 8) {
+        *reinterpret_cast<uint32_t *>(urow) = uw;
+        *reinterpret_cast<uint32_t *>(vrow) = vw;
+    } else {
+        for (int c = 0; c < npx / 2; c++) { urow[c] = (uint8_t)((uw >> (8 * c)) & 255u); vrow[c] = (uint8_t)((vw >> (8 * c)) & 255u); }
+    }
+}
+
 } // namespace ntscsim

@@ -83,6 +83,8 @@ struct ntscsim_ctx {
     std::vector<Field422Dev> host_fields422;
     std::vector<Out422Dev> host_out422;
     DevBuf<Out422Dev> out422;
+    std::vector<YuvDev> host_yuv;
+    DevBuf<YuvDev> yuv;
     DevBuf<uint32_t> rs_luma, rs_chroma;
     FieldDev *stage[2] = {nullptr, nullptr};
     size_t stage_cap[2] = {0, 0};
@@ -96,7 +98,8 @@ struct ntscsim_ctx {
     // host-frame path
     DevBuf<uint8_t> fsrc, fdst;
     // ntscsim_frames_host(): two chunk slots, copy streams and events, kept between calls
-    struct HostSlot { DevBuf<uint8_t> dsrc, ddst; hipEvent_t up = nullptr, done = nullptr, down = nullptr; };
+    struct HostSlot { DevBuf<uint8_t> dsrc, ddst, dyuv; DevBuf<YuvDev> yrec;
+                      hipEvent_t up = nullptr, done = nullptr, down = nullptr; };
     HostSlot hslot[2];
     hipStream_t s_up = nullptr, s_dn = nullptr;
 
@@ -310,10 +313,10 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geom.sstart.release(); c->geom.jwarm.release();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->comp_ghost.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (auto &h : c->hslot) {
-        h.dsrc.release(); h.ddst.release();
+        h.dsrc.release(); h.ddst.release(); h.dyuv.release(); h.yrec.release();
         if (h.up) (void)hipEventDestroy(h.up);
         if (h.done) (void)hipEventDestroy(h.done);
         if (h.down) (void)hipEventDestroy(h.down);
@@ -431,6 +434,7 @@ static int prepare_records(ntscsim_ctx *c, const ntscsim_field_desc *descs, int 
         al_dst = al_dst && !(((uintptr_t)d.dst_dev | (uintptr_t)d.dst_linesize) & 15);
         any_bob = any_bob || (d.flags & NTSCSIM_DESC_BOB);
     }
+    if (any_bob && n > 65535) return NTSCSIM_E_SIZE;      // k_bob: one grid row per field
     c->rng_pos = pos;
     D.src_al16 = al_src; D.dst_al16 = al_dst;
     return NTSCSIM_OK;
@@ -647,6 +651,7 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     if (n == 0) return NTSCSIM_OK;
     if (n < 0) return NTSCSIM_E_ARG;
     if (W < 16 || (W & 1) || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;   // 4:2:2
+    if (n > 65535) return NTSCSIM_E_SIZE;                 // render / black-key grids: one plane per field
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     const ntscsim_params &p = c->prm;
@@ -793,6 +798,7 @@ extern "C" int ntscsim_output422_device(ntscsim_ctx *c, const ntscsim_out422_des
     if (n == 0) return NTSCSIM_OK;
     if (n < 0) return NTSCSIM_E_ARG;
     if (W < 16 || (W & 1) || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
+    if (n > 65535) return NTSCSIM_E_SIZE;                 // one grid row per descriptor
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
     c->host_out422.resize((size_t)n);
@@ -823,6 +829,46 @@ extern "C" int ntscsim_output422_device(ntscsim_ctx *c, const ntscsim_out422_des
     HIPCHK(c, hipStreamSynchronize(st));
     hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)n), dim3(256), 0, st, D, c->out422.p,
                        al4 ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_bgra_to_yuv_device(ntscsim_ctx *c, const ntscsim_yuv_desc *descs, int n,
+                                          int W, int H, int pix_fmt, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0 || (pix_fmt != NTSCSIM_PIX_YUV420P && pix_fmt != NTSCSIM_PIX_YUV422P)) return NTSCSIM_E_ARG;
+    if (W < 2 || (W & 1) || H < 1 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
+    if (n > 65535) return NTSCSIM_E_SIZE;                 // one grid plane per frame
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->host_yuv.resize((size_t)n);
+    bool vec = (W & 7) == 0;
+    for (int i = 0; i < n; i++) {
+        const ntscsim_yuv_desc &d = descs[i];
+        if (!d.bgra_dev || !d.yuv_dev[0] || !d.yuv_dev[1] || !d.yuv_dev[2]) return NTSCSIM_E_ARG;
+        if (d.bgra_linesize < 4 * W || (d.bgra_linesize & 3) || ((uintptr_t)d.bgra_dev & 3)) return NTSCSIM_E_SIZE;
+        if (d.yuv_linesize[0] < W || d.yuv_linesize[1] < W / 2 || d.yuv_linesize[2] < W / 2) return NTSCSIM_E_SIZE;
+        YuvDev &o = c->host_yuv[(size_t)i];
+        o.bgra = (const uint8_t *)d.bgra_dev; o.bgra_ls = d.bgra_linesize;
+        o.y = (uint8_t *)d.yuv_dev[0]; o.u = (uint8_t *)d.yuv_dev[1]; o.v = (uint8_t *)d.yuv_dev[2];
+        o.y_ls = d.yuv_linesize[0]; o.u_ls = d.yuv_linesize[1]; o.v_ls = d.yuv_linesize[2];
+        vec = vec && !(((uintptr_t)o.bgra | (uintptr_t)o.bgra_ls) & 15) &&
+              !(((uintptr_t)o.y | (uintptr_t)o.y_ls) & 7) &&
+              !(((uintptr_t)o.u | (uintptr_t)o.u_ls | (uintptr_t)o.v | (uintptr_t)o.v_ls) & 3);
+    }
+    DevParams D;
+    std::memset(&D, 0, sizeof(D));
+    D.W = W; D.H = H;
+    HIPCHK(c, c->yuv.ensure((size_t)n));
+    HIPCHK(c, hipMemcpyAsync(c->yuv.p, c->host_yuv.data(), (size_t)n * sizeof(YuvDev),
+                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // (pageable staging vector)
+    const int v420 = pix_fmt == NTSCSIM_PIX_YUV420P;
+    const unsigned rows = v420 ? (unsigned)(H + 1) / 2 : (unsigned)H;
+    hipLaunchKernelGGL(k_bgra_to_yuv, dim3((unsigned)((W / 8 + 1 + 127) / 128), rows, (unsigned)n),
+                       dim3(128), 0, st, D, c->yuv.p, v420, vec ? 1 : 0);
     HIPCHK(c, hipGetLastError());
     return NTSCSIM_OK;
 }
@@ -873,24 +919,40 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
 {
     if (!c || !src || !dst || n_frames < 0) return NTSCSIM_E_ARG;
     if (n_frames == 0) return NTSCSIM_OK;
-    if (src_ls < 4 * W || dst_ls < 4 * W) return NTSCSIM_E_SIZE;
+    const uint32_t yuv_bits = flags & (NTSCSIM_HOST_YUV420P | NTSCSIM_HOST_YUV422P);
+    if (yuv_bits == (NTSCSIM_HOST_YUV420P | NTSCSIM_HOST_YUV422P)) return NTSCSIM_E_ARG;
+    const bool yuv = yuv_bits != 0, v420 = yuv_bits == NTSCSIM_HOST_YUV420P;
+    const uint32_t desc_flags = flags & 0xFFFu;
+    if (src_ls < 4 * W) return NTSCSIM_E_SIZE;
+    if (yuv ? (dst_ls < W || (dst_ls & 1) || (W & 1)) : dst_ls < 4 * W) return NTSCSIM_E_SIZE;
     if (W < 16 || H < 2) return NTSCSIM_E_SIZE;
     HIPCHK(c, hipSetDevice(c->device));
     if (chunk_frames <= 0) chunk_frames = 32;
     if (chunk_frames > n_frames) chunk_frames = n_frames;
+    if (chunk_frames > 16384) chunk_frames = 16384;
     // device frames are packed at a 16-byte row pitch (the kernels' vector path); when the host
     // layout is the same, a whole chunk moves as ONE linear copy instead of per-frame 2-D copies
     const size_t pitch = (((size_t)W * 4 + 15) / 16) * 16;
     const size_t fbytes = pitch * H;
+    // planar output frame (host and device): Y rows, then U rows, then V rows
+    const size_t crows = v420 ? ((size_t)H + 1) / 2 : (size_t)H;
+    const size_t ypitch_d = (((size_t)W + 15) / 16) * 16, cpitch_d = ypitch_d / 2;
+    const size_t ybytes_d = ypitch_d * H, cbytes_d = cpitch_d * crows;
+    const size_t obytes_d = yuv ? ybytes_d + 2 * cbytes_d : fbytes;       // multiple of 8
+    const size_t ybytes_h = (size_t)dst_ls * H, cbytes_h = (size_t)(dst_ls / 2) * crows;
+    const size_t obytes_h = yuv ? ybytes_h + 2 * cbytes_h : (size_t)dst_ls * H;
+    if (dst_frame_stride < obytes_h) return NTSCSIM_E_SIZE;
     const bool lin_src = (size_t)src_ls == pitch && src_frame_stride == fbytes;
-    const bool lin_dst = (size_t)dst_ls == pitch && dst_frame_stride == fbytes;
+    const bool lin_dst = yuv ? ((size_t)dst_ls == ypitch_d && dst_frame_stride == obytes_d)
+                             : ((size_t)dst_ls == pitch && dst_frame_stride == fbytes);
     const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (size_t)src_ls * H;
-    const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + (size_t)dst_ls * H;
+    const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + obytes_h;
     const bool pin_src = hipHostRegister((void *)src, src_span, hipHostRegisterDefault) == hipSuccess;
     const bool pin_dst = hipHostRegister((void *)dst, dst_span, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
 
-    struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr; hipEvent_t up = nullptr, done = nullptr, down = nullptr; bool used = false; };
+    struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr, *dyuv = nullptr; YuvDev *yrec = nullptr;
+                  hipEvent_t up = nullptr, done = nullptr, down = nullptr; bool used = false; };
     Slot slot[2];
     int rc = NTSCSIM_OK;
     auto fail = [&](hipError_t e, const char *what) {
@@ -900,6 +962,7 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     if (!c->s_up) fail(hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking), "hipStreamCreate");
     if (!c->s_dn) fail(hipStreamCreateWithFlags(&c->s_dn, hipStreamNonBlocking), "hipStreamCreate");
     const hipStream_t s_up = c->s_up, s_dn = c->s_dn;
+    std::vector<YuvDev> yrec_host;
     for (int i = 0; i < 2 && rc == NTSCSIM_OK; i++) {
         ntscsim_ctx::HostSlot &h = c->hslot[i];
         fail(h.dsrc.ensure(fbytes * chunk_frames), "hipMalloc");
@@ -909,7 +972,26 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
         if (!h.down) fail(hipEventCreateWithFlags(&h.down, hipEventDisableTiming), "hipEventCreate");
         slot[i].dsrc = h.dsrc.p; slot[i].ddst = h.ddst.p;
         slot[i].up = h.up; slot[i].done = h.done; slot[i].down = h.down;
+        if (yuv && rc == NTSCSIM_OK) {
+            // conversion records of this slot: fixed addresses, uploaded once per call
+            fail(h.dyuv.ensure(obytes_d * chunk_frames * 2), "hipMalloc");
+            fail(h.yrec.ensure((size_t)chunk_frames * 2), "hipMalloc");
+            if (rc != NTSCSIM_OK) break;
+            slot[i].dyuv = h.dyuv.p; slot[i].yrec = h.yrec.p;
+            yrec_host.resize((size_t)chunk_frames * 2);
+            for (int k = 0; k < 2 * chunk_frames; k++) {
+                YuvDev &o = yrec_host[(size_t)k];
+                o.bgra = h.ddst.p + fbytes * (size_t)k; o.bgra_ls = (int32_t)pitch;
+                o.y = h.dyuv.p + obytes_d * (size_t)k; o.u = o.y + ybytes_d; o.v = o.u + cbytes_d;
+                o.y_ls = (int32_t)ypitch_d; o.u_ls = o.v_ls = (int32_t)cpitch_d;
+            }
+            fail(hipMemcpy(h.yrec.p, yrec_host.data(), yrec_host.size() * sizeof(YuvDev),
+                           hipMemcpyHostToDevice), "hipMemcpy");
+        }
     }
+    DevParams Dyuv;
+    std::memset(&Dyuv, 0, sizeof(Dyuv));
+    Dyuv.W = W; Dyuv.H = H;
     std::vector<ntscsim_field_desc> descs((size_t)chunk_frames * 2);
     uint64_t cur = first_fieldno;
     int chunk_no = 0;
@@ -939,7 +1021,7 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
             d.dst_dev = sl.ddst + fbytes * (size_t)k;
             d.src_linesize = (int)pitch; d.dst_linesize = (int)pitch;
             d.field = (uint32_t)((cur & 1) ^ 1);              // ffmpeg_ntsc.cpp:2229
-            d.flags = flags;
+            d.flags = desc_flags;
             d.fieldno = cur++;
             d.rng_pos = NTSCSIM_RNG_AUTO;
         }
@@ -947,16 +1029,37 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
             const int r2 = ntscsim_fields_device(c, descs.data(), 2 * nf, W, H, c->stream);
             if (r2 != NTSCSIM_OK) { rc = r2; break; }
         }
+        if (yuv) {
+            // the encoder's pixel format, made on the GPU: the download shrinks 4 -> 1.5 / 2 B per pixel
+            const unsigned rows = (unsigned)crows;
+            hipLaunchKernelGGL(k_bgra_to_yuv, dim3((unsigned)((W / 8 + 1 + 127) / 128), rows, (unsigned)(2 * nf)),
+                               dim3(128), 0, c->stream, Dyuv, sl.yrec, v420 ? 1 : 0, (W & 7) == 0 ? 1 : 0);
+            fail(hipGetLastError(), "k_bgra_to_yuv");
+        }
         fail(hipEventRecord(sl.done, c->stream), "hipEventRecord");
         // D2H on its own stream, after the kernels
         fail(hipStreamWaitEvent(s_dn, sl.done, 0), "hipStreamWaitEvent");
+        const uint8_t *dout = yuv ? sl.dyuv : sl.ddst;
         if (lin_dst)
-            fail(hipMemcpyAsync(dst + fbytes * (size_t)(2 * f0), sl.ddst, fbytes * (size_t)(2 * nf),
+            fail(hipMemcpyAsync(dst + obytes_d * (size_t)(2 * f0), dout, obytes_d * (size_t)(2 * nf),
                                 hipMemcpyDeviceToHost, s_dn), "hipMemcpyAsync D2H");
-        else for (int k = 0; k < 2 * nf && rc == NTSCSIM_OK; k++)
-            fail(hipMemcpy2DAsync(dst + dst_frame_stride * (size_t)(2 * f0 + k), (size_t)dst_ls,
-                                  sl.ddst + fbytes * (size_t)k, pitch, (size_t)W * 4, (size_t)H,
-                                  hipMemcpyDeviceToHost, s_dn), "hipMemcpy2DAsync D2H");
+        else if (!yuv)
+            for (int k = 0; k < 2 * nf && rc == NTSCSIM_OK; k++)
+                fail(hipMemcpy2DAsync(dst + dst_frame_stride * (size_t)(2 * f0 + k), (size_t)dst_ls,
+                                      sl.ddst + fbytes * (size_t)k, pitch, (size_t)W * 4, (size_t)H,
+                                      hipMemcpyDeviceToHost, s_dn), "hipMemcpy2DAsync D2H");
+        else
+            for (int k = 0; k < 2 * nf && rc == NTSCSIM_OK; k++) {
+                uint8_t *hf = dst + dst_frame_stride * (size_t)(2 * f0 + k);
+                const uint8_t *df = sl.dyuv + obytes_d * (size_t)k;
+                fail(hipMemcpy2DAsync(hf, (size_t)dst_ls, df, ypitch_d, (size_t)W, (size_t)H,
+                                      hipMemcpyDeviceToHost, s_dn), "hipMemcpy2DAsync D2H");
+                fail(hipMemcpy2DAsync(hf + ybytes_h, (size_t)dst_ls / 2, df + ybytes_d, cpitch_d,
+                                      (size_t)W / 2, crows, hipMemcpyDeviceToHost, s_dn), "hipMemcpy2DAsync D2H");
+                fail(hipMemcpy2DAsync(hf + ybytes_h + cbytes_h, (size_t)dst_ls / 2, df + ybytes_d + cbytes_d,
+                                      cpitch_d, (size_t)W / 2, crows, hipMemcpyDeviceToHost, s_dn),
+                     "hipMemcpy2DAsync D2H");
+            }
         fail(hipEventRecord(sl.down, s_dn), "hipEventRecord");
         sl.used = true;
     }

@@ -8,7 +8,7 @@ import ctypes as C
 
 from . import _capi
 from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, Field422Desc, FieldDesc,
-                    NtscsimError, Out422Desc, Params, lib, make_params, make_params_to_composite)
+                    NtscsimError, Out422Desc, YuvDesc, Params, lib, make_params, make_params_to_composite)
 
 __all__ = ["FieldSimulator", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
            "field_rows", "calls_per_field", "field_schedule"]
@@ -81,16 +81,42 @@ class FieldSimulator:
                                      dst.strides[0], w, h, int(field), int(fieldno))
         self._chk(rc, "ntscsim_field")
 
-    def frames_host(self, dst, src, first_fieldno=0, bob=True, chunk_frames=0):
-        """The field loop over host frames: src numpy uint8 [N, H, W, 4], dst [2N, H, W, 4]."""
+    def frames_host(self, dst, src, first_fieldno=0, bob=True, chunk_frames=0, yuv=None):
+        """The field loop over host frames: src numpy uint8 [N, H, W, 4], dst [2N, H, W, 4].
+        yuv = "420" / "422": dst is uint8 [2N, frame_bytes], each frame Y|U|V planes packed at
+        linesize W (chroma W/2)."""
         n, h, w = src.shape[:3]
-        assert dst.shape == (2 * n, h, w, 4) and src.flags.c_contiguous and dst.flags.c_contiguous
+        assert src.flags.c_contiguous and dst.flags.c_contiguous
         u8p = C.POINTER(C.c_uint8)
+        flags = DESC_BOB if bob else 0
+        if yuv is None:
+            assert dst.shape == (2 * n, h, w, 4)
+            dls = dst.strides[1]
+        else:
+            flags |= _capi.HOST_YUV420P if yuv == "420" else _capi.HOST_YUV422P
+            assert dst.ndim == 2 and dst.shape[0] == 2 * n
+            dls = w
         rc = self._lib.ntscsim_frames_host(self._h, src.ctypes.data_as(u8p), src.strides[0],
                                            src.strides[1], n, dst.ctypes.data_as(u8p),
-                                           dst.strides[0], dst.strides[1], w, h, int(first_fieldno),
-                                           DESC_BOB if bob else 0, int(chunk_frames))
+                                           dst.strides[0], dls, w, h, int(first_fieldno),
+                                           flags, int(chunk_frames))
         self._chk(rc, "ntscsim_frames_host")
+
+    def bgra_to_yuv(self, jobs, width, height, pix_fmt, stream=None):
+        """jobs: list of (bgra CUDA uint8 tensor [H, ls], (y, u, v) CUDA uint8 tensors [rows, ls])."""
+        arr = (YuvDesc * len(jobs))()
+        for d, (bgra, planes) in zip(arr, jobs):
+            d.bgra_dev = bgra.data_ptr()
+            d.bgra_linesize = bgra.stride(0)
+            for k in range(3):
+                d.yuv_dev[k] = planes[k].data_ptr()
+                d.yuv_linesize[k] = planes[k].stride(0)
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.ntscsim_bgra_to_yuv_device(self._h, arr, len(jobs), int(width), int(height),
+                                                  int(pix_fmt), C.c_void_p(stream))
+        self._chk(rc, "ntscsim_bgra_to_yuv_device")
 
     # ---- batched, device-resident -----------------------------------------------------------
     def build_descs(self, src, dst, jobs, bob=False, interlaced=0, tff=0, rng_pos=None):

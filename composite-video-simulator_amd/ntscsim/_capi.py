@@ -29,7 +29,7 @@ EXPORTS = (
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
     "ntscsim_debug_force_generic",
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
-    "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_rng_calls_per_field_422",
+    "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_bgra_to_yuv_device", "ntscsim_rng_calls_per_field_422",
 )
 
 
@@ -125,6 +125,20 @@ class Out422Desc(C.Structure):
 
 OUT422_BOB422, OUT422_BOB420, OUT422_INTERLACED420 = 0, 1, 2
 
+
+class YuvDesc(C.Structure):
+    """struct ntscsim_yuv_desc"""
+    _fields_ = [
+        ("bgra_dev", C.c_void_p),
+        ("yuv_dev", C.c_void_p * 3),
+        ("bgra_linesize", C.c_int32),
+        ("yuv_linesize", C.c_int32 * 3),
+    ]
+
+
+PIX_YUV420P, PIX_YUV422P = 0, 1
+HOST_YUV420P, HOST_YUV422P = 0x1000, 0x2000
+
 _u8p = C.POINTER(C.c_uint8)
 _lib = None
 
@@ -204,6 +218,9 @@ def lib():
     L.ntscsim_output422_device.argtypes = [C.c_void_p, C.POINTER(Out422Desc), C.c_int, C.c_int,
                                            C.c_int, C.c_void_p]
     L.ntscsim_output422_device.restype = C.c_int
+    L.ntscsim_bgra_to_yuv_device.argtypes = [C.c_void_p, C.POINTER(YuvDesc), C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p]
+    L.ntscsim_bgra_to_yuv_device.restype = C.c_int
     L.ntscsim_rng_calls_per_field_422.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_uint]
     L.ntscsim_rng_calls_per_field_422.restype = C.c_uint64
     L.ntscsim_debug_force_generic.argtypes = [C.c_void_p, C.c_int]

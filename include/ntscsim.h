@@ -217,6 +217,12 @@ int ntscsim_frames_host(ntscsim_ctx *ctx, const uint8_t *src, size_t src_frame_s
                         int src_linesize, int n_frames, uint8_t *dst, size_t dst_frame_stride,
                         int dst_linesize, int width, int height, uint64_t first_fieldno,
                         uint32_t flags, int chunk_frames);
+/* `flags` bits for ntscsim_frames_host() in addition to NTSCSIM_DESC_*: deliver the output frames as
+ * planar YUV instead of BGRA (each output frame at dst + k*dst_frame_stride holds the Y plane,
+ * height rows of dst_linesize bytes, then U, then V, chroma rows of dst_linesize/2 bytes;
+ * dst_linesize >= width, even). */
+#define NTSCSIM_HOST_YUV420P 0x1000u
+#define NTSCSIM_HOST_YUV422P 0x2000u
 
 /* ---- batched, device-resident form (what the field loop :2202-2282 becomes) -------------- */
 
@@ -324,6 +330,25 @@ typedef struct ntscsim_out422_desc {
 
 int ntscsim_output422_device(ntscsim_ctx *ctx, const ntscsim_out422_desc *descs, int n,
                              int width, int height, void *hip_stream);
+
+/* ---- encoder-side colour conversion (output side) ------------------------
+ * What the tool does with sws_scale(BGRA -> codec pix_fmt) at ffmpeg_ntsc.cpp:2266 (pix_fmt chosen
+ * at :1998: YUV420P, or YUV422P with -422).  libswscale is a third-party dependency that is not
+ * in the reference tree, so this is NOT a bit-clone of it ("parity unpinned"): BT.601 limited
+ * range, 15-bit fixed point, Y = (8414 R + 16519 G + 3208 B + (16<<15) + (1<<14)) >> 15; Cb/Cr from
+ * the channel sums of each 2x1 (4:2:2) or 2x2 (4:2:0; an odd last row counts twice) block with
+ * coefficients (-4864,-9527,14392) / (14392,-12060,-2331), +128, rounded.  Width must be even.
+ * Converting on the GPU shrinks the device-to-host payload from 4 to 1.5 / 2 bytes per pixel. */
+#define NTSCSIM_PIX_YUV420P 0
+#define NTSCSIM_PIX_YUV422P 1
+typedef struct ntscsim_yuv_desc {
+    const void *bgra_dev;           /* BGRA frame (e.g. a bob frame written by ntscsim_fields_device) */
+    void       *yuv_dev[3];         /* Y, U, V planes; chroma (height+1)/2 rows for 4:2:0          */
+    int32_t     bgra_linesize;
+    int32_t     yuv_linesize[3];
+} ntscsim_yuv_desc;
+int ntscsim_bgra_to_yuv_device(ntscsim_ctx *ctx, const ntscsim_yuv_desc *descs, int n,
+                               int width, int height, int pix_fmt, void *hip_stream);
 /* draws of one composite_video_process() call (chroma noise runs at width/2 samples per row) */
 uint64_t ntscsim_rng_calls_per_field_422(const ntscsim_params *p, int width, int height,
                                          unsigned field);

@@ -589,3 +589,38 @@ void ntsc_oracle_make_noise(uint8_t *bgra, int linesize, int W, int H, uint32_t 
         }
     }
 }
+
+/* see ntsc_oracle.h: the product's own BT.601 definition (parity unpinned, no libswscale here) */
+void ntsc_oracle_bgra_to_yuv(const uint8_t *bgra, int bgra_linesize, int width, int height,
+                             uint8_t *y, int y_linesize, uint8_t *u, int u_linesize,
+                             uint8_t *v, int v_linesize, int is420)
+{
+    const int RY = (int)(0.299 * 219 / 255 * 32768 + 0.5), GY = (int)(0.587 * 219 / 255 * 32768 + 0.5),
+              BY = (int)(0.114 * 219 / 255 * 32768 + 0.5);
+    const int RU = (int)(-0.169 * 224 / 255 * 32768 + 0.5), GU = (int)(-0.331 * 224 / 255 * 32768 + 0.5),
+              BU = (int)(0.500 * 224 / 255 * 32768 + 0.5);
+    const int RV = (int)(0.500 * 224 / 255 * 32768 + 0.5), GV = (int)(-0.419 * 224 / 255 * 32768 + 0.5),
+              BV = (int)(-0.081 * 224 / 255 * 32768 + 0.5);
+    for (int yy = 0; yy < height; yy++)
+        for (int x = 0; x < width; x++) {
+            const uint8_t *p = bgra + (size_t)bgra_linesize * yy + 4 * x;
+            y[(size_t)y_linesize * yy + x] =
+                (uint8_t)((RY * p[2] + GY * p[1] + BY * p[0] + (16 << 15) + (1 << 14)) >> 15);
+        }
+    const int step = is420 ? 2 : 1, lg = is420 ? 2 : 1, sh = 15 + lg;
+    for (int y0 = 0, cy = 0; y0 < height; y0 += step, cy++) {
+        const int y1 = (is420 && y0 + 1 < height) ? y0 + 1 : y0;
+        for (int cx = 0; cx < width / 2; cx++) {
+            int rs = 0, gs = 0, bs = 0;
+            for (int r = 0; r < (is420 ? 2 : 1); r++)
+                for (int k = 0; k < 2; k++) {
+                    const uint8_t *p = bgra + (size_t)bgra_linesize * (r ? y1 : y0) + 4 * (2 * cx + k);
+                    bs += p[0]; gs += p[1]; rs += p[2];
+                }
+            u[(size_t)u_linesize * cy + cx] =
+                (uint8_t)((RU * rs + GU * gs + BU * bs + (128 << sh) + (1 << (sh - 1))) >> sh);
+            v[(size_t)v_linesize * cy + cx] =
+                (uint8_t)((RV * rs + GV * gs + BV * bs + (128 << sh) + (1 << (sh - 1))) >> sh);
+        }
+    }
+}

@@ -67,6 +67,14 @@ uint64_t ntsc_oracle_fnv1a(const void *buf, size_t n);
 void ntsc_oracle_make_bars(uint8_t *bgra, int linesize, int width, int height, int rot);
 void ntsc_oracle_make_noise(uint8_t *bgra, int linesize, int width, int height, uint32_t seed);
 
+/* Encoder-side colour conversion (output side; the tool calls sws_scale at
+ * ffmpeg_ntsc.cpp:2266).  PARITY UNPINNED: libswscale is not in the reference tree; this is the
+ * plain-C statement of the product's own definition (include/ntscsim.h: BT.601 limited range,
+ * 15-bit fixed point, 2x1 / 2x2 block chroma), used to check the HIP kernel bit for bit. */
+void ntsc_oracle_bgra_to_yuv(const uint8_t *bgra, int bgra_linesize, int width, int height,
+                             uint8_t *y, int y_linesize, uint8_t *u, int u_linesize,
+                             uint8_t *v, int v_linesize, int is420);
+
 #ifdef __cplusplus
 }
 #endif

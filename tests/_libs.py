@@ -69,6 +69,9 @@ def oracle():
         lib.ntsc_oracle_field.restype = C.c_int
         lib.ntsc_oracle_bob.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_uint]
         lib.ntsc_oracle_bob.restype = None
+        lib.ntsc_oracle_bgra_to_yuv.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u8p,
+                                                C.c_int, _u8p, C.c_int, C.c_int]
+        lib.ntsc_oracle_bgra_to_yuv.restype = None
         lib.ntsc_oracle_fnv1a.argtypes = [C.c_void_p, C.c_size_t]
         lib.ntsc_oracle_fnv1a.restype = C.c_uint64
         lib.ntsc_oracle_make_bars.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -340,3 +343,16 @@ class TocompRefStream:
         d, ls = frame.ptr_arrays()
         tocomp_ref().tocomp_ref_process(C.cast(d, C.POINTER(C.POINTER(C.c_uint8))), ls, frame.w,
                                         frame.h, field, fieldno)
+
+
+def oracle_bgra_to_yuv(bgra, is420):
+    """bgra: uint8 [H, W, 4] -> (Y [H, W], U, V [(H+1)//2 or H, W//2]) by the oracle's definition."""
+    h, w = bgra.shape[:2]
+    ch = (h + 1) // 2 if is420 else h
+    y = np.zeros((h, w), np.uint8)
+    u = np.zeros((ch, w // 2), np.uint8)
+    v = np.zeros((ch, w // 2), np.uint8)
+    src = np.ascontiguousarray(bgra)
+    oracle().ntsc_oracle_bgra_to_yuv(_ptr(src), w * 4, w, h, _ptr(y), w, _ptr(u), w // 2, _ptr(v), w // 2,
+                                     1 if is420 else 0)
+    return y, u, v

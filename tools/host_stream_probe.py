@@ -32,3 +32,14 @@ for ch in (16, 32, 64, 150, 300):
     dt = time.perf_counter() - t0
     print("pinned, chunk %d frames: %.0f fields/s (%.1f GB/s combined)" % (ch, 2 * n / dt, (src.nbytes + dst.nbytes) / dt / 1e9))
 assert (tdst.numpy() == dst).all()
+
+# encoder pixel format made on the GPU: planar YUV 4:2:0 out (1.5 B/pixel instead of 4)
+fb = w * h + 2 * (w // 2) * ((h + 1) // 2)
+tyuv = torch.empty((2 * n, fb), dtype=torch.uint8).pin_memory()
+for ch in (16, 32, 64):
+    sim.rng_pos = 0
+    t0 = time.perf_counter()
+    sim.frames_host(tyuv.numpy(), tsrc.numpy(), first_fieldno=0, chunk_frames=ch, yuv="420")
+    dt = time.perf_counter() - t0
+    print("pinned, YUV420P out, chunk %d frames: %.0f fields/s (%.1f GB/s combined)" % (
+        ch, 2 * n / dt, (src.nbytes + tyuv.numel()) / dt / 1e9))
