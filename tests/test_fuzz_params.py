@@ -1,0 +1,228 @@
+"""Seeded random sweeps over the tool's switches and frame geometries.
+
+CPU (-m "not gpu"): the oracle against the reference's own composite_layer() (oracle/_ref) --
+widens the pin of the restatement beyond the hand-written case matrix.
+GPU (-m gpu): the HIP path against the oracle on the same draws.  Bit-exact (tolerance 0)."""
+import random
+
+import numpy as np
+import pytest
+
+import _libs as L
+import cases
+
+N_REF = 200         # oracle vs reference draws (CPU, small frames)
+N_GPU = 200         # HIP vs oracle draws
+
+
+def draw(seed):
+    """One random configuration: (flags, W, H, n_fields, source kind, interlaced, tff)."""
+    r = random.Random(seed)
+    f = []
+    if r.random() < 0.6:
+        f.append("-vhs")
+    if r.random() < 0.35:
+        f += ["-vhs-speed", r.choice(["sp", "lp", "ep"])]
+    if r.random() < 0.15:
+        f += ["-tvstd", "pal"]
+    if r.random() < 0.3:
+        f += ["-comp-phase", r.choice(["0", "90", "180", "270"])]
+    if r.random() < 0.3:
+        f += ["-comp-phase-offset", str(r.randrange(0, 4))]
+    if r.random() < 0.3:
+        f.append(r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"]))
+    elif r.random() < 0.15:
+        f += ["-comp-pre", "%.3f" % r.uniform(0.2, 2.5), "-comp-cut", str(r.randrange(300000, 3000000))]
+    if r.random() < 0.35:
+        f += ["-noise", str(r.choice([0, 1, 2, 7, 30, 200]))]
+    if r.random() < 0.35:
+        f += ["-chroma-noise", str(r.choice([0, 1, 5, 16, 64, 300]))]
+    if r.random() < 0.35:
+        f += ["-chroma-phase-noise", str(r.choice([0, 1, 4, 25, 90]))]
+    if r.random() < 0.3:
+        f += ["-chroma-dropout", str(r.choice([0, 4, 2000, 30000, 99999]))]
+    if r.random() < 0.25:
+        f += ["-subcarrier-amp", str(r.choice([10, 30, 50, 75, 120]))]
+    if r.random() < 0.2:
+        f += ["-in-composite-lowpass", str(r.randrange(0, 2))]
+    if r.random() < 0.25:
+        f += ["-out-composite-lowpass", str(r.randrange(0, 2))]
+    if r.random() < 0.25:
+        f += ["-out-composite-lowpass-lite", str(r.randrange(0, 2))]
+    if r.random() < 0.12:
+        f.append("-nocolor-subcarrier")
+    if r.random() < 0.2:
+        f += ["-vhs-svideo", str(r.randrange(0, 2))]
+    if r.random() < 0.2:
+        f += ["-vhs-chroma-vblend", str(r.randrange(0, 2))]
+    if r.random() < 0.25:
+        # head switch inside a small frame: point in rows, phase in columns
+        f += ["-vhs-head-switching", "1", "-vhs-head-switching-point", "%.4f" % r.uniform(0.09, 0.125),
+              "-vhs-head-switching-phase", "%.5f" % r.uniform(0.0003, 0.0035)]
+        if r.random() < 0.4:
+            f += ["-vhs-head-switching-noise-level", r.choice(["0", "0.000005", "0.00002"])]
+    w = r.choice([16, 17, 31, 64, 65, 96, 100, 127, 130])
+    h = r.choice([2, 3, 7, 16, 31, 32, 33, 40])
+    n = r.randrange(1, 5)
+    kind = r.choice(["noise", "noise", "bars", "ramp", "impulse"])
+    if kind in ("ramp", "impulse") and (w < 4 or h < 3):
+        kind = "noise"
+    il = r.randrange(0, 2)
+    tff = r.randrange(0, 2)
+    return f, w, h, n, kind, il, tff
+
+
+def test_draws_are_valid_and_varied():
+    seen = set()
+    for s in range(max(N_REF, N_GPU)):
+        f, w, h, n, kind, il, tff = draw(s)
+        L.make_params(f)                      # must parse and validate
+        seen.add(tuple(f))
+    assert len(seen) > 0.8 * max(N_REF, N_GPU)
+
+
+@pytest.mark.skipif(not L.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("seed", range(N_REF))
+def test_oracle_equals_reference_on_random_parameters(seed):
+    f, w, h, n, kind, il, tff = draw(seed)
+    p = L.make_params(f)
+    srcs = [cases.make_source(kind, w, h, j + seed) for j in range((n + 1) // 2)]
+    o, r = L.OracleStream(p), L.RefStream(p)
+    do = np.full((h, w, 4), 9, np.uint8)
+    dr = np.full((h, w, 4), 9, np.uint8)
+    for (si, field, fieldno) in cases.case_jobs(n):
+        if field >= h:
+            continue
+        r.field(dr, srcs[si], field, fieldno, il, tff)
+        o.field(do, srcs[si], field, fieldno, il, tff)
+        assert np.array_equal(do, dr), (f, w, h, fieldno)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_GPU))
+def test_hip_equals_oracle_on_random_parameters(seed):
+    import torch
+    import ntscsim
+    f, w, h, n, kind, il, tff = draw(1000 + seed)
+    p = L.make_params(f)
+    srcs = [cases.make_source(kind, w, h, j + seed) for j in range((n + 1) // 2)]
+    o = L.OracleStream(p)
+    want = np.full((h, w, 4), 9, np.uint8)
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.full((1, h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    for (si, field, fieldno) in cases.case_jobs(n):
+        if field >= h:
+            continue
+        o.field(want, srcs[si], field, fieldno, il, tff)
+        sim.fields(src, dst, [(si, 0, field, fieldno)], interlaced=il, tff=tff)
+        sim.sync()
+        assert np.array_equal(dst[0].cpu().numpy(), want), (f, w, h, fieldno)
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+# ------------------------------------------------------------- 8-bit YUV422P variant ----------
+N_REF422 = 120
+N_GPU422 = 120
+
+
+def draw422(seed):
+    """One random ffmpeg_to_composite configuration: (flags, W (even), H, n_fields, source)."""
+    r = random.Random(50000 + seed)
+    f = []
+    if r.random() < 0.6:
+        f.append("-vhs")
+    if r.random() < 0.35:
+        f += ["-vhs-speed", r.choice(["sp", "lp", "ep"])]
+    if r.random() < 0.15:
+        f += ["-tvstd", "pal"]
+    if r.random() < 0.3:
+        f += ["-comp-phase", r.choice(["0", "90", "180", "270"])]
+    if r.random() < 0.3:
+        f += ["-comp-phase-offset", str(r.randrange(0, 4))]
+    if r.random() < 0.3:
+        f.append(r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3"]))
+    if r.random() < 0.35:
+        f += ["-noise", str(r.choice([0, 1, 2, 7, 30]))]
+    if r.random() < 0.35:
+        f += ["-chroma-noise", str(r.choice([0, 1, 5, 16, 64]))]
+    if r.random() < 0.35:
+        f += ["-chroma-phase-noise", str(r.choice([0, 1, 4, 25, 90]))]
+    if r.random() < 0.3:
+        f += ["-chroma-dropout", str(r.choice([0, 4, 2000, 30000, 99999]))]
+    if r.random() < 0.25:
+        f += ["-subcarrier-amp", str(r.choice([10, 30, 50, 75, 120]))]
+    if r.random() < 0.2:
+        f += ["-in-composite-lowpass", str(r.randrange(0, 2))]
+    if r.random() < 0.25:
+        f += ["-out-composite-lowpass", str(r.randrange(0, 2))]
+    if r.random() < 0.25:
+        f += ["-out-composite-lowpass-lite", str(r.randrange(0, 2))]
+    if r.random() < 0.12:
+        f.append("-nocolor-subcarrier")
+    if r.random() < 0.12:
+        f.append("-nocolor-subcarrier-after-yc-sep")
+    if r.random() < 0.2:
+        f += ["-yc-recomb", str(r.randrange(0, 4))]
+    if r.random() < 0.2:
+        f += ["-vhs-svideo", str(r.randrange(0, 2))]
+    if r.random() < 0.2:
+        f += ["-vhs-chroma-vblend", str(r.randrange(0, 2))]
+    if r.random() < 0.25:
+        f += ["-vhs-head-switching", "1", "-vhs-head-switching-point", "%.4f" % r.uniform(0.09, 0.125)]
+    w = r.choice([32, 34, 64, 66, 96, 100, 128, 130])
+    h = r.choice([4, 7, 16, 31, 32, 33, 40])
+    n = r.randrange(1, 5)
+    kind = r.choice(["noise", "noise", "bars"])
+    return f, w, h, n, kind
+
+
+def _refresh(dst, src, field):
+    for i in range(3):
+        dst.plane(i)[field::2] = src.plane(i)[field::2]
+
+
+@pytest.mark.skipif(not L.have_tocomp_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("seed", range(N_REF422))
+def test_variant_oracle_equals_reference_on_random_parameters(seed):
+    import cases422
+    f, w, h, n, kind = draw422(seed)
+    p = L.make_params_tocomp(f)
+    pad = 32 if seed & 1 else 0
+    srcs = [cases422.make_source422(kind, w, h, j + seed, pad) for j in range((n + 1) // 2)]
+    a, b = srcs[0].copy(), srcs[0].copy()
+    r, o = L.TocompRefStream(p), L.TocompOracleStream(p, L.OOB_MEMORY)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        _refresh(a, srcs[k // 2], field)
+        _refresh(b, srcs[k // 2], field)
+        r.process(a, field, k)
+        o.process(b, field, k)
+        assert np.array_equal(a.buf, b.buf), (f, w, h, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_GPU422))
+def test_variant_hip_equals_oracle_on_random_parameters(seed):
+    import torch
+    import cases422
+    import ntscsim
+    f, w, h, n, kind = draw422(7000 + seed)
+    p = L.make_params_tocomp(f)
+    srcs = [cases422.make_source422(kind, w, h, j + seed) for j in range((n + 1) // 2)]
+    o = L.TocompOracleStream(p, L.OOB_DEFINED)
+    frame = srcs[0].copy()
+    sim = ntscsim.FieldSimulator(params=p)
+    dev = [torch.from_numpy(np.ascontiguousarray(frame.plane(i))).cuda() for i in range(3)]
+    for k in range(n):
+        field = (k & 1) ^ 1
+        _refresh(frame, srcs[k // 2], field)
+        o.process(frame, field, k)
+        srcd = [torch.from_numpy(np.ascontiguousarray(srcs[k // 2].plane(i))).cuda() for i in range(3)]
+        sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
+        sim.sync()
+        for i in range(3):
+            assert np.array_equal(dev[i].cpu().numpy(), frame.pix(i)), (f, w, h, k, i)
+        assert sim.rng_pos == o.rng_pos
+    sim.close()
