@@ -115,3 +115,36 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(root, f), errors="ignore").read()
                 assert "ntsc_oracle" not in txt and "oracle/" not in txt, os.path.join(root, f)
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
+    """include/ntscsim.h compiles as strict C99 and as C++, and every descriptor struct has the
+    size and field offsets of its ctypes mirror (the GPU tests would catch a mismatch only as
+    wrong pixels)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    structs = {"ntscsim_params": _capi.Params, "ntscsim_field_desc": _capi.FieldDesc,
+               "ntscsim_field422_desc": _capi.Field422Desc, "ntscsim_out422_desc": _capi.Out422Desc,
+               "ntscsim_yuv_desc": _capi.YuvDesc}
+    lines = ['#include "ntscsim.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for cname, mirror in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in mirror._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(L.ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)])
+    out = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, mirror in structs.items():
+        assert int(out[cname]) == C.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert int(out["%s.%s" % (cname, fname)]) == getattr(mirror, fname).offset, (cname, fname)
+    if shutil.which("g++"):
+        cpp = tmp_path / "hdr.cpp"
+        cpp.write_text('#include "ntscsim.h"\nint main() { return 0; }\n')
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)])
