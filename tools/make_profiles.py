@@ -91,19 +91,23 @@ for kn, key in (("k_decode", "decode"), ("k_encode", "encode")):
     md.append("| `%s` | %.1f | %.1f | %.1f / %.1f / %.1f |" % (kn, ev[key] * 1e3, ia[0], pa[1], pa[0], pa[2]))
 rs, fs = find(b, "k_row_states"), find(b, "k_field_setup")
 md.append("| `k_row_states` + `k_field_setup` (+ memset) | %.1f (\"setup\") | %.1f + %.1f | |\n" % (ev["setup"] * 1e3, rs[0], fs[0]))
-vd = dec["SQ_INSTS_VALU"] / (dec["SQ_WAVES"] * (720 + 39))
+DSTEPS = 720 + 24      # W + pipeline depth SKT = 7 + cdelay(9, SP) + 7 + 1 (k_decode, -vhs preset)
+vd = dec["SQ_INSTS_VALU"] / (dec["SQ_WAVES"] * DSTEPS)
 ve = enc["SQ_INSTS_VALU"] / (enc["SQ_WAVES"] * (720 + 4))
 ghz = dec["GRBM_GUI_ACTIVE"] / 8 / (find(b, "k_decode")[0] * 1e-6) / 1e9
 md += ["## Where the time goes\n",
-       "* `k_decode<VHS,COMPOUT,preset>`: %d waves x 759 pipeline steps, %.0f VALU instructions per step per wave "
-       "(SQ_INSTS_VALU / waves / steps); every VALU instruction (fp64 or int) occupies its SIMD for 4 cycles "
-       "(SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in quad-cycles).  All-VALU-busy time for the busiest SIMDs (3 resident "
-       "waves) = 3 x 759 x %.0f x 4 cycles = %.2f ms at the observed %.2f GHz; measured %.2f ms => ~%.0f%% VALU issue "
-       "utilisation.  With perfect load balance (2,315 waves over 1,024 SIMDs = 2.26 waves/SIMD) the same instruction "
+       "* `k_decode<VHS,COMPOUT,preset>`: %d waves x 744 pipeline steps (W + depth 24), %.0f VALU instructions per step per wave "
+       "(SQ_INSTS_VALU / waves / steps, averaged over steady and guarded steps).  DERIVED, assuming every VALU "
+       "instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in quad-cycles; "
+       "`tools/valu_rate_probe.hip` shows simple int/fp32 ops can issue faster, so this is an upper bound on the "
+       "busy time): all-VALU-busy time for the busiest SIMDs (3 resident waves) = 3 x 744 x %.0f x 4 cycles = "
+       "%.2f ms at the observed %.2f GHz vs %.2f ms measured (~%.0f%%).  The PMC-based fractions over ALL SIMDs are in "
+       "the bench line: `roofline.valu.k_decode_frac` (one launch) and `path_frac` (three steps in flight).  With "
+       "perfect load balance (2,315 waves over 1,024 SIMDs = 2.26 waves/SIMD) the same instruction "
        "stream would need %.2f ms; three steps in flight recover most of that (%.2f ms per step for the whole chain; a "
        "single 2,400-field batch reaches the same rate on one stream, `tools/bigbatch_probe.py`)." % (
-           int(dec["SQ_WAVES"]), vd, vd, 3 * 759 * vd * 4 / (ghz * 1e9) * 1e3, ghz, ev["decode"],
-           100 * 3 * 759 * vd * 4 / (ghz * 1e9) * 1e3 / ev["decode"], 2.26 * 759 * vd * 4 / (ghz * 1e9) * 1e3, d["ms_per_step"]),
+           int(dec["SQ_WAVES"]), vd, vd, 3 * DSTEPS * vd * 4 / (ghz * 1e9) * 1e3, ghz, ev["decode"],
+           100 * 3 * DSTEPS * vd * 4 / (ghz * 1e9) * 1e3 / ev["decode"], 2.26 * DSTEPS * vd * 4 / (ghz * 1e9) * 1e3, d["ms_per_step"]),
        "* `k_encode<preset>`: %d waves x 724 steps, %.0f VALU instructions per step." % (int(enc["SQ_WAVES"]), ve),
        "* HBM: k_decode %.0f MB fetched + %.0f MB written per launch, k_encode %.0f MB written (= the composite plane, "
        "exact) -- algorithmic 839.8 MB for the whole path; at the measured %.2f ms per step that is %.1f TB/s of "
