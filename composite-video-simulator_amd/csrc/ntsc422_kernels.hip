@@ -10,8 +10,14 @@
 // reference (clampu8 :335), so the sweeps communicate through bytes exactly as the reference's
 // in-place frame does.
 //
-// The reference's Y/C separator reads Y[x+2] two bytes past the row (:496, undefined behaviour);
-// here that read returns 16, the box filter's own pre-charge value (oracle: TOCOMP_OOB_DEFINED).
+// The reference's Y/C separator reads Y[x+2] two bytes past the row (:496).  For every row whose two
+// following bytes lie inside the caller's luma plane (the next row's first pixels, or linesize
+// padding) that read is deterministic, and the kernel reproduces it: the two bytes are fetched once
+// per row before anything is modified (they belong to a row of the OTHER field or to padding, which
+// this call never writes) and fed to every Y/C separation of the row (oracle: TOCOMP_OOB_MEMORY).
+// Only where the read would leave the plane (last row with linesize < W + 2) it returns 16, the box
+// filter's own pre-charge value.  The reference's three writes past its chroma scratch array
+// (:529-532) are dropped, as in the oracle.
 //
 // Included by ntscsim_hip.hip after ntsc_kernels.hip (shares OnePole/Lp3/LaneRand/helpers).
 #pragma clang fp contract(off)
@@ -372,7 +378,7 @@ DEV void chroma_post422(const DevParams &P, ChromaPost422 *cp, int &u, int &v)
 }
 
 DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA,
-                       bool after_yc_sep, ChromaPost422 *cpost = nullptr)
+                       bool after_yc_sep, int oob0, int oob1, ChromaPost422 *cpost = nullptr)
 {
     const int W2 = W / 2;
     // the reader runs over the row; sample x+2 is needed at step x: keep a 2-sample look-ahead
@@ -383,7 +389,7 @@ DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, 
     oy.begin(R.Y); ou.begin(R.U); ov.begin(R.V);
     // Step the reader position r = x + 2.  Outputs at x = r - 2 go to words the reader has passed.
     SWEEP_BEGIN(R.Y, W + 2)
-        const int c_in = x < W ? in : 16;          // Y[r] (16 beyond the row)
+        const int c_in = x < W ? in : (x == W ? oob0 : oob1);   // Y[r]; r >= W: the caller's bytes (:496)
         if (x == 0) { d2 = (unsigned)c_in; sum = 32 + d2; }
         else if (x == 1) { d3 = (unsigned)c_in; sum += d3; }
         else {
@@ -451,6 +457,14 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
     uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
     uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    // the two bytes the reference's Y/C separator reads past the row (:496): inside the luma plane
+    // they are the caller's own bytes, outside it (last row, linesize < W + 2) the defined value 16
+    int oob0 = 16, oob1 = 16;
+    {
+        const size_t off = (size_t)fd.dst_ls[0] * y + (size_t)W, end = (size_t)fd.dst_ls[0] * (size_t)P.H;
+        if (off < end) oob0 = fy[W];
+        if (off + 1 < end) oob1 = fy[W + 1];
+    }
 
     // ---- frame row -> packed transposed scratch.  A scratch word holds 4 consecutive samples in
     // memory order, so aligned rows are moved 16 (luma) / 8 (chroma) bytes per lane per load.
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
             n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
             cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
         }
-        if (!P.nocolor) demodulate422(P, R, W, xi, P.m_amp_back, after_yc_sep != 0, &cp_);
+        if (!P.nocolor) demodulate422(P, R, W, xi, P.m_amp_back, after_yc_sep != 0, oob0, oob1, &cp_);
         else if (cp_.noise_on || cp_.phase_on) {
             // no separation (-nocolor-subcarrier): the noise stages still run on the stored chroma
             Reader422 rv; rv.begin(R.V, W2);
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
         }
         if (!P.svideo) {                                     // :926-929
             modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
-            demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0);
+            demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0, oob0, oob1);
         }
     }
     // ---- chroma dropout :932-942
@@ -615,7 +629,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     // ---- extra Y/C recombine passes :943-946
     for (int i = 0; i < yc_recombine; i++) {
         modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
-        demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0);
+        demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0, oob0, oob1);
     }
     // ---- output chroma low-pass :948-951 (full if "out", else lite if "lite")
     if (P.out_lp == 2) {

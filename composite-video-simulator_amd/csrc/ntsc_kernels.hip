@@ -839,6 +839,14 @@ DEV int dec_steady(const DevParams &P, DecState<RT> &S, const DecConst &C, const
             {
                 const int xo0 = t - SKT;                   // multiple of 4
                 const int sub = (xo0 >> 2) & 3;
+#ifdef NTSC_DIRECT_STORE
+                (void)sub; (void)ostage;
+                if (P.dst_al16) {
+                    if (is_out) *reinterpret_cast<uint4 *>(drow + xo0) = make_uint4(o[0], o[1], o[2], o[3]);
+                } else if (is_out) {
+                    drow[xo0] = o[0]; drow[xo0 + 1] = o[1]; drow[xo0 + 2] = o[2]; drow[xo0 + 3] = o[3];
+                }
+#else
                 if (P.dst_al16) {
                     *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) =
                         make_uint4(o[0], o[1], o[2], o[3]);
@@ -851,6 +859,7 @@ DEV int dec_steady(const DevParams &P, DecState<RT> &S, const DecConst &C, const
                 } else if (is_out) {
                     drow[xo0] = o[0]; drow[xo0 + 1] = o[1]; drow[xo0 + 2] = o[2]; drow[xo0 + 3] = o[3];
                 }
+#endif
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
@@ -860,8 +869,11 @@ DEV int dec_steady(const DevParams &P, DecState<RT> &S, const DecConst &C, const
     return t;
 }
 
+#ifndef NTSC_DEC_WAVES
+#define NTSC_DEC_WAVES 3
+#endif
 template <bool VHS, bool COMPOUT, unsigned F, class RT>
-__global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, NTSC_DEC_WAVES) void k_decode(DevParams P, GeomDev G,
                                                const FieldDev *__restrict__ fields,
                                                const int *__restrict__ comp,
                                                const uint32_t *__restrict__ rs_chroma,
@@ -874,7 +886,11 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
 {
     __shared__ uint32_t ring[31 * 64];
     // output staging: 16 pixels per lane, row stride 20 dwords (16-byte aligned, b128 accesses)
+#ifdef NTSC_DIRECT_STORE
+    uint32_t *ostage = nullptr;
+#else
     __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
+#endif
 
     const int lane = threadIdx.x;
     // 63 output rows per wave; lane 0 recomputes the row above (halo for the vertical blend)
@@ -975,6 +991,10 @@ __global__ __launch_bounds__(64, 3) void k_decode(DevParams P, GeomDev G,
         uint32_t px; int xo;
         if (!dec_step<VHS, COMPOUT, true, O, -1, -1, RT>(P, S, C, ring, t, cs(t), VHS ? cs(t - LOFF) : 0, px, xo))
             continue;
+#ifdef NTSC_DIRECT_STORE
+        if (is_out) drow[xo] = px;
+        continue;
+#endif
         if (!P.dst_al16) { if (is_out) drow[xo] = px; continue; }
         // same 16-pixel staging as the steady loop: whole 64-byte bursts, then the row's tail
         ostage[lane * 20 + (xo & 15)] = px;
