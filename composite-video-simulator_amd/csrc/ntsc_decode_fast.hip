@@ -1,0 +1,522 @@
+// ntsc_decode_fast.hip -- the decoder of the two presets that matter for throughput (the default
+// preset and the full `-vhs` family), written instruction by instruction for the gfx950 VALU.
+// Same execution model and the same results as k_decode (ntsc_kernels.hip): one lane = one
+// scanline, 63 rows + 1 halo row per wave, all stages streamed in x.  What differs is the cost:
+// measured on MI355X (tools/valu_rate_probe.hip) every fp64 instruction and most integer opcodes
+// (v_cndmask, v_lshl*, v_add3, v_med3, v_mul_*) occupy a SIMD for ~4.3 cycles per wave, only
+// add/sub/and/xor/shift-right/mov run at ~2.7, and the decoder sits at ~75 % of that VALU roof --
+// so the only way to go faster is to issue less.  This kernel
+//   * carries each one-pole filter as r = p - p*a, the term the NEXT step adds to its input
+//     product, and feeds pole k+1 (same alpha) with the product p_k*a that pole k needs anyway:
+//     3 fp64 instructions per pole instead of 4 (same operations on the same operands, so the
+//     same bits: ffmpeg_ntsc.cpp:90-99);
+//   * keeps the demodulator windows un-negated and applies the sign when a sample is picked
+//     (ffmpeg_ntsc.cpp:1539-1561: for an even scanline phase the picked sample is negated iff
+//     x = 1 mod 4, which is a compile-time property of the unrolled loop position);
+//   * replaces per-lane selects by mask arithmetic on the full-rate opcodes, the LDS
+//     __shfl_up of the vertical blend by a DPP wave shift, 64-bit address arithmetic by buffer
+//     loads whose bounds check also implements the zero fill of the head-switch displacement
+//     (ffmpeg_ntsc.cpp:1687-1697) for free.
+// Preconditions (checked by the launcher, otherwise k_decode runs): even scanline phase for every
+// row (-comp-phase 180 with an even offset), subcarrier amplitude 50 both ways, output low-pass
+// "lite", 16-byte aligned destination rows, composite plane below 4 GiB, head-switch displacement
+// of at most W/10 samples; VHS form: chroma noise + phase noise on, composite (not s-video) out.
+#pragma clang fp contract(off)
+
+namespace ntscsim {
+namespace fastdec {
+
+#ifdef NTSC_NO_STEP_SCHED_BARRIER
+#define NTSC_STEP_SCHED_BARRIER() ((void)0)
+#else
+// keeps the scheduler from interleaving whole pipeline steps (costs registers, gains nothing)
+#define NTSC_STEP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// ------------------------------------------------------------------ filters
+// three one-pole low-passes with ONE alpha (LowpassFilter x3, ffmpeg_ntsc.cpp:1399-1427 etc.)
+template <class RT>
+struct Casc3;
+template <>
+struct Casc3<double> {
+    double r0, r1, r2;       // r_k = p_k - (p_k * a)
+    DEV void reset(double v, double a) { const double r = v - (v * a); r0 = r1 = r2 = r; }
+    // s = input sample.  Returns the output p2; m2 = p2 * a for a following same-alpha stage.
+    DEV double push(double s, double a, double &m2)
+    {
+        const double p0 = (s * a) + r0;
+        const double m0 = p0 * a;
+        r0 = p0 - m0;
+        const double p1 = m0 + r1;
+        const double m1 = p1 * a;
+        r1 = p1 - m1;
+        const double p2 = m1 + r2;
+        m2 = p2 * a;
+        r2 = p2 - m2;
+        return p2;
+    }
+    DEV double push(double s, double a) { double m; return push(s, a, m); }
+};
+template <>
+struct Casc3<float> {       // FAST32 mode: p += a * (s - p), tests/test_gpu_fast_mode.py
+    float p0, p1, p2;
+    DEV void reset(float v, float) { p0 = p1 = p2 = v; }
+    DEV float push(float s, float a, float &m2)
+    {
+        p0 = __builtin_fmaf(a, s - p0, p0);
+        p1 = __builtin_fmaf(a, p0 - p1, p1);
+        p2 = __builtin_fmaf(a, p1 - p2, p2);
+        m2 = 0.f;
+        return p2;
+    }
+    DEV float push(float s, float a) { float m; return push(s, a, m); }
+};
+// one more pole of the same alpha behind a cascade, used as a high-pass (s - lowpass(s))
+template <class RT>
+struct PoleHp;
+template <>
+struct PoleHp<double> {
+    double r;
+    DEV void reset(double v, double a) { r = v - (v * a); }
+    DEV double hp(double s, double s_times_a, double a)
+    {
+        const double p = s_times_a + r;
+        r = p - (p * a);
+        return s - p;
+    }
+};
+template <>
+struct PoleHp<float> {
+    float p;
+    DEV void reset(float v, float) { p = v; }
+    DEV float hp(float s, float, float a) { p = __builtin_fmaf(a, s - p, p); return s - p; }
+};
+
+// C `/ 4` (truncating) for |n| < 2^30: the two top bits of a negative n are 11
+DEV int sdiv4s(int n) { return (n + (int)((unsigned)n >> 30)) >> 2; }
+
+// ------------------------------------------------------------------ Y/C separation, raw windows
+// chroma_from_luma (ffmpeg_ntsc.cpp:1497-1567) with the half-cycle flip (:1539-1542) applied when
+// a sample is picked instead of when it is stored.  Valid for EVEN scanline phase xi in {0, 2}:
+// the I sample for odd x is raw(x+1+xi), the Q sample raw(x+2+xi), both negated iff x = 3 mod 4
+// (the reference's double negation :1539 / :1552-1553 leaves +raw at x = 1 mod 4).
+struct DemodR {
+    int c0, c1, c2, csum;         // cs(t-3), cs(t-2), cs(t-1) and their sum
+    int w0, w1, w2, w3, w4, w5;   // raw chroma at q-5 .. q   (q = t-2)
+    int y0, y1, y2, y3, y4;       // box-filtered luma at q-5 .. q-1
+    int ieP, qeP, ieN, qeN;
+    DEV void init()
+    {
+        c0 = c1 = c2 = csum = 0;
+        w0 = w1 = w2 = w3 = w4 = w5 = 0;
+        y0 = y1 = y2 = y3 = y4 = 0;
+        ieP = qeP = ieN = qeN = 0;
+    }
+    // steady state: every position inside the row.  ODD = x is odd; NEGS = 0 / -1 (x = 1 / 3 mod 4)
+    // as a compile-time (NEG >= 0) or wave-uniform (sneg) value; hi = lane mask of xi == 2.
+    template <bool ODD, int NEG, bool LUMA>
+    DEV void push(int ct, bool hi, int sneg, int &Yo, int &Io, int &Qo)
+    {
+        const int yb = sdiv4s(csum + ct);
+        const int ch = ct - yb;
+        csum = csum - c0 + ct;
+        c0 = c1; c1 = c2; c2 = ct;
+        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
+        if (LUMA) { Yo = y0; y0 = y1; y1 = y2; y2 = y3; y3 = y4; y4 = yb; }
+        if (ODD) {
+            const int a = hi ? w3 : w1, b = hi ? w4 : w2;
+            if (NEG == 0) { ieN = a; qeN = b; }
+            else if (NEG == 1) { ieN = -a; qeN = -b; }
+            else { ieN = (a ^ sneg) - sneg; qeN = (b ^ sneg) - sneg; }
+            Io = (ieP + ieN) >> 1;
+            Qo = (qeP + qeN) >> 1;
+        } else {
+            Io = ieN; Qo = qeN;
+            ieP = ieN; qeP = qeN;
+        }
+    }
+    // any position (row ends, pipeline fill and drain); t is wave-uniform, xi per lane
+    DEV void push_edge(int ct, int t, unsigned xi, bool hi, int W, int xe, int &Yo, int &Io, int &Qo)
+    {
+        const int yb = sdiv4(c0 + c1 + c2 + ct);
+        const int ch = ct - yb;
+        csum = c1 + c2 + ct;
+        c0 = c1; c1 = c2; c2 = ct;
+        w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
+        Yo = y0; y0 = y1; y1 = y2; y2 = y3; y3 = y4; y4 = yb;
+        const int x = t - 7;
+        int I, Q;
+        if (x & 1) {
+            const bool m = (x + 1 + (int)xi + 1) < W;                    // :1550
+            const int a = hi ? w3 : w1, b = hi ? w4 : w2;
+            const bool pos = (x & 3) == 1;
+            ieN = m ? (pos ? a : -a) : 0;
+            qeN = m ? (pos ? b : -b) : 0;
+            I = (ieP + ieN) >> 1;
+            Q = (qeP + qeN) >> 1;
+        } else {
+            I = ieN; Q = qeN;
+            ieP = ieN; qeP = qeN;
+        }
+        if (x >= xe) { I = 0; Q = 0; }                                   // :1553-1556, :1562-1565
+        Io = I; Qo = Q;
+    }
+};
+
+template <bool VHS, class RT>
+struct State {
+    DemodR D1, D2;
+    int l0, l1, l2, lsum;                     // luma stream window (VHS)
+    Casc3<RT> vl, vcU, vcV, sh, oU, oV;
+    PoleHp<RT> vpre;
+    int Yprev, Uraw, Vraw;                    // previous step's output-stage inputs
+    LaneRand rng;
+    int nU, nV;
+};
+
+// per-lane / per-launch constants
+template <class RT>
+struct Const {
+    unsigned xi;
+    bool hi;                  // xi == 2
+    int W, xe, lane;
+    int d, SKT, LOFF;
+    int mL, mNL;              // -1 / 0 masks of hi and !hi (sign of the re-modulated chroma)
+    int bA, bC;               // vertical blend: and-mask of the row above, carry/shift (0: blend off)
+    int dm;                   // dropout and-mask (0 = this row's chroma is dropped)
+    RT cosv, sinv;
+    RT a_vc, a_vl, a_sh, a_tv, sharp2;
+    int *tailU, *tailV;
+    size_t rstride;
+    __amdgpu_buffer_rsrc_t comp;   // the whole composite plane; out-of-range reads return 0
+    int vbase;                // byte offset of this lane's column (+ head-switch displacement)
+    int rowbytes;             // bytes between consecutive x
+};
+
+// composite sample x of this lane's row after head switching, for 0 <= x < W (the caller's duty:
+// the bounds check only covers the displaced index)
+template <class RT>
+DEV int cs_load(const Const<RT> &C, int x)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(C.comp, (int)((unsigned)C.vbase + (unsigned)x * (unsigned)C.rowbytes), 0, 0);
+}
+
+DEV int wave_up(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+
+template <class RT>
+DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
+{
+    // YIQ_to_RGB :1385-1396: (int)(x / 256) then clamp; for the clamp's sake (int)x >> 8 is the
+    // same (a negative quotient clamps to 0 whichever way it was rounded)
+    const RT y = (RT)Yo;
+    int r = (int)((y + (RT(0.956) * fU)) + (RT(0.621) * fV)) >> 8;
+    int g = (int)((y + (RT(-0.272) * fU)) + (RT(-0.647) * fV)) >> 8;
+    int b = (int)((y + (RT(-1.106) * fU)) + (RT(1.703) * fV)) >> 8;
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    return (((uint32_t)r << 16) | (uint32_t)b) | ((uint32_t)g << 8);
+}
+
+// One steady-state pipeline step at unrolled position J (t = SKT + 4n + J).  Position phases:
+//   second demodulator / output   x3 = t - 14 - d = 4n + J + 1     -> odd for even J, sign by J
+//   re-modulation                 x2 = x3 + 7     = 4n + J (mod 4) -> U for even J, sign by J & 2
+//   first demodulator             x1 = t - 7      = d + J (mod 4)  -> parity by DP = d & 1 (template),
+//                                                                     sign wave-uniform (sneg1)
+// Non-VHS form: x3 = x1 = t - 7 = 4n + J + 1 (SKT = 8), one demodulator.
+template <bool VHS, int DP, int J, class RT>
+DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring,
+                  int pc, int pl, int sneg1)
+{
+    int Y, U, V;
+    if (!VHS) {
+        S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(pc, C.hi, 0, Y, U, V);
+    } else {
+        constexpr bool odd1 = ((DP + J) & 1) != 0;
+        int Yd;
+        S.D1.template push<odd1, -1, false>(pc, C.hi, sneg1, Yd, U, V);
+        // chroma noise :1719-1735
+        U += S.nU; V += S.nV;
+        S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+        S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+        // chroma phase noise :1748-1762; (double)(int)d == trunc(d) up to the sign of zero, which
+        // no later stage can observe
+        const RT u = (RT)U, v = (RT)V;
+        const RT Ud = rtrunc<RT>((u * C.cosv) - (v * C.sinv));
+        const RT Vd = rtrunc<RT>((u * C.sinv) + (v * C.cosv));
+        // VHS chroma low-pass :1814-1836 (value for input x1 lands at x2 = x1 - d)
+        const int fU = (int)S.vcU.push(Ud, C.a_vc);
+        const int fV = (int)S.vcV.push(Vd, C.a_vc);
+        // luma at x2: box -> low-pass + emphasis :1793-1812 -> sharpen :1866-1883
+        const int yb = sdiv4s(S.lsum + pl);
+        S.lsum = S.lsum - S.l0 + pl;
+        S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
+        RT m2;
+        RT s = S.vl.push((RT)yb, C.a_vl, m2);
+        s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
+        const RT s0 = rtrunc<RT>(s);
+        const RT ts = S.sh.push(s0, C.a_sh);
+        Y = (int)(s0 + ((s0 - ts) * C.sharp2));
+        // vertical chroma blend :1843-1863: (above + cur + 1) >> 1, above = 0 for the field's
+        // second row, untouched for its first row / blend off (mask, carry and shift all 0)
+        U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
+        V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
+        // composite out of the VCR :1885-1888: modulate at x2 (amplitude 50: (v*50)/50 == v) ...
+        const int chroma = (J & 1) ? V : U;
+        const int mm = (J & 2) ? C.mNL : C.mL;
+        const int c2 = Y + ((chroma ^ mm) - mm);
+        // ... and separate again at x3
+        S.D2.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(c2, C.hi, 0, Y, U, V);
+    }
+    // dropout :1891-1901
+    U &= C.dm; V &= C.dm;
+    // composite_lowpass_tv :1399-1427 (delay 1) and YIQ -> RGB for the previous position
+    const RT fUd = rtrunc<RT>(S.oU.push((RT)U, C.a_tv));
+    const RT fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_tv));
+    const int Yo = S.Yprev;
+    S.Yprev = Y;
+    return yiq_to_bgra<RT>(Yo, fUd, fVd);
+}
+
+// One guarded step at any stream position t (wave-uniform): pipeline fill, row end, filter
+// tails, drain.  Same state, same results as `step` where both apply.
+template <bool VHS, class RT>
+DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring, int t,
+                   uint32_t &px, int &xo_out)
+{
+    const int W = C.W;
+    const int pc = t < W ? cs_load(C, t) : 0;             // t is wave-uniform
+    int Y, U, V;
+    S.D1.push_edge(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+    const int x1 = t - 7;
+    int x3 = x1;
+    if (VHS) {
+        const bool in1 = x1 >= 0 && x1 < W;
+        int fU = 0, fV = 0;
+        if (in1) {
+            U += S.nU; V += S.nV;
+            S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+            S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+            const RT u = (RT)U, v = (RT)V;
+            U = (int)((u * C.cosv) - (v * C.sinv));
+            V = (int)((u * C.sinv) + (v * C.cosv));
+            fU = (int)S.vcU.push((RT)U, C.a_vc);
+            fV = (int)S.vcV.push((RT)V, C.a_vc);
+            if (x1 >= W - C.d) {                  // raw tail of the chroma low-pass :1830
+                C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
+                C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
+            }
+        }
+        const int x2 = x1 - C.d;
+        const int xl = t - C.LOFF;
+        const int pl = (xl >= 0 && xl < W) ? cs_load(C, xl) : 0;
+        const int yb = sdiv4(S.l0 + S.l1 + S.l2 + pl);
+        S.lsum = S.l1 + S.l2 + pl;
+        S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
+        const bool in2 = x2 >= 0 && x2 < W;
+        if (in2) {
+            if (x2 >= W - C.d) {
+                fU = C.tailU[(size_t)(x2 & 15) * C.rstride];
+                fV = C.tailV[(size_t)(x2 & 15) * C.rstride];
+            }
+            RT m2;
+            RT s = S.vl.push((RT)yb, C.a_vl, m2);
+            s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
+            const RT s0 = rtrunc<RT>(s);
+            const RT ts = S.sh.push(s0, C.a_sh);
+            Y = (int)(s0 + ((s0 - ts) * C.sharp2));
+        }
+        U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
+        V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
+        int c2 = 0;
+        if (in2) {
+            const unsigned s = (C.xi + (unsigned)x2) & 3u;
+            int chroma = (s & 1u) ? V : U;
+            if (s & 2u) chroma = -chroma;
+            c2 = Y + chroma;
+        }
+        S.D2.push_edge(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
+        x3 = x2 - 7;
+    }
+    if (x3 < 0 || x3 > W) return false;
+    const bool in3 = x3 < W;
+    if (!in3) { U = 0; V = 0; Y = 0; }
+    U &= C.dm; V &= C.dm;
+    RT fUd = 0, fVd = 0;
+    if (in3) {
+        fUd = rtrunc<RT>(S.oU.push((RT)U, C.a_tv));
+        fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_tv));
+    }
+    const int xo = x3 - 1;
+    const int Yo = S.Yprev;
+    const int Ur = S.Uraw, Vr = S.Vraw;
+    S.Yprev = Y; S.Uraw = U; S.Vraw = V;
+    if (xo < 0) return false;
+    if (xo >= W - 1) { fUd = (RT)Ur; fVd = (RT)Vr; }      // last sample keeps its input :1419-1424
+    px = yiq_to_bgra<RT>(Yo, fUd, fVd);
+    xo_out = xo;
+    return true;
+}
+
+// Steady-state loop: every stage strictly inside the row.  Starts at t = SKT (mod 4), 4 pixels per
+// iteration, the next iteration's composite samples requested before the current ones are used.
+template <bool VHS, int DP, class RT>
+DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring,
+               uint32_t *ostage, uint32_t *drow, bool is_out, int t)
+{
+    // last steady position: every composite sample inside the row (t < W) and no raw chroma tail
+    // needed yet (x1 = t - 7 < W - d)
+    const int t_end = C.W - (C.d > 7 ? C.d - 7 : 0);
+    const int SKT = C.SKT, LOFF = C.LOFF, lane = C.lane;
+    if (t + 4 > t_end) return t;
+    // sign of the first demodulator's picks: x1 = t - 7 = d + J (mod 4); negated iff x1 = 3 (mod 4)
+    const int dph = C.d & 3;
+    int pc[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load(C, t + j - LOFF) : 0; }
+    for (; t + 4 <= t_end; t += 4) {
+        uint32_t o[4];
+        // each sample is replaced by the next iteration's as soon as its step has consumed it
+        // (reads past the row end return 0 and are never used)
+#define NTSC_FAST_STEP(J)                                                                         \
+        o[J] = step<VHS, DP, J, RT>(P, S, C, ring, pc[J], pl[J], ((dph + J) & 3) == 3 ? -1 : 0);   \
+        pc[J] = cs_load(C, t + 4 + J);                                                            \
+        if (VHS) pl[J] = cs_load(C, t + 4 + J - LOFF);                                            \
+        NTSC_STEP_SCHED_BARRIER();
+        NTSC_FAST_STEP(0)
+        NTSC_FAST_STEP(1)
+        NTSC_FAST_STEP(2)
+        NTSC_FAST_STEP(3)
+#undef NTSC_FAST_STEP
+        // stage 4 pixels; every 4th iteration write the lane's 16 pixels as one 64-byte burst
+        const int xo0 = t - SKT;                   // multiple of 4
+        const int sub = (xo0 >> 2) & 3;
+        *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (sub == 3 && is_out) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
+            uint4 *dp = reinterpret_cast<uint4 *>(drow + (xo0 - 12));
+            const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
+            dp[0] = a; dp[1] = b; dp[2] = c4; dp[3] = d4;
+        }
+    }
+    return t;
+}
+
+} // namespace fastdec
+
+// =============================================================================== k_decode_fast
+// Occupancy: the VHS form keeps 19 fp64 filter states, two demodulators and a dozen per-lane
+// constants alive; squeezed into the 168 registers of 3 waves per SIMD it spills inside the loop
+// (every spill reload is an s_waitcnt vmcnt(0) that also waits for the prefetched samples:
+// 1.31 ms per 600 fields), with 2 waves per SIMD it needs no scratch at all (0.94 ms) -- and two
+// waves already saturate a SIMD's fp64 pipe (tools/chain_probe.hip).
+#ifndef NTSC_FAST_WAVES
+#define NTSC_FAST_WAVES 2
+#endif
+template <bool VHS, class RT>
+__global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(DevParams P, GeomDev G,
+                                                     const FieldDev *__restrict__ fields,
+                                                     const int *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rs_chroma,
+                                                     const int *__restrict__ n0_u,
+                                                     const int *__restrict__ n0_v,
+                                                     const int *__restrict__ hs_shift,
+                                                     const int *__restrict__ pn_noise,
+                                                     const int *__restrict__ dropout,
+                                                     int *__restrict__ tails)
+{
+    using namespace fastdec;
+    __shared__ uint32_t ring[31 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
+
+    const int lane = threadIdx.x;
+    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok;
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const int W = P.W;
+    uint32_t *drow = reinterpret_cast<uint32_t *>(fd.dst + (size_t)fd.dst_ls * y);
+    const size_t tcol = (size_t)blockIdx.x * 64 + lane;
+    const size_t tstride = (size_t)gridDim.x * 64;
+
+    Const<RT> C;
+    C.xi = scan_phase(P, y, fd.fieldno);
+    C.hi = (C.xi & 2u) != 0;
+    C.W = W;
+    C.xe = (W & 1) ? W - 1 : W - 2;
+    C.lane = lane;
+    C.d = VHS ? P.cdelay : 0;
+    C.SKT = VHS ? 15 + C.d : 8;
+    C.LOFF = 5 + C.d;
+    C.mL = C.hi ? -1 : 0;
+    C.mNL = ~C.mL;
+    const bool vb = VHS && P.vblend && P.ntsc;
+    C.bA = (vb && k >= 2) ? -1 : 0;
+    C.bC = (vb && k >= 1) ? 1 : 0;
+    C.dm = (P.loss && dropout[rc] != 0) ? 0 : -1;
+    C.cosv = 1; C.sinv = 0;
+    if (VHS) {
+        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+        C.cosv = (RT)G.ptab[2 * n]; C.sinv = (RT)G.ptab[2 * n + 1];
+    }
+    C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
+    C.sharp2 = (RT)(P.sharpen * 2);            // (x * s) * 2 == x * (s * 2): scaling by 2 is exact
+    C.tailU = tails + tcol;
+    C.tailV = tails + 16 * tstride + tcol;
+    C.rstride = tstride;
+    C.rowbytes = P.Rpad * 4;
+    // head switching :1687-1697 for |shift| <= W/10: Y[x] = row[x + shift] inside the row, 0
+    // elsewhere -- a per-lane byte offset plus the buffer bounds check
+    const int hs = P.hs ? hs_shift[rc] : 0;
+    C.vbase = (int)((unsigned)rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
+    C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0,
+                                               (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
+
+    State<VHS, RT> S;
+    S.D1.init(); S.D2.init();
+    S.l0 = S.l1 = S.l2 = S.lsum = 0;
+    S.vl.reset(16, C.a_vl); S.vpre.reset(16, C.a_vl); S.vcU.reset(0, C.a_vc); S.vcV.reset(0, C.a_vc);
+    S.sh.reset(0, C.a_sh); S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv);
+    S.Yprev = S.Uraw = S.Vraw = 0;
+    S.nU = S.nV = 0;
+    if (VHS) {
+        S.rng.init(ring, rs_chroma + rc, P.Rpad, lane);
+        S.nU = n0_u[rc]; S.nV = n0_v[rc];
+    }
+
+    const int SKT = C.SKT;
+    const int total = W + SKT;
+    int t = 0;
+    // ---------------- pipeline fill
+    for (; t < SKT && t < total; t++) {
+        uint32_t px; int xo;
+        (void)edge_step<VHS, RT>(P, S, C, ring, t, px, xo);
+    }
+    // ---------------- steady state: 4 pixels per iteration, ends 16 samples before the row end
+    if (C.d & 1) t = steady<VHS, 1, RT>(P, S, C, ring, ostage, drow, is_out, t);
+    else t = steady<VHS, 0, RT>(P, S, C, ring, ostage, drow, is_out, t);
+    // ---------------- row end, filter tails, pipeline drain
+    for (; t < total; t++) {
+        uint32_t px; int xo;
+        if (!edge_step<VHS, RT>(P, S, C, ring, t, px, xo)) continue;
+        ostage[lane * 20 + (xo & 15)] = px;
+        if ((xo & 15) == 15) {
+            if (is_out) {
+                const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
+                uint4 *dp = reinterpret_cast<uint4 *>(drow + (xo - 15));
+                const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
+                dp[0] = a; dp[1] = b; dp[2] = c4; dp[3] = d4;
+            }
+        } else if (xo == W - 1 && is_out) {
+            const int xb = xo & ~15;
+            for (int q = xb; q <= xo; q++) drow[q] = ostage[lane * 20 + (q - xb)];
+        }
+    }
+}
+
+} // namespace ntscsim

@@ -3,6 +3,7 @@
 // field loop (ffmpeg_ntsc.cpp:2229) and the per-call heap planes it allocates (:1590-1592).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +16,7 @@
 
 // single translation unit: the kernels are compiled together with their launcher
 #include "ntsc_kernels.hip"
+#include "ntsc_decode_fast.hip"
 #include "ntsc422_kernels.hip"
 
 using namespace ntscsim;
@@ -110,6 +112,7 @@ struct ntscsim_ctx {
     std::vector<EvSet> ev_live, ev_free;
     int warm_override[2] = {0, 0};
     bool force_generic = false;
+    bool no_fast_decode = false;     // debug: keep the PRESET template kernels (A/B against k_decode_fast)
     int mode = NTSCSIM_MODE_EXACT;
 };
 
@@ -380,6 +383,11 @@ extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
     if (c) c->force_generic = on != 0;
 }
 
+extern "C" void ntscsim_debug_no_fast_decode(ntscsim_ctx *c, int on)
+{
+    if (c) c->no_fast_decode = on != 0;
+}
+
 extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chroma_draws)
 {
     if (!c) return;
@@ -438,6 +446,26 @@ static int prepare_records(ntscsim_ctx *c, const ntscsim_field_desc *descs, int 
     c->rng_pos = pos;
     D.src_al16 = al_src; D.dst_al16 = al_dst;
     return NTSCSIM_OK;
+}
+
+// Largest head-switch displacement any field can get (k_field_setup, ffmpeg_ntsc.cpp:1647-1684)
+// is at most W/10 samples: then "row[(x + shift) mod twidth] with zero fill" is "row[x + shift]
+// inside the row, 0 elsewhere", which k_decode_fast gets from a buffer bounds check.
+static bool head_switch_is_small(const DevParams &D, int W)
+{
+    if (!D.hs) return true;
+    const unsigned tw = (unsigned)W + (unsigned)W / 10u;
+    const double t = D.ntsc ? tw * 262.5 : tw * 312.5;
+    const double pn = D.hs_noise_on ? std::fabs(D.hs_pn) : 0.0;
+    const double lo = D.hs_phase - pn, hi = D.hs_phase + pn;
+    if (lo < 0 || std::trunc(lo) != std::trunc(hi)) return false;
+    const unsigned plo = (unsigned)((lo - std::trunc(lo)) * t), phi = (unsigned)((hi - std::trunc(hi)) * t);
+    if (plo / tw != phi / tw) return false;
+    const unsigned hlo = plo % tw, hh = phi % tw;
+    if ((hlo >= tw / 2) != (hh >= tw / 2)) return false;
+    const int a = hlo >= tw / 2 ? (int)(hlo - tw) : (int)hlo, b = hh >= tw / 2 ? (int)(hh - tw) : (int)hh;
+    const int m = std::max(std::abs(a), std::abs(b));
+    return m <= (int)(tw - (unsigned)W);
 }
 
 // ---- step 2: scratch + the kernel chain over device-resident records
@@ -503,6 +531,21 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
 #define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
     do { if (fast) NTSC_LAUNCH_DECODE_RT(VHS, CO, F, float);                                     \
          else NTSC_LAUNCH_DECODE_RT(VHS, CO, F, double); } while (0)
+    // hand-tuned decoder of the two presets (ntsc_decode_fast.hip) when its preconditions hold
+    const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 &&
+                          (D.phase_mode == 180 || (D.phase_mode != 90 && D.phase_mode != 270)) &&
+                          !(D.phase_off & 1) && (size_t)D.Rpad * (size_t)W * 4 < 0xFFF00000ull &&
+                          head_switch_is_small(D, W);
+#define NTSC_LAUNCH_FAST(VHS, RT)                                                                \
+    hipLaunchKernelGGL((k_decode_fast<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
+                       c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
+                       c->dropout.p, c->tails.p)
+    if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
+        if (fast) NTSC_LAUNCH_FAST(true, float); else NTSC_LAUNCH_FAST(true, double);
+    } else if (dec_fast && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
+        if (fast) NTSC_LAUNCH_FAST(false, float); else NTSC_LAUNCH_FAST(false, double);
+    } else
+#undef NTSC_LAUNCH_FAST
     if (!D.vhs) {
         if (dec_common && !D.cnoise_k && !D.pnoise_k) NTSC_LAUNCH_DECODE(false, false, 0u);
         else NTSC_LAUNCH_DECODE(false, false, F_GENERIC);

@@ -237,6 +237,9 @@ class FieldSimulator:
     def debug_force_generic(self, on=True):
         self._lib.ntscsim_debug_force_generic(self._h, 1 if on else 0)
 
+    def debug_no_fast_decode(self, on=True):
+        self._lib.ntscsim_debug_no_fast_decode(self._h, 1 if on else 0)
+
     def debug_set_warmup(self, luma_draws, chroma_draws):
         self._lib.ntscsim_debug_set_warmup(self._h, int(luma_draws), int(chroma_draws))
 

@@ -377,6 +377,10 @@ void ntscsim_debug_set_warmup(ntscsim_ctx *ctx, int luma_draws, int chroma_draws
  * specialisations chosen for the default / -vhs parameter sets.  Results must not change. */
 void ntscsim_debug_force_generic(ntscsim_ctx *ctx, int on);
 
+/* Test hook: keep the template-specialised PRESET decoder (k_decode) where the hand-tuned one
+ * (k_decode_fast, csrc/ntsc_decode_fast.hip) would run.  Results must not change. */
+void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ while [ $# -ge 2 ]; do
         -Rpass-analysis=kernel-resource-usage 2> "$OUT/$name.log" || { tail -20 "$OUT/$name.log"; exit 1; }
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 "$SRC/params.o" "$SRC/glibc_rand.o" "$OUT/$name.o" -o "$OUT/lib_$name.so"
     rm -f "$OUT/$name.o"
-    echo "built $name: $(grep -A8 'k_decodeILb1ELb1ELj6Ed' "$OUT/$name.log" | grep -E 'VGPRs:|Spill|Occupancy|LDS|Scratch' | sed 's/.*remark: *//' | tr '\n' ' ')"
+    echo "built $name: $(grep -A8 'k_decode_fastILb1Ed' "$OUT/$name.log" | grep -E 'VGPRs:|Spill|Occupancy|LDS|Scratch' | sed 's/.*remark: *//' | tr '\n' ' ')"
   ) &
 done
 wait

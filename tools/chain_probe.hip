@@ -14,7 +14,7 @@
 #include <algorithm>
 
 #define STEPS 16      // pole steps per chain per unrolled body
-#define ITERS 64
+#define ITERS 256
 
 template <int NCH>
 __global__ void k_chain(double *out, uint64_t *cyc, double a, double s)
@@ -67,30 +67,33 @@ __global__ void k_chain_i32(uint32_t *out, uint64_t *cyc, uint32_t a, uint32_t s
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// Exactly `wps` waves on every SIMD: one workgroup of 256 x wps threads per CU, forced by a
+// 160 KiB dynamic-LDS request (see tools/valu_rate_probe.hip).
 template <class T, class F>
 static void run(const char *name, int nch, F kern, T a, T s, int wps)
 {
-    // one wave per workgroup and a dummy LDS-free kernel: the dispatcher spreads waves over SIMDs
-    const int blocks = 256 * 4 * wps / 4;
+    const int blocks = 256, threads = 256 * wps;
+    const size_t lds = 160 * 1024;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     T *out; uint64_t *cyc;
-    hipMalloc(&out, (size_t)blocks * 256 * sizeof(T));
-    hipMalloc(&cyc, (size_t)blocks * 4 * sizeof(uint64_t));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, cyc, a, s);
-    hipDeviceSynchronize();
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, cyc, a, s);
-    hipEventRecord(e1);
-    hipDeviceSynchronize();
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<uint64_t> h((size_t)blocks * 4);
-    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMalloc(&out, (size_t)blocks * threads * sizeof(T));
+    (void)hipMalloc(&cyc, (size_t)blocks * (threads / 64) * sizeof(uint64_t));
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, out, cyc, a, s);
+    (void)hipDeviceSynchronize();
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, out, cyc, a, s);
+    (void)hipEventRecord(e1);
+    (void)hipDeviceSynchronize();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h((size_t)blocks * (threads / 64));
+    (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double n = (double)STEPS * 4 * ITERS * nch;
     const double med = (double)h[h.size() / 2];
-    printf("%-12s chains %d waves/SIMD %d: %6.2f cyc/instr/SIMD  (one wave: %6.2f cyc between its own instructions; kernel %.3f ms)\n",
-           name, nch, wps, med / n / wps, med / n, ms);
-    hipFree(out); hipFree(cyc);
+    printf("%-10s chains %d waves/SIMD %d: %6.2f cyc/instr/SIMD median wave, %6.2f slowest, %6.2f from the kernel time (%.3f ms); one wave: %6.2f cyc between its own instructions\n",
+           name, nch, wps, med / n / wps, (double)h.back() / n / wps, ms * 1e-3 * 2.4e9 / n / wps, ms, med / n);
+    (void)hipFree(out); (void)hipFree(cyc);
 }
 
 int main()

@@ -9,7 +9,7 @@
 #include <algorithm>
 
 #define REPS 64
-#define ITERS 64
+#define ITERS 256
 
 #define BODY8(ASM, C) \
     asm volatile(ASM : "+" C(r0) : C(a), C(b)); asm volatile(ASM : "+" C(r1) : C(a), C(b)); \
@@ -60,6 +60,15 @@ KERNEL(k_cndmask, uint32_t, "v_cndmask_b32 %0, %0, %1, vcc")
 KERNEL(k_cmp_cnd, uint32_t, "v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc")
 KERNEL(k_sub_co, uint32_t, "v_sub_co_u32 %0, vcc, %0, %1")
 KERNEL(k_perm, uint32_t, "v_perm_b32 %0, %0, %1, %2")
+KERNEL(k_ldexp_f64, double, "v_ldexp_f64 %0, %0, -8")
+KERNEL(k_xor_b32, uint32_t, "v_xor_b32 %0, %0, %1")
+KERNEL(k_sub_u32, uint32_t, "v_sub_u32 %0, %0, %1")
+KERNEL(k_lshr_b32, uint32_t, "v_lshrrev_b32 %0, 1, %0")
+KERNEL(k_lshl_or, uint32_t, "v_lshl_or_b32 %0, %0, 8, %1")
+KERNEL(k_xad_u32, uint32_t, "v_xad_u32 %0, %0, %1, %2")
+KERNEL(k_min_i32, uint32_t, "v_min_i32 %0, %0, %1")
+KERNEL(k_dpp_wave_shr, uint32_t, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf")
+KERNEL(k_cndmask_sgpr, uint32_t, "v_cndmask_b32 %0, %0, %1, s[10:11]")
 
 // 64-bit <-> 32-bit conversions need mixed register widths: hand-written bodies
 __global__ void k_cvt_f64_i32(double *out, uint64_t *cyc, int a, int b)
@@ -139,35 +148,42 @@ __global__ void k_ds_read_b32(uint32_t *out, uint64_t *cyc, uint32_t a, uint32_t
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
+// Exactly `waves_per_simd` waves on every SIMD: ONE workgroup of 256 x waves_per_simd threads per
+// CU (wave i of a workgroup lands on SIMD i % 4), forced by a 160 KiB dynamic-LDS request that no
+// second workgroup can fit beside.  Both the median wave (s_memtime) and the kernel wall time are
+// reported; they agree when the placement is what it should be.
 template <class T, class A, class F>
-static void run(const char *name, F kern, A a, A b, int waves_per_simd)
+static void run(const char *name, F kern, A a, A b, int waves_per_simd, size_t lds = 160 * 1024)
 {
-    const int blocks = 256 * 4 * waves_per_simd / 4;      // 256-thread blocks = 4 waves
+    const int blocks = 256, threads = 256 * waves_per_simd;
+    (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     T *out; uint64_t *cyc;
-    hipMalloc(&out, (size_t)blocks * 256 * sizeof(T));
-    hipMalloc(&cyc, (size_t)blocks * 4 * sizeof(uint64_t));
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, cyc, a, b);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, cyc, a, b);
-    hipEventRecord(e1);
-    hipDeviceSynchronize();
-    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-    std::vector<uint64_t> h((size_t)blocks * 4);
-    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMalloc(&out, (size_t)blocks * threads * sizeof(T));
+    (void)hipMalloc(&cyc, (size_t)blocks * (threads / 64) * sizeof(uint64_t));
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, out, cyc, a, b);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, out, cyc, a, b);
+    (void)hipEventRecord(e1);
+    (void)hipDeviceSynchronize();
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<uint64_t> h((size_t)blocks * (threads / 64));
+    (void)hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double n = (double)REPS * ITERS;
-    const double med = (double)h[h.size() / 2];
-    printf("%-16s waves/SIMD %d: %6.2f cyc/instr/SIMD (median wave %8.0f cyc for %g instr; kernel %.3f ms => %.2f ns/instr/SIMD)\n",
-           name, waves_per_simd, med / n / waves_per_simd, med, n, ms, ms * 1e6 / n / waves_per_simd);
-    hipFree(out); hipFree(cyc);
+    const double med = (double)h[h.size() / 2], mx = (double)h.back();
+    printf("%-16s waves/SIMD %d: %6.2f cyc/instr/SIMD median wave, %6.2f slowest wave, %6.2f from the kernel time (%.3f ms, 2.4 GHz)\n",
+           name, waves_per_simd, med / n / waves_per_simd, mx / n / waves_per_simd,
+           ms * 1e-3 * 2.4e9 / n / waves_per_simd, ms);
+    (void)hipFree(out); (void)hipFree(cyc);
 }
 
 int main()
 {
-    for (int w : {1, 4}) {
+    for (int w : {1, 2, 3, 4}) {
 #define R(K, T, A, x, y) run<T, A>(#K, K, (A)x, (A)y, w)
+#define RL(K, T, A, x, y, L) run<T, A>(#K, K, (A)x, (A)y, w, L)
         R(k_add_f64, double, double, 1.000001, 0.999999);
         R(k_mul_f64, double, double, 1.000001, 0.999999);
         R(k_fma_f64, double, double, 1.000001, 0.999999);
@@ -194,13 +210,22 @@ int main()
         R(k_cmp_cnd, uint32_t, uint32_t, 3, 5);
         R(k_sub_co, uint32_t, uint32_t, 3, 5);
         R(k_perm, uint32_t, uint32_t, 3, 5);
+        R(k_ldexp_f64, double, double, 1.000001, 0.999999);
+        R(k_xor_b32, uint32_t, uint32_t, 3, 5);
+        R(k_sub_u32, uint32_t, uint32_t, 3, 5);
+        R(k_lshr_b32, uint32_t, uint32_t, 3, 5);
+        R(k_lshl_or, uint32_t, uint32_t, 3, 5);
+        R(k_xad_u32, uint32_t, uint32_t, 3, 5);
+        R(k_min_i32, uint32_t, uint32_t, 3, 5);
+        R(k_dpp_wave_shr, uint32_t, uint32_t, 3, 5);
+        R(k_cndmask_sgpr, uint32_t, uint32_t, 3, 5);
         R(k_mul_lo_u32, uint32_t, uint32_t, 3, 5);
         R(k_mul_hi_u32, uint32_t, uint32_t, 3, 5);
         R(k_mul_u24, uint32_t, uint32_t, 3, 5);
         R(k_mad_u24, uint32_t, uint32_t, 3, 5);
         R(k_mad_i24, uint32_t, uint32_t, 3, 5);
         R(k_mad_u64_u32, uint64_t, uint32_t, 3, 5);
-        R(k_ds_read_b32, uint32_t, uint32_t, 3, 5);
+        RL(k_ds_read_b32, uint32_t, uint32_t, 3, 5, 128 * 1024);
     }
     return 0;
 }
