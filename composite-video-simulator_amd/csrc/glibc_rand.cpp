@@ -109,7 +109,7 @@ Magic31 magic31(uint32_t d)
 {
     Magic31 m;
     m.div = d;
-    if (d <= 1) { m.mul = 0; m.shift = 0; return m; }   // callers never divide by 1
+    if (d <= 1) { m.mul = 0; m.shift = 0; return m; }   // mul == 0: sdivm() returns n (d == 1)
     uint32_t l = 0;
     while ((1ull << l) < d) l++;                          // l = ceil(log2 d)
     const unsigned __int128 num = (unsigned __int128)1 << (31 + l);

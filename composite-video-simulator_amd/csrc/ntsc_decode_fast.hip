@@ -26,12 +26,50 @@
 namespace ntscsim {
 namespace fastdec {
 
+// Frame pointers come out of the FieldDev records as generic pointers, for which hipcc emits FLAT
+// loads / stores.  A FLAT access counts on lgkmcnt as well as vmcnt, so every LDS wait behind it
+// (the rand() ring, the pixel staging) also waits for the HBM round trip.  Frames are global
+// memory: say so, and the accesses become global_load / global_store (vmcnt only).
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4u *g_v4u_ptr;
+typedef __attribute__((address_space(1))) const v4u *g_cv4u_ptr;
+DEV v4u to_v4u(const uint4 &a) { return v4u{a.x, a.y, a.z, a.w}; }
+typedef __attribute__((address_space(1))) uint32_t *g_u32_ptr;
+typedef __attribute__((address_space(1))) const uint32_t *g_cu32_ptr;
+
 #ifdef NTSC_NO_STEP_SCHED_BARRIER
 #define NTSC_STEP_SCHED_BARRIER() ((void)0)
 #else
 // keeps the scheduler from interleaving whole pipeline steps (costs registers, gains nothing)
 #define NTSC_STEP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
+
+// ------------------------------------------------------------------ rand() with a prefetched ring word
+// LaneRand (ntsc_kernels.hip) whose NEXT ring word is requested one draw ahead: the LDS round trip
+// (~100 cycles) overlaps half a pipeline step of arithmetic instead of stalling the wave at an
+// s_waitcnt right behind the ds_read.  Slot k+1 was last written 30 draws ago: no hazard.
+struct LaneRandP {
+    uint32_t p3, p2, p1, pre;   // s[i-3], s[i-2], s[i-1]; pre = s[i-31] of the coming draw
+    int slot;                   // wave-uniform
+    DEV void init(uint32_t *ring, const uint32_t *state, int stride, int lane)
+    {
+        for (int j = 0; j < 31; j++) ring[j * 64 + lane] = state[(size_t)j * stride];
+        p3 = ring[28 * 64 + lane];
+        p2 = ring[29 * 64 + lane];
+        p1 = ring[30 * 64 + lane];
+        slot = 0;
+        pre = ring[lane];
+    }
+    DEV uint32_t next(uint32_t *ring, int lane)
+    {
+        const uint32_t v = pre + p3;
+        ring[slot * 64 + lane] = v;
+        p3 = p2; p2 = p1; p1 = v;
+        slot = (slot == 30) ? 0 : slot + 1;
+        pre = ring[slot * 64 + lane];
+        return v >> 1;
+    }
+};
 
 // ------------------------------------------------------------------ filters
 // three one-pole low-passes with ONE alpha (LowpassFilter x3, ffmpeg_ntsc.cpp:1399-1427 etc.)
@@ -170,7 +208,11 @@ struct State {
     Casc3<RT> vl, vcU, vcV, sh, oU, oV;
     PoleHp<RT> vpre;
     int Yprev, Uraw, Vraw;                    // previous step's output-stage inputs
+#ifdef NTSC_RANDP
+    LaneRandP rng;
+#else
     LaneRand rng;
+#endif
     int nU, nV;
 };
 
@@ -198,8 +240,16 @@ struct Const {
 template <class RT>
 DEV int cs_load(const Const<RT> &C, int x)
 {
+#ifdef NTSC_AB_NOLOAD      // timing-only A/B build (WRONG pixels): no composite loads
+    return C.vbase + x;
+#endif
     return __builtin_amdgcn_raw_buffer_load_b32(C.comp, (int)((unsigned)C.vbase + (unsigned)x * (unsigned)C.rowbytes), 0, 0);
 }
+
+// Masks built from per-lane / wave-uniform booleans are laundered through an empty asm so that the
+// compiler cannot turn the full-rate and / xor / sub back into half-rate v_cndmask selects.
+DEV int opaque_v(int v) { asm volatile("" : "+v"(v)); return v; }
+DEV int opaque_s(int v) { return __builtin_amdgcn_readfirstlane(v); }   // (also proves uniformity)
 
 DEV int wave_up(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 
@@ -215,7 +265,55 @@ DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
     r = r < 0 ? 0 : (r > 255 ? 255 : r);
     g = g < 0 ? 0 : (g > 255 ? 255 : g);
     b = b < 0 ? 0 : (b > 255 ? 255 : b);
-    return (((uint32_t)r << 16) | (uint32_t)b) | ((uint32_t)g << 8);
+    return (((uint32_t)r << 16) | (uint32_t)b) | ((uint32_t)g << 8);   // two v_lshl_or_b32
+}
+
+// One steady-state pipeline step at unrolled position J (t = SKT + 4n + J).  Position phases:
+//   second demodulator / output   x3 = t - 14 - d = 4n + J + 1     -> odd for even J, sign by J
+//   re-modulation                 x2 = x3 + 7     = 4n + J (mod 4) -> U for even J, sign by J & 2
+//   first demodulator             x1 = t - 7      = d + J (mod 4)  -> parity by DP = d & 1 (template),
+//                                                                     sign wave-uniform (sneg1)
+// Non-VHS form: x3 = x1 = t - 7 = 4n + J + 1 (SKT = 8), one demodulator.
+// The VCR half of a steady step (VHS form): first demodulator at x1 = t - 7, chroma noise, phase
+// noise, VHS chroma / luma filters, vertical blend, re-modulation.  Returns the composite sample
+// the VCR puts out at x2 = x1 - d (ffmpeg_ntsc.cpp:1716-1888).
+template <int DP, int J, class RT>
+DEV int vcr_step(const DevParams &P, State<true, RT> &S, const Const<RT> &C, uint32_t *ring,
+                 int pc, int pl, int sneg1)
+{
+    constexpr bool odd1 = ((DP + J) & 1) != 0;
+    int Yd, U, V;
+    S.D1.template push<odd1, -1, false>(pc, C.hi, sneg1, Yd, U, V);
+    // chroma noise :1719-1735
+    U += S.nU; V += S.nV;
+    S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+    S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+    // chroma phase noise :1748-1762; (double)(int)d == trunc(d) up to the sign of zero, which
+    // no later stage can observe
+    const RT u = (RT)U, v = (RT)V;
+    const RT Ud = rtrunc<RT>((u * C.cosv) - (v * C.sinv));
+    const RT Vd = rtrunc<RT>((u * C.sinv) + (v * C.cosv));
+    // VHS chroma low-pass :1814-1836 (value for input x1 lands at x2 = x1 - d)
+    const int fU = (int)S.vcU.push(Ud, C.a_vc);
+    const int fV = (int)S.vcV.push(Vd, C.a_vc);
+    // luma at x2: box -> low-pass + emphasis :1793-1812 -> sharpen :1866-1883
+    const int yb = sdiv4s(S.lsum + pl);
+    S.lsum = S.lsum - S.l0 + pl;
+    S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
+    RT m2;
+    RT s = S.vl.push((RT)yb, C.a_vl, m2);
+    s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
+    const RT s0 = rtrunc<RT>(s);
+    const RT ts = S.sh.push(s0, C.a_sh);
+    const int Y = (int)(s0 + ((s0 - ts) * C.sharp2));
+    // vertical chroma blend :1843-1863: (above + cur + 1) >> 1, above = 0 for the field's
+    // second row, untouched for its first row / blend off (mask, carry and shift all 0)
+    U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
+    V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
+    // composite out of the VCR :1885-1888: modulate at x2 (amplitude 50: (v*50)/50 == v)
+    const int chroma = (J & 1) ? V : U;
+    const int mm = (J & 2) ? C.mNL : C.mL;
+    return Y + ((chroma ^ mm) - mm);
 }
 
 // One steady-state pipeline step at unrolled position J (t = SKT + 4n + J).  Position phases:
@@ -229,42 +327,10 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uin
                   int pc, int pl, int sneg1)
 {
     int Y, U, V;
-    if (!VHS) {
+    if constexpr (!VHS) {
         S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(pc, C.hi, 0, Y, U, V);
     } else {
-        constexpr bool odd1 = ((DP + J) & 1) != 0;
-        int Yd;
-        S.D1.template push<odd1, -1, false>(pc, C.hi, sneg1, Yd, U, V);
-        // chroma noise :1719-1735
-        U += S.nU; V += S.nV;
-        S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
-        S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
-        // chroma phase noise :1748-1762; (double)(int)d == trunc(d) up to the sign of zero, which
-        // no later stage can observe
-        const RT u = (RT)U, v = (RT)V;
-        const RT Ud = rtrunc<RT>((u * C.cosv) - (v * C.sinv));
-        const RT Vd = rtrunc<RT>((u * C.sinv) + (v * C.cosv));
-        // VHS chroma low-pass :1814-1836 (value for input x1 lands at x2 = x1 - d)
-        const int fU = (int)S.vcU.push(Ud, C.a_vc);
-        const int fV = (int)S.vcV.push(Vd, C.a_vc);
-        // luma at x2: box -> low-pass + emphasis :1793-1812 -> sharpen :1866-1883
-        const int yb = sdiv4s(S.lsum + pl);
-        S.lsum = S.lsum - S.l0 + pl;
-        S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
-        RT m2;
-        RT s = S.vl.push((RT)yb, C.a_vl, m2);
-        s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
-        const RT s0 = rtrunc<RT>(s);
-        const RT ts = S.sh.push(s0, C.a_sh);
-        Y = (int)(s0 + ((s0 - ts) * C.sharp2));
-        // vertical chroma blend :1843-1863: (above + cur + 1) >> 1, above = 0 for the field's
-        // second row, untouched for its first row / blend off (mask, carry and shift all 0)
-        U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
-        V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
-        // composite out of the VCR :1885-1888: modulate at x2 (amplitude 50: (v*50)/50 == v) ...
-        const int chroma = (J & 1) ? V : U;
-        const int mm = (J & 2) ? C.mNL : C.mL;
-        const int c2 = Y + ((chroma ^ mm) - mm);
+        const int c2 = vcr_step<DP, J, RT>(P, S, C, ring, pc, pl, sneg1);
         // ... and separate again at x3
         S.D2.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(c2, C.hi, 0, Y, U, V);
     }
@@ -280,63 +346,78 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uin
 
 // One guarded step at any stream position t (wave-uniform): pipeline fill, row end, filter
 // tails, drain.  Same state, same results as `step` where both apply.
-template <bool VHS, class RT>
-DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring, int t,
-                   uint32_t &px, int &xo_out)
+// The VCR half of a guarded step: returns the VCR's composite sample at x2 = t - 7 - d (0 outside
+// the row).
+template <class RT>
+DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const Const<RT> &C, uint32_t *ring, int t)
 {
     const int W = C.W;
     const int pc = t < W ? cs_load(C, t) : 0;             // t is wave-uniform
     int Y, U, V;
     S.D1.push_edge(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
     const int x1 = t - 7;
-    int x3 = x1;
-    if (VHS) {
-        const bool in1 = x1 >= 0 && x1 < W;
-        int fU = 0, fV = 0;
-        if (in1) {
-            U += S.nU; V += S.nV;
-            S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
-            S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
-            const RT u = (RT)U, v = (RT)V;
-            U = (int)((u * C.cosv) - (v * C.sinv));
-            V = (int)((u * C.sinv) + (v * C.cosv));
-            fU = (int)S.vcU.push((RT)U, C.a_vc);
-            fV = (int)S.vcV.push((RT)V, C.a_vc);
-            if (x1 >= W - C.d) {                  // raw tail of the chroma low-pass :1830
-                C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
-                C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
-            }
+    const bool in1 = x1 >= 0 && x1 < W;
+    int fU = 0, fV = 0;
+    if (in1) {
+        U += S.nU; V += S.nV;
+        S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+        S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+        const RT u = (RT)U, v = (RT)V;
+        U = (int)((u * C.cosv) - (v * C.sinv));
+        V = (int)((u * C.sinv) + (v * C.cosv));
+        fU = (int)S.vcU.push((RT)U, C.a_vc);
+        fV = (int)S.vcV.push((RT)V, C.a_vc);
+        if (x1 >= W - C.d) {                  // raw tail of the chroma low-pass :1830
+            C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
+            C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
         }
-        const int x2 = x1 - C.d;
-        const int xl = t - C.LOFF;
-        const int pl = (xl >= 0 && xl < W) ? cs_load(C, xl) : 0;
-        const int yb = sdiv4(S.l0 + S.l1 + S.l2 + pl);
-        S.lsum = S.l1 + S.l2 + pl;
-        S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
-        const bool in2 = x2 >= 0 && x2 < W;
-        if (in2) {
-            if (x2 >= W - C.d) {
-                fU = C.tailU[(size_t)(x2 & 15) * C.rstride];
-                fV = C.tailV[(size_t)(x2 & 15) * C.rstride];
-            }
-            RT m2;
-            RT s = S.vl.push((RT)yb, C.a_vl, m2);
-            s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
-            const RT s0 = rtrunc<RT>(s);
-            const RT ts = S.sh.push(s0, C.a_sh);
-            Y = (int)(s0 + ((s0 - ts) * C.sharp2));
+    }
+    const int x2 = x1 - C.d;
+    const int xl = t - C.LOFF;
+    const int pl = (xl >= 0 && xl < W) ? cs_load(C, xl) : 0;
+    const int yb = sdiv4(S.l0 + S.l1 + S.l2 + pl);
+    S.lsum = S.l1 + S.l2 + pl;
+    S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
+    const bool in2 = x2 >= 0 && x2 < W;
+    if (in2) {
+        if (x2 >= W - C.d) {
+            fU = C.tailU[(size_t)(x2 & 15) * C.rstride];
+            fV = C.tailV[(size_t)(x2 & 15) * C.rstride];
         }
-        U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
-        V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
-        int c2 = 0;
-        if (in2) {
-            const unsigned s = (C.xi + (unsigned)x2) & 3u;
-            int chroma = (s & 1u) ? V : U;
-            if (s & 2u) chroma = -chroma;
-            c2 = Y + chroma;
-        }
+        RT m2;
+        RT s = S.vl.push((RT)yb, C.a_vl, m2);
+        s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
+        const RT s0 = rtrunc<RT>(s);
+        const RT ts = S.sh.push(s0, C.a_sh);
+        Y = (int)(s0 + ((s0 - ts) * C.sharp2));
+    }
+    U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
+    V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
+    int c2 = 0;
+    if (in2) {
+        const unsigned s = (C.xi + (unsigned)x2) & 3u;
+        int chroma = (s & 1u) ? V : U;
+        if (s & 2u) chroma = -chroma;
+        c2 = Y + chroma;
+    }
+    return c2;
+}
+
+template <bool VHS, class RT>
+DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring, int t,
+                   uint32_t &px, int &xo_out)
+{
+    const int W = C.W;
+    int Y, U, V;
+    int x3 = t - 7;
+    if constexpr (VHS) {
+        const int c2 = vcr_edge<RT>(P, S, C, ring, t);
+        const int x2 = t - 7 - C.d;
         S.D2.push_edge(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
         x3 = x2 - 7;
+    } else {
+        const int pc = t < W ? cs_load(C, t) : 0;         // t is wave-uniform
+        S.D1.push_edge(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
     }
     if (x3 < 0 || x3 > W) return false;
     const bool in3 = x3 < W;
@@ -371,32 +452,48 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32
     if (t + 4 > t_end) return t;
     // sign of the first demodulator's picks: x1 = t - 7 = d + J (mod 4); negated iff x1 = 3 (mod 4)
     const int dph = C.d & 3;
+    const int sn0 = opaque_s(((dph + 0) & 3) == 3 ? -1 : 0), sn1 = opaque_s(((dph + 1) & 3) == 3 ? -1 : 0),
+              sn2 = opaque_s(((dph + 2) & 3) == 3 ? -1 : 0), sn3 = opaque_s(((dph + 3) & 3) == 3 ? -1 : 0);
     int pc[4], pl[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load(C, t + j - LOFF) : 0; }
+    // Where the registers allow it (non-VHS form) the next iteration's samples are requested at the
+    // top of the current one: a whole iteration of arithmetic hides the HBM latency.  The one-launch
+    // VHS form has no registers to spare and reloads each sample right after its step consumed it
+    // (its steps are long enough to cover most of the latency).
+    constexpr bool PFTOP = !VHS;
     for (; t + 4 <= t_end; t += 4) {
         uint32_t o[4];
-        // each sample is replaced by the next iteration's as soon as its step has consumed it
-        // (reads past the row end return 0 and are never used)
+        int nc[4] = {0, 0, 0, 0}, nl[4] = {0, 0, 0, 0};
+        if (PFTOP) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = VHS ? cs_load(C, t + 4 + j - LOFF) : 0; }
+        }
 #define NTSC_FAST_STEP(J)                                                                         \
-        o[J] = step<VHS, DP, J, RT>(P, S, C, ring, pc[J], pl[J], ((dph + J) & 3) == 3 ? -1 : 0);   \
-        pc[J] = cs_load(C, t + 4 + J);                                                            \
-        if (VHS) pl[J] = cs_load(C, t + 4 + J - LOFF);                                            \
+        o[J] = step<VHS, DP, J, RT>(P, S, C, ring, pc[J], pl[J], sn##J);                          \
+        if (!PFTOP) {                                                                             \
+            pc[J] = cs_load(C, t + 4 + J);                                                        \
+            if (VHS) pl[J] = cs_load(C, t + 4 + J - LOFF);                                        \
+        }                                                                                         \
         NTSC_STEP_SCHED_BARRIER();
         NTSC_FAST_STEP(0)
         NTSC_FAST_STEP(1)
         NTSC_FAST_STEP(2)
         NTSC_FAST_STEP(3)
 #undef NTSC_FAST_STEP
+        if (PFTOP) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
+        }
         // stage 4 pixels; every 4th iteration write the lane's 16 pixels as one 64-byte burst
         const int xo0 = t - SKT;                   // multiple of 4
         const int sub = (xo0 >> 2) & 3;
         *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) = make_uint4(o[0], o[1], o[2], o[3]);
         if (sub == 3 && is_out) {
             const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
-            uint4 *dp = reinterpret_cast<uint4 *>(drow + (xo0 - 12));
+            g_v4u_ptr dp = (g_v4u_ptr)(drow + (xo0 - 12));
             const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
-            dp[0] = a; dp[1] = b; dp[2] = c4; dp[3] = d4;
+            dp[0] = to_v4u(a); dp[1] = to_v4u(b); dp[2] = to_v4u(c4); dp[3] = to_v4u(d4);
         }
     }
     return t;
@@ -436,7 +533,11 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
     const FieldDev &fd = fields[f];
     const unsigned field = fd.field & 1u;
     const bool rowok = (int)(field + 2u * k) < P.H;
+#ifdef NTSC_AB_NOSTORE      // timing-only A/B build (WRONG pixels): no pixel stores
+    const bool is_out = false;
+#else
     const bool is_out = lane >= 1 && gidx < P.R && rowok;
+#endif
     const unsigned y = rowok ? field + 2u * (unsigned)k : field;
     const int W = P.W;
     uint32_t *drow = reinterpret_cast<uint32_t *>(fd.dst + (size_t)fd.dst_ls * y);
@@ -452,12 +553,12 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
     C.d = VHS ? P.cdelay : 0;
     C.SKT = VHS ? 15 + C.d : 8;
     C.LOFF = 5 + C.d;
-    C.mL = C.hi ? -1 : 0;
-    C.mNL = ~C.mL;
+    C.mL = opaque_v(C.hi ? -1 : 0);
+    C.mNL = opaque_v(~C.mL);
     const bool vb = VHS && P.vblend && P.ntsc;
-    C.bA = (vb && k >= 2) ? -1 : 0;
-    C.bC = (vb && k >= 1) ? 1 : 0;
-    C.dm = (P.loss && dropout[rc] != 0) ? 0 : -1;
+    C.bA = opaque_v((vb && k >= 2) ? -1 : 0);
+    C.bC = opaque_v((vb && k >= 1) ? 1 : 0);
+    C.dm = opaque_v((P.loss && dropout[rc] != 0) ? 0 : -1);
     C.cosv = 1; C.sinv = 0;
     if (VHS) {
         int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
@@ -508,14 +609,140 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
         if ((xo & 15) == 15) {
             if (is_out) {
                 const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
-                uint4 *dp = reinterpret_cast<uint4 *>(drow + (xo - 15));
+                g_v4u_ptr dp = (g_v4u_ptr)(drow + (xo - 15));
                 const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
-                dp[0] = a; dp[1] = b; dp[2] = c4; dp[3] = d4;
+                dp[0] = to_v4u(a); dp[1] = to_v4u(b); dp[2] = to_v4u(c4); dp[3] = to_v4u(d4);
             }
         } else if (xo == W - 1 && is_out) {
             const int xb = xo & ~15;
-            for (int q = xb; q <= xo; q++) drow[q] = ostage[lane * 20 + (q - xb)];
+            for (int q = xb; q <= xo; q++) ((g_u32_ptr)drow)[q] = ostage[lane * 20 + (q - xb)];
         }
+    }
+}
+
+// =============================================================================== k_vcr_front
+// The VHS form as two launches (A/B alternative, ntscsim_debug_no_fast_decode bit 1): this kernel
+// runs the VCR half of every row (vcr_step / vcr_edge) and writes the VCR's composite output to a
+// second transposed plane; the TV half is then exactly the non-VHS decoder (k_decode_fast<false>)
+// reading that plane.  Each half keeps about half of the filter states and needs no scratch at 3
+// (VCR) / 6 (TV) waves per SIMD, but the composite signal makes one more pass through HBM and a
+// 600-field launch cannot fill the extra wave slots: measured 0.86 ms for the pair against 0.80 ms
+// for the one-launch form, which therefore stays the default.
+#ifndef NTSC_FRONT_WAVES
+#define NTSC_FRONT_WAVES 3
+#endif
+template <class RT>
+__global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P, GeomDev G,
+                                                      const FieldDev *__restrict__ fields,
+                                                      const int *__restrict__ comp,
+                                                      int *__restrict__ comp_out,
+                                                      const uint32_t *__restrict__ rs_chroma,
+                                                      const int *__restrict__ n0_u,
+                                                      const int *__restrict__ n0_v,
+                                                      const int *__restrict__ hs_shift,
+                                                      const int *__restrict__ pn_noise,
+                                                      int *__restrict__ tails)
+{
+    using namespace fastdec;
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R;
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const int W = P.W;
+    const size_t tcol = (size_t)blockIdx.x * 64 + lane;
+    const size_t tstride = (size_t)gridDim.x * 64;
+
+    Const<RT> C;
+    C.xi = scan_phase(P, y, fd.fieldno);
+    C.hi = (C.xi & 2u) != 0;
+    C.W = W;
+    C.xe = (W & 1) ? W - 1 : W - 2;
+    C.lane = lane;
+    C.d = P.cdelay;
+    C.SKT = 7 + C.d;                   // depth of this half: x2 = t - 7 - d
+    C.LOFF = 5 + C.d;
+    C.mL = opaque_v(C.hi ? -1 : 0);
+    C.mNL = opaque_v(~C.mL);
+    const bool vb = P.vblend && P.ntsc;
+    C.bA = opaque_v((vb && k >= 2) ? -1 : 0);
+    C.bC = opaque_v((vb && k >= 1) ? 1 : 0);
+    C.dm = -1;
+    {
+        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+        C.cosv = (RT)G.ptab[2 * n]; C.sinv = (RT)G.ptab[2 * n + 1];
+    }
+    C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
+    C.sharp2 = (RT)(P.sharpen * 2);
+    C.tailU = tails + tcol;
+    C.tailV = tails + 16 * tstride + tcol;
+    C.rstride = tstride;
+    C.rowbytes = P.Rpad * 4;
+    const int hs = P.hs ? hs_shift[rc] : 0;
+    C.vbase = (int)((unsigned)rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
+    C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0,
+                                               (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(comp_out, 0,
+                                               (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
+    // halo lanes and the lanes past the last row write to padding columns (R <= column < Rpad)
+    const int vout = (is_out ? gidx : P.R + lane) * 4;
+
+    State<true, RT> S;
+    S.D1.init(); S.D2.init();
+    S.l0 = S.l1 = S.l2 = S.lsum = 0;
+    S.vl.reset(16, C.a_vl); S.vpre.reset(16, C.a_vl); S.vcU.reset(0, C.a_vc); S.vcV.reset(0, C.a_vc);
+    S.sh.reset(0, C.a_sh); S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv);
+    S.Yprev = S.Uraw = S.Vraw = 0;
+    S.rng.init(ring, rs_chroma + rc, P.Rpad, lane);
+    S.nU = n0_u[rc]; S.nV = n0_v[rc];
+
+    const int SK1 = C.SKT, LOFF = C.LOFF;
+    const int total = W + SK1;
+    const unsigned rb = (unsigned)C.rowbytes;
+    int t = 0;
+    // ---------------- pipeline fill (no output: x2 < 0)
+    for (; t < SK1 && t < total; t++) (void)vcr_edge<RT>(P, S, C, ring, t);
+    // ---------------- steady state
+    {
+        const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
+        if (t + 4 <= t_end) {
+            const int dph = C.d & 3;
+            const int sn0 = opaque_s(((dph + 0) & 3) == 3 ? -1 : 0), sn1 = opaque_s(((dph + 1) & 3) == 3 ? -1 : 0),
+                      sn2 = opaque_s(((dph + 2) & 3) == 3 ? -1 : 0), sn3 = opaque_s(((dph + 3) & 3) == 3 ? -1 : 0);
+            int pc[4], pl[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = cs_load(C, t + j - LOFF); }
+            unsigned soff = (unsigned)(t - SK1) * rb;
+#define NTSC_VCR_STEP(DPV, J)                                                                     \
+            {                                                                                     \
+                const int c2 = vcr_step<DPV, J, RT>(P, S, C, ring, pc[J], pl[J], sn##J);          \
+                __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
+                soff += rb;                                                                       \
+                NTSC_STEP_SCHED_BARRIER();                                                        \
+            }
+#define NTSC_VCR_ITER(DPV)                                                                        \
+            for (; t + 4 <= t_end; t += 4) {                                                      \
+                int nc[4], nl[4];                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = cs_load(C, t + 4 + j - LOFF); } \
+                NTSC_VCR_STEP(DPV, 0) NTSC_VCR_STEP(DPV, 1) NTSC_VCR_STEP(DPV, 2) NTSC_VCR_STEP(DPV, 3)  \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }   \
+            }
+            if (C.d & 1) { NTSC_VCR_ITER(1) } else { NTSC_VCR_ITER(0) }
+#undef NTSC_VCR_ITER
+#undef NTSC_VCR_STEP
+        }
+    }
+    // ---------------- row end, filter tails, drain
+    for (; t < total; t++) {
+        const int c2 = vcr_edge<RT>(P, S, C, ring, t);
+        const int x2 = t - SK1;
+        if (x2 >= 0) __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)((unsigned)x2 * rb), 0);
     }
 }
 

@@ -1,0 +1,224 @@
+// ntsc_encode_fast.hip -- the encoder of the default / -vhs presets (BGRA -> composite signal),
+// trimmed for the gfx950 VALU the same way as k_decode_fast (ntsc_decode_fast.hip): same results
+// as k_encode (ntsc_kernels.hip), fewer and cheaper instructions.
+//   * RGB -> YIQ (ffmpeg_ntsc.cpp:1375-1383) is evaluated on 256 * {r, g, b}: scaling by a power
+//     of two commutes with every rounding, so (int)(256 * expr(r, g, b)) == (int)expr(256r, 256g,
+//     256b) bit for bit, the three `256 *` multiplications disappear and the byte extraction is
+//     full-rate and / shift work;
+//   * the two input chroma low-passes (composite_lowpass :1429-1458) run in carry form (3 fp64
+//     instructions per pole), fed with trunc() instead of an int round trip;
+//   * 16 pixels per iteration, fully unrolled: every delay line is register renaming, the
+//     subcarrier phase of each position is a compile-time constant (even scanline phase) and the
+//     sign of the modulated chroma is mask arithmetic on full-rate opcodes;
+//   * stores through a buffer descriptor (uniform row offset in an SGPR), unconditional: every
+//     lane owns a column of the transposed plane, also the ones past the last row.
+// Preconditions (launcher): input chroma low-pass on, no pre-emphasis, luma noise on, subcarrier
+// amplitude 50, even scanline phase, 16-byte aligned source rows, composite plane below 4 GiB.
+#pragma clang fp contract(off)
+
+namespace ntscsim {
+namespace fastenc {
+
+using fastdec::Casc3;
+using fastdec::opaque_v;
+
+template <class RT>
+struct EState {
+    Casc3<RT> lpI, lpQ;
+    int Yd[4];            // 256 * luma of pixels t-4 .. t-1
+    int Ir[4], Qr[4];     // raw I, Q of pixels t-4 .. t-1 (row tail :1447-1455), edge steps only
+    int fI[2];            // filtered I pushed at t-2, t-1
+#ifdef NTSC_RANDP
+    fastdec::LaneRandP rng;
+#else
+    LaneRand rng;
+#endif
+    int noise;
+};
+
+template <class RT>
+struct EConst {
+    unsigned xi;
+    int W, lane;
+    int mL, mNL;          // -1 / 0 masks of (xi == 2) and its complement
+    RT a_i, a_q;
+    __amdgpu_buffer_rsrc_t comp;
+    int vcol;             // byte offset of this lane's column
+    int rowbytes;
+};
+
+// 256 * (Y, I, Q) of one BGRA pixel as reals; I and Q already truncated like the reference's (int)
+template <class RT>
+DEV void rgb_to_yiq256(uint32_t px, RT &dY, RT &Id, RT &Qd)
+{
+    const RT r = (RT)((px >> 8) & 0xFF00u), g = (RT)(px & 0xFF00u), b = (RT)((px << 8) & 0xFF00u);
+    dY = ((RT(0.30) * r) + (RT(0.59) * g)) + (RT(0.11) * b);
+    const RT bd = b - dY, rd = r - dY;
+    Id = rtrunc<RT>((RT(-0.27) * bd) + (RT(0.74) * rd));
+    Qd = rtrunc<RT>((RT(0.41) * bd) + (RT(0.48) * rd));
+}
+
+// One steady-state step at unrolled position J of a 16-pixel chunk starting at t0 = 0 (mod 4):
+// consumes pixel t = t0 + J, emits composite sample x = t - 4 = J (mod 4).
+//   Yx = 256 * luma of pixel x, I2 = filtered I pushed two steps ago (index x).
+template <int J, class RT>
+DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
+             RT Id, RT Qd, int Yx, int I2, int &fI_out)
+{
+    fI_out = (int)S.lpI.push(Id, C.a_i);            // lands at index t - 2
+    const int fQ = (int)S.lpQ.push(Qd, C.a_q);      // lands at index t - 4 = x
+    // chroma_into_luma :1460-1495, phase (xi + x) & 3 with xi in {0, 2}: I for even x, sign by
+    // (x & 2) ^ (xi & 2)
+    const int chroma = (J & 1) ? fQ : I2;
+    const int mm = (J & 2) ? C.mNL : C.mL;
+    int Y = Yx + ((chroma ^ mm) - mm);
+    // luma noise :1632-1644
+    Y += S.noise;
+    S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
+    return Y;
+}
+
+// One guarded step at any stream position t (wave-uniform): row start, row end, filter tails.
+template <class RT>
+DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
+                   const uint32_t *srow, int t)
+{
+    const int W = C.W;
+    const uint32_t px = t < W ? ((fastdec::g_cu32_ptr)srow)[t] : 0u;
+    RT dY, Id, Qd;
+    rgb_to_yiq256<RT>(px, dY, Id, Qd);
+    const int Yx = S.Yd[0], Ix = S.Ir[0], Qx = S.Qr[0];          // pixel t - 4
+#pragma unroll
+    for (int q = 0; q < 3; q++) { S.Yd[q] = S.Yd[q + 1]; S.Ir[q] = S.Ir[q + 1]; S.Qr[q] = S.Qr[q + 1]; }
+    S.Yd[3] = (int)dY; S.Ir[3] = (int)Id; S.Qr[3] = (int)Qd;
+    const int I2 = S.fI[0];
+    S.fI[0] = S.fI[1];
+    S.fI[1] = (int)S.lpI.push(Id, C.a_i);
+    const int fQ = (int)S.lpQ.push(Qd, C.a_q);
+    const int x = t - 4;
+    if (x < 0) return;
+    const int I1 = x < W - 2 ? I2 : Ix;                           // the last `delay` samples keep their input
+    const int Q1 = x < W - 4 ? fQ : Qx;
+    const unsigned s = (C.xi + (unsigned)x) & 3u;
+    int chroma = (s & 1u) ? Q1 : I1;
+    if (s & 2u) chroma = -chroma;
+    int Y = Yx + chroma;
+    Y += S.noise;
+    S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
+    __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)((unsigned)x * (unsigned)C.rowbytes), 0);
+}
+
+DEV void load_chunk(const uint8_t *srow, int t0, uint32_t (&px)[16])
+{
+    fastdec::g_cv4u_ptr p = (fastdec::g_cv4u_ptr)(srow + 4 * (size_t)t0);          // global, not FLAT
+    const fastdec::v4u a = p[0], b = p[1], c = p[2], d = p[3];
+    px[0] = a.x; px[1] = a.y; px[2] = a.z; px[3] = a.w;
+    px[4] = b.x; px[5] = b.y; px[6] = b.z; px[7] = b.w;
+    px[8] = c.x; px[9] = c.y; px[10] = c.z; px[11] = c.w;
+    px[12] = d.x; px[13] = d.y; px[14] = d.z; px[15] = d.w;
+}
+
+} // namespace fastenc
+
+template <class RT>
+__global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev *__restrict__ fields,
+                                                    const uint32_t *__restrict__ rs_luma,
+                                                    const int *__restrict__ n0_luma,
+                                                    int *__restrict__ comp)
+{
+    using namespace fastenc;
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int rho = blockIdx.x * 64 + lane;
+    const int rc = rho < P.R ? rho : P.R - 1;
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool valid = rho < P.R && (int)(field + 2u * k) < P.H;
+    const unsigned y = valid ? field + 2u * (unsigned)k : field;
+    // source row: min(y + opposite, H-1), ffmpeg_ntsc.cpp:1585-1588, :1599
+    const unsigned opposite = (fd.flags & 1u) ? ((fd.flags & 2u) ? 1u : 0u) : 0u;
+    unsigned sy = y + opposite;
+    if (sy > (unsigned)P.H - 1u) sy = (unsigned)P.H - 1u;
+    const uint8_t *srow = fd.src + (size_t)fd.src_ls * sy;
+    const int W = P.W;
+
+    EConst<RT> C;
+    C.xi = scan_phase(P, y, fd.fieldno);
+    C.W = W;
+    C.lane = lane;
+    C.mL = opaque_v((C.xi & 2u) ? -1 : 0);
+    C.mNL = opaque_v(~C.mL);
+    C.a_i = (RT)P.a_in_i; C.a_q = (RT)P.a_in_q;
+    C.rowbytes = P.Rpad * 4;
+    C.vcol = rho * 4;                  // rho < Rpad: lanes past the last row own padding columns
+    C.comp = __builtin_amdgcn_make_buffer_rsrc(comp, 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
+
+    EState<RT> S;
+    S.rng.init(ring, rs_luma + rc, P.Rpad, lane);
+    S.noise = n0_luma[rc];
+    S.lpI.reset(0, C.a_i); S.lpQ.reset(0, C.a_q);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { S.Yd[q] = 0; S.Ir[q] = 0; S.Qr[q] = 0; }
+    S.fI[0] = S.fI[1] = 0;
+
+    // ---------------- row start: pixels 0..3 fill the 4-sample look-ahead of the Q low-pass
+    int t = 0;
+    for (; t < 4; t++) edge_step<RT>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    // ---------------- steady state: 16-pixel chunks strictly inside the row
+    if (t + 16 <= W) {
+        uint32_t cur[16], nxt[16];
+        load_chunk(srow, t, cur);
+        int Y0 = S.Yd[0], Y1 = S.Yd[1], Y2 = S.Yd[2], Y3 = S.Yd[3];   // luma of pixels t-4 .. t-1
+        int I0 = S.fI[0], I1 = S.fI[1];                               // filtered I of indices t-4, t-3
+        RT IdT[4], QdT[4];     // raw I, Q of the chunk's last four pixels (row tail)
+        for (; t + 16 <= W; t += 16) {
+            const bool more = t + 32 <= W;
+            if (more) load_chunk(srow, t + 16, nxt);
+            unsigned soff = (unsigned)(t - 4) * (unsigned)C.rowbytes;
+            int Yn[16], F[16];
+#define NTSC_ENC_STEP(J, YX, IX)                                                                  \
+            {                                                                                     \
+                RT dY, Id_, Qd_;                                                                  \
+                rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
+                Yn[J] = (int)dY;                                                                  \
+                if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
+                const int Y = step<J, RT>(P, S, C, ring, Id_, Qd_, YX, IX, F[J]);                 \
+                __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
+                soff += (unsigned)C.rowbytes;                                                     \
+            }
+            NTSC_ENC_STEP(0, Y0, I0)
+            NTSC_ENC_STEP(1, Y1, I1)
+            NTSC_ENC_STEP(2, Y2, F[0])
+            NTSC_ENC_STEP(3, Y3, F[1])
+            NTSC_ENC_STEP(4, Yn[0], F[2])
+            NTSC_ENC_STEP(5, Yn[1], F[3])
+            NTSC_ENC_STEP(6, Yn[2], F[4])
+            NTSC_ENC_STEP(7, Yn[3], F[5])
+            NTSC_ENC_STEP(8, Yn[4], F[6])
+            NTSC_ENC_STEP(9, Yn[5], F[7])
+            NTSC_ENC_STEP(10, Yn[6], F[8])
+            NTSC_ENC_STEP(11, Yn[7], F[9])
+            NTSC_ENC_STEP(12, Yn[8], F[10])
+            NTSC_ENC_STEP(13, Yn[9], F[11])
+            NTSC_ENC_STEP(14, Yn[10], F[12])
+            NTSC_ENC_STEP(15, Yn[11], F[13])
+#undef NTSC_ENC_STEP
+            Y0 = Yn[12]; Y1 = Yn[13]; Y2 = Yn[14]; Y3 = Yn[15];
+            I0 = F[14]; I1 = F[15];
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) cur[j] = nxt[j];
+            }
+        }
+        // hand the delay lines back to the guarded steps
+        S.Yd[0] = Y0; S.Yd[1] = Y1; S.Yd[2] = Y2; S.Yd[3] = Y3;
+        S.fI[0] = I0; S.fI[1] = I1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { S.Ir[q] = (int)IdT[q]; S.Qr[q] = (int)QdT[q]; }
+    }
+    // ---------------- row end + drain
+    for (; t < W + 4; t++) edge_step<RT>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+}
+
+} // namespace ntscsim

@@ -36,6 +36,7 @@ DEV unsigned udiv31(unsigned n, const Magic31 &m) { return __umulhi(n, m.mul) >>
 DEV unsigned umod31(unsigned n, const Magic31 &m) { return n - udiv31(n, m) * m.div; }
 DEV int sdivm(int n, const Magic31 &m)                                   // C `/ d`, d > 0
 {
+    if (m.mul == 0) return n;                  // d == 1 has no 32-bit magic (wave-uniform branch)
     const unsigned a = (unsigned)(n < 0 ? -n : n);
     const int q = (int)udiv31(a, m);
     return n < 0 ? -q : q;
@@ -131,6 +132,11 @@ struct LaneRand {
     }
     DEV uint32_t next(uint32_t *ring, int lane)
     {
+#ifdef NTSC_AB_NORAND      // timing-only A/B build (WRONG pixels): no LDS ring
+        (void)ring; (void)lane;
+        p3 = p3 * 1664525u + 1013904223u;
+        return p3 >> 1;
+#endif
         const uint32_t v = ring[slot * 64 + lane] + p3;   // s[i-31] + s[i-3]
         ring[slot * 64 + lane] = v;
         p3 = p2; p2 = p1; p1 = v;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,6 +18,7 @@
 // single translation unit: the kernels are compiled together with their launcher
 #include "ntsc_kernels.hip"
 #include "ntsc_decode_fast.hip"
+#include "ntsc_encode_fast.hip"
 #include "ntsc422_kernels.hip"
 
 using namespace ntscsim;
@@ -72,13 +74,18 @@ struct ntscsim_ctx {
     struct Delta { uint64_t n; RandPoly p; };
     std::vector<Delta> deltas;
 
-    Geometry geom;
+    // Per-geometry jump tables: one IMMUTABLE set of device buffers per (W, H, tool) ever used on
+    // this ctx.  A table is uploaded once into buffers nothing else references and never rewritten,
+    // so launches queued for geometry A are not disturbed by a later call for geometry B (the
+    // header's promise that scratch is stream-ordered).  `geom` = the entry of the current call.
+    std::vector<Geometry *> geoms;
+    Geometry *geom_cur = nullptr;
     DevBuf<double> ptab;
     bool ptab_ready = false;
 
     // per-batch scratch
     DevBuf<FieldDev> fields;
-    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, comp_ghost, tails;
+    DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, comp_ghost, comp_vcr, tails;
     DevBuf<Field422Dev> fields422;
     DevBuf<uint32_t> scratch422;
     std::vector<FieldDev> host_fields;
@@ -112,6 +119,7 @@ struct ntscsim_ctx {
     std::vector<EvSet> ev_live, ev_free;
     int warm_override[2] = {0, 0};
     bool force_generic = false;
+    bool split_vhs = false;          // debug / A-B: VCR half + TV half in two launches instead of k_decode_fast<true>
     bool no_fast_decode = false;     // debug: keep the PRESET template kernels (A/B against k_decode_fast)
     int mode = NTSCSIM_MODE_EXACT;
 };
@@ -210,8 +218,22 @@ static uint64_t chroma_stream_offset(const ntscsim_params &p, int W, int L)
 
 static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
 {
-    Geometry &g = c->geom;
-    if (g.valid && g.W == W && g.H == H && g.variant == D.variant) return NTSCSIM_OK;
+    for (Geometry *e : c->geoms)
+        if (e->valid && e->W == W && e->H == H && e->variant == D.variant) { c->geom_cur = e; return NTSCSIM_OK; }
+    if (c->geoms.size() >= 16) {
+        // a context that cycles through more than 16 geometries: drain the device, then start over
+        HIPCHK(c, hipDeviceSynchronize());
+        for (Geometry *e : c->geoms) {
+            e->lskip.release(); e->pskip.release(); e->jrow.release(); e->sstart.release(); e->jwarm.release();
+            delete e;
+        }
+        c->geoms.clear();
+    }
+    Geometry *gp = new (std::nothrow) Geometry();
+    if (!gp) return NTSCSIM_E_NOMEM;
+    c->geoms.push_back(gp);
+    c->geom_cur = gp;
+    Geometry &g = *gp;
     g.valid = false;
     // chroma-noise draws per row: 2 per pixel (BGRA path) / 2 per chroma sample (YUV422P path)
     const uint64_t cdraws = D.variant ? 2ull * (uint64_t)(W / 2) : 2ull * (uint64_t)W;
@@ -297,6 +319,11 @@ extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx *
     if (!c) return NTSCSIM_E_NOMEM;
     c->prm = *p;
     c->device = device;
+    // developer A/B switch (same as ntscsim_debug_no_fast_decode): NTSCSIM_DEBUG_DECODE=1|2|3
+    if (const char *e = std::getenv("NTSCSIM_DEBUG_DECODE")) {
+        const int v = std::atoi(e);
+        c->no_fast_decode = (v & 1) != 0; c->split_vhs = (v & 2) != 0;
+    }
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -312,11 +339,14 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    c->geom.lskip.release(); c->geom.pskip.release(); c->geom.jrow.release();
-    c->geom.sstart.release(); c->geom.jwarm.release();
+    for (Geometry *e : c->geoms) {
+        e->lskip.release(); e->pskip.release(); e->jrow.release(); e->sstart.release(); e->jwarm.release();
+        delete e;
+    }
+    c->geoms.clear();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->comp_ghost.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (auto &h : c->hslot) {
         h.dsrc.release(); h.ddst.release(); h.dyuv.release(); h.yrec.release();
@@ -385,7 +415,7 @@ extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
 
 extern "C" void ntscsim_debug_no_fast_decode(ntscsim_ctx *c, int on)
 {
-    if (c) c->no_fast_decode = on != 0;
+    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; }
 }
 
 extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chroma_draws)
@@ -393,13 +423,16 @@ extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chr
     if (!c) return;
     c->warm_override[0] = luma_draws;
     c->warm_override[1] = chroma_draws & ~1;
-    c->geom.valid = false;
+    // (test hook only) the tables depend on the warm-up lengths: drain and forget them
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (Geometry *e : c->geoms) e->valid = false;
 }
 
 // ---- step 1: descriptors -> device records.  The rand() window of every field is computed on
 // the host (one 31x31 multiply-accumulate per consecutive field).
 static int prepare_records(ntscsim_ctx *c, const ntscsim_field_desc *descs, int n, int W, int H,
-                           DevParams &D, FieldDev *fh, bool &any_bob)
+                           DevParams &D, FieldDev *fh, bool &any_bob, uint64_t &rng_end)
 {
     if (W < 16 || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
     fill_dev_params(c->prm, D);
@@ -437,13 +470,28 @@ static int prepare_records(ntscsim_ctx *c, const ntscsim_field_desc *descs, int 
         const RandState s = ctx_state_at(c, pos);
         std::memcpy(o.rng, s.w, sizeof(s.w));
         for (int j = 31; j < 61; j++) o.rng[j] = o.rng[j - 31] + o.rng[j - 3];
-        pos += c->geom.calls[d.field & 1];
+        pos += c->geom_cur->calls[d.field & 1];
         al_src = al_src && !(((uintptr_t)d.src_dev | (uintptr_t)d.src_linesize) & 15);
         al_dst = al_dst && !(((uintptr_t)d.dst_dev | (uintptr_t)d.dst_linesize) & 15);
         any_bob = any_bob || (d.flags & NTSCSIM_DESC_BOB);
     }
     if (any_bob && n > 65535) return NTSCSIM_E_SIZE;      // k_bob: one grid row per field
-    c->rng_pos = pos;
+    // Descriptors of one batch run concurrently: two of them may share a destination frame only
+    // as its two fields (different parity, no bob) -- anything else is a write-write race.
+    if (n > 1) {
+        std::vector<std::pair<uintptr_t, unsigned>> keys((size_t)n);
+        for (int i = 0; i < n; i++)
+            keys[(size_t)i] = {(uintptr_t)descs[i].dst_dev,
+                               (descs[i].flags & NTSCSIM_DESC_BOB) ? 2u : (descs[i].field & 1u)};
+        std::sort(keys.begin(), keys.end());
+        for (int i = 1; i < n; i++)
+            if (keys[(size_t)i].first == keys[(size_t)i - 1].first &&
+                (keys[(size_t)i].second == keys[(size_t)i - 1].second || keys[(size_t)i].second == 2u)) {
+                c->err = "descriptors of one batch share a destination frame (same field parity, or bob)";
+                return NTSCSIM_E_ARG;
+            }
+    }
+    rng_end = pos;          // committed by the caller once the launch has succeeded
     D.src_al16 = al_src; D.dst_al16 = al_dst;
     return NTSCSIM_OK;
 }
@@ -491,8 +539,8 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     if (D.vhs) HIPCHK(c, c->tails.ensure((size_t)32 * 64 * dgrid.x));
 
     GeomDev G;
-    G.lskip = c->geom.lskip.p; G.pskip = c->geom.pskip.p; G.jrow = c->geom.jrow.p;
-    G.jwarm = c->geom.jwarm.p; G.sstart = c->geom.sstart.p; G.ptab = c->ptab.p;
+    G.lskip = c->geom_cur->lskip.p; G.pskip = c->geom_cur->pskip.p; G.jrow = c->geom_cur->jrow.p;
+    G.jwarm = c->geom_cur->jwarm.p; G.sstart = c->geom_cur->sstart.p; G.ptab = c->ptab.p;
 
     if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
     if (D.hs || D.pnoise_k || D.loss)
@@ -510,7 +558,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
 #define NTSC_LAUNCH_ENCODE(F, RT)                                                               \
     hipLaunchKernelGGL((k_encode<F, RT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,             \
                        fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p)
-    if (enc_preset) { if (fast) NTSC_LAUNCH_ENCODE(F_LNOISE, float); else NTSC_LAUNCH_ENCODE(F_LNOISE, double); }
+    const bool even_phase = (D.phase_mode == 180 || (D.phase_mode != 90 && D.phase_mode != 270)) && !(D.phase_off & 1);
+    const bool small_plane = (size_t)D.Rpad * (size_t)W * 4 < 0xFFF00000ull;
+    if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
+        // hand-tuned encoder of the presets (ntsc_encode_fast.hip)
+        if (fast) hipLaunchKernelGGL((k_encode_fast<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                                     fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+        else hipLaunchKernelGGL((k_encode_fast<double>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                                fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    } else if (enc_preset) { if (fast) NTSC_LAUNCH_ENCODE(F_LNOISE, float); else NTSC_LAUNCH_ENCODE(F_LNOISE, double); }
     else { if (fast) NTSC_LAUNCH_ENCODE(F_GENERIC, float); else NTSC_LAUNCH_ENCODE(F_GENERIC, double); }
 #undef NTSC_LAUNCH_ENCODE
     // extension: ghosting between encoder and decoder (reads the raw plane, writes a second one)
@@ -532,15 +588,31 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     do { if (fast) NTSC_LAUNCH_DECODE_RT(VHS, CO, F, float);                                     \
          else NTSC_LAUNCH_DECODE_RT(VHS, CO, F, double); } while (0)
     // hand-tuned decoder of the two presets (ntsc_decode_fast.hip) when its preconditions hold
-    const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 &&
-                          (D.phase_mode == 180 || (D.phase_mode != 90 && D.phase_mode != 270)) &&
-                          !(D.phase_off & 1) && (size_t)D.Rpad * (size_t)W * 4 < 0xFFF00000ull &&
+    const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane &&
                           head_switch_is_small(D, W);
 #define NTSC_LAUNCH_FAST(VHS, RT)                                                                \
     hipLaunchKernelGGL((k_decode_fast<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p)
-    if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
+    if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
+        // VCR half -> second composite plane -> TV half (= the non-VHS decoder without head switching)
+        HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
+        if (fast) hipLaunchKernelGGL((k_vcr_front<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                     c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                                     c->pn_noise.p, c->tails.p);
+        else hipLaunchKernelGGL((k_vcr_front<double>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                                c->pn_noise.p, c->tails.p);
+        DevParams D2 = D;
+        D2.hs = 0;
+        const int *tv_in = c->comp_vcr.p;
+        if (fast) hipLaunchKernelGGL((k_decode_fast<false, float>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
+                                     tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                                     c->pn_noise.p, c->dropout.p, c->tails.p);
+        else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
+                                tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                                c->pn_noise.p, c->dropout.p, c->tails.p);
+    } else if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(true, float); else NTSC_LAUNCH_FAST(true, double);
     } else if (dec_fast && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(false, float); else NTSC_LAUNCH_FAST(false, double);
@@ -595,7 +667,8 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     }
     DevParams D;
     bool any_bob = false;
-    int rc = prepare_records(c, descs, n, W, H, D, c->stage[si], any_bob);
+    uint64_t rng_end = c->rng_pos;
+    int rc = prepare_records(c, descs, n, W, H, D, c->stage[si], any_bob, rng_end);
     if (rc != NTSCSIM_OK) return rc;
     HIPCHK(c, c->fields.ensure((size_t)n));
 
@@ -613,6 +686,7 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     rc = launch_records(c, D, c->fields.p, any_bob, st, prof ? &evs : nullptr);
     if (rc != NTSCSIM_OK) return rc;
     if (prof) c->ev_live.push_back(evs);
+    c->rng_pos = rng_end;
     return NTSCSIM_OK;
 }
 
@@ -635,9 +709,9 @@ extern "C" int ntscsim_batch_create(ntscsim_ctx *c, const ntscsim_field_desc *de
     ntscsim_batch *b = new (std::nothrow) ntscsim_batch();
     if (!b) return NTSCSIM_E_NOMEM;
     b->ctx = c;
-    int rc = prepare_records(c, descs, n, W, H, b->D, host.data(), b->any_bob);
-    if (rc != NTSCSIM_OK) { delete b; return rc; }
     b->rng_end = c->rng_pos;
+    int rc = prepare_records(c, descs, n, W, H, b->D, host.data(), b->any_bob, b->rng_end);
+    if (rc != NTSCSIM_OK) { delete b; return rc; }
     if (b->records.ensure((size_t)n) != hipSuccess ||
         hipMemcpy(b->records.p, host.data(), (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice) !=
             hipSuccess) {
@@ -773,7 +847,7 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         const RandState s = ctx_state_at(c, pos);
         std::memcpy(fo.rng, s.w, sizeof(s.w));
         for (int j = 31; j < 61; j++) fo.rng[j] = fo.rng[j - 31] + fo.rng[j - 3];
-        if (!(d.flags & NTSCSIM_422_NOCOMP)) pos += c->geom.calls[d.field & 1];
+        if (!(d.flags & NTSCSIM_422_NOCOMP)) pos += c->geom_cur->calls[d.field & 1];
     }
     c->rng_pos = pos;
     D.src_al16 = al_y16;      // (422 path: luma rows 16-byte aligned)
@@ -803,8 +877,8 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     HIPCHK(c, hipStreamSynchronize(st));
 
     GeomDev G;
-    G.lskip = c->geom.lskip.p; G.pskip = c->geom.pskip.p; G.jrow = c->geom.jrow.p;
-    G.jwarm = c->geom.jwarm.p; G.sstart = c->geom.sstart.p; G.ptab = c->ptab.p;
+    G.lskip = c->geom_cur->lskip.p; G.pskip = c->geom_cur->pskip.p; G.jrow = c->geom_cur->jrow.p;
+    G.jwarm = c->geom_cur->jwarm.p; G.sstart = c->geom_cur->sstart.p; G.ptab = c->ptab.p;
     Scratch422 Sc;
     Sc.S = S;
     Sc.Y = c->scratch422.p;
@@ -990,8 +1064,22 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
                              : ((size_t)dst_ls == pitch && dst_frame_stride == fbytes);
     const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (size_t)src_ls * H;
     const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + obytes_h;
-    const bool pin_src = hipHostRegister((void *)src, src_span, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_dst = hipHostRegister((void *)dst, dst_span, hipHostRegisterDefault) == hipSuccess;
+    // Pin the caller's buffers in place for the duration of the call (whole pages, explicitly).
+    // Small buffers are not worth a registration, and two registrations must never share a page:
+    // small heap allocations often do, and unpinning the first one then pulls the page from under
+    // the second (seen as sporadic aborts inside later, unrelated hipMemcpy calls of the process).
+    const uintptr_t PG = 4096, MIN_PIN = 1u << 20;
+    uintptr_t s0 = (uintptr_t)src & ~(PG - 1), s1 = ((uintptr_t)src + src_span + PG - 1) & ~(PG - 1);
+    uintptr_t d0 = (uintptr_t)dst & ~(PG - 1), d1 = ((uintptr_t)dst + dst_span + PG - 1) & ~(PG - 1);
+    bool want_src = src_span >= MIN_PIN, want_dst = dst_span >= MIN_PIN;
+    if (want_src && want_dst && s0 < d1 && d0 < s1) {          // page ranges touch: one registration
+        s0 = s0 < d0 ? s0 : d0; s1 = s1 > d1 ? s1 : d1;
+        want_dst = false;
+    } else if (s0 < d1 && d0 < s1) {
+        want_src = want_dst = false;                            // a small buffer inside the other's pages
+    }
+    const bool pin_src = want_src && hipHostRegister((void *)s0, s1 - s0, hipHostRegisterDefault) == hipSuccess;
+    const bool pin_dst = want_dst && hipHostRegister((void *)d0, d1 - d0, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
 
     struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr, *dyuv = nullptr; YuvDev *yrec = nullptr;
@@ -1109,8 +1197,8 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     (void)hipStreamSynchronize(s_up);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(s_dn);
-    if (pin_src) (void)hipHostUnregister((void *)src);
-    if (pin_dst) (void)hipHostUnregister((void *)dst);
+    if (pin_src) (void)hipHostUnregister((void *)s0);
+    if (pin_dst) (void)hipHostUnregister((void *)d0);
     return rc;
 }
 

@@ -112,8 +112,7 @@ class FieldSimulator:
                 d.yuv_dev[k] = planes[k].data_ptr()
                 d.yuv_linesize[k] = planes[k].stride(0)
         if stream is None:
-            import torch
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = self._torch_stream()
         rc = self._lib.ntscsim_bgra_to_yuv_device(self._h, arr, len(jobs), int(width), int(height),
                                                   int(pix_fmt), C.c_void_p(stream))
         self._chk(rc, "ntscsim_bgra_to_yuv_device")
@@ -146,8 +145,7 @@ class FieldSimulator:
     def run_descs(self, descs, width, height, stream=None):
         """Enqueue; does not synchronise."""
         if stream is None:
-            import torch
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = self._torch_stream()
         rc = self._lib.ntscsim_fields_device(self._h, descs, len(descs), int(width), int(height),
                                              C.c_void_p(stream))
         self._chk(rc, "ntscsim_fields_device")
@@ -162,8 +160,7 @@ class FieldSimulator:
 
     def run_prepared(self, batch, stream=None):
         if stream is None:
-            import torch
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = self._torch_stream()
         self._chk(self._lib.ntscsim_batch_run(batch, C.c_void_p(stream)), "ntscsim_batch_run")
 
     def free_prepared(self, batch):
@@ -195,8 +192,7 @@ class FieldSimulator:
             d.fieldno = j["fieldno"]
             d.rng_pos = RNG_AUTO if j.get("rng_pos") is None else int(j["rng_pos"])
         if stream is None:
-            import torch
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = self._torch_stream()
         rc = self._lib.ntscsim_fields422_device(self._h, arr, len(jobs), int(width), int(height),
                                                 C.c_void_p(stream))
         self._chk(rc, "ntscsim_fields422_device")
@@ -213,11 +209,20 @@ class FieldSimulator:
             d.field = j["field"]
             d.mode = j["mode"]
         if stream is None:
-            import torch
-            stream = torch.cuda.current_stream(self.device).cuda_stream
+            stream = self._torch_stream()
         rc = self._lib.ntscsim_output422_device(self._h, arr, len(jobs), int(width), int(height),
                                                 C.c_void_p(stream))
         self._chk(rc, "ntscsim_output422_device")
+
+    def _torch_stream(self):
+        """Handle of torch's current stream.  The legacy default stream has handle 0, which the C
+        ABI reads as "the context's own (non-blocking) stream": nothing would order the kernels
+        behind torch work still queued on the default stream, so that work is waited for here."""
+        import torch
+        st = torch.cuda.current_stream(self.device)
+        if st.cuda_stream == 0:
+            st.synchronize()
+        return st.cuda_stream
 
     def sync(self):
         self._chk(self._lib.ntscsim_sync(self._h), "ntscsim_sync")
@@ -238,7 +243,8 @@ class FieldSimulator:
         self._lib.ntscsim_debug_force_generic(self._h, 1 if on else 0)
 
     def debug_no_fast_decode(self, on=True):
-        self._lib.ntscsim_debug_no_fast_decode(self._h, 1 if on else 0)
+        """on: True/1 = template PRESET kernels, 2 = two-launch (VCR half / TV half) VHS decoder."""
+        self._lib.ntscsim_debug_no_fast_decode(self._h, int(on))
 
     def debug_set_warmup(self, luma_draws, chroma_draws):
         self._lib.ntscsim_debug_set_warmup(self._h, int(luma_draws), int(chroma_draws))

@@ -251,7 +251,11 @@ typedef struct ntscsim_field_desc {
  * `hip_stream` (a hipStream_t passed as void*, NULL = the ctx's own stream) and the call returns
  * without synchronising; scratch owned by the ctx is reused by the next call on the same ctx,
  * which is stream-ordered after this one.  descs[0].rng_pos == NTSCSIM_RNG_AUTO continues from
- * the ctx position; on return the ctx position is the end of the last descriptor.
+ * the ctx position; after a successful call the ctx position is the end of the last descriptor
+ * (a call that fails leaves it where it was).
+ * The descriptors of one call run concurrently: two of them may share a destination frame only as
+ * its two fields (different `field`, neither with NTSCSIM_DESC_BOB); any other sharing is refused
+ * with NTSCSIM_E_ARG.
  */
 int ntscsim_fields_device(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int n,
                           int width, int height, void *hip_stream);
@@ -262,6 +266,8 @@ int ntscsim_fields_device(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int
  * (any number of times, e.g. a clip that is re-rendered, or a ring of frame buffers that is
  * refilled in place).  The descriptors' pointers must stay valid.  A batch uses its ctx's scratch:
  * runs on one ctx are stream-ordered by the caller; use one ctx per stream to overlap batches.
+ * ntscsim_batch_create() does not move the ctx's rand() position; every successful
+ * ntscsim_batch_run() leaves it at the end of the batch's last descriptor.
  */
 typedef struct ntscsim_batch ntscsim_batch;
 int  ntscsim_batch_create(ntscsim_ctx *ctx, const ntscsim_field_desc *descs, int n,
@@ -377,8 +383,10 @@ void ntscsim_debug_set_warmup(ntscsim_ctx *ctx, int luma_draws, int chroma_draws
  * specialisations chosen for the default / -vhs parameter sets.  Results must not change. */
 void ntscsim_debug_force_generic(ntscsim_ctx *ctx, int on);
 
-/* Test hook: keep the template-specialised PRESET decoder (k_decode) where the hand-tuned one
- * (k_decode_fast, csrc/ntsc_decode_fast.hip) would run.  Results must not change. */
+/* Test hook: bit 0 keeps the template-specialised PRESET kernels (k_encode / k_decode) where the
+ * hand-tuned ones (csrc/ntsc_encode_fast.hip, csrc/ntsc_decode_fast.hip) would run; bit 1 runs
+ * the hand-tuned VHS decoder as two launches (VCR half -> second composite plane -> TV half)
+ * instead of one.  Results must not change. */
 void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
 
 #ifdef __cplusplus

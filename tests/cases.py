@@ -31,6 +31,7 @@ CASES = [
     ("nocolor", ["-nocolor-subcarrier"], 96, 32, 4, "noise", 0, 0),
     ("nocolor_vhs", ["-vhs", "-nocolor-subcarrier"], 96, 32, 4, "noise", 0, 0),
     ("amp30", ["-vhs", "-subcarrier-amp", "30"], 96, 32, 4, "noise", 0, 0),
+    ("amp1", ["-vhs", "-subcarrier-amp", "1"], 96, 32, 4, "noise", 0, 0),
     ("dropout_often", ["-vhs", "-chroma-dropout", "50000"], 96, 32, 4, "noise", 0, 0),
     ("phase_noise20", ["-chroma-phase-noise", "20"], 96, 32, 4, "noise", 0, 0),
     ("chroma_noise_only", ["-noise", "0", "-chroma-noise", "40"], 96, 32, 4, "noise", 0, 0),

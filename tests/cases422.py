@@ -25,6 +25,7 @@ CASES422 = [
     ("after_yc_sep", ["-vhs", "-nocolor-subcarrier-after-yc-sep"], 96, 32, 4, "noise"),
     ("yc_recomb2", ["-vhs", "-yc-recomb", "2"], 96, 32, 4, "noise"),
     ("amp30", ["-vhs", "-subcarrier-amp", "30"], 96, 32, 4, "noise"),
+    ("amp1", ["-vhs", "-subcarrier-amp", "1"], 96, 32, 4, "noise"),
     ("dropout_often", ["-vhs", "-chroma-dropout", "50000"], 96, 32, 4, "noise"),
     ("phase_noise20", ["-chroma-phase-noise", "20"], 96, 32, 4, "noise"),
     ("hs_inframe", ["-vhs", "-vhs-head-switching-point", "0.105"], 96, 32, 4, "noise"),

@@ -286,6 +286,41 @@ def test_preset_and_generic_kernels_agree(flags, w, h):
     assert np.array_equal(a, e)
 
 
+@pytest.mark.parametrize("flags,w,h", [
+    ([], 96, 32), ([], 720, 486), (["-vhs"], 96, 32), (["-vhs"], 720, 486), (["-vhs"], 101, 35),
+    (["-vhs", "-vhs-speed", "lp"], 100, 33), (["-vhs", "-vhs-speed", "ep"], 128, 40),
+    (["-tvstd", "pal", "-vhs"], 96, 36), (["-vhs", "-vhs-chroma-vblend", "0"], 96, 32),
+    (["-vhs", "-chroma-dropout", "50000"], 96, 32), (["-vhs", "-comp-phase-offset", "2"], 96, 32),
+    (["-comp-phase", "0", "-comp-phase-offset", "2"], 96, 32),
+    # preconditions of the hand-tuned kernels NOT met -> they must fall back, results unchanged
+    (["-vhs", "-comp-phase-offset", "1"], 96, 32), (["-vhs", "-comp-phase", "90"], 96, 32),
+    (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.0012"], 96, 32),
+    (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32),
+])
+def test_every_decoder_path_agrees_with_the_oracle(flags, w, h):
+    """The hand-tuned kernels (ntsc_encode_fast.hip / ntsc_decode_fast.hip, one- and two-launch VHS
+    forms), the template-specialised PRESET kernels and the GENERIC kernels are one function."""
+    n = 4
+    p = L.make_params(flags)
+    srcs = [L.noise_frame(w, h, 77 + j) for j in range(2)]
+    jobs = cases.case_jobs(n)
+    o = L.OracleStream(p)
+    e = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(e[k], srcs[si], field, fieldno)
+    for mode in ("hand-tuned", "two-launch", "template", "generic"):
+        sim = ntscsim.FieldSimulator(params=p)
+        if mode == "two-launch":
+            sim.debug_no_fast_decode(2)
+        elif mode == "template":
+            sim.debug_no_fast_decode(1)
+        elif mode == "generic":
+            sim.debug_force_generic(True)
+        got = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+        sim.close()
+        assert np.array_equal(got, e), mode
+
+
 def test_bob_line_doubling():
     w, h = 96, 32
     for hh in (h, h + 1):
