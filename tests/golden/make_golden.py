@@ -48,8 +48,9 @@ def main():
                    "cases": manifest}, f, indent=1)
     # full-size hashes (inputs are procedural: 8-bar clip, frame k//2 rotated by k//2 pixels)
     big = []
-    for (w, h, flags, n) in [(720, 480, [], 8), (720, 480, ["-vhs"], 8), (720, 486, ["-vhs"], 8),
-                             (1920, 1080, ["-vhs"], 4), (3840, 2160, ["-vhs"], 2)]:
+    for (w, h, flags, n) in [(720, 480, [], 8), (720, 480, ["-vhs"], 8), (720, 486, [], 8),
+                             (720, 486, ["-vhs"], 8), (1920, 1080, [], 4), (1920, 1080, ["-vhs"], 4),
+                             (3840, 2160, [], 4), (3840, 2160, ["-vhs"], 8)]:
         p = L.make_params(flags)
         r = L.RefStream(p)
         dst = np.zeros((h, w, 4), np.uint8)

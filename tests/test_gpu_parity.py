@@ -105,8 +105,9 @@ def test_composite_signal_stage_tap(flags):
     sim.close()
 
 
-@pytest.mark.parametrize("w,h,flags,nf", [(720, 480, [], 4), (720, 480, ["-vhs"], 6),
-                                          (720, 486, ["-vhs"], 6), (1920, 1080, ["-vhs"], 3)])
+@pytest.mark.parametrize("w,h,flags,nf", [(720, 480, [], 4), (720, 480, ["-vhs"], 6), (720, 486, [], 6),
+                                          (720, 486, ["-vhs"], 6), (1920, 1080, ["-vhs"], 3),
+                                          (1920, 1080, [], 2), (3840, 2160, ["-vhs"], 8)])
 def test_full_size_vs_oracle(w, h, flags, nf):
     p = L.make_params(flags)
     srcs = [L.bars(w, h, j) if j % 2 == 0 else L.noise_frame(w, h, 77 + j) for j in range((nf + 1) // 2)]
