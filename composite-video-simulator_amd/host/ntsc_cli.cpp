@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -45,7 +48,7 @@ void usage(const char *arg0)
         " -yc-recomb <n>  -nocomp  -422  -420\n"
         " (audio only, accepted: -preemphasis -deemphasis -audio-hiss -vhs-linear-video-crosstalk\n"
         "  -vhs-linear-high-boost)\n"
-        " extra (not in the reference): --batch <fields per GPU batch, default 256> --height <n>\n"
+        " extra (not in the reference): --batch <fields per GPU batch, default 128> --height <n>\n"
         "                               --ghost <delay px>:<gain/256>  (multipath ghost tap, up to 4)\n",
         arg0);
 }
@@ -56,16 +59,16 @@ struct Source {
     long synth_frames = -1;   // >= 0: synthetic
     int synth_kind = 0;       // 0 bars, 1 noise
     long next = 0;
+    bool eof = false;
 };
 
 void make_bars(uint8_t *f, int W, int H, long rot)
 {
     static const uint32_t table[8] = {0xC0C0C0, 0xC0C000, 0x00C0C0, 0x00C000,
                                       0xC000C0, 0xC00000, 0x0000C0, 0x000000};
-    for (int y = 0; y < H; y++) {
-        uint32_t *row = reinterpret_cast<uint32_t *>(f + (size_t)y * W * 4);
-        for (int x = 0; x < W; x++) row[x] = table[(8 * (int)((x + rot) % W)) / W];
-    }
+    uint32_t *row0 = reinterpret_cast<uint32_t *>(f);
+    for (int x = 0; x < W; x++) row0[x] = table[(8 * (int)((x + rot) % W)) / W];
+    for (int y = 1; y < H; y++) std::memcpy(f + (size_t)y * W * 4, f, (size_t)W * 4);   // every row alike
 }
 
 void make_noise(uint8_t *f, int W, int H, uint32_t seed)
@@ -87,11 +90,12 @@ bool open_source(Source &s)
     return s.fp != nullptr;
 }
 
-// false at end of input
+// false at end of input (a trailing partial frame is reported and dropped)
 bool read_frame(Source &s, uint8_t *dst, int W, int H)
 {
+    if (s.eof) return false;
     if (s.synth_frames >= 0) {
-        if (s.next >= s.synth_frames) return false;
+        if (s.next >= s.synth_frames) { s.eof = true; return false; }
         if (s.synth_kind == 0) make_bars(dst, W, H, s.next);
         else make_noise(dst, W, H, 0x1234567u + (uint32_t)s.next);
         s.next++;
@@ -99,7 +103,12 @@ bool read_frame(Source &s, uint8_t *dst, int W, int H)
     }
     const size_t n = (size_t)W * H * 4;
     const size_t got = std::fread(dst, 1, n, s.fp);
-    if (got != n) return false;
+    if (got != n) {
+        if (got != 0)
+            std::fprintf(stderr, "\n%s: truncated final frame (%zu of %zu bytes) dropped\n", s.spec.c_str(), got, n);
+        s.eof = true;
+        return false;
+    }
     s.next++;
     return true;
 }
@@ -118,7 +127,7 @@ bool read_frame(Source &s, uint8_t *dst, int W, int H)
 int main(int argc, char **argv)
 {
     // pull out the two switches the reference does not have, pass the rest to the mirror parser
-    int batch_fields = 256, height_override = 0;
+    int batch_fields = 128, height_override = 0;
     int ghost_n = 0, ghost_d[4] = {0, 0, 0, 0}, ghost_g[4] = {0, 0, 0, 0};
     std::vector<const char *> av;
     av.push_back(argv[0]);
@@ -172,12 +181,19 @@ int main(int argc, char **argv)
     if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_create: %s\n", ntscsim_strerror(rc)); return 1; }
 
     const int nframes_batch = batch_fields / 2;
-    uint8_t *d_src = nullptr, *d_dst = nullptr, *h_src = nullptr, *h_dst = nullptr;
+    uint8_t *d_src = nullptr, *d_dst = nullptr, *h_srcs[2] = {nullptr, nullptr}, *h_dst = nullptr;
     HIPOK(hipMalloc((void **)&d_src, fbytes * nframes_batch));
     HIPOK(hipMalloc((void **)&d_dst, fbytes * batch_fields));
-    HIPOK(hipHostMalloc((void **)&h_src, fbytes * nframes_batch, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) HIPOK(hipHostMalloc((void **)&h_srcs[i], fbytes * nframes_batch, hipHostMallocDefault));
     HIPOK(hipHostMalloc((void **)&h_dst, fbytes * batch_fields, hipHostMallocDefault));
     HIPOK(hipMemset(d_dst, 0, fbytes * batch_fields));   // ring frames start zeroed (:2088)
+    {
+        // one-off initialisation outside the clock: code objects, streams, chunk slots
+        const int nw = nframes_batch < 32 ? nframes_batch : 32;
+        std::memset(h_srcs[0], 0, fbytes * nw);
+        (void)ntscsim_frames_host(sim, h_srcs[0], fbytes, W * 4, nw, h_dst, fbytes, W * 4, W, H, 0, NTSCSIM_DESC_BOB, 32);
+        ntscsim_set_rng_pos(sim, 0);
+    }
 
     // frame-delay ring (:2070-2092): only its row H-1 can survive composite_layer + bob
     const int delay = cli.frame_delay;
@@ -189,51 +205,108 @@ int main(int argc, char **argv)
     unsigned long long current = 0;     // output field counter (:2140)
     unsigned long long total_fields = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    bool eof = false;
-    while (!eof) {
-        // ---- read up to nframes_batch frames from the LAST input (it overwrites the layers
-        //      below it, :2203-2230); lower layers only advance the rand() stream
-        int nf = 0;
-        for (; nf < nframes_batch; nf++) {
-            bool ok = true;
-            for (size_t li = 0; li + 1 < inputs.size(); li++)
-                ok = read_frame(inputs[li], scratch.data(), W, H) && ok;
-            ok = read_frame(inputs.back(), h_src + fbytes * nf, W, H) && ok;
-            if (!ok) { eof = true; break; }
+    const bool layered = inputs.size() > 1;
+    // ---- reader thread: fills the next batch of source frames while the GPU works on the current
+    //      one.  It reads up to nframes_batch frames from the LAST input (it overwrites the layers
+    //      below it, :2203-2230).  A lower layer that has ended keeps compositing its last frame in
+    //      the reference (:2218-2226), i.e. it goes on drawing from rand(): only the end of the
+    //      last input ends the run.
+    struct Slot { int nf = 0; bool ready = false, last = false; } slot[2];
+    bool stop = false;                  // set on every way out of main(): lets the reader leave
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread reader([&] {
+        bool eof = false;
+        for (int b = 0; !eof; b ^= 1) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return !slot[b].ready || stop; }); if (stop) return; }
+            uint8_t *buf = h_srcs[b];
+            int nf = 0;
+            Source &top = inputs.back();
+            if (top.synth_frames >= 0 && !layered) {
+                // synthetic source: frames are independent, fill the batch with a few threads
+                const long left = top.synth_frames - top.next;
+                nf = (int)(left < nframes_batch ? left : nframes_batch);
+                const long first = top.next;
+                const int nt = nf >= 8 ? 4 : 1;
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; t++)
+                    th.emplace_back([&, t] {
+                        for (int i = t; i < nf; i += nt) {
+                            if (top.synth_kind == 0) make_bars(buf + fbytes * i, W, H, first + i);
+                            else make_noise(buf + fbytes * i, W, H, 0x1234567u + (uint32_t)(first + i));
+                        }
+                    });
+                for (auto &x : th) x.join();
+                top.next += nf;
+                if (top.next >= top.synth_frames) { top.eof = true; eof = true; }
+            } else {
+                for (; nf < nframes_batch; nf++) {
+                    for (size_t li = 0; li + 1 < inputs.size(); li++)
+                        (void)read_frame(inputs[li], scratch.data(), W, H);
+                    if (!read_frame(top, buf + fbytes * nf, W, H)) { eof = true; break; }
+                }
+            }
+            { std::lock_guard<std::mutex> lk(mu); slot[b].nf = nf; slot[b].last = eof; slot[b].ready = true; }
+            cv.notify_all();
         }
-        if (nf == 0) break;
-        HIPOK(hipMemcpy(d_src, h_src, fbytes * nf, hipMemcpyHostToDevice));
+    });
+    struct Joiner {
+        std::thread &t; std::mutex &m; std::condition_variable &c; bool &stop;
+        ~Joiner() { { std::lock_guard<std::mutex> lk(m); stop = true; } c.notify_all(); if (t.joinable()) t.join(); }
+    } joiner{reader, mu, cv, stop};
+    for (int b = 0;; b ^= 1) {
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[b].ready; }); }
+        const int nf = slot[b].nf;
+        const bool last_batch = slot[b].last;
+        uint8_t *h_src = h_srcs[b];
+        auto release = [&] { { std::lock_guard<std::mutex> lk(mu); slot[b].ready = false; } cv.notify_all(); };
+        if (nf == 0) { release(); break; }
         const int nfields = nf * 2;
-        const uint64_t layers = (uint64_t)inputs.size();
-        uint64_t pos = ntscsim_get_rng_pos(sim);
-        for (int k = 0; k < nfields; k++) {
-            const unsigned long long cur = current + (unsigned)k;
-            const unsigned field = (unsigned)((cur & 1) ^ 1);                       // :2229
-            const uint64_t calls = ntscsim_rng_calls_per_field(&prm, W, H, field);
-            pos += calls * (layers - 1);          // draws made by the layers underneath
-            ntscsim_field_desc &d = descs[(size_t)k];
-            std::memset(&d, 0, sizeof(d));
-            d.src_dev = d_src + fbytes * (size_t)(k / 2);
-            d.dst_dev = d_dst + fbytes * (size_t)k;
-            d.src_linesize = W * 4; d.dst_linesize = W * 4;
-            d.field = field;
-            d.flags = NTSCSIM_DESC_BOB;                                             // :2233-2257
-            d.fieldno = cur;
-            d.rng_pos = pos;
-            pos += calls;
+        if (!layered) {
+            // one input: the library's own field loop over host frames (H2D | kernels | D2H pipelined
+            // in chunks; field = (current & 1) ^ 1, fieldno = current, sequential rand() stream)
+            rc = ntscsim_frames_host(sim, h_src, fbytes, W * 4, nf, h_dst, fbytes, W * 4, W, H, current,
+                                     NTSCSIM_DESC_BOB, 32);
+            if (rc != NTSCSIM_OK) {
+                std::fprintf(stderr, "ntscsim_frames_host: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim));
+                return 1;
+            }
+        } else {
+            HIPOK(hipMemcpy(d_src, h_src, fbytes * nf, hipMemcpyHostToDevice));
+            const uint64_t layers = (uint64_t)inputs.size();
+            uint64_t pos = ntscsim_get_rng_pos(sim);
+            for (int k = 0; k < nfields; k++) {
+                const unsigned long long cur = current + (unsigned)k;
+                const unsigned field = (unsigned)((cur & 1) ^ 1);                       // :2229
+                const uint64_t calls = ntscsim_rng_calls_per_field(&prm, W, H, field);
+                pos += calls * (layers - 1);          // draws made by the layers underneath
+                ntscsim_field_desc &d = descs[(size_t)k];
+                std::memset(&d, 0, sizeof(d));
+                d.src_dev = d_src + fbytes * (size_t)(k / 2);
+                d.dst_dev = d_dst + fbytes * (size_t)k;
+                d.src_linesize = W * 4; d.dst_linesize = W * 4;
+                d.field = field;
+                d.flags = NTSCSIM_DESC_BOB;                                             // :2233-2257
+                d.fieldno = cur;
+                d.rng_pos = pos;
+                pos += calls;
+            }
+            rc = ntscsim_fields_device(sim, descs.data(), nfields, W, H, nullptr);
+            if (rc != NTSCSIM_OK) {
+                std::fprintf(stderr, "ntscsim_fields_device: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim));
+                return 1;
+            }
+            rc = ntscsim_sync(sim);
+            if (rc != NTSCSIM_OK) return 1;
+            ntscsim_set_rng_pos(sim, pos);
+            HIPOK(hipMemcpy(h_dst, d_dst, fbytes * nfields, hipMemcpyDeviceToHost));
+            // the device frames are reused by the next batch: clear what bob did not overwrite
+            HIPOK(hipMemset(d_dst, 0, fbytes * batch_fields));
         }
-        rc = ntscsim_fields_device(sim, descs.data(), nfields, W, H, nullptr);
-        if (rc != NTSCSIM_OK) {
-            std::fprintf(stderr, "ntscsim_fields_device: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim));
-            return 1;
-        }
-        rc = ntscsim_sync(sim);
-        if (rc != NTSCSIM_OK) return 1;
-        ntscsim_set_rng_pos(sim, pos);
-        HIPOK(hipMemcpy(h_dst, d_dst, fbytes * nfields, hipMemcpyDeviceToHost));
+        release();                          // the reader may refill this slot now
         for (int k = 0; k < nfields; k++) {
             uint8_t *f = h_dst + fbytes * (size_t)k;
-            const unsigned field = descs[(size_t)k].field;
+            const unsigned field = (unsigned)(((current + (unsigned)k) & 1) ^ 1);
             uint8_t *last = f + (size_t)(H - 1) * W * 4;
             // the row neither composite_layer nor bob writes keeps the ring frame's content
             const bool stale = ((H & 1) == 0 && field == 0) || ((H & 1) == 1 && field == 1);
@@ -243,17 +316,16 @@ int main(int argc, char **argv)
             ring_idx = (ring_idx + 1) % (size_t)delay;                              // :2277
             if (out && std::fwrite(f, 1, fbytes, out) != fbytes) { std::fprintf(stderr, "write failed\n"); return 1; }
         }
-        // the device frames are reused by the next batch: clear what bob did not overwrite
-        HIPOK(hipMemset(d_dst, 0, fbytes * batch_fields));
         current += (unsigned)nfields;
         total_fields += (unsigned)nfields;
         std::fprintf(stderr, "\rOutput field %llu ", current);                      // :1361
+        if (last_batch) break;
     }
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(stderr, "\n%llu fields in %.3f s (%.1f fields/s incl. host I/O)\n", total_fields, dt,
                  dt > 0 ? total_fields / dt : 0.0);
     if (out && out != stdout) std::fclose(out);
     ntscsim_destroy(sim);
-    (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipHostFree(h_src); (void)hipHostFree(h_dst);
+    (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipHostFree(h_srcs[0]); (void)hipHostFree(h_srcs[1]); (void)hipHostFree(h_dst);
     return 0;
 }

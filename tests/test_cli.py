@@ -100,3 +100,33 @@ def test_cli_layered_inputs_advance_the_rand_stream(tmp_path):
         o.field(ring, L.noise_frame(w, h, 0x1234567 + cur // 2), field, cur)
         L.oracle().ntsc_oracle_bob(L._ptr(ring), w * 4, w, h, field)
         assert np.array_equal(got[cur], ring), cur
+
+
+@pytest.mark.gpu
+def test_cli_lower_layer_ending_early_does_not_end_the_run(tmp_path):
+    """The reference keeps compositing an ended layer's last frame (:2218-2226): it goes on drawing
+    from rand(), and only the end of the last input ends the run."""
+    w, h = 96, 32
+    outp = tmp_path / "o.bgra"
+    r = run(["-vhs", "-width", str(w), "--height", str(h), "-i", "bars:1", "-i", "noise:3", "-o", str(outp)])
+    assert r.returncode == 0, r.stderr.decode()
+    got = np.frombuffer(outp.read_bytes(), np.uint8).reshape(6, h, w, 4)
+    p = L.make_params(["-vhs"], output_height=h, output_width=w)
+    o = L.OracleStream(p)
+    ring = np.zeros((h, w, 4), np.uint8)
+    for cur in range(6):
+        field = (cur & 1) ^ 1
+        o.field(ring, L.bars(w, h, 0), field, cur)                       # layer 1: its last frame
+        o.field(ring, L.noise_frame(w, h, 0x1234567 + cur // 2), field, cur)
+        L.oracle().ntsc_oracle_bob(L._ptr(ring), w * 4, w, h, field)
+        assert np.array_equal(got[cur], ring), cur
+
+
+@pytest.mark.gpu
+def test_cli_truncated_final_frame_is_reported(tmp_path):
+    w, h = 96, 32
+    inp, outp = tmp_path / "in.bgra", tmp_path / "o.bgra"
+    inp.write_bytes(L.noise_frame(w, h, 5).tobytes() + b"\x00" * 100)
+    r = run(["-width", str(w), "--height", str(h), "-i", str(inp), "-o", str(outp)])
+    assert r.returncode == 0 and b"truncated final frame" in r.stderr
+    assert len(outp.read_bytes()) == 2 * w * h * 4

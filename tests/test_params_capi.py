@@ -148,3 +148,47 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
         cpp = tmp_path / "hdr.cpp"
         cpp.write_text('#include "ntscsim.h"\nint main() { return 0; }\n')
         subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)])
+
+
+def test_avframe_adapter_compiles_and_maps_the_guards(tmp_path):
+    """include/ntscsim_avframe.h (header-only AVFrame shim): compiles as C99 and C++
+    against a local POD with the six members composite_layer() reads, links against the product
+    library, and turns the reference's silent returns (ffmpeg_ntsc.cpp:1578-1583) into the error
+    codes -- all before any GPU work (a NULL ctx is never dereferenced on those paths)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "av.c"
+    src.write_text(r'''
+#include <stdint.h>
+#include <stdio.h>
+struct my_frame { uint8_t *data[8]; int linesize[8]; int width, height; int format;
+                  int interlaced_frame, top_field_first; };
+#define NTSCSIM_AVFRAME_T struct my_frame
+#include "ntscsim_avframe.h"
+int main(void) {
+    static uint8_t buf[64 * 4 * 8];
+    struct my_frame a = {{buf}, {64 * 4}, 64, 8, 0, 0, 0}, b = a, c = a, d = a;
+    c.width = 32; d.linesize[0] = 100;
+    int r[5];
+    r[0] = ntscsim_field_avframe(0, 0, &a, 0, 0);
+    r[1] = ntscsim_field_avframe(0, &a, &c, 0, 0);
+    r[2] = ntscsim_field_avframe(0, &d, &b, 0, 0);
+    r[3] = ntscsim_field_avframe(0, &a, &b, 0, 0) != NTSCSIM_OK;
+    b.data[0] = 0;
+    r[4] = ntscsim_field_avframe(0, &a, &b, 0, 0);
+    printf("%d %d %d %d %d\n", r[0], r[1], r[2], r[3], r[4]);
+    return 0;
+}
+''')
+    inc = os.path.join(L.ROOT, "include")
+    exe = tmp_path / "av"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                           "-L", L.PKG, "-lntscsim", "-Wl,-rpath," + L.PKG])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert [int(x) for x in out] == [_capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, 1, _capi.E_ARG]
+    if shutil.which("g++"):
+        cpp = tmp_path / "av.cpp"
+        cpp.write_text(src.read_text())
+        subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)])
