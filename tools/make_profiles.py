@@ -1,119 +1,150 @@
 #!/usr/bin/env python3
-"""Copies the rocprofv3 / PMC summaries of one measurement round from gpurun_out/ into profiles/
-and regenerates profiles/traffic.json and profiles/README.md.
-Usage: python tools/make_profiles.py <bench.json> <prof default dir> <prof inflight1 dir> <pmc dir> [fast32 bench.json]"""
-import csv, json, shutil, sys
+"""Assembles profiles/ for one measurement round from what the GPU runs left in gpurun_out/ and
+from the ISA census of the shipped kernels, and regenerates profiles/traffic.json (read by
+bench.py for `roofline.traffic` / `roofline.valu`) and profiles/README.md.
 
-bench = sys.argv[1]
-fast = None
-if len(sys.argv) >= 5:      # full refresh; with only <bench.json> the committed summaries are kept
-    pdef, psingle, pmc = sys.argv[2:5]
-    fast = sys.argv[5] if len(sys.argv) > 5 else None
-    shutil.copy(pdef + "/r01_kernel_stats.csv", "profiles/r01_kernel_stats_default_cmd.csv")
-    shutil.copy(psingle + "/r01_kernel_stats.csv", "profiles/r01_kernel_stats_inflight1.csv")
-    shutil.copy(pmc + "/summary.txt", "profiles/r01_pmc_summary.txt")
-if bench != "profiles/r01_bench.json":
-    shutil.copy(bench, "profiles/r01_bench.json")
+  python tools/make_profiles.py r02 <bench.json> <kstats default dir> <kstats inflight1 dir> \
+         <pmc dir> <valu_rates.txt> <chain_probe.txt> <census dir> [bench_fast32.json]
+
+census dir = JSON files written by tools/isa_cost.py --json for k_decode_fast<true,double>,
+k_encode_fast<double>, k_row_states, k_field_setup (see tools/refresh_profiles.sh).
+"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag, bench, kdef, kif1, pmc, rates, chain, census = sys.argv[1:9]
+fast = sys.argv[9] if len(sys.argv) > 9 else None
+P = "profiles"
+os.makedirs(P, exist_ok=True)
+shutil.copy(os.path.join(kdef, "kernel_stats.csv"), "%s/%s_kernel_stats_default_cmd.csv" % (P, tag))
+shutil.copy(os.path.join(kif1, "kernel_stats.csv"), "%s/%s_kernel_stats_inflight1.csv" % (P, tag))
+shutil.copy(os.path.join(pmc, "summary.txt"), "%s/%s_pmc_summary.txt" % (P, tag))
+shutil.copy(rates, "%s/%s_valu_rates.txt" % (P, tag))
+shutil.copy(chain, "%s/%s_chain_probe.txt" % (P, tag))
+shutil.copy(bench, "%s/%s_bench.json" % (P, tag))
 if fast:
-    shutil.copy(fast, "profiles/r01_bench_fast32.json")
-else:
-    fast = "profiles/r01_bench_fast32.json"
+    shutil.copy(fast, "%s/%s_bench_fast32.json" % (P, tag))
+
+KERN = {"k_decode": "k_decode_fastILb1EdE", "k_encode": "k_encode_fastIdE",
+        "k_row_states": "k_row_states", "k_field_setup": "k_field_setup"}
+cen = {}
+for k, f in KERN.items():
+    j = json.load(open(os.path.join(census, f + ".json")))
+    cen[k] = {x: j[x] for x in ("kernel", "steps_per_pass", "valu_per_step", "fp64_per_step",
+                                "half_rate_int_per_step", "full_rate_per_step", "valu_pipe_cycles_per_step",
+                                "mean_cycles_per_valu", "salu_per_step", "lds_per_step", "vmem_per_step")}
+json.dump({"tool": "tools/isa_cost.py on hipcc -S of csrc/ntscsim_hip.hip (hottest loop of each kernel)",
+           "issue_cost_cycles": {"half_rate (fp64, cvt, v_cndmask, v_lshl*, v_add3, v_med3, v_mul_*, DPP)": 4.3,
+                                 "full_rate (v_add/sub_u32, and/or/xor, shift right, v_mov)": 2.7,
+                                 "source": "%s/%s_valu_rates.txt, slowest wave at 3 waves per SIMD" % (P, tag)},
+           "kernels": cen}, open("%s/%s_isa_cost.json" % (P, tag), "w"), indent=1)
 
 
-def top(path):
-    out = []
+def stats(path):
+    out = {}
     for r in csv.DictReader(open(path)):
         if "ntscsim" in r["Name"]:
-            out.append((r["Name"].split("(")[0], int(r["Calls"]), float(r["AverageNs"]) / 1e3,
-                        float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+            out[r["Name"].split("(")[0].replace("void ", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3,
+                                                                  float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3)
     return out
 
 
-def find(lst, name):
-    for n, c, avg, mn, mx in lst:
-        if name in n:
-            return avg, mn, mx
+def pick(d, name):
+    for k, v in d.items():
+        if name in k:
+            return v
     raise KeyError(name)
 
 
-a, b = top("profiles/r01_kernel_stats_default_cmd.csv"), top("profiles/r01_kernel_stats_inflight1.csv")
-d = json.load(open("profiles/r01_bench.json"))
+a, b = stats("%s/%s_kernel_stats_default_cmd.csv" % (P, tag)), stats("%s/%s_kernel_stats_inflight1.csv" % (P, tag))
+d = json.load(open("%s/%s_bench.json" % (P, tag)))
 pm, cur = {}, None
-for l in open("profiles/r01_pmc_summary.txt"):
+for l in open("%s/%s_pmc_summary.txt" % (P, tag)):
     if not l.startswith(" "):
         cur = l.strip()
     else:
         pm.setdefault(cur, {})[l.split()[0]] = float(l.split("mean=")[1])
-dec = [v for k, v in pm.items() if "k_decode<true, true, 6u" in k][0]
-enc = [v for k, v in pm.items() if "k_encode<8u" in k][0]
+dec = pick(pm, "k_decode_fast<true")
+enc = pick(pm, "k_encode_fast")
+rs, fs = pick(pm, "k_row_states"), pick(pm, "k_field_setup")
 traffic = {"720x486 -vhs": {
     "fields_per_launch": 600,
     "k_decode_hbm_bytes_per_launch": (dec["FETCH_SIZE"] + dec["WRITE_SIZE"]) * 1024,
     "k_decode_fetch_KiB": dec["FETCH_SIZE"], "k_decode_write_KiB": dec["WRITE_SIZE"],
-    "k_encode_fetch_KiB_raw": enc["FETCH_SIZE"],
-    "k_encode_fetch_KiB_x2_gfx950_wide_load_correction": 2 * enc["FETCH_SIZE"],
-    "k_encode_write_KiB": enc["WRITE_SIZE"],
-    "valu_wave_insts_per_launch": {"k_decode": dec["SQ_INSTS_VALU"], "k_encode": enc["SQ_INSTS_VALU"],
-                                   "setup": sum(v["SQ_INSTS_VALU"] for k, v in pm.items()
-                                                if "k_row_states" in k or "k_field_setup" in k)},
-    "note": "rocprofv3 --pmc, one counter per pass (tools/pmc.sh), bench.py --inflight 1; FETCH_SIZE/"
-            "WRITE_SIZE are in KiB; WRITE_SIZE is calibrated by k_encode, whose only stores are the "
-            "composite plane: 410062 KiB == 720*145800*4 B exactly; k_decode loads are 4 B/lane (no x2 "
-            "correction applies), k_encode loads are 16 B/lane (the guide's x2 correction applies)"}}
-json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
-ev = d["roofline"]["kernel_ms_all"]
-md = ["# profiles/ -- round 1 (MI355X, gfx950, ROCm 7.2)\n",
-      "All files come from `python bench.py` (BASELINE configs[1]: 720x486, 600 fields per step, `-vhs`); "
-      "regenerate with `tools/make_profiles.py`.\n",
-      "| file | command | what |", "|---|---|---|",
-      "| `r01_bench.json` | `python bench.py` | the bench line (value, roofline, cpu_baseline) |",
-      "| `r01_bench_fast32.json` | `python bench.py --mode fast32 --cpu-fields 0` | the optional fp32 mode (stated tolerance) |",
-      "| `r01_kernel_stats_default_cmd.csv` | `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-fields 0` | same command as the bench line: 3 steps in flight, so kernels of different steps share the GPU and their wall durations stretch; the **Min** column is the un-shared duration |",
-      "| `r01_kernel_stats_inflight1.csv` | `... bench.py --cpu-fields 0 --inflight 1` | one step at a time: per-kernel durations without overlap |",
-      "| `r01_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--inflight 1`) | FETCH_SIZE, WRITE_SIZE, SQ instruction counters per kernel (mean per launch) |",
-      "| `traffic.json` | derived from the PMC summary | HBM bytes per launch that `bench.py` reports as `roofline.traffic` |\n",
-      "## Bench line\n",
-      "`value` = %.0f frames/s (fields/s), %.3f ms per 600-field step; `roofline.frac` = %.3f (k_decode, HBM "
-      "algorithmic bytes) and `roofline.valu.path_frac` = %.2f (VALU issue slots, the bound that applies).  CPU beside "
-      "it on the GPU box's host (2x EPYC 9575F, cgroup quota 16 CPUs): the reference's own `composite_layer()` "
-      "(`oracle/_ref`, single-threaded like the tool) %.1f fields/s => %.0fx; our port 1 core %.1f fields/s; our port on "
-      "all %d usable CPUs %.0f fields/s => %.0fx.%s\n" % (
-          d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["valu"]["path_frac"],
-          d["cpu_baseline"]["value"], d["speedup_vs_cpu_1core"], d["cpu_baseline"]["port_1core"],
-          d["cpu_baseline"]["port_all_cores"]["cores"], d["cpu_baseline"]["port_all_cores"]["value"],
-          d["speedup_vs_cpu_all_cores"],
-          (" FAST32 mode: %.0f frames/s." % json.load(open(fast))["value"]) if fast else ""),
-      "## Kernel durations (us): hipEvents in bench.py vs rocprofv3\n",
-      "| kernel | bench.py hipEvents (isolated pass) | rocprofv3 inflight 1 avg | rocprofv3 default cmd min / avg / max |",
-      "|---|---|---|---|"]
-for kn, key in (("k_decode", "decode"), ("k_encode", "encode")):
-    ia, pa = find(b, kn), find(a, kn)
-    md.append("| `%s` | %.1f | %.1f | %.1f / %.1f / %.1f |" % (kn, ev[key] * 1e3, ia[0], pa[1], pa[0], pa[2]))
-rs, fs = find(b, "k_row_states"), find(b, "k_field_setup")
-md.append("| `k_row_states` + `k_field_setup` (+ memset) | %.1f (\"setup\") | %.1f + %.1f | |\n" % (ev["setup"] * 1e3, rs[0], fs[0]))
-DSTEPS = 720 + 24      # W + pipeline depth SKT = 7 + cdelay(9, SP) + 7 + 1 (k_decode, -vhs preset)
-vd = dec["SQ_INSTS_VALU"] / (dec["SQ_WAVES"] * DSTEPS)
-ve = enc["SQ_INSTS_VALU"] / (enc["SQ_WAVES"] * (720 + 4))
-ghz = dec["GRBM_GUI_ACTIVE"] / 8 / (find(b, "k_decode")[0] * 1e-6) / 1e9
-md += ["## Where the time goes\n",
-       "* `k_decode<VHS,COMPOUT,preset>`: %d waves x 744 pipeline steps (W + depth 24), %.0f VALU instructions per step per wave "
-       "(SQ_INSTS_VALU / waves / steps, averaged over steady and guarded steps).  DERIVED, assuming every VALU "
-       "instruction occupies its SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU in quad-cycles; "
-       "`tools/valu_rate_probe.hip` shows simple int/fp32 ops can issue faster, so this is an upper bound on the "
-       "busy time): all-VALU-busy time for the busiest SIMDs (3 resident waves) = 3 x 744 x %.0f x 4 cycles = "
-       "%.2f ms at the observed %.2f GHz vs %.2f ms measured (~%.0f%%).  The PMC-based fractions over ALL SIMDs are in "
-       "the bench line: `roofline.valu.k_decode_frac` (one launch) and `path_frac` (three steps in flight).  With "
-       "perfect load balance (2,315 waves over 1,024 SIMDs = 2.26 waves/SIMD) the same instruction "
-       "stream would need %.2f ms; three steps in flight recover most of that (%.2f ms per step for the whole chain; a "
-       "single 2,400-field batch reaches the same rate on one stream, `tools/bigbatch_probe.py`)." % (
-           int(dec["SQ_WAVES"]), vd, vd, 3 * DSTEPS * vd * 4 / (ghz * 1e9) * 1e3, ghz, ev["decode"],
-           100 * 3 * DSTEPS * vd * 4 / (ghz * 1e9) * 1e3 / ev["decode"], 2.26 * DSTEPS * vd * 4 / (ghz * 1e9) * 1e3, d["ms_per_step"]),
-       "* `k_encode<preset>`: %d waves x 724 steps, %.0f VALU instructions per step." % (int(enc["SQ_WAVES"]), ve),
-       "* HBM: k_decode %.0f MB fetched + %.0f MB written per launch, k_encode %.0f MB written (= the composite plane, "
-       "exact) -- algorithmic 839.8 MB for the whole path; at the measured %.2f ms per step that is %.1f TB/s of "
-       "physical traffic, far from the 6.3 TB/s achievable: the path is VALU-bound." % (
-           dec["FETCH_SIZE"] * 1024 / 1e6, dec["WRITE_SIZE"] * 1024 / 1e6, enc["WRITE_SIZE"] * 1024 / 1e6, d["ms_per_step"],
-           ((dec["FETCH_SIZE"] + dec["WRITE_SIZE"] + 2 * enc["FETCH_SIZE"] + enc["WRITE_SIZE"]) * 1024 / 1e12) / (d["ms_per_step"] * 1e-3)),
-       ""]
-open("profiles/README.md", "w").write("\n".join(md))
-print("\n".join(md[-12:]))
+    "k_encode_fetch_KiB_raw": enc["FETCH_SIZE"], "k_encode_write_KiB": enc["WRITE_SIZE"],
+    "path_hbm_bytes_per_launch_lower_bound": (dec["FETCH_SIZE"] + dec["WRITE_SIZE"] + enc["FETCH_SIZE"] + enc["WRITE_SIZE"]) * 1024,
+    "valu": {
+        "k_decode": {"wave_insts_per_launch": dec["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_decode"]["mean_cycles_per_valu"]},
+        "k_encode": {"wave_insts_per_launch": enc["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_encode"]["mean_cycles_per_valu"]},
+        "k_row_states": {"wave_insts_per_launch": rs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_row_states"]["mean_cycles_per_valu"]},
+        "k_field_setup": {"wave_insts_per_launch": fs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_field_setup"]["mean_cycles_per_valu"]},
+    },
+    "note": "rocprofv3 --pmc, separate passes (tools/pmc.sh), bench.py --inflight 1; FETCH_SIZE / WRITE_SIZE in "
+            "KiB; WRITE_SIZE is calibrated by the encoder, whose only stores are the composite plane "
+            "(%d KiB vs 720*145800*4 B = 410062.5 KiB); k_decode loads are 4 B/lane (no wide-load "
+            "correction applies); k_encode loads are 16 B/lane, for which the guide prescribes a x2 "
+            "correction of FETCH_SIZE on gfx950 -- the raw figure is kept here and the encoder's fetch "
+            "is therefore a lower bound" % enc["WRITE_SIZE"],
+}}
+json.dump(traffic, open("%s/traffic.json" % P, "w"), indent=1)
+
+v = d["roofline"].get("valu") or {}
+e2e = d.get("end_to_end", {})
+rd = "# profiles/ -- round %s (MI355X, gfx950, ROCm 7.2)\n\n" % tag[1:]
+rd += "Everything here comes from `python bench.py` (BASELINE configs[1]: 720x486, 600 fields per step, `-vhs`) and the probes in `tools/`; `tools/refresh_profiles.sh` shows the commands, `tools/make_profiles.py` assembles this directory.  Round-1 files (`r01_*`) are kept for comparison.\n\n"
+rd += "| file | command | what |\n|---|---|---|\n"
+rd += "| `%s_bench.json` | `python bench.py` | the bench line: value, value_sustained, roofline (+ cycle-weighted `valu`), cpu_baseline, end_to_end, variant422, sizes, presets |\n" % tag
+rd += "| `%s_kernel_stats_default_cmd.csv` | `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-fields 0 --no-extras` | 4 steps in flight: kernels of different steps share the GPU, wall durations stretch; **Min** = un-shared duration |\n" % tag
+rd += "| `%s_kernel_stats_inflight1.csv` | `... --inflight 1` | one step at a time: per-kernel durations without overlap |\n" % tag
+rd += "| `%s_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--inflight 1`) | FETCH_SIZE, WRITE_SIZE, SQ counters per kernel (mean per launch) |\n" % tag
+rd += "| `%s_valu_rates.txt` | `tools/valu_rate_probe.hip` | issue cost of every opcode class the kernels use, 1-4 waves per SIMD with forced placement |\n" % tag
+rd += "| `%s_chain_probe.txt` | `tools/chain_probe.hip` | cost of dependent fp64 / int chains vs instruction-level parallelism |\n" % tag
+rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction census of each kernel's steady loop |\n" % tag
+rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
+rd += "## Bench line\n\n"
+rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (
+    d["value"], d["steps"], d["ms_per_step"], d.get("value_sustained", 0), d.get("sustained", {}).get("seconds", 0))
+rd += "`roofline.frac` = %.3f (k_decode, algorithmic HBM bytes / 8 TB/s); `roofline.valu.path_frac` = %.2f (cycle-weighted VALU issue, the bound that applies).  " % (
+    d["roofline"]["frac"], v.get("path_frac", 0))
+cb = d.get("cpu_baseline", {})
+if cb:
+    rd += "CPU beside it on the GPU box's host: the reference's own `composite_layer()` (`oracle/_ref`, 1 thread like the tool) %.1f fields/s => %.0fx; our port 1 core %.1f" % (
+        cb["value"], d.get("speedup_vs_cpu_1core", 0), cb.get("port_1core", 0))
+    if "port_all_cores" in cb:
+        rd += "; our port on all %d usable CPUs %.0f fields/s => %.0fx" % (cb["port_all_cores"]["cores"], cb["port_all_cores"]["value"], d.get("speedup_vs_cpu_all_cores", 0))
+    rd += ".\n\n"
+if e2e:
+    rd += "PCIe-inclusive (`end_to_end`, never `value`): BGRA out %.0f frames/s (pinned caller buffers), %.0f (pageable, pinned in place by the call), YUV420P out %.0f.  " % (
+        e2e.get("bgra_pinned", 0), e2e.get("bgra_pageable", 0), e2e.get("yuv420p_pinned", 0))
+if "variant422" in d:
+    rd += "YUV422P tool: %.0f frames/s.  " % d["variant422"]["value"]
+if "sizes" in d:
+    rd += "1920x1080: %.0f, 3840x2160: %.0f frames/s.  " % (d["sizes"]["1920x1080"]["value"], d["sizes"]["3840x2160"]["value"])
+if "presets" in d:
+    rd += "Default preset at 720x486: %.0f frames/s.\n\n" % d["presets"]["default"]["value"]
+rd += "## Kernel durations (us): hipEvents in bench.py vs rocprofv3\n\n"
+rd += "| kernel | bench.py hipEvents (isolated pass) | rocprofv3 inflight 1 avg | rocprofv3 default cmd min / avg / max |\n|---|---|---|---|\n"
+k = d["roofline"]["kernel_ms_all"]
+for nm, key, ev in (("`k_decode_fast<true,double>`", "k_decode_fast<true", k["decode"]), ("`k_encode_fast<double>`", "k_encode_fast", k["encode"])):
+    x, y = pick(b, key), pick(a, key)
+    rd += "| %s | %.1f | %.1f | %.1f / %.1f / %.1f |\n" % (nm, ev * 1e3, x[1], y[2], y[1], y[3])
+rd += "| `k_row_states` + `k_field_setup` (+ memset) | %.1f (\"setup\") | %.1f + %.1f | |\n\n" % (
+    k["setup"] * 1e3, pick(b, "k_row_states")[1], pick(b, "k_field_setup")[1])
+rd += "## Where the time goes\n\n"
+cd = cen["k_decode"]
+ce = cen["k_encode"]
+rd += ("* `k_decode_fast<true,double>`: 2315 waves x 744 pipeline steps; steady step = %.0f VALU instructions (%.0f fp64, %.0f other half-rate, %.0f full-rate) = %.0f SIMD pipe cycles "
+       "(`%s_isa_cost.json`); %.3g wave-instructions per launch (SQ_INSTS_VALU).  256 VGPRs, 2 waves per SIMD: 2048 wave slots for 2315 waves, so an isolated launch pays a second, "
+       "one-wave-per-SIMD round (a lone wave needs ~1150 cycles per step, a pair ~1750): that is why `kernel_ms` (%.3f ms) is far above the launch's share of a saturated step.\n" % (
+           cd["valu_per_step"], cd["fp64_per_step"], cd["half_rate_int_per_step"], cd["full_rate_per_step"], cd["valu_pipe_cycles_per_step"], tag, dec["SQ_INSTS_VALU"], k["decode"]))
+rd += ("* `k_encode_fast<double>`: 2279 waves x 724 steps; steady step = %.0f VALU instructions = %.0f pipe cycles; %.3g wave-instructions per launch.  76 VGPRs; with 2.2 waves per SIMD in one launch it "
+       "runs latency-bound (each wave ~410 cycles per step), with more waves resident (steps in flight) it approaches its pipe cost.\n" % (ce["valu_per_step"], ce["valu_pipe_cycles_per_step"], enc["SQ_INSTS_VALU"]))
+rd += ("* HBM (PMC): k_decode %.0f MB fetched + %.0f MB written, k_encode >= %.0f MB fetched (raw counter, see traffic.json) + %.0f MB written per 600 fields; algorithmic 839.8 MB.  "
+       "At %.2f ms per step that is ~%.1f TB/s of physical traffic against 6.3 TB/s achievable: the path is VALU-bound.\n" % (
+           dec["FETCH_SIZE"] * 1024 / 1e6, dec["WRITE_SIZE"] * 1024 / 1e6, enc["FETCH_SIZE"] * 1024 / 1e6, enc["WRITE_SIZE"] * 1024 / 1e6,
+           d["ms_per_step"], traffic["720x486 -vhs"]["path_hbm_bytes_per_launch_lower_bound"] / (d["ms_per_step"] * 1e-3) / 1e12))
+open("%s/README.md" % P, "w").write(rd)
+print(rd)

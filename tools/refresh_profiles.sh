@@ -1,0 +1,30 @@
+#!/bin/bash
+# How profiles/ is produced (two GPU calls + one local step); TAG = r02, r03, ...
+#
+# 1. GPU box:   bash tools/refresh_profiles.sh gpu r02        (counters, kernel stats, probes, bench line)
+# 2. locally:   bash tools/refresh_profiles.sh local r02      (ISA census + assemble profiles/)
+# 3. GPU box again for the bench line once profiles/traffic.json has changed (bench.py reads it for
+#    roofline.traffic / roofline.valu), then step 2 again.
+set -u
+mode=${1:-local}; tag=${2:-r02}
+if [ "$mode" = gpu ]; then
+  timeout 700 bash tools/pmc.sh pmc_$tag > /dev/null 2>&1
+  timeout 250 tools/kstats.sh ks_${tag}_if1 --inflight 1 --steps 20 --no-extras --sustain-seconds 0 > /dev/null
+  timeout 250 tools/kstats.sh ks_${tag}_default --steps 20 --no-extras --sustain-seconds 0 > /dev/null
+  timeout 120 tools/bin/valu_rate_probe > gpurun_out/valu_rates_$tag.txt 2>&1
+  timeout 120 tools/bin/chain_probe > gpurun_out/chain_probe_$tag.txt 2>&1
+  timeout 500 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+  timeout 200 python bench.py --mode fast32 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_fast32.json 2>> gpurun_out/bench_$tag.err
+  tail -c 600 gpurun_out/bench_$tag.json
+else
+  S=composite-video-simulator_amd/csrc
+  mkdir -p /tmp/census_$tag
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$S --offload-arch=gfx950 -S --cuda-device-only \
+      -o /tmp/census_$tag/ntscsim.s $S/ntscsim_hip.hip 2> /dev/null
+  for k in 'k_decode_fastILb1EdE:4' 'k_decode_fastILb0EdE:4' 'k_encode_fastIdE:16' 'k_row_states:1' 'k_field_setup:1'; do
+    python tools/isa_cost.py /tmp/census_$tag/ntscsim.s "${k%%:*}" --steps "${k##*:}" --json "/tmp/census_$tag/${k%%:*}.json" | head -1
+  done
+  python tools/make_profiles.py $tag gpurun_out/bench_$tag.json gpurun_out/ks_${tag}_default gpurun_out/ks_${tag}_if1 \
+      gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
+      gpurun_out/bench_${tag}_fast32.json > /dev/null && echo "profiles/ assembled"
+fi
