@@ -20,6 +20,7 @@
 #include "ntsc_decode_fast.hip"
 #include "ntsc_encode_fast.hip"
 #include "ntsc422_kernels.hip"
+#include "ntsc_scale.hip"
 
 using namespace ntscsim;
 
@@ -94,6 +95,8 @@ struct ntscsim_ctx {
     DevBuf<Out422Dev> out422;
     std::vector<YuvDev> host_yuv;
     DevBuf<YuvDev> yuv;
+    std::vector<ScaleDev> host_scale;
+    DevBuf<ScaleDev> scale;
     DevBuf<uint32_t> rs_luma, rs_chroma;
     FieldDev *stage[2] = {nullptr, nullptr};
     size_t stage_cap[2] = {0, 0};
@@ -107,7 +110,7 @@ struct ntscsim_ctx {
     // host-frame path
     DevBuf<uint8_t> fsrc, fdst;
     // ntscsim_frames_host(): two chunk slots, copy streams and events, kept between calls
-    struct HostSlot { DevBuf<uint8_t> dsrc, ddst, dyuv; DevBuf<YuvDev> yrec;
+    struct HostSlot { DevBuf<uint8_t> dsrc, ddst, dyuv, draw; DevBuf<YuvDev> yrec; DevBuf<ScaleDev> srec;
                       hipEvent_t up = nullptr, done = nullptr, down = nullptr; };
     HostSlot hslot[2];
     hipStream_t s_up = nullptr, s_dn = nullptr;
@@ -346,10 +349,10 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geoms.clear();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scale.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (auto &h : c->hslot) {
-        h.dsrc.release(); h.ddst.release(); h.dyuv.release(); h.yrec.release();
+        h.dsrc.release(); h.ddst.release(); h.dyuv.release(); h.yrec.release(); h.draw.release(); h.srec.release();
         if (h.up) (void)hipEventDestroy(h.up);
         if (h.done) (void)hipEventDestroy(h.done);
         if (h.down) (void)hipEventDestroy(h.down);
@@ -990,6 +993,50 @@ extern "C" int ntscsim_bgra_to_yuv_device(ntscsim_ctx *c, const ntscsim_yuv_desc
     return NTSCSIM_OK;
 }
 
+
+static int fill_scale_dev(const ntscsim_scale_desc &d, int W, ScaleDev &o)
+{
+    if (d.src_format < NTSCSIM_SRC_BGRA || d.src_format > NTSCSIM_SRC_YUV422P) return NTSCSIM_E_ARG;
+    if (!d.src_dev[0] || !d.bgra_dev) return NTSCSIM_E_ARG;
+    if (d.src_width < 1 || d.src_height < 1 || d.src_width > 16384 || d.src_height > 16384) return NTSCSIM_E_SIZE;
+    if (d.bgra_linesize < 4 * W || (d.bgra_linesize & 3) || ((uintptr_t)d.bgra_dev & 3)) return NTSCSIM_E_SIZE;
+    std::memset(&o, 0, sizeof(o));
+    if (d.src_format == NTSCSIM_SRC_BGRA) {
+        if (d.src_linesize[0] < 4 * d.src_width) return NTSCSIM_E_SIZE;
+    } else {
+        const int cw = (d.src_width + 1) / 2;
+        if (!d.src_dev[1] || !d.src_dev[2]) return NTSCSIM_E_ARG;
+        if (d.src_linesize[0] < d.src_width || d.src_linesize[1] < cw || d.src_linesize[2] < cw) return NTSCSIM_E_SIZE;
+    }
+    for (int k = 0; k < 3; k++) { o.src[k] = (const uint8_t *)d.src_dev[k]; o.src_ls[k] = d.src_linesize[k]; }
+    o.dst = (uint8_t *)d.bgra_dev; o.dst_ls = d.bgra_linesize;
+    o.sw = d.src_width; o.sh = d.src_height; o.fmt = d.src_format;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_scale_to_bgra_device(ntscsim_ctx *c, const ntscsim_scale_desc *descs, int n,
+                                            int W, int H, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0) return NTSCSIM_E_ARG;
+    if (W < 1 || H < 1 || W > 16384 || H > 16384 || n > 65535) return NTSCSIM_E_SIZE;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    c->host_scale.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const int rc = fill_scale_dev(descs[i], W, c->host_scale[(size_t)i]);
+        if (rc != NTSCSIM_OK) return rc;
+    }
+    HIPCHK(c, c->scale.ensure((size_t)n));
+    HIPCHK(c, hipMemcpyAsync(c->scale.p, c->host_scale.data(), (size_t)n * sizeof(ScaleDev), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // (pageable staging vector)
+    hipLaunchKernelGGL(k_scale_to_bgra, dim3((unsigned)((W + 127) / 128), (unsigned)H, (unsigned)n), dim3(128), 0, st,
+                       c->scale.p, W, H);
+    HIPCHK(c, hipGetLastError());
+    return NTSCSIM_OK;
+}
+
 extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int src_interlaced,
                              int src_tff, uint8_t *dst, int dst_ls, int W, int H, unsigned field,
                              uint64_t fieldno)
@@ -1029,13 +1076,25 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
 // chunk slots, so the PCIe transfers of neighbouring chunks overlap the kernels (and each other:
 // the link is full duplex).  The caller's buffers are pinned in place (hipHostRegister) for the
 // duration of the call; if that fails the copies still work, just synchronously.
-extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t src_frame_stride,
-                                   int src_ls, int n_frames, uint8_t *dst, size_t dst_frame_stride,
-                                   int dst_ls, int W, int H, uint64_t first_fieldno, uint32_t flags,
-                                   int chunk_frames)
+static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const uint8_t *src, size_t src_frame_stride,
+                            int src_ls, int n_frames, uint8_t *dst, size_t dst_frame_stride,
+                            int dst_ls, int W, int H, uint64_t first_fieldno, uint32_t flags,
+                            int chunk_frames)
 {
     if (!c || !src || !dst || n_frames < 0) return NTSCSIM_E_ARG;
     if (n_frames == 0) return NTSCSIM_OK;
+    if (S) {
+        if (S->format < NTSCSIM_SRC_BGRA || S->format > NTSCSIM_SRC_YUV422P) return NTSCSIM_E_ARG;
+        if (S->width < 1 || S->height < 1 || S->width > 16384 || S->height > 16384) return NTSCSIM_E_SIZE;
+        if (S->frame_bytes == 0 || src_frame_stride < S->frame_bytes) return NTSCSIM_E_SIZE;
+        const int np = S->format == NTSCSIM_SRC_BGRA ? 1 : 3;
+        for (int p = 0; p < np; p++) {
+            const int need = S->format == NTSCSIM_SRC_BGRA ? 4 * S->width : (p == 0 ? S->width : (S->width + 1) / 2);
+            const size_t rows = (p == 0 || S->format != NTSCSIM_SRC_YUV420P) ? (size_t)S->height : ((size_t)S->height + 1) / 2;
+            if (S->linesize[p] < need || S->plane_offset[p] + (size_t)S->linesize[p] * rows > S->frame_bytes) return NTSCSIM_E_SIZE;
+        }
+        src_ls = 4 * W;       // (the BGRA frames the field loop reads are made on the device)
+    }
     const uint32_t yuv_bits = flags & (NTSCSIM_HOST_YUV420P | NTSCSIM_HOST_YUV422P);
     if (yuv_bits == (NTSCSIM_HOST_YUV420P | NTSCSIM_HOST_YUV422P)) return NTSCSIM_E_ARG;
     const bool yuv = yuv_bits != 0, v420 = yuv_bits == NTSCSIM_HOST_YUV420P;
@@ -1059,10 +1118,11 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     const size_t ybytes_h = (size_t)dst_ls * H, cbytes_h = (size_t)(dst_ls / 2) * crows;
     const size_t obytes_h = yuv ? ybytes_h + 2 * cbytes_h : (size_t)dst_ls * H;
     if (dst_frame_stride < obytes_h) return NTSCSIM_E_SIZE;
-    const bool lin_src = (size_t)src_ls == pitch && src_frame_stride == fbytes;
+    const size_t rawbytes = S ? ((S->frame_bytes + 15) / 16) * 16 : 0;    // device copy of one source frame
+    const bool lin_src = S ? src_frame_stride == rawbytes : ((size_t)src_ls == pitch && src_frame_stride == fbytes);
     const bool lin_dst = yuv ? ((size_t)dst_ls == ypitch_d && dst_frame_stride == obytes_d)
                              : ((size_t)dst_ls == pitch && dst_frame_stride == fbytes);
-    const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (size_t)src_ls * H;
+    const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (S ? S->frame_bytes : (size_t)src_ls * H);
     const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + obytes_h;
     // Pin the caller's buffers in place for the duration of the call (whole pages, explicitly).
     // Small buffers are not worth a registration, and two registrations must never share a page:
@@ -1082,7 +1142,7 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     const bool pin_dst = want_dst && hipHostRegister((void *)d0, d1 - d0, hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
 
-    struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr, *dyuv = nullptr; YuvDev *yrec = nullptr;
+    struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr, *dyuv = nullptr, *draw = nullptr; YuvDev *yrec = nullptr; ScaleDev *srec = nullptr;
                   hipEvent_t up = nullptr, done = nullptr, down = nullptr; bool used = false; };
     Slot slot[2];
     int rc = NTSCSIM_OK;
@@ -1103,6 +1163,22 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
         if (!h.down) fail(hipEventCreateWithFlags(&h.down, hipEventDisableTiming), "hipEventCreate");
         slot[i].dsrc = h.dsrc.p; slot[i].ddst = h.ddst.p;
         slot[i].up = h.up; slot[i].done = h.done; slot[i].down = h.down;
+        if (S && rc == NTSCSIM_OK) {
+            // raw source frames of this slot + their conversion records (fixed addresses: uploaded once)
+            fail(h.draw.ensure(rawbytes * chunk_frames), "hipMalloc");
+            fail(h.srec.ensure((size_t)chunk_frames), "hipMalloc");
+            if (rc != NTSCSIM_OK) break;
+            slot[i].draw = h.draw.p; slot[i].srec = h.srec.p;
+            std::vector<ScaleDev> recs((size_t)chunk_frames);
+            for (int k = 0; k < chunk_frames; k++) {
+                ScaleDev &o = recs[(size_t)k];
+                std::memset(&o, 0, sizeof(o));
+                for (int p = 0; p < 3; p++) { o.src[p] = h.draw.p + rawbytes * (size_t)k + S->plane_offset[p]; o.src_ls[p] = S->linesize[p]; }
+                o.dst = h.dsrc.p + fbytes * (size_t)k; o.dst_ls = (int32_t)pitch;
+                o.sw = S->width; o.sh = S->height; o.fmt = S->format;
+            }
+            fail(hipMemcpy(h.srec.p, recs.data(), recs.size() * sizeof(ScaleDev), hipMemcpyHostToDevice), "hipMemcpy");
+        }
         if (yuv && rc == NTSCSIM_OK) {
             // conversion records of this slot: fixed addresses, uploaded once per call
             fail(h.dyuv.ensure(obytes_d * chunk_frames * 2), "hipMalloc");
@@ -1131,8 +1207,16 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
         const int nf = (n_frames - f0 < chunk_frames) ? n_frames - f0 : chunk_frames;
         // the slot's previous download must have left the device buffers
         if (sl.used) { if (fail(hipEventSynchronize(sl.down), "hipEventSynchronize")) break; }
-        // H2D: nf frames, row by row into the device pitch
-        if (lin_src)
+        // H2D: nf frames, row by row into the device pitch (or, for a scaled source, as they are)
+        if (S && lin_src)
+            fail(hipMemcpyAsync(sl.draw, src + rawbytes * (size_t)f0, rawbytes * (size_t)nf,
+                                hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D");
+        else if (S)
+            for (int j = 0; j < nf; j++)
+                if (fail(hipMemcpyAsync(sl.draw + rawbytes * (size_t)j, src + src_frame_stride * (size_t)(f0 + j),
+                                        S->frame_bytes, hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D")) break;
+        if (S) { /* uploaded above */ }
+        else if (lin_src)
             fail(hipMemcpyAsync(sl.dsrc, src + fbytes * (size_t)f0, fbytes * (size_t)nf,
                                 hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D");
         else
@@ -1145,6 +1229,11 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
         // kernels on the ctx stream, after the upload
         fail(hipStreamWaitEvent(c->stream, sl.up, 0), "hipStreamWaitEvent");
         fail(hipMemsetAsync(sl.ddst, 0, fbytes * nf * 2, c->stream), "hipMemsetAsync");
+        if (S) {
+            hipLaunchKernelGGL(k_scale_to_bgra, dim3((unsigned)((W + 127) / 128), (unsigned)H, (unsigned)nf), dim3(128), 0,
+                               c->stream, sl.srec, W, H);
+            fail(hipGetLastError(), "k_scale_to_bgra");
+        }
         for (int k = 0; k < 2 * nf; k++) {
             ntscsim_field_desc &d = descs[(size_t)k];
             std::memset(&d, 0, sizeof(d));
@@ -1200,6 +1289,25 @@ extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t sr
     if (pin_src) (void)hipHostUnregister((void *)s0);
     if (pin_dst) (void)hipHostUnregister((void *)d0);
     return rc;
+}
+
+extern "C" int ntscsim_frames_host(ntscsim_ctx *c, const uint8_t *src, size_t src_frame_stride,
+                                   int src_ls, int n_frames, uint8_t *dst, size_t dst_frame_stride,
+                                   int dst_ls, int W, int H, uint64_t first_fieldno, uint32_t flags,
+                                   int chunk_frames)
+{
+    return frames_host_impl(c, nullptr, src, src_frame_stride, src_ls, n_frames, dst, dst_frame_stride, dst_ls, W, H,
+                            first_fieldno, flags, chunk_frames);
+}
+
+extern "C" int ntscsim_frames_host_scaled(ntscsim_ctx *c, const ntscsim_host_source *source, const uint8_t *src,
+                                          size_t src_frame_stride, int n_frames, uint8_t *dst,
+                                          size_t dst_frame_stride, int dst_ls, int W, int H,
+                                          uint64_t first_fieldno, uint32_t flags, int chunk_frames)
+{
+    if (!source) return NTSCSIM_E_ARG;
+    return frames_host_impl(c, source, src, src_frame_stride, 4 * W, n_frames, dst, dst_frame_stride, dst_ls, W, H,
+                            first_fieldno, flags, chunk_frames);
 }
 
 extern "C" int ntscsim_debug_read_composite(ntscsim_ctx *c, int32_t *out, size_t out_elems)

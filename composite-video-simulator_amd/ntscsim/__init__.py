@@ -8,7 +8,8 @@ import ctypes as C
 
 from . import _capi
 from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, Field422Desc, FieldDesc,
-                    NtscsimError, Out422Desc, YuvDesc, Params, lib, make_params, make_params_to_composite)
+                    NtscsimError, Out422Desc, YuvDesc, ScaleDesc, HostSource, Params, lib, make_params,
+                    make_params_to_composite)
 
 __all__ = ["FieldSimulator", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
            "field_rows", "calls_per_field", "field_schedule"]
@@ -116,6 +117,35 @@ class FieldSimulator:
         rc = self._lib.ntscsim_bgra_to_yuv_device(self._h, arr, len(jobs), int(width), int(height),
                                                   int(pix_fmt), C.c_void_p(stream))
         self._chk(rc, "ntscsim_bgra_to_yuv_device")
+
+    def scale_to_bgra(self, jobs, width, height, stream=None):
+        """jobs: list of (src planes: 1 (BGRA) or 3 (Y, U, V) CUDA uint8 tensors [rows, ls], src_width,
+        src_height, format _capi.SRC_*, dst BGRA CUDA uint8 tensor [height, ls])."""
+        arr = (ScaleDesc * len(jobs))()
+        for d, (planes, sw, sh, fmt, dst) in zip(arr, jobs):
+            for k, pl in enumerate(planes):
+                d.src_dev[k] = pl.data_ptr()
+                d.src_linesize[k] = pl.stride(0)
+            d.bgra_dev = dst.data_ptr()
+            d.bgra_linesize = dst.stride(0)
+            d.src_width, d.src_height, d.src_format = int(sw), int(sh), int(fmt)
+        if stream is None:
+            stream = self._torch_stream()
+        rc = self._lib.ntscsim_scale_to_bgra_device(self._h, arr, len(jobs), int(width), int(height),
+                                                    C.c_void_p(stream))
+        self._chk(rc, "ntscsim_scale_to_bgra_device")
+
+    def frames_host_scaled(self, dst, src, source, width, height, first_fieldno=0, bob=True, chunk_frames=0):
+        """src: numpy uint8 [N, frame_bytes] (frames in the layout `source`, a HostSource);
+        dst: numpy uint8 [2N, height, width, 4]."""
+        n = src.shape[0]
+        assert src.flags.c_contiguous and dst.flags.c_contiguous and dst.shape == (2 * n, height, width, 4)
+        u8p = C.POINTER(C.c_uint8)
+        rc = self._lib.ntscsim_frames_host_scaled(self._h, C.byref(source), src.ctypes.data_as(u8p), src.strides[0], n,
+                                                  dst.ctypes.data_as(u8p), dst.strides[0], dst.strides[1],
+                                                  int(width), int(height), int(first_fieldno),
+                                                  DESC_BOB if bob else 0, int(chunk_frames))
+        self._chk(rc, "ntscsim_frames_host_scaled")
 
     # ---- batched, device-resident -----------------------------------------------------------
     def build_descs(self, src, dst, jobs, bob=False, interlaced=0, tff=0, rng_pos=None):

@@ -30,6 +30,7 @@ EXPORTS = (
     "ntscsim_debug_force_generic", "ntscsim_debug_no_fast_decode",
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
     "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_bgra_to_yuv_device", "ntscsim_rng_calls_per_field_422",
+    "ntscsim_scale_to_bgra_device", "ntscsim_frames_host_scaled",
 )
 
 
@@ -138,6 +139,33 @@ class YuvDesc(C.Structure):
 
 PIX_YUV420P, PIX_YUV422P = 0, 1
 HOST_YUV420P, HOST_YUV422P = 0x1000, 0x2000
+SRC_BGRA, SRC_YUV420P, SRC_YUV422P = 0, 1, 2
+
+
+class ScaleDesc(C.Structure):
+    """struct ntscsim_scale_desc"""
+    _fields_ = [
+        ("src_dev", C.c_void_p * 3),
+        ("bgra_dev", C.c_void_p),
+        ("src_linesize", C.c_int32 * 3),
+        ("bgra_linesize", C.c_int32),
+        ("src_width", C.c_int32),
+        ("src_height", C.c_int32),
+        ("src_format", C.c_int32),
+        ("_pad", C.c_int32),
+    ]
+
+
+class HostSource(C.Structure):
+    """struct ntscsim_host_source"""
+    _fields_ = [
+        ("format", C.c_int32),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("linesize", C.c_int32 * 3),
+        ("plane_offset", C.c_size_t * 3),
+        ("frame_bytes", C.c_size_t),
+    ]
 
 _u8p = C.POINTER(C.c_uint8)
 _lib = None
@@ -221,6 +249,13 @@ def lib():
     L.ntscsim_bgra_to_yuv_device.argtypes = [C.c_void_p, C.POINTER(YuvDesc), C.c_int, C.c_int,
                                              C.c_int, C.c_int, C.c_void_p]
     L.ntscsim_bgra_to_yuv_device.restype = C.c_int
+    L.ntscsim_scale_to_bgra_device.argtypes = [C.c_void_p, C.POINTER(ScaleDesc), C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p]
+    L.ntscsim_scale_to_bgra_device.restype = C.c_int
+    L.ntscsim_frames_host_scaled.argtypes = [C.c_void_p, C.POINTER(HostSource), C.POINTER(C.c_uint8), C.c_size_t,
+                                             C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                             C.c_uint64, C.c_uint32, C.c_int]
+    L.ntscsim_frames_host_scaled.restype = C.c_int
     L.ntscsim_rng_calls_per_field_422.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_uint]
     L.ntscsim_rng_calls_per_field_422.restype = C.c_uint64
     L.ntscsim_debug_force_generic.argtypes = [C.c_void_p, C.c_int]

@@ -224,6 +224,47 @@ int ntscsim_frames_host(ntscsim_ctx *ctx, const uint8_t *src, size_t src_frame_s
 #define NTSCSIM_HOST_YUV420P 0x1000u
 #define NTSCSIM_HOST_YUV422P 0x2000u
 
+/*
+ * Source scaling / pixel-format conversion before the field loop: what the tool does with
+ * libswscale (sws_getContext(any format, any size -> BGRA W x H, SWS_BILINEAR), ffmpeg_ntsc.cpp
+ * :573-583, sws_scale :603; ffmpeg_to_composite.cpp:1773).  libswscale is third-party code that
+ * is not part of the reference tree: this is NOT a bit-clone of it (parity unpinned) but the
+ * definition in csrc/ntsc_scale.hip -- pixel-centre-aligned bilinear resampling with 8-bit weights,
+ * BT.601 limited-range YUV -> RGB, alpha 255 -- which tests/_libs.py restates and the GPU tests
+ * compare bit for bit.
+ */
+#define NTSCSIM_SRC_BGRA    0
+#define NTSCSIM_SRC_YUV420P 1
+#define NTSCSIM_SRC_YUV422P 2
+typedef struct ntscsim_scale_desc {
+    const void *src_dev[3];     /* device pointers: BGRA uses [0]; planar YUV: Y, U, V            */
+    void       *bgra_dev;       /* device pointer, BGRA frame of the call's width x height        */
+    int32_t     src_linesize[3];
+    int32_t     bgra_linesize;  /* >= 4*width, multiple of 4                                      */
+    int32_t     src_width, src_height;   /* chroma planes: (w+1)/2 wide, (h+1)/2 (4:2:0) or h rows */
+    int32_t     src_format;     /* NTSCSIM_SRC_*                                                  */
+    int32_t     _pad;
+} ntscsim_scale_desc;
+int ntscsim_scale_to_bgra_device(ntscsim_ctx *ctx, const ntscsim_scale_desc *descs, int n,
+                                 int width, int height, void *hip_stream);
+
+/* Layout of one SOURCE frame in host memory for ntscsim_frames_host_scaled(): plane p starts
+ * `plane_offset[p]` bytes into the frame and has rows of `linesize[p]` bytes. */
+typedef struct ntscsim_host_source {
+    int32_t format;             /* NTSCSIM_SRC_*                                                  */
+    int32_t width, height;
+    int32_t linesize[3];
+    size_t  plane_offset[3];
+    size_t  frame_bytes;        /* bytes of one frame that must travel to the device              */
+} ntscsim_host_source;
+/* ntscsim_frames_host() for sources of any size in BGRA / YUV420P / YUV422P: every chunk is uploaded
+ * in its own format, converted to BGRA width x height on the GPU (ntscsim_scale_to_bgra_device) and
+ * fed to the field loop; everything else as ntscsim_frames_host(). */
+int ntscsim_frames_host_scaled(ntscsim_ctx *ctx, const ntscsim_host_source *source, const uint8_t *src,
+                               size_t src_frame_stride, int n_frames, uint8_t *dst,
+                               size_t dst_frame_stride, int dst_linesize, int width, int height,
+                               uint64_t first_fieldno, uint32_t flags, int chunk_frames);
+
 /* ---- batched, device-resident form (what the field loop :2202-2282 becomes) -------------- */
 
 #define NTSCSIM_RNG_AUTO  UINT64_MAX   /* rng_pos: continue after the previous descriptor      */

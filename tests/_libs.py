@@ -356,3 +356,38 @@ def oracle_bgra_to_yuv(bgra, is420):
     oracle().ntsc_oracle_bgra_to_yuv(_ptr(src), w * 4, w, h, _ptr(y), w, _ptr(u), w // 2, _ptr(v), w // 2,
                                      1 if is420 else 0)
     return y, u, v
+
+
+# ---- f2 input side: the definition of csrc/ntsc_scale.hip restated in numpy (test infrastructure)
+def _scale_pos(n_dst, n_src):
+    x = np.arange(n_dst, dtype=np.int64)
+    pos = (((2 * x + 1) * n_src) << 15) // n_dst - 32768
+    pos = np.clip(pos, 0, (n_src - 1) << 16)
+    i0 = pos >> 16
+    return i0, np.minimum(i0 + 1, n_src - 1), (pos >> 8) & 255
+
+
+def _plane_resample(p, W, H):
+    """uint8 [h, w] or [h, w, c] -> int64 [H, W(, c)] by the 8-bit-weight bilinear rule."""
+    p = p.astype(np.int64)
+    x0, x1, fx = _scale_pos(W, p.shape[1])
+    y0, y1, fy = _scale_pos(H, p.shape[0])
+    if p.ndim == 3:
+        fx = fx[None, :, None]; fy = fy[:, None, None]
+    else:
+        fx = fx[None, :]; fy = fy[:, None]
+    top = p[y0][:, x0] * (256 - fx) + p[y0][:, x1] * fx
+    bot = p[y1][:, x0] * (256 - fx) + p[y1][:, x1] * fx
+    return (top * (256 - fy) + bot * fy + 32768) >> 16
+
+
+def oracle_scale_to_bgra(planes, fmt, W, H):
+    """planes: [bgra [h, w, 4]] or [Y [h, w], U, V] (uint8); fmt 0 BGRA, 1 YUV420P, 2 YUV422P."""
+    if fmt == 0:
+        return np.ascontiguousarray(_plane_resample(planes[0], W, H).astype(np.uint8))
+    y, u, v = (_plane_resample(p, W, H) for p in planes)
+    c, d, e = y - 16, u - 128, v - 128
+    r = np.clip((298 * c + 409 * e + 128) >> 8, 0, 255)
+    g = np.clip((298 * c - 100 * d - 208 * e + 128) >> 8, 0, 255)
+    b = np.clip((298 * c + 516 * d + 128) >> 8, 0, 255)
+    return np.ascontiguousarray(np.stack([b, g, r, np.full_like(b, 255)], axis=-1).astype(np.uint8))
