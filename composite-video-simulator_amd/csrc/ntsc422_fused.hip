@@ -1,0 +1,503 @@
+// ntsc422_fused.hip -- composite_video_process() (ffmpeg_to_composite.cpp:629-952) for the VHS
+// family of option sets in FOUR sweeps per scanline instead of the twelve of k422_process:
+//
+//   A   frame row -> input chroma low-pass :353-393 -> modulate :434-477 -> pre-emphasis :636-651
+//       -> luma noise :654-666                                   -> composite bytes (scratch Y)
+//       (head switching :669-732 on the composite bytes, as in k422_process)
+//   B1  Y/C separation :480-553 -> chroma noise :738-754 -> phase noise :755-781 (chroma)
+//       -> VHS luma low-pass + emphasis :812-831 -> luma sharpen :887-901 (luma, same sweep)
+//   B2  VHS chroma low-pass :834-855 -> vertical blend :862-882 -> chroma sharpen :904-924
+//       -> re-modulate :926-928 onto the luma of B1               -> composite bytes (scratch Y)
+//   B3  Y/C separation :929 -> chroma dropout :932-942 -> output chroma low-pass :948-951
+//       -> the frame row
+//
+// Same execution model (one lane = one scanline, 63 rows + 1 halo row per wave, byte planes kept
+// transposed and packed in HBM scratch between sweeps, every stage clamped to uint8 like the
+// reference) and bit-identical results; what changes is the traffic: the frame is read and written
+// directly (no copy sweeps), chroma planes that the next Y/C separation overwrites anyway are never
+// stored, and each scratch plane makes one round trip per sweep -- ~12 byte-visits per luma sample
+// instead of ~48.  Filters run in the carry form of ntsc_decode_fast.hip (3 fp64 instructions per pole).
+//
+// Preconditions (launcher; otherwise k422_process): VHS emulation with composite output (not
+// s-video), colour subcarrier on, input chroma low-pass on, no -nocolor-subcarrier-after-yc-sep,
+// no extra -yc-recomb passes.  Everything else (tape speed, PAL, noise levels, pre-emphasis, head
+// switching, blend, dropout, output low-pass mode, subcarrier amplitude, phase mode) is handled.
+#pragma clang fp contract(off)
+
+namespace ntscsim {
+namespace fused422 {
+
+using fastdec::Casc3;
+
+typedef __attribute__((address_space(1))) const uint8_t *g_cu8;
+typedef __attribute__((address_space(1))) uint8_t *g_u8;
+typedef __attribute__((address_space(1))) const uint32_t *g_cu32;
+typedef __attribute__((address_space(1))) uint32_t *g_u32;
+
+// sequential byte reader over a frame row (global memory), 4 bytes per load when aligned
+struct RowReader {
+    g_cu8 p;
+    bool al4;
+    int nfull;                    // bytes covered by whole words inside the row
+    uint32_t w;
+    DEV void begin(const uint8_t *row, bool aligned4, int n) { p = (g_cu8)row; al4 = aligned4; nfull = n & ~3; w = 0; }
+    DEV int get(int x)            // x ascending, every index exactly once
+    {
+        if (!al4 || x >= nfull) return p[x];
+        if (!(x & 3)) w = *(g_cu32)(p + x);
+        return (int)((w >> (8 * (x & 3))) & 0xFFu);
+    }
+};
+// sequential byte writer into a frame row: bytes are gathered into NW 32-bit words and leave as ONE
+// 4*NW-byte store per lane (rows aligned to 4*NW bytes; a lane's stores of a sweep then cover
+// whole 16 / 8-byte pieces of its row instead of four times as many 4-byte ones)
+template <int NW>
+struct RowWriter {
+    g_u8 p;
+    bool al, on;
+    uint32_t acc, w0, w1, w2;     // finished words of the current group, oldest first
+    DEV void begin(uint8_t *row, bool aligned, bool enabled) { p = (g_u8)row; al = aligned; on = enabled; acc = w0 = w1 = w2 = 0; }
+    DEV void put(int x, int v)    // x ascending, every index exactly once
+    {
+        if (!al) { if (on) p[x] = (uint8_t)v; return; }
+        const uint32_t sh = 8u * (unsigned)(x & 3);
+        acc = (x & 3) ? (acc | ((uint32_t)v << sh)) : (uint32_t)v;
+        if ((x & 3) != 3) return;
+        const int wi = (x >> 2) & (NW - 1);
+        if (wi == NW - 1) {
+            if (on) {
+                if (NW == 4) { typedef uint32_t v4 __attribute__((ext_vector_type(4))); *(__attribute__((address_space(1))) v4 *)(p + (x & ~15)) = v4{w0, w1, w2, acc}; }
+                else { typedef uint32_t v2 __attribute__((ext_vector_type(2))); *(__attribute__((address_space(1))) v2 *)(p + (x & ~7)) = v2{w2, acc}; }
+            }
+        } else {
+            w0 = w1; w1 = w2; w2 = acc;           // NW == 2 keeps its one finished word in w2
+        }
+    }
+    DEV void finish(int n)        // n bytes were put: flush the words and bytes of an incomplete group
+    {
+        if (!al || !on) return;
+        const int g0 = n & ~(4 * NW - 1);                 // start of the incomplete group
+        const int nwords = (n - g0) >> 2;
+        for (int i = nwords; i < 3; i++) { w0 = w1; w1 = w2; }       // oldest finished word -> w0
+        if (nwords > 0) *(g_u32)(p + g0) = w0;
+        if (nwords > 1) *(g_u32)(p + g0 + 4) = w1;
+        if (nwords > 2) *(g_u32)(p + g0 + 8) = w2;
+        for (int i = 0; i < (n & 3); i++) p[(n & ~3) + i] = (uint8_t)((acc >> (8 * i)) & 0xFFu);
+    }
+};
+
+// 16 luma / 8 chroma bytes of a frame row as words, zero past the row; one vector load when the
+// row is aligned and the block lies inside it
+DEV void load_block16(const uint8_t *row, int x0, int n, bool al16, uint32_t (&w)[4])
+{
+    if (al16 && x0 + 16 <= n) {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        const v4 v = *(__attribute__((address_space(1))) const v4 *)(row + x0);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const int x = x0 + 4 * q + b; if (x < n) a |= (uint32_t)((g_cu8)row)[x] << (8 * b); }
+            w[q] = a;
+        }
+    }
+}
+DEV void load_block8(const uint8_t *row, int x0, int n, bool al8, uint32_t (&w)[2])
+{
+    if (al8 && x0 + 8 <= n) {
+        typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+        const v2 v = *(__attribute__((address_space(1))) const v2 *)(row + x0);
+        w[0] = v.x; w[1] = v.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            uint32_t a = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) { const int x = x0 + 4 * q + b; if (x < n) a |= (uint32_t)((g_cu8)row)[x] << (8 * b); }
+            w[q] = a;
+        }
+    }
+}
+DEV int byte_of(uint32_t w, int b) { return (int)((w >> (8 * b)) & 0xFFu); }
+
+// composite_video_chroma_lowpass :353-393 as a stream: push(raw) returns the filtered value that
+// lands `delay` samples back
+struct ChromaLpFull {
+    OnePole hp;
+    Casc3<double> lp;
+    double a_lp, a_hp;
+    DEV void begin(double alp, double ahp) { a_lp = alp; a_hp = ahp; hp.p = 128; lp.reset(128, alp); }
+    DEV int push(int raw)
+    {
+        double s = raw;
+        s += hp.hp(s, a_hp);
+        return clampu8((int)lp.push(s, a_lp));
+    }
+};
+
+// ---------------------------------------------------------------------------------- sweep A
+// Stream index m = the chroma sample being modulated; the low-passes run D = 4 (NTSC: the V delay)
+// or 2 (PAL) samples ahead of it.
+template <bool NTSC>
+DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
+                 int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q)
+{
+    constexpr int D = NTSC ? 4 : 2, DU = 2, DV = NTSC ? 4 : 2;
+    const int W2 = W / 2;
+    const bool al16 = P.src_al16 != 0, al8 = P.dst_al16 != 0;
+    ChromaLpFull lU, lV;
+    lU.begin(P.a_in_i, a_hp_i);
+    lV.begin(NTSC ? P.a_in_q : P.a_in_i, NTSC ? a_hp_q : a_hp_i);
+    Packer422 oy; oy.begin(R.Y);
+    // history (newest last): raw U, V of the last D+1 inputs, filtered U of the last D-DU+1 pushes
+    int rawU[D + 1], rawV[D + 1], filU[D - DU + 1];
+#pragma unroll
+    for (int i = 0; i <= D; i++) { rawU[i] = 128; rawV[i] = 128; }
+#pragma unroll
+    for (int i = 0; i <= D - DU; i++) filU[i] = 128;
+    int filV = 128;
+    // blocks of 8 chroma inputs c0 .. c0+7; the 16 luma bytes they modulate start at 2*(c0 - D): the
+    // upper part of the previous 16-byte luma block and the lower part of the current one.  The
+    // next block's bytes are requested before the current block is worked on.
+    uint32_t cu[2], cv[2], nu[2], nv[2], ly_prev[4] = {0, 0, 0, 0}, ly[4], nly[4];
+    load_block8(fu, 0, W2, al8, cu); load_block8(fv, 0, W2, al8, cv);
+    load_block16(fy, 0, W, al16, ly);
+    for (int c0 = 0; c0 < W2 + D; c0 += 8) {
+        load_block8(fu, c0 + 8, W2, al8, nu); load_block8(fv, c0 + 8, W2, al8, nv);
+        load_block16(fy, 2 * c0 + 16, W, al16, nly);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int c = c0 + j;
+            // ---- push input sample c (if any): filtered U lands at c - DU, filtered V at c - D
+#pragma unroll
+            for (int i = 0; i < D; i++) { rawU[i] = rawU[i + 1]; rawV[i] = rawV[i + 1]; }
+#pragma unroll
+            for (int i = 0; i < D - DU; i++) filU[i] = filU[i + 1];
+            if (c < W2) {
+                const int u = byte_of(cu[j >> 2], j & 3), v = byte_of(cv[j >> 2], j & 3);
+                rawU[D] = u; rawV[D] = v;
+                filU[D - DU] = lU.push(u);
+                filV = lV.push(v);
+            }
+            // ---- modulate chroma sample m = c - D onto luma 2m, 2m+1 (:434-477)
+            const int m = c - D;
+            if (m < 0 || m >= W2) continue;
+            // the last `delay` samples of a row keep their input (:386)
+            const int U1 = m < W2 - DU ? filU[0] : rawU[0];
+            const int V1 = m < W2 - DV ? filV : rawV[0];
+#pragma unroll
+            for (int sx = 0; sx < 2; sx++) {
+                const int x = 2 * m + sx;
+                // byte 2*(j - D) + sx of the current luma block, or of the previous one if negative
+                const int lb = 2 * (j - D) + sx;
+                const int yin = lb >= 0 ? byte_of(ly[lb >> 2], lb & 3) : byte_of(ly_prev[(lb + 16) >> 2], (lb + 16) & 3);
+                const unsigned s = (xi + (unsigned)x) & 3u;
+                int chroma = ((s & 1u) ? V1 - 128 : U1 - 128) * P.amp;
+                if (s & 2u) chroma = -chroma;
+                int yv = clampu8(yin + chroma / 50);
+                if (post.pre_on) {
+                    double sd = yv;
+                    sd += post.pre.hp(sd, P.a_pre) * P.pre_gain;
+                    yv = clampu8((int)sd);
+                }
+                if (post.noise_on) {
+                    yv = clampu8(yv + post.noise);
+                    post.noise = sdiv2(post.noise + (int)umod31(post.rng.next(post.ring, post.lane), P.m_noise) - P.noise_k);
+                }
+                oy.put(x, yv);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ly_prev[q] = ly[q]; ly[q] = nly[q]; }
+        cu[0] = nu[0]; cu[1] = nu[1]; cv[0] = nv[0]; cv[1] = nv[1];
+    }
+    oy.finish(W);
+}
+
+// ---------------------------------------------------------------------------------- luma chain (B1)
+// VHS luma low-pass + emphasis :812-831, then sharpen :887-901, each clamped like its own sweep
+struct LumaVhs {
+    Casc3<double> vl, sh;
+    fastdec::PoleHp<double> pre;
+    double a_vl, a_sh, sharpen;
+    DEV void begin(double avl, double ash, double sharp)
+    {
+        a_vl = avl; a_sh = ash; sharpen = sharp;
+        vl.reset(16, avl); pre.reset(16, avl); sh.reset(16, ash);
+    }
+    DEV int run(int yb)
+    {
+        double m2;
+        double s = vl.push((double)yb, a_vl, m2);
+        s += pre.hp(s, m2, a_vl) * 1.6;
+        const double y1 = clampu8((int)s);
+        const double ts = sh.push(y1, a_sh);
+        return clampu8((int)(y1 + ((y1 - ts) * sharpen)));
+    }
+};
+
+// ---------------------------------------------------------------------------------- frame sink (B3)
+// chroma dropout :932-942 -> output chroma low-pass :948-951 -> the frame row
+struct FrameSink {
+    RowWriter<4> wy;
+    RowWriter<2> wu, wv;
+    bool drop;
+    int mode, dU, dV, W2;             // mode: 0 none, 1 lite (:395-431), 2 full (:353-393)
+    ChromaLpFull fU, fV;
+    Casc3<double> tU, tV;
+    double a_tv;
+    int u1, u2, u3, u4, v1, v2, v3, v4;   // the last 4 inputs, 1 = newest (row tails); named, not an
+                                          // array: a dynamically indexed array would live in scratch
+    DEV void begin(const DevParams &P, uint8_t *fy, uint8_t *fu, uint8_t *fv, bool is_out, bool dropped,
+                   double a_hp_i, double a_hp_q, int W)
+    {
+        wy.begin(fy, P.src_al16 != 0, is_out); wu.begin(fu, P.dst_al16 != 0, is_out); wv.begin(fv, P.dst_al16 != 0, is_out);
+        drop = dropped; mode = P.out_lp; W2 = W / 2;
+        dU = mode == 2 ? 2 : (mode == 1 ? 1 : 0);
+        dV = mode == 2 ? (P.ntsc ? 4 : 2) : (mode == 1 ? 1 : 0);
+        fU.begin(P.a_in_i, a_hp_i);
+        fV.begin(P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i);
+        a_tv = P.a_tv; tU.reset(128, a_tv); tV.reset(128, a_tv);
+        u1 = u2 = u3 = u4 = v1 = v2 = v3 = v4 = 128;
+    }
+    DEV void luma(int x, int y) { wy.put(x, y); }
+    DEV void chroma(int c, int u, int v)
+    {
+        if (drop) { u = 128; v = 128; }
+        u4 = u3; u3 = u2; u2 = u1; u1 = u;
+        v4 = v3; v3 = v2; v2 = v1; v1 = v;
+        if (mode == 0) { wu.put(c, u); wv.put(c, v); return; }
+        int ou, ov;
+        if (mode == 2) { ou = fU.push(u); ov = fV.push(v); }
+        else { ou = clampu8((int)tU.push((double)u, a_tv)); ov = clampu8((int)tV.push((double)v, a_tv)); }
+        if (c >= dU) wu.put(c - dU, ou);
+        if (c >= dV) wv.put(c - dV, ov);
+    }
+    DEV void finish(int W)
+    {
+        // the last `delay` (1, 2 or 4) samples keep their input
+        if (dU == 4) { wu.put(W2 - 4, u4); wu.put(W2 - 3, u3); }
+        if (dU >= 2) wu.put(W2 - 2, u2);
+        if (dU >= 1) wu.put(W2 - 1, u1);
+        if (dV == 4) { wv.put(W2 - 4, v4); wv.put(W2 - 3, v3); }
+        if (dV >= 2) wv.put(W2 - 2, v2);
+        if (dV >= 1) wv.put(W2 - 1, v1);
+        wy.finish(W); wu.finish(W2); wv.finish(W2);
+    }
+};
+
+// composite_ntsc_to_yuv :480-553 in one sweep over scratch plane R.Y (see demodulate422).  LUMA:
+// the separated luma goes through the VHS luma chain and back to R.Y, chroma to R.U / R.V.  SINK:
+// everything goes to the frame through `sink`.
+template <bool SINK>
+DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA, int oob0, int oob1,
+               ChromaPost422 &cpost_in, LumaVhs &lv_in, FrameSink &sink_in)
+{
+    // private copies: the states live in registers for the whole sweep
+    ChromaPost422 cpost = cpost_in;
+    LumaVhs lv = lv_in;
+    FrameSink sink = sink_in;
+    const int W2 = W / 2;
+    unsigned d0 = 16, d1 = 16, d2 = 0, d3 = 0, sum = 0;
+    int ch_even = 0;
+    Packer422 oy, ou, ov;
+    if (!SINK) { oy.begin(R.Y); ou.begin(R.U); ov.begin(R.V); }
+    SWEEP_BEGIN(R.Y, W + 2)
+        const int c_in = x < W ? in : (x == W ? oob0 : oob1);   // Y[r]; r >= W: the caller's bytes (:496)
+        if (x == 0) { d2 = (unsigned)c_in; sum = 32 + d2; }
+        else if (x == 1) { d3 = (unsigned)c_in; sum += d3; }
+        else {
+            const int xo = x - 2;
+            const unsigned c = (unsigned)c_in;
+            sum -= d0;
+            d0 = d1; d1 = d2; d2 = d3; d3 = c;
+            sum += c;
+            const unsigned yb = (sum / 4u) & 0xFFu;
+            int ch = clampu8((int)c + 128 - (int)yb);
+            if (SINK) sink.luma(xo, (int)yb);
+            else oy.put(xo, lv.run((int)yb));
+            const unsigned g = (unsigned)(xo - 2 + (int)xi) & 3u;
+            if ((g == 0u && xo >= 2) || (g == 1u && xo >= 3)) ch = 255 - ch;
+            ch = clampu8(sdivm((ch - 128) * 50, mA) + 128);
+            if (!(xo & 1)) ch_even = ch;
+            else {
+                const int a = ch_even, b = ch;
+                int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
+                if (!SINK) chroma_post422(P, &cpost, u, v);
+                if (SINK) sink.chroma(xo >> 1, u, v);
+                else { ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
+            }
+        }
+    SWEEP_END
+    if (!SINK) { oy.finish(W); ou.finish(W2); ov.finish(W2); }
+    else sink.finish(W);
+}
+
+// ---------------------------------------------------------------------------------- sweep B2
+// VHS chroma low-pass :834-855 (output lands d samples back, the last d keep their input) ->
+// vertical blend :862-882 -> chroma sharpen :904-924 -> modulate onto the luma in R.Y :926-928.
+DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k, double a_sh_c, double sharpen_c)
+{
+    const int W2 = W / 2;
+    const int d = P.cdelay;
+    const bool blend = P.vblend && P.ntsc;
+    Casc3<double> lU, lV, sU, sV;
+    lU.reset(128, P.a_vc); lV.reset(128, P.a_vc); sU.reset(128, a_sh_c); sV.reset(128, a_sh_c);
+    int wu[7] = {0, 0, 0, 0, 0, 0, 0}, wv[7] = {0, 0, 0, 0, 0, 0, 0};   // last 7 inputs, [6] newest
+    Reader422 rv; rv.begin(R.V, W2);
+    // the luma plane is read and rewritten in place, 2 samples per chroma output
+    Reader422 ry; ry.begin(R.Y, W);
+    Packer422 oy; oy.begin(R.Y);
+    SWEEP_BEGIN(R.U, W2 + d)
+        if (j_ == 0) rv.prefetch(x0_);
+        const int inV = rv.get(j_);
+        int fU = 0, fV = 0;
+        if (x < W2) {
+            fU = clampu8((int)lU.push((double)in, P.a_vc));
+            fV = clampu8((int)lV.push((double)inV, P.a_vc));
+        }
+#pragma unroll
+        for (int q = 0; q < 6; q++) { wu[q] = wu[q + 1]; wv[q] = wv[q + 1]; }
+        wu[6] = in; wv[6] = inV;
+        const int xo = x - d;
+        if (xo >= 0) {
+            const int rawU = d == 4 ? wu[2] : (d == 5 ? wu[1] : wu[0]);
+            const int rawV = d == 4 ? wv[2] : (d == 5 ? wv[1] : wv[0]);
+            int u = xo < W2 - d ? fU : rawU, v = xo < W2 - d ? fV : rawV;
+            const int upU = __shfl_up(u, 1), upV = __shfl_up(v, 1);
+            if (blend && k >= 1) {
+                u = ((k >= 2 ? upU : 128) + u + 1) >> 1;
+                v = ((k >= 2 ? upV : 128) + v + 1) >> 1;
+            }
+            double s = u;
+            double ts = sU.push(s, a_sh_c);
+            u = clampu8((int)(s + ((s - ts) * sharpen_c)));
+            s = v;
+            ts = sV.push(s, a_sh_c);
+            v = clampu8((int)(s + ((s - ts) * sharpen_c)));
+            // composite_video_yuv_to_ntsc :434-477 for luma 2*xo, 2*xo+1
+            const int lj = (2 * xo) & 7;                 // position inside the luma reader's block
+            if (lj == 0) { if (xo > 0) ry.advance(); ry.prefetch(2 * xo); }
+#pragma unroll
+            for (int sx = 0; sx < 2; sx++) {
+                const int lx = 2 * xo + sx;
+                const unsigned ph = (xi + (unsigned)lx) & 3u;
+                int chroma = ((ph & 1u) ? v - 128 : u - 128) * P.amp;
+                if (ph & 2u) chroma = -chroma;
+                oy.put(lx, clampu8(ry.get(lj + sx) + chroma / 50));
+            }
+        }
+        if (j_ == BK - 1 || x == W2 + d - 1) rv.advance();
+    SWEEP_END
+    oy.finish(W);
+}
+
+} // namespace fused422
+
+__global__ __launch_bounds__(64) void k422_fused(DevParams P, GeomDev G,
+                                                 const Field422Dev *__restrict__ fields,
+                                                 Scratch422 Sc,
+                                                 const uint32_t *__restrict__ rs_luma,
+                                                 const int *__restrict__ n0_luma,
+                                                 const uint32_t *__restrict__ rs_chroma,
+                                                 const int *__restrict__ n0_u,
+                                                 const int *__restrict__ n0_v,
+                                                 const int *__restrict__ hs_shift,
+                                                 const int *__restrict__ pn_noise,
+                                                 const int *__restrict__ dropout,
+                                                 double a_hp_i, double a_hp_q, double a_sh_c,
+                                                 double sharpen_c)
+{
+    using namespace fused422;
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const Field422Dev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok && !(fd.flags & F422_NOCOMP);
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const unsigned xi = scan_phase422(P, y, fd.fieldno);
+    const int W = P.W;
+    const size_t slot = (size_t)blockIdx.x * 64 + lane;
+    Row422 R;
+    R.Y.p = Sc.Y + slot; R.T.p = Sc.T + slot; R.U.p = Sc.U + slot; R.V.p = Sc.V + slot;
+    R.Y.S = R.T.S = R.U.S = R.V.S = Sc.S;
+    uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
+    uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
+    uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    // the two bytes the reference's Y/C separator reads past the row (:496), see ntsc422_kernels.hip
+    int oob0 = 16, oob1 = 16;
+    {
+        const size_t off = (size_t)fd.dst_ls[0] * y + (size_t)W, end = (size_t)fd.dst_ls[0] * (size_t)P.H;
+        if (off < end) oob0 = fy[W];
+        if (off + 1 < end) oob1 = fy[W + 1];
+    }
+
+    // ---- A: frame row -> composite bytes
+    {
+        LumaPost422 lp_;
+        lp_.pre_on = P.pre_on != 0; lp_.noise_on = P.noise_k != 0;
+        lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
+        if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
+        if (P.ntsc) sweep_a<true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        else sweep_a<false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+    }
+    // ---- head switching :669-732 (displaced copy, fill value 16)
+    if (P.hs) {
+        const int hs = hs_shift[rc];
+        if (__any(hs != 0)) {
+            const int tw = W + W / 10;
+            const int nw = (W + 3) >> 2;
+            for (int q = 0; q < nw; q++) R.T.set_word(q, R.Y.word(q));
+            Packer422 o; o.begin(R.Y);
+            for (int x0 = 0; x0 < W; x0 += BK) {
+                int v[BK], ix[BK];
+#pragma unroll
+                for (int j = 0; j < BK; j++) {
+                    int idx = x0 + j + hs;
+                    idx += (idx >> 31) & tw;
+                    idx -= (idx >= tw) ? tw : 0;
+                    ix[j] = idx;
+                    v[j] = R.T.byte_at(idx < W ? idx : W - 1);
+                }
+#pragma unroll
+                for (int j = 0; j < BK; j++)
+                    if (x0 + j < W) o.put(x0 + j, ix[j] < W ? v[j] : 16);
+            }
+            o.finish(W);
+        }
+    }
+    // ---- B1: Y/C separation + chroma noise + phase noise | VHS luma low-pass + sharpen
+    {
+        ChromaPost422 cp_;
+        cp_.noise_on = P.cnoise_k != 0; cp_.phase_on = P.pnoise_k != 0;
+        cp_.nU = cp_.nV = 0; cp_.cosv = 1; cp_.sinv = 0; cp_.ring = ring; cp_.lane = lane;
+        if (cp_.noise_on) { cp_.rng.init(ring, rs_chroma + rc, P.Rpad, lane); cp_.nU = n0_u[rc]; cp_.nV = n0_v[rc]; }
+        if (cp_.phase_on) {
+            int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+            n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+            cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
+        }
+        LumaVhs lv;
+        lv.begin(P.a_vl, P.a_sh, P.sharpen);
+        FrameSink none;
+        demod<false>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, lv, none);
+    }
+    // ---- B2: VHS chroma low-pass + blend + sharpen | re-modulate
+    sweep_b2(P, R, W, xi, k, a_sh_c, sharpen_c);
+    // ---- B3: Y/C separation | dropout | output chroma low-pass -> frame
+    {
+        FrameSink sink;
+        sink.begin(P, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        ChromaPost422 nocp;
+        LumaVhs nolv;
+        demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);
+    }
+}
+
+} // namespace ntscsim

@@ -20,6 +20,7 @@
 #include "ntsc_decode_fast.hip"
 #include "ntsc_encode_fast.hip"
 #include "ntsc422_kernels.hip"
+#include "ntsc422_fused.hip"
 #include "ntsc_scale.hip"
 
 using namespace ntscsim;
@@ -903,6 +904,14 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
                            c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
+    // four-sweep form (ntsc422_fused.hip) for the VHS family of option sets, twelve-sweep form otherwise
+    const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
+                       !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
+    if (fused)
+        hipLaunchKernelGGL(k422_fused, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
+                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    else
     hipLaunchKernelGGL(k422_process, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma,
