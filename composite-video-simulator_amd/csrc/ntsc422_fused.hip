@@ -34,57 +34,86 @@ typedef __attribute__((address_space(1))) uint8_t *g_u8;
 typedef __attribute__((address_space(1))) const uint32_t *g_cu32;
 typedef __attribute__((address_space(1))) uint32_t *g_u32;
 
-// sequential byte reader over a frame row (global memory), 4 bytes per load when aligned
-struct RowReader {
-    g_cu8 p;
-    bool al4;
-    int nfull;                    // bytes covered by whole words inside the row
-    uint32_t w;
-    DEV void begin(const uint8_t *row, bool aligned4, int n) { p = (g_cu8)row; al4 = aligned4; nfull = n & ~3; w = 0; }
-    DEV int get(int x)            // x ascending, every index exactly once
-    {
-        if (!al4 || x >= nfull) return p[x];
-        if (!(x & 3)) w = *(g_cu32)(p + x);
-        return (int)((w >> (8 * (x & 3))) & 0xFFu);
-    }
-};
 // sequential byte writer into a frame row: bytes are gathered into NW 32-bit words and leave as ONE
-// 4*NW-byte store per lane (rows aligned to 4*NW bytes; a lane's stores of a sweep then cover
-// whole 16 / 8-byte pieces of its row instead of four times as many 4-byte ones)
+// 4*NW-byte store per lane (rows aligned to 4*NW bytes)
 template <int NW>
 struct RowWriter {
+    typedef uint32_t vec __attribute__((ext_vector_type(NW)));
+    typedef __attribute__((address_space(1))) vec *g_vec;
     g_u8 p;
     bool al, on;
-    uint32_t acc, w0, w1, w2;     // finished words of the current group, oldest first
-    DEV void begin(uint8_t *row, bool aligned, bool enabled) { p = (g_u8)row; al = aligned; on = enabled; acc = w0 = w1 = w2 = 0; }
+    uint32_t acc, w[NW - 1];      // finished words of the current piece, oldest first
+    DEV void begin(uint8_t *row, bool aligned, bool enabled)
+    {
+        p = (g_u8)row; al = aligned; on = enabled; acc = 0;
+#pragma unroll
+        for (int i = 0; i < NW - 1; i++) w[i] = 0;
+    }
     DEV void put(int x, int v)    // x ascending, every index exactly once
     {
         if (!al) { if (on) p[x] = (uint8_t)v; return; }
         const uint32_t sh = 8u * (unsigned)(x & 3);
         acc = (x & 3) ? (acc | ((uint32_t)v << sh)) : (uint32_t)v;
         if ((x & 3) != 3) return;
-        const int wi = (x >> 2) & (NW - 1);
-        if (wi == NW - 1) {
-            if (on) {
-                if (NW == 4) { typedef uint32_t v4 __attribute__((ext_vector_type(4))); *(__attribute__((address_space(1))) v4 *)(p + (x & ~15)) = v4{w0, w1, w2, acc}; }
-                else { typedef uint32_t v2 __attribute__((ext_vector_type(2))); *(__attribute__((address_space(1))) v2 *)(p + (x & ~7)) = v2{w2, acc}; }
-            }
-        } else {
-            w0 = w1; w1 = w2; w2 = acc;           // NW == 2 keeps its one finished word in w2
+        if (((x >> 2) & (NW - 1)) != NW - 1) {          // word done, piece not
+#pragma unroll
+            for (int i = 0; i < NW - 2; i++) w[i] = w[i + 1];
+            w[NW - 2] = acc;
+            return;
         }
+        vec pc;
+#pragma unroll
+        for (int i = 0; i < NW - 1; i++) pc[i] = w[i];
+        pc[NW - 1] = acc;
+#ifdef F422_AB_NOSTORE    // timing-only A/B build (WRONG frames): the piece is folded into one word instead
+        { w[0] ^= pc[0] ^ pc[NW - 1]; if (x < 0 && on) p[0] = (uint8_t)w[0]; return; }
+#endif
+        if (on) *(g_vec)(p + (x & ~(4 * NW - 1))) = pc;
     }
-    DEV void finish(int n)        // n bytes were put: flush the words and bytes of an incomplete group
+    DEV void finish(int n)        // n bytes were put: flush what an incomplete piece holds
     {
         if (!al || !on) return;
-        const int g0 = n & ~(4 * NW - 1);                 // start of the incomplete group
-        const int nwords = (n - g0) >> 2;
-        for (int i = nwords; i < 3; i++) { w0 = w1; w1 = w2; }       // oldest finished word -> w0
-        if (nwords > 0) *(g_u32)(p + g0) = w0;
-        if (nwords > 1) *(g_u32)(p + g0 + 4) = w1;
-        if (nwords > 2) *(g_u32)(p + g0 + 8) = w2;
+        const int w0 = n & ~(4 * NW - 1);                // start of the incomplete piece
+        const int nwords = (n - w0) >> 2;
+        for (int i = nwords; i < NW - 1; i++) {
+#pragma unroll
+            for (int k = 0; k < NW - 2; k++) w[k] = w[k + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NW - 1; i++)
+            if (i < nwords) *(g_u32)(p + w0 + 4 * i) = w[i];
         for (int i = 0; i < (n & 3); i++) p[(n & ~3) + i] = (uint8_t)((acc >> (8 * i)) & 0xFFu);
     }
 };
+
+// A scratch plane read in blocks of 4*NWB samples: body(x, j, byte) for x = 0 .. N-1 with j = x mod
+// the block size a compile-time constant.  Whole blocks run without any bounds test; the ragged
+// last block is a second copy of the body.  The next block's words are requested before the
+// current block is worked on.
+template <int NWB, class F>
+DEV void sweep_blocks(const Plane422 &pl, int N, F body)
+{
+    constexpr int B = 4 * NWB;
+    const int nwords = (N + 3) >> 2;
+    uint32_t c[NWB], n[NWB];
+#pragma unroll
+    for (int i = 0; i < NWB; i++) c[i] = i < nwords ? pl.word(i) : 0u;
+    int x0 = 0;
+    for (; x0 + B <= N; x0 += B) {
+        const int q = (x0 >> 2) + NWB;
+#pragma unroll
+        for (int i = 0; i < NWB; i++) n[i] = q + i < nwords ? pl.word(q + i) : 0u;
+#pragma unroll
+        for (int j = 0; j < B; j++) body(x0 + j, j, (int)((c[j >> 2] >> (8 * (j & 3))) & 0xFFu));
+#pragma unroll
+        for (int i = 0; i < NWB; i++) c[i] = n[i];
+    }
+    if (x0 < N) {
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            if (x0 + j < N) body(x0 + j, j, (int)((c[j >> 2] >> (8 * (j & 3))) & 0xFFu));
+    }
+}
 
 // 16 luma / 8 chroma bytes of a frame row as words, zero past the row; one vector load when the
 // row is aligned and the block lies inside it
@@ -158,15 +187,26 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
 #pragma unroll
     for (int i = 0; i <= D - DU; i++) filU[i] = 128;
     int filV = 128;
-    // blocks of 8 chroma inputs c0 .. c0+7; the 16 luma bytes they modulate start at 2*(c0 - D): the
-    // upper part of the previous 16-byte luma block and the lower part of the current one.  The
-    // next block's bytes are requested before the current block is worked on.
-    uint32_t cu[2], cv[2], nu[2], nv[2], ly_prev[4] = {0, 0, 0, 0}, ly[4], nly[4];
-    load_block8(fu, 0, W2, al8, cu); load_block8(fv, 0, W2, al8, cv);
-    load_block16(fy, 0, W, al16, ly);
-    for (int c0 = 0; c0 < W2 + D; c0 += 8) {
-        load_block8(fu, c0 + 8, W2, al8, nu); load_block8(fv, c0 + 8, W2, al8, nv);
-        load_block16(fy, 2 * c0 + 16, W, al16, nly);
+    // Groups of 32 chroma inputs = 64 luma bytes = 4 blocks of 8 chroma inputs.  A group's 64 + 32 + 32
+    // frame bytes are requested together one group ahead (the pieces of one cache line back to back,
+    // so a line is fetched twice / four times per row instead of 8 / 16 times) and rotate through
+    // the "current block" registers.  Block c0 .. c0+7 modulates the 16 luma bytes from 2*(c0 - D):
+    // the upper part of the previous luma block and the lower part of the current one.
+    uint32_t gy[4][4], gu[4][2], gv[4][2], ny[4][4], nu[4][2], nv[4][2], ly_prev[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        load_block16(fy, 16 * b, W, al16, gy[b]);
+        load_block8(fu, 8 * b, W2, al8, gu[b]); load_block8(fv, 8 * b, W2, al8, gv[b]);
+    }
+    for (int g0 = 0; g0 < W2 + D; g0 += 32) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+          load_block16(fy, 2 * g0 + 64 + 16 * b, W, al16, ny[b]);
+          load_block8(fu, g0 + 32 + 8 * b, W2, al8, nu[b]); load_block8(fv, g0 + 32 + 8 * b, W2, al8, nv[b]);
+      }
+#pragma unroll 1
+      for (int c0 = g0; c0 < g0 + 32 && c0 < W2 + D; c0 += 8) {
+        uint32_t (&ly)[4] = gy[0], (&cu)[2] = gu[0], (&cv)[2] = gv[0];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int c = c0 + j;
@@ -209,9 +249,23 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
                 oy.put(x, yv);
             }
         }
+        // next block of the group becomes the current one
 #pragma unroll
-        for (int q = 0; q < 4; q++) { ly_prev[q] = ly[q]; ly[q] = nly[q]; }
-        cu[0] = nu[0]; cu[1] = nu[1]; cv[0] = nv[0]; cv[1] = nv[1];
+        for (int q = 0; q < 4; q++) ly_prev[q] = gy[0][q];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) gy[b][q] = gy[b + 1][q];
+            gu[b][0] = gu[b + 1][0]; gu[b][1] = gu[b + 1][1];
+            gv[b][0] = gv[b + 1][0]; gv[b][1] = gv[b + 1][1];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) gy[b][q] = ny[b][q];
+          gu[b][0] = nu[b][0]; gu[b][1] = nu[b][1]; gv[b][0] = nv[b][0]; gv[b][1] = nv[b][1];
+      }
     }
     oy.finish(W);
 }
@@ -250,11 +304,11 @@ struct FrameSink {
     double a_tv;
     int u1, u2, u3, u4, v1, v2, v3, v4;   // the last 4 inputs, 1 = newest (row tails); named, not an
                                           // array: a dynamically indexed array would live in scratch
-    DEV void begin(const DevParams &P, uint8_t *fy, uint8_t *fu, uint8_t *fv, bool is_out, bool dropped,
+    DEV void begin(const DevParams &P, int out_lp, uint8_t *fy, uint8_t *fu, uint8_t *fv, bool is_out, bool dropped,
                    double a_hp_i, double a_hp_q, int W)
     {
         wy.begin(fy, P.src_al16 != 0, is_out); wu.begin(fu, P.dst_al16 != 0, is_out); wv.begin(fv, P.dst_al16 != 0, is_out);
-        drop = dropped; mode = P.out_lp; W2 = W / 2;
+        drop = dropped; mode = out_lp; W2 = W / 2;
         dU = mode == 2 ? 2 : (mode == 1 ? 1 : 0);
         dV = mode == 2 ? (P.ntsc ? 4 : 2) : (mode == 1 ? 1 : 0);
         fU.begin(P.a_in_i, a_hp_i);
@@ -304,7 +358,7 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
     int ch_even = 0;
     Packer422 oy, ou, ov;
     if (!SINK) { oy.begin(R.Y); ou.begin(R.U); ov.begin(R.V); }
-    SWEEP_BEGIN(R.Y, W + 2)
+    sweep_blocks<4>(R.Y, W + 2, [&](int x, int, int in) {
         const int c_in = x < W ? in : (x == W ? oob0 : oob1);   // Y[r]; r >= W: the caller's bytes (:496)
         if (x == 0) { d2 = (unsigned)c_in; sum = 32 + d2; }
         else if (x == 1) { d3 = (unsigned)c_in; sum += d3; }
@@ -330,7 +384,7 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
                 else { ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
             }
         }
-    SWEEP_END
+    });
     if (!SINK) { oy.finish(W); ou.finish(W2); ov.finish(W2); }
     else sink.finish(W);
 }
@@ -338,10 +392,12 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
 // ---------------------------------------------------------------------------------- sweep B2
 // VHS chroma low-pass :834-855 (output lands d samples back, the last d keep their input) ->
 // vertical blend :862-882 -> chroma sharpen :904-924 -> modulate onto the luma in R.Y :926-928.
+// DS: the chroma delay as a constant (4 = SP tape speed), 0 = read it from P
+template <int DS>
 DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k, double a_sh_c, double sharpen_c)
 {
     const int W2 = W / 2;
-    const int d = P.cdelay;
+    const int d = DS ? DS : P.cdelay;
     const bool blend = P.vblend && P.ntsc;
     Casc3<double> lU, lV, sU, sV;
     lU.reset(128, P.a_vc); lV.reset(128, P.a_vc); sU.reset(128, a_sh_c); sV.reset(128, a_sh_c);
@@ -396,7 +452,14 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 
 } // namespace fused422
 
-__global__ __launch_bounds__(64) void k422_fused(DevParams P, GeomDev G,
+// SPEC: the switch set of the '-vhs' preset (NTSC, SP tape speed, no pre-emphasis, luma / chroma /
+// phase noise on, lite output low-pass) as compile-time constants -- the sweeps then carry no state of branches
+// the preset never takes.  Same arithmetic; every other switch set runs the SPEC = false kernel.
+#ifndef F422_WAVES
+#define F422_WAVES 1
+#endif
+template <bool SPEC>
+__global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDev G,
                                                  const Field422Dev *__restrict__ fields,
                                                  Scratch422 Sc,
                                                  const uint32_t *__restrict__ rs_luma,
@@ -441,12 +504,15 @@ __global__ __launch_bounds__(64) void k422_fused(DevParams P, GeomDev G,
     // ---- A: frame row -> composite bytes
     {
         LumaPost422 lp_;
-        lp_.pre_on = P.pre_on != 0; lp_.noise_on = P.noise_k != 0;
+        lp_.pre_on = SPEC ? false : P.pre_on != 0; lp_.noise_on = SPEC ? true : P.noise_k != 0;
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
-        if (P.ntsc) sweep_a<true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        if (SPEC || P.ntsc) sweep_a<true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
         else sweep_a<false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
     }
+#if defined(F422_AB_STOP) && F422_AB_STOP <= 1      // timing-only A/B builds (WRONG frames): stop after a sweep
+    return;
+#endif
     // ---- head switching :669-732 (displaced copy, fill value 16)
     if (P.hs) {
         const int hs = hs_shift[rc];
@@ -472,10 +538,13 @@ __global__ __launch_bounds__(64) void k422_fused(DevParams P, GeomDev G,
             o.finish(W);
         }
     }
+#if defined(F422_AB_STOP) && F422_AB_STOP <= 2
+    return;
+#endif
     // ---- B1: Y/C separation + chroma noise + phase noise | VHS luma low-pass + sharpen
     {
         ChromaPost422 cp_;
-        cp_.noise_on = P.cnoise_k != 0; cp_.phase_on = P.pnoise_k != 0;
+        cp_.noise_on = SPEC ? true : P.cnoise_k != 0; cp_.phase_on = SPEC ? true : P.pnoise_k != 0;
         cp_.nU = cp_.nV = 0; cp_.cosv = 1; cp_.sinv = 0; cp_.ring = ring; cp_.lane = lane;
         if (cp_.noise_on) { cp_.rng.init(ring, rs_chroma + rc, P.Rpad, lane); cp_.nU = n0_u[rc]; cp_.nV = n0_v[rc]; }
         if (cp_.phase_on) {
@@ -488,12 +557,18 @@ __global__ __launch_bounds__(64) void k422_fused(DevParams P, GeomDev G,
         FrameSink none;
         demod<false>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, lv, none);
     }
+#if defined(F422_AB_STOP) && F422_AB_STOP <= 3
+    return;
+#endif
     // ---- B2: VHS chroma low-pass + blend + sharpen | re-modulate
-    sweep_b2(P, R, W, xi, k, a_sh_c, sharpen_c);
+    sweep_b2<SPEC ? 4 : 0>(P, R, W, xi, k, a_sh_c, sharpen_c);
+#if defined(F422_AB_STOP) && F422_AB_STOP <= 4
+    return;
+#endif
     // ---- B3: Y/C separation | dropout | output chroma low-pass -> frame
     {
         FrameSink sink;
-        sink.begin(P, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        sink.begin(P, SPEC ? 1 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
         ChromaPost422 nocp;
         LumaVhs nolv;
         demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);

@@ -907,8 +907,15 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     // four-sweep form (ntsc422_fused.hip) for the VHS family of option sets, twelve-sweep form otherwise
     const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
                        !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
-    if (fused)
-        hipLaunchKernelGGL(k422_fused, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
+    // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
+    const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 1 &&
+                      D.cdelay == 4;
+    if (fused && spec)
+        hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
+                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    else if (fused)
+        hipLaunchKernelGGL(k422_fused<false>, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
                            c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                            c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
     else

@@ -202,9 +202,10 @@ class FieldSimulator:
         return descs
 
     # ---- 8-bit YUV422P sibling (ffmpeg_to_composite) ---------------------------------------
-    def fields422(self, jobs, width, height, stream=None):
+    def build_descs422(self, jobs):
         """jobs: list of dicts with keys dst (3 CUDA uint8 tensors [H, ls]), optional src (3
-        tensors) + src_height, optional flt (3 tensors), field, fieldno, flags, rng_pos."""
+        tensors) + src_height, optional flt (3 tensors), field, fieldno, flags, rng_pos.
+        Returns the ntscsim_field422_desc array (reusable: run_descs422)."""
         arr = (Field422Desc * len(jobs))()
         for d, j in zip(arr, jobs):
             for k in range(3):
@@ -221,11 +222,18 @@ class FieldSimulator:
             d.flags = j.get("flags", 0)
             d.fieldno = j["fieldno"]
             d.rng_pos = RNG_AUTO if j.get("rng_pos") is None else int(j["rng_pos"])
+        return arr
+
+    def run_descs422(self, arr, width, height, stream=None):
         if stream is None:
             stream = self._torch_stream()
-        rc = self._lib.ntscsim_fields422_device(self._h, arr, len(jobs), int(width), int(height),
+        rc = self._lib.ntscsim_fields422_device(self._h, arr, len(arr), int(width), int(height),
                                                 C.c_void_p(stream))
         self._chk(rc, "ntscsim_fields422_device")
+
+    def fields422(self, jobs, width, height, stream=None):
+        """build_descs422 + run_descs422."""
+        self.run_descs422(self.build_descs422(jobs), width, height, stream)
 
     def output422(self, jobs, width, height, stream=None):
         """jobs: list of dicts {frame: 3 CUDA uint8 tensors, bob: 3 tensors, field, mode}."""

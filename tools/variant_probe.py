@@ -26,5 +26,5 @@ print("variant 720x486 -vhs: %.2f ms per 600 fields, %.0f fields/s" % (dt * 1e3,
 o = L.TocompOracleStream(p, L.OOB_DEFINED)
 fr = base.copy()
 t0 = time.perf_counter()
-for k in range(20): o.process(fr, (k & 1) ^ 1, k)
+for k in range(2): o.process(fr, (k & 1) ^ 1, k)
 print("oracle: %.2f ms/field" % ((time.perf_counter() - t0) / 20 * 1e3))
