@@ -289,6 +289,40 @@ def test_hip_reproduces_reference_golden(m):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["-vhs"], ["-vhs", "-vhs-speed", "ep"], ["-tvstd", "pal", "-vhs"], ["-vhs", "-comp-catv"],
+                                   ["-vhs", "-out-composite-lowpass-lite", "0"], ["-vhs", "-noise", "0"]],
+                         ids=["vhs", "vhs-ep", "pal-vhs", "vhs-catv", "vhs-fulllp", "vhs-nonoise"])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["default", "twelve-sweep", "general-fused"])
+def test_every_variant_kernel_form_agrees_with_the_oracle(flags, mode):
+    """The three kernel forms of the -vhs family (k422_fused<true> for the preset's own switch set,
+    k422_fused<false>, k422_process) on the same fields: each must equal the oracle.  mode = the
+    ntscsim_debug_no_fast_decode() bits (1: twelve-sweep form, 2: no preset instantiation)."""
+    import torch
+    w, h, n = 128, 38, 4
+    p = L.make_params_tocomp(flags)
+    srcs = [cases422.make_source422("noise" if j else "bars", w, h, j + 9, 0) for j in range(n // 2)]
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    frame = srcs[0].copy()
+    mask = last_row_margin_mask(frame, 0)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.debug_no_fast_decode(mode)
+    whole, dev = to_dev_onebuf(torch, frame)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        refresh(frame, srcs[k // 2], field)
+        o.process(frame, field, k)
+        _, srcd = to_dev_onebuf(torch, srcs[k // 2])
+        sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
+        sim.sync()
+        got = whole.cpu().numpy()
+        bad = (got != frame.buf) & mask
+        assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
+        frame.buf[~mask] = got[~mask]
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
 def test_hip_batch_of_fields_full_size():
     """720x480 -vhs, 8 fields in ONE batch (each field its own frame), explicit rand() positions."""
     import torch
