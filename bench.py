@@ -196,6 +196,169 @@ def device_rate(torch, ntscsim, dev, local_rank, flags, w, h, n_frames, reps, in
     return len(jobs) / dt
 
 
+def variant_contexts(torch, ntscsim, dev, local_rank, args, nq):
+    """The 8-bit YUV422P tool (ffmpeg_to_composite): nq contexts, each with 2 x frames colour-bars
+    YUV422P frames resident in HBM (every field its own frame, processed in place), its descriptor
+    array and its stream.  Returns (simulators, step(i), frames of context 0)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs as L
+    w, h = args.width, args.height
+    p422 = ntscsim.make_params_to_composite(args.preset.split())
+    lib = ntscsim.lib()
+    base = L.yuv_bars(w, h, 0, pad=16)
+    nf = 2 * args.frames
+    sims, arrs, streams, frames = [], [], [], []
+    for q in range(nq):
+        sm = ntscsim.FieldSimulator(params=p422, device=local_rank)
+        fr = [[torch.from_numpy(base.plane(i).copy()).to(dev) for i in range(3)] for _ in range(nf)]
+        jobs, pos = [], 0
+        for k in range(nf):
+            field = (k & 1) ^ 1
+            jobs.append({"dst": fr[k], "field": field, "fieldno": k, "rng_pos": pos})
+            pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p422), w, h, field)
+        sims.append(sm); arrs.append(sm.build_descs422(jobs)); frames.append(fr)
+        streams.append(torch.cuda.Stream(dev))
+
+    def vstep(i):
+        q = i % nq
+        sims[q].run_descs422(arrs[q], w, h, stream=streams[q].cuda_stream)
+    vstep.keep = (arrs, frames, streams)
+    return sims, vstep, frames[0]
+
+
+def main_to_composite(args):
+    """bench.py --tool to_composite: the same contract for the YUV422P sibling tool
+    (ffmpeg_to_composite.cpp:629-952 composite_video_process, one call per field)."""
+    import numpy as np
+    import torch
+    import ntscsim
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    w, h = args.width, args.height
+    nf = 2 * args.frames
+    nq = max(1, args.inflight)
+    sims, vstep, frames0 = variant_contexts(torch, ntscsim, dev, local_rank, args, nq)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for i in range(args.warmup):
+        vstep(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        vstep(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_s, t1 = 0, time.perf_counter()
+        while True:
+            for i in range(4 * nq):
+                vstep(n_s + i)
+            n_s += 4 * nq
+            torch.cuda.synchronize(dev)
+            if time.perf_counter() - t1 >= args.sustain_seconds:
+                break
+        sustained = (n_s, time.perf_counter() - t1)
+    # kernel time: hipEvents around the kernels of un-shared launches on one context
+    sims[0].set_profiling(True)
+    for _ in range(5):
+        vstep(0)
+    torch.cuda.synchronize(dev)
+    tm = sims[0].timings_ms()
+    sims[0].set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        import ctypes as C
+        import _libs as L
+        calls = max(1, tm["calls"])
+        k_ms, set_ms = tm["decode"] / calls, tm["setup"] / calls
+        rows = (ntscsim.field_rows(h, 0) + ntscsim.field_rows(h, 1)) / 2.0
+        alg = 4.0 * w * rows * nf            # 2 B/pixel read + 2 B/pixel written, rows of the field
+        value = world * nf * args.steps / elapsed
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj.get("%dx%d %s to_composite" % (w, h, args.preset), {}).get("k422_hbm_bytes_per_launch")
+        except Exception:
+            pass
+        out = {
+            "metric": "frames/sec (ffmpeg_to_composite: output frames = fields; 720x486 YUV422P, full VHS preset)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%d YUV422P colour-bars frames, preset '%s': %d fields per GPU per step, every "
+                                   "field its own frame, processed in place (composite_video_process per field)"
+                                   % (w, h, args.preset, nf),
+                       "tool": "to_composite", "steps_in_flight": nq},
+            "roofline": {"bound": "hbm", "kernel": "k422_fused", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
+                         "kernel_ms_all": {"setup": set_ms, "process": k_ms},
+                         "note": "4*W*L algorithmic bytes per field; like the BGRA tool the kernel is bound by "
+                                 "dependent fp64 filter chains, not by HBM (DESIGN.md section 7)"},
+        }
+        if sustained is not None:
+            out["value_sustained"] = world * nf * sustained[0] / sustained[1]
+        if args.cpu_fields > 0:
+            p422 = ntscsim.make_params_to_composite(args.preset.split())
+            ncpu = min(args.cpu_fields, nf)
+            have_ref = L.have_tocomp_ref()
+            # parity spot check: 4 fresh fields through HIP and through the CPU engine
+            o = L.TocompOracleStream(p422, L.OOB_MEMORY)
+            sm = ntscsim.FieldSimulator(params=p422, device=local_rank)
+            ok = 0
+            for k in range(4):
+                fr = L.yuv_bars(w, h, k, pad=16)
+                d = [torch.from_numpy(fr.plane(i).copy()).to(dev) for i in range(3)]
+                sm.fields422([{"dst": d, "field": (k & 1) ^ 1, "fieldno": k}], w, h)
+                sm.sync()
+                o.process(fr, (k & 1) ^ 1, k)
+                for i in range(3):
+                    # (the frame's last row reads past the plane in the reference: excluded, DESIGN.md 7)
+                    if not np.array_equal(d[i].cpu().numpy()[:h - 1, :fr.pix(i).shape[1]], fr.pix(i)[:h - 1]):
+                        raise AssertionError("bench: HIP output of field %d differs from the oracle" % k)
+                ok += 1
+            sm.close()
+            eng = L.TocompRefStream(p422) if have_ref else L.TocompOracleStream(p422, L.OOB_MEMORY)
+            fr = L.yuv_bars(w, h, 0, pad=16)
+            t0 = time.perf_counter()
+            for k in range(ncpu):
+                eng.process(fr, (k & 1) ^ 1, k)
+            cpu_fps = ncpu / (time.perf_counter() - t0)
+            out["cpu_baseline"] = {"value": cpu_fps, "unit": "frames/s", "cores": 1,
+                                   "kind": "reference" if have_ref else "port",
+                                   "sample": "%d fields of one 720x486 frame processed in place, single thread; %s; "
+                                             "%d fresh fields compared byte-for-byte with the HIP output first"
+                                             % (ncpu, "composite_video_process() of the reference (oracle/_ref)"
+                                                if have_ref else "oracle/tocomp_oracle.c", ok)}
+            out["speedup_vs_cpu_1core"] = value / cpu_fps
+        print(json.dumps(out), flush=True)
+    for sm in sims:
+        sm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def extras(torch, ntscsim, dev, local_rank, args):
     """The numbers README / DESIGN quote beside the headline value (N = 1, rank 0)."""
     import ctypes as C
@@ -237,25 +400,9 @@ def extras(torch, ntscsim, dev, local_rank, args):
     out["end_to_end"] = e2e
     del src_pin, dst_pin, yuv_pin, src_pg, dst_pg
     # ---- the 8-bit YUV422P tool (ffmpeg_to_composite), 600 fields, every field its own frame
-    p422 = ntscsim.make_params_to_composite(args.preset.split())
-    lib = ntscsim.lib()
-    base = L.yuv_bars(w, h, 0, pad=16)
     nf = 2 * args.frames
     nq = max(1, args.inflight)
-    sims, arrs, streams, frames = [], [], [], []
-    for q in range(nq):
-        sm = ntscsim.FieldSimulator(params=p422, device=local_rank)
-        fr = [[torch.from_numpy(base.plane(i).copy()).to(dev) for i in range(3)] for _ in range(nf)]
-        jobs, pos = [], 0
-        for k in range(nf):
-            field = (k & 1) ^ 1
-            jobs.append({"dst": fr[k], "field": field, "fieldno": k, "rng_pos": pos})
-            pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p422), w, h, field)
-        sims.append(sm); arrs.append(sm.build_descs422(jobs)); frames.append(fr)
-        streams.append(torch.cuda.Stream(dev))
-    def vstep(i):
-        q = i % nq
-        sims[q].run_descs422(arrs[q], w, h, stream=streams[q].cuda_stream)
+    sims, vstep, _ = variant_contexts(torch, ntscsim, dev, local_rank, args, nq)
     for i in range(nq):
         vstep(i)
     dt = time_steps(torch, dev, vstep, 5 * nq)
@@ -264,7 +411,6 @@ def extras(torch, ntscsim, dev, local_rank, args):
     out["variant422"] = {"value": nf / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                          "workload": "%dx%d YUV422P, preset '%s', %d fields per step (every field its own frame, "
                                      "processed in place), %d steps in flight" % (w, h, args.preset, nf, nq)}
-    del frames
     # ---- other sizes / presets on the BGRA path
     out["sizes"] = {
         "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 60, 6),
@@ -327,6 +473,9 @@ def main():
                          "one 300-frame clip is dealt over the ranks")
     ap.add_argument("--streams", type=int, default=0,
                     help="BASELINE configs[3]: this many independent clips, stream s on rank s %% N")
+    ap.add_argument("--tool", default="ntsc", choices=["ntsc", "to_composite"],
+                    help="ntsc = ffmpeg_ntsc's composite_layer on BGRA (BASELINE's metric, default); "
+                         "to_composite = the 8-bit YUV422P sibling (ffmpeg_to_composite)")
     ap.add_argument("--mode", default="exact", choices=["exact", "fast32"],
                     help="exact = bit-identical to the reference (fp64, default); fast32 = fp32 "
                          "filters within the tolerance of tests/test_gpu_fast_mode.py")
@@ -346,6 +495,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker(args)
+    if args.tool == "to_composite":
+        return main_to_composite(args)
 
     import torch
     import ntscsim

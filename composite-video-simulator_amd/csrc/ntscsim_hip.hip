@@ -90,8 +90,6 @@ struct ntscsim_ctx {
     DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, comp_ghost, comp_vcr, tails;
     DevBuf<Field422Dev> fields422;
     DevBuf<uint32_t> scratch422;
-    std::vector<FieldDev> host_fields;
-    std::vector<Field422Dev> host_fields422;
     std::vector<Out422Dev> host_out422;
     DevBuf<Out422Dev> out422;
     std::vector<YuvDev> host_yuv;
@@ -104,6 +102,12 @@ struct ntscsim_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
     int stage_idx = 0;
+    // same for the YUV422P tool: n FieldDev records followed by n Field422Dev records
+    unsigned char *stage422[2] = {nullptr, nullptr};
+    size_t stage422_cap[2] = {0, 0};
+    hipEvent_t stage422_ev[2] = {nullptr, nullptr};
+    bool stage422_used[2] = {false, false};
+    int stage422_idx = 0;
 
     // last batch (debug tap)
     int last_n = 0, last_W = 0, last_H = 0, last_Rpad = 0, last_Lslot = 0;
@@ -334,6 +338,7 @@ extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx *
         return NTSCSIM_E_HIP;
     }
     for (int i = 0; i < 2; i++) (void)hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 2; i++) (void)hipEventCreateWithFlags(&c->stage422_ev[i], hipEventDisableTiming);
     *out = c;
     return NTSCSIM_OK;
 }
@@ -363,6 +368,8 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
+        if (c->stage422[i]) (void)hipHostFree(c->stage422[i]);
+        if (c->stage422_ev[i]) (void)hipEventDestroy(c->stage422_ev[i]);
     }
     for (auto &s : c->ev_live) for (int i = 0; i < 5; i++) (void)hipEventDestroy(s.e[i]);
     for (auto &s : c->ev_free) for (int i = 0; i < 5; i++) (void)hipEventDestroy(s.e[i]);
@@ -809,15 +816,27 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     if (rc != NTSCSIM_OK) return rc;
     if (D.pnoise_k) { rc = build_ptab(c); if (rc != NTSCSIM_OK) return rc; }
 
-    c->host_fields.resize((size_t)n);
-    c->host_fields422.resize((size_t)n);
+    // pinned staging for the records, double-buffered against the asynchronous upload
+    const int si = c->stage422_idx;
+    c->stage422_idx ^= 1;
+    if (c->stage422_used[si]) HIPCHK(c, hipEventSynchronize(c->stage422_ev[si]));
+    const size_t rec_bytes = sizeof(FieldDev) + sizeof(Field422Dev);
+    if (c->stage422_cap[si] < (size_t)n) {
+        if (c->stage422[si]) (void)hipHostFree(c->stage422[si]);
+        c->stage422[si] = nullptr; c->stage422_cap[si] = 0;
+        const size_t want = (size_t)n + (size_t)n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->stage422[si], want * rec_bytes, hipHostMallocDefault));
+        c->stage422_cap[si] = want;
+    }
+    FieldDev *const host_fields = (FieldDev *)c->stage422[si];
+    Field422Dev *const host_fields422 = (Field422Dev *)(c->stage422[si] + (size_t)n * sizeof(FieldDev));
     uint64_t pos = c->rng_pos;
     bool any_render = false, any_flt = false;
     bool al_y16 = true, al_c8 = true;      // vector copies between frame rows and scratch words
     for (int i = 0; i < n; i++) {
         const ntscsim_field422_desc &d = descs[i];
         if (d.field > 1) return NTSCSIM_E_ARG;
-        Field422Dev &o = c->host_fields422[(size_t)i];
+        Field422Dev &o = host_fields422[(size_t)i];
         std::memset(&o, 0, sizeof(o));
         for (int k = 0; k < 3; k++) {
             if (!d.dst_dev[k]) return NTSCSIM_E_ARG;
@@ -845,7 +864,7 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         o.src_height = d.src_height;
         o.field = d.field; o.flags = d.flags; o.fieldno = d.fieldno;
         if (d.rng_pos != NTSCSIM_RNG_AUTO) pos = d.rng_pos;
-        FieldDev &fo = c->host_fields[(size_t)i];
+        FieldDev &fo = host_fields[(size_t)i];
         std::memset(&fo, 0, sizeof(fo));
         fo.field = d.field; fo.fieldno = d.fieldno;
         const RandState s = ctx_state_at(c, pos);
@@ -853,7 +872,6 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         for (int j = 31; j < 61; j++) fo.rng[j] = fo.rng[j - 31] + fo.rng[j - 3];
         if (!(d.flags & NTSCSIM_422_NOCOMP)) pos += c->geom_cur->calls[d.field & 1];
     }
-    c->rng_pos = pos;
     D.src_al16 = al_y16;      // (422 path: luma rows 16-byte aligned)
     D.dst_al16 = al_c8;       // (422 path: chroma rows 8-byte aligned)
 
@@ -873,12 +891,18 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         HIPCHK(c, c->n0_u.ensure((size_t)D.Rpad));
         HIPCHK(c, c->n0_v.ensure((size_t)D.Rpad));
     }
-    // (pageable host staging: the copies below are synchronous with respect to the host buffers)
-    HIPCHK(c, hipMemcpyAsync(c->fields.p, c->host_fields.data(), (size_t)n * sizeof(FieldDev),
+    ntscsim_ctx::EvSet evs;
+    const bool prof = c->profiling;
+    if (prof) {
+        rc = take_events(c, evs);
+        if (rc != NTSCSIM_OK) return rc;
+        HIPCHK(c, hipEventRecord(evs.e[0], st));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->fields.p, host_fields, (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->fields422.p, host_fields422, (size_t)n * sizeof(Field422Dev),
                              hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->fields422.p, c->host_fields422.data(), (size_t)n * sizeof(Field422Dev),
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipEventRecord(c->stage422_ev[si], st));
+    c->stage422_used[si] = true;
 
     GeomDev G;
     G.lskip = c->geom_cur->lskip.p; G.pskip = c->geom_cur->pskip.p; G.jrow = c->geom_cur->jrow.p;
@@ -904,6 +928,9 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
                            c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
+    // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
+    // empty, "decode" = the one kernel that does composite_video_process)
+    if (prof) { HIPCHK(c, hipEventRecord(evs.e[1], st)); HIPCHK(c, hipEventRecord(evs.e[2], st)); }
     // four-sweep form (ntsc422_fused.hip) for the VHS family of option sets, twelve-sweep form otherwise
     const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
                        !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
@@ -924,6 +951,12 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma,
                        p.video_yc_recombine, p.nocolor_subcarrier_after_yc_sep);
     HIPCHK(c, hipGetLastError());
+    if (prof) {
+        HIPCHK(c, hipEventRecord(evs.e[3], st));
+        HIPCHK(c, hipEventRecord(evs.e[4], st));
+        c->ev_live.push_back(evs);
+    }
+    c->rng_pos = pos;
     return NTSCSIM_OK;
 }
 

@@ -17,6 +17,7 @@ import sys
 
 tag, bench, kdef, kif1, pmc, rates, chain, census = sys.argv[1:9]
 fast = sys.argv[9] if len(sys.argv) > 9 else None
+tocomp = sys.argv[10:13] if len(sys.argv) > 12 else None      # bench json, kstats dir, pmc dir of the YUV422P tool
 P = "profiles"
 os.makedirs(P, exist_ok=True)
 shutil.copy(os.path.join(kdef, "kernel_stats.csv"), "%s/%s_kernel_stats_default_cmd.csv" % (P, tag))
@@ -89,6 +90,27 @@ traffic = {"720x486 -vhs": {
             "correction of FETCH_SIZE on gfx950 -- the raw figure is kept here and the encoder's fetch "
             "is therefore a lower bound" % enc["WRITE_SIZE"],
 }}
+tc = None
+if tocomp and os.path.exists(tocomp[0]) and os.path.getsize(tocomp[0]) > 10:
+    shutil.copy(tocomp[0], "%s/%s_bench_to_composite.json" % (P, tag))
+    shutil.copy(os.path.join(tocomp[1], "kernel_stats.csv"), "%s/%s_kernel_stats_to_composite.csv" % (P, tag))
+    shutil.copy(os.path.join(tocomp[2], "summary.txt"), "%s/%s_pmc_summary_to_composite.txt" % (P, tag))
+    pm2, cur = {}, None
+    for l in open(os.path.join(tocomp[2], "summary.txt")):
+        if not l.startswith(" "):
+            cur = l.strip()
+        else:
+            pm2.setdefault(cur, {})[l.split()[0]] = float(l.split("mean=")[1])
+    k4 = pick(pm2, "k422_fused")
+    tc = {"bench": json.load(open(tocomp[0])), "pmc": k4,
+          "stats": stats("%s/%s_kernel_stats_to_composite.csv" % (P, tag))}
+    traffic["720x486 -vhs to_composite"] = {
+        "fields_per_launch": 600,
+        "k422_hbm_bytes_per_launch": (k4["FETCH_SIZE"] + k4["WRITE_SIZE"]) * 1024,
+        "k422_fetch_KiB": k4["FETCH_SIZE"], "k422_write_KiB": k4["WRITE_SIZE"],
+        "k422_wave_insts_per_launch": k4["SQ_INSTS_VALU"],
+        "note": "tools/pmc422.sh (tools/variant_probe.py: one 600-field launch per call); FETCH/WRITE include the "
+                "packed scratch planes the four sweeps hand to each other, which are larger than the caches"}
 json.dump(traffic, open("%s/traffic.json" % P, "w"), indent=1)
 
 v = d["roofline"].get("valu") or {}
@@ -103,6 +125,7 @@ rd += "| `%s_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--in
 rd += "| `%s_valu_rates.txt` | `tools/valu_rate_probe.hip` | issue cost of every opcode class the kernels use, 1-4 waves per SIMD with forced placement |\n" % tag
 rd += "| `%s_chain_probe.txt` | `tools/chain_probe.hip` | cost of dependent fp64 / int chains vs instruction-level parallelism |\n" % tag
 rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction census of each kernel's steady loop |\n" % tag
+rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_pmc_summary_to_composite.txt` | `python bench.py --tool to_composite`, `tools/kstats.sh ... --tool to_composite --inflight 1`, `tools/pmc422.sh` | the same three for the YUV422P tool |\n" % (tag, tag, tag)
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (
@@ -146,5 +169,18 @@ rd += ("* HBM (PMC): k_decode %.0f MB fetched + %.0f MB written, k_encode >= %.0
        "At %.2f ms per step that is ~%.1f TB/s of physical traffic against 6.3 TB/s achievable: the path is VALU-bound.\n" % (
            dec["FETCH_SIZE"] * 1024 / 1e6, dec["WRITE_SIZE"] * 1024 / 1e6, enc["FETCH_SIZE"] * 1024 / 1e6, enc["WRITE_SIZE"] * 1024 / 1e6,
            d["ms_per_step"], traffic["720x486 -vhs"]["path_hbm_bytes_per_launch_lower_bound"] / (d["ms_per_step"] * 1e-3) / 1e12))
+if tc:
+    b4 = tc["bench"]
+    ks = pick(tc["stats"], "k422_fused")
+    rd += ("\n## The YUV422P tool (`bench.py --tool to_composite`)\n\n"
+           "`%s_bench_to_composite.json`: value = %.0f frames/s (%.3f ms per 600-field step, %d steps in flight), value_sustained = %.0f; "
+           "`k422_fused<true>`: %.1f us by hipEvents, %.1f us rocprofv3 avg with one step at a time (`%s_kernel_stats_to_composite.csv`); "
+           "roofline.frac = %.3f of 8 TB/s on 4*W*L algorithmic bytes (%.0f MB per launch) against %.0f MB fetched + %.0f MB written "
+           "(`%s_pmc_summary_to_composite.txt`: the scratch planes between the sweeps); %.3g wave-instructions per launch.  "
+           "CPU beside it: %.1f frames/s (%s, 1 thread) => %.0fx.\n" % (
+               tag, b4["value"], b4["ms_per_step"], b4["config"]["steps_in_flight"], b4.get("value_sustained", 0),
+               b4["roofline"]["kernel_ms"] * 1e3, ks[1], tag, b4["roofline"]["frac"], b4["roofline"]["algorithmic_bytes_per_launch"] / 1e6,
+               tc["pmc"]["FETCH_SIZE"] * 1024 / 1e6, tc["pmc"]["WRITE_SIZE"] * 1024 / 1e6, tag, tc["pmc"]["SQ_INSTS_VALU"],
+               b4.get("cpu_baseline", {}).get("value", 0), b4.get("cpu_baseline", {}).get("kind", "-"), b4.get("speedup_vs_cpu_1core", 0)))
 open("%s/README.md" % P, "w").write(rd)
 print(rd)

@@ -15,7 +15,10 @@ if [ "$mode" = gpu ]; then
   timeout 120 tools/bin/chain_probe > gpurun_out/chain_probe_$tag.txt 2>&1
   timeout 500 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
   timeout 200 python bench.py --mode fast32 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_fast32.json 2>> gpurun_out/bench_$tag.err
-  tail -c 600 gpurun_out/bench_$tag.json
+  timeout 500 bash tools/pmc422.sh pmc422_$tag > /dev/null 2>&1
+  timeout 250 tools/kstats.sh ks_${tag}_tocomp --tool to_composite --inflight 1 --steps 20 --sustain-seconds 0 > /dev/null
+  timeout 300 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
+  tail -c 600 gpurun_out/bench_$tag.json; tail -c 400 gpurun_out/bench_${tag}_tocomp.json
 else
   S=composite-video-simulator_amd/csrc
   mkdir -p /tmp/census_$tag
@@ -26,5 +29,6 @@ else
   done
   python tools/make_profiles.py $tag gpurun_out/bench_$tag.json gpurun_out/ks_${tag}_default gpurun_out/ks_${tag}_if1 \
       gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
-      gpurun_out/bench_${tag}_fast32.json > /dev/null && echo "profiles/ assembled"
+      gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
+      gpurun_out/pmc422_$tag > /dev/null && echo "profiles/ assembled"
 fi
