@@ -10,7 +10,7 @@ mode=${1:-local}; tag=${2:-r02}
 if [ "$mode" = gpu ]; then
   timeout 700 bash tools/pmc.sh pmc_$tag > /dev/null 2>&1
   timeout 250 tools/kstats.sh ks_${tag}_if1 --inflight 1 --steps 20 --no-extras --sustain-seconds 0 > /dev/null
-  timeout 250 tools/kstats.sh ks_${tag}_default --steps 20 --no-extras --sustain-seconds 0 > /dev/null
+  timeout 250 tools/kstats.sh ks_${tag}_default --no-extras --sustain-seconds 0 > /dev/null
   timeout 120 tools/bin/valu_rate_probe > gpurun_out/valu_rates_$tag.txt 2>&1
   timeout 120 tools/bin/chain_probe > gpurun_out/chain_probe_$tag.txt 2>&1
   timeout 500 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
