@@ -400,6 +400,22 @@ def extras(torch, ntscsim, dev, local_rank, args):
                    "on three streams, chunks of 32 frames; pageable = the call pins the caller's buffers "
                    "in place first; yuv420p = the encoder's pixel format made on the GPU (1.5 B/pixel "
                    "back instead of 4)" % (n, 2 * n))
+    # ---- the ffmpeg_ntsc-compatible command line host (synthetic source, discarded output)
+    cli = os.path.join(ROOT, "composite-video-simulator_amd", "ntsc_cli")
+    if os.path.exists(cli) and (w, h) == (720, 486):
+        import re
+        import subprocess
+        best = 0.0
+        for _ in range(2):
+            pr = subprocess.run([cli] + args.preset.split() + ["-i", "bars:3000", "-o", "null:"],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
+            m = re.search(r"\(([0-9.]+) fields/s incl", pr.stderr.decode(errors="replace"))
+            if m:
+                best = max(best, float(m.group(1)))
+        e2e["cli"] = best
+        e2e["cli_note"] = ("ntsc_cli %s -i bars:3000 -o null: (6000 fields; the tool's own figure for its field loop: host frame "
+                           "synthesis, upload, kernels, download; one-off initialisation is outside its clock; best "
+                           "of 2 runs)" % args.preset)
     out["end_to_end"] = e2e
     del src_pin, dst_pin, yuv_pin, src_pg, dst_pg
     # ---- the 8-bit YUV422P tool (ffmpeg_to_composite), 600 fields, every field its own frame
