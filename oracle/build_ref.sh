@@ -47,3 +47,18 @@ src2="$ref/ffmpeg_to_composite.cpp"
     cat "$here/ref_tocomp_post.cpp"
 } | g++ -x c++ -O2 -w -ffp-contract=off -fPIC -shared -I"$here/../include" - -o "$here/_ref/libtocomp_ref.so"
 echo "built $here/_ref/libtocomp_ref.so"
+
+# ---- the raw-composite decoder, ffmpeg_raw28ntsc.cpp:
+# 74-108 LowpassFilter | 207-366 globals, rate/geometry, sample buffer (open/flush/refill/close_src),
+# RGBTRIPLET | 383-399 preset_PAL / preset_NTSC | 544-598 hsync_dc_proc | 600-849 composite_layer
+src3="$ref/ffmpeg_raw28ntsc.cpp"
+{
+    cat "$here/ref_raw28_pre.hpp"
+    sed -n '74,108p' "$src3"
+    sed -n '207,366p' "$src3"
+    sed -n '383,399p' "$src3"
+    sed -n '544,598p' "$src3"
+    sed -n '600,849p' "$src3"
+    cat "$here/ref_raw28_post.cpp"
+} | g++ -x c++ -O2 -w -ffp-contract=off -fPIC -shared - -o "$here/_ref/libraw28_ref.so"
+echo "built $here/_ref/libraw28_ref.so"
