@@ -1,0 +1,735 @@
+// raw28_decode.hip -- the raw-composite decoder of ffmpeg_raw28ntsc.cpp on gfx950 (SURVEY.md
+// section 8(f) row f4; C ABI in include/ntscsim.h: ntscsim_raw28_*).
+//
+// How the tool's three serial recurrences are run in parallel without changing a bit:
+//
+//  (1) hsync_dc_proc() :556-594 is one fp64 recurrence over the whole capture (three one-pole
+//      low-passes and an envelope follower with a data-dependent coefficient).  It is a contraction:
+//      at every sync pulse the follower is pulled to the sync tip with a 95-sample time constant,
+//      so two trajectories that start apart halve their distance every scanline or faster and
+//      become bit-identical after about a hundred.
+//      The capture is cut into chunks; chunk c starts `warm` scanlines early from a guessed state
+//      (follower at 255, i.e. above the truth) and records the state it reaches at its first own
+//      sample and at its end.  The result is exact iff every chunk started from its predecessor's
+//      end state -- which is CHECKED (bitwise) on the device; chunks that did not are recomputed
+//      from their predecessor's end state, round after round, until every link holds.  At the
+//      fixed point chunk 0 started from the tool's initial state and every later chunk from the
+//      true state before it: the whole stream is the serial result.  (Worst case = as many rounds
+//      as chunks, i.e. the serial algorithm.)
+//  (2) The sync search of composite_layer() :622-693, :789-830 walks runs of "below threshold"
+//      samples.  The runs are extracted on the GPU (count | scan | scatter); the walk itself is a
+//      few hundred scalar steps per field over that run list and stays on the host, together with
+//      the buffer-window arithmetic of :277-332 that bounds it.
+//  (3) The comb filter's work arrays are file-scope in the tool (:258-261): the last 16 chroma
+//      values of a scanline leak into the next one.  tail(y) = G(samples of y, tail(y-1)) is
+//      iterated for all scanlines in parallel from tail = 0 until nothing changes (the map forgets
+//      its input after a few lines: values are divided by 8 on the way through), again a checked
+//      fixed point.
+#include "ntscsim.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <class T>
+struct Buf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    ~Buf() { if (p) (void)hipFree(p); }
+};
+
+struct FrontState { double p0, p1, p2, level; };
+
+struct FrontConst {
+    double alpha, a_fast, om_fast, a_slow, om_slow;   // a, 1.0 - a of the two follower rates (:563-570)
+    int thr;
+};
+
+// one sample of hsync_dc_proc() :556-594 (the raw delay line is a pure index shift and lives in the
+// consumers: raw_delayed[s] = raw[s - D])
+__device__ __forceinline__ int front_step(FrontState &s, const FrontConst &K, double lv)
+{
+    lv = (lv * K.alpha) + (s.p0 - (s.p0 * K.alpha)); s.p0 = lv;        // LowpassFilter::lowpass :92-96
+    lv = (lv * K.alpha) + (s.p1 - (s.p1 * K.alpha)); s.p1 = lv;
+    lv = (lv * K.alpha) + (s.p2 - (s.p2 * K.alpha)); s.p2 = lv;
+    if (s.level > lv) s.level = (s.level * K.om_fast) + (lv * K.a_fast);
+    else s.level = (s.level * K.om_slow) + (lv * K.a_slow);
+    int x = (int)(lv - s.level);
+    x = x < 0 ? 0 : (x > 255 ? 255 : x);
+    return x;
+}
+
+// round 0 (speculative, all chunks) and repair rounds (flagged chunks, start = predecessor's end)
+__global__ __launch_bounds__(64) void k_raw28_front(const uint8_t *__restrict__ raw, size_t N, uint8_t *__restrict__ h,
+                                                    int chunk, int warm, int nchunks, FrontConst K, FrontState init,
+                                                    FrontState *__restrict__ st_begin, FrontState *__restrict__ st_end,
+                                                    const FrontState *__restrict__ prev_end, const int *__restrict__ flags)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= nchunks) return;
+    if (flags && !flags[c]) return;
+    const size_t s0 = (size_t)c * (size_t)chunk;
+    const size_t s1 = s0 + (size_t)chunk < N ? s0 + (size_t)chunk : N;
+    FrontState st;
+    if (flags) {
+        st = prev_end[c - 1];                      // repair: the true state before this chunk (so far)
+    } else if (s0 <= (size_t)warm) {
+        st = init;                                 // from the start of the stream: exact
+        for (size_t s = 0; s < s0; s++) (void)front_step(st, K, (double)raw[s]);
+    } else {
+        const size_t w0 = s0 - (size_t)warm;
+        const double r0 = (double)raw[w0];
+        st.p0 = st.p1 = st.p2 = r0; st.level = 255.0;
+        // (warm and chunk are multiples of 4: whole words)
+        const uint32_t *rw = (const uint32_t *)(raw + w0);
+        for (int q = 0; q < warm / 4; q++) {
+            const uint32_t w = rw[q];
+            (void)front_step(st, K, (double)(w & 0xFFu));
+            (void)front_step(st, K, (double)((w >> 8) & 0xFFu));
+            (void)front_step(st, K, (double)((w >> 16) & 0xFFu));
+            (void)front_step(st, K, (double)(w >> 24));
+        }
+    }
+    st_begin[c] = st;
+    const uint32_t *rw = (const uint32_t *)(raw + s0);
+    uint32_t *hw = (uint32_t *)(h + s0);
+    const int nfull = (int)((s1 - s0) / 4);
+    for (int q = 0; q < nfull; q++) {
+        const uint32_t w = rw[q];
+        uint32_t o = (uint32_t)front_step(st, K, (double)(w & 0xFFu));
+        o |= (uint32_t)front_step(st, K, (double)((w >> 8) & 0xFFu)) << 8;
+        o |= (uint32_t)front_step(st, K, (double)((w >> 16) & 0xFFu)) << 16;
+        o |= (uint32_t)front_step(st, K, (double)(w >> 24)) << 24;
+        hw[q] = o;
+    }
+    for (size_t s = s0 + (size_t)nfull * 4; s < s1; s++) h[s] = (uint8_t)front_step(st, K, (double)raw[s]);
+    st_end[c] = st;
+}
+
+__global__ void k_raw28_links(const FrontState *__restrict__ st_begin, const FrontState *__restrict__ st_end,
+                              int nchunks, int *__restrict__ flags, int *__restrict__ nbad)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    int bad = 0;
+    if (c > 0) {
+        const unsigned long long *a = (const unsigned long long *)&st_begin[c];
+        const unsigned long long *b = (const unsigned long long *)&st_end[c - 1];
+        bad = (a[0] != b[0]) | (a[1] != b[1]) | (a[2] != b[2]) | (a[3] != b[3]);
+    }
+    flags[c] = bad;
+    if (bad) atomicAdd(nbad, 1);
+}
+
+// ---- runs of h < thr: segment counts (starts in the low word, ends in the high word) | scan | scatter
+constexpr int SEG = 256;
+__device__ __forceinline__ bool below_at(const uint8_t *h, size_t s, size_t N, int thr) { return s < N && h[s] < thr; }
+
+__global__ void k_raw28_run_count(const uint8_t *__restrict__ h, size_t N, int thr, unsigned long long *__restrict__ cnt, size_t nseg)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseg) return;
+    const size_t s0 = g * SEG, s1 = s0 + SEG < N ? s0 + SEG : N;
+    bool prev = s0 > 0 && h[s0 - 1] < thr;
+    unsigned ns = 0, ne = 0;
+    for (size_t s = s0; s < s1; s++) {
+        const bool b = h[s] < thr;
+        ns += (b && !prev); ne += (!b && prev);
+        prev = b;
+    }
+    if (s1 == N && prev) ne++;                    // a run open at the end of the capture ends there
+    cnt[g] = (unsigned long long)ns | ((unsigned long long)ne << 32);
+}
+__global__ void k_raw28_run_scatter(const uint8_t *__restrict__ h, size_t N, int thr, const unsigned long long *__restrict__ off,
+                                    size_t nseg, uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend)
+{
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nseg) return;
+    const size_t s0 = g * SEG, s1 = s0 + SEG < N ? s0 + SEG : N;
+    bool prev = s0 > 0 && h[s0 - 1] < thr;
+    uint32_t os = (uint32_t)(off[g] & 0xFFFFFFFFull), oe = (uint32_t)(off[g] >> 32);
+    for (size_t s = s0; s < s1; s++) {
+        const bool b = h[s] < thr;
+        if (b && !prev) rstart[os++] = (uint32_t)s;
+        if (!b && prev) rend[oe++] = (uint32_t)s;
+        prev = b;
+    }
+    if (s1 == N && prev) rend[oe++] = (uint32_t)N;
+}
+
+// ---- calibration sums of the equalising pulses :661-676: one wave per range [si, i)
+struct CalRange { uint32_t si, i; };
+struct CalSums { int mina, mind, maxa, maxd; };
+__device__ __forceinline__ int raw_delayed(const uint8_t *raw, const uint8_t *h, size_t s, int D, int thr, int mark)
+{
+    if (mark && h[s] < thr) return 255;            // :590-591
+    return s >= (size_t)D ? raw[s - D] : 0;        // :572-581 (the delay line starts zero-filled)
+}
+__global__ __launch_bounds__(64) void k_raw28_cal(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h,
+                                                  const CalRange *__restrict__ rg, CalSums *__restrict__ out,
+                                                  int D, int thr, int mark)
+{
+    const CalRange r = rg[blockIdx.x];
+    int mina = 0, mind = 0, maxa = 0, maxd = 0;
+    for (size_t s = (size_t)r.si + threadIdx.x; s < (size_t)r.i; s += 64) {
+        const int v = raw_delayed(raw, h, s, D, thr, mark);
+        if (h[s] >= thr) { maxa += v; maxd++; } else { mina += v; mind++; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mina += __shfl_down(mina, o); mind += __shfl_down(mind, o);
+        maxa += __shfl_down(maxa, o); maxd += __shfl_down(maxd, o);
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = CalSums{mina, mind, maxa, maxd};
+}
+
+// ---- per scanline: equalisation :701-716, comb split :719-755, rendering :757-775
+struct LineRec {
+    uint32_t pos;          // first sample of the scanline (absolute)
+    int32_t field, row;    // destination frame and row
+    double blank, white;   // levels in force while the field is rendered
+};
+struct RenderConst {
+    int len, width, D, thr;
+    int mark, no_equ, no_wequ, no_sc, show_sc;
+};
+__device__ __forceinline__ int equalised(const uint8_t *raw, const uint8_t *h, size_t N, const LineRec &L,
+                                         const RenderConst &R, int x)
+{
+    const size_t s = (size_t)L.pos + (size_t)x;
+    int v = s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark) : 0;     // int16 luma = raw :702
+    if (!R.no_equ) {
+        v = (int)((double)v - L.blank);                                 // :708
+        if (!R.no_wequ) v = (int)((double)(v * 255) / (L.white - L.blank));   // :709
+        v = (int)(int16_t)v;                                            // :710 (int16 member)
+    }
+    return v;
+}
+
+// tail(y) from the last 32 positions of the scanline and tail(y-1): the 16 values the tool leaves in
+// int_chroma[len .. len+15] (:744-745 applied to int_chroma[len-16 .. len-1])
+__global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
+                              const LineRec *__restrict__ lines, int nlines, RenderConst R,
+                              const int *__restrict__ tin, int *__restrict__ tout, int *__restrict__ nchanged)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nlines) return;
+    const LineRec L = lines[y];
+    const int len = R.len;
+    int S[20], C[32];                              // S: positions len-16 .. len+3; C: len-16 .. len+15
+#pragma unroll
+    for (int k = 0; k < 20; k++) S[k] = equalised(raw, h, N, L, R, len - 16 + k);
+#pragma unroll
+    for (int k = 0; k < 16; k++) C[k] = S[k] - (S[k] + S[k + 4] + 1) / 2;     // :731-734
+#pragma unroll
+    for (int k = 0; k < 16; k++) C[16 + k] = y > 0 ? tin[(size_t)(y - 1) * 16 + k] : 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) C[k] = C[k] + C[k + 8] - C[k + 4] - C[k + 12];   // :736-737 (ascending, in place)
+#pragma unroll
+    for (int it = 0; it < 4; it++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) C[k] -= (C[k] + C[k + 4]) / 2;                // :739-742
+    int ch = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int v = C[k] / 4;                                                    // :744-745
+        ch |= (tin[(size_t)y * 16 + k] != v);      // against this scanline's value of the previous round
+        tout[(size_t)y * 16 + k] = v;
+    }
+    if (ch) atomicAdd(nchanged, 1);
+}
+
+__global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
+                                                      const LineRec *__restrict__ lines, RenderConst R,
+                                                      const int *__restrict__ tails, uint8_t *__restrict__ frames,
+                                                      size_t frame_stride, int linesize)
+{
+    extern __shared__ int lds[];
+    const int len = R.len, n = len + 16;
+    int *S = lds, *A = lds + n, *B2 = lds + 2 * n;
+    const int y = blockIdx.x;
+    const LineRec L = lines[y];
+    for (int x = threadIdx.x; x < n; x += 256) S[x] = equalised(raw, h, N, L, R, x);
+    __syncthreads();
+    uint32_t *dst = (uint32_t *)(frames + (size_t)L.field * frame_stride + (size_t)L.row * (size_t)linesize);
+    if (R.no_sc) {
+        for (int x = threadIdx.x; x < R.width; x += 256) {
+            int Y = R.show_sc ? 128 : S[x];        // chroma stays 0 (:703)
+            Y = Y < 0 ? 0 : (Y > 255 ? 255 : Y);
+            dst[x] = (uint32_t)Y * 0x010101u;
+        }
+        return;
+    }
+    for (int x = threadIdx.x; x < n; x += 256)
+        A[x] = x < len ? S[x] - (S[x] + S[x + 4] + 1) / 2 : (y > 0 ? tails[(size_t)(y - 1) * 16 + (x - len)] : 0);
+    __syncthreads();
+    for (int x = threadIdx.x; x < n; x += 256) B2[x] = x < len ? A[x] + A[x + 8] - A[x + 4] - A[x + 12] : A[x];
+    __syncthreads();
+    int *in = B2, *out = A;
+    for (int it = 0; it < 4; it++) {
+        for (int x = threadIdx.x; x < n; x += 256) out[x] = x < len ? in[x] - (in[x] + in[x + 4]) / 2 : in[x];
+        __syncthreads();
+        int *t = in; in = out; out = t;
+    }
+    // `in` = int_chroma before the shift :744; final chroma[x] = x < 16 ? in[x] : in[x - 16] / 4
+    for (int x = threadIdx.x; x < R.width; x += 256) {
+        int Y;
+        if (x < len) {
+            const int chroma = x < 16 ? in[x] : in[x - 16] / 4;
+            Y = R.show_sc ? (int)(int16_t)chroma + 128 : (int)(int16_t)(S[x] - chroma);     // :751-753, :760-763
+        } else {
+            Y = R.show_sc ? 128 : S[x];            // past the comb's range: luma as equalised, chroma 0
+        }
+        Y = Y < 0 ? 0 : (Y > 255 ? 255 : Y);
+        dst[x] = (uint32_t)Y * 0x010101u;          // RGBTRIPLET :366, alpha 0
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------ host
+struct ntscsim_raw28 {
+    ntscsim_raw28_opts o;
+    int device = 0;
+    std::string err;
+    // geometry / constants (compute_NTSC :247-256, preset_NTSC :395-402, main :936-946)
+    double sample_rate, one_frame_time, one_scanline_time;
+    unsigned len;
+    int width, height, D;
+    FrontConst K;
+    FrontState init;
+    int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
+    // results of the last call
+    double blank = 0, white = 192;
+    uint64_t read_pos = 0;
+    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    size_t last_n = 0;
+    // device scratch
+    Buf<uint8_t> raw, h, tmp;
+    Buf<FrontState> st_begin, st_end, st_prev;
+    Buf<int> flags, counters, tails_a, tails_b;
+    Buf<unsigned long long> segcnt, segoff;
+    Buf<uint32_t> rstart, rend;
+    Buf<CalRange> cal_rg;
+    Buf<CalSums> cal_out;
+    Buf<LineRec> lines;
+};
+
+#define R28CHK(d, call)                                                                    \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            (d)->err = std::string(#call) + ": " + hipGetErrorString(e__);                 \
+            return NTSCSIM_E_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+static void raw28_geometry(const ntscsim_raw28_opts &o, double &rate, double &frame_t, double &line_t,
+                           unsigned &len, int &width, int &height)
+{
+    rate = o.sample_rate > 0 ? o.sample_rate : ((315000000.00 * 8.0) / 88.00);   // :237-245
+    frame_t = rate / (30000.00 / 1001.00);                                        // :249
+    line_t = frame_t / 525.00;                                                    // :250
+    len = (unsigned int)(line_t + 0.5);                                           // :251
+    height = 262;                                                                 // :398
+    width = (int)((len + 1) & (~1u));                                             // :399
+}
+
+extern "C" void ntscsim_raw28_opts_init(ntscsim_raw28_opts *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
+}
+
+extern "C" int ntscsim_raw28_parse_argv(ntscsim_raw28_opts *o, int argc, const char *const *argv, int start)
+{
+    if (!o || (argc > 0 && !argv)) return NTSCSIM_E_ARG;
+    for (int i = start; i < argc;) {                       // parse_argv :442-520
+        const char *a = argv[i++];
+        if (*a != '-') return NTSCSIM_E_FLAG;              // "Unhandled arg"
+        do { a++; } while (*a == '-');
+        if (!std::strcmp(a, "h") || !std::strcmp(a, "help")) return NTSCSIM_E_HELP;
+        else if (!std::strcmp(a, "marksig")) o->mark_sync = 1;
+        else if (!std::strcmp(a, "noequ")) o->disable_equalization = 1;
+        else if (!std::strcmp(a, "nowequ")) o->disable_wp_equ = 1;
+        else if (!std::strcmp(a, "nosig")) o->disable_sync = 1;
+        else if (!std::strcmp(a, "nosc")) o->disable_subcarrier = 1;
+        else if (!std::strcmp(a, "showsc")) o->show_subcarrier = 1;
+        else if (!std::strcmp(a, "s")) {
+            if (i >= argc || !argv[i]) return NTSCSIM_E_FLAG;
+            const char *v = argv[i++];
+            if (!std::strcmp(v, "ntsc28")) o->sample_rate = 0;                    // main :918-928
+            else if (!std::strcmp(v, "40mhz")) o->sample_rate = 40000000.00;
+            else if (*v >= '0' && *v <= '9') o->sample_rate = std::atof(v);
+            else o->sample_rate = 0;                       // "Unknown -s preset": falls back to ntsc28
+        } else if (!std::strcmp(a, "width")) {
+            if (i >= argc || !argv[i]) return NTSCSIM_E_FLAG;
+            if ((int)std::strtoul(argv[i++], nullptr, 0) < 32) return NTSCSIM_E_FLAG;
+        } else if (!std::strcmp(a, "i") || !std::strcmp(a, "o")) {
+            if (i >= argc || !argv[i]) return NTSCSIM_E_FLAG;
+            i++;
+        } else if (!std::strcmp(a, "422") || !std::strcmp(a, "420") || !std::strcmp(a, "inntsc")) {
+        } else return NTSCSIM_E_FLAG;                      // "Unknown switch"
+    }
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_raw28_geometry(const ntscsim_raw28_opts *o, int *width, int *height, int *scanline_samples)
+{
+    if (!o) return NTSCSIM_E_ARG;
+    double r, f, l; unsigned len; int w, h;
+    raw28_geometry(*o, r, f, l, len, w, h);
+    if (len < 64 || len > 4000) return NTSCSIM_E_PARAM;    // the tool's scratch arrays hold 4096 samples :258
+    if (width) *width = w;
+    if (height) *height = h;
+    if (scanline_samples) *scanline_samples = (int)len;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, ntscsim_raw28 **out)
+{
+    if (!o || !out) return NTSCSIM_E_ARG;
+    if (o->struct_size != sizeof(ntscsim_raw28_opts)) return NTSCSIM_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return NTSCSIM_E_NODEV;
+    int w, h, sl;
+    const int rc = ntscsim_raw28_geometry(o, &w, &h, &sl);
+    if (rc != NTSCSIM_OK) return rc;
+    ntscsim_raw28 *d = new ntscsim_raw28();
+    d->o = *o;
+    d->device = device;
+    raw28_geometry(*o, d->sample_rate, d->one_frame_time, d->one_scanline_time, d->len, d->width, d->height);
+    d->D = (int)(size_t)((d->one_scanline_time * 0.075 * 0.75) * 0.5);            // main :937
+    if (d->D < 1) { delete d; return NTSCSIM_E_PARAM; }    // (the tool would index an empty delay line)
+    // detector filters: setFilter :80-88 with main :941, then one frame time of lowpass(128) :942
+    {
+        const double rate = d->sample_rate, hz = d->sample_rate / (d->one_scanline_time * 0.075 * 0.75);
+        const double timeInterval = 1.0 / rate;
+        const double tau = 1 / (hz * 2 * M_PI);
+        d->K.alpha = timeInterval / (tau + timeInterval);
+        double prev = 0;
+        for (size_t j = 0; j < d->one_frame_time; j++) {
+            const double stage1 = 128 * d->K.alpha;
+            const double stage2 = prev - (prev * d->K.alpha);
+            prev = stage1 + stage2;
+        }
+        d->init.p0 = d->init.p1 = d->init.p2 = prev;
+        d->init.level = 128.0;                                                    // :552
+    }
+    d->K.a_fast = 1.0 / (d->one_scanline_time * 0.07 * 0.75);                     // :564
+    d->K.om_fast = 1.0 - d->K.a_fast;
+    d->K.a_slow = 1.0 / (d->one_frame_time * 0.6);                                // :568
+    d->K.om_slow = 1.0 - d->K.a_slow;
+    d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
+    *out = d;
+    return NTSCSIM_OK;
+}
+
+extern "C" void ntscsim_raw28_destroy(ntscsim_raw28 *d) { delete d; }
+extern "C" const char *ntscsim_raw28_last_error(const ntscsim_raw28 *d) { return d ? d->err.c_str() : ""; }
+extern "C" int ntscsim_raw28_get_levels(const ntscsim_raw28 *d, double *blank, double *white, uint64_t *read_pos)
+{
+    if (!d) return NTSCSIM_E_ARG;
+    if (blank) *blank = d->blank;
+    if (white) *white = d->white;
+    if (read_pos) *read_pos = d->read_pos;
+    return NTSCSIM_OK;
+}
+extern "C" void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *d, int warm_lines, int chunk_samples)
+{
+    if (!d) return;
+    if (warm_lines >= 0) d->warm_lines = warm_lines;
+    if (chunk_samples >= 64) d->chunk = (chunk_samples + 3) & ~3;
+}
+extern "C" void ntscsim_raw28_debug_stats(const ntscsim_raw28 *d, int64_t out[6])
+{
+    if (d && out) std::memcpy(out, d->stats, sizeof(d->stats));
+}
+extern "C" int ntscsim_raw28_debug_read_front(ntscsim_raw28 *d, uint8_t *hs, size_t n)
+{
+    if (!d || !hs || n > d->last_n) return NTSCSIM_E_ARG;
+    R28CHK(d, hipSetDevice(d->device));
+    R28CHK(d, hipMemcpy(hs, d->h.p, n, hipMemcpyDeviceToHost));
+    return NTSCSIM_OK;
+}
+
+namespace {
+
+// The walk over the sync runs: composite_layer() :622-693 and :789-830 with the buffer window of
+// :277-332 reduced to its two numbers (begin, end of the buffered part of the stream).
+struct RunWalk {
+    const uint32_t *rs, *re;
+    size_t nruns;
+    // first run that ends after position i: [si, ei) clipped to i and E; si == ei == E when none
+    void next(size_t i, size_t E, size_t &si, size_t &ei) const
+    {
+        const size_t k = (size_t)(std::upper_bound(re, re + nruns, (uint32_t)std::min<size_t>(i, 0xFFFFFFFFu)) - re);
+        if (k >= nruns || (size_t)rs[k] >= E) { si = ei = E; return; }
+        si = std::max<size_t>(rs[k], i);
+        ei = std::min<size_t>(re[k], E);
+    }
+};
+
+} // namespace
+
+static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_device, size_t N, void *frames_dev,
+                             size_t frame_stride, int linesize, int max_fields, int *n_fields)
+{
+    if (!d || !capture || !frames_dev || !n_fields || max_fields < 0) return NTSCSIM_E_ARG;
+    if (N >= 0xFFFFFFFFull) return NTSCSIM_E_SIZE;
+    if (linesize < d->width * 4 || (linesize & 3) || frame_stride < (size_t)linesize * (size_t)d->height) return NTSCSIM_E_SIZE;
+    *n_fields = 0;
+    R28CHK(d, hipSetDevice(d->device));
+    hipStream_t st = nullptr;
+    const unsigned len = d->len;
+    std::memset(d->stats, 0, sizeof(d->stats));
+    d->blank = (uint8_t)0; d->white = (uint8_t)192; d->read_pos = 0;              // :553-554
+    d->last_n = N;
+
+    // ---- (1) front end
+    const uint8_t *raw = (const uint8_t *)capture;
+    if (!on_device) {
+        R28CHK(d, d->raw.ensure(N + 16));
+        R28CHK(d, hipMemcpyAsync(d->raw.p, capture, N, hipMemcpyHostToDevice, st));
+        raw = d->raw.p;
+    } else if ((uintptr_t)capture & 3) {
+        R28CHK(d, d->raw.ensure(N + 16));
+        R28CHK(d, hipMemcpyAsync(d->raw.p, capture, N, hipMemcpyDeviceToDevice, st));
+        raw = d->raw.p;
+    }
+    R28CHK(d, d->h.ensure(N + 16));
+    const int chunk = d->chunk;
+    const int warm = (int)(((size_t)d->warm_lines * len + 3) & ~(size_t)3);
+    const int nchunks = (int)((N + (size_t)chunk - 1) / (size_t)chunk);
+    R28CHK(d, d->counters.ensure(4));
+    if (nchunks > 0) {
+        R28CHK(d, d->st_begin.ensure((size_t)nchunks));
+        R28CHK(d, d->st_end.ensure((size_t)nchunks));
+        R28CHK(d, d->st_prev.ensure((size_t)nchunks));
+        R28CHK(d, d->flags.ensure((size_t)nchunks));
+        hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + 63) / 64), dim3(64), 0, st, raw, N, d->h.p, chunk, warm,
+                           nchunks, d->K, d->init, d->st_begin.p, d->st_end.p, (const FrontState *)nullptr, (const int *)nullptr);
+        for (;;) {
+            R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_raw28_links, dim3((nchunks + 255) / 256), dim3(256), 0, st, d->st_begin.p, d->st_end.p,
+                               nchunks, d->flags.p, d->counters.p);
+            int nbad = 0;
+            R28CHK(d, hipMemcpyAsync(&nbad, d->counters.p, sizeof(int), hipMemcpyDeviceToHost, st));
+            R28CHK(d, hipStreamSynchronize(st));
+            if (nbad == 0) break;
+            d->stats[0]++; d->stats[1] += nbad;
+            // repair round: flagged chunks restart from their predecessor's end state as it is NOW
+            R28CHK(d, hipMemcpyAsync(d->st_prev.p, d->st_end.p, (size_t)nchunks * sizeof(FrontState), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + 63) / 64), dim3(64), 0, st, raw, N, d->h.p, chunk, warm,
+                               nchunks, d->K, d->init, d->st_begin.p, d->st_end.p, (const FrontState *)d->st_prev.p,
+                               (const int *)d->flags.p);
+        }
+    }
+
+    // ---- (2) runs of h < thr
+    const size_t nseg = (N + SEG - 1) / SEG;
+    std::vector<uint32_t> rs, re;
+    if (nseg > 0) {
+        R28CHK(d, d->segcnt.ensure(nseg + 1));
+        R28CHK(d, d->segoff.ensure(nseg + 1));
+        hipLaunchKernelGGL(k_raw28_run_count, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d->h.p, N, d->K.thr,
+                           d->segcnt.p, nseg);
+        R28CHK(d, hipMemsetAsync(d->segcnt.p + nseg, 0, sizeof(unsigned long long), st));
+        size_t tmp_bytes = 0;
+        R28CHK(d, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d->segcnt.p, d->segoff.p, (int)(nseg + 1), st));
+        R28CHK(d, d->tmp.ensure(tmp_bytes + 16));
+        R28CHK(d, hipcub::DeviceScan::ExclusiveSum(d->tmp.p, tmp_bytes, d->segcnt.p, d->segoff.p, (int)(nseg + 1), st));
+        unsigned long long total = 0;
+        R28CHK(d, hipMemcpyAsync(&total, d->segoff.p + nseg, sizeof(total), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipStreamSynchronize(st));
+        const size_t nruns = (size_t)(total & 0xFFFFFFFFull);
+        if ((size_t)(total >> 32) != nruns) { d->err = "run extraction: starts != ends"; return NTSCSIM_E_INTERNAL; }
+        if (nruns > 0) {
+            R28CHK(d, d->rstart.ensure(nruns));
+            R28CHK(d, d->rend.ensure(nruns));
+            hipLaunchKernelGGL(k_raw28_run_scatter, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d->h.p, N,
+                               d->K.thr, d->segoff.p, nseg, d->rstart.p, d->rend.p);
+            rs.resize(nruns); re.resize(nruns);
+            R28CHK(d, hipMemcpyAsync(rs.data(), d->rstart.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            R28CHK(d, hipMemcpyAsync(re.data(), d->rend.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            R28CHK(d, hipStreamSynchronize(st));
+        }
+        d->stats[3] = (int64_t)nruns;
+    }
+
+    // ---- (3) the walk: field loop main() :1016-1030 around composite_layer()'s searches
+    const RunWalk W{rs.data(), re.data(), rs.size()};
+    const size_t CAP = (size_t)len * 2048;                                        // open_src :353
+    const size_t L30 = (size_t)(int)(len * 0.3), L06 = (size_t)(int)(len * 0.06), L02 = (size_t)(int)(len * 0.02);
+    size_t Bw = 0, Rd = 0;                          // buffer begin, read position (absolute)
+    std::vector<LineRec> lines;
+    std::vector<CalRange> cal;                     // calibration ranges in order
+    std::vector<int> cal_field;                    // number of ranges seen before each field is rendered
+    int nf = 0;
+    while (nf < max_fields) {
+        if (Rd - Bw > CAP / 2u) Bw = Rd;           // lazy_flush_src :329 (twice per field, idempotent)
+        const size_t E = std::min(N, Bw + CAP);    // refill_src :307
+        if (E - Rd < (size_t)len * 256) break;     // main :1021
+        if (!d->o.disable_sync) {                  // :622-693
+            size_t i = Rd;
+            int vsb = 0;
+            while (i < E) {
+                size_t si, ei;
+                W.next(i, E, si, ei);
+                i = ei;
+                const size_t synclen = ei - si;
+                if (synclen >= L30) { i = si + L30; if (i < ei) i = ei; vsb++; }
+                else if (synclen >= L06) { if (vsb >= 9) { Rd = si + synclen / 2; break; } }
+                else if (synclen >= L02) {
+                    i = si + L30; if (i < ei) i = ei; vsb++;
+                    // (the tool sums records up to i even past the end of the buffered stream; we stop at E)
+                    cal.push_back(CalRange{(uint32_t)si, (uint32_t)std::min(i, E)});
+                }
+            }
+        }
+        cal_field.push_back((int)cal.size());
+        size_t scan = Rd;
+        const size_t start = Rd;
+        for (unsigned y = 0; y < (unsigned)d->height && (scan + (size_t)len * 2) < E; y++) {      // :700
+            LineRec L;
+            L.pos = (uint32_t)scan; L.field = nf; L.row = (int)y; L.blank = 0; L.white = 0;
+            lines.push_back(L);
+            scan += len;                            // :777-787 (one_scanline_width is integral: err stays 0)
+            if (scan > E) scan = E;
+            if (!d->o.disable_sync) {              // :789-830
+                size_t i = scan;
+                int vsb = 0;
+                if (i > Rd) {
+                    size_t avail = i - Rd;
+                    if ((double)avail >= (len * 0.1)) avail = (size_t)(len * 0.1);
+                    i -= avail;
+                }
+                while (i < E) {
+                    size_t si, ei;
+                    W.next(i, E, si, ei);
+                    i = ei;
+                    const size_t synclen = ei - si;
+                    if (synclen >= L30) { i = si + L30; if (i < ei) i = ei; vsb++; }
+                    else if (synclen >= L06) { scan = si + synclen / 2; break; }
+                    else if (synclen >= L02) { i = si + L30; if (i < ei) i = ei; vsb++; }
+                    if (vsb >= 9) { y = INT_MAX; break; }
+                }
+            }
+        }
+        if (d->o.disable_sync) Rd = scan;          // :833
+        {
+            size_t should = start + (size_t)len * 240;                             // :836-845
+            if (should > E) should = E;
+            if (Rd < should) Rd = should;
+        }
+        nf++;
+    }
+    d->read_pos = Rd;
+    d->stats[4] = (int64_t)lines.size();
+    d->stats[5] = (int64_t)cal.size();
+    *n_fields = nf;
+
+    // ---- (4) black / white levels :661-688: sums on the GPU, the eight-tap recurrence here
+    std::vector<CalSums> sums(cal.size());
+    if (!cal.empty()) {
+        R28CHK(d, d->cal_rg.ensure(cal.size()));
+        R28CHK(d, d->cal_out.ensure(cal.size()));
+        R28CHK(d, hipMemcpyAsync(d->cal_rg.p, cal.data(), cal.size() * sizeof(CalRange), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_raw28_cal, dim3((unsigned)cal.size()), dim3(64), 0, st, raw, d->h.p, d->cal_rg.p,
+                           d->cal_out.p, d->D, d->K.thr, d->o.mark_sync ? 1 : 0);
+        R28CHK(d, hipMemcpyAsync(sums.data(), d->cal_out.p, cal.size() * sizeof(CalSums), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipStreamSynchronize(st));
+    }
+    {
+        size_t ci = 0, li = 0;
+        for (int f = 0; f < nf; f++) {
+            for (; ci < (size_t)cal_field[(size_t)f]; ci++) {
+                int mina = sums[ci].mina, maxa = sums[ci].maxa;
+                if (sums[ci].mind > 0) mina /= sums[ci].mind;
+                if (sums[ci].maxd > 0) maxa /= sums[ci].maxd;
+                int t = (int)(maxa + ((maxa - mina) / (0.25 + 0.125)));
+                t = std::min(std::max(t, maxa + 1), 240);
+                const int nwhite = (uint8_t)t, nblack = maxa;
+                const double a = 1.0 / 8.0;
+                d->white = (d->white * (1.0 - a)) + (nwhite * a);
+                d->blank = (d->blank * (1.0 - a)) + (nblack * a);
+            }
+            for (; li < lines.size() && lines[li].field == f; li++) { lines[li].blank = d->blank; lines[li].white = d->white; }
+        }
+    }
+
+    // ---- (5) comb tails to their fixed point, then every scanline at once
+    for (int f = 0; f < nf; f++)
+        R28CHK(d, hipMemsetAsync((uint8_t *)frames_dev + (size_t)f * frame_stride, 0, (size_t)linesize * (size_t)d->height, st));
+    const int nlines = (int)lines.size();
+    if (nlines > 0) {
+        RenderConst RC;
+        RC.len = (int)len; RC.width = d->width; RC.D = d->D; RC.thr = d->K.thr;
+        RC.mark = d->o.mark_sync ? 1 : 0; RC.no_equ = d->o.disable_equalization ? 1 : 0;
+        RC.no_wequ = d->o.disable_wp_equ ? 1 : 0; RC.no_sc = d->o.disable_subcarrier ? 1 : 0;
+        RC.show_sc = d->o.show_subcarrier ? 1 : 0;
+        R28CHK(d, d->lines.ensure((size_t)nlines));
+        R28CHK(d, hipMemcpyAsync(d->lines.p, lines.data(), (size_t)nlines * sizeof(LineRec), hipMemcpyHostToDevice, st));
+        int *tails = nullptr;
+        if (!RC.no_sc) {
+            R28CHK(d, d->tails_a.ensure((size_t)nlines * 16));
+            R28CHK(d, d->tails_b.ensure((size_t)nlines * 16));
+            R28CHK(d, hipMemsetAsync(d->tails_a.p, 0, (size_t)nlines * 16 * sizeof(int), st));
+            R28CHK(d, hipMemsetAsync(d->tails_b.p, 0, (size_t)nlines * 16 * sizeof(int), st));
+            int *tin = d->tails_a.p, *tout = d->tails_b.p;
+            for (int round = 0;; round++) {
+                // round r: tout(y) = G(samples of y, tin(y-1)); it ends when tout == tin everywhere, i.e.
+                // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = 0: the serial result
+                R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
+                hipLaunchKernelGGL(k_raw28_tails, dim3((nlines + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
+                                   nlines, RC, (const int *)tin, tout, d->counters.p);
+                int nch = 0;
+                R28CHK(d, hipMemcpyAsync(&nch, d->counters.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                R28CHK(d, hipStreamSynchronize(st));
+                d->stats[2]++;
+                std::swap(tin, tout);
+                if (nch == 0) break;
+                if (round > nlines + 2) { d->err = "comb tails did not settle"; return NTSCSIM_E_INTERNAL; }
+            }
+            // both arrays now hold the fixed point
+            tails = tin;
+        }
+        const size_t lds = (size_t)3 * (len + 16) * sizeof(int);
+        hipLaunchKernelGGL(k_raw28_render, dim3((unsigned)nlines), dim3(256), lds, st, raw, d->h.p, N, d->lines.p, RC,
+                           (const int *)tails, (uint8_t *)frames_dev, frame_stride, linesize);
+    }
+    R28CHK(d, hipGetLastError());
+    R28CHK(d, hipStreamSynchronize(st));
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_raw28_decode(ntscsim_raw28 *d, const uint8_t *capture_host, size_t n, void *frames_dev,
+                                    size_t frame_stride, int linesize, int max_fields, int *n_fields)
+{
+    return raw28_decode_impl(d, capture_host, false, n, frames_dev, frame_stride, linesize, max_fields, n_fields);
+}
+extern "C" int ntscsim_raw28_decode_device(ntscsim_raw28 *d, const void *capture_dev, size_t n, void *frames_dev,
+                                           size_t frame_stride, int linesize, int max_fields, int *n_fields)
+{
+    return raw28_decode_impl(d, capture_dev, true, n, frames_dev, frame_stride, linesize, max_fields, n_fields);
+}

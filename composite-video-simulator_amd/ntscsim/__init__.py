@@ -295,3 +295,68 @@ class FieldSimulator:
             self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size)
         self._chk(rc, "ntscsim_debug_read_composite")
         return a
+
+
+class Raw28Decoder:
+    """The raw-composite decoder (ffmpeg_raw28ntsc): one decode() = one run of the tool on a capture."""
+
+    def __init__(self, flags=(), device=0, opts=None):
+        self._lib = lib()
+        self.opts = opts if opts is not None else _capi.make_raw28_opts(flags)
+        w, h, sl = C.c_int(), C.c_int(), C.c_int()
+        rc = self._lib.ntscsim_raw28_geometry(C.byref(self.opts), C.byref(w), C.byref(h), C.byref(sl))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_raw28_geometry")
+        self.width, self.height, self.scanline = w.value, h.value, sl.value
+        hnd = C.c_void_p()
+        rc = self._lib.ntscsim_raw28_create(C.byref(self.opts), int(device), C.byref(hnd))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_raw28_create")
+        self._h = hnd
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ntscsim_raw28_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, capture, frames, max_fields=None):
+        """capture: numpy uint8 (host) or CUDA uint8 tensor; frames: CUDA uint8 tensor
+        [F, height, >= 4*width].  Returns the number of fields decoded."""
+        n = C.c_int()
+        mf = int(frames.shape[0] if max_fields is None else max_fields)
+        if hasattr(capture, "data_ptr"):
+            fn, ptr, ns = self._lib.ntscsim_raw28_decode_device, capture.data_ptr(), capture.numel()
+        else:
+            fn, ptr, ns = self._lib.ntscsim_raw28_decode, capture.ctypes.data, capture.size
+        rc = fn(self._h, C.c_void_p(ptr), ns, C.c_void_p(frames.data_ptr()), frames.stride(0), frames.stride(1),
+                mf, C.byref(n))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, self._lib.ntscsim_raw28_last_error(self._h).decode())
+        return n.value
+
+    def levels(self):
+        b, w, p = C.c_double(), C.c_double(), C.c_uint64()
+        self._lib.ntscsim_raw28_get_levels(self._h, C.byref(b), C.byref(w), C.byref(p))
+        return b.value, w.value, p.value
+
+    def set_speculation(self, warm_lines=-1, chunk_samples=0):
+        self._lib.ntscsim_raw28_debug_set_speculation(self._h, int(warm_lines), int(chunk_samples))
+
+    def stats(self):
+        a = (C.c_int64 * 6)()
+        self._lib.ntscsim_raw28_debug_stats(self._h, a)
+        return dict(zip(("front_rounds", "chunks_repaired", "tail_rounds", "sync_runs", "scanlines", "cal_pulses"), list(a)))
+
+    def read_front(self, n):
+        import numpy as np
+        out = np.empty(n, np.uint8)
+        rc = self._lib.ntscsim_raw28_debug_read_front(self._h, C.c_void_p(out.ctypes.data), n)
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_raw28_debug_read_front")
+        return out

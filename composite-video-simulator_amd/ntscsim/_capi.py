@@ -31,7 +31,19 @@ EXPORTS = (
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
     "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_bgra_to_yuv_device", "ntscsim_rng_calls_per_field_422",
     "ntscsim_scale_to_bgra_device", "ntscsim_frames_host_scaled",
+    "ntscsim_raw28_opts_init", "ntscsim_raw28_parse_argv", "ntscsim_raw28_geometry", "ntscsim_raw28_create",
+    "ntscsim_raw28_destroy", "ntscsim_raw28_last_error", "ntscsim_raw28_decode", "ntscsim_raw28_decode_device",
+    "ntscsim_raw28_get_levels", "ntscsim_raw28_debug_set_speculation", "ntscsim_raw28_debug_stats",
+    "ntscsim_raw28_debug_read_front",
 )
+
+
+class Raw28Opts(C.Structure):
+    """struct ntscsim_raw28_opts -- keep in lock-step with include/ntscsim.h."""
+    _fields_ = [("struct_size", C.c_uint32), ("_pad0", C.c_uint32), ("sample_rate", C.c_double),
+                ("mark_sync", C.c_int32), ("disable_sync", C.c_int32), ("disable_wp_equ", C.c_int32),
+                ("show_subcarrier", C.c_int32), ("disable_subcarrier", C.c_int32),
+                ("disable_equalization", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -262,6 +274,29 @@ def lib():
     L.ntscsim_debug_force_generic.restype = None
     L.ntscsim_debug_no_fast_decode.argtypes = [C.c_void_p, C.c_int]
     L.ntscsim_debug_no_fast_decode.restype = None
+    L.ntscsim_raw28_opts_init.argtypes = [C.POINTER(Raw28Opts)]
+    L.ntscsim_raw28_opts_init.restype = None
+    L.ntscsim_raw28_parse_argv.argtypes = [C.POINTER(Raw28Opts), C.c_int, C.POINTER(C.c_char_p), C.c_int]
+    L.ntscsim_raw28_parse_argv.restype = C.c_int
+    L.ntscsim_raw28_geometry.argtypes = [C.POINTER(Raw28Opts)] + [C.POINTER(C.c_int)] * 3
+    L.ntscsim_raw28_geometry.restype = C.c_int
+    L.ntscsim_raw28_create.argtypes = [C.POINTER(Raw28Opts), C.c_int, C.POINTER(C.c_void_p)]
+    L.ntscsim_raw28_create.restype = C.c_int
+    L.ntscsim_raw28_destroy.argtypes = [C.c_void_p]
+    L.ntscsim_raw28_destroy.restype = None
+    L.ntscsim_raw28_last_error.argtypes = [C.c_void_p]
+    L.ntscsim_raw28_last_error.restype = C.c_char_p
+    for fn in (L.ntscsim_raw28_decode, L.ntscsim_raw28_decode_device):
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        fn.restype = C.c_int
+    L.ntscsim_raw28_get_levels.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.ntscsim_raw28_get_levels.restype = C.c_int
+    L.ntscsim_raw28_debug_set_speculation.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ntscsim_raw28_debug_set_speculation.restype = None
+    L.ntscsim_raw28_debug_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.ntscsim_raw28_debug_stats.restype = None
+    L.ntscsim_raw28_debug_read_front.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ntscsim_raw28_debug_read_front.restype = C.c_int
     _lib = L
     return L
 
@@ -305,3 +340,16 @@ def make_params(flags=(), **overrides):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def make_raw28_opts(flags=()):
+    """ntscsim_raw28_opts from ffmpeg_raw28ntsc's switches (ffmpeg_raw28ntsc.cpp parse_argv :442)."""
+    L = lib()
+    o = Raw28Opts()
+    L.ntscsim_raw28_opts_init(C.byref(o))
+    argv = [b"ffmpeg_raw28ntsc"] + [str(f).encode() for f in flags]
+    arr = (C.c_char_p * len(argv))(*argv)
+    rc = L.ntscsim_raw28_parse_argv(C.byref(o), len(argv), arr, 1)
+    if rc != OK:
+        raise NtscsimError(rc, "raw28 parse_argv(%r)" % (list(flags),))
+    return o

@@ -430,6 +430,62 @@ void ntscsim_debug_force_generic(ntscsim_ctx *ctx, int on);
  * instead of one.  Results must not change. */
 void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
 
+/* ---- the raw-composite decoder: ffmpeg_raw28ntsc.cpp ---------------
+ * The tool reads 8-bit composite video sampled at 8 x fsc (28.636 MHz, e.g. a cxadc capture) and
+ * renders one grey-scale BGRA frame of (scanline_samples + 1 & ~1) x 262 per field:
+ *   hsync_dc_proc() :556-594 on every sample (sync-tip tracking, low-passed sync detector);
+ *   composite_layer() :601-849 per field: vertical-sync search, black / white calibration on the
+ *   equalising pulses, then per scanline: level equalisation, delay-4 comb luma / chroma split,
+ *   rendering, horizontal re-sync;  field loop main() :1016-1047.
+ * One ntscsim_raw28_decode*() call = one run of the tool on one input file: the decoder state
+ * starts from the tool's initial state every call.  Results are bit-identical to the tool's except
+ * where the tool itself reads buffer records past the end of the capture (only possible while it
+ * searches for a vertical sync that the last 256 scanlines do not contain).
+ */
+typedef struct ntscsim_raw28_opts {
+    uint32_t struct_size;            /* sizeof(ntscsim_raw28_opts)                               */
+    uint32_t _pad0;
+    double   sample_rate;            /* -s: 0 = "ntsc28" = 315e6*8/88; "40mhz" = 40e6; else Hz   */
+    int32_t  mark_sync;              /* -marksig :458                                            */
+    int32_t  disable_sync;           /* -nosig   :467                                            */
+    int32_t  disable_wp_equ;         /* -nowequ  :464                                            */
+    int32_t  show_subcarrier;        /* -showsc  :473                                            */
+    int32_t  disable_subcarrier;     /* -nosc    :470                                            */
+    int32_t  disable_equalization;   /* -noequ   :461                                            */
+} ntscsim_raw28_opts;
+typedef struct ntscsim_raw28 ntscsim_raw28;
+
+void ntscsim_raw28_opts_init(ntscsim_raw28_opts *o);
+/* mirror of parse_argv() :442-520 (-marksig -noequ -nowequ -nosig -nosc -showsc -s <rate>; -width,
+ * -i, -o, -422, -420, -inntsc are accepted and have no effect on the decoder: preset_NTSC() :395
+ * overrides the width after parsing).  Returns NTSCSIM_OK, NTSCSIM_E_HELP or NTSCSIM_E_FLAG (the tool's
+ * "return 1"). */
+int  ntscsim_raw28_parse_argv(ntscsim_raw28_opts *o, int argc, const char *const *argv, int start);
+int  ntscsim_raw28_geometry(const ntscsim_raw28_opts *o, int *width, int *height, int *scanline_samples);
+int  ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, ntscsim_raw28 **out);
+void ntscsim_raw28_destroy(ntscsim_raw28 *dec);
+const char *ntscsim_raw28_last_error(const ntscsim_raw28 *dec);
+/* Decode a whole capture.  `capture` is host memory (ntscsim_raw28_decode) or device memory
+ * (ntscsim_raw28_decode_device), n_samples < 2^32.  frames_dev: device memory for max_fields BGRA
+ * frames, frame k at frames_dev + k * frame_stride, rows of `linesize` bytes (>= 4 * width).  Rows
+ * the tool does not render are zero, alpha is 0 (:757-775).  Synchronous.  *n_fields = fields the
+ * tool would have produced (its loop stops when fewer than 256 scanlines remain), capped at
+ * max_fields. */
+int  ntscsim_raw28_decode(ntscsim_raw28 *dec, const uint8_t *capture_host, size_t n_samples,
+                          void *frames_dev, size_t frame_stride, int linesize, int max_fields, int *n_fields);
+int  ntscsim_raw28_decode_device(ntscsim_raw28 *dec, const void *capture_dev, size_t n_samples,
+                                 void *frames_dev, size_t frame_stride, int linesize, int max_fields, int *n_fields);
+/* blank_level, white_level (:553-554) and the stream position (total_count_src) after the last call */
+int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *white, uint64_t *read_pos);
+/* Test hooks.  warm-up scanlines of the speculative front end (default 112; 0 forces every chunk
+ * through the exact repair rounds) and chunk size in samples (default 4096); results must not
+ * change.  stats: [0] front-end repair rounds, [1] chunks repaired, [2] comb-tail rounds,
+ * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call. */
+void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
+void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[6]);
+/* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */
+int  ntscsim_raw28_debug_read_front(ntscsim_raw28 *dec, uint8_t *hsync_dc_raw, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -391,3 +391,117 @@ def oracle_scale_to_bgra(planes, fmt, W, H):
     g = np.clip((298 * c - 100 * d - 208 * e + 128) >> 8, 0, 255)
     b = np.clip((298 * c + 516 * d + 128) >> 8, 0, 255)
     return np.ascontiguousarray(np.stack([b, g, r, np.full_like(b, 255)], axis=-1).astype(np.uint8))
+
+
+# ---- the raw-composite decoder (ffmpeg_raw28ntsc.cpp): oracle + reference extract ---------------
+RAW28_REF_SO = os.path.join(ROOT, "oracle", "_ref", "libraw28_ref.so")
+RAW28_FLAGS = ("mark_sync", "disable_sync", "disable_wp_equ", "show_subcarrier", "disable_subcarrier",
+               "disable_equalization")
+
+
+class Raw28OracleOpts(C.Structure):       # struct raw28_opts (oracle/raw28_oracle.h)
+    _fields_ = [("sample_rate", C.c_double)] + [(n, C.c_int32) for n in RAW28_FLAGS]
+
+
+def raw28_oracle_opts(sample_rate=0.0, **kw):
+    o = Raw28OracleOpts()
+    o.sample_rate = sample_rate
+    for k, v in kw.items():
+        assert k in RAW28_FLAGS
+        setattr(o, k, int(v))
+    return o
+
+
+_raw28_bound = False
+
+
+def _bind_raw28_oracle():
+    global _raw28_bound
+    o = oracle()
+    if not _raw28_bound:
+        o.raw28_synth_capture.restype = C.c_size_t
+        o.raw28_synth_capture.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int]
+        o.raw28_oracle_open.restype = C.c_void_p
+        o.raw28_oracle_open.argtypes = [C.POINTER(Raw28OracleOpts), C.c_void_p, C.c_size_t]
+        o.raw28_oracle_next_field.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        o.raw28_oracle_close.argtypes = [C.c_void_p]
+        o.raw28_oracle_geometry.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 3
+        o.raw28_oracle_levels.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        o.raw28_oracle_front.argtypes = [C.POINTER(Raw28OracleOpts), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        _raw28_bound = True
+    return o
+
+
+def raw28_capture(fields, seed=1, noise=3, cut=0):
+    """Synthetic 8 x fsc capture of `fields` fields (oracle/raw28_oracle.c); cut = samples dropped from
+    its start (an arbitrary tuning-in point)."""
+    o = _bind_raw28_oracle()
+    buf = np.zeros(fields * 477750 + 16, np.uint8)
+    n = o.raw28_synth_capture(buf.ctypes.data, buf.size, fields, seed, noise)
+    return np.ascontiguousarray(buf[cut:n])
+
+
+def raw28_oracle_run(opts, capture, max_fields=1 << 30):
+    """(frames [F, H, W*4], (blank, white, read_pos)) of the oracle on a capture."""
+    o = _bind_raw28_oracle()
+    d = o.raw28_oracle_open(C.byref(opts), capture.ctypes.data, capture.size)
+    w, h, sl = C.c_int(), C.c_int(), C.c_int()
+    o.raw28_oracle_geometry(d, C.byref(w), C.byref(h), C.byref(sl))
+    frames = []
+    while len(frames) < max_fields:
+        f = np.empty((h.value, w.value * 4), np.uint8)
+        if not o.raw28_oracle_next_field(d, f.ctypes.data, w.value * 4):
+            break
+        frames.append(f)
+    b, wh, rp = C.c_double(), C.c_double(), C.c_uint64()
+    o.raw28_oracle_levels(d, C.byref(b), C.byref(wh), C.byref(rp))
+    o.raw28_oracle_close(d)
+    out = np.stack(frames) if frames else np.zeros((0, h.value, w.value * 4), np.uint8)
+    return out, (b.value, wh.value, rp.value)
+
+
+def raw28_oracle_front(opts, capture):
+    o = _bind_raw28_oracle()
+    h = np.empty(capture.size, np.uint8)
+    r = np.empty(capture.size, np.uint8)
+    o.raw28_oracle_front(C.byref(opts), capture.ctypes.data, capture.size, h.ctypes.data, r.ctypes.data)
+    return h, r
+
+
+def have_raw28_ref():
+    return os.path.exists(RAW28_REF_SO)
+
+
+_raw28_ref = None
+
+
+def raw28_ref_run(opts, capture, path, max_fields=64):
+    """The reference extract (oracle/_ref/libraw28_ref.so) on the capture written to `path`."""
+    global _raw28_ref
+    if _raw28_ref is None:
+        _raw28_ref = C.CDLL(RAW28_REF_SO)
+        _raw28_ref.raw28_ref_run.argtypes = ([C.POINTER(Raw28OracleOpts), C.c_char_p, C.c_void_p, C.c_int] +
+                                             [C.POINTER(C.c_int)] * 3 + [C.POINTER(C.c_double)] * 2 +
+                                             [C.POINTER(C.c_ulonglong)])
+        _raw28_ref.raw28_ref_front.argtypes = [C.POINTER(Raw28OracleOpts), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    with open(path, "wb") as f:
+        f.write(capture.tobytes())
+    w, h, sl = C.c_int(), C.c_int(), C.c_int()
+    b, wh, rp = C.c_double(), C.c_double(), C.c_ulonglong()
+    out = np.zeros((max_fields, 262, 1820 * 4), np.uint8)
+    n = _raw28_ref.raw28_ref_run(C.byref(opts), str(path).encode(), out.ctypes.data, max_fields, C.byref(w),
+                                 C.byref(h), C.byref(sl), C.byref(b), C.byref(wh), C.byref(rp))
+    assert n >= 0 and (w.value, h.value) == (1820, 262)
+    return out[:n], (b.value, wh.value, rp.value)
+
+
+def raw28_ref_front(opts, capture):
+    raw28_ref_run  # noqa: the binding above
+    global _raw28_ref
+    if _raw28_ref is None:
+        _raw28_ref = C.CDLL(RAW28_REF_SO)
+        _raw28_ref.raw28_ref_front.argtypes = [C.POINTER(Raw28OracleOpts), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    h = np.empty(capture.size, np.uint8)
+    r = np.empty(capture.size, np.uint8)
+    _raw28_ref.raw28_ref_front(C.byref(opts), capture.ctypes.data, capture.size, h.ctypes.data, r.ctypes.data)
+    return h, r

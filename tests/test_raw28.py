@@ -1,0 +1,173 @@
+"""The raw-composite decoder (ffmpeg_raw28ntsc.cpp): oracle == reference
+extract (CPU, build container), oracle == committed hashes (CPU, everywhere), HIP == oracle (GPU)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _libs as L
+from ntscsim import _capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "raw28_hashes.json")
+
+# (name, oracle options, product switches)
+CASES = [
+    ("default", {}, []),
+    ("marksig", {"mark_sync": 1}, ["-marksig"]),
+    ("nosig", {"disable_sync": 1}, ["-nosig"]),
+    ("nowequ", {"disable_wp_equ": 1}, ["-nowequ"]),
+    ("showsc", {"show_subcarrier": 1}, ["-showsc"]),
+    ("nosc", {"disable_subcarrier": 1}, ["-nosc"]),
+    ("noequ", {"disable_equalization": 1}, ["-noequ"]),
+    ("nosc_showsc_marksig", {"disable_subcarrier": 1, "show_subcarrier": 1, "mark_sync": 1}, ["-nosc", "-showsc", "-marksig"]),
+]
+# (fields, seed, noise, samples cut from the start)
+CAPTURES = {"clean": (5, 1, 0, 0), "noisy_cut": (6, 7, 4, 123457), "long": (13, 3, 2, 600001)}
+
+
+def _digest(frames, levels):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(frames).tobytes())
+    h.update(np.array(levels[:2], np.float64).tobytes())
+    h.update(np.array([levels[2]], np.uint64).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.skipif(not L.have_raw28_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("cap", sorted(CAPTURES))
+@pytest.mark.parametrize("c", CASES, ids=[c[0] for c in CASES])
+def test_oracle_equals_reference_extract(c, cap, tmp_path):
+    if cap == "long" and c[0] not in ("default", "marksig"):
+        pytest.skip("the long capture runs with two switch sets")
+    capture = L.raw28_capture(*CAPTURES[cap])
+    opts = L.raw28_oracle_opts(**c[1])
+    got, lv = L.raw28_oracle_run(opts, capture)
+    want, lv2 = L.raw28_ref_run(opts, capture, tmp_path / "cap.u8")
+    assert got.shape == want.shape and got.shape[0] >= CAPTURES[cap][0] - 2
+    assert np.array_equal(got, want)
+    assert lv == lv2
+
+
+@pytest.mark.skipif(not L.have_raw28_ref(), reason="oracle/_ref not built (no /root/reference)")
+def test_front_end_equals_reference_extract():
+    capture = L.raw28_capture(3, 5, 3, 1000)
+    for kw in ({}, {"mark_sync": 1}):
+        opts = L.raw28_oracle_opts(**kw)
+        h1, r1 = L.raw28_oracle_front(opts, capture)
+        h2, r2 = L.raw28_ref_front(opts, capture)
+        assert np.array_equal(h1, h2) and np.array_equal(r1, r2)
+
+
+def test_oracle_reproduces_reference_hashes():
+    """tests/golden/raw28_hashes.json was written from the REFERENCE extract (make_golden.py)."""
+    gold = json.load(open(GOLD))
+    for key, want in gold.items():
+        cname, cap = key.split("@")
+        c = [x for x in CASES if x[0] == cname][0]
+        capture = L.raw28_capture(*CAPTURES[cap])
+        frames, lv = L.raw28_oracle_run(L.raw28_oracle_opts(**c[1]), capture)
+        assert _digest(frames, lv) == want["sha256"], key
+        assert frames.shape[0] == want["fields"]
+
+
+def test_flag_mirror_and_geometry():
+    lib = L.product()
+    o = _capi.make_raw28_opts(["-marksig", "-nosig", "-s", "40mhz", "-width", "800", "-i", "x", "-o", "y", "-420"])
+    assert (o.mark_sync, o.disable_sync, o.sample_rate) == (1, 1, 40e6)
+    with pytest.raises(_capi.NtscsimError):
+        _capi.make_raw28_opts(["-bogus"])
+    with pytest.raises(_capi.NtscsimError):
+        _capi.make_raw28_opts(["-width", "16"])
+    import ctypes as C
+    w, h, sl = C.c_int(), C.c_int(), C.c_int()
+    d = _capi.make_raw28_opts([])
+    assert lib.ntscsim_raw28_geometry(C.byref(d), C.byref(w), C.byref(h), C.byref(sl)) == 0
+    assert (w.value, h.value, sl.value) == (1820, 262, 1820)
+    assert lib.ntscsim_raw28_geometry(C.byref(o), C.byref(w), C.byref(h), C.byref(sl)) == 0
+    assert (w.value, h.value, sl.value) == (2542, 262, 2542)
+
+
+# ------------------------------------------------------------------------------------------- GPU
+def _hip_run(flags, capture, on_device=False, warm=None, chunk=None, max_fields=None):
+    import torch
+    import ntscsim
+    dec = ntscsim.Raw28Decoder(flags)
+    if warm is not None or chunk is not None:
+        dec.set_speculation(-1 if warm is None else warm, 0 if chunk is None else chunk)
+    cap_f = capture.size // (dec.scanline * 262) + 2
+    frames = torch.full((cap_f if max_fields is None else max_fields, dec.height, dec.width * 4 + 16), 9,
+                        dtype=torch.uint8, device="cuda")
+    src = torch.from_numpy(capture).cuda() if on_device else capture
+    n = dec.decode(src, frames)
+    out = frames[:n].cpu().numpy()
+    assert (out[:, :, dec.width * 4:] == 0).all()          # the tool's memset covers linesize x height (:1024)
+    res = (np.ascontiguousarray(out[:, :, :dec.width * 4]), dec.levels(), dec.stats(), dec)
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", sorted(CAPTURES))
+@pytest.mark.parametrize("c", CASES, ids=[c[0] for c in CASES])
+def test_hip_equals_oracle(c, cap):
+    if cap == "long" and c[0] not in ("default", "marksig", "nosig"):
+        pytest.skip("the long capture runs with three switch sets")
+    capture = L.raw28_capture(*CAPTURES[cap])
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(**c[1]), capture)
+    got, lv2, st, dec = _hip_run(c[2], capture, on_device=(cap == "noisy_cut"))
+    assert got.shape == want.shape, (got.shape, want.shape)
+    bad = [int(f) for f in range(got.shape[0]) if not np.array_equal(got[f], want[f])]
+    assert not bad, (bad, st)
+    assert lv2 == lv
+    dec.close()
+
+
+@pytest.mark.gpu
+def test_hip_front_end_equals_oracle_and_repairs_are_exact():
+    """hsync_dc_raw of every sample; then with the speculation crippled (no warm-up, or a tiny one
+    with large chunks) so that the repair rounds do the work -- results must not change."""
+    capture = L.raw28_capture(4, 11, 3, 4321)
+    h, _ = L.raw28_oracle_front(L.raw28_oracle_opts(), capture)
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    for warm, chunk in ((None, None), (0, 65536), (2, 16384), (64, 1024)):
+        got, lv2, st, dec = _hip_run([], capture, warm=warm, chunk=chunk)
+        assert np.array_equal(dec.read_front(capture.size), h), (warm, chunk)
+        assert np.array_equal(got, want) and lv2 == lv
+        if warm == 0:
+            assert st["front_rounds"] >= 1 and st["chunks_repaired"] >= 1
+        if warm is None:
+            assert st["front_rounds"] <= 1, st               # the default warm-up (nearly) always suffices here
+        dec.close()
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_hashes():
+    gold = json.load(open(GOLD))
+    for key, want in gold.items():
+        cname, cap = key.split("@")
+        if cap == "long" and cname != "default":
+            continue
+        c = [x for x in CASES if x[0] == cname][0]
+        got, lv, _, dec = _hip_run(c[2], L.raw28_capture(*CAPTURES[cap]))
+        assert _digest(got, lv) == want["sha256"], key
+        dec.close()
+
+
+@pytest.mark.gpu
+def test_hip_max_fields_and_errors():
+    import torch
+    import ntscsim
+    capture = L.raw28_capture(4, 2, 1, 0)
+    want, _ = L.raw28_oracle_run(L.raw28_oracle_opts(), capture, max_fields=2)
+    got, _, _, dec = _hip_run([], capture, max_fields=2)
+    assert got.shape[0] == 2 and np.array_equal(got, want)
+    small = torch.zeros((1, dec.height, dec.width * 4 - 4), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        dec.decode(capture, small)
+    assert e.value.code == _capi.E_SIZE
+    # a capture shorter than 256 scanlines decodes to zero fields, like the tool
+    frames = torch.zeros((2, dec.height, dec.width * 4), dtype=torch.uint8, device="cuda")
+    assert dec.decode(capture[:1820 * 200].copy(), frames) == 0
+    dec.close()
