@@ -430,6 +430,50 @@ def extras(torch, ntscsim, dev, local_rank, args):
     out["variant422"] = {"value": nf / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
                          "workload": "%dx%d YUV422P, preset '%s', %d fields per step (every field its own frame, "
                                      "processed in place), %d steps in flight" % (w, h, args.preset, nf, nq)}
+    # ---- the raw-composite decoder (ffmpeg_raw28ntsc): a synthetic 8 x fsc capture resident in HBM
+    try:
+        # 600 fields (a 10 s capture) = a 30-field synthetic capture repeated 20 times
+        nfr = 600
+        base = L.raw28_capture(30, 5, 3, 0)
+        capture = np.ascontiguousarray(np.tile(base[:30 * 477750], 20)[250000:])
+        dec = ntscsim.Raw28Decoder([], device=local_rank)
+        cap_dev = torch.from_numpy(capture).to(dev)
+        fr = torch.empty((nfr + 2, dec.height, dec.width * 4), dtype=torch.uint8, device=dev)
+        nout = dec.decode(cap_dev, fr)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            dec.decode(cap_dev, fr)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        st = dec.stats()
+        # CPU beside it: the reference text (oracle/_ref) or the port, first 12 fields of the same capture
+        sub = np.ascontiguousarray(capture[:14 * 477750])
+        t0 = time.perf_counter()
+        if L.have_raw28_ref():
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                ref_frames, _ = L.raw28_ref_run(L.raw28_oracle_opts(), sub, os.path.join(td, "cap.u8"))
+            kind = "reference"
+        else:
+            ref_frames, _ = L.raw28_oracle_run(L.raw28_oracle_opts(), sub)
+            kind = "port"
+        cpu_dt = time.perf_counter() - t0
+        ncmp = min(8, ref_frames.shape[0])
+        same = bool(np.array_equal(fr[:ncmp].cpu().numpy().reshape(ncmp, dec.height, -1), ref_frames[:ncmp]))
+        out["raw28"] = {"value": nout / dt, "unit": "fields/s", "ms_per_capture": dt * 1e3, "fields": nout,
+                        "workload": "ffmpeg_raw28ntsc decoder: synthetic %d-field capture at 8 x fsc (%.0f MB, 8 bit) "
+                                    "resident in HBM -> %d grey BGRA frames of %dx%d; whole call incl. the host's "
+                                    "sync walk" % (nfr, capture.size / 1e6, nout, dec.width, dec.height),
+                        "stats": st,
+                        "cpu_1core": {"value": ref_frames.shape[0] / cpu_dt, "kind": kind,
+                                      "sample": "%d fields of the same capture incl. the tool's start-up filter run" % ref_frames.shape[0]},
+                        "first_%d_fields_equal_cpu" % ncmp: same}
+        dec.close()
+        del cap_dev, fr
+    except Exception as e:
+        out["raw28_error"] = repr(e)
     # ---- other sizes / presets on the BGRA path
     out["sizes"] = {
         "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 60, 6),

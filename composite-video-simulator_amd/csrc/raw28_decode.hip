@@ -31,6 +31,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -79,6 +80,92 @@ __device__ __forceinline__ int front_step(FrontState &s, const FrontConst &K, do
     return x;
 }
 
+// The same arithmetic as front_step(), software-pipelined over four consecutive samples: in one step
+// low-pass 0 works on sample t, low-pass 1 on t-1, low-pass 2 on t-2 and the follower on t-3, each
+// reading what its predecessor produced one step earlier.  Four independent dependency chains per
+// step instead of one long one -- a lone wavefront per SIMD is latency-bound on this kernel.
+struct FrontPipe {
+    double p0, p1, p2, level;      // serial state (p_k = last output of low-pass k)
+    double r0, r1, r2;             // p_k - p_k * alpha, the part of the next update that is already known
+    double l0, l1, l2;             // outputs waiting for the next stage
+    __device__ __forceinline__ void load(const FrontState &s, const FrontConst &K)
+    {
+        p0 = s.p0; p1 = s.p1; p2 = s.p2; level = s.level;
+        r0 = p0 - (p0 * K.alpha); r1 = p1 - (p1 * K.alpha); r2 = p2 - (p2 * K.alpha);
+        l0 = l1 = l2 = 0;
+    }
+    __device__ __forceinline__ FrontState state() const { return FrontState{p0, p1, p2, level}; }
+    // stages; call order within a step is D, C, B, A so that each reads its predecessor's OLD output
+    __device__ __forceinline__ void A(const FrontConst &K, double x) { l0 = (x * K.alpha) + r0; p0 = l0; r0 = l0 - (l0 * K.alpha); }
+    __device__ __forceinline__ void B(const FrontConst &K) { l1 = (l0 * K.alpha) + r1; p1 = l1; r1 = l1 - (l1 * K.alpha); }
+    __device__ __forceinline__ void C(const FrontConst &K) { l2 = (l1 * K.alpha) + r2; p2 = l2; r2 = l2 - (l2 * K.alpha); }
+    __device__ __forceinline__ int D(const FrontConst &K)
+    {
+        const double lv = l2;
+        if (level > lv) level = (level * K.om_fast) + (lv * K.a_fast);
+        else level = (level * K.om_slow) + (lv * K.a_slow);
+        int x = (int)(lv - level);
+        return x < 0 ? 0 : (x > 255 ? 255 : x);
+    }
+};
+
+// samples [s0, s1) of the stream, s0 a multiple of 16; OUT: store hsync_dc_raw.  On return `st` is the
+// serial state after sample s1 - 1.
+template <bool OUT>
+__device__ __forceinline__ void front_span(FrontState &st, const FrontConst &K, const uint8_t *__restrict__ raw,
+                                           uint8_t *__restrict__ h, size_t s0, size_t s1)
+{
+    const size_t n = s1 - s0;
+    if (n < 12) {
+        for (size_t s = s0; s < s1; s++) { const int v = front_step(st, K, (double)raw[s]); if (OUT) h[s] = (uint8_t)v; }
+        return;
+    }
+    FrontPipe P;
+    P.load(st, K);
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const uint32_t *rw = (const uint32_t *)(raw + s0);
+    const v4 *rv = (const v4 *)(raw + s0);         // (s0 is a multiple of 16; raw is padded by 64 bytes)
+    uint32_t *hw = (uint32_t *)(h + s0);
+    v4 cur = rv[0], nxt = rv[1];
+    // fill: steps 0, 1, 2
+    P.A(K, (double)(cur.x & 0xFFu));
+    P.B(K); P.A(K, (double)((cur.x >> 8) & 0xFFu));
+    P.C(K); P.B(K); P.A(K, (double)((cur.x >> 16) & 0xFFu));
+    // steady: iteration q runs steps 4q+3 .. 4q+6 (all four stages busy) and completes output word q
+#define FRONT_ITER(W, WN, O)                                                                         \
+    O = (uint32_t)P.D(K); P.C(K); P.B(K); P.A(K, (double)((W) >> 24));                                \
+    O |= (uint32_t)P.D(K) << 8; P.C(K); P.B(K); P.A(K, (double)((WN) & 0xFFu));                       \
+    O |= (uint32_t)P.D(K) << 16; P.C(K); P.B(K); P.A(K, (double)(((WN) >> 8) & 0xFFu));               \
+    O |= (uint32_t)P.D(K) << 24; P.C(K); P.B(K); P.A(K, (double)(((WN) >> 16) & 0xFFu));
+    const size_t nq = (n - 3) / 4;                 // steps up to 4*nq + 2 <= n - 1 feed stage A
+    size_t q = 0;
+    for (size_t g = 0; 4 * (g + 1) <= nq; g++, q += 4) {      // 16 samples; the next 16 bytes are already on their way
+        const v4 nn = rv[g + 2];
+        v4 o;
+        FRONT_ITER(cur.x, cur.y, o.x)
+        FRONT_ITER(cur.y, cur.z, o.y)
+        FRONT_ITER(cur.z, cur.w, o.z)
+        FRONT_ITER(cur.w, nxt.x, o.w)
+        if (OUT) *(v4 *)(hw + q) = o;
+        cur = nxt; nxt = nn;
+    }
+    for (; q < nq; q++) {
+        const uint32_t w = rw[q], wn = rw[q + 1];
+        uint32_t o;
+        FRONT_ITER(w, wn, o)
+        if (OUT) hw[q] = o;
+    }
+#undef FRONT_ITER
+    // drain: the remaining steps one at a time (stage X handles sample t - X while that sample exists)
+    for (size_t t = 4 * nq + 3; t < n + 3; t++) {
+        if (t >= 3) { const int v = P.D(K); if (OUT) h[s0 + t - 3] = (uint8_t)v; }
+        if (t - 2 < n) P.C(K);
+        if (t - 1 < n) P.B(K);
+        if (t < n) P.A(K, (double)raw[s0 + t]);
+    }
+    st = P.state();
+}
+
 // round 0 (speculative, all chunks) and repair rounds (flagged chunks, start = predecessor's end)
 __global__ __launch_bounds__(64) void k_raw28_front(const uint8_t *__restrict__ raw, size_t N, uint8_t *__restrict__ h,
                                                     int chunk, int warm, int nchunks, FrontConst K, FrontState init,
@@ -95,34 +182,15 @@ __global__ __launch_bounds__(64) void k_raw28_front(const uint8_t *__restrict__ 
         st = prev_end[c - 1];                      // repair: the true state before this chunk (so far)
     } else if (s0 <= (size_t)warm) {
         st = init;                                 // from the start of the stream: exact
-        for (size_t s = 0; s < s0; s++) (void)front_step(st, K, (double)raw[s]);
+        front_span<false>(st, K, raw, h, 0, s0);
     } else {
-        const size_t w0 = s0 - (size_t)warm;
+        const size_t w0 = s0 - (size_t)warm;       // (warm and chunk are multiples of 16)
         const double r0 = (double)raw[w0];
         st.p0 = st.p1 = st.p2 = r0; st.level = 255.0;
-        // (warm and chunk are multiples of 4: whole words)
-        const uint32_t *rw = (const uint32_t *)(raw + w0);
-        for (int q = 0; q < warm / 4; q++) {
-            const uint32_t w = rw[q];
-            (void)front_step(st, K, (double)(w & 0xFFu));
-            (void)front_step(st, K, (double)((w >> 8) & 0xFFu));
-            (void)front_step(st, K, (double)((w >> 16) & 0xFFu));
-            (void)front_step(st, K, (double)(w >> 24));
-        }
+        front_span<false>(st, K, raw, h, w0, s0);
     }
     st_begin[c] = st;
-    const uint32_t *rw = (const uint32_t *)(raw + s0);
-    uint32_t *hw = (uint32_t *)(h + s0);
-    const int nfull = (int)((s1 - s0) / 4);
-    for (int q = 0; q < nfull; q++) {
-        const uint32_t w = rw[q];
-        uint32_t o = (uint32_t)front_step(st, K, (double)(w & 0xFFu));
-        o |= (uint32_t)front_step(st, K, (double)((w >> 8) & 0xFFu)) << 8;
-        o |= (uint32_t)front_step(st, K, (double)((w >> 16) & 0xFFu)) << 16;
-        o |= (uint32_t)front_step(st, K, (double)(w >> 24)) << 24;
-        hw[q] = o;
-    }
-    for (size_t s = s0 + (size_t)nfull * 4; s < s1; s++) h[s] = (uint8_t)front_step(st, K, (double)raw[s]);
+    front_span<true>(st, K, raw, h, s0, s1);
     st_end[c] = st;
 }
 
@@ -141,40 +209,61 @@ __global__ void k_raw28_links(const FrontState *__restrict__ st_begin, const Fro
     if (bad) atomicAdd(nbad, 1);
 }
 
-// ---- runs of h < thr: segment counts (starts in the low word, ends in the high word) | scan | scatter
-constexpr int SEG = 256;
-__device__ __forceinline__ bool below_at(const uint8_t *h, size_t s, size_t N, int thr) { return s < N && h[s] < thr; }
-
-__global__ void k_raw28_run_count(const uint8_t *__restrict__ h, size_t N, int thr, unsigned long long *__restrict__ cnt, size_t nseg)
+// ---- runs of h < thr.  A block looks at 4096 samples, 16 per thread as one 128-bit load turned into a
+// bit mask; run starts / ends are the 0->1 / 1->0 transitions of that mask.  Pass 1 counts them per
+// block (starts in the low word, ends in the high word), a device scan turns the counts into
+// offsets, pass 2 writes the positions in stream order.
+constexpr int RUN_T = 256, RUN_PER = 16, RUN_BLOCK = RUN_T * RUN_PER;
+__device__ __forceinline__ void run_masks(const uint8_t *__restrict__ h, size_t N, int thr, size_t s0,
+                                          uint32_t &starts, uint32_t &ends)
 {
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nseg) return;
-    const size_t s0 = g * SEG, s1 = s0 + SEG < N ? s0 + SEG : N;
-    bool prev = s0 > 0 && h[s0 - 1] < thr;
-    unsigned ns = 0, ne = 0;
-    for (size_t s = s0; s < s1; s++) {
-        const bool b = h[s] < thr;
-        ns += (b && !prev); ne += (!b && prev);
-        prev = b;
+    starts = ends = 0;
+    if (s0 >= N) return;
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 v = *(const v4 *)(h + s0);            // (h is allocated 16 bytes past N)
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t byte = (v[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        m |= (uint32_t)((int)byte < thr) << k;
     }
-    if (s1 == N && prev) ne++;                    // a run open at the end of the capture ends there
-    cnt[g] = (unsigned long long)ns | ((unsigned long long)ne << 32);
+    const uint32_t nvalid = N - s0 >= 16 ? 16u : (uint32_t)(N - s0);
+    const uint32_t valid = nvalid >= 16 ? 0xFFFFu : ((1u << nvalid) - 1u);
+    m &= valid;
+    const uint32_t prev = (s0 > 0 && h[s0 - 1] < thr) ? 1u : 0u;
+    const uint32_t sh = ((m << 1) | prev);
+    starts = m & ~sh & valid;
+    ends = ~m & sh & valid;
+    // a run still open at the end of the capture ends at N: bit `nvalid` (position N)
+    if (s0 + nvalid == N && ((m >> (nvalid - 1)) & 1u)) ends |= 1u << nvalid;
 }
-__global__ void k_raw28_run_scatter(const uint8_t *__restrict__ h, size_t N, int thr, const unsigned long long *__restrict__ off,
-                                    size_t nseg, uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend)
+__global__ __launch_bounds__(RUN_T) void k_raw28_run_count(const uint8_t *__restrict__ h, size_t N, int thr,
+                                                           unsigned long long *__restrict__ cnt)
 {
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nseg) return;
-    const size_t s0 = g * SEG, s1 = s0 + SEG < N ? s0 + SEG : N;
-    bool prev = s0 > 0 && h[s0 - 1] < thr;
-    uint32_t os = (uint32_t)(off[g] & 0xFFFFFFFFull), oe = (uint32_t)(off[g] >> 32);
-    for (size_t s = s0; s < s1; s++) {
-        const bool b = h[s] < thr;
-        if (b && !prev) rstart[os++] = (uint32_t)s;
-        if (!b && prev) rend[oe++] = (uint32_t)s;
-        prev = b;
-    }
-    if (s1 == N && prev) rend[oe++] = (uint32_t)N;
+    typedef hipcub::BlockReduce<unsigned long long, RUN_T> Red;
+    __shared__ typename Red::TempStorage tmp;
+    uint32_t st, en;
+    run_masks(h, N, thr, ((size_t)blockIdx.x * RUN_T + threadIdx.x) * RUN_PER, st, en);
+    const unsigned long long mine = (unsigned long long)__popc(st) | ((unsigned long long)__popc(en) << 32);
+    const unsigned long long tot = Red(tmp).Sum(mine);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(RUN_T) void k_raw28_run_scatter(const uint8_t *__restrict__ h, size_t N, int thr,
+                                                             const unsigned long long *__restrict__ off,
+                                                             uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend)
+{
+    typedef hipcub::BlockScan<unsigned long long, RUN_T> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    const size_t s0 = ((size_t)blockIdx.x * RUN_T + threadIdx.x) * RUN_PER;
+    uint32_t st, en;
+    run_masks(h, N, thr, s0, st, en);
+    const unsigned long long mine = (unsigned long long)__popc(st) | ((unsigned long long)__popc(en) << 32);
+    unsigned long long before;
+    Scan(tmp).ExclusiveSum(mine, before);
+    before += off[blockIdx.x];
+    uint32_t os = (uint32_t)(before & 0xFFFFFFFFull), oe = (uint32_t)(before >> 32);
+    while (st) { const int k = __ffs(st) - 1; st &= st - 1; rstart[os++] = (uint32_t)(s0 + k); }
+    while (en) { const int k = __ffs(en) - 1; en &= en - 1; rend[oe++] = (uint32_t)(s0 + k); }
 }
 
 // ---- calibration sums of the equalising pulses :661-676: one wave per range [si, i)
@@ -317,11 +406,12 @@ struct ntscsim_raw28 {
     int width, height, D;
     FrontConst K;
     FrontState init;
+    bool chunk_forced = false;
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
     // results of the last call
     double blank = 0, white = 192;
     uint64_t read_pos = 0;
-    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
+    int64_t stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t last_n = 0;
     // device scratch
     Buf<uint8_t> raw, h, tmp;
@@ -459,9 +549,9 @@ extern "C" void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *d, int warm_l
 {
     if (!d) return;
     if (warm_lines >= 0) d->warm_lines = warm_lines;
-    if (chunk_samples >= 64) d->chunk = (chunk_samples + 3) & ~3;
+    if (chunk_samples >= 64) { d->chunk = (chunk_samples + 15) & ~15; d->chunk_forced = true; }
 }
-extern "C" void ntscsim_raw28_debug_stats(const ntscsim_raw28 *d, int64_t out[6])
+extern "C" void ntscsim_raw28_debug_stats(const ntscsim_raw28 *d, int64_t out[12])
 {
     if (d && out) std::memcpy(out, d->stats, sizeof(d->stats));
 }
@@ -480,10 +570,12 @@ namespace {
 struct RunWalk {
     const uint32_t *rs, *re;
     size_t nruns;
+    mutable size_t k = 0;          // cursor: the searches move forward, or back by a fraction of a scanline
     // first run that ends after position i: [si, ei) clipped to i and E; si == ei == E when none
     void next(size_t i, size_t E, size_t &si, size_t &ei) const
     {
-        const size_t k = (size_t)(std::upper_bound(re, re + nruns, (uint32_t)std::min<size_t>(i, 0xFFFFFFFFu)) - re);
+        while (k > 0 && (size_t)re[k - 1] > i) k--;
+        while (k < nruns && (size_t)re[k] <= i) k++;
         if (k >= nruns || (size_t)rs[k] >= E) { si = ei = E; return; }
         si = std::max<size_t>(rs[k], i);
         ei = std::min<size_t>(re[k], E);
@@ -506,20 +598,26 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     d->blank = (uint8_t)0; d->white = (uint8_t)192; d->read_pos = 0;              // :553-554
     d->last_n = N;
 
+    // wall-clock split of the call (every phase ends in a stream synchronisation), stats[6..11] in us
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](int slot) {
+        const auto t = std::chrono::steady_clock::now();
+        d->stats[slot] += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(t - t_last).count();
+        t_last = t;
+    };
     // ---- (1) front end
-    const uint8_t *raw = (const uint8_t *)capture;
-    if (!on_device) {
-        R28CHK(d, d->raw.ensure(N + 16));
-        R28CHK(d, hipMemcpyAsync(d->raw.p, capture, N, hipMemcpyHostToDevice, st));
-        raw = d->raw.p;
-    } else if ((uintptr_t)capture & 3) {
-        R28CHK(d, d->raw.ensure(N + 16));
-        R28CHK(d, hipMemcpyAsync(d->raw.p, capture, N, hipMemcpyDeviceToDevice, st));
-        raw = d->raw.p;
-    }
-    R28CHK(d, d->h.ensure(N + 16));
-    const int chunk = d->chunk;
-    const int warm = (int)(((size_t)d->warm_lines * len + 3) & ~(size_t)3);
+    // the kernels read whole 16-byte pieces: a copy that is aligned and padded by 64 zero bytes
+    R28CHK(d, d->raw.ensure(N + 64));
+    R28CHK(d, hipMemcpyAsync(d->raw.p, capture, N, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    R28CHK(d, hipMemsetAsync(d->raw.p + N, 0, 64, st));
+    const uint8_t *raw = d->raw.p;
+    R28CHK(d, d->h.ensure(N + 64));
+    // one lane per chunk, and no more chunks than one wavefront per SIMD can hold (1,024 x 64): a lane's
+    // run is warm-up + chunk samples long whatever the chunk count, so a second wavefront per SIMD would
+    // only double the time
+    int chunk = d->chunk;
+    if (!d->chunk_forced && N / (size_t)chunk >= 65536) chunk = (int)((N / 65536 + 16) & ~(size_t)15);
+    const int warm = (int)(((size_t)d->warm_lines * len + 15) & ~(size_t)15);
     const int nchunks = (int)((N + (size_t)chunk - 1) / (size_t)chunk);
     R28CHK(d, d->counters.ensure(4));
     if (nchunks > 0) {
@@ -546,14 +644,14 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         }
     }
 
+    lap(6);
     // ---- (2) runs of h < thr
-    const size_t nseg = (N + SEG - 1) / SEG;
+    const size_t nseg = (N + RUN_BLOCK - 1) / RUN_BLOCK;
     std::vector<uint32_t> rs, re;
     if (nseg > 0) {
         R28CHK(d, d->segcnt.ensure(nseg + 1));
         R28CHK(d, d->segoff.ensure(nseg + 1));
-        hipLaunchKernelGGL(k_raw28_run_count, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d->h.p, N, d->K.thr,
-                           d->segcnt.p, nseg);
+        hipLaunchKernelGGL(k_raw28_run_count, dim3((unsigned)nseg), dim3(RUN_T), 0, st, d->h.p, N, d->K.thr, d->segcnt.p);
         R28CHK(d, hipMemsetAsync(d->segcnt.p + nseg, 0, sizeof(unsigned long long), st));
         size_t tmp_bytes = 0;
         R28CHK(d, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d->segcnt.p, d->segoff.p, (int)(nseg + 1), st));
@@ -567,8 +665,8 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         if (nruns > 0) {
             R28CHK(d, d->rstart.ensure(nruns));
             R28CHK(d, d->rend.ensure(nruns));
-            hipLaunchKernelGGL(k_raw28_run_scatter, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, st, d->h.p, N,
-                               d->K.thr, d->segoff.p, nseg, d->rstart.p, d->rend.p);
+            hipLaunchKernelGGL(k_raw28_run_scatter, dim3((unsigned)nseg), dim3(RUN_T), 0, st, d->h.p, N, d->K.thr,
+                               d->segoff.p, d->rstart.p, d->rend.p);
             rs.resize(nruns); re.resize(nruns);
             R28CHK(d, hipMemcpyAsync(rs.data(), d->rstart.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             R28CHK(d, hipMemcpyAsync(re.data(), d->rend.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -577,8 +675,10 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         d->stats[3] = (int64_t)nruns;
     }
 
+    lap(7);
     // ---- (3) the walk: field loop main() :1016-1030 around composite_layer()'s searches
-    const RunWalk W{rs.data(), re.data(), rs.size()};
+    RunWalk W;
+    W.rs = rs.data(); W.re = re.data(); W.nruns = rs.size();
     const size_t CAP = (size_t)len * 2048;                                        // open_src :353
     const size_t L30 = (size_t)(int)(len * 0.3), L06 = (size_t)(int)(len * 0.06), L02 = (size_t)(int)(len * 0.02);
     size_t Bw = 0, Rd = 0;                          // buffer begin, read position (absolute)
@@ -649,6 +749,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     d->stats[5] = (int64_t)cal.size();
     *n_fields = nf;
 
+    lap(8);
     // ---- (4) black / white levels :661-688: sums on the GPU, the eight-tap recurrence here
     std::vector<CalSums> sums(cal.size());
     if (!cal.empty()) {
@@ -678,6 +779,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         }
     }
 
+    lap(9);
     // ---- (5) comb tails to their fixed point, then every scanline at once
     for (int f = 0; f < nf; f++)
         R28CHK(d, hipMemsetAsync((uint8_t *)frames_dev + (size_t)f * frame_stride, 0, (size_t)linesize * (size_t)d->height, st));
@@ -697,29 +799,35 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
             R28CHK(d, hipMemsetAsync(d->tails_a.p, 0, (size_t)nlines * 16 * sizeof(int), st));
             R28CHK(d, hipMemsetAsync(d->tails_b.p, 0, (size_t)nlines * 16 * sizeof(int), st));
             int *tin = d->tails_a.p, *tout = d->tails_b.p;
-            for (int round = 0;; round++) {
+            for (int round = 0;;) {
                 // round r: tout(y) = G(samples of y, tin(y-1)); it ends when tout == tin everywhere, i.e.
-                // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = 0: the serial result
-                R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
-                hipLaunchKernelGGL(k_raw28_tails, dim3((nlines + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
-                                   nlines, RC, (const int *)tin, tout, d->counters.p);
+                // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = 0: the serial result.  Four rounds
+                // are enqueued between two looks at the counter of the last one.
+                for (int b4 = 0; b4 < 4; b4++, round++) {
+                    R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
+                    hipLaunchKernelGGL(k_raw28_tails, dim3((nlines + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
+                                       nlines, RC, (const int *)tin, tout, d->counters.p);
+                    d->stats[2]++;
+                    std::swap(tin, tout);
+                }
                 int nch = 0;
                 R28CHK(d, hipMemcpyAsync(&nch, d->counters.p, sizeof(int), hipMemcpyDeviceToHost, st));
                 R28CHK(d, hipStreamSynchronize(st));
-                d->stats[2]++;
-                std::swap(tin, tout);
                 if (nch == 0) break;
-                if (round > nlines + 2) { d->err = "comb tails did not settle"; return NTSCSIM_E_INTERNAL; }
+                if (round > nlines + 8) { d->err = "comb tails did not settle"; return NTSCSIM_E_INTERNAL; }
             }
             // both arrays now hold the fixed point
             tails = tin;
         }
+        R28CHK(d, hipStreamSynchronize(st));
+        lap(10);
         const size_t lds = (size_t)3 * (len + 16) * sizeof(int);
         hipLaunchKernelGGL(k_raw28_render, dim3((unsigned)nlines), dim3(256), lds, st, raw, d->h.p, N, d->lines.p, RC,
                            (const int *)tails, (uint8_t *)frames_dev, frame_stride, linesize);
     }
     R28CHK(d, hipGetLastError());
     R28CHK(d, hipStreamSynchronize(st));
+    lap(11);
     return NTSCSIM_OK;
 }
 

@@ -480,9 +480,11 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
 /* Test hooks.  warm-up scanlines of the speculative front end (default 112; 0 forces every chunk
  * through the exact repair rounds) and chunk size in samples (default 4096); results must not
  * change.  stats: [0] front-end repair rounds, [1] chunks repaired, [2] comb-tail rounds,
- * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call. */
+ * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call; [6..11] wall-clock
+ * microseconds of its phases: front end, run extraction, sync walk, level calibration, comb tails
+ * (incl. clearing the frames), rendering. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
-void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[6]);
+void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[12]);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */
 int  ntscsim_raw28_debug_read_front(ntscsim_raw28 *dec, uint8_t *hsync_dc_raw, size_t n);
 
