@@ -146,6 +146,10 @@ if e2e:
         rd += "`ntsc_cli -vhs -i bars:3000 -o null:` %.0f fields/s (`end_to_end.cli`).  " % e2e["cli"]
 if "variant422" in d:
     rd += "YUV422P tool: %.0f frames/s.  " % d["variant422"]["value"]
+if "raw28" in d:
+    r28 = d["raw28"]
+    rd += "Raw-composite decoder (`raw28`): %d fields in %.1f ms = %.0f fields/s (phases in `raw28.stats`, us); reference text on one host core %.0f fields/s.  " % (
+        r28["fields"], r28["ms_per_capture"], r28["value"], r28["cpu_1core"]["value"])
 if "sizes" in d:
     rd += "1920x1080: %.0f, 3840x2160: %.0f frames/s.  " % (d["sizes"]["1920x1080"]["value"], d["sizes"]["3840x2160"]["value"])
 if "presets" in d:
