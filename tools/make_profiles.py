@@ -130,6 +130,10 @@ rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VAL
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (
     d["value"], d["steps"], d["ms_per_step"], d.get("value_sustained", 0), d.get("sustained", {}).get("seconds", 0))
+drv = "gpurun_out/bench_%s_driver_cmd.json" % tag
+if os.path.exists(drv) and os.path.getsize(drv) > 10:
+    dj = json.load(open(drv))
+    rd += "With the driver's own window (`python bench.py --gpus 1 --steps 20 --warmup 5`, `%s_bench_driver_cmd.json`): %.0f frames/s -- 20 steps with four in flight include the pipeline's fill and drain.  " % (tag, dj["value"])
 rd += "`roofline.frac` = %.3f (k_decode, algorithmic HBM bytes / 8 TB/s); `roofline.valu.path_frac` = %.2f (cycle-weighted VALU issue, the bound that applies).  " % (
     d["roofline"]["frac"], v.get("path_frac", 0))
 cb = d.get("cpu_baseline", {})

@@ -15,6 +15,8 @@ if [ "$mode" = gpu ]; then
   timeout 120 tools/bin/chain_probe > gpurun_out/chain_probe_$tag.txt 2>&1
   timeout 500 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
   timeout 200 python bench.py --mode fast32 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_fast32.json 2>> gpurun_out/bench_$tag.err
+  # the command the driver runs at round end (its own K / W)
+  timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_driver_cmd.json 2>> gpurun_out/bench_$tag.err
   timeout 500 bash tools/pmc422.sh pmc422_$tag > /dev/null 2>&1
   timeout 250 tools/kstats.sh ks_${tag}_tocomp --tool to_composite --inflight 1 --steps 20 --sustain-seconds 0 > /dev/null
   timeout 300 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
@@ -31,4 +33,5 @@ else
       gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
       gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
       gpurun_out/pmc422_$tag > /dev/null && echo "profiles/ assembled"
+  [ -s gpurun_out/bench_${tag}_driver_cmd.json ] && cp gpurun_out/bench_${tag}_driver_cmd.json profiles/${tag}_bench_driver_cmd.json
 fi
