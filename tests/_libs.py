@@ -405,7 +405,7 @@ class Raw28OracleOpts(C.Structure):       # struct raw28_opts (oracle/raw28_orac
 
 def raw28_oracle_opts(sample_rate=0.0, **kw):
     o = Raw28OracleOpts()
-    o.sample_rate = sample_rate
+    o.sample_rate = float(sample_rate)
     for k, v in kw.items():
         assert k in RAW28_FLAGS
         setattr(o, k, int(v))
@@ -488,10 +488,14 @@ def raw28_ref_run(opts, capture, path, max_fields=64):
         f.write(capture.tobytes())
     w, h, sl = C.c_int(), C.c_int(), C.c_int()
     b, wh, rp = C.c_double(), C.c_double(), C.c_ulonglong()
-    out = np.zeros((max_fields, 262, 1820 * 4), np.uint8)
+    # frame size of this sample rate (compute_NTSC :247-256, preset_NTSC :395-402)
+    rate = opts.sample_rate if opts.sample_rate > 0 else (315000000.00 * 8.0) / 88.00
+    length = int((rate / (30000.00 / 1001.00)) / 525.00 + 0.5)
+    width = (length + 1) & ~1
+    out = np.zeros((max_fields, 262, width * 4), np.uint8)
     n = _raw28_ref.raw28_ref_run(C.byref(opts), str(path).encode(), out.ctypes.data, max_fields, C.byref(w),
                                  C.byref(h), C.byref(sl), C.byref(b), C.byref(wh), C.byref(rp))
-    assert n >= 0 and (w.value, h.value) == (1820, 262)
+    assert n >= 0 and (w.value, h.value, sl.value) == (width, 262, length)
     return out[:n], (b.value, wh.value, rp.value)
 
 
