@@ -1,0 +1,49 @@
+"""bench.py's output contract on a small workload (GPU): one JSON line with the keys the driver
+reads, `roofline` and `cpu_baseline` objects, for both tools."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _run(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--frames", "12", "--sustain-seconds", "0.05"] + extra
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_primary_tool():
+    d = _run(["--cpu-fields", "6", "--cpu-mt-fields", "0", "--no-extras"])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["value"] > 0 and abs(d["value"] - 24 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["algorithmic_bytes_per_launch"] == 8 * 720 * 243 * 24
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 0
+    assert "workload" in d["config"] and d["value_sustained"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_to_composite_tool():
+    d = _run(["--tool", "to_composite", "--cpu-fields", "6"])
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["config"]["tool"] == "to_composite" and d["roofline"]["kernel"] == "k422_fused"
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 4 * 720 * 243 * 24
+    assert d["cpu_baseline"]["value"] > 0 and d["value"] > 0
