@@ -394,12 +394,23 @@ def extras(torch, ntscsim, dev, local_rank, args):
             sim.frames_host(d, s_, first_fieldno=0, chunk_frames=32, **kw)
             best = max(best, 2 * n / (time.perf_counter() - t0))
         e2e[name] = best
+    # ---- the 1:1 drop-in: one composite_layer() call per ntscsim_field() call, host frames in and out
+    one_dst = np.zeros((h, w, 4), np.uint8)
+    sim.rng_pos = 0
+    for k in range(4):
+        sim.field_host(one_dst, one, (k & 1) ^ 1, k)
+    t0 = time.perf_counter()
+    nfc = 200
+    for k in range(nfc):
+        sim.field_host(one_dst, one, (k & 1) ^ 1, k)
+    e2e["field_call"] = nfc / (time.perf_counter() - t0)
     sim.close()
     e2e["unit"] = "frames/s"
     e2e["note"] = ("ntscsim_frames_host: %d host frames in, %d bob frames out through H2D | kernels | D2H "
                    "on three streams, chunks of 32 frames; pageable = the call pins the caller's buffers "
                    "in place first; yuv420p = the encoder's pixel format made on the GPU (1.5 B/pixel "
-                   "back instead of 4)" % (n, 2 * n))
+                   "back instead of 4); field_call = ntscsim_field(), the synchronous one-field-per-call drop-in "
+                   "for composite_layer() on pageable host frames (upload, three kernels on 4 wavefronts, download)" % (n, 2 * n))
     # ---- the ffmpeg_ntsc-compatible command line host (synthetic source, discarded output)
     cli = os.path.join(ROOT, "composite-video-simulator_amd", "ntsc_cli")
     if os.path.exists(cli) and (w, h) == (720, 486):

@@ -146,6 +146,8 @@ if cb:
 if e2e:
     rd += "PCIe-inclusive (`end_to_end`, never `value`): BGRA out %.0f frames/s (pinned caller buffers), %.0f (pageable, pinned in place by the call), YUV420P out %.0f.  " % (
         e2e.get("bgra_pinned", 0), e2e.get("bgra_pageable", 0), e2e.get("yuv420p_pinned", 0))
+    if e2e.get("field_call"):
+        rd += "One field per `ntscsim_field()` call (the 1:1 drop-in, synchronous, pageable host frames): %.0f fields/s.  " % e2e["field_call"]
     if e2e.get("cli"):
         rd += "`ntsc_cli -vhs -i bars:3000 -o null:` %.0f fields/s (`end_to_end.cli`).  " % e2e["cli"]
 if "variant422" in d:

@@ -14,6 +14,7 @@ cb, e = d["cpu_baseline"], d["end_to_end"]
 r28 = d.get("raw28")
 raw28 = ("  The raw-composite decoder (`ffmpeg_raw28ntsc`, `raw28`): a 600-field capture resident in HBM decodes at "
          "%.1fk fields/s (the reference text on one host core: %.0f)." % (r28["value"] / 1e3, r28["cpu_1core"]["value"])) if r28 else ""
+fcall = ("  One field per synchronous `ntscsim_field()` call (the 1:1 drop-in on host frames): %.0f fields/s." % e["field_call"]) if e.get("field_call") else ""
 cli = ("  The raw-file CLI `ntsc_cli -vhs -i bars:3000 -o null:` runs at %.0fk fields/s (`end_to_end.cli`)." % (e["cli"] / 1e3)) if e.get("cli") else ""
 new = ("Round-2 numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` preset, exact mode; every figure is\n"
        "a key of `profiles/%s_bench.json`, the line `python bench.py` prints; `profiles/README.md` maps the\n"
@@ -28,13 +29,13 @@ new = ("Round-2 numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` prese
        "%.2f of the cycle-weighted VALU issue capacity (PMC instruction counts × the measured issue cost of\n"
        "each kernel's instruction mix ÷ measured time) — see `profiles/README.md` and DESIGN.md §5 for what\n"
        "was measured and what is derived.  PCIe-inclusive (`end_to_end`, `ntscsim_frames_host`): %.0fk\n"
-       "fields/s BGRA out, %.0fk with YUV420P made on the GPU.%s%s  Optional `NTSCSIM_MODE_FAST32` (fp32 filters,\n"
+       "fields/s BGRA out, %.0fk with YUV420P made on the GPU.%s%s%s  Optional `NTSCSIM_MODE_FAST32` (fp32 filters,\n"
        "≤1 LSB, not bit-exact): %dk fields/s (`profiles/%s_bench_fast32.json`).\n\n" % (
            tag, round(d["value"] / 1e3), d["steps"], round(d["value_sustained"] / 1e3), cb["value"], cb["port_1core"],
            round(cb["port_all_cores"]["value"]), cb["port_all_cores"]["cores"],
            d["sizes"]["1920x1080"]["value"] / 1e3, d["sizes"]["3840x2160"]["value"] / 1e3,
            round(d["presets"]["default"]["value"] / 1e3), tag, round(t["value"] / 1e3), d["roofline"]["frac"],
-           d["roofline"]["valu"]["path_frac"], e["bgra_pinned"] / 1e3, e["yuv420p_pinned"] / 1e3, cli, raw28,
+           d["roofline"]["valu"]["path_frac"], e["bgra_pinned"] / 1e3, e["yuv420p_pinned"] / 1e3, fcall, cli, raw28,
            round(f["value"] / 1e3), tag))
 open("README.md", "w").write(s[:a] + new + s[b:])
 print(new)
