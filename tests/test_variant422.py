@@ -323,6 +323,37 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w", [16, 18, 30, 62, 64, 66, 126, 722])
+@pytest.mark.parametrize("pad", [0, 3, 16])
+def test_fused_kernel_widths_and_row_alignments(w, pad):
+    """-vhs (the preset instantiation of the four-sweep kernel) at widths around its 16 / 64-sample
+    block sizes, with row paddings that make luma / chroma rows 16- / 8-byte aligned or not."""
+    import torch
+    h, n = 10, 3
+    p = L.make_params_tocomp(["-vhs"])
+    srcs = [cases422.make_source422("noise", w, h, j + 31 + w, pad) for j in range((n + 1) // 2)]
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    frame = srcs[0].copy()
+    mask = last_row_margin_mask(frame, pad)
+    sim = ntscsim.FieldSimulator(params=p)
+    whole, dev = to_dev_onebuf(torch, frame)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        refresh(frame, srcs[k // 2], field)
+        o.process(frame, field, k)
+        _, srcd = to_dev_onebuf(torch, srcs[k // 2])
+        sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
+        sim.sync()
+        got = whole.cpu().numpy()
+        bad = (got != frame.buf) & mask
+        assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
+        if pad < 2:
+            frame.buf[~mask] = got[~mask]
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
 def test_hip_batch_of_fields_full_size():
     """720x480 -vhs, 8 fields in ONE batch (each field its own frame), explicit rand() positions."""
     import torch
