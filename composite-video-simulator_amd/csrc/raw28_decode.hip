@@ -267,7 +267,7 @@ __global__ __launch_bounds__(RUN_T) void k_raw28_run_scatter(const uint8_t *__re
 }
 
 // ---- calibration sums of the equalising pulses :661-676: one wave per range [si, i)
-struct CalRange { uint32_t si, i; };
+struct CalRange { uint32_t si, i, pulse, _pad; };   // samples [si, i) of the stream, summed into pulse `pulse`
 struct CalSums { int mina, mind, maxa, maxd; };
 __device__ __forceinline__ int raw_delayed(const uint8_t *raw, const uint8_t *h, size_t s, int D, int thr, int mark)
 {
@@ -411,7 +411,7 @@ struct ntscsim_raw28 {
     // results of the last call
     double blank = 0, white = 192;
     uint64_t read_pos = 0;
-    int64_t stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t last_n = 0;
     // device scratch
     Buf<uint8_t> raw, h, tmp;
@@ -551,7 +551,7 @@ extern "C" void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *d, int warm_l
     if (warm_lines >= 0) d->warm_lines = warm_lines;
     if (chunk_samples >= 64) { d->chunk = (chunk_samples + 15) & ~15; d->chunk_forced = true; }
 }
-extern "C" void ntscsim_raw28_debug_stats(const ntscsim_raw28 *d, int64_t out[12])
+extern "C" void ntscsim_raw28_debug_stats(const ntscsim_raw28 *d, int64_t out[16])
 {
     if (d && out) std::memcpy(out, d->stats, sizeof(d->stats));
 }
@@ -579,6 +579,45 @@ struct RunWalk {
         if (k >= nruns || (size_t)rs[k] >= E) { si = ei = E; return; }
         si = std::max<size_t>(rs[k], i);
         ei = std::min<size_t>(re[k], E);
+    }
+};
+
+// What the tool's sample buffer holds (:264-357): which stream position every record of the array was
+// last filled from.  Only the calibration sums of :661-676 can run past the filled part (the search
+// position jumps 0.3 scanlines ahead of a pulse, :655), and there they read whatever the records held
+// before -- samples of an earlier window after the buffer has been moved down, zero-initialised
+// records (hsync_dc_raw 0, raw 0) while the array has never been full.
+struct BufMap {
+    struct Seg { size_t k0, k1, abs0; };           // records [k0, k1) hold samples abs0 + (k - k0)
+    std::vector<Seg> segs;                         // sorted, disjoint
+    void assign(size_t k0, size_t k1, size_t abs0)
+    {
+        if (k0 >= k1) return;
+        std::vector<Seg> out;
+        for (const Seg &g : segs) {
+            if (g.k1 <= k0 || g.k0 >= k1) { out.push_back(g); continue; }
+            if (g.k0 < k0) out.push_back(Seg{g.k0, k0, g.abs0});
+            if (g.k1 > k1) out.push_back(Seg{k1, g.k1, g.abs0 + (k1 - g.k0)});
+        }
+        out.push_back(Seg{k0, k1, abs0});
+        std::sort(out.begin(), out.end(), [](const Seg &a, const Seg &b) { return a.k0 < b.k0; });
+        segs.swap(out);
+    }
+    // records [k0, k1): stream pieces through `piece(abs_begin, abs_end)`, returns the number of records
+    // that were never filled
+    template <class F>
+    size_t lookup(size_t k0, size_t k1, F piece) const
+    {
+        size_t zeros = 0, k = k0;
+        for (const Seg &g : segs) {
+            if (g.k1 <= k || g.k0 >= k1) continue;
+            if (g.k0 > k) { zeros += g.k0 - k; k = g.k0; }
+            const size_t e = std::min(g.k1, k1);
+            piece(g.abs0 + (k - g.k0), g.abs0 + (e - g.k0));
+            k = e;
+        }
+        if (k < k1) zeros += k1 - k;
+        return zeros;
     }
 };
 
@@ -681,14 +720,20 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     W.rs = rs.data(); W.re = re.data(); W.nruns = rs.size();
     const size_t CAP = (size_t)len * 2048;                                        // open_src :353
     const size_t L30 = (size_t)(int)(len * 0.3), L06 = (size_t)(int)(len * 0.06), L02 = (size_t)(int)(len * 0.02);
-    size_t Bw = 0, Rd = 0;                          // buffer begin, read position (absolute)
+    size_t Bw = 0, Rd = 0, Ew = 0;                  // buffer begin, read position, buffer end (absolute)
+    BufMap bm;
     std::vector<LineRec> lines;
-    std::vector<CalRange> cal;                     // calibration ranges in order
-    std::vector<int> cal_field;                    // number of ranges seen before each field is rendered
+    std::vector<CalRange> cal;                     // pieces of the calibration ranges, in pulse order
+    std::vector<int> cal_zero;                     // per pulse: never-filled records inside its range
+    std::vector<int> cal_field;                    // number of pulses seen before each field is rendered
     int nf = 0;
     while (nf < max_fields) {
-        if (Rd - Bw > CAP / 2u) Bw = Rd;           // lazy_flush_src :329 (twice per field, idempotent)
+        if (Rd - Bw > CAP / 2u) {                  // lazy_flush_src :329 -> flush_src :290 (twice per field, idempotent)
+            bm.assign(0, Ew - Rd, Rd);             // memmove: the live records move to the front, the rest stays
+            Bw = Rd;
+        }
         const size_t E = std::min(N, Bw + CAP);    // refill_src :307
+        if (E > Ew) { bm.assign(Ew - Bw, E - Bw, Ew); Ew = E; }
         if (E - Rd < (size_t)len * 256) break;     // main :1021
         if (!d->o.disable_sync) {                  // :622-693
             size_t i = Rd;
@@ -702,12 +747,23 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
                 else if (synclen >= L06) { if (vsb >= 9) { Rd = si + synclen / 2; break; } }
                 else if (synclen >= L02) {
                     i = si + L30; if (i < ei) i = ei; vsb++;
-                    // (the tool sums records up to i even past the end of the buffered stream; we stop at E)
-                    cal.push_back(CalRange{(uint32_t)si, (uint32_t)std::min(i, E)});
+                    const uint32_t pulse = (uint32_t)cal_zero.size();
+                    cal.push_back(CalRange{(uint32_t)si, (uint32_t)std::min(i, E), pulse, 0});
+                    size_t zeros = 0;
+                    if (i > E) {                   // records past the buffered stream: what the array still holds
+                        const size_t k1 = std::min(i - Bw, CAP);          // (past the array itself: undefined in the tool, zero here)
+                        zeros = (i - Bw) - k1;
+                        if (E - Bw < k1)
+                            zeros += bm.lookup(E - Bw, k1, [&](size_t a, size_t b) {
+                                cal.push_back(CalRange{(uint32_t)a, (uint32_t)b, pulse, 0});
+                            });
+                    }
+                    if (i > E) { d->stats[12]++; d->stats[13] += (int64_t)zeros; }
+                    cal_zero.push_back((int)zeros);
                 }
             }
         }
-        cal_field.push_back((int)cal.size());
+        cal_field.push_back((int)cal_zero.size());
         size_t scan = Rd;
         const size_t start = Rd;
         for (unsigned y = 0; y < (unsigned)d->height && (scan + (size_t)len * 2) < E; y++) {      // :700
@@ -746,21 +802,27 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     }
     d->read_pos = Rd;
     d->stats[4] = (int64_t)lines.size();
-    d->stats[5] = (int64_t)cal.size();
+    d->stats[5] = (int64_t)cal_zero.size();
     *n_fields = nf;
 
     lap(8);
     // ---- (4) black / white levels :661-688: sums on the GPU, the eight-tap recurrence here
-    std::vector<CalSums> sums(cal.size());
+    std::vector<CalSums> sums(cal_zero.size(), CalSums{0, 0, 0, 0});
     if (!cal.empty()) {
+        std::vector<CalSums> part(cal.size());
         R28CHK(d, d->cal_rg.ensure(cal.size()));
         R28CHK(d, d->cal_out.ensure(cal.size()));
         R28CHK(d, hipMemcpyAsync(d->cal_rg.p, cal.data(), cal.size() * sizeof(CalRange), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_raw28_cal, dim3((unsigned)cal.size()), dim3(64), 0, st, raw, d->h.p, d->cal_rg.p,
                            d->cal_out.p, d->D, d->K.thr, d->o.mark_sync ? 1 : 0);
-        R28CHK(d, hipMemcpyAsync(sums.data(), d->cal_out.p, cal.size() * sizeof(CalSums), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipMemcpyAsync(part.data(), d->cal_out.p, cal.size() * sizeof(CalSums), hipMemcpyDeviceToHost, st));
         R28CHK(d, hipStreamSynchronize(st));
+        for (size_t k = 0; k < cal.size(); k++) {
+            CalSums &t = sums[cal[k].pulse];
+            t.mina += part[k].mina; t.mind += part[k].mind; t.maxa += part[k].maxa; t.maxd += part[k].maxd;
+        }
     }
+    for (size_t k = 0; k < cal_zero.size(); k++) sums[k].mind += cal_zero[k];   // zero records: below threshold, raw 0
     {
         size_t ci = 0, li = 0;
         for (int f = 0; f < nf; f++) {

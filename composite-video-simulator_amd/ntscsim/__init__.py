@@ -349,10 +349,11 @@ class Raw28Decoder:
         self._lib.ntscsim_raw28_debug_set_speculation(self._h, int(warm_lines), int(chunk_samples))
 
     def stats(self):
-        a = (C.c_int64 * 12)()
+        a = (C.c_int64 * 16)()
         self._lib.ntscsim_raw28_debug_stats(self._h, a)
         return dict(zip(("front_rounds", "chunks_repaired", "tail_rounds", "sync_runs", "scanlines", "cal_pulses",
-                         "us_front", "us_runs", "us_walk", "us_levels", "us_tails", "us_render"), list(a)))
+                         "us_front", "us_runs", "us_walk", "us_levels", "us_tails", "us_render",
+                         "pulses_past_stream", "zero_records"), list(a)))
 
     def read_front(self, n):
         import numpy as np

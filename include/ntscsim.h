@@ -438,9 +438,10 @@ void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
  *   equalising pulses, then per scanline: level equalisation, delay-4 comb luma / chroma split,
  *   rendering, horizontal re-sync;  field loop main() :1016-1047.
  * One ntscsim_raw28_decode*() call = one run of the tool on one input file: the decoder state
- * starts from the tool's initial state every call.  Results are bit-identical to the tool's except
- * where the tool itself reads buffer records past the end of the capture (only possible while it
- * searches for a vertical sync that the last 256 scanlines do not contain).
+ * starts from the tool's initial state every call.  Results are bit-identical to the tool's, including
+ * where its calibration sums run past the buffered part of the capture into stale or never-filled
+ * records of its sample buffer (:655-676); only reads past the END of that array (undefined in the
+ * tool) are defined here, as zero records.
  */
 typedef struct ntscsim_raw28_opts {
     uint32_t struct_size;            /* sizeof(ntscsim_raw28_opts)                               */
@@ -482,9 +483,10 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * change.  stats: [0] front-end repair rounds, [1] chunks repaired, [2] comb-tail rounds,
  * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call; [6..11] wall-clock
  * microseconds of its phases: front end, run extraction, sync walk, level calibration, comb tails
- * (incl. clearing the frames), rendering. */
+ * (incl. clearing the frames), rendering; [12] calibration pulses whose sums ran past the buffered
+ * stream, [13] never-filled records among them. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
-void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[12]);
+void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */
 int  ntscsim_raw28_debug_read_front(ntscsim_raw28 *dec, uint8_t *hsync_dc_raw, size_t n);
 

@@ -32,6 +32,29 @@ CASES = [
 CAPTURES = {"clean": (5, 1, 0, 0), "noisy_cut": (6, 7, 4, 123457), "long": (13, 3, 2, 600001)}
 
 
+def _odd_capture(kind):
+    """Captures that drive the tool into the corners of its sample buffer: no vertical sync in the
+    last scanlines and an equalising-length pulse right at the end of the data, so that the
+    calibration sums (:661-676) run past the buffered stream -- into never-filled records (short
+    capture) or into stale records of an earlier window (capture longer than the buffer); random
+    bytes; a constant."""
+    if kind in ("tail_short", "tail_long"):
+        base = L.raw28_capture(3 if kind == "tail_short" else 10, 21, 2, 0)
+        line = base[(9 + 100) * 1820:(9 + 101) * 1820]
+        tail = np.concatenate([np.tile(line, 330), np.full(73, 18, np.uint8), np.full(90, 62, np.uint8)])
+        return np.ascontiguousarray(np.concatenate([base, tail]))
+    if kind == "random":
+        return np.random.RandomState(5).randint(0, 256, 1820 * 900, dtype=np.uint8)
+    if kind == "random_low":
+        return (np.random.RandomState(6).randint(0, 64, 1820 * 700) + 10).astype(np.uint8)
+    if kind == "constant":
+        return np.full(1820 * 600, 100, np.uint8)
+    raise KeyError(kind)
+
+
+ODD = ["tail_short", "tail_long", "random", "random_low", "constant"]
+
+
 def _digest(frames, levels):
     h = hashlib.sha256()
     h.update(np.ascontiguousarray(frames).tobytes())
@@ -53,6 +76,18 @@ def test_oracle_equals_reference_extract(c, cap, tmp_path):
     assert got.shape == want.shape and got.shape[0] >= (CAPTURES[cap][0] - 2) * (1 if "sample_rate" not in c[1] else 0.5)
     assert np.array_equal(got, want)
     assert lv == lv2
+
+
+@pytest.mark.skipif(not L.have_raw28_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("kind", ODD)
+def test_oracle_equals_reference_extract_on_odd_captures(kind, tmp_path):
+    capture = _odd_capture(kind)
+    for kw in ({}, {"mark_sync": 1}):
+        opts = L.raw28_oracle_opts(**kw)
+        got, lv = L.raw28_oracle_run(opts, capture)
+        want, lv2 = L.raw28_ref_run(opts, capture, tmp_path / "cap.u8")
+        assert got.shape == want.shape and got.shape[0] >= 1
+        assert np.array_equal(got, want) and lv == lv2
 
 
 @pytest.mark.skipif(not L.have_raw28_ref(), reason="oracle/_ref not built (no /root/reference)")
@@ -126,6 +161,24 @@ def test_hip_equals_oracle(c, cap):
     assert not bad, (bad, st)
     assert lv2 == lv
     dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ODD)
+def test_hip_equals_oracle_on_odd_captures(kind):
+    """incl. the records the tool reads past the buffered stream (never filled / stale)"""
+    capture = _odd_capture(kind)
+    for kw, flags in (({}, []), ({"mark_sync": 1}, ["-marksig"])):
+        want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(**kw), capture)
+        got, lv2, st, dec = _hip_run(flags, capture)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        assert np.array_equal(got, want), st
+        assert lv2 == lv, (lv2, lv, st)
+        if kind == "tail_short":
+            assert st["pulses_past_stream"] >= 1 and st["zero_records"] > 0, st        # never-filled records
+        if kind == "tail_long":
+            assert st["pulses_past_stream"] >= 1 and st["zero_records"] == 0, st       # stale records of an earlier window
+        dec.close()
 
 
 @pytest.mark.gpu
