@@ -123,14 +123,17 @@ DEV void load_block16(const uint8_t *row, int x0, int n, bool al16, uint32_t (&w
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const v4 v = *(__attribute__((address_space(1))) const v4 *)(row + x0);
         w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint32_t a = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) { const int x = x0 + 4 * q + b; if (x < n) a |= (uint32_t)((g_cu8)row)[x] << (8 * b); }
-            w[q] = a;
+    } else {                                       // row ends and unaligned rows: byte by byte (kept as a loop: small code)
+        uint32_t a[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int b = 0; b < 16; b++) {
+            const int x = x0 + b;
+            const uint32_t v = x < n ? (uint32_t)((g_cu8)row)[x] : 0u;
+            const uint32_t sh = v << (8 * (b & 3));
+            a[0] |= (b >> 2) == 0 ? sh : 0u; a[1] |= (b >> 2) == 1 ? sh : 0u;
+            a[2] |= (b >> 2) == 2 ? sh : 0u; a[3] |= (b >> 2) == 3 ? sh : 0u;
         }
+        w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3];
     }
 }
 DEV void load_block8(const uint8_t *row, int x0, int n, bool al8, uint32_t (&w)[2])
@@ -140,13 +143,15 @@ DEV void load_block8(const uint8_t *row, int x0, int n, bool al8, uint32_t (&w)[
         const v2 v = *(__attribute__((address_space(1))) const v2 *)(row + x0);
         w[0] = v.x; w[1] = v.y;
     } else {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            uint32_t a = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) { const int x = x0 + 4 * q + b; if (x < n) a |= (uint32_t)((g_cu8)row)[x] << (8 * b); }
-            w[q] = a;
+        uint32_t a0 = 0, a1 = 0;
+#pragma unroll 1
+        for (int b = 0; b < 8; b++) {
+            const int x = x0 + b;
+            const uint32_t v = x < n ? (uint32_t)((g_cu8)row)[x] : 0u;
+            const uint32_t sh = v << (8 * (b & 3));
+            a0 |= b < 4 ? sh : 0u; a1 |= b < 4 ? 0u : sh;
         }
+        w[0] = a0; w[1] = a1;
     }
 }
 DEV int byte_of(uint32_t w, int b) { return (int)((w >> (8 * b)) & 0xFFu); }
@@ -169,13 +174,13 @@ struct ChromaLpFull {
 // ---------------------------------------------------------------------------------- sweep A
 // Stream index m = the chroma sample being modulated; the low-passes run D = 4 (NTSC: the V delay)
 // or 2 (PAL) samples ahead of it.
-template <bool NTSC>
+template <bool NTSC, bool ALIGNED>
 DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
                  int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q)
 {
     constexpr int D = NTSC ? 4 : 2, DU = 2, DV = NTSC ? 4 : 2;
     const int W2 = W / 2;
-    const bool al16 = P.src_al16 != 0, al8 = P.dst_al16 != 0;
+    const bool al16 = ALIGNED || P.src_al16 != 0, al8 = ALIGNED || P.dst_al16 != 0;
     ChromaLpFull lU, lV;
     lU.begin(P.a_in_i, a_hp_i);
     lV.begin(NTSC ? P.a_in_q : P.a_in_i, NTSC ? a_hp_q : a_hp_i);
@@ -304,10 +309,11 @@ struct FrameSink {
     double a_tv;
     int u1, u2, u3, u4, v1, v2, v3, v4;   // the last 4 inputs, 1 = newest (row tails); named, not an
                                           // array: a dynamically indexed array would live in scratch
-    DEV void begin(const DevParams &P, int out_lp, uint8_t *fy, uint8_t *fu, uint8_t *fv, bool is_out, bool dropped,
+    DEV void begin(const DevParams &P, bool aligned, int out_lp, uint8_t *fy, uint8_t *fu, uint8_t *fv, bool is_out, bool dropped,
                    double a_hp_i, double a_hp_q, int W)
     {
-        wy.begin(fy, P.src_al16 != 0, is_out); wu.begin(fu, P.dst_al16 != 0, is_out); wv.begin(fv, P.dst_al16 != 0, is_out);
+        wy.begin(fy, aligned || P.src_al16 != 0, is_out); wu.begin(fu, aligned || P.dst_al16 != 0, is_out);
+        wv.begin(fv, aligned || P.dst_al16 != 0, is_out);
         drop = dropped; mode = out_lp; W2 = W / 2;
         dU = mode == 2 ? 2 : (mode == 1 ? 1 : 0);
         dV = mode == 2 ? (P.ntsc ? 4 : 2) : (mode == 1 ? 1 : 0);
@@ -453,7 +459,7 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 } // namespace fused422
 
 // SPEC: the switch set of the '-vhs' preset (NTSC, SP tape speed, no pre-emphasis, luma / chroma /
-// phase noise on, lite output low-pass) as compile-time constants -- the sweeps then carry no state of branches
+// phase noise on, lite output low-pass; frame rows 16- / 8-byte aligned) as compile-time constants -- the sweeps then carry no state of branches
 // the preset never takes.  Same arithmetic; every other switch set runs the SPEC = false kernel.
 #ifndef F422_WAVES
 #define F422_WAVES 1
@@ -507,8 +513,8 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         lp_.pre_on = SPEC ? false : P.pre_on != 0; lp_.noise_on = SPEC ? true : P.noise_k != 0;
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
-        if (SPEC || P.ntsc) sweep_a<true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
-        else sweep_a<false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        if (SPEC || P.ntsc) sweep_a<true, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        else sweep_a<false, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
     }
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 1      // timing-only A/B builds (WRONG frames): stop after a sweep
     return;
@@ -568,7 +574,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
     // ---- B3: Y/C separation | dropout | output chroma low-pass -> frame
     {
         FrameSink sink;
-        sink.begin(P, SPEC ? 1 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        sink.begin(P, SPEC, SPEC ? 1 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
         ChromaPost422 nocp;
         LumaVhs nolv;
         demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);

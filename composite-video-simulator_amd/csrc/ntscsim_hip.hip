@@ -936,7 +936,7 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
                        !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
     // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
     const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 1 &&
-                      D.cdelay == 4;
+                      D.cdelay == 4 && D.src_al16 && D.dst_al16;
     if (fused && spec)
         hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
                            c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
