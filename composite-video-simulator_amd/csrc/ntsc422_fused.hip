@@ -25,6 +25,18 @@
 #pragma clang fp contract(off)
 
 namespace ntscsim {
+#ifdef F422_AB_TIMES   // developer A/B build: wave-clock time per sweep, summed over waves (tools/sweep_times.py)
+__device__ unsigned long long g422_times[8];
+extern "C" int ntscsim_debug_422_times(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g422_times), sizeof(g422_times)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g422_times), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define F422_STAMP(k) do { const unsigned long long t__ = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g422_times[k], t__ - t_prev__); t_prev__ = t__; } while (0)
+#else
+#define F422_STAMP(k) do { } while (0)
+#endif
 namespace fused422 {
 
 using fastdec::Casc3;
@@ -507,6 +519,9 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         if (off + 1 < end) oob1 = fy[W + 1];
     }
 
+#ifdef F422_AB_TIMES
+    unsigned long long t_prev__ = __builtin_readcyclecounter();
+#endif
     // ---- A: frame row -> composite bytes
     {
         LumaPost422 lp_;
@@ -516,6 +531,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         if (SPEC || P.ntsc) sweep_a<true, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
         else sweep_a<false, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
     }
+    F422_STAMP(0);
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 1      // timing-only A/B builds (WRONG frames): stop after a sweep
     return;
 #endif
@@ -523,27 +539,31 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
     if (P.hs) {
         const int hs = hs_shift[rc];
         if (__any(hs != 0)) {
+            // gathered from plane Y into plane T, 16 samples per step (16 independent loads in flight), then
+            // the two planes trade places for the rest of the kernel -- the wave's columns of the scratch
+            // planes are its own, and every lane of the wave takes this path (shift 0 = plain copy)
             const int tw = W + W / 10;
-            const int nw = (W + 3) >> 2;
-            for (int q = 0; q < nw; q++) R.T.set_word(q, R.Y.word(q));
-            Packer422 o; o.begin(R.Y);
-            for (int x0 = 0; x0 < W; x0 += BK) {
-                int v[BK], ix[BK];
+            Packer422 o; o.begin(R.T);
+            constexpr int HB = 16;
+            for (int x0 = 0; x0 < W; x0 += HB) {
+                int v[HB], ix[HB];
 #pragma unroll
-                for (int j = 0; j < BK; j++) {
+                for (int j = 0; j < HB; j++) {
                     int idx = x0 + j + hs;
                     idx += (idx >> 31) & tw;
                     idx -= (idx >= tw) ? tw : 0;
                     ix[j] = idx;
-                    v[j] = R.T.byte_at(idx < W ? idx : W - 1);
+                    v[j] = R.Y.byte_at(idx < W ? idx : W - 1);
                 }
 #pragma unroll
-                for (int j = 0; j < BK; j++)
+                for (int j = 0; j < HB; j++)
                     if (x0 + j < W) o.put(x0 + j, ix[j] < W ? v[j] : 16);
             }
             o.finish(W);
+            { const Plane422 t = R.Y; R.Y = R.T; R.T = t; }
         }
     }
+    F422_STAMP(1);
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 2
     return;
 #endif
@@ -563,11 +583,13 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         FrameSink none;
         demod<false>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, lv, none);
     }
+    F422_STAMP(2);
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 3
     return;
 #endif
     // ---- B2: VHS chroma low-pass + blend + sharpen | re-modulate
     sweep_b2<SPEC ? 4 : 0>(P, R, W, xi, k, a_sh_c, sharpen_c);
+    F422_STAMP(3);
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 4
     return;
 #endif
@@ -579,6 +601,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         LumaVhs nolv;
         demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);
     }
+    F422_STAMP(4);
 }
 
 } // namespace ntscsim
