@@ -297,10 +297,22 @@ def main_to_composite(args):
         rows = (ntscsim.field_rows(h, 0) + ntscsim.field_rows(h, 1)) / 2.0
         alg = 4.0 * w * rows * nf            # 2 B/pixel read + 2 B/pixel written, rows of the field
         value = world * nf * args.steps / elapsed
-        traffic = None
+        traffic, valu = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tj.get("%dx%d %s to_composite" % (w, h, args.preset), {}).get("k422_hbm_bytes_per_launch")
+            te = tj.get("%dx%d %s to_composite" % (w, h, args.preset), {})
+            scale = nf / float(te.get("fields_per_launch", nf))
+            traffic = te.get("k422_hbm_bytes_per_launch") and te["k422_hbm_bytes_per_launch"] * scale
+            if te.get("k422_mean_cycles_per_inst"):
+                need = te["k422_wave_insts_per_launch"] * scale * te["k422_mean_cycles_per_inst"]
+                peak = 1024 * 2.4e9
+                valu = {"bound": "valu-issue (cycle-weighted)", "unit": "SIMD pipe cycles/s", "peak": peak,
+                        "pipe_cycles_per_step": need, "mean_cycles_per_inst": te["k422_mean_cycles_per_inst"],
+                        "path_frac": need / (elapsed / args.steps) / peak,
+                        "kernel_frac": need / (k_ms * 1e-3) / peak if k_ms else None,
+                        "note": "SQ_INSTS_VALU of k422_fused per launch (profiles/*_pmc_summary_to_composite.txt) x the "
+                                "mean issue cost of its loops' instruction mix (tools/loop_census.py --mean); the setup "
+                                "kernels are left out of `need`"}
         except Exception:
             pass
         out = {
@@ -316,7 +328,7 @@ def main_to_composite(args):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
-                         "kernel_ms_all": {"setup": set_ms, "process": k_ms},
+                         "kernel_ms_all": {"setup": set_ms, "process": k_ms}, "valu": valu,
                          "note": "4*W*L algorithmic bytes per field; like the BGRA tool the kernel is bound by "
                                  "dependent fp64 filter chains, not by HBM (DESIGN.md section 7)"},
         }

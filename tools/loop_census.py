@@ -1,10 +1,31 @@
 #!/usr/bin/env python3
 """Developer tool: VALU census of EVERY loop of a kernel (isa_cost.py prices only the hottest one).
   tools/loop_census.py file.s 'k422_fusedILb1' [--hist]"""
-import collections, sys
+import collections, json, sys
 import isa_cost as I
+def mean_cost(asm, pat, min_valu=400):
+    """VALU instructions and cycle-weighted cost summed over the big loops of a kernel -> mean cycles
+    per instruction (static mix; the loops run comparable trip counts)."""
+    blocks = I.parse_kernel(asm, pat)
+    succ = I.cfg(blocks)
+    nv = cyc = 0
+    for comp in I.sccs(succ):
+        if not (len(comp) > 1 or comp[0] in succ[comp[0]]):
+            continue
+        ops = [op for n in comp for op, _ in blocks[n]]
+        v = sum(1 for op in ops if op.startswith("v_"))
+        if v >= min_valu:
+            nv += v
+            cyc += sum(I.cost_of(op) for op in ops)
+    return nv, cyc, (cyc / nv if nv else 0.0)
+
+
 def main():
     asm, pat = sys.argv[1], sys.argv[2]
+    if "--mean" in sys.argv:
+        nv, cyc, m = mean_cost(asm, pat)
+        print(json.dumps({"kernel": pat, "valu_in_loops": nv, "pipe_cycles": cyc, "mean_cycles_per_valu": m}))
+        return
     blocks = I.parse_kernel(asm, pat)
     succ = I.cfg(blocks)
     names = list(blocks)

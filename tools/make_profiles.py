@@ -109,6 +109,8 @@ if tocomp and os.path.exists(tocomp[0]) and os.path.getsize(tocomp[0]) > 10:
         "k422_hbm_bytes_per_launch": (k4["FETCH_SIZE"] + k4["WRITE_SIZE"]) * 1024,
         "k422_fetch_KiB": k4["FETCH_SIZE"], "k422_write_KiB": k4["WRITE_SIZE"],
         "k422_wave_insts_per_launch": k4["SQ_INSTS_VALU"],
+        "k422_mean_cycles_per_inst": (json.load(open(os.path.join(census, "k422_fused.json")))["mean_cycles_per_valu"]
+                                      if os.path.exists(os.path.join(census, "k422_fused.json")) else None),
         "note": "tools/pmc422.sh (tools/variant_probe.py: one 600-field launch per call); FETCH/WRITE include the "
                 "packed scratch planes the four sweeps hand to each other, which are larger than the caches"}
 json.dump(traffic, open("%s/traffic.json" % P, "w"), indent=1)
