@@ -228,3 +228,36 @@ def test_hip_max_fields_and_errors():
     frames = torch.zeros((2, dec.height, dec.width * 4), dtype=torch.uint8, device="cuda")
     assert dec.decode(capture[:1820 * 200].copy(), frames) == 0
     dec.close()
+
+
+# ------------------------------------------------------------------------------- command line host
+RAW28_CLI = os.path.join(L.PKG, "raw28_cli")
+
+
+def test_raw28_cli_exists_and_rejects_like_the_tool():
+    import subprocess
+    assert os.path.exists(RAW28_CLI), "build with make -C composite-video-simulator_amd/csrc"
+    r = subprocess.run([RAW28_CLI, "-bogus"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1
+    r = subprocess.run([RAW28_CLI, "-i", "x.u8"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"No output file specified" in r.stderr          # :510-513
+    r = subprocess.run([RAW28_CLI, "-o", "null:"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"No input file specified" in r.stderr           # :514-517
+
+
+@pytest.mark.gpu
+def test_raw28_cli_equals_oracle(tmp_path):
+    import subprocess
+    capture = L.raw28_capture(4, 9, 2, 31337)
+    src, dst = tmp_path / "cap.u8", tmp_path / "out.bgra"
+    src.write_bytes(capture.tobytes())
+    for flags, kw in ((["-showsc"], {"show_subcarrier": 1}), ([], {})):
+        r = subprocess.run([RAW28_CLI] + flags + ["-i", str(src), "-o", str(dst)], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-500:]
+        want, _ = L.raw28_oracle_run(L.raw28_oracle_opts(**kw), capture)
+        got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(-1, 262, 1820 * 4)
+        assert got.shape == want.shape and np.array_equal(got, want)
+    r = subprocess.run([RAW28_CLI, "--max-fields", "2", "-i", str(src), "-o", "null:"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"2 fields of 1820x262" in r.stderr
