@@ -499,10 +499,10 @@ def extras(torch, ntscsim, dev, local_rank, args):
         out["raw28_error"] = repr(e)
     # ---- other sizes / presets on the BGRA path
     out["sizes"] = {
-        "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 60, 6),
-                      "unit": "frames/s", "workload": "preset '%s', 120 fields per step, 3 steps in flight" % args.preset},
-        "3840x2160": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 3840, 2160, 16, 6),
-                      "unit": "frames/s", "workload": "preset '%s', 32 fields per step, 3 steps in flight" % args.preset},
+        "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 136, 8, args.inflight),
+                      "unit": "frames/s", "workload": "preset '%s', 272 fields (146,880 scanlines) per step, %d steps in flight" % (args.preset, args.inflight)},
+        "3840x2160": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 3840, 2160, 68, 8, args.inflight),
+                      "unit": "frames/s", "workload": "preset '%s', 136 fields (146,880 scanlines) per step, %d steps in flight" % (args.preset, args.inflight)},
     }
     out["presets"] = {
         "default": {"value": device_rate(torch, ntscsim, dev, local_rank, [], w, h, args.frames, 12, args.inflight),
