@@ -48,7 +48,7 @@ void usage(const char *arg0)
         " -yc-recomb <n>  -nocomp  -422  -420\n"
         " (audio only, accepted: -preemphasis -deemphasis -audio-hiss -vhs-linear-video-crosstalk\n"
         "  -vhs-linear-high-boost)\n"
-        " extra (not in the reference): --batch <fields per GPU batch, default 128> --height <n>\n"
+        " extra (not in the reference): --batch <fields per GPU batch, default 512> --height <n>\n"
         "                               --ghost <delay px>:<gain/256>  (multipath ghost tap, up to 4)\n",
         arg0);
 }
@@ -127,7 +127,7 @@ bool read_frame(Source &s, uint8_t *dst, int W, int H)
 int main(int argc, char **argv)
 {
     // pull out the two switches the reference does not have, pass the rest to the mirror parser
-    int batch_fields = 128, height_override = 0;
+    int batch_fields = 512, height_override = 0;   // 512: the up / kernels / down pipeline of a batch has room to overlap
     int ghost_n = 0, ghost_d[4] = {0, 0, 0, 0}, ghost_g[4] = {0, 0, 0, 0};
     std::vector<const char *> av;
     av.push_back(argv[0]);
