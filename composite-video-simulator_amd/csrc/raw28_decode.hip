@@ -843,8 +843,8 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
 
     lap(9);
     // ---- (5) comb tails to their fixed point, then every scanline at once
-    for (int f = 0; f < nf; f++)
-        R28CHK(d, hipMemsetAsync((uint8_t *)frames_dev + (size_t)f * frame_stride, 0, (size_t)linesize * (size_t)d->height, st));
+    if (nf > 0)                                    // the tool's memset before every composite_layer() :1024, all frames at once
+        R28CHK(d, hipMemset2DAsync(frames_dev, frame_stride, 0, (size_t)linesize * (size_t)d->height, (size_t)nf, st));
     const int nlines = (int)lines.size();
     if (nlines > 0) {
         RenderConst RC;

@@ -128,6 +128,8 @@ rd += "| `%s_valu_rates.txt` | `tools/valu_rate_probe.hip` | issue cost of every
 rd += "| `%s_chain_probe.txt` | `tools/chain_probe.hip` | cost of dependent fp64 / int chains vs instruction-level parallelism |\n" % tag
 rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction census of each kernel's steady loop |\n" % tag
 rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_pmc_summary_to_composite.txt` | `python bench.py --tool to_composite`, `tools/kstats.sh ... --tool to_composite --inflight 1`, `tools/pmc422.sh` | the same three for the YUV422P tool |\n" % (tag, tag, tag)
+rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- python tools/raw28_probe.py` | kernels of the raw-composite decoder on a 600-field capture (4 calls) |\n" % tag
+rd += "| `%s_bench_driver_cmd.json`, `%s_variant_sweeps.txt` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...`; `tools/sweep_times.py` | the driver's own window; wave-clock share of the YUV422P kernel's sweeps |\n" % (tag, tag)
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (

@@ -20,6 +20,9 @@ if [ "$mode" = gpu ]; then
   timeout 500 bash tools/pmc422.sh pmc422_$tag > /dev/null 2>&1
   timeout 250 tools/kstats.sh ks_${tag}_tocomp --tool to_composite --inflight 1 --steps 20 --sustain-seconds 0 > /dev/null
   timeout 300 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
+  ( export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/ks_${tag}_raw28; mkdir -p $O; cd /tmp;
+    timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ks -- python $R/tools/raw28_probe.py > $O/probe.log 2>&1 < /dev/null;
+    f=$(find $O -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv )
   tail -c 600 gpurun_out/bench_$tag.json; tail -c 400 gpurun_out/bench_${tag}_tocomp.json
 else
   S=composite-video-simulator_amd/csrc
@@ -34,5 +37,6 @@ else
       gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
       gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
       gpurun_out/pmc422_$tag > /dev/null && echo "profiles/ assembled"
+  [ -s gpurun_out/ks_${tag}_raw28/kernel_stats.csv ] && cp gpurun_out/ks_${tag}_raw28/kernel_stats.csv profiles/${tag}_kernel_stats_raw28.csv
   [ -s gpurun_out/bench_${tag}_driver_cmd.json ] && cp gpurun_out/bench_${tag}_driver_cmd.json profiles/${tag}_bench_driver_cmd.json
 fi
