@@ -219,11 +219,12 @@ def variant_contexts(torch, ntscsim, dev, local_rank, args, nq):
             pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p422), w, h, field)
         sims.append(sm); arrs.append(sm.build_descs422(jobs)); frames.append(fr)
         streams.append(torch.cuda.Stream(dev))
+    plans = [sm.prepare422(a, w, h) for sm, a in zip(sims, arrs)]       # prepared batches: a step is only the launches
 
     def vstep(i):
         q = i % nq
-        sims[q].run_descs422(arrs[q], w, h, stream=streams[q].cuda_stream)
-    vstep.keep = (arrs, frames, streams)
+        sims[q].run_prepared422(plans[q], stream=streams[q].cuda_stream)
+    vstep.keep = (arrs, frames, streams, plans)
     return sims, vstep, frames[0]
 
 

@@ -772,19 +772,24 @@ static double alpha_rate(double rate, double hz)
     return timeInterval / (tau + timeInterval);
 }
 
-extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
-                                        int W, int H, void *hip_stream)
+// One ntscsim_fields422_device() call in two halves, so that a prepared batch (ntscsim_batch422_*) can
+// repeat the second: everything derived from the descriptors ...
+struct Prep422 {
+    DevParams D;
+    bool any_render = false, any_flt = false;
+    double a_hp_i = 0, a_hp_q = 0, a_sh_c = 0;
+    uint64_t rng_end = 0;          // in: position of the first descriptor with NTSCSIM_RNG_AUTO; out: after the last
+    int n = 0, W = 0, H = 0;
+};
+static int prepare422(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n, int W, int H, Prep422 &P,
+                      FieldDev *host_fields, Field422Dev *host_fields422)
 {
-    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
-    if (n == 0) return NTSCSIM_OK;
-    if (n < 0) return NTSCSIM_E_ARG;
     if (W < 16 || (W & 1) || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;   // 4:2:2
     if (n > 65535) return NTSCSIM_E_SIZE;                 // render / black-key grids: one plane per field
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    P.n = n; P.W = W; P.H = H;
     const ntscsim_params &p = c->prm;
 
-    DevParams D;
+    DevParams &D = P.D;
     fill_dev_params(p, D);
     if (c->warm_override[0] > 0) D.warm_luma = c->warm_override[0];
     if (c->warm_override[1] > 0) D.warm_chroma = c->warm_override[1];
@@ -802,12 +807,12 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     if (p.output_vhs_tape_speed == NTSCSIM_VHS_EP) { luma_cut = 1400000; chroma_cut = 280000; D.cdelay = 6; }
     D.a_in_i = alpha_rate(rc2, 1300000);                                // :366-381
     D.a_in_q = alpha_rate(rc2, 600000);
-    const double a_hp_i = alpha_rate(rc2, 1300000 / 2.0), a_hp_q = alpha_rate(rc2, 600000 / 2.0);
+    P.a_hp_i = alpha_rate(rc2, 1300000 / 2.0); P.a_hp_q = alpha_rate(rc2, 600000 / 2.0);
     D.a_tv = alpha_rate(rc2, (315000000.00 * 4) / (88 * 2 * 4));        // lite :408
     D.a_vl = alpha_rate(rl, luma_cut);
     D.a_vc = alpha_rate(rc2, chroma_cut);
     D.a_sh = alpha_rate(rl, luma_cut * 2);                              // :893
-    const double a_sh_c = alpha_rate(rc2, chroma_cut * 2);              // :911
+    P.a_sh_c = alpha_rate(rc2, chroma_cut * 2);                          // :911
     D.sharpen = p.vhs_out_sharpen;
     D.out_lp = p.composite_out_chroma_lowpass ? 2 : (p.composite_out_chroma_lowpass_lite ? 1 : 0);  // :948-951
     if (p.video_yc_recombine < 0 || p.video_yc_recombine > 64) return NTSCSIM_E_PARAM;
@@ -816,21 +821,7 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     if (rc != NTSCSIM_OK) return rc;
     if (D.pnoise_k) { rc = build_ptab(c); if (rc != NTSCSIM_OK) return rc; }
 
-    // pinned staging for the records, double-buffered against the asynchronous upload
-    const int si = c->stage422_idx;
-    c->stage422_idx ^= 1;
-    if (c->stage422_used[si]) HIPCHK(c, hipEventSynchronize(c->stage422_ev[si]));
-    const size_t rec_bytes = sizeof(FieldDev) + sizeof(Field422Dev);
-    if (c->stage422_cap[si] < (size_t)n) {
-        if (c->stage422[si]) (void)hipHostFree(c->stage422[si]);
-        c->stage422[si] = nullptr; c->stage422_cap[si] = 0;
-        const size_t want = (size_t)n + (size_t)n / 4 + 16;
-        HIPCHK(c, hipHostMalloc((void **)&c->stage422[si], want * rec_bytes, hipHostMallocDefault));
-        c->stage422_cap[si] = want;
-    }
-    FieldDev *const host_fields = (FieldDev *)c->stage422[si];
-    Field422Dev *const host_fields422 = (Field422Dev *)(c->stage422[si] + (size_t)n * sizeof(FieldDev));
-    uint64_t pos = c->rng_pos;
+    uint64_t pos = P.rng_end;
     bool any_render = false, any_flt = false;
     bool al_y16 = true, al_c8 = true;      // vector copies between frame rows and scratch words
     for (int i = 0; i < n; i++) {
@@ -875,11 +866,26 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     D.src_al16 = al_y16;      // (422 path: luma rows 16-byte aligned)
     D.dst_al16 = al_c8;       // (422 path: chroma rows 8-byte aligned)
 
+    P.any_render = any_render; P.any_flt = any_flt;
+    P.rng_end = pos;
+    return NTSCSIM_OK;
+}
+
+// ... and the launches, on records that are already in device memory
+static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_dev, const Field422Dev *fields422_dev,
+                     hipStream_t st, ntscsim_ctx::EvSet *evs)
+{
+    const ntscsim_params &p = c->prm;
+    DevParams D = P.D;
+    const int n = P.n, W = P.W, H = P.H;
+    const bool any_render = P.any_render, any_flt = P.any_flt;
+    const double a_hp_i = P.a_hp_i, a_hp_q = P.a_hp_q, a_sh_c = P.a_sh_c;
+    int rc = build_geometry(c, W, H, D);           // (cached per geometry; selects this call's tables)
+    if (rc != NTSCSIM_OK) return rc;
+    if (D.pnoise_k) { rc = build_ptab(c); if (rc != NTSCSIM_OK) return rc; }
     const dim3 pgrid((D.R + 62) / 63);
     const size_t S = (size_t)pgrid.x * 64;
     const size_t W2 = (size_t)W / 2;
-    HIPCHK(c, c->fields.ensure((size_t)n));
-    HIPCHK(c, c->fields422.ensure((size_t)n));
     const size_t Wq = ((size_t)W + 3) / 4 + 2, W2q = (W2 + 3) / 4 + 2;   // words per row (+slack)
     HIPCHK(c, c->scratch422.ensure(S * (2 * Wq + 2 * W2q) + 256));
     if (D.hs) HIPCHK(c, c->hs_shift.ensure((size_t)D.R));
@@ -891,6 +897,88 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         HIPCHK(c, c->n0_u.ensure((size_t)D.Rpad));
         HIPCHK(c, c->n0_v.ensure((size_t)D.Rpad));
     }
+    GeomDev G;
+    G.lskip = c->geom_cur->lskip.p; G.pskip = c->geom_cur->pskip.p; G.jrow = c->geom_cur->jrow.p;
+    G.jwarm = c->geom_cur->jwarm.p; G.sstart = c->geom_cur->sstart.p; G.ptab = c->ptab.p;
+    Scratch422 Sc;
+    Sc.S = S;
+    Sc.Y = c->scratch422.p;
+    Sc.T = Sc.Y + S * Wq;
+    Sc.U = Sc.T + S * Wq;
+    Sc.V = Sc.U + S * W2q;
+
+    if (any_render)
+        hipLaunchKernelGGL(k422_render, dim3((unsigned)((2 * W + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
+                           dim3(256), 0, st, D, fields422_dev);
+    if (any_flt)
+        hipLaunchKernelGGL(k422_bkey, dim3((unsigned)((W2 + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
+                           dim3(256), 0, st, D, fields422_dev, p.black_key_level_feedback);
+    if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
+    if (D.hs || D.pnoise_k || D.loss)
+        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
+                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
+    if (D.noise_k || D.cnoise_k)
+        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
+                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
+                           c->n0_v.p);
+    // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
+    // empty, "decode" = the one kernel that does composite_video_process)
+    if (evs) { HIPCHK(c, hipEventRecord(evs->e[1], st)); HIPCHK(c, hipEventRecord(evs->e[2], st)); }
+    // four-sweep form (ntsc422_fused.hip) for the VHS family of option sets, twelve-sweep form otherwise
+    const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
+                       !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
+    // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
+    const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 1 &&
+                      D.cdelay == 4 && D.src_al16 && D.dst_al16;
+    if (fused && spec)
+        hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    else if (fused)
+        hipLaunchKernelGGL(k422_fused<false>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    else
+    hipLaunchKernelGGL(k422_process, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                       c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                       c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma,
+                       p.video_yc_recombine, p.nocolor_subcarrier_after_yc_sep);
+    HIPCHK(c, hipGetLastError());
+    if (evs) {
+        HIPCHK(c, hipEventRecord(evs->e[3], st));
+        HIPCHK(c, hipEventRecord(evs->e[4], st));
+    }
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
+                                        int W, int H, void *hip_stream)
+{
+    if (!c || (n > 0 && !descs)) return NTSCSIM_E_ARG;
+    if (n == 0) return NTSCSIM_OK;
+    if (n < 0) return NTSCSIM_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    // pinned staging for the records, double-buffered against the asynchronous upload
+    const int si = c->stage422_idx;
+    c->stage422_idx ^= 1;
+    if (c->stage422_used[si]) HIPCHK(c, hipEventSynchronize(c->stage422_ev[si]));
+    const size_t rec_bytes = sizeof(FieldDev) + sizeof(Field422Dev);
+    if (c->stage422_cap[si] < (size_t)n) {
+        if (c->stage422[si]) (void)hipHostFree(c->stage422[si]);
+        c->stage422[si] = nullptr; c->stage422_cap[si] = 0;
+        const size_t want = (size_t)n + (size_t)n / 4 + 16;
+        HIPCHK(c, hipHostMalloc((void **)&c->stage422[si], want * rec_bytes, hipHostMallocDefault));
+        c->stage422_cap[si] = want;
+    }
+    FieldDev *const host_fields = (FieldDev *)c->stage422[si];
+    Field422Dev *const host_fields422 = (Field422Dev *)(c->stage422[si] + (size_t)n * sizeof(FieldDev));
+    Prep422 P;
+    P.rng_end = c->rng_pos;
+    int rc = prepare422(c, descs, n, W, H, P, host_fields, host_fields422);
+    if (rc != NTSCSIM_OK) return rc;
+    HIPCHK(c, c->fields.ensure((size_t)n));
+    HIPCHK(c, c->fields422.ensure((size_t)n));
     ntscsim_ctx::EvSet evs;
     const bool prof = c->profiling;
     if (prof) {
@@ -904,60 +992,74 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     HIPCHK(c, hipEventRecord(c->stage422_ev[si], st));
     c->stage422_used[si] = true;
 
-    GeomDev G;
-    G.lskip = c->geom_cur->lskip.p; G.pskip = c->geom_cur->pskip.p; G.jrow = c->geom_cur->jrow.p;
-    G.jwarm = c->geom_cur->jwarm.p; G.sstart = c->geom_cur->sstart.p; G.ptab = c->ptab.p;
-    Scratch422 Sc;
-    Sc.S = S;
-    Sc.Y = c->scratch422.p;
-    Sc.T = Sc.Y + S * Wq;
-    Sc.U = Sc.T + S * Wq;
-    Sc.V = Sc.U + S * W2q;
-
-    if (any_render)
-        hipLaunchKernelGGL(k422_render, dim3((unsigned)((2 * W + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
-                           dim3(256), 0, st, D, c->fields422.p);
-    if (any_flt)
-        hipLaunchKernelGGL(k422_bkey, dim3((unsigned)((W2 + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
-                           dim3(256), 0, st, D, c->fields422.p, p.black_key_level_feedback);
-    if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
-    if (D.hs || D.pnoise_k || D.loss)
-        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, c->fields.p,
-                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
-    if (D.noise_k || D.cnoise_k)
-        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
-                           c->fields.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
-                           c->n0_v.p);
-    // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
-    // empty, "decode" = the one kernel that does composite_video_process)
-    if (prof) { HIPCHK(c, hipEventRecord(evs.e[1], st)); HIPCHK(c, hipEventRecord(evs.e[2], st)); }
-    // four-sweep form (ntsc422_fused.hip) for the VHS family of option sets, twelve-sweep form otherwise
-    const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
-                       !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
-    // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
-    const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 1 &&
-                      D.cdelay == 4 && D.src_al16 && D.dst_al16;
-    if (fused && spec)
-        hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
-                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
-    else if (fused)
-        hipLaunchKernelGGL(k422_fused<false>, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
-                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
-    else
-    hipLaunchKernelGGL(k422_process, pgrid, dim3(64), 0, st, D, G, c->fields422.p, Sc, c->rs_luma.p,
-                       c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                       c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma,
-                       p.video_yc_recombine, p.nocolor_subcarrier_after_yc_sep);
-    HIPCHK(c, hipGetLastError());
-    if (prof) {
-        HIPCHK(c, hipEventRecord(evs.e[3], st));
-        HIPCHK(c, hipEventRecord(evs.e[4], st));
-        c->ev_live.push_back(evs);
-    }
-    c->rng_pos = pos;
+    rc = launch422(c, P, c->fields.p, c->fields422.p, st, prof ? &evs : nullptr);
+    if (rc != NTSCSIM_OK) return rc;
+    if (prof) c->ev_live.push_back(evs);
+    c->rng_pos = P.rng_end;
     return NTSCSIM_OK;
+}
+
+// ---- prepared batch of the YUV422P tool: validate + derive + upload once, launch many times
+struct ntscsim_batch422 {
+    ntscsim_ctx *ctx;
+    Prep422 P;
+    DevBuf<FieldDev> fields;
+    DevBuf<Field422Dev> fields422;
+};
+
+extern "C" int ntscsim_batch422_create(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n, int W, int H,
+                                       ntscsim_batch422 **out)
+{
+    if (!c || !descs || !out || n <= 0) return NTSCSIM_E_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<FieldDev> hf((size_t)n);
+    std::vector<Field422Dev> hf422((size_t)n);
+    ntscsim_batch422 *b = new (std::nothrow) ntscsim_batch422();
+    if (!b) return NTSCSIM_E_NOMEM;
+    b->ctx = c;
+    b->P.rng_end = c->rng_pos;
+    const int rc = prepare422(c, descs, n, W, H, b->P, hf.data(), hf422.data());
+    if (rc != NTSCSIM_OK) { delete b; return rc; }
+    if (b->fields.ensure((size_t)n) != hipSuccess || b->fields422.ensure((size_t)n) != hipSuccess ||
+        hipMemcpy(b->fields.p, hf.data(), (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(b->fields422.p, hf422.data(), (size_t)n * sizeof(Field422Dev), hipMemcpyHostToDevice) != hipSuccess) {
+        b->fields.release(); b->fields422.release();
+        delete b;
+        c->err = "ntscsim_batch422_create: device allocation / upload failed";
+        return NTSCSIM_E_HIP;
+    }
+    *out = b;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_batch422_run(ntscsim_batch422 *b, void *hip_stream)
+{
+    if (!b) return NTSCSIM_E_ARG;
+    ntscsim_ctx *c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    ntscsim_ctx::EvSet evs;
+    const bool prof = c->profiling;
+    if (prof) {
+        const int rc = take_events(c, evs);
+        if (rc != NTSCSIM_OK) return rc;
+        HIPCHK(c, hipEventRecord(evs.e[0], st));
+    }
+    const int rc = launch422(c, b->P, b->fields.p, b->fields422.p, st, prof ? &evs : nullptr);
+    if (rc != NTSCSIM_OK) return rc;
+    if (prof) c->ev_live.push_back(evs);
+    c->rng_pos = b->P.rng_end;
+    return NTSCSIM_OK;
+}
+
+extern "C" void ntscsim_batch422_destroy(ntscsim_batch422 *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipDeviceSynchronize();
+    b->fields.release(); b->fields422.release();
+    delete b;
 }
 
 extern "C" int ntscsim_output422_device(ntscsim_ctx *c, const ntscsim_out422_desc *descs, int n,

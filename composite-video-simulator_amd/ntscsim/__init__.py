@@ -231,6 +231,21 @@ class FieldSimulator:
                                                 C.c_void_p(stream))
         self._chk(rc, "ntscsim_fields422_device")
 
+    def prepare422(self, arr, width, height):
+        """ntscsim_batch422_create on a descriptor array (keep `arr` and its tensors alive)."""
+        b = C.c_void_p()
+        rc = self._lib.ntscsim_batch422_create(self._h, arr, len(arr), int(width), int(height), C.byref(b))
+        self._chk(rc, "ntscsim_batch422_create")
+        return b
+
+    def run_prepared422(self, batch, stream=None):
+        if stream is None:
+            stream = self._torch_stream()
+        self._chk(self._lib.ntscsim_batch422_run(batch, C.c_void_p(stream)), "ntscsim_batch422_run")
+
+    def free_prepared422(self, batch):
+        self._lib.ntscsim_batch422_destroy(batch)
+
     def fields422(self, jobs, width, height, stream=None):
         """build_descs422 + run_descs422."""
         self.run_descs422(self.build_descs422(jobs), width, height, stream)

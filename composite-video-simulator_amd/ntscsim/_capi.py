@@ -31,6 +31,7 @@ EXPORTS = (
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
     "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_bgra_to_yuv_device", "ntscsim_rng_calls_per_field_422",
     "ntscsim_scale_to_bgra_device", "ntscsim_frames_host_scaled",
+    "ntscsim_batch422_create", "ntscsim_batch422_run", "ntscsim_batch422_destroy",
     "ntscsim_raw28_opts_init", "ntscsim_raw28_parse_argv", "ntscsim_raw28_geometry", "ntscsim_raw28_create",
     "ntscsim_raw28_destroy", "ntscsim_raw28_last_error", "ntscsim_raw28_decode", "ntscsim_raw28_decode_device",
     "ntscsim_raw28_get_levels", "ntscsim_raw28_debug_set_speculation", "ntscsim_raw28_debug_stats",
@@ -274,6 +275,13 @@ def lib():
     L.ntscsim_debug_force_generic.restype = None
     L.ntscsim_debug_no_fast_decode.argtypes = [C.c_void_p, C.c_int]
     L.ntscsim_debug_no_fast_decode.restype = None
+    L.ntscsim_batch422_create.argtypes = [C.c_void_p, C.POINTER(Field422Desc), C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_void_p)]
+    L.ntscsim_batch422_create.restype = C.c_int
+    L.ntscsim_batch422_run.argtypes = [C.c_void_p, C.c_void_p]
+    L.ntscsim_batch422_run.restype = C.c_int
+    L.ntscsim_batch422_destroy.argtypes = [C.c_void_p]
+    L.ntscsim_batch422_destroy.restype = None
     L.ntscsim_raw28_opts_init.argtypes = [C.POINTER(Raw28Opts)]
     L.ntscsim_raw28_opts_init.restype = None
     L.ntscsim_raw28_parse_argv.argtypes = [C.POINTER(Raw28Opts), C.c_int, C.POINTER(C.c_char_p), C.c_int]

@@ -352,6 +352,17 @@ typedef struct ntscsim_field422_desc {
 int ntscsim_fields422_device(ntscsim_ctx *ctx, const ntscsim_field422_desc *descs, int n,
                              int width, int height, void *hip_stream);
 
+/* Prepared batch of the same call (like ntscsim_batch_create/run/destroy above): descriptors are
+ * validated, their rand() windows derived and everything uploaded once; every ntscsim_batch422_run()
+ * is then only the kernel launches.  The descriptors' frame pointers must stay valid; runs on one ctx
+ * are stream-ordered by the caller (one ctx per stream to overlap batches). */
+typedef struct ntscsim_batch422 ntscsim_batch422;
+int  ntscsim_batch422_create(ntscsim_ctx *ctx, const ntscsim_field422_desc *descs, int n,
+                             int width, int height, ntscsim_batch422 **out);
+int  ntscsim_batch422_run(ntscsim_batch422 *batch, void *hip_stream);
+void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
+
+
 /*
  * The pixel work of output_frame() ffmpeg_to_composite.cpp:1131, lines :1177-1236: line-double
  * ("bob") the rows of `field` of a processed YUV422P frame into the frame handed to the encoder.

@@ -354,6 +354,48 @@ def test_fused_kernel_widths_and_row_alignments(w, pad):
 
 
 @pytest.mark.gpu
+def test_prepared_batch422_equals_direct_call():
+    """ntscsim_batch422_create/run == ntscsim_fields422_device on the same descriptors, twice in a row
+    (the second run starts from the frames the first one left, like a direct call would), and the ctx
+    rand() position ends where the direct call leaves it."""
+    import torch
+    w, h, n = 128, 40, 6
+    p = L.make_params_tocomp(["-vhs"])
+    lib = L.product()
+    srcs = [cases422.make_source422("noise", w, h, 50 + j, 0) for j in range(n)]
+
+    def run(prepared):
+        sim = ntscsim.FieldSimulator(params=p)
+        devs = [to_dev(torch, s_) for s_ in srcs]
+        jobs, pos = [], 0
+        for k in range(n):
+            field = (k & 1) ^ 1
+            jobs.append({"dst": devs[k], "field": field, "fieldno": k, "rng_pos": pos})
+            pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, field)
+        arr = sim.build_descs422(jobs)
+        if prepared:
+            b = sim.prepare422(arr, w, h)
+            assert sim.rng_pos == 0                          # creating a batch does not move the stream
+            sim.run_prepared422(b); sim.run_prepared422(b)
+            sim.sync()
+            sim.free_prepared422(b)
+        else:
+            sim.run_descs422(arr, w, h); sim.run_descs422(arr, w, h)
+            sim.sync()
+        out = [[t.cpu().numpy().copy() for t in d] for d in devs]
+        rp = sim.rng_pos
+        sim.close()
+        return out, rp
+
+    a, rpa = run(False)
+    b, rpb = run(True)
+    assert rpa == rpb and rpa > 0
+    for k in range(n):
+        for i in range(3):
+            assert np.array_equal(a[k][i], b[k][i]), (k, i)
+
+
+@pytest.mark.gpu
 def test_hip_batch_of_fields_full_size():
     """720x480 -vhs, 8 fields in ONE batch (each field its own frame), explicit rand() positions."""
     import torch
