@@ -22,6 +22,7 @@ int raw28_ref_run(const raw28_ref_opts *o, const char *path, uint8_t *frames, in
     show_subcarrier = o->show_subcarrier != 0; disable_subcarrier = o->disable_subcarrier != 0;
     disable_equalization = o->disable_equalization != 0;
     src_byte_counter = 0; close_src();
+    std::vector<oneprocsamp>().swap(input_samples);      // a fresh process starts with an empty (then zero-filled) buffer
     memset(int_scanline, 0, sizeof(int_scanline)); memset(int_chroma, 0, sizeof(int_chroma));
     memset(int_luma, 0, sizeof(int_luma));
     hsync_dc_level = 128.0; blank_level = (uint8_t)0; white_level = (uint8_t)192;
