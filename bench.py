@@ -446,9 +446,9 @@ def extras(torch, ntscsim, dev, local_rank, args):
     nf = 2 * args.frames
     nq = max(1, args.inflight)
     sims, vstep, _ = variant_contexts(torch, ntscsim, dev, local_rank, args, nq)
-    for i in range(nq):
+    for i in range(4 * nq):
         vstep(i)
-    dt = time_steps(torch, dev, vstep, 5 * nq)
+    dt = time_steps(torch, dev, vstep, 12 * nq)
     for sm in sims:
         sm.close()
     out["variant422"] = {"value": nf / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
