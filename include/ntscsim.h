@@ -448,6 +448,7 @@ void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
  *   composite_layer() :601-849 per field: vertical-sync search, black / white calibration on the
  *   equalising pulses, then per scanline: level equalisation, delay-4 comb luma / chroma split,
  *   rendering, horizontal re-sync;  field loop main() :1016-1047.
+ * A decoder object is not re-entrant (one thread at a time); calls are synchronous.
  * One ntscsim_raw28_decode*() call = one run of the tool on one input file: the decoder state
  * starts from the tool's initial state every call.  Results are bit-identical to the tool's, including
  * where its calibration sums run past the buffered part of the capture into stale or never-filled
