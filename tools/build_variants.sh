@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/composite-video-simulator_amd/csrc
 OUT=$ROOT/tools/bin/variants
 mkdir -p "$OUT"
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$SRC"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -I$ROOT/include -I$SRC ${SCHED--mllvm -amdgpu-sched-strategy=iterative-maxocc}"   # SCHED="" = the compiler's default strategy
 [ -f "$SRC/params.o" ] && [ -f "$SRC/raw28_decode.o" ] || (cd "$SRC" && make -s params.o glibc_rand.o raw28_decode.o)
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2

@@ -27,7 +27,7 @@ if [ "$mode" = gpu ]; then
 else
   S=composite-video-simulator_amd/csrc
   mkdir -p /tmp/census_$tag
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$S --offload-arch=gfx950 -S --cuda-device-only \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-maxocc -Iinclude -I$S --offload-arch=gfx950 -S --cuda-device-only \
       -o /tmp/census_$tag/ntscsim.s $S/ntscsim_hip.hip 2> /dev/null
   for k in 'k_decode_fastILb1EdE:4' 'k_decode_fastILb0EdE:4' 'k_encode_fastIdE:16' 'k_row_states:1' 'k_field_setup:1'; do
     python tools/isa_cost.py /tmp/census_$tag/ntscsim.s "${k%%:*}" --steps "${k##*:}" --json "/tmp/census_$tag/${k%%:*}.json" | head -1
