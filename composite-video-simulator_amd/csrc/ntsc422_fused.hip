@@ -3,7 +3,8 @@
 //
 //   A   frame row -> input chroma low-pass :353-393 -> modulate :434-477 -> pre-emphasis :636-651
 //       -> luma noise :654-666                                   -> composite bytes (scratch Y)
-//       (head switching :669-732 on the composite bytes, as in k422_process)
+//       (head switching :669-732: waves that hold switched rows gather the displaced bytes into the
+//       spare scratch plane and swap the two planes)
 //   B1  Y/C separation :480-553 -> chroma noise :738-754 -> phase noise :755-781 (chroma)
 //       -> VHS luma low-pass + emphasis :812-831 -> luma sharpen :887-901 (luma, same sweep)
 //   B2  VHS chroma low-pass :834-855 -> vertical blend :862-882 -> chroma sharpen :904-924
@@ -17,6 +18,9 @@
 // directly (no copy sweeps), chroma planes that the next Y/C separation overwrites anyway are never
 // stored, and each scratch plane makes one round trip per sweep -- ~12 byte-visits per luma sample
 // instead of ~48.  Filters run in the carry form of ntsc_decode_fast.hip (3 fp64 instructions per pole).
+//
+// k422_fused<true> is the '-vhs' preset's own switch set with the switches as compile-time constants
+// (and aligned frame rows); k422_fused<false> reads them at run time.
 //
 // Preconditions (launcher; otherwise k422_process): VHS emulation with composite output (not
 // s-video), colour subcarrier on, input chroma low-pass on, no -nocolor-subcarrier-after-yc-sep,
