@@ -19,8 +19,8 @@
 // stored, and each scratch plane makes one round trip per sweep -- ~12 byte-visits per luma sample
 // instead of ~48.  Filters run in the carry form of ntsc_decode_fast.hip (3 fp64 instructions per pole).
 //
-// k422_fused<true> is the '-vhs' preset's own switch set with the switches as compile-time constants
-// (and aligned frame rows); k422_fused<false> reads them at run time.
+// k422_fused<true> is the '-vhs' preset's own switch set (full output low-pass) with the switches as
+// compile-time constants (and aligned frame rows); k422_fused<false> reads them at run time.
 //
 // Preconditions (launcher; otherwise k422_process): VHS emulation with composite output (not
 // s-video), colour subcarrier on, input chroma low-pass on, no -nocolor-subcarrier-after-yc-sep,
@@ -474,8 +474,9 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 
 } // namespace fused422
 
-// SPEC: the switch set of the '-vhs' preset (NTSC, SP tape speed, no pre-emphasis, luma / chroma /
-// phase noise on, lite output low-pass; frame rows 16- / 8-byte aligned) as compile-time constants -- the sweeps then carry no state of branches
+// SPEC: the switch set `ffmpeg_to_composite -vhs` runs (NTSC, SP tape speed, no pre-emphasis, luma / chroma /
+// phase noise on, FULL output chroma low-pass -- ffmpeg_to_composite.cpp:278 default, selection :948-951; frame
+// rows 16- / 8-byte aligned) as compile-time constants -- the sweeps then carry no state of branches
 // the preset never takes.  Same arithmetic; every other switch set runs the SPEC = false kernel.
 #ifndef F422_WAVES
 #define F422_WAVES 1
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
     // ---- B3: Y/C separation | dropout | output chroma low-pass -> frame
     {
         FrameSink sink;
-        sink.begin(P, SPEC, SPEC ? 1 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        sink.begin(P, SPEC, SPEC ? 2 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
         ChromaPost422 nocp;
         LumaVhs nolv;
         demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);

@@ -109,6 +109,8 @@ struct ntscsim_ctx {
     bool stage422_used[2] = {false, false};
     int stage422_idx = 0;
 
+    // kernel forms enqueued by the last launch (ntscsim_debug_last_kernels)
+    std::string kernels;
     // last batch (debug tap)
     int last_n = 0, last_W = 0, last_H = 0, last_Rpad = 0, last_Lslot = 0;
 
@@ -140,6 +142,14 @@ struct ntscsim_ctx {
             return NTSCSIM_E_HIP;                                                      \
         }                                                                              \
     } while (0)
+
+// which kernel form a launch site chose (read back by ntscsim_debug_last_kernels; the parity tests
+// assert on it, so that a specialised form cannot silently stop being the one that runs)
+static void note_kernel(ntscsim_ctx *c, const char *name)
+{
+    if (!c->kernels.empty()) c->kernels += ';';
+    c->kernels += name;
+}
 
 static RandState ctx_state_at(ntscsim_ctx *c, uint64_t pos)
 {
@@ -429,6 +439,15 @@ extern "C" void ntscsim_debug_no_fast_decode(ntscsim_ctx *c, int on)
     if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; }
 }
 
+extern "C" int ntscsim_debug_last_kernels(const ntscsim_ctx *c, char *out, size_t cap)
+{
+    if (!c || !out || cap == 0) return NTSCSIM_E_ARG;
+    const size_t n = std::min(cap - 1, c->kernels.size());
+    std::memcpy(out, c->kernels.data(), n);
+    out[n] = 0;
+    return (int)c->kernels.size();
+}
+
 extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chroma_draws)
 {
     if (!c) return;
@@ -553,26 +572,33 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     G.lskip = c->geom_cur->lskip.p; G.pskip = c->geom_cur->pskip.p; G.jrow = c->geom_cur->jrow.p;
     G.jwarm = c->geom_cur->jwarm.p; G.sstart = c->geom_cur->sstart.p; G.ptab = c->ptab.p;
 
+    c->kernels.clear();
     if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
-    if (D.hs || D.pnoise_k || D.loss)
+    if (D.hs || D.pnoise_k || D.loss) {
+        note_kernel(c, "k_field_setup");
         hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p);
-    if (D.noise_k || D.cnoise_k)
+    }
+    if (D.noise_k || D.cnoise_k) {
+        note_kernel(c, "k_row_states");
         hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
                            fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
+    }
     if (evs) HIPCHK(c, hipEventRecord(evs->e[1], st));
     // PRESET kernels (options folded at compile time) when the parameters match the default
     // preset or the full -vhs preset exactly; otherwise the GENERIC kernels.  Same results.
     const bool enc_preset = !c->force_generic && D.in_lp && !D.pre_on && D.noise_k != 0 && D.amp == 50;
     const bool fast = c->mode == NTSCSIM_MODE_FAST32;
 #define NTSC_LAUNCH_ENCODE(F, RT)                                                               \
+    do { note_kernel(c, ("k_encode<" + std::to_string((unsigned)(F)) + "u," #RT ">").c_str());  \
     hipLaunchKernelGGL((k_encode<F, RT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,             \
-                       fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p)
+                       fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p); } while (0)
     const bool even_phase = (D.phase_mode == 180 || (D.phase_mode != 90 && D.phase_mode != 270)) && !(D.phase_off & 1);
     const bool small_plane = (size_t)D.Rpad * (size_t)W * 4 < 0xFFF00000ull;
     if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
         // hand-tuned encoder of the presets (ntsc_encode_fast.hip)
+        note_kernel(c, fast ? "k_encode_fast<float>" : "k_encode_fast<double>");
         if (fast) hipLaunchKernelGGL((k_encode_fast<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
                                      fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
         else hipLaunchKernelGGL((k_encode_fast<double>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
@@ -583,6 +609,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     // extension: ghosting between encoder and decoder (reads the raw plane, writes a second one)
     const int *dec_in = c->comp.p;
     if (D.ghost_taps > 0) {
+        note_kernel(c, "k_ghost");
         HIPCHK(c, c->comp_ghost.ensure((size_t)D.Rpad * W));
         hipLaunchKernelGGL(k_ghost, dim3((D.R + 255) / 256, (unsigned)W), dim3(256), 0, st, D,
                            c->comp.p, c->comp_ghost.p);
@@ -592,9 +619,10 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     const bool dec_common = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50 &&
                             D.amp_back == 50;
 #define NTSC_LAUNCH_DECODE_RT(VHS, CO, F, RT)                                                   \
+    do { note_kernel(c, ("k_decode<" #VHS "," #CO "," + std::to_string((unsigned)(F)) + "u," #RT ">").c_str()); \
     hipLaunchKernelGGL((k_decode<VHS, CO, F, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev,     \
                        dec_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,           \
-                       c->pn_noise.p, c->dropout.p, c->tails.p)
+                       c->pn_noise.p, c->dropout.p, c->tails.p); } while (0)
 #define NTSC_LAUNCH_DECODE(VHS, CO, F)                                                          \
     do { if (fast) NTSC_LAUNCH_DECODE_RT(VHS, CO, F, float);                                     \
          else NTSC_LAUNCH_DECODE_RT(VHS, CO, F, double); } while (0)
@@ -602,12 +630,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane &&
                           head_switch_is_small(D, W);
 #define NTSC_LAUNCH_FAST(VHS, RT)                                                                \
+    do { note_kernel(c, "k_decode_fast<" #VHS "," #RT ">");                                      \
     hipLaunchKernelGGL((k_decode_fast<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
-                       c->dropout.p, c->tails.p)
+                       c->dropout.p, c->tails.p); } while (0)
     if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
         // VCR half -> second composite plane -> TV half (= the non-VHS decoder without head switching)
         HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
+        note_kernel(c, fast ? "k_vcr_front<float>" : "k_vcr_front<double>");
+        note_kernel(c, fast ? "k_decode_fast<false,float>" : "k_decode_fast<false,double>");
         if (fast) hipLaunchKernelGGL((k_vcr_front<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
                                      c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                      c->pn_noise.p, c->tails.p);
@@ -641,8 +672,10 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
 #undef NTSC_LAUNCH_DECODE
 #undef NTSC_LAUNCH_DECODE_RT
     if (evs) HIPCHK(c, hipEventRecord(evs->e[3], st));
-    if (any_bob)
+    if (any_bob) {
+        note_kernel(c, "k_bob");
         hipLaunchKernelGGL(k_bob, dim3((H + 1) / 2, n), dim3(256), 0, st, D, fields_dev);
+    }
     if (evs) HIPCHK(c, hipEventRecord(evs->e[4], st));
     HIPCHK(c, hipGetLastError());
     c->last_n = n; c->last_W = W; c->last_H = H; c->last_Rpad = D.Rpad; c->last_Lslot = D.Lslot;
@@ -863,6 +896,33 @@ static int prepare422(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
         for (int j = 31; j < 61; j++) fo.rng[j] = fo.rng[j - 31] + fo.rng[j - 3];
         if (!(d.flags & NTSCSIM_422_NOCOMP)) pos += c->geom_cur->calls[d.field & 1];
     }
+    // Descriptors of one call run concurrently and in place.  Two of them on the same destination frame
+    // are a write-write race when they have the same field parity, and a read-write race when the luma
+    // rows are tighter than width + 2: the Y/C separator reads two bytes past its row (:496), i.e. the
+    // first bytes of the OTHER field's row, which the tool has / has not processed yet depending on the
+    // order of its sequential loop (:1783-1800).  Refuse both; separate calls are stream-ordered.
+    if (n > 1) {
+        struct Key { uintptr_t dst; unsigned field; int ls; unsigned nocomp; };
+        std::vector<Key> keys((size_t)n);
+        for (int i = 0; i < n; i++)
+            keys[(size_t)i] = {(uintptr_t)descs[i].dst_dev[0], descs[i].field & 1u, descs[i].dst_linesize[0],
+                               (descs[i].flags & NTSCSIM_422_NOCOMP) ? 1u : 0u};
+        std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+            return a.dst != b.dst ? a.dst < b.dst : a.field < b.field; });
+        for (int i = 1; i < n; i++) {
+            const Key &a = keys[(size_t)i - 1], &b = keys[(size_t)i];
+            if (a.dst != b.dst) continue;
+            if (a.field == b.field) {
+                c->err = "descriptors of one batch share a destination frame and field";
+                return NTSCSIM_E_ARG;
+            }
+            if ((a.ls < W + 2 || b.ls < W + 2) && !(a.nocomp && b.nocomp)) {
+                c->err = "both fields of one destination frame in one batch need dst_linesize[0] >= width + 2 "
+                         "(the Y/C separator reads two bytes past each luma row); use separate calls";
+                return NTSCSIM_E_ARG;
+            }
+        }
+    }
     D.src_al16 = al_y16;      // (422 path: luma rows 16-byte aligned)
     D.dst_al16 = al_c8;       // (422 path: chroma rows 8-byte aligned)
 
@@ -907,6 +967,9 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     Sc.U = Sc.T + S * Wq;
     Sc.V = Sc.U + S * W2q;
 
+    c->kernels.clear();
+    if (any_render) note_kernel(c, "k422_render");
+    if (any_flt) note_kernel(c, "k422_bkey");
     if (any_render)
         hipLaunchKernelGGL(k422_render, dim3((unsigned)((2 * W + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
                            dim3(256), 0, st, D, fields422_dev);
@@ -914,13 +977,17 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
         hipLaunchKernelGGL(k422_bkey, dim3((unsigned)((W2 + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
                            dim3(256), 0, st, D, fields422_dev, p.black_key_level_feedback);
     if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
-    if (D.hs || D.pnoise_k || D.loss)
+    if (D.hs || D.pnoise_k || D.loss) {
+        note_kernel(c, "k_field_setup");
         hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p);
-    if (D.noise_k || D.cnoise_k)
+    }
+    if (D.noise_k || D.cnoise_k) {
+        note_kernel(c, "k_row_states");
         hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
                            fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
+    }
     // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
     // empty, "decode" = the one kernel that does composite_video_process)
     if (evs) { HIPCHK(c, hipEventRecord(evs->e[1], st)); HIPCHK(c, hipEventRecord(evs->e[2], st)); }
@@ -928,8 +995,11 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
                        !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
     // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
-    const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 1 &&
+    // = what `ffmpeg_to_composite -vhs` runs: NTSC, SP, no pre-emphasis, all three noises and the FULL
+    // output chroma low-pass (ffmpeg_to_composite.cpp:278 default true, selection :948-951)
+    const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 2 &&
                       D.cdelay == 4 && D.src_al16 && D.dst_al16;
+    note_kernel(c, !fused ? "k422_process" : (spec ? "k422_fused<true>" : "k422_fused<false>"));
     if (fused && spec)
         hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
                            c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,

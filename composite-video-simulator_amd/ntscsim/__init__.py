@@ -299,6 +299,14 @@ class FieldSimulator:
         """on: True/1 = template PRESET kernels, 2 = two-launch (VCR half / TV half) VHS decoder."""
         self._lib.ntscsim_debug_no_fast_decode(self._h, int(on))
 
+    def last_kernels(self):
+        """Names of the kernel forms the last fields / fields422 / batch call enqueued, in order."""
+        buf = C.create_string_buffer(1024)
+        n = self._lib.ntscsim_debug_last_kernels(self._h, buf, len(buf))
+        if n < 0:
+            raise RuntimeError("ntscsim_debug_last_kernels: %d" % n)
+        return [k for k in buf.value.decode().split(";") if k]
+
     def debug_set_warmup(self, luma_draws, chroma_draws):
         self._lib.ntscsim_debug_set_warmup(self._h, int(luma_draws), int(chroma_draws))
 

@@ -325,10 +325,16 @@ void ntscsim_batch_destroy(ntscsim_batch *batch);
  *                                               YUV422P frame dst (skipped with NTSCSIM_422_NOCOMP,
  *                                               the tool's -nocomp :1789)
  * Create the ctx from ntscsim_params_init_to_composite()/..._parse_argv_to_composite() parameters.
- * The reference's Y/C separator reads two bytes past each luma row (:496, undefined behaviour);
- * this implementation reads the value 16 there, so up to ~16 luma / ~12 chroma samples at the
- * right edge of a row can differ from a particular run of the reference.
- * Fields that share a feedback frame must not be in the same batch (frame-to-frame recurrence).
+ * The reference's Y/C separator reads two bytes past the end of each luma row (`Y[x+2]`, :496).  This
+ * implementation has the same memory semantics: for the last two positions of a row it reads the
+ * caller's bytes dst[0][y*linesize + width], [.. + width + 1] when they lie inside the luma plane
+ * (height * linesize bytes) -- with linesize < width + 2 those are the first bytes of the NEXT row,
+ * which belongs to the other field -- and the value 16 otherwise (the frame's last row).
+ * Consequences for batching: (1) fields that share a feedback frame must not be in the same batch
+ * (frame-to-frame recurrence); (2) when dst_linesize[0] < width + 2, the two fields of one destination
+ * frame must not be in the same batch either: one field's kernel would read bytes the other rewrites
+ * in place, whereas the tool processes them one after the other (:1783-1800).  Such a batch is refused
+ * with NTSCSIM_E_ARG; submit the fields in separate, stream-ordered calls (or pad the rows).
  */
 #define NTSCSIM_422_INTERLACED 1u   /* src->interlaced_frame                                     */
 #define NTSCSIM_422_TFF        2u   /* src->top_field_first                                      */
@@ -440,6 +446,14 @@ void ntscsim_debug_force_generic(ntscsim_ctx *ctx, int on);
  * the hand-tuned VHS decoder as two launches (VCR half -> second composite plane -> TV half)
  * instead of one.  Results must not change. */
 void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
+
+/* Which kernel forms the last ntscsim_fields_device() / ntscsim_fields422_device() / batch run on this
+ * ctx enqueued, in launch order, as a ';'-separated list of names as they appear in a rocprofv3 kernel
+ * trace without the argument list (e.g. "k_field_setup;k_row_states;k_encode_fast<double>;
+ * k_decode_fast<true,double>").  Returns the length of the full list (it is truncated to cap-1
+ * characters), or NTSCSIM_E_ARG.  The parity tests assert on it so that a specialised form cannot
+ * silently stop being the one that runs. */
+int ntscsim_debug_last_kernels(const ntscsim_ctx *ctx, char *out, size_t cap);
 
 /* ---- the raw-composite decoder: ffmpeg_raw28ntsc.cpp ---------------
  * The tool reads 8-bit composite video sampled at 8 x fsc (28.636 MHz, e.g. a cxadc capture) and

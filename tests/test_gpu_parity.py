@@ -287,22 +287,24 @@ def test_preset_and_generic_kernels_agree(flags, w, h):
     assert np.array_equal(a, e)
 
 
-@pytest.mark.parametrize("flags,w,h", [
-    ([], 96, 32), ([], 720, 486), (["-vhs"], 96, 32), (["-vhs"], 720, 486), (["-vhs"], 101, 35),
-    (["-vhs", "-vhs-speed", "lp"], 100, 33), (["-vhs", "-vhs-speed", "ep"], 128, 40),
-    (["-tvstd", "pal", "-vhs"], 96, 36), (["-vhs", "-vhs-chroma-vblend", "0"], 96, 32),
-    (["-vhs", "-chroma-dropout", "50000"], 96, 32), (["-vhs", "-comp-phase-offset", "2"], 96, 32),
-    (["-comp-phase", "0", "-comp-phase-offset", "2"], 96, 32),
+@pytest.mark.parametrize("flags,w,h,fast_ok", [
+    ([], 96, 32, 1), ([], 720, 486, 1), (["-vhs"], 96, 32, 1), (["-vhs"], 720, 486, 1), (["-vhs"], 101, 35, 1),
+    (["-vhs", "-vhs-speed", "lp"], 100, 33, 1), (["-vhs", "-vhs-speed", "ep"], 128, 40, 1),
+    (["-tvstd", "pal", "-vhs"], 96, 36, 1), (["-vhs", "-vhs-chroma-vblend", "0"], 96, 32, 1),
+    (["-vhs", "-chroma-dropout", "50000"], 96, 32, 1), (["-vhs", "-comp-phase-offset", "2"], 96, 32, 1),
+    (["-comp-phase", "0", "-comp-phase-offset", "2"], 96, 32, 1),
     # preconditions of the hand-tuned kernels NOT met -> they must fall back, results unchanged
-    (["-vhs", "-comp-phase-offset", "1"], 96, 32), (["-vhs", "-comp-phase", "90"], 96, 32),
-    (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.0012"], 96, 32),
-    (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32),
+    (["-vhs", "-comp-phase-offset", "1"], 96, 32, 0), (["-vhs", "-comp-phase", "90"], 96, 32, 0),
+    (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.0012"], 96, 32, 0),
+    (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32, 0),
 ])
-def test_every_decoder_path_agrees_with_the_oracle(flags, w, h):
+def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
     """The hand-tuned kernels (ntsc_encode_fast.hip / ntsc_decode_fast.hip, one- and two-launch VHS
-    forms), the template-specialised PRESET kernels and the GENERIC kernels are one function."""
+    forms), the template-specialised PRESET kernels and the GENERIC kernels are one function -- and the
+    form each mode is meant to exercise is the form that ran (ntscsim_debug_last_kernels)."""
     n = 4
     p = L.make_params(flags)
+    vhs = "-vhs" in flags
     srcs = [L.noise_frame(w, h, 77 + j) for j in range(2)]
     jobs = cases.case_jobs(n)
     o = L.OracleStream(p)
@@ -318,8 +320,21 @@ def test_every_decoder_path_agrees_with_the_oracle(flags, w, h):
         elif mode == "generic":
             sim.debug_force_generic(True)
         got = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+        ran = sim.last_kernels()
         sim.close()
         assert np.array_equal(got, e), mode
+        dec = [k for k in ran if k.startswith(("k_decode", "k_vcr_front"))]
+        if mode == "generic":
+            assert len(dec) == 1 and dec[0].startswith("k_decode<") and dec[0].endswith(",1u,double>"), (mode, ran)
+        elif mode == "template" or not fast_ok:
+            # the template PRESET forms (every case here keeps the presets' filter switches; what the
+            # not-fast_ok cases break is only a precondition of the hand-tuned kernels)
+            assert dec == ["k_decode<true,true,6u,double>" if vhs else "k_decode<false,false,0u,double>"], (mode, ran)
+        elif mode == "two-launch" and vhs:
+            assert dec == ["k_vcr_front<double>", "k_decode_fast<false,double>"], (mode, ran)
+        else:
+            assert dec == ["k_decode_fast<%s,double>" % ("true" if vhs else "false")], (mode, ran)
+            assert "k_encode_fast<double>" in ran, ran
 
 
 def test_bob_line_doubling():

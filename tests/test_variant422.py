@@ -288,14 +288,31 @@ def test_hip_reproduces_reference_golden(m):
     sim.close()
 
 
+# (flags, the kernel form the launcher must pick by default).  `ffmpeg_to_composite -vhs` runs the FULL
+# output chroma low-pass (ffmpeg_to_composite.cpp:278, :948-951): that switch set is k422_fused<true>.
+_FORM_CASES = [
+    (["-vhs"], "k422_fused<true>"),
+    (["-vhs", "-out-composite-lowpass-lite", "0"], "k422_fused<true>"),          # full low-pass still on
+    (["-vhs", "-out-composite-lowpass", "0"], "k422_fused<false>"),              # lite output low-pass
+    (["-vhs", "-out-composite-lowpass", "0", "-out-composite-lowpass-lite", "0"], "k422_fused<false>"),
+    (["-vhs", "-vhs-speed", "ep"], "k422_fused<false>"),
+    (["-tvstd", "pal", "-vhs"], "k422_fused<false>"),
+    (["-vhs", "-comp-catv"], "k422_fused<false>"),
+    (["-vhs", "-noise", "0"], "k422_fused<false>"),
+    (["-vhs", "-vhs-svideo", "1"], "k422_process"),
+    ([], "k422_process"),
+]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [["-vhs"], ["-vhs", "-vhs-speed", "ep"], ["-tvstd", "pal", "-vhs"], ["-vhs", "-comp-catv"],
-                                   ["-vhs", "-out-composite-lowpass-lite", "0"], ["-vhs", "-noise", "0"]],
-                         ids=["vhs", "vhs-ep", "pal-vhs", "vhs-catv", "vhs-fulllp", "vhs-nonoise"])
+@pytest.mark.parametrize("flags,form", _FORM_CASES,
+                         ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-ep", "pal-vhs", "vhs-catv", "vhs-nonoise",
+                              "vhs-svideo", "default"])
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["default", "twelve-sweep", "general-fused"])
-def test_every_variant_kernel_form_agrees_with_the_oracle(flags, mode):
+def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
     """The three kernel forms of the -vhs family (k422_fused<true> for the preset's own switch set,
-    k422_fused<false>, k422_process) on the same fields: each must equal the oracle.  mode = the
+    k422_fused<false>, k422_process) on the same fields: each must equal the oracle, and the form
+    that ran must be the one the case names (ntscsim_debug_last_kernels).  mode = the
     ntscsim_debug_no_fast_decode() bits (1: twelve-sweep form, 2: no preset instantiation)."""
     import torch
     w, h, n = 128, 38, 4
@@ -306,6 +323,7 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, mode):
     mask = last_row_margin_mask(frame, 0)
     sim = ntscsim.FieldSimulator(params=p)
     sim.debug_no_fast_decode(mode)
+    want = "k422_process" if mode == 1 else ("k422_fused<false>" if mode == 2 and form == "k422_fused<true>" else form)
     whole, dev = to_dev_onebuf(torch, frame)
     for k in range(n):
         field = (k & 1) ^ 1
@@ -314,6 +332,8 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, mode):
         _, srcd = to_dev_onebuf(torch, srcs[k // 2])
         sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
         sim.sync()
+        ran = sim.last_kernels()
+        assert want in ran and sum(x.startswith(("k422_fused", "k422_process")) for x in ran) == 1, ran
         got = whole.cpu().numpy()
         bad = (got != frame.buf) & mask
         assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
@@ -323,11 +343,46 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, mode):
 
 
 @pytest.mark.gpu
+def test_422_batch_refuses_racing_descriptors():
+    """Two descriptors of one call on the same destination frame: same field = write-write race; both
+    fields with luma rows tighter than width + 2 = the Y/C separator of one field would read bytes the
+    other rewrites (ffmpeg_to_composite.cpp:496 vs the tool's sequential loop :1783-1800).  Both are
+    refused; with padded rows, or as separate calls, both fields of a frame are fine and equal the oracle."""
+    import torch
+    w, h = 64, 16
+    p = L.make_params_tocomp(["-vhs"])
+    lib = L.product()
+    pos1 = lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, 1)
+    sim = ntscsim.FieldSimulator(params=p)
+    tight = cases422.make_source422("noise", w, h, 5, 0)
+    _, dev = to_dev_onebuf(torch, tight)
+    for jobs in ([{"dst": dev, "field": 1, "fieldno": 0, "rng_pos": 0}, {"dst": dev, "field": 1, "fieldno": 1, "rng_pos": pos1}],
+                 [{"dst": dev, "field": 1, "fieldno": 0, "rng_pos": 0}, {"dst": dev, "field": 0, "fieldno": 1, "rng_pos": pos1}]):
+        with pytest.raises(ntscsim.NtscsimError) as e:
+            sim.fields422(jobs, w, h)
+        assert e.value.code == _capi.E_ARG
+        assert sim.rng_pos == 0
+    # padded rows: one batch with both fields == the oracle's sequential result
+    padded = cases422.make_source422("noise", w, h, 5, 16)
+    exp = padded.copy()
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    o.process(exp, 1, 0); o.process(exp, 0, 1)
+    whole, devp = to_dev_onebuf(torch, padded)
+    sim.fields422([{"dst": devp, "field": 1, "fieldno": 0, "rng_pos": 0}, {"dst": devp, "field": 0, "fieldno": 1, "rng_pos": pos1}], w, h)
+    sim.sync()
+    mask = last_row_margin_mask(padded, 16)
+    bad = (whole.cpu().numpy() != exp.buf) & mask
+    assert not bad.any(), int(bad.sum())
+    sim.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("w", [16, 18, 30, 62, 64, 66, 126, 722])
 @pytest.mark.parametrize("pad", [0, 3, 16])
 def test_fused_kernel_widths_and_row_alignments(w, pad):
-    """-vhs (the preset instantiation of the four-sweep kernel) at widths around its 16 / 64-sample
-    block sizes, with row paddings that make luma / chroma rows 16- / 8-byte aligned or not."""
+    """-vhs at widths around the four-sweep kernel's 16 / 64-sample block sizes, with row paddings that
+    make luma / chroma rows 16- / 8-byte aligned (k422_fused<true>, the preset instantiation) or not
+    (k422_fused<false>); the form that ran is asserted."""
     import torch
     h, n = 10, 3
     p = L.make_params_tocomp(["-vhs"])
@@ -344,6 +399,9 @@ def test_fused_kernel_widths_and_row_alignments(w, pad):
         _, srcd = to_dev_onebuf(torch, srcs[k // 2])
         sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
         sim.sync()
+        # aligned luma (16) and chroma (8) rows and plane starts -> the preset instantiation
+        al = all(o_ % a == 0 and l_ % a == 0 for o_, l_, a in zip(frame.off, frame.ls, (16, 8, 8)))
+        assert ("k422_fused<true>" if al else "k422_fused<false>") in sim.last_kernels(), (al, sim.last_kernels())
         got = whole.cpu().numpy()
         bad = (got != frame.buf) & mask
         assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
