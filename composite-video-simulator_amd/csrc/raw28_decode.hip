@@ -715,7 +715,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     }
 
     lap(7);
-    // ---- (3) the walk: field loop main() :1016-1030 around composite_layer()'s searches
+    // ---- (3) the walk: field loop main() :1006-1019 around composite_layer()'s searches
     RunWalk W;
     W.rs = rs.data(); W.re = re.data(); W.nruns = rs.size();
     const size_t CAP = (size_t)len * 2048;                                        // open_src :353

@@ -1,7 +1,7 @@
 // raw28_cli.cpp -- `ffmpeg_raw28ntsc`-compatible command line host for the GPU raw-composite decoder.
 //
 // Mirrors the reference's switch parser (ffmpeg_raw28ntsc.cpp parse_argv :442-520) and its field
-// loop (main() :1016-1047) around ntscsim_raw28_decode().  The media layer (libav* encode of the
+// loop (main() :1006-1038) around ntscsim_raw28_decode().  The media layer (libav* encode of the
 // rendered frames, :1032-1046) is NOT rebuilt: the capture is read from a file of 8-bit samples and
 // the frames leave as raw BGRA, `width x 262` each, one per field --
 //

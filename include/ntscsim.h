@@ -461,7 +461,7 @@ int ntscsim_debug_last_kernels(const ntscsim_ctx *ctx, char *out, size_t cap);
  *   hsync_dc_proc() :556-594 on every sample (sync-tip tracking, low-passed sync detector);
  *   composite_layer() :601-849 per field: vertical-sync search, black / white calibration on the
  *   equalising pulses, then per scanline: level equalisation, delay-4 comb luma / chroma split,
- *   rendering, horizontal re-sync;  field loop main() :1016-1047.
+ *   rendering, horizontal re-sync;  field loop main() :1006-1038.
  * A decoder object is not re-entrant (one thread at a time); calls are synchronous.
  * One ntscsim_raw28_decode*() call = one run of the tool on one input file: the decoder state
  * starts from the tool's initial state every call.  Results are bit-identical to the tool's, including

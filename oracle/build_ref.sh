@@ -8,8 +8,10 @@
 # git-ignored).  -ffp-contract=off + baseline x86-64 = the reference's default build semantics
 # (plain `g++ -O2` via automake has no FMA on x86-64).
 #
-# Ranges: 72-106 LowpassFilter | 205-214 output/phase globals | 756-809 L1 globals + VHS enum |
-#         1375-1921 RGB_to_YIQ ... composite_layer
+# Ranges: 72-106 LowpassFilter | 205-214 output/phase globals | 223, 226 the output frame ring and its
+#         index | 756-809 L1 globals + VHS enum | 1375-1921 RGB_to_YIQ ... composite_layer |
+#         2233-2257 the "field deinterlace" (bob) block of main()'s field loop, given a function head
+#         and tail of our own (it only touches the frame ring, its index and `current`)
 set -e
 here=$(cd "$(dirname "$0")" && pwd)
 ref=${NTSC_REFERENCE_DIR:-/root/reference}
@@ -20,8 +22,12 @@ mkdir -p "$here/_ref"
     cat "$here/ref_shim_pre.hpp"
     sed -n '72,106p' "$src"
     sed -n '205,214p' "$src"
+    sed -n '223p;226p' "$src"
     sed -n '756,809p' "$src"
     sed -n '1375,1921p' "$src"
+    # the bob block of main() :2233-2257 as a function of the loop variable it reads
+    echo 'static void ref_field_deinterlace(unsigned long long current)'
+    sed -n '2233,2257p' "$src"
     cat "$here/ref_shim_post.cpp"
 } | g++ -x c++ -O2 -w -ffp-contract=off -fPIC -shared -I"$here/../include" - -o "$here/_ref/libntsc_ref.so"
 echo "built $here/_ref/libntsc_ref.so"

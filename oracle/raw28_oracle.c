@@ -317,7 +317,7 @@ static void composite_layer(raw28_oracle *d, uint8_t *frame, int linesize)
     }
 }
 
-int raw28_oracle_next_field(raw28_oracle *d, uint8_t *bgra, int linesize)   /* main() :1016-1047 */
+int raw28_oracle_next_field(raw28_oracle *d, uint8_t *bgra, int linesize)   /* main() :1006-1038 */
 {
     lazy_flush_src(d);
     refill_src(d);

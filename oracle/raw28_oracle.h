@@ -6,7 +6,7 @@
  * follower, a raw-sample delay line), the buffer window open_src/flush_src/refill_src/lazy_flush_src
  * :277-357, composite_layer() :601-849 (vertical-sync search, black / white level calibration on the
  * equalisation pulses, per-line equalisation, delay-4 comb Y/C split, grey-scale rendering, per-line
- * horizontal re-sync) and the field loop of main() :1016-1047.  One oracle object = one run of the
+ * horizontal re-sync) and the field loop of main() :1006-1038.  One oracle object = one run of the
  * tool on one input file.
  */
 #ifndef RAW28_ORACLE_H
@@ -35,7 +35,7 @@ raw28_oracle *raw28_oracle_open(const raw28_opts *o, const uint8_t *capture, siz
 void raw28_oracle_close(raw28_oracle *d);
 /* output frame size (preset_NTSC :395-402) and samples per scanline (compute_NTSC :253) */
 void raw28_oracle_geometry(const raw28_oracle *d, int *width, int *height, int *scanline_samples);
-/* one iteration of the field loop :1016-1047: returns 1 and fills the BGRA frame (memset 0 +
+/* one iteration of the field loop :1006-1038: returns 1 and fills the BGRA frame (memset 0 +
  * composite_layer), or 0 when the tool would stop (fewer than 256 scanlines left) */
 int raw28_oracle_next_field(raw28_oracle *d, uint8_t *bgra, int linesize);
 /* decoder state after the last field (tests compare it with the product's) */

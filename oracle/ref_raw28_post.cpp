@@ -1,8 +1,9 @@
 // ref_raw28_post.cpp -- TEST INFRASTRUCTURE ONLY.  Appended after the extracted ranges of
 // ffmpeg_raw28ntsc.cpp: a C entry point that performs main()'s own set-up and field loop around the
 // extracted functions.  main() itself cannot be extracted (it is interleaved with libav* calls), so
-// the statements below RESTATE :918-951 (rate, geometry, delay line, detector filters, open_src) and
-// :1016-1030 (the loop body up to composite_layer); everything they call is the reference's text.
+// the statements below RESTATE :866-897 (rate :866-875, compute_NTSC :876, preset_NTSC :877, delay line
+// :886-887, detector filters :889-892, open_src :894) and :1006-1019 + :1037 (the loop body up to
+// composite_layer, and current++); everything they call is the reference's text.
 extern "C" {
 
 struct raw28_ref_opts {
@@ -29,7 +30,7 @@ int raw28_ref_run(const raw28_ref_opts *o, const char *path, uint8_t *frames, in
     for (size_t i = 0; i < hsync_dc_detect_passes; i++) hsync_dc_detect[i] = LowpassFilter();
     src_composite.clear();
     src_composite.push_back(path);
-    // ---- main() :918-951
+    // ---- main() :866-897
     if (o->sample_rate > 0) sample_rate = o->sample_rate; else NTSC28MHz();
     compute_NTSC();
     preset_NTSC();
@@ -47,7 +48,7 @@ int raw28_ref_run(const raw28_ref_opts *o, const char *path, uint8_t *frames, in
     AVFrame fr;
     memset(&fr, 0, sizeof(fr));
     fr.width = output_width; fr.height = output_height; fr.linesize[0] = output_width * 4;
-    // ---- main() :1016-1030
+    // ---- main() :1006-1019, :1037
     signed long long current = 0;
     int n = 0;
     while (n < max_fields) {

@@ -1,6 +1,7 @@
 // ref_shim_post.cpp -- TEST INFRASTRUCTURE ONLY.  Appended after the extracted reference text:
 // C entry points that load an ntscsim_params snapshot into the reference's globals
-// (ffmpeg_ntsc.cpp:205-214, :756-809) and call its composite_layer() (:1570).
+// (ffmpeg_ntsc.cpp:205-214, :756-809) and call its composite_layer() (:1570), and one that runs the
+// field loop's bob block (:2233-2257, wrapped as ref_field_deinterlace by build_ref.sh) on a frame.
 #include "ntscsim.h"
 extern "C" void ntsc_ref_set_params(const ntscsim_params *p)
 {
@@ -51,4 +52,17 @@ extern "C" void ntsc_ref_composite_layer(uint8_t *dst, int dst_linesize,
     s.width = width; s.height = height;
     s.interlaced_frame = src_interlaced; s.top_field_first = src_tff;
     composite_layer(&d, &s, dummy, field, fieldno);
+}
+
+// the "field deinterlace" block of main()'s field loop on one BGRA frame; `current` is the loop's field
+// counter (field = (current & 1) ^ 1, :2234)
+extern "C" void ntsc_ref_bob(uint8_t *frame, int linesize, int width, int height, unsigned long long current)
+{
+    AVFrame f;
+    memset(&f, 0, sizeof(f));
+    f.data[0] = frame; f.linesize[0] = linesize; f.width = width; f.height = height;
+    output_avstream_video_frame.assign(1, &f);
+    output_avstream_video_frame_index = 0;
+    ref_field_deinterlace(current);
+    output_avstream_video_frame.clear();
 }

@@ -99,6 +99,8 @@ def ref():
         lib.ntsc_ref_composite_layer.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_uint, C.c_ulonglong]
         lib.ntsc_ref_composite_layer.restype = None
+        lib.ntsc_ref_bob.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_ulonglong]
+        lib.ntsc_ref_bob.restype = None
         _ref = lib
     return _ref
 
@@ -170,6 +172,12 @@ class RefStream:
         h, w = src.shape[:2]
         ref().ntsc_ref_composite_layer(_ptr(dst), w * 4, _ptr(src), w * 4, interlaced, tff,
                                        w, h, field, fieldno)
+
+    @staticmethod
+    def bob(frame, fieldno):
+        """the field loop's "field deinterlace" block (ffmpeg_ntsc.cpp:2233-2257) with current = fieldno"""
+        h, w = frame.shape[:2]
+        ref().ntsc_ref_bob(_ptr(frame), w * 4, w, h, fieldno)
 
 
 # ------------------------------------------------------------------ 8-bit YUV422P variant -----

@@ -351,6 +351,34 @@ def test_bob_line_doubling():
             assert np.array_equal(g[0], e), (hh, field)
 
 
+_BOB = None
+
+
+@pytest.mark.parametrize("c", [("bob_default_even", [], 96, 32, 4), ("bob_default_odd", [], 96, 33, 4),
+                               ("bob_vhs_even", ["-vhs"], 96, 32, 4), ("bob_vhs_odd", ["-vhs"], 100, 35, 4),
+                               ("bob_vhs_h2", ["-vhs"], 64, 2, 2), ("bob_vhs_h3", ["-vhs"], 64, 3, 2)],
+                         ids=lambda c: c[0])
+def test_field_loop_with_bob_reproduces_reference_golden(c):
+    """NTSCSIM_DESC_BOB == the reference's field loop text (composite_layer :2229 + the "field
+    deinterlace" block :2233-2257), field after field into one frame, against the frames the reference
+    extract wrote (tests/golden/ntsc_bob_golden.npz)."""
+    global _BOB
+    torch = torch_mod()
+    if _BOB is None:
+        _BOB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ntsc_bob_golden.npz"))
+    name, flags, w, h, n = c
+    p = L.make_params(flags)
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.ascontiguousarray(_BOB["%s__src" % name])).cuda()
+    dst = torch.full((1, h, w, 4), 0x5A, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        sim.fields(src, dst, [(k // 2, 0, (k & 1) ^ 1, k)], bob=True)
+        sim.sync()
+        assert "k_bob" in sim.last_kernels()
+        assert np.array_equal(dst[0].cpu().numpy(), _BOB["%s__after%d" % (name, k)]), "field %d" % k
+    sim.close()
+
+
 def test_error_codes():
     torch = torch_mod()
     p = L.make_params([])

@@ -75,3 +75,25 @@ def test_bob_matches_loop_description():
     a = f.copy()
     L.oracle().ntsc_oracle_bob(L._ptr(a), w * 4, w, h, 0)
     assert [int(a[y, 0, 0]) for y in range(h)] == [0, 2, 2, 4, 4, 6, 6, 7]
+
+
+_BOB = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ntsc_bob_golden.npz"))
+BOB_CASES = [("bob_default_even", [], 96, 32, 4), ("bob_default_odd", [], 96, 33, 4),
+             ("bob_vhs_even", ["-vhs"], 96, 32, 4), ("bob_vhs_odd", ["-vhs"], 100, 35, 4),
+             ("bob_vhs_h2", ["-vhs"], 64, 2, 2), ("bob_vhs_h3", ["-vhs"], 64, 3, 2)]
+
+
+@pytest.mark.parametrize("c", BOB_CASES, ids=[c[0] for c in BOB_CASES])
+def test_field_loop_with_bob_matches_reference_golden(c):
+    """composite_layer() + the loop's bob block (ffmpeg_ntsc.cpp:2229-2257), field after field into one
+    frame: oracle == the frames the reference text produced (tests/golden/make_golden_bob.py)."""
+    name, flags, w, h, n = c
+    p = L.make_params(flags)
+    srcs = [np.ascontiguousarray(a) for a in _BOB["%s__src" % name]]
+    o = L.OracleStream(p)
+    dst = np.full((h, w, 4), 0x5A, np.uint8)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        o.field(dst, srcs[k // 2], field, k)
+        L.oracle().ntsc_oracle_bob(L._ptr(dst), w * 4, w, h, field)
+        assert np.array_equal(dst, _BOB["%s__after%d" % (name, k)]), "field %d" % k

@@ -44,3 +44,19 @@ def test_rand_stream_is_libc():
     import ctypes as C
     for _ in range(5000):
         assert r.ntsc_ref_rand() == L.oracle().ntsc_oracle_rng_next(C.byref(g))
+
+
+@pytest.mark.parametrize("h", [2, 3, 8, 9, 32, 33])
+@pytest.mark.parametrize("current", [0, 1, 2, 5])
+def test_bob_block_of_the_field_loop(h, current):
+    """ntsc_oracle_bob == the reference's own "field deinterlace" block (ffmpeg_ntsc.cpp:2233-2257,
+    extracted verbatim by oracle/build_ref.sh) for both field parities, even and odd heights (the
+    field-0 branch's y + 1 < height bound, :2248) and a padded linesize."""
+    import ctypes as C
+    w, pad = 24, 3
+    rng = np.random.RandomState(100 * h + current)
+    a = rng.randint(0, 256, size=(h, w + pad, 4), dtype=np.uint8)
+    b = a.copy()
+    L.ref().ntsc_ref_bob(L._ptr(a), (w + pad) * 4, w, h, current)
+    L.oracle().ntsc_oracle_bob(L._ptr(b), (w + pad) * 4, w, h, (current & 1) ^ 1)
+    assert np.array_equal(a, b)
