@@ -401,7 +401,7 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
             else {
                 const int a = ch_even, b = ch;
                 int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
-                if (!SINK) chroma_post422(P, &cpost, u, v);
+                if (!SINK) chroma_post422(P, cpost, u, v);
                 if (SINK) sink.chroma(xo >> 1, u, v);
                 else { ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
             }

@@ -359,27 +359,30 @@ struct ChromaPost422 {
     uint32_t *ring;
     int lane;
 };
-DEV void chroma_post422(const DevParams &P, ChromaPost422 *cp, int &u, int &v)
+DEV void chroma_post422(const DevParams &P, ChromaPost422 &cp, int &u, int &v)
 {
-    if (!cp) return;
-    if (cp->noise_on) {
-        u = clampu8(u + cp->nU);
-        v = clampu8(v + cp->nV);
-        cp->nU = sdiv2(cp->nU + (int)umod31(cp->rng.next(cp->ring, cp->lane), P.m_cnoise) - P.cnoise_k);
-        cp->nV = sdiv2(cp->nV + (int)umod31(cp->rng.next(cp->ring, cp->lane), P.m_cnoise) - P.cnoise_k);
+    if (cp.noise_on) {
+        u = clampu8(u + cp.nU);
+        v = clampu8(v + cp.nV);
+        cp.nU = sdiv2(cp.nU + (int)umod31(cp.rng.next(cp.ring, cp.lane), P.m_cnoise) - P.cnoise_k);
+        cp.nV = sdiv2(cp.nV + (int)umod31(cp.rng.next(cp.ring, cp.lane), P.m_cnoise) - P.cnoise_k);
     }
-    if (cp->phase_on) {
+    if (cp.phase_on) {
         const double du = u - 128, dv = v - 128;
-        const double u_ = (du * cp->cosv) - (du * cp->sinv);
-        const double v_ = (dv * cp->cosv) + (dv * cp->sinv);
+        const double u_ = (du * cp.cosv) - (du * cp.sinv);
+        const double v_ = (dv * cp.cosv) + (dv * cp.sinv);
         u = clampu8((int)(u_ + 128));
         v = clampu8((int)(v_ + 128));
     }
 }
 
+// POST: the chroma post-stages ride in this sweep; their state is copied into registers for the sweep
+// (a struct reached through a pointer would live in scratch memory)
+template <bool POST>
 DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA,
-                       bool after_yc_sep, int oob0, int oob1, ChromaPost422 *cpost = nullptr)
+                       bool after_yc_sep, int oob0, int oob1, const ChromaPost422 &cpost_in)
 {
+    ChromaPost422 cpost = cpost_in;
     const int W2 = W / 2;
     // the reader runs over the row; sample x+2 is needed at step x: keep a 2-sample look-ahead
     unsigned d0 = 16, d1 = 16, d2 = 0, d3 = 0, sum = 0;
@@ -402,7 +405,7 @@ DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, 
             int ch = clampu8((int)c + 128 - (int)yb);
             if (after_yc_sep) {                                  // :503-507
                 oy.put(xo, ch);
-                if (!(xo & 1)) { int u = 128, v = 128; chroma_post422(P, cpost, u, v); ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
+                if (!(xo & 1)) { int u = 128, v = 128; if (POST) chroma_post422(P, cpost, u, v); ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
             } else {
                 oy.put(xo, (int)yb);
                 const unsigned g = (unsigned)(xo - 2 + (int)xi) & 3u;
@@ -412,7 +415,7 @@ DEV void demodulate422(const DevParams &P, const Row422 &R, int W, unsigned xi, 
                 else {
                     const int a = ch_even, b = ch;
                     int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
-                    chroma_post422(P, cpost, u, v);
+                    if (POST) chroma_post422(P, cpost, u, v);
                     ou.put(xo >> 1, u);
                     ov.put(xo >> 1, v);
                 }
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
             n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
             cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
         }
-        if (!P.nocolor) demodulate422(P, R, W, xi, P.m_amp_back, after_yc_sep != 0, oob0, oob1, &cp_);
+        if (!P.nocolor) demodulate422<true>(P, R, W, xi, P.m_amp_back, after_yc_sep != 0, oob0, oob1, cp_);
         else if (cp_.noise_on || cp_.phase_on) {
             // no separation (-nocolor-subcarrier): the noise stages still run on the stored chroma
             Reader422 rv; rv.begin(R.V, W2);
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
             SWEEP_BEGIN(R.U, W2)
                 if (j_ == 0) rv.prefetch(x0_);
                 int u = in, v = rv.get(j_);
-                chroma_post422(P, &cp_, u, v);
+                chroma_post422(P, cp_, u, v);
                 ou.put(x, u); ov.put(x, v);
                 if (j_ == BK - 1 || x == W2 - 1) rv.advance();
             SWEEP_END
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
         }
         if (!P.svideo) {                                     // :926-929
             modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
-            demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0, oob0, oob1);
+            demodulate422<false>(P, R, W, xi, P.m_amp, after_yc_sep != 0, oob0, oob1, ChromaPost422());
         }
     }
     // ---- chroma dropout :932-942
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     // ---- extra Y/C recombine passes :943-946
     for (int i = 0; i < yc_recombine; i++) {
         modulate422(P, R, W, xi, P.amp, P.nocolor != 0);
-        demodulate422(P, R, W, xi, P.m_amp, after_yc_sep != 0, oob0, oob1);
+        demodulate422<false>(P, R, W, xi, P.m_amp, after_yc_sep != 0, oob0, oob1, ChromaPost422());
     }
     // ---- output chroma low-pass :948-951 (full if "out", else lite if "lite")
     if (P.out_lp == 2) {

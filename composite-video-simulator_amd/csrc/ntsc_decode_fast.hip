@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
 // 600-field launch cannot fill the extra wave slots: measured 0.86 ms for the pair against 0.80 ms
 // for the one-launch form, which therefore stays the default.
 #ifndef NTSC_FRONT_WAVES
-#define NTSC_FRONT_WAVES 3
+#define NTSC_FRONT_WAVES 2
 #endif
 template <class RT>
 __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P, GeomDev G,

@@ -875,11 +875,19 @@ DEV int dec_steady(const DevParams &P, DecState<RT> &S, const DecConst &C, const
     return t;
 }
 
+// Occupancy: the VHS forms with the composite re-encode (two demodulators, 19 filter states, run-time
+// switches) do not fit the 168 registers of 3 waves per SIMD without spilling inside the loop (99 / 7
+// spilled registers for the PRESET / GENERIC form, and a spill reload waits on vmcnt(0), i.e. on the
+// prefetched samples too); with 2 waves per SIMD they need no scratch, and two waves saturate a SIMD's
+// fp64 pipe (tools/chain_probe.hip) -- the same trade as k_decode_fast.
 #ifndef NTSC_DEC_WAVES
 #define NTSC_DEC_WAVES 3
 #endif
+#ifndef NTSC_DEC_WAVES_VHS
+#define NTSC_DEC_WAVES_VHS 2
+#endif
 template <bool VHS, bool COMPOUT, unsigned F, class RT>
-__global__ __launch_bounds__(64, NTSC_DEC_WAVES) void k_decode(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, (VHS && COMPOUT) ? NTSC_DEC_WAVES_VHS : NTSC_DEC_WAVES) void k_decode(DevParams P, GeomDev G,
                                                const FieldDev *__restrict__ fields,
                                                const int *__restrict__ comp,
                                                const uint32_t *__restrict__ rs_chroma,

@@ -546,6 +546,26 @@ static bool head_switch_is_small(const DevParams &D, int W)
     return m <= (int)(tw - (unsigned)W);
 }
 
+// The hand-tuned kernels address the transposed composite plane through a raw buffer descriptor with a
+// 32-bit byte offset: offset = row*4 + (x + head-switch displacement) * Rpad*4, compared (unsigned)
+// with num_records = W * Rpad*4, and out-of-range reads return the reference's fill value 0.  That only
+// works while the displaced offset cannot wrap around 2^32 back INTO the plane: the displacement lies in
+// [-W/10, +W/10] (head_switch_is_small), so both x + shift >= W and x + shift < 0 stay outside iff
+// (W + W/10 + 1) * Rpad*4 fits in 32 bits.  Larger planes take the generic kernels (64-bit addressing).
+static bool fast_plane_ok(size_t Rpad, int W, bool head_switching)
+{
+    const size_t span = (size_t)W + (head_switching ? (size_t)W / 10u + 1u : 0u);
+    return span * Rpad * 4u < 0xFFF00000ull;
+}
+
+extern "C" int ntscsim_debug_fast_plane_ok(int n_fields, int W, int H, int head_switching)
+{
+    if (n_fields <= 0 || W <= 0 || H <= 0) return 0;
+    const long long R = (long long)n_fields * ((H + 1) / 2);
+    const size_t Rpad = (size_t)(((R + 63) / 64) * 64 + 64);         // as prepare_records
+    return fast_plane_ok(Rpad, W, head_switching != 0) ? 1 : 0;
+}
+
 // ---- step 2: scratch + the kernel chain over device-resident records
 static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fields_dev,
                           bool any_bob, hipStream_t st, const ntscsim_ctx::EvSet *evs)
@@ -595,7 +615,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_encode<F, RT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,             \
                        fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p); } while (0)
     const bool even_phase = (D.phase_mode == 180 || (D.phase_mode != 90 && D.phase_mode != 270)) && !(D.phase_off & 1);
-    const bool small_plane = (size_t)D.Rpad * (size_t)W * 4 < 0xFFF00000ull;
+    const bool small_plane = fast_plane_ok((size_t)D.Rpad, W, D.hs != 0);
     if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
         // hand-tuned encoder of the presets (ntsc_encode_fast.hip)
         note_kernel(c, fast ? "k_encode_fast<float>" : "k_encode_fast<double>");

@@ -66,6 +66,28 @@ struct FrontConst {
     int thr;
 };
 
+// The follower's rate switch `if (hsync_dc_level > lv)` :563-570 without a compare / select pair (on
+// gfx950 a v_cndmask fed by a VALU compare costs several times an fp64 operation, and this loop is one
+// long dependent chain): level > lv  <=>  lv - level < 0, and the sign of a rounded fp64 difference is
+// the sign of the exact one (x - x is +0; fp64 subnormals are kept), so the high word of (lv - level),
+// shifted down arithmetically, is the all-ones / all-zeros mask of the FAST branch.  The two constants
+// are then picked word by word with v_bfi (mask laundered so that it is not folded back into a select).
+__device__ __forceinline__ double pick64(int m, double if_set, double if_clear)
+{
+    const unsigned long long a = (unsigned long long)__double_as_longlong(if_set),
+                             b = (unsigned long long)__double_as_longlong(if_clear);
+    const unsigned um = (unsigned)m;
+    const unsigned lo = ((unsigned)a & um) | ((unsigned)b & ~um);
+    const unsigned hi = ((unsigned)(a >> 32) & um) | ((unsigned)(b >> 32) & ~um);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double follow(double level, double lv, const FrontConst &K)
+{
+    int m = __double2hiint(lv - level) >> 31;
+    asm volatile("" : "+v"(m));
+    return (level * pick64(m, K.om_fast, K.om_slow)) + (lv * pick64(m, K.a_fast, K.a_slow));
+}
+
 // one sample of hsync_dc_proc() :556-594 (the raw delay line is a pure index shift and lives in the
 // consumers: raw_delayed[s] = raw[s - D])
 __device__ __forceinline__ int front_step(FrontState &s, const FrontConst &K, double lv)
@@ -73,8 +95,7 @@ __device__ __forceinline__ int front_step(FrontState &s, const FrontConst &K, do
     lv = (lv * K.alpha) + (s.p0 - (s.p0 * K.alpha)); s.p0 = lv;        // LowpassFilter::lowpass :92-96
     lv = (lv * K.alpha) + (s.p1 - (s.p1 * K.alpha)); s.p1 = lv;
     lv = (lv * K.alpha) + (s.p2 - (s.p2 * K.alpha)); s.p2 = lv;
-    if (s.level > lv) s.level = (s.level * K.om_fast) + (lv * K.a_fast);
-    else s.level = (s.level * K.om_slow) + (lv * K.a_slow);
+    s.level = follow(s.level, lv, K);
     int x = (int)(lv - s.level);
     x = x < 0 ? 0 : (x > 255 ? 255 : x);
     return x;
@@ -102,8 +123,7 @@ struct FrontPipe {
     __device__ __forceinline__ int D(const FrontConst &K)
     {
         const double lv = l2;
-        if (level > lv) level = (level * K.om_fast) + (lv * K.a_fast);
-        else level = (level * K.om_slow) + (lv * K.a_slow);
+        level = follow(level, lv, K);
         int x = (int)(lv - level);
         return x < 0 ? 0 : (x > 255 ? 255 : x);
     }

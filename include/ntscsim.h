@@ -455,6 +455,12 @@ void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
  * silently stop being the one that runs. */
 int ntscsim_debug_last_kernels(const ntscsim_ctx *ctx, char *out, size_t cap);
 
+/* Test hook (pure host arithmetic, no ctx): 1 when a batch of n_fields fields of width x height may take
+ * the hand-tuned kernels as far as the size of its composite plane is concerned -- they address the
+ * plane with 32-bit buffer offsets, and with head switching on the displaced index (up to width/10
+ * samples either way) must not wrap around 2^32 back into the plane.  0 = the generic kernels run. */
+int ntscsim_debug_fast_plane_ok(int n_fields, int width, int height, int head_switching);
+
 /* ---- the raw-composite decoder: ffmpeg_raw28ntsc.cpp ---------------
  * The tool reads 8-bit composite video sampled at 8 x fsc (28.636 MHz, e.g. a cxadc capture) and
  * renders one grey-scale BGRA frame of (scanline_samples + 1 & ~1) x 262 per field:

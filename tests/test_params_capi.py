@@ -193,3 +193,65 @@ int main(void) {
         cpp = tmp_path / "av.cpp"
         cpp.write_text(src.read_text())
         subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, str(cpp)])
+
+
+def test_no_product_kernel_uses_scratch_memory():
+    """Code-object metadata of the built device objects: no product kernel has a private segment (spilled
+    registers or a stack object).  A spill inside one of the streamed filter loops couples its reload
+    (s_waitcnt vmcnt(0)) to the prefetched samples and costs tens of per cent -- it must not creep back in."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    objs = [os.path.join(root, "composite-video-simulator_amd", "csrc", n) for n in ("ntscsim_hip.o", "raw28_decode.o")]
+    tool = os.path.join(root, "tools", "kres.sh")
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") \
+            or shutil.which("c++filt") is None:
+        pytest.skip("device objects or llvm tools not present")
+    out = subprocess.run(["sh", tool] + objs, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stderr
+    rows = [l for l in out.stdout.splitlines() if "\t" in l]
+    ours = [l for l in rows if "ntscsim::" in l or "k_raw28" in l]
+    assert len(ours) >= 40, len(ours)
+    bad = [l for l in ours if " scratch 0 " not in l + " " or not l.rstrip().endswith("spill 0")]
+    assert not bad, "\n".join(bad)
+
+
+def test_fast_kernel_plane_predicate_covers_the_displaced_range():
+    """ntscsim_debug_fast_plane_ok: the hand-tuned kernels' 32-bit buffer offsets.  Without head switching
+    the plane itself must fit; with it, the plane plus the largest displacement (W/10 samples of Rpad*4
+    bytes each) must, or an offset just past the row end -- or a negative one -- would wrap around 2^32
+    and read real samples where the reference has zeros (ffmpeg_ntsc.cpp:1687-1697)."""
+    lib = L.product()
+    W, H = 720, 486
+    lslot = (H + 1) // 2
+
+    def rpad(n):
+        r = n * lslot
+        return ((r + 63) // 64) * 64 + 64
+
+    def wraps(n, hs):
+        """exact model: does any offset of a sample OUTSIDE the row land inside num_records (mod 2^32)?"""
+        rb = rpad(n) * 4
+        num = W * rb
+        if num >= 2 ** 32:
+            return True
+        lo, hi = (-(W // 10), W - 1 + W // 10) if hs else (0, W - 1)
+        for xs in list(range(lo, 0)) + list(range(W, hi + 1)):
+            # any row: offsets row*4 + xs*rb for row in [0, Rpad); the interval start suffices (+ its end)
+            for row4 in (0, rb - 4):
+                if (row4 + xs * rb) % (2 ** 32) < num:
+                    return True
+        return False
+
+    assert lib.ntscsim_debug_fast_plane_ok(600, W, H, 1) == 1 and lib.ntscsim_debug_fast_plane_ok(600, W, H, 0) == 1
+    seen = set()
+    for n in list(range(5000, 6300, 37)) + list(range(5400, 5560)) + list(range(6050, 6150)):
+        for hs in (0, 1):
+            ok = lib.ntscsim_debug_fast_plane_ok(n, W, H, hs)
+            seen.add((hs, ok))
+            if ok:
+                assert not wraps(n, hs), (n, hs)
+    # the sweep crosses both thresholds, and there are sizes only the no-head-switch case may take
+    assert seen == {(0, 0), (0, 1), (1, 0), (1, 1)}
+    assert any(lib.ntscsim_debug_fast_plane_ok(n, W, H, 0) and not lib.ntscsim_debug_fast_plane_ok(n, W, H, 1)
+               for n in range(5400, 6200, 7))
