@@ -172,10 +172,12 @@ def time_steps(torch, dev, fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def device_rate(torch, ntscsim, dev, local_rank, flags, w, h, n_frames, reps, inflight=3):
-    """fields/s of the BGRA path on a resident bars clip of n_frames frames (both fields each)."""
+def device_rate(torch, ntscsim, dev, local_rank, flags, w, h, n_frames, reps, inflight=3, params=None, kernels=None):
+    """fields/s of the BGRA path on a resident bars clip of n_frames frames (both fields each).
+    kernels: a list that receives the kernel forms the step enqueued (ntscsim_debug_last_kernels)."""
     from ntscsim import shard
-    params = ntscsim.make_params(flags)
+    if params is None:
+        params = ntscsim.make_params(flags)
     jobs = shard.jobs_for_rank(params, w, h, 2 * n_frames, 0, 1)
     src = make_bars_clip(torch, n_frames, w, h, 0, 1, dev)
     loc = [(cur // 2, cur // 2, field, fieldno) for (cur, field, fieldno, _) in jobs]
@@ -191,6 +193,8 @@ def device_rate(torch, ntscsim, dev, local_rank, flags, w, h, n_frames, reps, in
     for i in range(inflight):
         step(i)
     dt = time_steps(torch, dev, step, reps)
+    if kernels is not None:
+        kernels.extend(sims[0].last_kernels())
     for sm, pl in zip(sims, plans):
         sm.free_prepared(pl); sm.close()
     return len(jobs) / dt
@@ -407,6 +411,32 @@ def extras(torch, ntscsim, dev, local_rank, args):
             sim.frames_host(d, s_, first_fieldno=0, chunk_frames=32, **kw)
             best = max(best, 2 * n / (time.perf_counter() - t0))
         e2e[name] = best
+    # ---- YUV420P in -> YUV420P out: 1.5 bytes per pixel each way over the link (the decoder's and the
+    # encoder's pixel format; both conversions on the GPU)
+    try:
+        from ntscsim import _capi as _c
+        hs = _c.HostSource()
+        cw, chh = w // 2, (h + 1) // 2
+        hs.format, hs.width, hs.height, hs.frame_bytes = _c.SRC_YUV420P, w, h, fb
+        for k_, (ls_, off_) in enumerate(((w, 0), (cw, w * h), (cw, w * h + cw * chh))):
+            hs.linesize[k_], hs.plane_offset[k_] = ls_, off_
+        yin = torch.empty((n, (fb + 15) // 16 * 16), dtype=torch.uint8).pin_memory()
+        ybars = L.yuv_bars(w, h, 0)
+        yin_np = yin.numpy()
+        for j in range(n):          # Y | U(4:2:0) | V(4:2:0) of the colour-bars frame rotated by j
+            yin_np[j, :w * h] = np.roll(ybars.pix(0), -j, axis=1).reshape(-1)
+            yin_np[j, w * h:w * h + cw * chh] = np.roll(ybars.pix(1)[::2], -(j // 2), axis=1).reshape(-1)
+            yin_np[j, w * h + cw * chh:fb] = np.roll(ybars.pix(2)[::2], -(j // 2), axis=1).reshape(-1)
+        best = 0.0
+        for _ in range(2):
+            sim.rng_pos = 0
+            t0 = time.perf_counter()
+            sim.frames_host_scaled(yuv_pin.numpy(), yin_np[:, :fb], hs, w, h, first_fieldno=0, chunk_frames=32, yuv="420")
+            best = max(best, 2 * n / (time.perf_counter() - t0))
+        e2e["yuv420p_in_yuv420p_out_pinned"] = best
+        del yin
+    except Exception as e:
+        e2e["yuv420p_in_error"] = repr(e)
     # ---- the 1:1 drop-in: one composite_layer() call per ntscsim_field() call, host frames in and out
     one_dst = np.zeros((h, w, 4), np.uint8)
     sim.rng_pos = 0
@@ -509,6 +539,28 @@ def extras(torch, ntscsim, dev, local_rank, args):
         "default": {"value": device_rate(torch, ntscsim, dev, local_rank, [], w, h, args.frames, 12, args.inflight),
                     "unit": "frames/s", "workload": "%dx%d, default preset (BASELINE configs[0] on the GPU), %d fields per step" % (w, h, 2 * args.frames)},
     }
+    # switch sets that fall off the hand-tuned kernels' preconditions (the GENERIC / template forms run):
+    # which decoder form each one took is recorded beside its rate
+    for name, fl in (("vhs_catv2", ["-vhs", "-comp-catv2"]), ("vhs_phase90", ["-vhs", "-comp-phase", "90"]),
+                     ("vhs_svideo", ["-vhs", "-vhs-svideo", "1"]),
+                     ("vhs_full_outlp", ["-vhs", "-out-composite-lowpass-lite", "0"]),
+                     ("vhs_ghost2", None)):
+        try:
+            kn = []
+            if fl is None:          # extension (absent from the reference, parity unpinned): two echo taps
+                prm = ntscsim.make_params(["-vhs"])
+                prm.ghost_taps = 2
+                prm.ghost_delay[0], prm.ghost_delay[1] = 12, 31
+                prm.ghost_gain[0], prm.ghost_gain[1] = 64, -32
+                v_ = device_rate(torch, ntscsim, dev, local_rank, None, w, h, args.frames, 8, args.inflight, params=prm, kernels=kn)
+                what = "-vhs + ghosting extension (2 taps: 12 samples x 64/256, 31 samples x -32/256; absent from the reference, parity unpinned)"
+            else:
+                v_ = device_rate(torch, ntscsim, dev, local_rank, fl, w, h, args.frames, 8, args.inflight, kernels=kn)
+                what = "preset '%s'" % " ".join(fl)
+            out["presets"][name] = {"value": v_, "unit": "frames/s", "kernels": [k_ for k_ in kn if not k_.startswith(("k_field", "k_row"))],
+                                    "workload": "%dx%d, %s, %d fields per step" % (w, h, what, 2 * args.frames)}
+        except Exception as e:
+            out["presets"][name] = {"error": repr(e)}
     return out
 
 
@@ -525,18 +577,32 @@ def valu_roofline(w, h, preset, fields_per_step, tm_ms, ms_per_step):
     scale = fields_per_step / float(tj["fields_per_launch"])
     peak = N_SIMD * VALU_CLOCK_HZ
     need = {k: v["wave_insts_per_launch"] * scale * v["mean_cycles_per_inst"] for k, v in kern.items()}
+    # the same wave-instructions priced at the guide's nominal issue costs (4 cycles per wave64 instruction
+    # for fp64 and the other half-rate opcodes, 2 for the full-rate ones): the pipe's real capacity; the
+    # measured slowest-wave figures above (4.3 / 2.7) include what a probe loses to arbitration
+    need_nom = {k: v["wave_insts_per_launch"] * scale * v.get("mean_cycles_per_inst_nominal", v["mean_cycles_per_inst"])
+                for k, v in kern.items()}
     out = {
         "bound": "valu-issue (cycle-weighted)",
         "unit": "SIMD pipe cycles/s",
         "peak": peak,
         "pipe_cycles_per_step": need,
+        "pipe_cycles_per_step_nominal": need_nom,
         "mean_cycles_per_inst": {k: v["mean_cycles_per_inst"] for k, v in kern.items()},
         "path_frac": sum(need.values()) / (ms_per_step * 1e-3) / peak,
-        "note": "needed = SQ_INSTS_VALU per launch (profiles/r02_pmc_summary.txt) x the mean issue cost "
-                "of each kernel's instruction mix (profiles/r02_isa_cost.json: 4.3 cycles for fp64 and "
-                "the other half-rate opcodes, 2.7 for the full-rate ones, measured by "
-                "tools/valu_rate_probe.hip -> profiles/r02_valu_rates.txt); peak = 1024 SIMDs x 2.4 GHz; "
-                "path_frac = needed / (ms_per_step x peak) with the steps in flight",
+        "path_frac_nominal": sum(need_nom.values()) / (ms_per_step * 1e-3) / peak,
+        "hbm_frac_ceiling_exact_mode": (8.0 * w * ((h + 1) // 2 + h // 2) / 2.0 * fields_per_step / (HBM_PEAK_GBS * 1e9)) /
+                                       (sum(need_nom.values()) / peak),
+        "note": "needed = SQ_INSTS_VALU per launch (profiles/*_pmc_summary.txt) x the mean issue cost "
+                "of each kernel's instruction mix (profiles/*_isa_cost.json).  path_frac prices it with the "
+                "slowest-wave figures of tools/valu_rate_probe.hip (4.3 cycles for fp64 and the other "
+                "half-rate opcodes, 2.7 for the full-rate ones: profiles/*_valu_rates.txt); "
+                "path_frac_nominal with the pipe's nominal 4 / 2 cycles (MI355X_MICROARCH.md) -- the "
+                "stricter figure, and the one to close on.  peak = 1024 SIMDs x 2.4 GHz; both are needed / "
+                "(ms_per_step x peak) with the steps in flight.  hbm_frac_ceiling_exact_mode = the HBM "
+                "roofline fraction a kernel chain with exactly this arithmetic would reach at 100 % "
+                "nominal VALU issue: the reference's fp64 op count per pixel, not memory, bounds "
+                "roofline.frac in exact mode",
     }
     if tm_ms.get("decode"):
         out["k_decode_frac"] = need.get("k_decode", 0.0) / (tm_ms["decode"] * 1e-3) / peak
@@ -569,6 +635,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the "
                          "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (and take the barrier / MAX / all-gather branches) even "
+                         "with one rank: exercises the RCCL code path on a single GPU")
     ap.add_argument("--cpu-fields", type=int, default=300,
                     help="fields of the clip timed on the single-threaded CPU engines (0 = skip)")
     ap.add_argument("--cpu-mt-fields", type=int, default=8,
@@ -602,9 +671,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     red_dev = dev                       # device of the tiny tensors the ranks exchange
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -767,6 +837,9 @@ def main():
             valu, traffic = valu_roofline(w, h, args.preset, launch_fields,
                                           {"decode": dec_ms, "encode": enc_ms, "setup": set_ms},
                                           ms_per_step * launch_fields / max(1, fields_per_step_local))
+            if valu and dec_ms > 0:
+                kd = valu["pipe_cycles_per_step_nominal"].get("k_decode", 0.0)
+                valu["k_decode_frac_nominal"] = kd / (dec_ms * 1e-3) / valu["peak"]
         if args.streams > 0:
             deal = "%d independent %d-frame streams, stream s on rank s %% %d" % (args.streams, args.frames, world)
         elif args.scaling == "weak":
@@ -776,7 +849,8 @@ def main():
             deal = "one %d-frame clip (%d fields per step) dealt frame-round-robin over %d GPU(s)" % (
                 args.frames, 2 * args.frames, world)
         out = {
-            "metric": "frames/sec (output frames = fields; 720x486 NTSC, full VHS preset)",
+            "metric": "frames/sec (output frames = fields; 720x486 NTSC, full VHS preset; steady-state "
+                      "pipelined throughput, %d steps in flight)" % nq,
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -813,7 +887,9 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "kernel_ms": dec_ms,
                 "note": "the exact path is bound by VALU issue, not by HBM (DESIGN.md, `valu` below): "
-                        "frac is reported as the contract asks; path_achieved uses encode+decode+setup time",
+                        "frac is reported as the contract asks and is capped near 0.25 in exact mode by the "
+                        "reference's fp64 arithmetic (valu.hbm_frac_ceiling_exact_mode); path_achieved uses "
+                        "encode+decode+setup time",
                 "path_achieved": alg_bytes_launch / (chain_ms * 1e-3) / 1e9 if chain_ms > 0 else 0.0,
                 "kernel_ms_all": {"setup": set_ms, "encode": enc_ms, "decode": dec_ms},
                 "valu": valu,

@@ -1449,8 +1449,8 @@ static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const 
         // the slot's previous download must have left the device buffers
         if (sl.used) { if (fail(hipEventSynchronize(sl.down), "hipEventSynchronize")) break; }
         // H2D: nf frames, row by row into the device pitch (or, for a scaled source, as they are)
-        if (S && lin_src)
-            fail(hipMemcpyAsync(sl.draw, src + rawbytes * (size_t)f0, rawbytes * (size_t)nf,
+        if (S && lin_src)      // (the last frame's rounding bytes are not the caller's: stop at frame_bytes)
+            fail(hipMemcpyAsync(sl.draw, src + rawbytes * (size_t)f0, rawbytes * (size_t)(nf - 1) + S->frame_bytes,
                                 hipMemcpyHostToDevice, s_up), "hipMemcpyAsync H2D");
         else if (S)
             for (int j = 0; j < nf; j++)

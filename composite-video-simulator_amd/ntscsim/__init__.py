@@ -135,16 +135,26 @@ class FieldSimulator:
                                                     C.c_void_p(stream))
         self._chk(rc, "ntscsim_scale_to_bgra_device")
 
-    def frames_host_scaled(self, dst, src, source, width, height, first_fieldno=0, bob=True, chunk_frames=0):
+    def frames_host_scaled(self, dst, src, source, width, height, first_fieldno=0, bob=True, chunk_frames=0, yuv=None):
         """src: numpy uint8 [N, frame_bytes] (frames in the layout `source`, a HostSource);
-        dst: numpy uint8 [2N, height, width, 4]."""
+        dst: numpy uint8 [2N, height, width, 4], or with yuv = "420" / "422" uint8 [2N, frame_bytes]
+        (Y|U|V planes packed at linesize width, chroma width/2)."""
         n = src.shape[0]
-        assert src.flags.c_contiguous and dst.flags.c_contiguous and dst.shape == (2 * n, height, width, 4)
+        # (frames may be strided: only each frame's own bytes must be contiguous)
+        assert src.ndim == 2 and src.strides[1] == 1 and dst.flags.c_contiguous
+        flags = DESC_BOB if bob else 0
+        if yuv is None:
+            assert dst.shape == (2 * n, height, width, 4)
+            dls = dst.strides[1]
+        else:
+            flags |= _capi.HOST_YUV420P if yuv == "420" else _capi.HOST_YUV422P
+            assert dst.ndim == 2 and dst.shape[0] == 2 * n
+            dls = width
         u8p = C.POINTER(C.c_uint8)
         rc = self._lib.ntscsim_frames_host_scaled(self._h, C.byref(source), src.ctypes.data_as(u8p), src.strides[0], n,
-                                                  dst.ctypes.data_as(u8p), dst.strides[0], dst.strides[1],
+                                                  dst.ctypes.data_as(u8p), dst.strides[0], dls,
                                                   int(width), int(height), int(first_fieldno),
-                                                  DESC_BOB if bob else 0, int(chunk_frames))
+                                                  flags, int(chunk_frames))
         self._chk(rc, "ntscsim_frames_host_scaled")
 
     # ---- batched, device-resident -----------------------------------------------------------

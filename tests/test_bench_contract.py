@@ -47,3 +47,27 @@ def test_bench_line_to_composite_tool():
     assert d["config"]["tool"] == "to_composite" and d["roofline"]["kernel"] == "k422_fused"
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 4 * 720 * 243 * 24
     assert d["cpu_baseline"]["value"] > 0 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_through_rccl_with_one_rank():
+    """--force-dist: the barrier, the MAX all-reduce of the elapsed time and the all-gather of the rank
+    checksums go through torch.distributed's nccl backend (= RCCL) even with a single rank, and rank 0's
+    re-computation of every rank's checksum agrees.  (More ranks need more GPUs: tools/run_scaling.sh.)"""
+    env_port = str(29600 + os.getpid() % 300)
+    os.environ["MASTER_PORT"] = env_port
+    try:
+        d = _run(["--cpu-fields", "0", "--no-extras", "--force-dist", "--dist-backend", "nccl"])
+    finally:
+        os.environ.pop("MASTER_PORT", None)
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["config"]["rank_checksums_verified"] is True and len(d["config"]["rank_checksums"]) == 1
+
+
+@pytest.mark.gpu
+def test_bench_config4_eight_streams_at_full_size_on_one_gpu():
+    """BASELINE configs[3] at its real size -- 8 independent 300-frame 720x486 streams -- dealt stream s
+    -> rank s % N; with the one GPU of this box N = 1, so rank 0 owns all eight (4,800 fields per step)."""
+    d = _run(["--cpu-fields", "0", "--no-extras", "--streams", "8", "--frames", "300", "--steps", "2", "--warmup", "1"])
+    assert d["config"]["fields_per_step_per_gpu"] == 8 * 600 and d["value"] > 0
+    assert "8 independent 300-frame streams" in d["config"]["workload"]

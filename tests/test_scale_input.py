@@ -112,3 +112,39 @@ def test_frames_host_scaled_equals_scale_then_field_loop(fmt, sw, sh):
     sim.frames_host(b, bgra, chunk_frames=2)
     sim.close()
     assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_frames_host_scaled_yuv_in_yuv_out_and_tight_last_frame():
+    """YUV420P frames in -> YUV420P bob frames out (1.5 bytes per pixel each way over the link) == the
+    scaled source through the plain host loop with the same output format.  The source frames are
+    4998 bytes each at a stride of 5008 (the device copy's 16-byte rounding) in a buffer that ENDS with
+    the last frame's last byte: the whole-chunk upload must not read the rounding bytes behind it."""
+    sw, sh, w, h, n = 98, 34, 96, 32, 5
+    cw, ch = (sw + 1) // 2, (sh + 1) // 2
+    sizes = [sw * sh, cw * ch, cw * ch]
+    fb = sum(sizes)
+    stride = (fb + 15) // 16 * 16
+    assert fb % 16 != 0
+    rng = np.random.RandomState(11)
+    flat = rng.randint(0, 256, size=stride * (n - 1) + fb, dtype=np.uint8)
+    src = np.lib.stride_tricks.as_strided(flat, shape=(n, fb), strides=(stride, 1))
+    hs = _capi.HostSource()
+    hs.format, hs.width, hs.height, hs.frame_bytes = _capi.SRC_YUV420P, sw, sh, fb
+    off = 0
+    for k, sz in enumerate(sizes):
+        hs.linesize[k], hs.plane_offset[k] = [sw, cw, cw][k], off
+        off += sz
+    bgra = np.stack([L.oracle_scale_to_bgra([src[j, :sizes[0]].reshape(sh, sw),
+                                             src[j, sizes[0]:sizes[0] + sizes[1]].reshape(ch, cw),
+                                             src[j, sizes[0] + sizes[1]:].reshape(ch, cw)], _capi.SRC_YUV420P, w, h)
+                     for j in range(n)])
+    ob = w * h + 2 * (w // 2) * ((h + 1) // 2)
+    a = np.zeros((2 * n, ob), np.uint8)
+    b = np.zeros_like(a)
+    sim = ntscsim.FieldSimulator(params=L.make_params(["-vhs"]))
+    sim.frames_host_scaled(a, src, hs, w, h, chunk_frames=2, yuv="420")
+    sim.rng_pos = 0
+    sim.frames_host(b, bgra, chunk_frames=2, yuv="420")
+    sim.close()
+    assert a.any() and np.array_equal(a, b)
