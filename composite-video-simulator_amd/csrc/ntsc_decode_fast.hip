@@ -19,8 +19,9 @@
 //     (ffmpeg_ntsc.cpp:1687-1697) for free.
 // Preconditions (checked by the launcher, otherwise k_decode runs): even scanline phase for every
 // row (-comp-phase 180 with an even offset), subcarrier amplitude 50 both ways, output low-pass
-// "lite", 16-byte aligned destination rows, composite plane below 4 GiB, head-switch displacement
-// of at most W/10 samples; VHS form: chroma noise + phase noise on, composite (not s-video) out.
+// "lite", 16-byte aligned destination rows, composite plane (plus the head-switch displacement) within
+// 32-bit buffer offsets; VHS form: chroma noise + phase noise on, composite (not s-video) out.  Head-switch
+// displacements beyond W/10 samples (wrap-around inside the 1.1 W window) run the WR instantiation.
 #pragma clang fp contract(off)
 
 namespace ntscsim {
@@ -216,9 +217,13 @@ struct State {
     int nU, nV;
 };
 
-// per-lane / per-launch constants
-template <class RT>
+// per-lane / per-launch constants.  WR: the head-switch displacement may wrap around the 1.1 W window
+// (address fix-up per load, see cs_load)
+template <class RT, bool WR = false>
 struct Const {
+    static constexpr bool wraps = WR;
+    int wrapoff;              // WR: byte offset of the wrapped index, -tw or +tw samples (sign of the shift)
+    int wrapA, wrapS;         // WR: x wraps iff ((wrapA - x) ^ wrapS) < 0
     unsigned xi;
     bool hi;                  // xi == 2
     int W, xe, lane;
@@ -236,14 +241,20 @@ struct Const {
 };
 
 // composite sample x of this lane's row after head switching, for 0 <= x < W (the caller's duty:
-// the bounds check only covers the displaced index)
-template <class RT>
-DEV int cs_load(const Const<RT> &C, int x)
+// the bounds check only covers the displaced index).  ffmpeg_ntsc.cpp:1687-1697: Y[x] = row[(x + shift)
+// mod tw] where that index is below W, else 0, with tw = W + W/10 and |shift| <= tw/2.  Without wrap
+// (|shift| <= W/10) the displaced index is x + shift and one bounds-checked load does it.  With wrap it
+// is x + shift - tw from x = tw - shift on (shift > 0), x + shift + tw below x = -shift (shift < 0):
+// one sign test per load, as mask arithmetic on full-rate opcodes, moves the offset by -+ tw samples.
+template <class CT>
+DEV int cs_load(const CT &C, int x)
 {
 #ifdef NTSC_AB_NOLOAD      // timing-only A/B build (WRONG pixels): no composite loads
     return C.vbase + x;
 #endif
-    return __builtin_amdgcn_raw_buffer_load_b32(C.comp, (int)((unsigned)C.vbase + (unsigned)x * (unsigned)C.rowbytes), 0, 0);
+    unsigned off = (unsigned)C.vbase + (unsigned)x * (unsigned)C.rowbytes;
+    if constexpr (CT::wraps) off += (unsigned)((((C.wrapA - x) ^ C.wrapS) >> 31) & C.wrapoff);
+    return __builtin_amdgcn_raw_buffer_load_b32(C.comp, (int)off, 0, 0);
 }
 
 // Masks built from per-lane / wave-uniform booleans are laundered through an empty asm so that the
@@ -277,8 +288,8 @@ DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
 // The VCR half of a steady step (VHS form): first demodulator at x1 = t - 7, chroma noise, phase
 // noise, VHS chroma / luma filters, vertical blend, re-modulation.  Returns the composite sample
 // the VCR puts out at x2 = x1 - d (ffmpeg_ntsc.cpp:1716-1888).
-template <int DP, int J, class RT>
-DEV int vcr_step(const DevParams &P, State<true, RT> &S, const Const<RT> &C, uint32_t *ring,
+template <int DP, int J, class RT, class CT>
+DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *ring,
                  int pc, int pl, int sneg1)
 {
     constexpr bool odd1 = ((DP + J) & 1) != 0;
@@ -322,15 +333,15 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, const Const<RT> &C, uin
 //   first demodulator             x1 = t - 7      = d + J (mod 4)  -> parity by DP = d & 1 (template),
 //                                                                     sign wave-uniform (sneg1)
 // Non-VHS form: x3 = x1 = t - 7 = 4n + J + 1 (SKT = 8), one demodulator.
-template <bool VHS, int DP, int J, class RT>
-DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring,
+template <bool VHS, int DP, int J, class RT, class CT>
+DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring,
                   int pc, int pl, int sneg1)
 {
     int Y, U, V;
     if constexpr (!VHS) {
         S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(pc, C.hi, 0, Y, U, V);
     } else {
-        const int c2 = vcr_step<DP, J, RT>(P, S, C, ring, pc, pl, sneg1);
+        const int c2 = vcr_step<DP, J, RT, CT>(P, S, C, ring, pc, pl, sneg1);
         // ... and separate again at x3
         S.D2.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(c2, C.hi, 0, Y, U, V);
     }
@@ -348,8 +359,8 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uin
 // tails, drain.  Same state, same results as `step` where both apply.
 // The VCR half of a guarded step: returns the VCR's composite sample at x2 = t - 7 - d (0 outside
 // the row).
-template <class RT>
-DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const Const<RT> &C, uint32_t *ring, int t)
+template <class RT, class CT>
+DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *ring, int t)
 {
     const int W = C.W;
     const int pc = t < W ? cs_load(C, t) : 0;             // t is wave-uniform
@@ -403,15 +414,15 @@ DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const Const<RT> &C, uin
     return c2;
 }
 
-template <bool VHS, class RT>
-DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring, int t,
+template <bool VHS, class RT, class CT>
+DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring, int t,
                    uint32_t &px, int &xo_out)
 {
     const int W = C.W;
     int Y, U, V;
     int x3 = t - 7;
     if constexpr (VHS) {
-        const int c2 = vcr_edge<RT>(P, S, C, ring, t);
+        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t);
         const int x2 = t - 7 - C.d;
         S.D2.push_edge(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
         x3 = x2 - 7;
@@ -441,8 +452,8 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, ui
 
 // Steady-state loop: every stage strictly inside the row.  Starts at t = SKT (mod 4), 4 pixels per
 // iteration, the next iteration's composite samples requested before the current ones are used.
-template <bool VHS, int DP, class RT>
-DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32_t *ring,
+template <bool VHS, int DP, class RT, class CT>
+DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring,
                uint32_t *ostage, uint32_t *drow, bool is_out, int t)
 {
     // last steady position: every composite sample inside the row (t < W) and no raw chroma tail
@@ -454,9 +465,11 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32
     const int dph = C.d & 3;
     const int sn0 = opaque_s(((dph + 0) & 3) == 3 ? -1 : 0), sn1 = opaque_s(((dph + 1) & 3) == 3 ? -1 : 0),
               sn2 = opaque_s(((dph + 2) & 3) == 3 ? -1 : 0), sn3 = opaque_s(((dph + 3) & 3) == 3 ? -1 : 0);
-    int pc[4], pl[4];
+    // samples in flight per stream: one unrolled iteration
+    constexpr int PD = 4;
+    int pc[PD], pl[PD];
 #pragma unroll
-    for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load(C, t + j - LOFF) : 0; }
+    for (int j = 0; j < PD; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load(C, t + j - LOFF) : 0; }
     // Where the registers allow it (non-VHS form) the next iteration's samples are requested at the
     // top of the current one: a whole iteration of arithmetic hides the HBM latency.  The one-launch
     // VHS form has no registers to spare and reloads each sample right after its step consumed it
@@ -470,10 +483,10 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32
             for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = VHS ? cs_load(C, t + 4 + j - LOFF) : 0; }
         }
 #define NTSC_FAST_STEP(J)                                                                         \
-        o[J] = step<VHS, DP, J, RT>(P, S, C, ring, pc[J], pl[J], sn##J);                          \
+        o[J] = step<VHS, DP, J, RT, CT>(P, S, C, ring, pc[J % PD], pl[J % PD], sn##J);            \
         if (!PFTOP) {                                                                             \
-            pc[J] = cs_load(C, t + 4 + J);                                                        \
-            if (VHS) pl[J] = cs_load(C, t + 4 + J - LOFF);                                        \
+            pc[J % PD] = cs_load(C, t + PD + J);                                                  \
+            if (VHS) pl[J % PD] = cs_load(C, t + PD + J - LOFF);                                  \
         }                                                                                         \
         NTSC_STEP_SCHED_BARRIER();
         NTSC_FAST_STEP(0)
@@ -481,7 +494,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32
         NTSC_FAST_STEP(2)
         NTSC_FAST_STEP(3)
 #undef NTSC_FAST_STEP
-        if (PFTOP) {
+        if constexpr (PFTOP) {
 #pragma unroll
             for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }
         }
@@ -510,7 +523,9 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const Const<RT> &C, uint32
 #ifndef NTSC_FAST_WAVES
 #define NTSC_FAST_WAVES 2
 #endif
-template <bool VHS, class RT>
+// WR (VHS form only): head-switch displacements beyond W/10 samples, e.g. PAL's 312.5-line field with
+// the default switching point (see cs_load)
+template <bool VHS, class RT, bool WR = false>
 __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(DevParams P, GeomDev G,
                                                      const FieldDev *__restrict__ fields,
                                                      const int *__restrict__ comp,
@@ -544,7 +559,8 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
     const size_t tcol = (size_t)blockIdx.x * 64 + lane;
     const size_t tstride = (size_t)gridDim.x * 64;
 
-    Const<RT> C;
+    typedef Const<RT, WR> CT;
+    CT C;
     C.xi = scan_phase(P, y, fd.fieldno);
     C.hi = (C.xi & 2u) != 0;
     C.W = W;
@@ -571,10 +587,17 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
     C.tailV = tails + 16 * tstride + tcol;
     C.rstride = tstride;
     C.rowbytes = P.Rpad * 4;
-    // head switching :1687-1697 for |shift| <= W/10: Y[x] = row[x + shift] inside the row, 0
-    // elsewhere -- a per-lane byte offset plus the buffer bounds check
+    // head switching :1687-1697: a per-lane byte offset plus the buffer bounds check (cs_load)
     const int hs = P.hs ? hs_shift[rc] : 0;
     C.vbase = (int)((unsigned)rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
+    {
+        // shift > 0: wrap iff x >= tw - shift, i.e. (tw - shift - 1 - x) < 0; shift < 0: wrap iff x < -shift,
+        // i.e. ~(-shift - 1 - x) < 0; shift == 0: never (A = INT_MAX / 2, no sign flip)
+        const int tw = W + W / 10;
+        C.wrapoff = (int)((unsigned)(hs > 0 ? -tw : tw) * (unsigned)C.rowbytes);
+        C.wrapA = hs > 0 ? tw - hs - 1 : (hs < 0 ? -hs - 1 : 0x3FFFFFFF);
+        C.wrapS = opaque_v(hs < 0 ? -1 : 0);
+    }
     C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0,
                                                (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
 
@@ -596,15 +619,15 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
     // ---------------- pipeline fill
     for (; t < SKT && t < total; t++) {
         uint32_t px; int xo;
-        (void)edge_step<VHS, RT>(P, S, C, ring, t, px, xo);
+        (void)edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo);
     }
     // ---------------- steady state: 4 pixels per iteration, ends 16 samples before the row end
-    if (C.d & 1) t = steady<VHS, 1, RT>(P, S, C, ring, ostage, drow, is_out, t);
-    else t = steady<VHS, 0, RT>(P, S, C, ring, ostage, drow, is_out, t);
+    if (C.d & 1) t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, drow, is_out, t);
+    else t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, drow, is_out, t);
     // ---------------- row end, filter tails, pipeline drain
     for (; t < total; t++) {
         uint32_t px; int xo;
-        if (!edge_step<VHS, RT>(P, S, C, ring, t, px, xo)) continue;
+        if (!edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo)) continue;
         ostage[lane * 20 + (xo & 15)] = px;
         if ((xo & 15) == 15) {
             if (is_out) {
@@ -658,7 +681,9 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     const size_t tcol = (size_t)blockIdx.x * 64 + lane;
     const size_t tstride = (size_t)gridDim.x * 64;
 
-    Const<RT> C;
+    typedef Const<RT, false> CT;
+    CT C;
+    C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
     C.xi = scan_phase(P, y, fd.fieldno);
     C.hi = (C.xi & 2u) != 0;
     C.W = W;
@@ -707,7 +732,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     const unsigned rb = (unsigned)C.rowbytes;
     int t = 0;
     // ---------------- pipeline fill (no output: x2 < 0)
-    for (; t < SK1 && t < total; t++) (void)vcr_edge<RT>(P, S, C, ring, t);
+    for (; t < SK1 && t < total; t++) (void)vcr_edge<RT, CT>(P, S, C, ring, t);
     // ---------------- steady state
     {
         const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
@@ -721,7 +746,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
             unsigned soff = (unsigned)(t - SK1) * rb;
 #define NTSC_VCR_STEP(DPV, J)                                                                     \
             {                                                                                     \
-                const int c2 = vcr_step<DPV, J, RT>(P, S, C, ring, pc[J], pl[J], sn##J);          \
+                const int c2 = vcr_step<DPV, J, RT, CT>(P, S, C, ring, pc[J], pl[J], sn##J);      \
                 __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
                 soff += rb;                                                                       \
                 NTSC_STEP_SCHED_BARRIER();                                                        \
@@ -740,7 +765,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     }
     // ---------------- row end, filter tails, drain
     for (; t < total; t++) {
-        const int c2 = vcr_edge<RT>(P, S, C, ring, t);
+        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t);
         const int x2 = t - SK1;
         if (x2 >= 0) __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)((unsigned)x2 * rb), 0);
     }

@@ -551,19 +551,24 @@ static bool head_switch_is_small(const DevParams &D, int W)
 // with num_records = W * Rpad*4, and out-of-range reads return the reference's fill value 0.  That only
 // works while the displaced offset cannot wrap around 2^32 back INTO the plane: the displacement lies in
 // [-W/10, +W/10] (head_switch_is_small), so both x + shift >= W and x + shift < 0 stay outside iff
-// (W + W/10 + 1) * Rpad*4 fits in 32 bits.  Larger planes take the generic kernels (64-bit addressing).
-static bool fast_plane_ok(size_t Rpad, int W, bool head_switching)
+// (W + W/10 + 1) * Rpad*4 fits in 32 bits.  When the displacement can wrap around the tw = 1.1 W window
+// (|shift| up to tw/2: k_decode_fast's WR form) the offset is first formed for x + shift, which reaches
+// from -tw/2 to W - 1 + tw/2, and then moved by -+ tw samples: (W + tw + 1) * Rpad*4 is required to fit,
+// a margin that covers every intermediate value.  Larger planes take the generic kernels (64-bit
+// addressing).  hs_mode: 0 no head switching, 1 displacement <= W/10, 2 any displacement.
+static bool fast_plane_ok(size_t Rpad, int W, int hs_mode)
 {
-    const size_t span = (size_t)W + (head_switching ? (size_t)W / 10u + 1u : 0u);
+    const size_t tw = (size_t)W + (size_t)W / 10u;
+    const size_t span = (size_t)W + (hs_mode == 0 ? 0u : (hs_mode == 1 ? (size_t)W / 10u + 1u : tw + 1u));
     return span * Rpad * 4u < 0xFFF00000ull;
 }
 
 extern "C" int ntscsim_debug_fast_plane_ok(int n_fields, int W, int H, int head_switching)
 {
-    if (n_fields <= 0 || W <= 0 || H <= 0) return 0;
+    if (n_fields <= 0 || W <= 0 || H <= 0 || head_switching < 0 || head_switching > 2) return 0;
     const long long R = (long long)n_fields * ((H + 1) / 2);
     const size_t Rpad = (size_t)(((R + 63) / 64) * 64 + 64);         // as prepare_records
-    return fast_plane_ok(Rpad, W, head_switching != 0) ? 1 : 0;
+    return fast_plane_ok(Rpad, W, head_switching) ? 1 : 0;
 }
 
 // ---- step 2: scratch + the kernel chain over device-resident records
@@ -615,7 +620,9 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_encode<F, RT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,             \
                        fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p); } while (0)
     const bool even_phase = (D.phase_mode == 180 || (D.phase_mode != 90 && D.phase_mode != 270)) && !(D.phase_off & 1);
-    const bool small_plane = fast_plane_ok((size_t)D.Rpad, W, D.hs != 0);
+    const bool hs_small = head_switch_is_small(D, W);
+    const int hs_mode = !D.hs ? 0 : (hs_small ? 1 : 2);
+    const bool small_plane = fast_plane_ok((size_t)D.Rpad, W, hs_mode);
     if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
         // hand-tuned encoder of the presets (ntsc_encode_fast.hip)
         note_kernel(c, fast ? "k_encode_fast<float>" : "k_encode_fast<double>");
@@ -647,14 +654,20 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     do { if (fast) NTSC_LAUNCH_DECODE_RT(VHS, CO, F, float);                                     \
          else NTSC_LAUNCH_DECODE_RT(VHS, CO, F, double); } while (0)
     // hand-tuned decoder of the two presets (ntsc_decode_fast.hip) when its preconditions hold
-    const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane &&
-                          head_switch_is_small(D, W);
+    // (the one-launch VHS form also exists with wrap-around head-switch loads; every other fast form
+    // needs the displacement to stay within W/10 samples)
+    const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane;
 #define NTSC_LAUNCH_FAST(VHS, RT)                                                                \
     do { note_kernel(c, "k_decode_fast<" #VHS "," #RT ">");                                      \
     hipLaunchKernelGGL((k_decode_fast<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
-    if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
+#define NTSC_LAUNCH_FAST_WR(RT)                                                                  \
+    do { note_kernel(c, "k_decode_fast<true," #RT ",true>");                                     \
+    hipLaunchKernelGGL((k_decode_fast<true, RT, true>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
+                       c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
+                       c->dropout.p, c->tails.p); } while (0)
+    if (dec_fast && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
         // VCR half -> second composite plane -> TV half (= the non-VHS decoder without head switching)
         HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
         note_kernel(c, fast ? "k_vcr_front<float>" : "k_vcr_front<double>");
@@ -674,12 +687,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
                                 tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                 c->pn_noise.p, c->dropout.p, c->tails.p);
-    } else if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
+    } else if (dec_fast && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(true, float); else NTSC_LAUNCH_FAST(true, double);
-    } else if (dec_fast && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
+    } else if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
+        if (fast) NTSC_LAUNCH_FAST_WR(float); else NTSC_LAUNCH_FAST_WR(double);
+    } else if (dec_fast && hs_small && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(false, float); else NTSC_LAUNCH_FAST(false, double);
     } else
 #undef NTSC_LAUNCH_FAST
+#undef NTSC_LAUNCH_FAST_WR
     if (!D.vhs) {
         if (dec_common && !D.cnoise_k && !D.pnoise_k) NTSC_LAUNCH_DECODE(false, false, 0u);
         else NTSC_LAUNCH_DECODE(false, false, F_GENERIC);

@@ -35,6 +35,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -187,12 +188,19 @@ __device__ __forceinline__ void front_span(FrontState &st, const FrontConst &K, 
 }
 
 // round 0 (speculative, all chunks) and repair rounds (flagged chunks, start = predecessor's end)
-__global__ __launch_bounds__(64) void k_raw28_front(const uint8_t *__restrict__ raw, size_t N, uint8_t *__restrict__ h,
+// Launched as 256-thread workgroups that each claim a whole CU's LDS (FRONT_PIN_LDS bytes of dynamic shared
+// memory nobody touches): one workgroup per CU, its four wavefronts on the CU's four SIMDs -- a lane's run
+// is a single dependent chain of warm-up + chunk samples, so the kernel takes as long as its most crowded
+// SIMD, and the default placement of 1,024 one-wave workgroups leaves some SIMDs with two or three waves
+// and others idle.
+constexpr int FRONT_WG = 256;
+constexpr size_t FRONT_PIN_LDS = 96 * 1024;        // > half of the CU's 160 KiB: a second workgroup cannot fit
+__global__ __launch_bounds__(FRONT_WG) void k_raw28_front(const uint8_t *__restrict__ raw, size_t N, uint8_t *__restrict__ h,
                                                     int chunk, int warm, int nchunks, FrontConst K, FrontState init,
                                                     FrontState *__restrict__ st_begin, FrontState *__restrict__ st_end,
                                                     const FrontState *__restrict__ prev_end, const int *__restrict__ flags)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int c = blockIdx.x * FRONT_WG + threadIdx.x;
     if (c >= nchunks) return;
     if (flags && !flags[c]) return;
     const size_t s0 = (size_t)c * (size_t)chunk;
@@ -427,6 +435,7 @@ struct ntscsim_raw28 {
     FrontConst K;
     FrontState init;
     bool chunk_forced = false;
+    bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
     // results of the last call
     double blank = 0, white = 192;
@@ -551,6 +560,7 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.a_slow = 1.0 / (d->one_frame_time * 0.6);                                // :568
     d->K.om_slow = 1.0 - d->K.a_slow;
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
+    if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
     *out = d;
     return NTSCSIM_OK;
 }
@@ -684,7 +694,9 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         R28CHK(d, d->st_end.ensure((size_t)nchunks));
         R28CHK(d, d->st_prev.ensure((size_t)nchunks));
         R28CHK(d, d->flags.ensure((size_t)nchunks));
-        hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + 63) / 64), dim3(64), 0, st, raw, N, d->h.p, chunk, warm,
+        const size_t pin = d->front_pin ? FRONT_PIN_LDS : 0;
+        if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
+        hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), pin, st, raw, N, d->h.p, chunk, warm,
                            nchunks, d->K, d->init, d->st_begin.p, d->st_end.p, (const FrontState *)nullptr, (const int *)nullptr);
         for (;;) {
             R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
@@ -697,7 +709,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
             d->stats[0]++; d->stats[1] += nbad;
             // repair round: flagged chunks restart from their predecessor's end state as it is NOW
             R28CHK(d, hipMemcpyAsync(d->st_prev.p, d->st_end.p, (size_t)nchunks * sizeof(FrontState), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + 63) / 64), dim3(64), 0, st, raw, N, d->h.p, chunk, warm,
+            hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), 0, st, raw, N, d->h.p, chunk, warm,
                                nchunks, d->K, d->init, d->st_begin.p, d->st_end.p, (const FrontState *)d->st_prev.p,
                                (const int *)d->flags.p);
         }

@@ -457,8 +457,10 @@ int ntscsim_debug_last_kernels(const ntscsim_ctx *ctx, char *out, size_t cap);
 
 /* Test hook (pure host arithmetic, no ctx): 1 when a batch of n_fields fields of width x height may take
  * the hand-tuned kernels as far as the size of its composite plane is concerned -- they address the
- * plane with 32-bit buffer offsets, and with head switching on the displaced index (up to width/10
- * samples either way) must not wrap around 2^32 back into the plane.  0 = the generic kernels run. */
+ * plane with 32-bit buffer offsets, and the displaced index of the head switch must not wrap around
+ * 2^32 back into the plane.  head_switching: 0 = off, 1 = displacement of at most width/10 samples,
+ * 2 = any displacement (the wrap-around form: a margin of a whole 1.1-width window either way).
+ * 0 = the generic kernels run. */
 int ntscsim_debug_fast_plane_ok(int n_fields, int width, int height, int head_switching);
 
 /* ---- the raw-composite decoder: ffmpeg_raw28ntsc.cpp ---------------

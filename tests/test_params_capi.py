@@ -219,11 +219,13 @@ def test_no_product_kernel_uses_scratch_memory():
 def test_fast_kernel_plane_predicate_covers_the_displaced_range():
     """ntscsim_debug_fast_plane_ok: the hand-tuned kernels' 32-bit buffer offsets.  Without head switching
     the plane itself must fit; with it, the plane plus the largest displacement (W/10 samples of Rpad*4
-    bytes each) must, or an offset just past the row end -- or a negative one -- would wrap around 2^32
-    and read real samples where the reference has zeros (ffmpeg_ntsc.cpp:1687-1697)."""
+    bytes each; a whole 1.1 W window for the wrap-around form) must, or an offset just past the row end
+    -- or a negative one -- would wrap around 2^32 and read real samples where the reference has zeros
+    (ffmpeg_ntsc.cpp:1687-1697)."""
     lib = L.product()
     W, H = 720, 486
     lslot = (H + 1) // 2
+    tw = W + W // 10
 
     def rpad(n):
         r = n * lslot
@@ -235,23 +237,25 @@ def test_fast_kernel_plane_predicate_covers_the_displaced_range():
         num = W * rb
         if num >= 2 ** 32:
             return True
-        lo, hi = (-(W // 10), W - 1 + W // 10) if hs else (0, W - 1)
+        lo, hi = {0: (0, W - 1), 1: (-(W // 10), W - 1 + W // 10), 2: (-tw, W - 1 + tw)}[hs]
         for xs in list(range(lo, 0)) + list(range(W, hi + 1)):
-            # any row: offsets row*4 + xs*rb for row in [0, Rpad); the interval start suffices (+ its end)
+            # any row: offsets row*4 + xs*rb for row in [0, Rpad); the interval's two ends suffice
             for row4 in (0, rb - 4):
                 if (row4 + xs * rb) % (2 ** 32) < num:
                     return True
         return False
 
-    assert lib.ntscsim_debug_fast_plane_ok(600, W, H, 1) == 1 and lib.ntscsim_debug_fast_plane_ok(600, W, H, 0) == 1
+    for hs in (0, 1, 2):
+        assert lib.ntscsim_debug_fast_plane_ok(600, W, H, hs) == 1
     seen = set()
-    for n in list(range(5000, 6300, 37)) + list(range(5400, 5560)) + list(range(6050, 6150)):
-        for hs in (0, 1):
+    for n in list(range(2500, 6300, 37)) + list(range(2900, 2960)) + list(range(5400, 5560)) + list(range(6050, 6150)):
+        for hs in (0, 1, 2):
             ok = lib.ntscsim_debug_fast_plane_ok(n, W, H, hs)
             seen.add((hs, ok))
             if ok:
                 assert not wraps(n, hs), (n, hs)
-    # the sweep crosses both thresholds, and there are sizes only the no-head-switch case may take
-    assert seen == {(0, 0), (0, 1), (1, 0), (1, 1)}
-    assert any(lib.ntscsim_debug_fast_plane_ok(n, W, H, 0) and not lib.ntscsim_debug_fast_plane_ok(n, W, H, 1)
-               for n in range(5400, 6200, 7))
+    # the sweep crosses all three thresholds, and each mode admits sizes the next one must refuse
+    assert seen == {(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (2, 1)}
+    for a, b in ((0, 1), (1, 2)):
+        assert any(lib.ntscsim_debug_fast_plane_ok(n, W, H, a) and not lib.ntscsim_debug_fast_plane_ok(n, W, H, b)
+                   for n in range(2500, 6200, 7)), (a, b)
