@@ -472,6 +472,166 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
     oy.finish(W);
 }
 
+
+// ---------------------------------------------------------------------------------- streamed B pass
+// B1 + B2 + B3 of the '-vhs' preset's switch set as ONE pass over the composite bytes of sweep A, every
+// stage's state in registers (the BGRA decoder's model, ntsc_decode_fast.hip): nothing but the composite
+// plane goes through HBM scratch between the frame row that comes in and the frame row that goes out.
+// One iteration i = one chroma sample period = two luma samples:
+//   main stream   composite bytes 2i, 2i+1 -> Y/C separation :480-553 at positions 2i-2, 2i-1: box luma
+//                 for the luma chain, chroma pair m1 = i-1 -> chroma noise :738-754, phase noise :755-781
+//   VCR chroma    U1/V1[i-1] -> VHS chroma low-pass :834-855, whose output lands d = 4 samples back, at
+//                 m2 = i-5 (the last d outputs of a row keep their raw input) -> vertical blend :862-882
+//                 (row above = lane-1, same iteration) -> chroma sharpen :904-924
+//   VCR luma      box luma -> VHS low-pass + emphasis :812-831 -> sharpen :887-901, held in an 8-deep
+//                 register delay line until the chroma of its position arrives (2d luma samples later)
+//   re-modulate   :926-928 luma 2m2, 2m2+1 + chroma m2 -> composite bytes, straight into
+//   separation 2  :929 at positions 2m2-2, 2m2-1 -> luma to the frame; chroma pair m3 = m2-1 -> dropout
+//                 :932-942 -> full output chroma low-pass :948-951 (U lands 2 back, V 4) -> the frame
+// The reference's read of two bytes past the row (:496) feeds both separations (oob0 / oob1).
+// iter<true> is the guarded form for any i (row start, row end, drain); iter<false> assumes every stage
+// strictly inside the row (6 <= i <= W/2 - 1) and is what the steady loop unrolls four times -- the
+// delay lines are shift registers in the source and plain register renaming in the unrolled loop.
+struct StreamB {
+    static constexpr int D = 4;                  // chroma delay of the SP tape speed :793-808
+    int W, W2, oob0, oob1, k;
+    unsigned xi;
+    bool blend;
+    double a_vc, a_sh_c, sharpen_c;
+    unsigned a0, a1, a2, a3, asum;               // separation 1: Y[x-1 .. x+2] window :486-500
+    int ev1;
+    ChromaPost422 cp;
+    LumaVhs lv;
+    int yq[8];                                   // VCR luma of the last 8 positions, [7] newest
+    Casc3<double> lU, lV, sU, sV;
+    int ru[5], rv[5];                            // chroma into the VHS low-pass, last 5 samples, [4] newest
+    unsigned b0, b1, b2, b3, bsum;               // separation 2
+    int ev3;
+    FrameSink sink;
+
+    DEV void begin(const DevParams &P, int W_, unsigned xi_, int k_, int o0, int o1, double ashc, double shc)
+    {
+        W = W_; W2 = W_ / 2; xi = xi_; k = k_; oob0 = o0; oob1 = o1;
+        blend = P.vblend && P.ntsc;
+        a_vc = P.a_vc; a_sh_c = ashc; sharpen_c = shc;
+        a0 = a1 = 16; a2 = a3 = 0; asum = 0; ev1 = 0;
+        b0 = b1 = 16; b2 = b3 = 0; bsum = 0; ev3 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) yq[q] = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) { ru[q] = 0; rv[q] = 0; }
+        lv.begin(P.a_vl, P.a_sh, P.sharpen);
+        lU.reset(128, P.a_vc); lV.reset(128, P.a_vc); sU.reset(128, ashc); sV.reset(128, ashc);
+    }
+    // the flip of the half-cycle positions :524-527 and the rescale :529-531 of one separated chroma sample
+    DEV int unflip(int ch, int xo, const Magic31 &mA) const
+    {
+        const unsigned g = (unsigned)(xo - 2 + (int)xi) & 3u;
+        if ((g == 0u && xo >= 2) || (g == 1u && xo >= 3)) ch = 255 - ch;
+        return clampu8(sdivm((ch - 128) * 50, mA) + 128);
+    }
+    // separation 2 consumes composite sample x of the VCR's output (:929) and feeds the frame sink
+    template <bool EDGE>
+    DEV void sep2(const DevParams &P, int x, int c_in)
+    {
+        const unsigned c = (unsigned)c_in;
+        if (EDGE && x == 0) { b2 = c; bsum = 32 + b2; return; }
+        if (EDGE && x == 1) { b3 = c; bsum += b3; return; }
+        const int xo = x - 2;
+        bsum -= b0;
+        b0 = b1; b1 = b2; b2 = b3; b3 = c;
+        bsum += c;
+        const unsigned yb = (bsum / 4u) & 0xFFu;
+        int ch = clampu8((int)c + 128 - (int)yb);
+        sink.luma(xo, (int)yb);
+        ch = unflip(ch, xo, P.m_amp);
+        if (!(xo & 1)) ev3 = ch;
+        else {
+            const int a = ev3, b = ch;
+            const int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
+            sink.chroma(xo >> 1, u, v);
+        }
+    }
+    // c0, c1: composite bytes 2i, 2i+1 after head switching (past the row: the caller's two bytes, then unused)
+    template <bool EDGE>
+    DEV void iter(const DevParams &P, int i, int c0, int c1)
+    {
+        // ---- main stream: separation 1 at x = 2i, 2i+1
+        int yb_[2] = {0, 0};
+        bool yok[2] = {false, false};
+        int U1 = 0, V1 = 0;
+        bool pair = false;
+#pragma unroll
+        for (int sx = 0; sx < 2; sx++) {
+            const int x = 2 * i + sx;
+            if (EDGE && x > W + 1) continue;
+            const unsigned c = (unsigned)(sx ? c1 : c0);
+            if (EDGE && x == 0) { a2 = c; asum = 32 + a2; continue; }
+            if (EDGE && x == 1) { a3 = c; asum += a3; continue; }
+            const int xo = x - 2;
+            asum -= a0;
+            a0 = a1; a1 = a2; a2 = a3; a3 = c;
+            asum += c;
+            const unsigned yb = (asum / 4u) & 0xFFu;
+            int ch = clampu8((int)c + 128 - (int)yb);
+            yb_[sx] = (int)yb; yok[sx] = true;
+            ch = unflip(ch, xo, P.m_amp_back);
+            if (!(xo & 1)) ev1 = ch;
+            else {
+                const int a = ev1, b = ch;
+                U1 = (xi & 1u) ? 255 - b : 255 - a; V1 = (xi & 1u) ? 255 - a : 255 - b;
+                chroma_post422(P, cp, U1, V1);
+                pair = true;
+            }
+        }
+        // ---- VCR chroma: input m1 = i - 1, output m2 = i - 1 - D
+        int fU = 0, fV = 0;
+        if (!EDGE || pair) {
+            fU = clampu8((int)lU.push((double)U1, a_vc));
+            fV = clampu8((int)lV.push((double)V1, a_vc));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ru[q] = ru[q + 1]; rv[q] = rv[q + 1]; }
+        ru[4] = U1; rv[4] = V1;
+        const int m2 = i - 1 - D;
+        if (!EDGE || (m2 >= 0 && m2 < W2)) {
+            int u = fU, v = fV;
+            if (EDGE && m2 >= W2 - D) { u = ru[0]; v = rv[0]; }          // row tail keeps its input :848-853
+            const int upU = fastdec::wave_up(u), upV = fastdec::wave_up(v);
+            if (blend && k >= 1) {
+                u = ((k >= 2 ? upU : 128) + u + 1) >> 1;
+                v = ((k >= 2 ? upV : 128) + v + 1) >> 1;
+            }
+            double s = u;
+            double ts = sU.push(s, a_sh_c);
+            u = clampu8((int)(s + ((s - ts) * sharpen_c)));
+            s = v;
+            ts = sV.push(s, a_sh_c);
+            v = clampu8((int)(s + ((s - ts) * sharpen_c)));
+            // re-modulate :434-477 onto the VCR luma of 2 m2, 2 m2 + 1, separate again
+#pragma unroll
+            for (int sx = 0; sx < 2; sx++) {
+                const int lx = 2 * m2 + sx;
+                const unsigned ph = (xi + (unsigned)lx) & 3u;
+                int chroma = ((ph & 1u) ? v - 128 : u - 128) * P.amp;
+                if (ph & 2u) chroma = -chroma;
+                sep2<EDGE>(P, lx, clampu8(yq[sx] + chroma / 50));
+            }
+        } else if (EDGE) {
+            // lanes must stay in step for the wave shift of the blend: nothing to shift here (m2 is wave-uniform)
+            if (m2 == W2) { sep2<true>(P, W, oob0); sep2<true>(P, W + 1, oob1); }   // Y[x+2] past the row :496
+        }
+        // ---- VCR luma of positions 2i-2, 2i-1 enters the delay line (a dummy while outside the row)
+#pragma unroll
+        for (int sx = 0; sx < 2; sx++) {
+            const int y1 = (!EDGE || yok[sx]) ? lv.run(yb_[sx]) : 0;
+#pragma unroll
+            for (int q = 0; q < 7; q++) yq[q] = yq[q + 1];
+            yq[7] = y1;
+        }
+    }
+};
+
 } // namespace fused422
 
 // SPEC: the switch set `ffmpeg_to_composite -vhs` runs (NTSC, SP tape speed, no pre-emphasis, luma / chroma /
@@ -481,7 +641,8 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 #ifndef F422_WAVES
 #define F422_WAVES 1
 #endif
-template <bool SPEC>
+// STREAM (with SPEC): sweeps B1-B3 as the one streamed pass of StreamB above.
+template <bool SPEC, bool STREAM = false>
 __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDev G,
                                                  const Field422Dev *__restrict__ fields,
                                                  Scratch422 Sc,
@@ -572,6 +733,40 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 2
     return;
 #endif
+    if constexpr (STREAM) {
+        // ---- B1 + B2 + B3 in one streamed pass (StreamB)
+        StreamB B;
+        B.begin(P, W, xi, k, oob0, oob1, a_sh_c, sharpen_c);
+        B.cp.noise_on = true; B.cp.phase_on = true; B.cp.ring = ring; B.cp.lane = lane;
+        B.cp.rng.init(ring, rs_chroma + rc, P.Rpad, lane); B.cp.nU = n0_u[rc]; B.cp.nV = n0_v[rc];
+        {
+            int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+            n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+            B.cp.cosv = G.ptab[2 * n]; B.cp.sinv = G.ptab[2 * n + 1];
+        }
+        B.sink.begin(P, true, 2, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        const int W2 = W / 2, NIT = W2 + StreamB::D + 2;
+        auto in_byte = [&](int x) -> int { return x < W ? R.Y.byte_at(x) : (x == W ? oob0 : (x == W + 1 ? oob1 : 0)); };
+        int i = 0;
+        for (; i < 8 && i < NIT; i++) B.iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        if (i == 8 && i + 3 <= W2 - 1) {
+            uint32_t w0 = R.Y.word(i >> 1), w1 = R.Y.word((i >> 1) + 1);
+            for (; i + 3 <= W2 - 1; i += 4) {
+                // the next two words are requested before this pair is worked on (clamped at the row end)
+                const int qn = (i >> 1) + 2, qmax = (W - 1) >> 2;
+                const uint32_t n0 = R.Y.word(qn <= qmax ? qn : qmax), n1 = R.Y.word(qn + 1 <= qmax ? qn + 1 : qmax);
+                B.iter<false>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                B.iter<false>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
+                B.iter<false>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
+                B.iter<false>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
+                w0 = n0; w1 = n1;
+            }
+        }
+        for (; i < NIT; i++) B.iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        B.sink.finish(W);
+        F422_STAMP(4);
+        return;
+    }
     // ---- B1: Y/C separation + chroma noise + phase noise | VHS luma low-pass + sharpen
     {
         ChromaPost422 cp_;

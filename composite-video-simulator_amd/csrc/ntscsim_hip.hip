@@ -131,6 +131,7 @@ struct ntscsim_ctx {
     bool force_generic = false;
     bool split_vhs = false;          // debug / A-B: VCR half + TV half in two launches instead of k_decode_fast<true>
     bool no_fast_decode = false;     // debug: keep the PRESET template kernels (A/B against k_decode_fast)
+    bool no_stream422 = false;       // debug: the YUV422P preset kernel as four sweeps instead of A + one streamed pass
     int mode = NTSCSIM_MODE_EXACT;
 };
 
@@ -340,7 +341,7 @@ extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx *
     // developer A/B switch (same as ntscsim_debug_no_fast_decode): NTSCSIM_DEBUG_DECODE=1|2|3
     if (const char *e = std::getenv("NTSCSIM_DEBUG_DECODE")) {
         const int v = std::atoi(e);
-        c->no_fast_decode = (v & 1) != 0; c->split_vhs = (v & 2) != 0;
+        c->no_fast_decode = (v & 1) != 0; c->split_vhs = (v & 2) != 0; c->no_stream422 = (v & 4) != 0;
     }
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -436,7 +437,7 @@ extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
 
 extern "C" void ntscsim_debug_no_fast_decode(ntscsim_ctx *c, int on)
 {
-    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; }
+    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; c->no_stream422 = (on & 4) != 0; }
 }
 
 extern "C" int ntscsim_debug_last_kernels(const ntscsim_ctx *c, char *out, size_t cap)
@@ -1035,8 +1036,14 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // output chroma low-pass (ffmpeg_to_composite.cpp:278 default true, selection :948-951)
     const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 2 &&
                       D.cdelay == 4 && D.src_al16 && D.dst_al16;
-    note_kernel(c, !fused ? "k422_process" : (spec ? "k422_fused<true>" : "k422_fused<false>"));
-    if (fused && spec)
+    // ... and runs its B sweeps as one streamed pass (debug bit 2 keeps the four-sweep preset form)
+    const bool stream = spec && !c->no_stream422;
+    note_kernel(c, !fused ? "k422_process" : (spec ? (stream ? "k422_fused<true,true>" : "k422_fused<true>") : "k422_fused<false>"));
+    if (fused && stream)
+        hipLaunchKernelGGL((k422_fused<true, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    else if (fused && spec)
         hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
                            c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                            c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);

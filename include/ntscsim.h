@@ -444,7 +444,9 @@ void ntscsim_debug_force_generic(ntscsim_ctx *ctx, int on);
 /* Test hook: bit 0 keeps the template-specialised PRESET kernels (k_encode / k_decode) where the
  * hand-tuned ones (csrc/ntsc_encode_fast.hip, csrc/ntsc_decode_fast.hip) would run; bit 1 runs
  * the hand-tuned VHS decoder as two launches (VCR half -> second composite plane -> TV half)
- * instead of one.  Results must not change. */
+ * instead of one; for the YUV422P tool bit 0 selects the twelve-sweep kernel, bit 1 the run-time-switch
+ * form of the four-sweep kernel, bit 2 the four-sweep form of the preset kernel (instead of sweep A + one
+ * streamed pass).  Results must not change. */
 void ntscsim_debug_no_fast_decode(ntscsim_ctx *ctx, int on);
 
 /* Which kernel forms the last ntscsim_fields_device() / ntscsim_fields422_device() / batch run on this

@@ -289,10 +289,11 @@ def test_hip_reproduces_reference_golden(m):
 
 
 # (flags, the kernel form the launcher must pick by default).  `ffmpeg_to_composite -vhs` runs the FULL
-# output chroma low-pass (ffmpeg_to_composite.cpp:278, :948-951): that switch set is k422_fused<true>.
+# output chroma low-pass (ffmpeg_to_composite.cpp:278, :948-951): that switch set is the preset kernel,
+# k422_fused<true,true> (sweep A + one streamed pass; as four sweeps it is k422_fused<true>).
 _FORM_CASES = [
-    (["-vhs"], "k422_fused<true>"),
-    (["-vhs", "-out-composite-lowpass-lite", "0"], "k422_fused<true>"),          # full low-pass still on
+    (["-vhs"], "k422_fused<true,true>"),
+    (["-vhs", "-out-composite-lowpass-lite", "0"], "k422_fused<true,true>"),     # full low-pass still on
     (["-vhs", "-out-composite-lowpass", "0"], "k422_fused<false>"),              # lite output low-pass
     (["-vhs", "-out-composite-lowpass", "0", "-out-composite-lowpass-lite", "0"], "k422_fused<false>"),
     (["-vhs", "-vhs-speed", "ep"], "k422_fused<false>"),
@@ -308,12 +309,13 @@ _FORM_CASES = [
 @pytest.mark.parametrize("flags,form", _FORM_CASES,
                          ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-ep", "pal-vhs", "vhs-catv", "vhs-nonoise",
                               "vhs-svideo", "default"])
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["default", "twelve-sweep", "general-fused"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 4], ids=["default", "twelve-sweep", "general-fused", "preset-four-sweep"])
 def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
-    """The three kernel forms of the -vhs family (k422_fused<true> for the preset's own switch set,
-    k422_fused<false>, k422_process) on the same fields: each must equal the oracle, and the form
-    that ran must be the one the case names (ntscsim_debug_last_kernels).  mode = the
-    ntscsim_debug_no_fast_decode() bits (1: twelve-sweep form, 2: no preset instantiation)."""
+    """The four kernel forms of the -vhs family (k422_fused<true,true> = sweep A + one streamed pass and
+    k422_fused<true> = four sweeps for the preset's own switch set, k422_fused<false>, k422_process) on
+    the same fields: each must equal the oracle, and the form that ran must be the one the case names
+    (ntscsim_debug_last_kernels).  mode = the ntscsim_debug_no_fast_decode() bits (1: twelve-sweep form,
+    2: no preset instantiation, 4: the preset as four sweeps)."""
     import torch
     w, h, n = 128, 38, 4
     p = L.make_params_tocomp(flags)
@@ -323,7 +325,9 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
     mask = last_row_margin_mask(frame, 0)
     sim = ntscsim.FieldSimulator(params=p)
     sim.debug_no_fast_decode(mode)
-    want = "k422_process" if mode == 1 else ("k422_fused<false>" if mode == 2 and form == "k422_fused<true>" else form)
+    preset = form == "k422_fused<true,true>"
+    want = "k422_process" if mode == 1 else ("k422_fused<false>" if mode == 2 and preset else
+                                             ("k422_fused<true>" if mode == 4 and preset else form))
     whole, dev = to_dev_onebuf(torch, frame)
     for k in range(n):
         field = (k & 1) ^ 1
@@ -381,7 +385,7 @@ def test_422_batch_refuses_racing_descriptors():
 @pytest.mark.parametrize("pad", [0, 3, 16])
 def test_fused_kernel_widths_and_row_alignments(w, pad):
     """-vhs at widths around the four-sweep kernel's 16 / 64-sample block sizes, with row paddings that
-    make luma / chroma rows 16- / 8-byte aligned (k422_fused<true>, the preset instantiation) or not
+    make luma / chroma rows 16- / 8-byte aligned (k422_fused<true,true>, the preset instantiation) or not
     (k422_fused<false>); the form that ran is asserted."""
     import torch
     h, n = 10, 3
@@ -401,7 +405,7 @@ def test_fused_kernel_widths_and_row_alignments(w, pad):
         sim.sync()
         # aligned luma (16) and chroma (8) rows and plane starts -> the preset instantiation
         al = all(o_ % a == 0 and l_ % a == 0 for o_, l_, a in zip(frame.off, frame.ls, (16, 8, 8)))
-        assert ("k422_fused<true>" if al else "k422_fused<false>") in sim.last_kernels(), (al, sim.last_kernels())
+        assert ("k422_fused<true,true>" if al else "k422_fused<false>") in sim.last_kernels(), (al, sim.last_kernels())
         got = whole.cpu().numpy()
         bad = (got != frame.buf) & mask
         assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
