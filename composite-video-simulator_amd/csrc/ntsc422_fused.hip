@@ -190,7 +190,12 @@ struct ChromaLpFull {
 // ---------------------------------------------------------------------------------- sweep A
 // Stream index m = the chroma sample being modulated; the low-passes run D = 4 (NTSC: the V delay)
 // or 2 (PAL) samples ahead of it.
-template <bool NTSC, bool ALIGNED>
+// FAST (the preset kernel's streamed form; launcher preconditions: NTSC, no pre-emphasis, luma noise on,
+// even scanline phase, subcarrier amplitude 50, aligned rows): blocks of 8 chroma samples that lie strictly
+// inside the row run a body without bounds tests or row-tail selects, with (chroma * 50) / 50 == chroma
+// (:470) and the modulation sign (:463-466: bit 1 of xi + x) as a per-lane mask chosen by the unrolled
+// position -- the same results as the general body, which still runs the first and the last block(s).
+template <bool NTSC, bool ALIGNED, bool FAST = false>
 DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
                  int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q)
 {
@@ -208,6 +213,8 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
 #pragma unroll
     for (int i = 0; i <= D - DU; i++) filU[i] = 128;
     int filV = 128;
+    const bool hi = (xi & 2u) != 0;
+    const int sm0 = fastdec::opaque_v(hi ? -1 : 0), sm1 = fastdec::opaque_v(hi ? 0 : -1);
     // Groups of 32 chroma inputs = 64 luma bytes = 4 blocks of 8 chroma inputs.  A group's 64 + 32 + 32
     // frame bytes are requested together one group ahead (the pieces of one cache line back to back,
     // so a line is fetched twice / four times per row instead of 8 / 16 times) and rotate through
@@ -228,6 +235,36 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
 #pragma unroll 1
       for (int c0 = g0; c0 < g0 + 32 && c0 < W2 + D; c0 += 8) {
         uint32_t (&ly)[4] = gy[0], (&cu)[2] = gu[0], (&cv)[2] = gv[0];
+        if (FAST && c0 >= 8 && c0 + 8 <= W2) {
+            // ---- every sample of the block strictly inside the row: D <= c < W2, 0 <= m < W2 - D
+            const int q0 = (c0 - D) >> 1;                   // scratch word of luma 2 (c0 - D) (c0 is a multiple of 8)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+#pragma unroll
+                for (int i = 0; i < D; i++) { rawU[i] = rawU[i + 1]; rawV[i] = rawV[i + 1]; }
+#pragma unroll
+                for (int i = 0; i < D - DU; i++) filU[i] = filU[i + 1];
+                const int u = byte_of(cu[j >> 2], j & 3), v = byte_of(cv[j >> 2], j & 3);
+                rawU[D] = u; rawV[D] = v;
+                filU[D - DU] = lU.push(u);
+                filV = lV.push(v);
+                const int U1 = filU[0], V1 = filV;
+                const int sm = (j & 1) ? sm1 : sm0;           // x & 2 = 2 ((c0 + j - D) & 1) = 2 (j & 1)
+#pragma unroll
+                for (int sx = 0; sx < 2; sx++) {
+                    const int lb = 2 * (j - D) + sx;
+                    const int yin = lb >= 0 ? byte_of(ly[lb >> 2], lb & 3) : byte_of(ly_prev[(lb + 16) >> 2], (lb + 16) & 3);
+                    const int cval = (sx ? V1 : U1) - 128;
+                    int yv = clampu8(yin + ((cval ^ sm) - sm));
+                    yv = clampu8(yv + post.noise);
+                    post.noise = sdiv2(post.noise + (int)umod31(post.rng.next(post.ring, post.lane), P.m_noise) - P.noise_k);
+                    // byte (2 j + sx) & 3 of scratch word q0 + ((2 j + sx) >> 2)
+                    const int kb = (2 * j + sx) & 3;
+                    oy.acc = kb ? (oy.acc | ((uint32_t)yv << (8 * kb))) : (uint32_t)yv;
+                    if (kb == 3) oy.pl.set_word(q0 + ((2 * j + sx) >> 2), oy.acc);
+                }
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int c = c0 + j;
@@ -269,6 +306,7 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
                 }
                 oy.put(x, yv);
             }
+        }
         }
         // next block of the group becomes the current one
 #pragma unroll
@@ -342,6 +380,10 @@ struct FrameSink {
     DEV void chroma(int c, int u, int v)
     {
         if (drop) { u = 128; v = 128; }
+        chroma_nodrop(c, u, v);
+    }
+    DEV void chroma_nodrop(int c, int u, int v)      // (the caller has applied the dropout)
+    {
         u4 = u3; u3 = u2; u2 = u1; u1 = u;
         v4 = v3; v3 = v2; v2 = v1; v1 = v;
         if (mode == 0) { wu.put(c, u); wv.put(c, v); return; }
@@ -630,6 +672,100 @@ struct StreamB {
             yq[7] = y1;
         }
     }
+
+    // ---- the steady-state form of iter() for the preset's arithmetic identities.  Preconditions (launcher):
+    // even scanline phase (xi is 0 or 2) and subcarrier amplitude 50 both ways, so that
+    //   * (x * 50) / 50 == x: the rescale :529-531 and the modulation's (chroma * amp) / 50 :470 vanish;
+    //   * the U/V pick :535-550 is u = 255 - a, v = 255 - b;
+    //   * the half-cycle flip :524-527 at position xo >= 3 is "iff bit 1 of xo + xi is set": the XOR of a
+    //     per-lane mask (xi == 2) and a property of the unrolled loop position (J: i = 4n + J);
+    //   * the sign of the modulated chroma at luma lx :463-466 is bit 1 of xi + lx, likewise.
+    // fm0 / fm1: 255 where a flip happens for xo & 2 == 0 / != 0; sm0 / sm1: -1 where the chroma is negated
+    // for lx & 2 == 0 / != 0; bA / b128 / bC: the vertical blend as mask arithmetic; dmask: dropout.
+    int fm0, fm1, sm0, sm1, bA, b128, bC, dmask;
+    DEV void begin_fast(bool dropped)
+    {
+        const bool hi = (xi & 2u) != 0;
+        fm0 = fastdec::opaque_v(hi ? 255 : 0); fm1 = fastdec::opaque_v(hi ? 0 : 255);
+        sm0 = fastdec::opaque_v(hi ? -1 : 0); sm1 = fastdec::opaque_v(hi ? 0 : -1);
+        const bool on = blend && k >= 1;
+        bA = fastdec::opaque_v(on && k >= 2 ? -1 : 0);
+        b128 = fastdec::opaque_v(on && k < 2 ? 128 : 0);
+        bC = fastdec::opaque_v(on ? 1 : 0);
+        dmask = fastdec::opaque_v(dropped ? 0 : -1);
+    }
+    template <int XO2>       // XO2 = xo & 2 of the position being separated
+    DEV void sep2_fast(int xo, bool odd, int c_in)
+    {
+        const unsigned c = (unsigned)c_in;
+        bsum -= b0;
+        b0 = b1; b1 = b2; b2 = b3; b3 = c;
+        bsum += c;
+        const unsigned yb = (bsum >> 2) & 0xFFu;
+        int ch = clampu8((int)c + 128 - (int)yb);
+        sink.luma(xo, (int)yb);
+        ch ^= XO2 ? fm1 : fm0;
+        if (!odd) ev3 = ch;
+        else {
+            // dropout :932-942 as a mask: 128 + ((x - 128) & dmask)
+            const int u = 128 + ((127 - ev3) & dmask), v = 128 + ((127 - ch) & dmask);
+            sink.chroma_nodrop(xo >> 1, u, v);
+        }
+    }
+    template <int J>
+    DEV void iter_fast(const DevParams &P, int ib, int c0, int c1)
+    {
+        const int i = ib + J;                     // ib is a multiple of 4
+        // ---- main stream: separation 1 at x = 2i, 2i+1 (xo = 2i-2 even, 2i-1 odd; xo & 2 = (2J - 2) & 2)
+        constexpr int XO2A = (2 * J + 2) & 2;
+        int yb_[2];
+        {
+            const unsigned c = (unsigned)c0;
+            asum -= a0; a0 = a1; a1 = a2; a2 = a3; a3 = c; asum += c;
+            const unsigned yb = (asum >> 2) & 0xFFu;
+            yb_[0] = (int)yb;
+            ev1 = clampu8((int)c + 128 - (int)yb) ^ (XO2A ? fm1 : fm0);
+        }
+        int U1, V1;
+        {
+            const unsigned c = (unsigned)c1;
+            asum -= a0; a0 = a1; a1 = a2; a2 = a3; a3 = c; asum += c;
+            const unsigned yb = (asum >> 2) & 0xFFu;
+            yb_[1] = (int)yb;
+            const int ch = clampu8((int)c + 128 - (int)yb) ^ (XO2A ? fm1 : fm0);
+            U1 = 255 - ev1; V1 = 255 - ch;
+            chroma_post422(P, cp, U1, V1);
+        }
+        // ---- VCR chroma: input m1 = i - 1, output m2 = i - 5 (strictly inside the row: filtered value)
+        int u = clampu8((int)lU.push((double)U1, a_vc));
+        int v = clampu8((int)lV.push((double)V1, a_vc));
+#pragma unroll
+        for (int q = 0; q < 4; q++) { ru[q] = ru[q + 1]; rv[q] = rv[q + 1]; }
+        ru[4] = U1; rv[4] = V1;
+        u = (((fastdec::wave_up(u) & bA) + b128) + u + bC) >> bC;
+        v = (((fastdec::wave_up(v) & bA) + b128) + v + bC) >> bC;
+        double s = u;
+        double ts = sU.push(s, a_sh_c);
+        u = clampu8((int)(s + ((s - ts) * sharpen_c)));
+        s = v;
+        ts = sV.push(s, a_sh_c);
+        v = clampu8((int)(s + ((s - ts) * sharpen_c)));
+        // ---- re-modulate onto the VCR luma of lx = 2i-10, 2i-9 (even: U, odd: V; lx & 2 = (2J - 10) & 2), and
+        // separate again at xo = lx - 2 (xo & 2 = (2J) & 2)
+        constexpr int LX2 = (2 * J + 2) & 2, XO2B = (2 * J) & 2;
+        const int sm = LX2 ? sm1 : sm0;
+        const int lx = 2 * i - 10;
+        sep2_fast<XO2B>(lx - 2, false, clampu8(yq[0] + (((u - 128) ^ sm) - sm)));
+        sep2_fast<XO2B>(lx - 1, true, clampu8(yq[1] + (((v - 128) ^ sm) - sm)));
+        // ---- VCR luma of positions 2i-2, 2i-1 enters the delay line
+#pragma unroll
+        for (int sx = 0; sx < 2; sx++) {
+            const int y1 = lv.run(yb_[sx]);
+#pragma unroll
+            for (int q = 0; q < 7; q++) yq[q] = yq[q + 1];
+            yq[7] = y1;
+        }
+    }
 };
 
 } // namespace fused422
@@ -694,7 +830,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         lp_.pre_on = SPEC ? false : P.pre_on != 0; lp_.noise_on = SPEC ? true : P.noise_k != 0;
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
-        if (SPEC || P.ntsc) sweep_a<true, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        if (SPEC || P.ntsc) sweep_a<true, SPEC, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
         else sweep_a<false, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
     }
     F422_STAMP(0);
@@ -745,6 +881,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
             B.cp.cosv = G.ptab[2 * n]; B.cp.sinv = G.ptab[2 * n + 1];
         }
         B.sink.begin(P, true, 2, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        B.begin_fast(P.loss && dropout[rc] != 0);
         const int W2 = W / 2, NIT = W2 + StreamB::D + 2;
         auto in_byte = [&](int x) -> int { return x < W ? R.Y.byte_at(x) : (x == W ? oob0 : (x == W + 1 ? oob1 : 0)); };
         int i = 0;
@@ -755,10 +892,17 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
                 // the next two words are requested before this pair is worked on (clamped at the row end)
                 const int qn = (i >> 1) + 2, qmax = (W - 1) >> 2;
                 const uint32_t n0 = R.Y.word(qn <= qmax ? qn : qmax), n1 = R.Y.word(qn + 1 <= qmax ? qn + 1 : qmax);
+#ifdef F422_STREAM_GENERIC_STEADY     /* A/B: the guard-free form of the generic iteration */
                 B.iter<false>(P, i, byte_of(w0, 0), byte_of(w0, 1));
                 B.iter<false>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
                 B.iter<false>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
                 B.iter<false>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
+#else
+                B.iter_fast<0>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                B.iter_fast<1>(P, i, byte_of(w0, 2), byte_of(w0, 3));
+                B.iter_fast<2>(P, i, byte_of(w1, 0), byte_of(w1, 1));
+                B.iter_fast<3>(P, i, byte_of(w1, 2), byte_of(w1, 3));
+#endif
                 w0 = n0; w1 = n1;
             }
         }

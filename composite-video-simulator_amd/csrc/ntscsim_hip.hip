@@ -1037,7 +1037,10 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     const bool spec = !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && D.cnoise_k && D.pnoise_k && D.out_lp == 2 &&
                       D.cdelay == 4 && D.src_al16 && D.dst_al16;
     // ... and runs its B sweeps as one streamed pass (debug bit 2 keeps the four-sweep preset form)
-    const bool stream = spec && !c->no_stream422;
+    // (its steady loop uses identities of an even scanline phase -- NTSC mode 180 with an even offset, or mode 0 --
+    // and of subcarrier amplitude 50 both ways: scan_phase422, ntsc422_fused.hip StreamB::iter_fast)
+    const bool even422 = D.phase_mode == 180 ? !(D.phase_off & 1) : (D.phase_mode != 90 && D.phase_mode != 270);
+    const bool stream = spec && even422 && D.amp == 50 && D.amp_back == 50 && !c->no_stream422;
     note_kernel(c, !fused ? "k422_process" : (spec ? (stream ? "k422_fused<true,true>" : "k422_fused<true>") : "k422_fused<false>"));
     if (fused && stream)
         hipLaunchKernelGGL((k422_fused<true, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
