@@ -9,11 +9,11 @@ p = ntscsim.make_params_to_composite(["-vhs"])
 lib = ntscsim.lib()
 sim = ntscsim.FieldSimulator(params=p)
 base = L.yuv_bars(w, h, 0)
-frames = [[torch.from_numpy(base.plane(i).copy()).cuda() for i in range(3)] for _ in range(nf // 2)]
+frames = [[torch.from_numpy(base.plane(i).copy()).cuda() for i in range(3)] for _ in range(nf)]   # every field its own frame
 jobs, pos = [], 0
 for k in range(nf):
     field = (k & 1) ^ 1
-    jobs.append({"dst": frames[k // 2], "field": field, "fieldno": k, "rng_pos": pos})
+    jobs.append({"dst": frames[k], "field": field, "fieldno": k, "rng_pos": pos})
     pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, field)
 sim.fields422(jobs, w, h); sim.sync()
 t0 = time.perf_counter()
