@@ -187,7 +187,10 @@ __device__ __forceinline__ void front_span(FrontState &st, const FrontConst &K, 
     st = P.state();
 }
 
-// round 0 (speculative, all chunks) and repair rounds (flagged chunks, start = predecessor's end)
+// round 0 (speculative, all chunks) and repair rounds (flagged chunks, start = predecessor's end).  The
+// samples [o0, N) of the buffer are new (a stream is decoded push by push; o0 = 0 for a whole capture): the
+// state before sample o0 is `init`, exactly.  Chunk 0 = [o0, a0 + chunk), chunk c = [a0 + c chunk, a0 + (c + 1)
+// chunk) with a0 = o0 rounded up to the 16-sample grid of the vector loads.
 // Launched as 256-thread workgroups that each claim a whole CU's LDS (FRONT_PIN_LDS bytes of dynamic shared
 // memory nobody touches): one workgroup per CU, its four wavefronts on the CU's four SIMDs -- a lane's run
 // is a single dependent chain of warm-up + chunk samples, so the kernel takes as long as its most crowded
@@ -196,29 +199,40 @@ __device__ __forceinline__ void front_span(FrontState &st, const FrontConst &K, 
 constexpr int FRONT_WG = 256;
 constexpr size_t FRONT_PIN_LDS = 96 * 1024;        // > half of the CU's 160 KiB: a second workgroup cannot fit
 __global__ __launch_bounds__(FRONT_WG) void k_raw28_front(const uint8_t *__restrict__ raw, size_t N, uint8_t *__restrict__ h,
-                                                    int chunk, int warm, int nchunks, FrontConst K, FrontState init,
+                                                    size_t o0, int chunk, int warm, int nchunks, FrontConst K, FrontState init,
                                                     FrontState *__restrict__ st_begin, FrontState *__restrict__ st_end,
                                                     const FrontState *__restrict__ prev_end, const int *__restrict__ flags)
 {
     const int c = blockIdx.x * FRONT_WG + threadIdx.x;
     if (c >= nchunks) return;
     if (flags && !flags[c]) return;
-    const size_t s0 = (size_t)c * (size_t)chunk;
-    const size_t s1 = s0 + (size_t)chunk < N ? s0 + (size_t)chunk : N;
+    const size_t a0 = (o0 + 15) & ~(size_t)15;
+    const size_t g0 = a0 + (size_t)c * (size_t)chunk;                      // on the 16-sample grid
+    const size_t s0 = c == 0 ? o0 : g0;
+    const size_t s1 = g0 + (size_t)chunk < N ? g0 + (size_t)chunk : N;
+    // the samples between o0 and the grid, one at a time (OUT: they belong to chunk 0)
+    auto head = [&](FrontState &st, bool out) {
+        const size_t e = a0 < N ? a0 : N;
+        for (size_t s = o0; s < e; s++) { const int v = front_step(st, K, (double)raw[s]); if (out) h[s] = (uint8_t)v; }
+    };
     FrontState st;
     if (flags) {
         st = prev_end[c - 1];                      // repair: the true state before this chunk (so far)
-    } else if (s0 <= (size_t)warm) {
-        st = init;                                 // from the start of the stream: exact
-        front_span<false>(st, K, raw, h, 0, s0);
+    } else if (c == 0) {
+        st = init;                                 // the state before the first new sample: exact
+    } else if (g0 - a0 <= (size_t)warm) {
+        st = init;                                 // close to the first new sample: walk there from the exact state
+        head(st, false);
+        front_span<false>(st, K, raw, h, a0, g0);
     } else {
-        const size_t w0 = s0 - (size_t)warm;       // (warm and chunk are multiples of 16)
+        const size_t w0 = g0 - (size_t)warm;       // (warm and chunk are multiples of 16)
         const double r0 = (double)raw[w0];
         st.p0 = st.p1 = st.p2 = r0; st.level = 255.0;
-        front_span<false>(st, K, raw, h, w0, s0);
+        front_span<false>(st, K, raw, h, w0, g0);
     }
     st_begin[c] = st;
-    front_span<true>(st, K, raw, h, s0, s1);
+    if (c == 0) { head(st, true); if (a0 < s1) front_span<true>(st, K, raw, h, a0, s1); }
+    else front_span<true>(st, K, raw, h, s0, s1);
     st_end[c] = st;
 }
 
@@ -297,19 +311,22 @@ __global__ __launch_bounds__(RUN_T) void k_raw28_run_scatter(const uint8_t *__re
 // ---- calibration sums of the equalising pulses :661-676: one wave per range [si, i)
 struct CalRange { uint32_t si, i, pulse, _pad; };   // samples [si, i) of the stream, summed into pulse `pulse`
 struct CalSums { int mina, mind, maxa, maxd; };
-__device__ __forceinline__ int raw_delayed(const uint8_t *raw, const uint8_t *h, size_t s, int D, int thr, int mark)
+// (base = stream position of sample 0 of the buffer: 0 for a whole capture; a stream keeps at least D
+// samples in front of every position it can still ask for)
+__device__ __forceinline__ int raw_delayed(const uint8_t *raw, const uint8_t *h, size_t s, int D, int thr, int mark,
+                                           unsigned long long base)
 {
     if (mark && h[s] < thr) return 255;            // :590-591
-    return s >= (size_t)D ? raw[s - D] : 0;        // :572-581 (the delay line starts zero-filled)
+    return base + s >= (unsigned long long)D ? raw[s - D] : 0;   // :572-581 (the delay line starts zero-filled)
 }
 __global__ __launch_bounds__(64) void k_raw28_cal(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h,
                                                   const CalRange *__restrict__ rg, CalSums *__restrict__ out,
-                                                  int D, int thr, int mark)
+                                                  int D, int thr, int mark, unsigned long long base)
 {
     const CalRange r = rg[blockIdx.x];
     int mina = 0, mind = 0, maxa = 0, maxd = 0;
     for (size_t s = (size_t)r.si + threadIdx.x; s < (size_t)r.i; s += 64) {
-        const int v = raw_delayed(raw, h, s, D, thr, mark);
+        const int v = raw_delayed(raw, h, s, D, thr, mark, base);
         if (h[s] >= thr) { maxa += v; maxd++; } else { mina += v; mind++; }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -328,12 +345,13 @@ struct LineRec {
 struct RenderConst {
     int len, width, D, thr;
     int mark, no_equ, no_wequ, no_sc, show_sc;
+    unsigned long long base;       // stream position of sample 0 of the buffer
 };
 __device__ __forceinline__ int equalised(const uint8_t *raw, const uint8_t *h, size_t N, const LineRec &L,
                                          const RenderConst &R, int x)
 {
     const size_t s = (size_t)L.pos + (size_t)x;
-    int v = s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark) : 0;     // int16 luma = raw :702
+    int v = s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark, R.base) : 0;     // int16 luma = raw :702
     if (!R.no_equ) {
         v = (int)((double)v - L.blank);                                 // :708
         if (!R.no_wequ) v = (int)((double)(v * 255) / (L.white - L.blank));   // :709
@@ -358,7 +376,7 @@ __global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__
 #pragma unroll
     for (int k = 0; k < 16; k++) C[k] = S[k] - (S[k] + S[k + 4] + 1) / 2;     // :731-734
 #pragma unroll
-    for (int k = 0; k < 16; k++) C[16 + k] = y > 0 ? tin[(size_t)(y - 1) * 16 + k] : 0;
+    for (int k = 0; k < 16; k++) C[16 + k] = tin[((ptrdiff_t)y - 1) * 16 + k];     // (row -1: the tail carried in, 0 at a stream's start)
 #pragma unroll
     for (int k = 0; k < 16; k++) C[k] = C[k] + C[k + 8] - C[k + 4] - C[k + 12];   // :736-737 (ascending, in place)
 #pragma unroll
@@ -397,7 +415,7 @@ __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict_
         return;
     }
     for (int x = threadIdx.x; x < n; x += 256)
-        A[x] = x < len ? S[x] - (S[x] + S[x + 4] + 1) / 2 : (y > 0 ? tails[(size_t)(y - 1) * 16 + (x - len)] : 0);
+        A[x] = x < len ? S[x] - (S[x] + S[x + 4] + 1) / 2 : tails[((ptrdiff_t)y - 1) * 16 + (x - len)];
     __syncthreads();
     for (int x = threadIdx.x; x < n; x += 256) B2[x] = x < len ? A[x] + A[x + 8] - A[x + 4] - A[x + 12] : A[x];
     __syncthreads();
@@ -424,6 +442,66 @@ __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict_
 } // namespace
 
 // ------------------------------------------------------------------------------------------ host
+namespace {
+
+// The walk over the sync runs: composite_layer() :622-693 and :789-830 with the buffer window of
+// :277-332 reduced to its two numbers (begin, end of the buffered part of the stream).
+struct RunWalk {
+    const uint32_t *rs, *re;
+    size_t nruns;
+    mutable size_t k = 0;          // cursor: the searches move forward, or back by a fraction of a scanline
+    // first run that ends after position i: [si, ei) clipped to i and E; si == ei == E when none
+    void next(size_t i, size_t E, size_t &si, size_t &ei) const
+    {
+        while (k > 0 && (size_t)re[k - 1] > i) k--;
+        while (k < nruns && (size_t)re[k] <= i) k++;
+        if (k >= nruns || (size_t)rs[k] >= E) { si = ei = E; return; }
+        si = std::max<size_t>(rs[k], i);
+        ei = std::min<size_t>(re[k], E);
+    }
+};
+
+// What the tool's sample buffer holds (:264-357): which stream position every record of the array was
+// last filled from.  Only the calibration sums of :661-676 can run past the filled part (the search
+// position jumps 0.3 scanlines ahead of a pulse, :655), and there they read whatever the records held
+// before -- samples of an earlier window after the buffer has been moved down, zero-initialised
+// records (hsync_dc_raw 0, raw 0) while the array has never been full.
+struct BufMap {
+    struct Seg { size_t k0, k1, abs0; };           // records [k0, k1) hold samples abs0 + (k - k0)
+    std::vector<Seg> segs;                         // sorted, disjoint
+    void assign(size_t k0, size_t k1, size_t abs0)
+    {
+        if (k0 >= k1) return;
+        std::vector<Seg> out;
+        for (const Seg &g : segs) {
+            if (g.k1 <= k0 || g.k0 >= k1) { out.push_back(g); continue; }
+            if (g.k0 < k0) out.push_back(Seg{g.k0, k0, g.abs0});
+            if (g.k1 > k1) out.push_back(Seg{k1, g.k1, g.abs0 + (k1 - g.k0)});
+        }
+        out.push_back(Seg{k0, k1, abs0});
+        std::sort(out.begin(), out.end(), [](const Seg &a, const Seg &b) { return a.k0 < b.k0; });
+        segs.swap(out);
+    }
+    // records [k0, k1): stream pieces through `piece(abs_begin, abs_end)`, returns the number of records
+    // that were never filled
+    template <class F>
+    size_t lookup(size_t k0, size_t k1, F piece) const
+    {
+        size_t zeros = 0, k = k0;
+        for (const Seg &g : segs) {
+            if (g.k1 <= k || g.k0 >= k1) continue;
+            if (g.k0 > k) { zeros += g.k0 - k; k = g.k0; }
+            const size_t e = std::min(g.k1, k1);
+            piece(g.abs0 + (k - g.k0), g.abs0 + (e - g.k0));
+            k = e;
+        }
+        if (k < k1) zeros += k1 - k;
+        return zeros;
+    }
+};
+
+} // namespace
+
 struct ntscsim_raw28 {
     ntscsim_raw28_opts o;
     int device = 0;
@@ -437,13 +515,25 @@ struct ntscsim_raw28 {
     bool chunk_forced = false;
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
-    // results of the last call
+    // decoder state: levels (:553-554), stream position; kept from push to push of a stream
     double blank = 0, white = 192;
     uint64_t read_pos = 0;
+    // stream state (ntscsim_raw28_stream_*; a whole-capture decode is a reset plus one final push).  The
+    // device buffers raw / h hold the samples [base, base + cnt) of the stream; every other position below
+    // is RELATIVE to base and moves down with it when the buffer is compacted.
+    uint64_t base = 0;
+    size_t cnt = 0;                // samples held
+    size_t front_done = 0;         // samples the front end has processed
+    FrontState front_state;        // its exact state after sample front_done - 1
+    size_t Bw = 0, Rd = 0, Ew = 0; // the tool's buffer window: begin, read position, end
+    BufMap bm;                     // what the tool's sample array holds (stale records included)
+    int tail_carry[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // comb tail of the last scanline rendered
+    bool eof = false;
+    uint64_t fields_total = 0;
     int64_t stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t last_n = 0;
     // device scratch
-    Buf<uint8_t> raw, h, tmp;
+    Buf<uint8_t> raw, h, raw_alt, h_alt, tmp;
     Buf<FrontState> st_begin, st_end, st_prev;
     Buf<int> flags, counters, tails_a, tails_b;
     Buf<unsigned long long> segcnt, segoff;
@@ -593,79 +683,56 @@ extern "C" int ntscsim_raw28_debug_read_front(ntscsim_raw28 *d, uint8_t *hs, siz
     return NTSCSIM_OK;
 }
 
-namespace {
 
-// The walk over the sync runs: composite_layer() :622-693 and :789-830 with the buffer window of
-// :277-332 reduced to its two numbers (begin, end of the buffered part of the stream).
-struct RunWalk {
-    const uint32_t *rs, *re;
-    size_t nruns;
-    mutable size_t k = 0;          // cursor: the searches move forward, or back by a fraction of a scanline
-    // first run that ends after position i: [si, ei) clipped to i and E; si == ei == E when none
-    void next(size_t i, size_t E, size_t &si, size_t &ei) const
-    {
-        while (k > 0 && (size_t)re[k - 1] > i) k--;
-        while (k < nruns && (size_t)re[k] <= i) k++;
-        if (k >= nruns || (size_t)rs[k] >= E) { si = ei = E; return; }
-        si = std::max<size_t>(rs[k], i);
-        ei = std::min<size_t>(re[k], E);
+// ---- a stream, push by push --------------------------------------------------------------------------
+static void raw28_stream_reset(ntscsim_raw28 *d)
+{
+    d->base = 0; d->cnt = 0; d->front_done = 0;
+    d->front_state = d->init;
+    d->Bw = d->Rd = d->Ew = 0;
+    d->bm.segs.clear();
+    std::memset(d->tail_carry, 0, sizeof(d->tail_carry));
+    d->eof = false;
+    d->fields_total = 0;
+    d->blank = (uint8_t)0; d->white = (uint8_t)192; d->read_pos = 0;              // :553-554
+    std::memset(d->stats, 0, sizeof(d->stats));
+    d->last_n = 0;
+}
+
+// make room for `need` bytes in a / b (same capacity policy), keeping the first `keep` bytes of both
+static int raw28_grow(ntscsim_raw28 *d, size_t keep, size_t need, hipStream_t st)
+{
+    if (need <= d->raw.cap && need <= d->h.cap) return NTSCSIM_OK;
+    const size_t want = need + need / 4 + 4096;
+    Buf<uint8_t> nr, nh;
+    R28CHK(d, nr.ensure(want));
+    R28CHK(d, nh.ensure(want));
+    if (keep) {
+        R28CHK(d, hipMemcpyAsync(nr.p, d->raw.p, keep, hipMemcpyDeviceToDevice, st));
+        R28CHK(d, hipMemcpyAsync(nh.p, d->h.p, keep, hipMemcpyDeviceToDevice, st));
+        R28CHK(d, hipStreamSynchronize(st));
     }
-};
+    std::swap(d->raw.p, nr.p); std::swap(d->raw.cap, nr.cap);
+    std::swap(d->h.p, nh.p); std::swap(d->h.cap, nh.cap);
+    return NTSCSIM_OK;            // (nr / nh free the old buffers)
+}
 
-// What the tool's sample buffer holds (:264-357): which stream position every record of the array was
-// last filled from.  Only the calibration sums of :661-676 can run past the filled part (the search
-// position jumps 0.3 scanlines ahead of a pulse, :655), and there they read whatever the records held
-// before -- samples of an earlier window after the buffer has been moved down, zero-initialised
-// records (hsync_dc_raw 0, raw 0) while the array has never been full.
-struct BufMap {
-    struct Seg { size_t k0, k1, abs0; };           // records [k0, k1) hold samples abs0 + (k - k0)
-    std::vector<Seg> segs;                         // sorted, disjoint
-    void assign(size_t k0, size_t k1, size_t abs0)
-    {
-        if (k0 >= k1) return;
-        std::vector<Seg> out;
-        for (const Seg &g : segs) {
-            if (g.k1 <= k0 || g.k0 >= k1) { out.push_back(g); continue; }
-            if (g.k0 < k0) out.push_back(Seg{g.k0, k0, g.abs0});
-            if (g.k1 > k1) out.push_back(Seg{k1, g.k1, g.abs0 + (k1 - g.k0)});
-        }
-        out.push_back(Seg{k0, k1, abs0});
-        std::sort(out.begin(), out.end(), [](const Seg &a, const Seg &b) { return a.k0 < b.k0; });
-        segs.swap(out);
-    }
-    // records [k0, k1): stream pieces through `piece(abs_begin, abs_end)`, returns the number of records
-    // that were never filled
-    template <class F>
-    size_t lookup(size_t k0, size_t k1, F piece) const
-    {
-        size_t zeros = 0, k = k0;
-        for (const Seg &g : segs) {
-            if (g.k1 <= k || g.k0 >= k1) continue;
-            if (g.k0 > k) { zeros += g.k0 - k; k = g.k0; }
-            const size_t e = std::min(g.k1, k1);
-            piece(g.abs0 + (k - g.k0), g.abs0 + (e - g.k0));
-            k = e;
-        }
-        if (k < k1) zeros += k1 - k;
-        return zeros;
-    }
-};
-
-} // namespace
-
-static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_device, size_t N, void *frames_dev,
+// One push of a stream: `n` more samples (host or device memory), `final` = the stream ends with them.
+// Decodes every field the tool would have produced so far whose buffer window (:307, 2048 scanlines) is
+// complete -- at most max_fields of them; the rest come out of later pushes (n = 0 is allowed).
+static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_device, size_t n, bool final, void *frames_dev,
                              size_t frame_stride, int linesize, int max_fields, int *n_fields)
 {
-    if (!d || !capture || !frames_dev || !n_fields || max_fields < 0) return NTSCSIM_E_ARG;
-    if (N >= 0xFFFFFFFFull) return NTSCSIM_E_SIZE;
-    if (linesize < d->width * 4 || (linesize & 3) || frame_stride < (size_t)linesize * (size_t)d->height) return NTSCSIM_E_SIZE;
+    if (!d || (n > 0 && !samples) || !n_fields || max_fields < 0 || (max_fields > 0 && !frames_dev)) return NTSCSIM_E_ARG;
+    if (d->eof && n > 0) { d->err = "the stream has ended: ntscsim_raw28_stream_reset() starts a new one"; return NTSCSIM_E_ARG; }
+    if (d->cnt + n >= 0xFFFFFFF0ull) return NTSCSIM_E_SIZE;
+    if (max_fields > 0 && (linesize < d->width * 4 || (linesize & 3) || frame_stride < (size_t)linesize * (size_t)d->height))
+        return NTSCSIM_E_SIZE;
     *n_fields = 0;
     R28CHK(d, hipSetDevice(d->device));
     hipStream_t st = nullptr;
     const unsigned len = d->len;
-    std::memset(d->stats, 0, sizeof(d->stats));
-    d->blank = (uint8_t)0; d->white = (uint8_t)192; d->read_pos = 0;              // :553-554
-    d->last_n = N;
+    if (final) d->eof = true;
 
     // wall-clock split of the call (every phase ends in a stream synchronisation), stats[6..11] in us
     auto t_last = std::chrono::steady_clock::now();
@@ -674,30 +741,38 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         d->stats[slot] += (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(t - t_last).count();
         t_last = t;
     };
-    // ---- (1) front end
-    // the kernels read whole 16-byte pieces: a copy that is aligned and padded by 64 zero bytes
-    R28CHK(d, d->raw.ensure(N + 64));
-    R28CHK(d, hipMemcpyAsync(d->raw.p, capture, N, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    R28CHK(d, hipMemsetAsync(d->raw.p + N, 0, 64, st));
+    // ---- (0) the new samples join the buffer (the kernels read whole 16-byte pieces: 64 zero bytes follow)
+    {
+        const int rc = raw28_grow(d, d->cnt, d->cnt + n + 64, st);
+        if (rc != NTSCSIM_OK) return rc;
+    }
+    if (n) R28CHK(d, hipMemcpyAsync(d->raw.p + d->cnt, samples, n, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    d->cnt += n;
+    R28CHK(d, hipMemsetAsync(d->raw.p + d->cnt, 0, 64, st));
+    const size_t N = d->cnt;
     const uint8_t *raw = d->raw.p;
-    R28CHK(d, d->h.ensure(N + 64));
+    d->last_n = N;
+    R28CHK(d, d->counters.ensure(4));
+
+    // ---- (1) front end over the new samples [front_done, N)
     // one lane per chunk, and no more chunks than one wavefront per SIMD can hold (1,024 x 64): a lane's
     // run is warm-up + chunk samples long whatever the chunk count, so a second wavefront per SIMD would
     // only double the time
-    int chunk = d->chunk;
-    if (!d->chunk_forced && N / (size_t)chunk >= 65536) chunk = (int)((N / 65536 + 16) & ~(size_t)15);
     const int warm = (int)(((size_t)d->warm_lines * len + 15) & ~(size_t)15);
-    const int nchunks = (int)((N + (size_t)chunk - 1) / (size_t)chunk);
-    R28CHK(d, d->counters.ensure(4));
-    if (nchunks > 0) {
+    if (N > d->front_done) {
+        const size_t o0 = d->front_done, fresh = N - o0;
+        int chunk = d->chunk;
+        if (!d->chunk_forced && fresh / (size_t)chunk >= 65536) chunk = (int)((fresh / 65536 + 16) & ~(size_t)15);
+        const size_t a0 = (o0 + 15) & ~(size_t)15;
+        const int nchunks = a0 >= N ? 1 : (int)((N - a0 + (size_t)chunk - 1) / (size_t)chunk);
         R28CHK(d, d->st_begin.ensure((size_t)nchunks));
         R28CHK(d, d->st_end.ensure((size_t)nchunks));
         R28CHK(d, d->st_prev.ensure((size_t)nchunks));
         R28CHK(d, d->flags.ensure((size_t)nchunks));
         const size_t pin = d->front_pin ? FRONT_PIN_LDS : 0;
         if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
-        hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), pin, st, raw, N, d->h.p, chunk, warm,
-                           nchunks, d->K, d->init, d->st_begin.p, d->st_end.p, (const FrontState *)nullptr, (const int *)nullptr);
+        hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), pin, st, raw, N, d->h.p, o0, chunk, warm,
+                           nchunks, d->K, d->front_state, d->st_begin.p, d->st_end.p, (const FrontState *)nullptr, (const int *)nullptr);
         for (;;) {
             R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_raw28_links, dim3((nchunks + 255) / 256), dim3(256), 0, st, d->st_begin.p, d->st_end.p,
@@ -709,14 +784,18 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
             d->stats[0]++; d->stats[1] += nbad;
             // repair round: flagged chunks restart from their predecessor's end state as it is NOW
             R28CHK(d, hipMemcpyAsync(d->st_prev.p, d->st_end.p, (size_t)nchunks * sizeof(FrontState), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), 0, st, raw, N, d->h.p, chunk, warm,
-                               nchunks, d->K, d->init, d->st_begin.p, d->st_end.p, (const FrontState *)d->st_prev.p,
+            hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), 0, st, raw, N, d->h.p, o0, chunk, warm,
+                               nchunks, d->K, d->front_state, d->st_begin.p, d->st_end.p, (const FrontState *)d->st_prev.p,
                                (const int *)d->flags.p);
         }
+        // the exact state after the last sample: where the next push starts
+        R28CHK(d, hipMemcpyAsync(&d->front_state, d->st_end.p + (nchunks - 1), sizeof(FrontState), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipStreamSynchronize(st));
+        d->front_done = N;
     }
 
     lap(6);
-    // ---- (2) runs of h < thr
+    // ---- (2) runs of h < thr over the buffer
     const size_t nseg = (N + RUN_BLOCK - 1) / RUN_BLOCK;
     std::vector<uint32_t> rs, re;
     if (nseg > 0) {
@@ -743,7 +822,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
             R28CHK(d, hipMemcpyAsync(re.data(), d->rend.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             R28CHK(d, hipStreamSynchronize(st));
         }
-        d->stats[3] = (int64_t)nruns;
+        d->stats[3] += (int64_t)nruns;
     }
 
     lap(7);
@@ -752,21 +831,24 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     W.rs = rs.data(); W.re = re.data(); W.nruns = rs.size();
     const size_t CAP = (size_t)len * 2048;                                        // open_src :353
     const size_t L30 = (size_t)(int)(len * 0.3), L06 = (size_t)(int)(len * 0.06), L02 = (size_t)(int)(len * 0.02);
-    size_t Bw = 0, Rd = 0, Ew = 0;                  // buffer begin, read position, buffer end (absolute)
-    BufMap bm;
+    size_t &Bw = d->Bw, &Rd = d->Rd, &Ew = d->Ew;   // buffer begin, read position, buffer end (relative to base)
+    BufMap &bm = d->bm;
     std::vector<LineRec> lines;
     std::vector<CalRange> cal;                     // pieces of the calibration ranges, in pulse order
     std::vector<int> cal_zero;                     // per pulse: never-filled records inside its range
     std::vector<int> cal_field;                    // number of pulses seen before each field is rendered
     int nf = 0;
     while (nf < max_fields) {
+        // the tool blocks in read() until its buffer is full; here a field whose window is not complete yet
+        // waits for the next push (nothing is changed before that is known)
+        if (!d->eof && ((Rd - Bw > CAP / 2u) ? Rd : Bw) + CAP > N) break;
         if (Rd - Bw > CAP / 2u) {                  // lazy_flush_src :329 -> flush_src :290 (twice per field, idempotent)
             bm.assign(0, Ew - Rd, Rd);             // memmove: the live records move to the front, the rest stays
             Bw = Rd;
         }
         const size_t E = std::min(N, Bw + CAP);    // refill_src :307
         if (E > Ew) { bm.assign(Ew - Bw, E - Bw, Ew); Ew = E; }
-        if (E - Rd < (size_t)len * 256) break;     // main :1021
+        if (E - Rd < (size_t)len * 256) break;     // main :1011
         if (!d->o.disable_sync) {                  // :622-693
             size_t i = Rd;
             int vsb = 0;
@@ -832,9 +914,11 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         }
         nf++;
     }
-    d->read_pos = Rd;
-    d->stats[4] = (int64_t)lines.size();
-    d->stats[5] = (int64_t)cal_zero.size();
+    d->read_pos = d->base + Rd;
+    d->stats[15] = (int64_t)std::max<size_t>((size_t)d->stats[15], N);      // most samples ever held at once
+    d->stats[4] += (int64_t)lines.size();
+    d->stats[5] += (int64_t)cal_zero.size();
+    d->fields_total += (uint64_t)nf;
     *n_fields = nf;
 
     lap(8);
@@ -846,7 +930,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         R28CHK(d, d->cal_out.ensure(cal.size()));
         R28CHK(d, hipMemcpyAsync(d->cal_rg.p, cal.data(), cal.size() * sizeof(CalRange), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_raw28_cal, dim3((unsigned)cal.size()), dim3(64), 0, st, raw, d->h.p, d->cal_rg.p,
-                           d->cal_out.p, d->D, d->K.thr, d->o.mark_sync ? 1 : 0);
+                           d->cal_out.p, d->D, d->K.thr, d->o.mark_sync ? 1 : 0, (unsigned long long)d->base);
         R28CHK(d, hipMemcpyAsync(part.data(), d->cal_out.p, cal.size() * sizeof(CalSums), hipMemcpyDeviceToHost, st));
         R28CHK(d, hipStreamSynchronize(st));
         for (size_t k = 0; k < cal.size(); k++) {
@@ -875,7 +959,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
 
     lap(9);
     // ---- (5) comb tails to their fixed point, then every scanline at once
-    if (nf > 0)                                    // the tool's memset before every composite_layer() :1024, all frames at once
+    if (nf > 0)                                    // the tool's memset before every composite_layer() :1016, all frames at once
         R28CHK(d, hipMemset2DAsync(frames_dev, frame_stride, 0, (size_t)linesize * (size_t)d->height, (size_t)nf, st));
     const int nlines = (int)lines.size();
     if (nlines > 0) {
@@ -884,19 +968,25 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
         RC.mark = d->o.mark_sync ? 1 : 0; RC.no_equ = d->o.disable_equalization ? 1 : 0;
         RC.no_wequ = d->o.disable_wp_equ ? 1 : 0; RC.no_sc = d->o.disable_subcarrier ? 1 : 0;
         RC.show_sc = d->o.show_subcarrier ? 1 : 0;
+        RC.base = (unsigned long long)d->base;
         R28CHK(d, d->lines.ensure((size_t)nlines));
         R28CHK(d, hipMemcpyAsync(d->lines.p, lines.data(), (size_t)nlines * sizeof(LineRec), hipMemcpyHostToDevice, st));
         int *tails = nullptr;
         if (!RC.no_sc) {
-            R28CHK(d, d->tails_a.ensure((size_t)nlines * 16));
-            R28CHK(d, d->tails_b.ensure((size_t)nlines * 16));
-            R28CHK(d, hipMemsetAsync(d->tails_a.p, 0, (size_t)nlines * 16 * sizeof(int), st));
-            R28CHK(d, hipMemsetAsync(d->tails_b.p, 0, (size_t)nlines * 16 * sizeof(int), st));
-            int *tin = d->tails_a.p, *tout = d->tails_b.p;
+            // row 0 of both arrays = the tail of the last scanline of the previous push (zeros at a stream's
+            // start); the kernels see the arrays from row 1 on and read row y - 1
+            const size_t trows = (size_t)nlines + 1;
+            R28CHK(d, d->tails_a.ensure(trows * 16));
+            R28CHK(d, d->tails_b.ensure(trows * 16));
+            R28CHK(d, hipMemsetAsync(d->tails_a.p, 0, trows * 16 * sizeof(int), st));
+            R28CHK(d, hipMemsetAsync(d->tails_b.p, 0, trows * 16 * sizeof(int), st));
+            R28CHK(d, hipMemcpyAsync(d->tails_a.p, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
+            R28CHK(d, hipMemcpyAsync(d->tails_b.p, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
+            int *tin = d->tails_a.p + 16, *tout = d->tails_b.p + 16;
             for (int round = 0;;) {
                 // round r: tout(y) = G(samples of y, tin(y-1)); it ends when tout == tin everywhere, i.e.
-                // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = 0: the serial result.  Four rounds
-                // are enqueued between two looks at the counter of the last one.
+                // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = the carried tail: the serial result.
+                // Four rounds are enqueued between two looks at the counter of the last one.
                 for (int b4 = 0; b4 < 4; b4++, round++) {
                     R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
                     hipLaunchKernelGGL(k_raw28_tails, dim3((nlines + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
@@ -912,6 +1002,7 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
             }
             // both arrays now hold the fixed point
             tails = tin;
+            R28CHK(d, hipMemcpyAsync(d->tail_carry, tin + (size_t)(nlines - 1) * 16, sizeof(d->tail_carry), hipMemcpyDeviceToHost, st));
         }
         R28CHK(d, hipStreamSynchronize(st));
         lap(10);
@@ -922,16 +1013,60 @@ static int raw28_decode_impl(ntscsim_raw28 *d, const void *capture, bool on_devi
     R28CHK(d, hipGetLastError());
     R28CHK(d, hipStreamSynchronize(st));
     lap(11);
+
+    // ---- (6) a stream that goes on: drop the samples nothing can ask for any more.  Still needed: the
+    // window [Bw, ...), whatever stale records of the tool's array refer to (bm), the front end's warm-up
+    // before the next new sample, and D samples of delay line in front of all of it.
+    if (!d->eof) {
+        size_t low = std::min(Bw, Rd);
+        for (const BufMap::Seg &g : bm.segs) low = std::min(low, g.abs0);
+        low = std::min(low, N > (size_t)warm + 64 ? N - (size_t)warm - 64 : 0);
+        const size_t margin = (size_t)d->D + 64;
+        size_t keep = low > margin ? (low - margin) & ~(size_t)15 : 0;
+        if (keep >= (4u << 20) && keep > N / 4) {          // (worth a copy)
+            const size_t rest = N - keep;
+            R28CHK(d, d->raw_alt.ensure(std::max(d->raw.cap, rest + 64)));
+            R28CHK(d, d->h_alt.ensure(std::max(d->h.cap, rest + 64)));
+            R28CHK(d, hipMemcpyAsync(d->raw_alt.p, d->raw.p + keep, rest, hipMemcpyDeviceToDevice, st));
+            R28CHK(d, hipMemcpyAsync(d->h_alt.p, d->h.p + keep, rest, hipMemcpyDeviceToDevice, st));
+            R28CHK(d, hipStreamSynchronize(st));
+            std::swap(d->raw.p, d->raw_alt.p); std::swap(d->raw.cap, d->raw_alt.cap);
+            std::swap(d->h.p, d->h_alt.p); std::swap(d->h.cap, d->h_alt.cap);
+            d->stats[14]++;
+            d->base += keep; d->cnt -= keep; d->front_done -= keep;
+            Bw -= keep; Rd -= keep; Ew -= keep;
+            for (BufMap::Seg &g : bm.segs) g.abs0 -= keep;
+        }
+    }
     return NTSCSIM_OK;
 }
 
+extern "C" int ntscsim_raw28_stream_reset(ntscsim_raw28 *d)
+{
+    if (!d) return NTSCSIM_E_ARG;
+    raw28_stream_reset(d);
+    return NTSCSIM_OK;
+}
+extern "C" int ntscsim_raw28_stream_push(ntscsim_raw28 *d, const void *samples, size_t n, int on_device, int final,
+                                         void *frames_dev, size_t frame_stride, int linesize, int max_fields, int *n_fields)
+{
+    return raw28_stream_push(d, samples, on_device != 0, n, final != 0, frames_dev, frame_stride, linesize, max_fields, n_fields);
+}
+
+// a whole capture = a stream of one push
 extern "C" int ntscsim_raw28_decode(ntscsim_raw28 *d, const uint8_t *capture_host, size_t n, void *frames_dev,
                                     size_t frame_stride, int linesize, int max_fields, int *n_fields)
 {
-    return raw28_decode_impl(d, capture_host, false, n, frames_dev, frame_stride, linesize, max_fields, n_fields);
+    if (!d || (n > 0 && !capture_host) || !frames_dev || !n_fields || max_fields < 0) return NTSCSIM_E_ARG;
+    if (n >= 0xFFFFFFFFull) return NTSCSIM_E_SIZE;
+    raw28_stream_reset(d);
+    return raw28_stream_push(d, capture_host, false, n, true, frames_dev, frame_stride, linesize, max_fields, n_fields);
 }
 extern "C" int ntscsim_raw28_decode_device(ntscsim_raw28 *d, const void *capture_dev, size_t n, void *frames_dev,
                                            size_t frame_stride, int linesize, int max_fields, int *n_fields)
 {
-    return raw28_decode_impl(d, capture_dev, true, n, frames_dev, frame_stride, linesize, max_fields, n_fields);
+    if (!d || (n > 0 && !capture_dev) || !frames_dev || !n_fields || max_fields < 0) return NTSCSIM_E_ARG;
+    if (n >= 0xFFFFFFFFull) return NTSCSIM_E_SIZE;
+    raw28_stream_reset(d);
+    return raw28_stream_push(d, capture_dev, true, n, true, frames_dev, frame_stride, linesize, max_fields, n_fields);
 }

@@ -373,6 +373,29 @@ class Raw28Decoder:
             raise NtscsimError(rc, self._lib.ntscsim_raw28_last_error(self._h).decode())
         return n.value
 
+    def stream_reset(self):
+        rc = self._lib.ntscsim_raw28_stream_reset(self._h)
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_raw28_stream_reset")
+
+    def stream_push(self, samples, frames, final=False, max_fields=None):
+        """samples: numpy uint8 (host), a CUDA uint8 tensor, or None / empty; frames: CUDA uint8 tensor
+        [F, height, >= 4*width].  Returns the number of fields this push wrote to frames[0:]."""
+        n = C.c_int()
+        mf = int(frames.shape[0] if max_fields is None else max_fields)
+        if samples is None:
+            ptr, ns, dev = None, 0, 0
+        elif hasattr(samples, "data_ptr"):
+            ptr, ns, dev = samples.data_ptr(), samples.numel(), 1
+        else:
+            ptr, ns, dev = samples.ctypes.data, samples.size, 0
+        rc = self._lib.ntscsim_raw28_stream_push(self._h, C.c_void_p(ptr), ns, dev, 1 if final else 0,
+                                                 C.c_void_p(frames.data_ptr()), frames.stride(0), frames.stride(1),
+                                                 mf, C.byref(n))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, self._lib.ntscsim_raw28_last_error(self._h).decode())
+        return n.value
+
     def levels(self):
         b, w, p = C.c_double(), C.c_double(), C.c_uint64()
         self._lib.ntscsim_raw28_get_levels(self._h, C.byref(b), C.byref(w), C.byref(p))
@@ -386,7 +409,7 @@ class Raw28Decoder:
         self._lib.ntscsim_raw28_debug_stats(self._h, a)
         return dict(zip(("front_rounds", "chunks_repaired", "tail_rounds", "sync_runs", "scanlines", "cal_pulses",
                          "us_front", "us_runs", "us_walk", "us_levels", "us_tails", "us_render",
-                         "pulses_past_stream", "zero_records"), list(a)))
+                         "pulses_past_stream", "zero_records", "compactions", "max_samples_held"), list(a)))
 
     def read_front(self, n):
         import numpy as np

@@ -34,6 +34,7 @@ EXPORTS = (
     "ntscsim_batch422_create", "ntscsim_batch422_run", "ntscsim_batch422_destroy",
     "ntscsim_raw28_opts_init", "ntscsim_raw28_parse_argv", "ntscsim_raw28_geometry", "ntscsim_raw28_create",
     "ntscsim_raw28_destroy", "ntscsim_raw28_last_error", "ntscsim_raw28_decode", "ntscsim_raw28_decode_device",
+    "ntscsim_raw28_stream_reset", "ntscsim_raw28_stream_push",
     "ntscsim_raw28_get_levels", "ntscsim_raw28_debug_set_speculation", "ntscsim_raw28_debug_stats",
     "ntscsim_raw28_debug_read_front",
 )
@@ -301,6 +302,11 @@ def lib():
     for fn in (L.ntscsim_raw28_decode, L.ntscsim_raw28_decode_device):
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
         fn.restype = C.c_int
+    L.ntscsim_raw28_stream_reset.argtypes = [C.c_void_p]
+    L.ntscsim_raw28_stream_reset.restype = C.c_int
+    L.ntscsim_raw28_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                            C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.ntscsim_raw28_stream_push.restype = C.c_int
     L.ntscsim_raw28_get_levels.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.ntscsim_raw28_get_levels.restype = C.c_int
     L.ntscsim_raw28_debug_set_speculation.argtypes = [C.c_void_p, C.c_int, C.c_int]

@@ -474,7 +474,8 @@ int ntscsim_debug_fast_plane_ok(int n_fields, int width, int height, int head_sw
  *   rendering, horizontal re-sync;  field loop main() :1006-1038.
  * A decoder object is not re-entrant (one thread at a time); calls are synchronous.
  * One ntscsim_raw28_decode*() call = one run of the tool on one input file: the decoder state
- * starts from the tool's initial state every call.  Results are bit-identical to the tool's, including
+ * starts from the tool's initial state every call (an empty capture gives 0 fields).  Long captures and
+ * pipes: ntscsim_raw28_stream_*() below.  Results are bit-identical to the tool's, including
  * where its calibration sums run past the buffered part of the capture into stale or never-filled
  * records of its sample buffer (:655-676); only reads past the END of that array (undefined in the
  * tool) are defined here, as zero records.
@@ -512,6 +513,23 @@ int  ntscsim_raw28_decode(ntscsim_raw28 *dec, const uint8_t *capture_host, size_
                           void *frames_dev, size_t frame_stride, int linesize, int max_fields, int *n_fields);
 int  ntscsim_raw28_decode_device(ntscsim_raw28 *dec, const void *capture_dev, size_t n_samples,
                                  void *frames_dev, size_t frame_stride, int linesize, int max_fields, int *n_fields);
+/* The same decoder on a stream of any length, push by push (a capture file read in pieces, a pipe): the
+ * tool itself keeps a window of 2048 scanlines (:353) and never needs the whole capture.
+ *   ntscsim_raw28_stream_reset()  start a new stream (the state of a fresh run of the tool);
+ *   ntscsim_raw28_stream_push()   `n` more samples (host memory, or device memory with on_device != 0;
+ *       n = 0 is allowed), `final` != 0 when the stream ends with them.  Decodes, into frames_dev as in
+ *       ntscsim_raw28_decode(), every field whose 2048-scanline window is complete -- the tool blocks in
+ *       read() until its buffer is full, so a field is produced exactly when the tool could produce it --
+ *       up to max_fields of them; fields held back by max_fields come out of the following pushes.  After
+ *       the final push: the fields the tool produces before its "fewer than 256 scanlines left" stop.
+ *       *n_fields = fields written by this call.  The sequence of all fields is bit-identical to one
+ *       ntscsim_raw28_decode() of the concatenated samples, whatever the push sizes.
+ * The decoder keeps only what it can still need (about two windows of samples on the device), so the
+ * stream may be far longer than 2^32 samples; one push must be shorter than that.
+ * ntscsim_raw28_decode*() are a reset followed by one final push. */
+int  ntscsim_raw28_stream_reset(ntscsim_raw28 *dec);
+int  ntscsim_raw28_stream_push(ntscsim_raw28 *dec, const void *samples, size_t n, int on_device, int final,
+                               void *frames_dev, size_t frame_stride, int linesize, int max_fields, int *n_fields);
 /* blank_level, white_level (:553-554) and the stream position (total_count_src) after the last call */
 int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *white, uint64_t *read_pos);
 /* Test hooks.  warm-up scanlines of the speculative front end (default 112; 0 forces every chunk
@@ -520,7 +538,8 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call; [6..11] wall-clock
  * microseconds of its phases: front end, run extraction, sync walk, level calibration, comb tails
  * (incl. clearing the frames), rendering; [12] calibration pulses whose sums ran past the buffered
- * stream, [13] never-filled records among them. */
+ * stream, [13] never-filled records among them; [14] compactions of the device buffer (streams),
+ * [15] the most samples the device buffer ever held.  Counters accumulate over the pushes of a stream. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
 void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */

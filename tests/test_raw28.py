@@ -230,6 +230,109 @@ def test_hip_max_fields_and_errors():
     dec.close()
 
 
+
+def _hip_stream(flags, capture, sizes, frames_per_push=None, device_every=0, warm=None, chunk=None):
+    """The capture pushed in pieces of the given sizes (cycled), the last piece flagged final; then drained
+    with empty pushes while fields keep coming.  Returns (frames, levels, number of pushes)."""
+    import torch
+    import ntscsim
+    dec = ntscsim.Raw28Decoder(flags)
+    if warm is not None or chunk is not None:
+        dec.set_speculation(-1 if warm is None else warm, 0 if chunk is None else chunk)
+    cap_f = capture.size // (dec.scanline * 240) + 4
+    ring = torch.full((cap_f if frames_per_push is None else frames_per_push, dec.height, dec.width * 4), 9,
+                      dtype=torch.uint8, device="cuda")
+    out, pos, k = [], 0, 0
+    dec.stream_reset()
+    while True:
+        n = min(sizes[k % len(sizes)], capture.size - pos)
+        piece = capture[pos:pos + n]
+        pos += n
+        final = pos >= capture.size
+        src = piece if n else None
+        if n and device_every and k % device_every == 0:
+            src = torch.from_numpy(np.ascontiguousarray(piece)).cuda()
+        got = dec.stream_push(src, ring, final=final)
+        out.append(ring[:got].cpu().numpy().copy())
+        k += 1
+        if final:
+            while got == ring.shape[0]:               # held back by max_fields: drain
+                got = dec.stream_push(None, ring, final=True)
+                out.append(ring[:got].cpu().numpy().copy())
+                k += 1
+            break
+    frames = np.concatenate(out) if out else np.zeros((0, dec.height, dec.width * 4), np.uint8)
+    res = (frames, dec.levels(), k, dec)
+    return res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,sizes,fpp,devn", [
+    ("one-megasample", [1000003], None, 0),                 # not a multiple of the 16-sample load grid
+    ("uneven", [1, 15, 4099, 2500000, 17, 777777, 3000001], None, 3),
+    ("one-field-at-a-time", [2 * 477750 + 5], 1, 0),        # every push may hand back a single field
+    ("whole-windows", [2048 * 1820], 12, 2),
+])
+def test_hip_stream_equals_one_shot(name, sizes, fpp, devn):
+    """ntscsim_raw28_stream_push: a 40-field capture (19 M samples, five buffer windows of the tool, several
+    compactions of the device buffer) pushed in pieces == the oracle's run on the whole capture: frames,
+    levels and stream position, whatever the piece sizes, the frames-per-push limit and where the pieces
+    live."""
+    capture = L.raw28_capture(40, 17, 3, 250001)
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    got, lv2, npush, dec = _hip_stream([], capture, sizes, fpp, devn)
+    assert got.shape == want.shape, (got.shape, want.shape, npush)
+    bad = [int(f) for f in range(got.shape[0]) if not np.array_equal(got[f], want[f])]
+    assert not bad, bad
+    assert lv2 == lv
+    st = dec.stats()
+    # the stream never sat on the device as a whole: old samples were dropped as the window moved on
+    # (unless the caller takes one field per push while handing in two fields' worth of samples)
+    if fpp != 1:
+        assert st["compactions"] >= 1 and st["max_samples_held"] < capture.size * 3 // 4, st
+    dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["tail_long", "tail_short", "random"])
+def test_hip_stream_on_odd_captures(kind):
+    """the stale / never-filled records of the tool's sample array (:655-676) when the capture arrives in
+    pieces, with marksig, and with the front end's speculation crippled"""
+    capture = _odd_capture(kind)
+    for kw, flags, warm, chunk in (({}, [], None, None), ({"mark_sync": 1}, ["-marksig"], 2, 16384)):
+        want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(**kw), capture)
+        got, lv2, _, dec = _hip_stream(flags, capture, [1234567, 333, 2000000], None, 2, warm, chunk)
+        assert got.shape == want.shape and np.array_equal(got, want), kind
+        assert lv2 == lv
+        dec.close()
+
+
+@pytest.mark.gpu
+def test_hip_stream_api_contract():
+    import torch
+    import ntscsim
+    dec = ntscsim.Raw28Decoder([])
+    frames = torch.zeros((4, dec.height, dec.width * 4), dtype=torch.uint8, device="cuda")
+    # an empty capture is a capture: zero fields, no error
+    assert dec.decode(np.zeros(0, np.uint8), frames) == 0
+    dec.stream_reset()
+    assert dec.stream_push(None, frames, final=True) == 0
+    # samples after the end of a stream are refused until the next reset
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        dec.stream_push(np.zeros(100, np.uint8), frames)
+    assert e.value.code == _capi.E_ARG
+    # a decode() after a stream starts from scratch, and a stream after a decode() too
+    capture = L.raw28_capture(5, 1, 0, 0)
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    big = torch.zeros((8, dec.height, dec.width * 4), dtype=torch.uint8, device="cuda")
+    n = dec.decode(capture, big)
+    assert n == want.shape[0] and np.array_equal(big[:n].cpu().numpy(), want) and dec.levels() == lv
+    dec.stream_reset()
+    n1 = dec.stream_push(capture[:3000000], big)
+    n2 = dec.stream_push(capture[3000000:], big[n1:], final=True)
+    assert n1 + n2 == want.shape[0] and np.array_equal(big[:n1 + n2].cpu().numpy(), want) and dec.levels() == lv
+    dec.close()
+
 # ------------------------------------------------------------------------------- command line host
 RAW28_CLI = os.path.join(L.PKG, "raw28_cli")
 
@@ -261,3 +364,15 @@ def test_raw28_cli_equals_oracle(tmp_path):
     r = subprocess.run([RAW28_CLI, "--max-fields", "2", "-i", str(src), "-o", "null:"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"2 fields of 1820x262" in r.stderr
+    # the capture through a pipe, read in 1 MB pieces with a ring of two frames: the same frames
+    want, _ = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    r = subprocess.run([RAW28_CLI, "--chunk-bytes", "1000000", "--ring-fields", "2", "-i", "-", "-o", str(dst)],
+                       input=capture.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-500:]
+    got = np.frombuffer(dst.read_bytes(), np.uint8).reshape(-1, 262, 1820 * 4)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # an empty capture: zero fields, exit code 0
+    empty = tmp_path / "empty.u8"
+    empty.write_bytes(b"")
+    r = subprocess.run([RAW28_CLI, "-i", str(empty), "-o", "null:"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b"0 fields of 1820x262" in r.stderr
