@@ -71,7 +71,7 @@ __global__ void k_scale_to_bgra(const ScaleDev *__restrict__ descs, int W, int H
         // "(x >> 8) clamped to 0..255, two of them packed" into gfx950's v_ashr_pk_u8_i32, assumes
         // that instruction clears the upper half of its destination, and ORs the red byte on top --
         // but the hardware keeps the destination's old upper 16 bits, so red comes out as 255 (old
-        // value negative) or off by one (tools/dbg_scale.py; only this kernel had the pattern).
+        // value negative) or off by one (only this kernel had the pattern).
         int tr = (298 * C + 409 * E + 128) >> 8, tg = (298 * C - 100 * D - 208 * E + 128) >> 8,
             tb = (298 * C + 516 * D + 128) >> 8;
         asm volatile("" : "+v"(tr), "+v"(tg), "+v"(tb));

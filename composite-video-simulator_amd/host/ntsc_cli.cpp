@@ -201,16 +201,17 @@ int main(int argc, char **argv)
     size_t ring_idx = 0;
 
     std::vector<ntscsim_field_desc> descs((size_t)batch_fields);
-    std::vector<uint8_t> scratch(fbytes);
+    std::vector<uint8_t> scratch(fbytes), top_last(fbytes, 0);
     unsigned long long current = 0;     // output field counter (:2140)
     unsigned long long total_fields = 0;
     const auto t0 = std::chrono::steady_clock::now();
     const bool layered = inputs.size() > 1;
     // ---- reader thread: fills the next batch of source frames while the GPU works on the current
-    //      one.  It reads up to nframes_batch frames from the LAST input (it overwrites the layers
-    //      below it, :2203-2230).  A lower layer that has ended keeps compositing its last frame in
-    //      the reference (:2218-2226), i.e. it goes on drawing from rand(): only the end of the
-    //      last input ends the run.
+    //      one.  Every layer is composited in every field and the LAST input overwrites the layers below
+    //      it (:2203-2230), so only its frames are kept.  The run goes on until EVERY input has ended
+    //      (:2149-2153, :2283): an input that has ended keeps compositing the last frame it delivered
+    //      (:2192-2197, :2218-2226) -- a lower layer goes on drawing from rand(), the top layer goes on
+    //      showing its last frame while a longer lower layer is still running.
     struct Slot { int nf = 0; bool ready = false, last = false; } slot[2];
     bool stop = false;                  // set on every way out of main(): lets the reader leave
     std::mutex mu;
@@ -241,18 +242,30 @@ int main(int argc, char **argv)
                 if (top.next >= top.synth_frames) { top.eof = true; eof = true; }
             } else {
                 for (; nf < nframes_batch; nf++) {
+                    bool any = false;
                     for (size_t li = 0; li + 1 < inputs.size(); li++)
-                        (void)read_frame(inputs[li], scratch.data(), W, H);
-                    if (!read_frame(top, buf + fbytes * nf, W, H)) { eof = true; break; }
+                        any = read_frame(inputs[li], scratch.data(), W, H) || any;
+                    uint8_t *dstf = buf + fbytes * nf;
+                    if (read_frame(top, dstf, W, H)) { any = true; std::memcpy(top_last.data(), dstf, fbytes); }
+                    else std::memcpy(dstf, top_last.data(), fbytes);       // ended: its last frame (black if it never had one)
+                    if (!any) { eof = true; break; }                       // every input has ended
                 }
             }
             { std::lock_guard<std::mutex> lk(mu); slot[b].nf = nf; slot[b].last = eof; slot[b].ready = true; }
             cv.notify_all();
         }
     });
+    // On the normal way out the reader has finished and is joined.  On an error return it may be sitting in
+    // fread() on a pipe nobody writes to any more: it is told to stop and detached, never waited for.
     struct Joiner {
-        std::thread &t; std::mutex &m; std::condition_variable &c; bool &stop;
-        ~Joiner() { { std::lock_guard<std::mutex> lk(m); stop = true; } c.notify_all(); if (t.joinable()) t.join(); }
+        std::thread &t; std::mutex &m; std::condition_variable &c; bool &stop; bool done = false;
+        ~Joiner()
+        {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            c.notify_all();
+            if (!t.joinable()) return;
+            if (done) t.join(); else t.detach();
+        }
     } joiner{reader, mu, cv, stop};
     for (int b = 0;; b ^= 1) {
         { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return slot[b].ready; }); }
@@ -321,6 +334,7 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "\rOutput field %llu ", current);                      // :1361
         if (last_batch) break;
     }
+    joiner.done = true;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::fprintf(stderr, "\n%llu fields in %.3f s (%.1f fields/s incl. host I/O)\n", total_fields, dt,
                  dt > 0 ? total_fields / dt : 0.0);

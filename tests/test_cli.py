@@ -105,7 +105,7 @@ def test_cli_layered_inputs_advance_the_rand_stream(tmp_path):
 @pytest.mark.gpu
 def test_cli_lower_layer_ending_early_does_not_end_the_run(tmp_path):
     """The reference keeps compositing an ended layer's last frame (:2218-2226): it goes on drawing
-    from rand(), and only the end of the last input ends the run."""
+    from rand() until every input has ended."""
     w, h = 96, 32
     outp = tmp_path / "o.bgra"
     r = run(["-vhs", "-width", str(w), "--height", str(h), "-i", "bars:1", "-i", "noise:3", "-o", str(outp)])
@@ -118,6 +118,28 @@ def test_cli_lower_layer_ending_early_does_not_end_the_run(tmp_path):
         field = (cur & 1) ^ 1
         o.field(ring, L.bars(w, h, 0), field, cur)                       # layer 1: its last frame
         o.field(ring, L.noise_frame(w, h, 0x1234567 + cur // 2), field, cur)
+        L.oracle().ntsc_oracle_bob(L._ptr(ring), w * 4, w, h, field)
+        assert np.array_equal(got[cur], ring), cur
+
+
+@pytest.mark.gpu
+def test_cli_top_layer_ending_early_keeps_its_last_frame(tmp_path):
+    """The loop runs until EVERY input has ended (ffmpeg_ntsc.cpp:2149-2153, :2283); an ended input keeps
+    compositing the last frame it delivered (:2192-2197) -- also the top one, while a longer lower layer
+    is still running: 3 frames of bars under 1 frame of noise = 6 fields, all of them the noise frame,
+    with the rand() stream advanced by both layers every field."""
+    w, h = 96, 32
+    outp = tmp_path / "o.bgra"
+    r = run(["-vhs", "-width", str(w), "--height", str(h), "-i", "bars:3", "-i", "noise:1", "-o", str(outp)])
+    assert r.returncode == 0, r.stderr.decode()
+    got = np.frombuffer(outp.read_bytes(), np.uint8).reshape(6, h, w, 4)
+    p = L.make_params(["-vhs"], output_height=h, output_width=w)
+    o = L.OracleStream(p)
+    ring = np.zeros((h, w, 4), np.uint8)
+    for cur in range(6):
+        field = (cur & 1) ^ 1
+        o.field(ring, L.bars(w, h, cur // 2), field, cur)
+        o.field(ring, L.noise_frame(w, h, 0x1234567), field, cur)        # top layer: its only frame, again and again
         L.oracle().ntsc_oracle_bob(L._ptr(ring), w * 4, w, h, field)
         assert np.array_equal(got[cur], ring), cur
 
