@@ -314,14 +314,18 @@ def main_to_composite(args):
                 valu = {"bound": "valu-issue (cycle-weighted)", "unit": "SIMD pipe cycles/s", "peak": peak,
                         "pipe_cycles_per_step": need, "mean_cycles_per_inst": te["k422_mean_cycles_per_inst"],
                         "path_frac": need / (elapsed / args.steps) / peak,
+                        "path_frac_nominal": (te["k422_wave_insts_per_launch"] * scale * te["k422_mean_cycles_per_inst_nominal"] /
+                                              (elapsed / args.steps) / peak) if te.get("k422_mean_cycles_per_inst_nominal") else None,
                         "kernel_frac": need / (k_ms * 1e-3) / peak if k_ms else None,
                         "note": "SQ_INSTS_VALU of k422_fused per launch (profiles/*_pmc_summary_to_composite.txt) x the "
-                                "mean issue cost of its loops' instruction mix (tools/loop_census.py --mean); the setup "
-                                "kernels are left out of `need`"}
+                                "mean issue cost of its loops' instruction mix (tools/loop_census.py --mean; path_frac at "
+                                "the probe's slowest-wave costs 4.3 / 2.7 cycles, path_frac_nominal at the pipe's "
+                                "nominal 4 / 2); the setup kernels are left out of `need`"}
         except Exception:
             pass
         out = {
-            "metric": "frames/sec (ffmpeg_to_composite: output frames = fields; 720x486 YUV422P, full VHS preset)",
+            "metric": "frames/sec (ffmpeg_to_composite: output frames = fields; 720x486 YUV422P, full VHS preset; "
+                      "steady-state pipelined throughput, %d steps in flight)" % nq,
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -334,6 +338,7 @@ def main_to_composite(args):
                          "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms,
                          "kernel_ms_all": {"setup": set_ms, "process": k_ms}, "valu": valu,
+                         "kernel_forms": sims[0].last_kernels(),
                          "note": "4*W*L algorithmic bytes per field; like the BGRA tool the kernel is bound by "
                                  "dependent fp64 filter chains, not by HBM (DESIGN.md section 7)"},
         }

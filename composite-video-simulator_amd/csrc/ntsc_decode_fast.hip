@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
 // 600-field launch cannot fill the extra wave slots: measured 0.86 ms for the pair against 0.80 ms
 // for the one-launch form, which therefore stays the default.
 #ifndef NTSC_FRONT_WAVES
-#define NTSC_FRONT_WAVES 2
+#define NTSC_FRONT_WAVES 3
 #endif
 template <class RT>
 __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P, GeomDev G,
@@ -747,16 +747,15 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
 #define NTSC_VCR_STEP(DPV, J)                                                                     \
             {                                                                                     \
                 const int c2 = vcr_step<DPV, J, RT, CT>(P, S, C, ring, pc[J], pl[J], sn##J);      \
+                pc[J] = cs_load(C, t + 4 + J);        /* reloaded right after its step consumed it */ \
+                pl[J] = cs_load(C, t + 4 + J - LOFF);                                             \
                 __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
                 soff += rb;                                                                       \
                 NTSC_STEP_SCHED_BARRIER();                                                        \
             }
 #define NTSC_VCR_ITER(DPV)                                                                        \
             for (; t + 4 <= t_end; t += 4) {                                                      \
-                int nc[4], nl[4];                                                                 \
-                _Pragma("unroll") for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = cs_load(C, t + 4 + j - LOFF); } \
                 NTSC_VCR_STEP(DPV, 0) NTSC_VCR_STEP(DPV, 1) NTSC_VCR_STEP(DPV, 2) NTSC_VCR_STEP(DPV, 3)  \
-                _Pragma("unroll") for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; }   \
             }
             if (C.d & 1) { NTSC_VCR_ITER(1) } else { NTSC_VCR_ITER(0) }
 #undef NTSC_VCR_ITER

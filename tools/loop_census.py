@@ -8,7 +8,7 @@ def mean_cost(asm, pat, min_valu=400):
     per instruction (static mix; the loops run comparable trip counts)."""
     blocks = I.parse_kernel(asm, pat)
     succ = I.cfg(blocks)
-    nv = cyc = 0
+    nv = cyc = nfull = 0
     for comp in I.sccs(succ):
         if not (len(comp) > 1 or comp[0] in succ[comp[0]]):
             continue
@@ -17,6 +17,8 @@ def mean_cost(asm, pat, min_valu=400):
         if v >= min_valu:
             nv += v
             cyc += sum(I.cost_of(op) for op in ops)
+            nfull += sum(1 for op in ops if op.startswith("v_") and I.cost_of(op) == I.C_FULL)
+    mean_cost.nominal = (4.0 * (nv - nfull) + 2.0 * nfull) / nv if nv else 0.0
     return nv, cyc, (cyc / nv if nv else 0.0)
 
 
@@ -24,7 +26,8 @@ def main():
     asm, pat = sys.argv[1], sys.argv[2]
     if "--mean" in sys.argv:
         nv, cyc, m = mean_cost(asm, pat)
-        print(json.dumps({"kernel": pat, "valu_in_loops": nv, "pipe_cycles": cyc, "mean_cycles_per_valu": m}))
+        print(json.dumps({"kernel": pat, "valu_in_loops": nv, "pipe_cycles": cyc, "mean_cycles_per_valu": m,
+                          "mean_cycles_per_valu_nominal": mean_cost.nominal}))
         return
     blocks = I.parse_kernel(asm, pat)
     succ = I.cfg(blocks)

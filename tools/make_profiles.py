@@ -29,17 +29,19 @@ shutil.copy(bench, "%s/%s_bench.json" % (P, tag))
 if fast:
     shutil.copy(fast, "%s/%s_bench_fast32.json" % (P, tag))
 
-KERN = {"k_decode": "k_decode_fastILb1EdE", "k_encode": "k_encode_fastIdE",
+KERN = {"k_decode": "k_decode_fastILb1EdLb0EE", "k_encode": "k_encode_fastIdE",
         "k_row_states": "k_row_states", "k_field_setup": "k_field_setup"}
 cen = {}
 for k, f in KERN.items():
     j = json.load(open(os.path.join(census, f + ".json")))
     cen[k] = {x: j[x] for x in ("kernel", "steps_per_pass", "valu_per_step", "fp64_per_step",
                                 "half_rate_int_per_step", "full_rate_per_step", "valu_pipe_cycles_per_step",
-                                "mean_cycles_per_valu", "salu_per_step", "lds_per_step", "vmem_per_step")}
+                                "mean_cycles_per_valu", "mean_cycles_per_valu_nominal", "salu_per_step", "lds_per_step",
+                                "vmem_per_step")}
 json.dump({"tool": "tools/isa_cost.py on hipcc -S of csrc/ntscsim_hip.hip (hottest loop of each kernel)",
            "issue_cost_cycles": {"half_rate (fp64, cvt, v_cndmask, v_lshl*, v_add3, v_med3, v_mul_*, DPP)": 4.3,
                                  "full_rate (v_add/sub_u32, and/or/xor, shift right, v_mov)": 2.7,
+                                 "nominal (mean_cycles_per_valu_nominal)": "4 / 2 cycles, MI355X_MICROARCH.md",
                                  "source": "%s/%s_valu_rates.txt, slowest wave at 3 waves per SIMD" % (P, tag)},
            "kernels": cen}, open("%s/%s_isa_cost.json" % (P, tag), "w"), indent=1)
 
@@ -78,10 +80,14 @@ traffic = {"720x486 -vhs": {
     "k_encode_fetch_KiB_raw": enc["FETCH_SIZE"], "k_encode_write_KiB": enc["WRITE_SIZE"],
     "path_hbm_bytes_per_launch_lower_bound": (dec["FETCH_SIZE"] + dec["WRITE_SIZE"] + enc["FETCH_SIZE"] + enc["WRITE_SIZE"]) * 1024,
     "valu": {
-        "k_decode": {"wave_insts_per_launch": dec["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_decode"]["mean_cycles_per_valu"]},
-        "k_encode": {"wave_insts_per_launch": enc["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_encode"]["mean_cycles_per_valu"]},
-        "k_row_states": {"wave_insts_per_launch": rs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_row_states"]["mean_cycles_per_valu"]},
-        "k_field_setup": {"wave_insts_per_launch": fs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_field_setup"]["mean_cycles_per_valu"]},
+        "k_decode": {"wave_insts_per_launch": dec["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_decode"]["mean_cycles_per_valu"],
+                     "mean_cycles_per_inst_nominal": cen["k_decode"]["mean_cycles_per_valu_nominal"]},
+        "k_encode": {"wave_insts_per_launch": enc["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_encode"]["mean_cycles_per_valu"],
+                     "mean_cycles_per_inst_nominal": cen["k_encode"]["mean_cycles_per_valu_nominal"]},
+        "k_row_states": {"wave_insts_per_launch": rs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_row_states"]["mean_cycles_per_valu"],
+                     "mean_cycles_per_inst_nominal": cen["k_row_states"]["mean_cycles_per_valu_nominal"]},
+        "k_field_setup": {"wave_insts_per_launch": fs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_field_setup"]["mean_cycles_per_valu"],
+                     "mean_cycles_per_inst_nominal": cen["k_field_setup"]["mean_cycles_per_valu_nominal"]},
     },
     "note": "rocprofv3 --pmc, separate passes (tools/pmc.sh), bench.py --inflight 1; FETCH_SIZE / WRITE_SIZE in "
             "KiB; WRITE_SIZE is calibrated by the encoder, whose only stores are the composite plane "
@@ -111,8 +117,12 @@ if tocomp and os.path.exists(tocomp[0]) and os.path.getsize(tocomp[0]) > 10:
         "k422_wave_insts_per_launch": k4["SQ_INSTS_VALU"],
         "k422_mean_cycles_per_inst": (json.load(open(os.path.join(census, "k422_fused.json")))["mean_cycles_per_valu"]
                                       if os.path.exists(os.path.join(census, "k422_fused.json")) else None),
+        "k422_mean_cycles_per_inst_nominal": (json.load(open(os.path.join(census, "k422_fused.json"))).get("mean_cycles_per_valu_nominal")
+                                              if os.path.exists(os.path.join(census, "k422_fused.json")) else None),
+        "k422_kernel": None,
         "note": "tools/pmc422.sh (tools/variant_probe.py: one 600-field launch per call); FETCH/WRITE include the "
-                "packed scratch planes the four sweeps hand to each other, which are larger than the caches"}
+                "packed composite-byte plane sweep A hands to the streamed pass (1 B/pixel each way)"}
+    traffic["720x486 -vhs to_composite"]["k422_kernel"] = [k for k in pm2 if "k422_fused" in k][0]
 json.dump(traffic, open("%s/traffic.json" % P, "w"), indent=1)
 
 v = d["roofline"].get("valu") or {}
@@ -188,14 +198,15 @@ rd += ("* HBM (PMC): k_decode %.0f MB fetched + %.0f MB written, k_encode >= %.0
 if tc:
     b4 = tc["bench"]
     ks = pick(tc["stats"], "k422_fused")
+    kname = [k for k in tc["stats"] if "k422_fused" in k][0].replace("ntscsim::", "")
     rd += ("\n## The YUV422P tool (`bench.py --tool to_composite`)\n\n"
            "`%s_bench_to_composite.json`: value = %.0f frames/s (%.3f ms per 600-field step, %d steps in flight), value_sustained = %.0f; "
-           "`k422_fused<true>`: %.1f us by hipEvents, %.1f us rocprofv3 avg with one step at a time (`%s_kernel_stats_to_composite.csv`); "
+           "`%s` (the name in `%s_kernel_stats_to_composite.csv`): %.1f us by hipEvents, %.1f us rocprofv3 avg with one step at a time; "
            "roofline.frac = %.3f of 8 TB/s on 4*W*L algorithmic bytes (%.0f MB per launch) against %.0f MB fetched + %.0f MB written "
-           "(`%s_pmc_summary_to_composite.txt`: the scratch planes between the sweeps); %.3g wave-instructions per launch.  "
+           "(`%s_pmc_summary_to_composite.txt`: frame rows in and out plus the one composite-byte plane between sweep A and the streamed pass); %.3g wave-instructions per launch.  "
            "CPU beside it: %.1f frames/s (%s, 1 thread) => %.0fx.\n" % (
                tag, b4["value"], b4["ms_per_step"], b4["config"]["steps_in_flight"], b4.get("value_sustained", 0),
-               b4["roofline"]["kernel_ms"] * 1e3, ks[1], tag, b4["roofline"]["frac"], b4["roofline"]["algorithmic_bytes_per_launch"] / 1e6,
+               kname, tag, b4["roofline"]["kernel_ms"] * 1e3, ks[1], b4["roofline"]["frac"], b4["roofline"]["algorithmic_bytes_per_launch"] / 1e6,
                tc["pmc"]["FETCH_SIZE"] * 1024 / 1e6, tc["pmc"]["WRITE_SIZE"] * 1024 / 1e6, tag, tc["pmc"]["SQ_INSTS_VALU"],
                b4.get("cpu_baseline", {}).get("value", 0), b4.get("cpu_baseline", {}).get("kind", "-"), b4.get("speedup_vs_cpu_1core", 0)))
 open("%s/README.md" % P, "w").write(rd)

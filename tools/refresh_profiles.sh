@@ -29,10 +29,10 @@ else
   mkdir -p /tmp/census_$tag
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-maxocc -Iinclude -I$S --offload-arch=gfx950 -S --cuda-device-only \
       -o /tmp/census_$tag/ntscsim.s $S/ntscsim_hip.hip 2> /dev/null
-  for k in 'k_decode_fastILb1EdE:4' 'k_decode_fastILb0EdE:4' 'k_encode_fastIdE:16' 'k_row_states:1' 'k_field_setup:1'; do
+  for k in 'k_decode_fastILb1EdLb0EE:4' 'k_decode_fastILb0EdLb0EE:4' 'k_encode_fastIdE:16' 'k_row_states:1' 'k_field_setup:1'; do
     python tools/isa_cost.py /tmp/census_$tag/ntscsim.s "${k%%:*}" --steps "${k##*:}" --json "/tmp/census_$tag/${k%%:*}.json" | head -1
   done
-  (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s 'k422_fusedILb1' --mean > /tmp/census_$tag/k422_fused.json)
+  (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s 'k422_fusedILb1ELb1E' --mean > /tmp/census_$tag/k422_fused.json)
   python tools/make_profiles.py $tag gpurun_out/bench_$tag.json gpurun_out/ks_${tag}_default gpurun_out/ks_${tag}_if1 \
       gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
       gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
