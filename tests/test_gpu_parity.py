@@ -120,6 +120,32 @@ def test_full_size_vs_oracle(w, h, flags, nf):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("w,h,nf", [(720, 486, 6), (3840, 2160, 4)])
+def test_full_size_ghosting_extension(w, h, nf):
+    """BASELINE configs 2 / 5 name "multi-tap ghosting": the extension (absent from the reference, parity
+    unpinned -- the oracle's own definition is the spec) at their sizes, four taps, `-vhs`: HIP == oracle,
+    and the kernel chain is the preset's with k_ghost in between."""
+    torch = torch_mod()
+    p = L.make_params(["-vhs"])
+    p.ghost_taps = 4
+    for k, (d, g) in enumerate(((9, 80), (31, -40), (70, 24), (w // 5, -12))):
+        p.ghost_delay[k] = d
+        p.ghost_gain[k] = g
+    srcs = [L.bars(w, h, j) if j % 2 == 0 else L.noise_frame(w, h, 177 + j) for j in range((nf + 1) // 2)]
+    jobs = cases.case_jobs(nf)
+    o = L.OracleStream(p)
+    exp = np.zeros((nf, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    sim = ntscsim.FieldSimulator(params=p)
+    got = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+    ran = sim.last_kernels()
+    sim.close()
+    assert np.array_equal(got, exp)
+    assert [k for k in ran if not k.startswith(("k_field", "k_row"))] == \
+        ["k_encode_fast<double>", "k_ghost", "k_decode_fast<true,double>"], ran
+
+
 @pytest.mark.parametrize("c", FULL, ids=lambda c: "%dx%d%s" % (c["w"], c["h"], "".join(c["flags"])))
 def test_full_size_reference_hashes(c):
     """Hashes recorded from the reference extract at the BASELINE sizes (incl. 3840x2160)."""
