@@ -227,6 +227,8 @@ struct ChromaLpFull {
         s += hp.hp(s, a_hp);
         return clampu8((int)lp.push(s, a_lp));
     }
+    // the three poles alone: composite_video_chroma_lowpass_lite :395-431
+    DEV int push_plain(int raw) { return clampu8((int)lp.push((double)raw, a_lp)); }
 };
 
 // ---------------------------------------------------------------------------------- sweep A
@@ -401,9 +403,7 @@ struct FrameSinkT {
     WC wu, wv;
     bool drop;
     int mode, dU, dV, W2;             // mode: 0 none, 1 lite (:395-431), 2 full (:353-393)
-    ChromaLpFull fU, fV;
-    Casc3<double> tU, tV;
-    double a_tv;
+    ChromaLpFull fU, fV;              // full: high-pass boost + three poles; lite: its three poles alone, at a_tv
     int u1, u2, u3, u4, v1, v2, v3, v4;   // the last 4 inputs, 1 = newest (row tails); named, not an
                                           // array: a dynamically indexed array would live in scratch
     DEV void begin(const DevParams &P, bool aligned, int out_lp, uint8_t *fy, uint8_t *fu, uint8_t *fv, bool is_out, bool dropped,
@@ -414,9 +414,11 @@ struct FrameSinkT {
         drop = dropped; mode = out_lp; W2 = W / 2;
         dU = mode == 2 ? 2 : (mode == 1 ? 1 : 0);
         dV = mode == 2 ? (P.ntsc ? 4 : 2) : (mode == 1 ? 1 : 0);
-        fU.begin(P.a_in_i, a_hp_i);
-        fV.begin(P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i);
-        a_tv = P.a_tv; tU.reset(128, a_tv); tV.reset(128, a_tv);
+        if (mode == 1) { fU.begin(P.a_tv, 0.0); fV.begin(P.a_tv, 0.0); }      // (both filters start from 128)
+        else {
+            fU.begin(P.a_in_i, a_hp_i);
+            fV.begin(P.ntsc ? P.a_in_q : P.a_in_i, P.ntsc ? a_hp_q : a_hp_i);
+        }
         u1 = u2 = u3 = u4 = v1 = v2 = v3 = v4 = 128;
     }
     DEV void luma(int x, int y) { wy.put(x, y); }
@@ -429,10 +431,16 @@ struct FrameSinkT {
     {
         u4 = u3; u3 = u2; u2 = u1; u1 = u;
         v4 = v3; v3 = v2; v2 = v1; v1 = v;
+        chroma_inner(c, u, v);
+    }
+    // a sample at least 4 before the row end: the row-tail history (u1 .. v4) is rebuilt from the samples
+    // behind it, all of which come through chroma() / chroma_nodrop()
+    DEV void chroma_inner(int c, int u, int v)
+    {
         if (mode == 0) { wu.put(c, u); wv.put(c, v); return; }
         int ou, ov;
         if (mode == 2) { ou = fU.push(u); ov = fV.push(v); }
-        else { ou = clampu8((int)tU.push((double)u, a_tv)); ov = clampu8((int)tV.push((double)v, a_tv)); }
+        else { ou = fU.push_plain(u); ov = fV.push_plain(v); }
         if (c >= dU) wu.put(c - dU, ou);
         if (c >= dV) wv.put(c - dV, ov);
     }
@@ -577,10 +585,10 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 //                 :932-942 -> full output chroma low-pass :948-951 (U lands 2 back, V 4) -> the frame
 // The reference's read of two bytes past the row (:496) feeds both separations (oob0 / oob1).
 // iter<true> is the guarded form for any i (row start, row end, drain); iter<false> assumes every stage
-// strictly inside the row (6 <= i <= W/2 - 1) and is what the steady loop unrolls four times -- the
+// strictly inside the row (D + 2 <= i <= W/2 - 1) and is what the steady loop unrolls four times -- the
 // delay lines are shift registers in the source and plain register renaming in the unrolled loop.
+template <int D>                                 // chroma delay of the tape speed :793-808: 4 (SP), 5 (LP), 6 (EP)
 struct StreamB {
-    static constexpr int D = 4;                  // chroma delay of the SP tape speed :793-808
     int W, W2, oob0, oob1, k;
     unsigned xi;
     bool blend;
@@ -589,9 +597,9 @@ struct StreamB {
     int ev1;
     ChromaPost422 cp;
     LumaVhs lv;
-    int yq[8];                                   // VCR luma of the last 8 positions, [7] newest
+    int yq[2 * D];                               // VCR luma of the last 2 D positions, [2 D - 1] newest
     Casc3<double> lU, lV, sU, sV;
-    int ru[5], rv[5];                            // chroma into the VHS low-pass, last 5 samples, [4] newest
+    int ru[D + 1], rv[D + 1];                    // chroma into the VHS low-pass, last D + 1 samples, [D] newest
     unsigned b0, b1, b2, b3, bsum;               // separation 2
     int ev3;
     FrameSinkBurst sink;
@@ -604,9 +612,9 @@ struct StreamB {
         a0 = a1 = 16; a2 = a3 = 0; asum = 0; ev1 = 0;
         b0 = b1 = 16; b2 = b3 = 0; bsum = 0; ev3 = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) yq[q] = 0;
+        for (int q = 0; q < 2 * D; q++) yq[q] = 0;
 #pragma unroll
-        for (int q = 0; q < 5; q++) { ru[q] = 0; rv[q] = 0; }
+        for (int q = 0; q <= D; q++) { ru[q] = 0; rv[q] = 0; }
         lv.begin(P.a_vl, P.a_sh, P.sharpen);
         lU.reset(128, P.a_vc); lV.reset(128, P.a_vc); sU.reset(128, ashc); sV.reset(128, ashc);
     }
@@ -635,8 +643,12 @@ struct StreamB {
         if (!(xo & 1)) ev3 = ch;
         else {
             const int a = ev3, b = ch;
-            const int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
-            sink.chroma(xo >> 1, u, v);
+            int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
+            if (EDGE) sink.chroma(xo >> 1, u, v);
+            else {
+                if (sink.drop) { u = 128; v = 128; }
+                sink.chroma_inner(xo >> 1, u, v);
+            }
         }
     }
     // c0, c1: composite bytes 2i, 2i+1 after head switching (past the row: the caller's two bytes, then unused)
@@ -677,9 +689,11 @@ struct StreamB {
             fU = clampu8((int)lU.push((double)U1, a_vc));
             fV = clampu8((int)lV.push((double)V1, a_vc));
         }
+        if (EDGE) {       // (the steady loop ends D + 1 inputs before the row does: the guarded steps refill this window)
 #pragma unroll
-        for (int q = 0; q < 4; q++) { ru[q] = ru[q + 1]; rv[q] = rv[q + 1]; }
-        ru[4] = U1; rv[4] = V1;
+            for (int q = 0; q < D; q++) { ru[q] = ru[q + 1]; rv[q] = rv[q + 1]; }
+            ru[D] = U1; rv[D] = V1;
+        }
         const int m2 = i - 1 - D;
         if (!EDGE || (m2 >= 0 && m2 < W2)) {
             int u = fU, v = fV;
@@ -713,8 +727,8 @@ struct StreamB {
         for (int sx = 0; sx < 2; sx++) {
             const int y1 = (!EDGE || yok[sx]) ? lv.run(yb_[sx]) : 0;
 #pragma unroll
-            for (int q = 0; q < 7; q++) yq[q] = yq[q + 1];
-            yq[7] = y1;
+            for (int q = 0; q < 2 * D - 1; q++) yq[q] = yq[q + 1];
+            yq[2 * D - 1] = y1;
         }
     }
 
@@ -754,12 +768,13 @@ struct StreamB {
         else {
             // dropout :932-942 as a mask: 128 + ((x - 128) & dmask)
             const int u = 128 + ((127 - ev3) & dmask), v = 128 + ((127 - ch) & dmask);
-            sink.chroma_nodrop(xo >> 1, u, v);
+            sink.chroma_inner(xo >> 1, u, v);
         }
     }
     template <int J>
     DEV void iter_fast(const DevParams &P, int ib, int c0, int c1)
     {
+        static_assert(D == 4, "the preset form: SP tape speed");
         const int i = ib + J;                     // ib is a multiple of 4
         // ---- main stream: separation 1 at x = 2i, 2i+1 (xo = 2i-2 even, 2i-1 odd; xo & 2 = (2J - 2) & 2)
         constexpr int XO2A = (2 * J + 2) & 2;
@@ -784,9 +799,6 @@ struct StreamB {
         // ---- VCR chroma: input m1 = i - 1, output m2 = i - 5 (strictly inside the row: filtered value)
         int u = clampu8((int)lU.push((double)U1, a_vc));
         int v = clampu8((int)lV.push((double)V1, a_vc));
-#pragma unroll
-        for (int q = 0; q < 4; q++) { ru[q] = ru[q + 1]; rv[q] = rv[q + 1]; }
-        ru[4] = U1; rv[4] = V1;
         u = (((fastdec::wave_up(u) & bA) + b128) + u + bC) >> bC;
         v = (((fastdec::wave_up(v) & bA) + b128) + v + bC) >> bC;
         double s = u;
@@ -822,9 +834,11 @@ struct StreamB {
 #ifndef F422_WAVES
 #define F422_WAVES 1
 #endif
-// STREAM (with SPEC): sweeps B1-B3 as the one streamed pass of StreamB above.
-template <bool SPEC, bool STREAM = false>
-__global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDev G,
+// STREAM: sweeps B1-B3 as the one streamed pass of StreamB above (aligned frame rows; DD = the chroma delay
+// of the tape speed).  With SPEC its steady loop is the preset's iter_fast, otherwise the guard-free form of
+// the general iteration with the switches read at run time.
+template <bool SPEC, bool STREAM = false, int DD = 4>
+__global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevParams P, GeomDev G,
                                                  const Field422Dev *__restrict__ fields,
                                                  Scratch422 Sc,
                                                  const uint32_t *__restrict__ rs_luma,
@@ -878,7 +892,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
         lp_.pre_on = SPEC ? false : P.pre_on != 0; lp_.noise_on = SPEC ? true : P.noise_k != 0;
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
-        if (SPEC || P.ntsc) sweep_a<true, SPEC, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        if (SPEC || P.ntsc) sweep_a<true, SPEC, SPEC && STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
         else sweep_a<false, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
     }
     F422_STAMP(0);
@@ -919,43 +933,46 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_fused(DevParams P, GeomDe
 #endif
     if constexpr (STREAM) {
         // ---- B1 + B2 + B3 in one streamed pass (StreamB)
-        StreamB B;
+        StreamB<DD> B;
         B.begin(P, W, xi, k, oob0, oob1, a_sh_c, sharpen_c);
-        B.cp.noise_on = true; B.cp.phase_on = true; B.cp.ring = ring; B.cp.lane = lane;
-        B.cp.rng.init(ring, rs_chroma + rc, P.Rpad, lane); B.cp.nU = n0_u[rc]; B.cp.nV = n0_v[rc];
-        {
+        B.cp.noise_on = SPEC ? true : P.cnoise_k != 0; B.cp.phase_on = SPEC ? true : P.pnoise_k != 0;
+        B.cp.nU = B.cp.nV = 0; B.cp.cosv = 1; B.cp.sinv = 0; B.cp.ring = ring; B.cp.lane = lane;
+        if (B.cp.noise_on) { B.cp.rng.init(ring, rs_chroma + rc, P.Rpad, lane); B.cp.nU = n0_u[rc]; B.cp.nV = n0_v[rc]; }
+        if (B.cp.phase_on) {
             int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
             n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
             B.cp.cosv = G.ptab[2 * n]; B.cp.sinv = G.ptab[2 * n + 1];
         }
-        B.sink.begin(P, true, 2, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        B.sink.begin(P, true, SPEC ? 2 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
         B.sink.wy.st = fstage + lane * 16; B.sink.wu.st = fstage + (64 + lane) * 16; B.sink.wv.st = fstage + (128 + lane) * 16;
-        B.begin_fast(P.loss && dropout[rc] != 0);
-        const int W2 = W / 2, NIT = W2 + StreamB::D + 2;
+        if constexpr (SPEC) B.begin_fast(P.loss && dropout[rc] != 0);
+        const int W2 = W / 2, NIT = W2 + DD + 2;
         auto in_byte = [&](int x) -> int { return x < W ? R.Y.byte_at(x) : (x == W ? oob0 : (x == W + 1 ? oob1 : 0)); };
         int i = 0;
-        for (; i < 8 && i < NIT; i++) B.iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
-        if (i == 8 && i + 3 <= W2 - 1) {
+        for (; i < 8 && i < NIT; i++) B.template iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        // steady iterations: every stage inside the row, and none of the last DD + 1 chroma inputs of the row
+        // (those refill the row-tail windows of the low-passes, which only the guarded iteration maintains)
+        if (i == 8 && i + 3 <= W2 - 2 - DD) {
             uint32_t w0 = R.Y.word(i >> 1), w1 = R.Y.word((i >> 1) + 1);
-            for (; i + 3 <= W2 - 1; i += 4) {
+            for (; i + 3 <= W2 - 2 - DD; i += 4) {
                 // the next two words are requested before this pair is worked on (clamped at the row end)
                 const int qn = (i >> 1) + 2, qmax = (W - 1) >> 2;
                 const uint32_t n0 = R.Y.word(qn <= qmax ? qn : qmax), n1 = R.Y.word(qn + 1 <= qmax ? qn + 1 : qmax);
-#ifdef F422_STREAM_GENERIC_STEADY     /* A/B: the guard-free form of the generic iteration */
-                B.iter<false>(P, i, byte_of(w0, 0), byte_of(w0, 1));
-                B.iter<false>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
-                B.iter<false>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
-                B.iter<false>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
-#else
-                B.iter_fast<0>(P, i, byte_of(w0, 0), byte_of(w0, 1));
-                B.iter_fast<1>(P, i, byte_of(w0, 2), byte_of(w0, 3));
-                B.iter_fast<2>(P, i, byte_of(w1, 0), byte_of(w1, 1));
-                B.iter_fast<3>(P, i, byte_of(w1, 2), byte_of(w1, 3));
-#endif
+                if constexpr (SPEC) {
+                    B.template iter_fast<0>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                    B.template iter_fast<1>(P, i, byte_of(w0, 2), byte_of(w0, 3));
+                    B.template iter_fast<2>(P, i, byte_of(w1, 0), byte_of(w1, 1));
+                    B.template iter_fast<3>(P, i, byte_of(w1, 2), byte_of(w1, 3));
+                } else {
+                    B.template iter<false>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                    B.template iter<false>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
+                    B.template iter<false>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
+                    B.template iter<false>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
+                }
                 w0 = n0; w1 = n1;
             }
         }
-        for (; i < NIT; i++) B.iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        for (; i < NIT; i++) B.template iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
         B.sink.finish(W);
         F422_STAMP(4);
         return;

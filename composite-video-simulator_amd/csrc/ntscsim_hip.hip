@@ -1041,11 +1041,23 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // and of subcarrier amplitude 50 both ways: scan_phase422, ntsc422_fused.hip StreamB::iter_fast)
     const bool even422 = D.phase_mode == 180 ? !(D.phase_off & 1) : (D.phase_mode != 90 && D.phase_mode != 270);
     const bool stream = spec && even422 && D.amp == 50 && D.amp_back == 50 && !c->no_stream422;
-    note_kernel(c, !fused ? "k422_process" : (spec ? (stream ? "k422_fused<true,true>" : "k422_fused<true>") : "k422_fused<false>"));
-    if (fused && stream)
-        hipLaunchKernelGGL((k422_fused<true, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
-                           c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                           c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    // every other switch set of the family gets the same streamed pass with the switches read at run time
+    // (aligned frame rows: the 64-byte frame bursts), per chroma delay of the tape speed
+    const bool stream_gen = fused && !stream && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 &&
+                            D.cdelay >= 4 && D.cdelay <= 6;
+    note_kernel(c, !fused ? "k422_process"
+                          : stream ? "k422_fused<true,true,4>"
+                          : stream_gen ? (D.cdelay == 4 ? "k422_fused<false,true,4>" : D.cdelay == 5 ? "k422_fused<false,true,5>" : "k422_fused<false,true,6>")
+                          : spec ? "k422_fused<true,false,4>" : "k422_fused<false,false,4>");
+#define NTSC_LAUNCH_422(...)                                                                                  \
+    hipLaunchKernelGGL((k422_fused<__VA_ARGS__>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
+                       c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
+                       c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma)
+    if (fused && stream) NTSC_LAUNCH_422(true, true, 4);
+    else if (stream_gen && D.cdelay == 4) NTSC_LAUNCH_422(false, true, 4);
+    else if (stream_gen && D.cdelay == 5) NTSC_LAUNCH_422(false, true, 5);
+    else if (stream_gen) NTSC_LAUNCH_422(false, true, 6);
+#undef NTSC_LAUNCH_422
     else if (fused && spec)
         hipLaunchKernelGGL(k422_fused<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
                            c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,

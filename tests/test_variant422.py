@@ -288,18 +288,26 @@ def test_hip_reproduces_reference_golden(m):
     sim.close()
 
 
-# (flags, the kernel form the launcher must pick by default).  `ffmpeg_to_composite -vhs` runs the FULL
-# output chroma low-pass (ffmpeg_to_composite.cpp:278, :948-951): that switch set is the preset kernel,
-# k422_fused<true,true> (sweep A + one streamed pass; as four sweeps it is k422_fused<true>).
+# (flags, the kernel form the launcher must pick by default; names as rocprofv3 prints them, without blanks).
+# `ffmpeg_to_composite -vhs` runs the FULL output chroma low-pass (ffmpeg_to_composite.cpp:278, :948-951):
+# that switch set is the preset kernel k422_fused<true,true,4> (sweep A + one streamed pass with the preset's
+# arithmetic identities).  The rest of the VHS family takes the same structure with the switches read at run
+# time, one instantiation per chroma delay (tape speed): k422_fused<false,true,D>.
 _FORM_CASES = [
-    (["-vhs"], "k422_fused<true,true>"),
-    (["-vhs", "-out-composite-lowpass-lite", "0"], "k422_fused<true,true>"),     # full low-pass still on
-    (["-vhs", "-out-composite-lowpass", "0"], "k422_fused<false>"),              # lite output low-pass
-    (["-vhs", "-out-composite-lowpass", "0", "-out-composite-lowpass-lite", "0"], "k422_fused<false>"),
-    (["-vhs", "-vhs-speed", "ep"], "k422_fused<false>"),
-    (["-tvstd", "pal", "-vhs"], "k422_fused<false>"),
-    (["-vhs", "-comp-catv"], "k422_fused<false>"),
-    (["-vhs", "-noise", "0"], "k422_fused<false>"),
+    (["-vhs"], "k422_fused<true,true,4>"),
+    (["-vhs", "-out-composite-lowpass-lite", "0"], "k422_fused<true,true,4>"),   # full low-pass still on
+    (["-vhs", "-out-composite-lowpass", "0"], "k422_fused<false,true,4>"),       # lite output low-pass
+    (["-vhs", "-out-composite-lowpass", "0", "-out-composite-lowpass-lite", "0"], "k422_fused<false,true,4>"),
+    (["-vhs", "-vhs-speed", "lp"], "k422_fused<false,true,5>"),
+    (["-vhs", "-vhs-speed", "ep"], "k422_fused<false,true,6>"),
+    (["-tvstd", "pal", "-vhs"], "k422_fused<false,true,4>"),
+    (["-tvstd", "pal", "-vhs", "-vhs-speed", "ep", "-chroma-noise", "0"], "k422_fused<false,true,6>"),
+    (["-vhs", "-comp-catv"], "k422_fused<false,true,4>"),
+    (["-vhs", "-noise", "0"], "k422_fused<false,true,4>"),
+    # (the preset's filter switches, but not its phase / amplitude identities: streamed with run-time switches;
+    # as four sweeps it is still the preset instantiation, which does not use those identities)
+    (["-vhs", "-comp-phase", "90", "-subcarrier-amp", "30"], "k422_fused<false,true,4>|k422_fused<true,false,4>"),
+    (["-vhs", "-chroma-dropout", "50000", "-chroma-phase-noise", "0"], "k422_fused<false,true,4>"),
     (["-vhs", "-vhs-svideo", "1"], "k422_process"),
     ([], "k422_process"),
 ]
@@ -307,15 +315,16 @@ _FORM_CASES = [
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,form", _FORM_CASES,
-                         ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-ep", "pal-vhs", "vhs-catv", "vhs-nonoise",
-                              "vhs-svideo", "default"])
+                         ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-lp", "vhs-ep", "pal-vhs", "pal-vhs-ep", "vhs-catv",
+                              "vhs-nonoise", "vhs-phase90-amp30", "vhs-dropout", "vhs-svideo", "default"])
 @pytest.mark.parametrize("mode", [0, 1, 2, 4], ids=["default", "twelve-sweep", "general-fused", "preset-four-sweep"])
 def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
-    """The four kernel forms of the -vhs family (k422_fused<true,true> = sweep A + one streamed pass and
-    k422_fused<true> = four sweeps for the preset's own switch set, k422_fused<false>, k422_process) on
-    the same fields: each must equal the oracle, and the form that ran must be the one the case names
-    (ntscsim_debug_last_kernels).  mode = the ntscsim_debug_no_fast_decode() bits (1: twelve-sweep form,
-    2: no preset instantiation, 4: the preset as four sweeps)."""
+    """The kernel forms of the -vhs family (streamed: k422_fused<true,true,4> for the preset's own switch
+    set, k422_fused<false,true,D> for the others; four sweeps: k422_fused<true,false,4> / <false,false,4>;
+    twelve sweeps: k422_process) on the same fields: each must equal the oracle, and the form that ran must
+    be the one the case names (ntscsim_debug_last_kernels).  mode = the ntscsim_debug_no_fast_decode() bits
+    (1: twelve-sweep form, 2: no preset instantiation and no streamed pass, 4: four sweeps instead of the
+    streamed pass)."""
     import torch
     w, h, n = 128, 38, 4
     p = L.make_params_tocomp(flags)
@@ -325,9 +334,15 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
     mask = last_row_margin_mask(frame, 0)
     sim = ntscsim.FieldSimulator(params=p)
     sim.debug_no_fast_decode(mode)
-    preset = form == "k422_fused<true,true>"
-    want = "k422_process" if mode == 1 else ("k422_fused<false>" if mode == 2 and preset else
-                                             ("k422_fused<true>" if mode == 4 and preset else form))
+    form, _, four = form.partition("|")
+    preset, fam = form == "k422_fused<true,true,4>" or four == "k422_fused<true,false,4>", form.startswith("k422_fused")
+    want = form
+    if mode == 1:
+        want = "k422_process"
+    elif mode == 2 and fam:
+        want = "k422_fused<false,false,4>"
+    elif mode == 4 and fam:
+        want = "k422_fused<true,false,4>" if preset else "k422_fused<false,false,4>"
     whole, dev = to_dev_onebuf(torch, frame)
     for k in range(n):
         field = (k & 1) ^ 1
@@ -385,8 +400,8 @@ def test_422_batch_refuses_racing_descriptors():
 @pytest.mark.parametrize("pad", [0, 3, 16])
 def test_fused_kernel_widths_and_row_alignments(w, pad):
     """-vhs at widths around the four-sweep kernel's 16 / 64-sample block sizes, with row paddings that
-    make luma / chroma rows 16- / 8-byte aligned (k422_fused<true,true>, the preset instantiation) or not
-    (k422_fused<false>); the form that ran is asserted."""
+    make luma / chroma rows 16- / 8-byte aligned (k422_fused<true,true,4>, the preset instantiation) or not
+    (k422_fused<false,false,4>, four sweeps with scalar row accesses); the form that ran is asserted."""
     import torch
     h, n = 10, 3
     p = L.make_params_tocomp(["-vhs"])
@@ -405,7 +420,7 @@ def test_fused_kernel_widths_and_row_alignments(w, pad):
         sim.sync()
         # aligned luma (16) and chroma (8) rows and plane starts -> the preset instantiation
         al = all(o_ % a == 0 and l_ % a == 0 for o_, l_, a in zip(frame.off, frame.ls, (16, 8, 8)))
-        assert ("k422_fused<true,true>" if al else "k422_fused<false>") in sim.last_kernels(), (al, sim.last_kernels())
+        assert ("k422_fused<true,true,4>" if al else "k422_fused<false,false,4>") in sim.last_kernels(), (al, sim.last_kernels())
         got = whole.cpu().numpy()
         bad = (got != frame.buf) & mask
         assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
