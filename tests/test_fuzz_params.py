@@ -234,3 +234,111 @@ def test_variant_hip_equals_oracle_on_random_parameters(seed):
         frame.buf[~mask] = got[~mask]
         assert sim.rng_pos == o.rng_pos
     sim.close()
+
+
+# ---- the streamed kernels of the YUV422P tool's VHS family: random geometry, alignment and switch mix
+N_FAMILY = 96
+
+
+def draw422_family(seed):
+    """A member of the -vhs family that the launcher runs as sweep A + one streamed pass when the frame rows
+    are aligned: about a third of the seeds are exactly the preset (`-vhs`), the rest change a few switches.
+    Returns (flags, W, H, pad, n_fields, source, expected kernel form or None for unaligned rows)."""
+    r = random.Random(90000 + seed)
+    f = ["-vhs"]
+    speed, preset = "sp", True
+    if r.random() < 0.35:
+        speed = r.choice(["lp", "ep"]); f += ["-vhs-speed", speed]; preset = False
+    if r.random() < 0.12:
+        f = ["-tvstd", "pal"] + f; preset = False
+    if r.random() < 0.2:
+        f.append(r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3"])); preset = False
+    if r.random() < 0.15:
+        f += ["-noise", str(r.choice([0, 1, 30]))]; preset = preset and f[-1] != "0"
+    if r.random() < 0.15:
+        f += ["-chroma-noise", str(r.choice([0, 5, 64]))]; preset = preset and f[-1] != "0"
+    if r.random() < 0.15:
+        f += ["-chroma-phase-noise", str(r.choice([0, 1, 25]))]; preset = preset and f[-1] != "0"
+    if r.random() < 0.2:
+        f += ["-chroma-dropout", str(r.choice([0, 2000, 60000]))]
+    if r.random() < 0.15:
+        f += ["-out-composite-lowpass", "0"]; preset = False
+        if r.random() < 0.5:
+            f += ["-out-composite-lowpass-lite", "0"]
+    if r.random() < 0.12:
+        f += ["-subcarrier-amp", str(r.choice([10, 30, 75]))]; preset = False
+    if r.random() < 0.12:
+        f += ["-comp-phase", r.choice(["0", "90", "270"])]; preset = preset and f[-1] == "0"
+    if r.random() < 0.12:
+        off = r.randrange(1, 4); f += ["-comp-phase-offset", str(off)]; preset = preset and (off % 2 == 0 or "-comp-phase" in f)
+    if r.random() < 0.2:
+        f += ["-vhs-chroma-vblend", "0"]
+    if r.random() < 0.3:
+        f += ["-vhs-head-switching-point", "%.4f" % r.uniform(0.09, 0.125)]
+    aligned = r.random() < 0.8
+    w = 16 * r.randrange(1, 14) if aligned else r.choice([18, 34, 50, 98, 130, 22])
+    pad = r.choice([0, 16, 32]) if aligned else r.choice([0, 3, 16])
+    h = r.choice([2, 3, 5, 8, 17, 32, 41])
+    n = r.randrange(1, 4)
+    kind = r.choice(["noise", "noise", "bars"])
+    form = None
+    if aligned:
+        d = {"sp": 4, "lp": 5, "ep": 6}[speed]
+        form = "k422_fused<true,true,4>" if preset else "k422_fused<false,true,%d>" % d
+    return f, w, h, pad, n, kind, form
+
+
+@pytest.mark.skipif(not L.have_tocomp_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("seed", range(N_FAMILY))
+def test_variant_family_oracle_equals_reference(seed):
+    """the same draws, oracle == reference extract over the whole buffer (CPU)"""
+    import cases422
+    f, w, h, pad, n, kind, _ = draw422_family(seed)
+    p = L.make_params_tocomp(f)
+    srcs = [cases422.make_source422(kind, w, h, j + seed, pad) for j in range((n + 1) // 2)]
+    a, b = srcs[0].copy(), srcs[0].copy()
+    r, o = L.TocompRefStream(p), L.TocompOracleStream(p, L.OOB_MEMORY)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        _refresh(a, srcs[k // 2], field)
+        _refresh(b, srcs[k // 2], field)
+        r.process(a, field, k)
+        o.process(b, field, k)
+        assert np.array_equal(a.buf, b.buf), (f, w, h, pad, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_FAMILY))
+def test_variant_streamed_family_on_random_geometry(seed):
+    """HIP == oracle (reference-memory semantics, whole buffer) for random members of the -vhs family at random
+    widths (16 ... 208), heights (2 ... 41), row paddings and sources; with aligned rows the streamed form the
+    launcher must pick is asserted by name."""
+    import torch
+    import cases422
+    import ntscsim
+    import test_variant422 as T
+    f, w, h, pad, n, kind, form = draw422_family(seed)
+    p = L.make_params_tocomp(f)
+    srcs = [cases422.make_source422(kind, w, h, j + seed, pad) for j in range((n + 1) // 2)]
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    frame = srcs[0].copy()
+    mask = T.last_row_margin_mask(frame, pad)
+    sim = ntscsim.FieldSimulator(params=p)
+    whole, dev = T.to_dev_onebuf(torch, frame)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        _refresh(frame, srcs[k // 2], field)
+        o.process(frame, field, k)
+        _, srcd = T.to_dev_onebuf(torch, srcs[k // 2])
+        sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
+        sim.sync()
+        ran = [x for x in sim.last_kernels() if x.startswith("k422_fused") or x == "k422_process"]
+        al = all(o_ % a == 0 and l_ % a == 0 for o_, l_, a in zip(frame.off, frame.ls, (16, 8, 8)))
+        if form is not None and al:
+            assert ran == [form], (f, w, h, pad, ran)
+        got = whole.cpu().numpy()
+        bad = (got != frame.buf) & mask
+        assert not bad.any(), (f, w, h, pad, k, int(bad.sum()), ran)
+        frame.buf[~mask] = got[~mask]
+        assert sim.rng_pos == o.rng_pos
+    sim.close()
