@@ -177,6 +177,9 @@ DEV void sweep_blocks(const Plane422 &pl, int N, F body)
 // row is aligned and the block lies inside it
 DEV void load_block16(const uint8_t *row, int x0, int n, bool al16, uint32_t (&w)[4])
 {
+#ifdef F422_AB_NOLOAD     // timing-only A/B build (WRONG frames): no frame loads
+    w[0] = w[1] = w[2] = w[3] = 0x40404040u + (uint32_t)x0; return;
+#endif
     if (al16 && x0 + 16 <= n) {
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         const v4 v = *(__attribute__((address_space(1))) const v4 *)(row + x0);
@@ -196,6 +199,9 @@ DEV void load_block16(const uint8_t *row, int x0, int n, bool al16, uint32_t (&w
 }
 DEV void load_block8(const uint8_t *row, int x0, int n, bool al8, uint32_t (&w)[2])
 {
+#ifdef F422_AB_NOLOAD
+    w[0] = w[1] = 0x80808080u + (uint32_t)x0; return;
+#endif
     if (al8 && x0 + 8 <= n) {
         typedef uint32_t v2 __attribute__((ext_vector_type(2)));
         const v2 v = *(__attribute__((address_space(1))) const v2 *)(row + x0);
@@ -211,6 +217,31 @@ DEV void load_block8(const uint8_t *row, int x0, int n, bool al8, uint32_t (&w)[
         }
         w[0] = a0; w[1] = a1;
     }
+}
+// The same for frame rows whose start and linesize are multiples of 16 / 8 bytes (the streamed forms): ONE
+// unconditional vector load -- a block that starts inside the linesize lies inside it entirely (the bytes
+// behind the row's width are padding nobody looks at), a block past it re-reads the row's last one (nobody
+// looks at that either).  No branch, no byte loop: the loads of a whole group stay in flight across the
+// blocks that are being worked on (with the guarded form hipcc drains vmcnt before the block loop).
+DEV void load_block16_al(const uint8_t *row, int x0, int ls, uint32_t (&w)[4])
+{
+#ifdef F422_AB_NOLOAD
+    w[0] = w[1] = w[2] = w[3] = 0x40404040u + (uint32_t)x0; return;
+#endif
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const int xa = x0 + 16 <= ls ? x0 : ls - 16;
+    const v4 v = *(__attribute__((address_space(1))) const v4 *)(row + xa);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+DEV void load_block8_al(const uint8_t *row, int x0, int ls, uint32_t (&w)[2])
+{
+#ifdef F422_AB_NOLOAD
+    w[0] = w[1] = 0x80808080u + (uint32_t)x0; return;
+#endif
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    const int xa = x0 + 8 <= ls ? x0 : ls - 8;
+    const v2 v = *(__attribute__((address_space(1))) const v2 *)(row + xa);
+    w[0] = v.x; w[1] = v.y;
 }
 DEV int byte_of(uint32_t w, int b) { return (int)((w >> (8 * b)) & 0xFFu); }
 
@@ -239,9 +270,10 @@ struct ChromaLpFull {
 // inside the row run a body without bounds tests or row-tail selects, with (chroma * 50) / 50 == chroma
 // (:470) and the modulation sign (:463-466: bit 1 of xi + x) as a per-lane mask chosen by the unrolled
 // position -- the same results as the general body, which still runs the first and the last block(s).
-template <bool NTSC, bool ALIGNED, bool FAST = false>
+// ALROWS (the streamed forms): rows aligned to 16 / 8 bytes, linesizes lsy / lsc known: branch-free loads.
+template <bool NTSC, bool ALIGNED, bool FAST = false, bool ALROWS = false>
 DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
-                 int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q)
+                 int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q, int lsy = 0, int lsu = 0, int lsv = 0)
 {
     constexpr int D = NTSC ? 4 : 2, DU = 2, DV = NTSC ? 4 : 2;
     const int W2 = W / 2;
@@ -259,28 +291,9 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
     int filV = 128;
     const bool hi = (xi & 2u) != 0;
     const int sm0 = fastdec::opaque_v(hi ? -1 : 0), sm1 = fastdec::opaque_v(hi ? 0 : -1);
-    // Groups of 32 chroma inputs = 64 luma bytes = 4 blocks of 8 chroma inputs.  A group's 64 + 32 + 32
-    // frame bytes are requested together one group ahead (the pieces of one cache line back to back,
-    // so a line is fetched twice / four times per row instead of 8 / 16 times) and rotate through
-    // the "current block" registers.  Block c0 .. c0+7 modulates the 16 luma bytes from 2*(c0 - D):
-    // the upper part of the previous luma block and the lower part of the current one.
-    uint32_t gy[4][4], gu[4][2], gv[4][2], ny[4][4], nu[4][2], nv[4][2], ly_prev[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        load_block16(fy, 16 * b, W, al16, gy[b]);
-        load_block8(fu, 8 * b, W2, al8, gu[b]); load_block8(fv, 8 * b, W2, al8, gv[b]);
-    }
-    for (int g0 = 0; g0 < W2 + D; g0 += 32) {
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-          load_block16(fy, 2 * g0 + 64 + 16 * b, W, al16, ny[b]);
-          load_block8(fu, g0 + 32 + 8 * b, W2, al8, nu[b]); load_block8(fv, g0 + 32 + 8 * b, W2, al8, nv[b]);
-      }
-#pragma unroll 1
-      for (int c0 = g0; c0 < g0 + 32 && c0 < W2 + D; c0 += 8) {
-        uint32_t (&ly)[4] = gy[0], (&cu)[2] = gu[0], (&cv)[2] = gv[0];
-        if (FAST && c0 >= 8 && c0 + 8 <= W2) {
-            // ---- every sample of the block strictly inside the row: D <= c < W2, 0 <= m < W2 - D
+    // one block of 8 chroma samples strictly inside the row (FAST): D <= c < W2, 0 <= m < W2 - D
+    auto fast_block = [&](int c0, const uint32_t (&ly)[4], const uint32_t (&cu)[2], const uint32_t (&cv)[2],
+                          const uint32_t (&ly_prev)[4]) {
             const int q0 = (c0 - D) >> 1;                   // scratch word of luma 2 (c0 - D) (c0 is a multiple of 8)
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -308,6 +321,50 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
                     if (kb == 3) oy.pl.set_word(q0 + ((2 * j + sx) >> 2), oy.acc);
                 }
             }
+    };
+    // Groups of 32 chroma inputs = 64 luma bytes = 4 blocks of 8 chroma inputs.  A group's 64 + 32 + 32
+    // frame bytes are requested together one group ahead (the pieces of one cache line back to back,
+    // so a line is fetched twice / four times per row instead of 8 / 16 times) and rotate through
+    // the "current block" registers.  Block c0 .. c0+7 modulates the 16 luma bytes from 2*(c0 - D):
+    // the upper part of the previous luma block and the lower part of the current one.
+    uint32_t gy[4][4], gu[4][2], gv[4][2], ny[4][4], nu[4][2], nv[4][2], ly_prev[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        if (ALROWS) {
+            load_block16_al(fy, 16 * b, lsy, gy[b]);
+            load_block8_al(fu, 8 * b, lsu, gu[b]); load_block8_al(fv, 8 * b, lsv, gv[b]);
+        } else {
+            load_block16(fy, 16 * b, W, al16, gy[b]);
+            load_block8(fu, 8 * b, W2, al8, gu[b]); load_block8(fv, 8 * b, W2, al8, gv[b]);
+        }
+    }
+    for (int g0 = 0; g0 < W2 + D; g0 += 32) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+          if (ALROWS) {
+              load_block16_al(fy, 2 * g0 + 64 + 16 * b, lsy, ny[b]);
+              load_block8_al(fu, g0 + 32 + 8 * b, lsu, nu[b]); load_block8_al(fv, g0 + 32 + 8 * b, lsv, nv[b]);
+          } else {
+              load_block16(fy, 2 * g0 + 64 + 16 * b, W, al16, ny[b]);
+              load_block8(fu, g0 + 32 + 8 * b, W2, al8, nu[b]); load_block8(fv, g0 + 32 + 8 * b, W2, al8, nv[b]);
+          }
+      }
+      if (FAST && g0 >= 32 && g0 + 32 <= W2) {
+          // a group whose four blocks are all inside the row: straight-line code, no block loop -- the loads of the
+          // next group (above) stay in flight while these 32 samples are worked on (hipcc drains vmcnt in front of a
+          // loop that contains stores)
+          fast_block(g0, gy[0], gu[0], gv[0], ly_prev);
+          fast_block(g0 + 8, gy[1], gu[1], gv[1], gy[0]);
+          fast_block(g0 + 16, gy[2], gu[2], gv[2], gy[1]);
+          fast_block(g0 + 24, gy[3], gu[3], gv[3], gy[2]);
+#pragma unroll
+          for (int q = 0; q < 4; q++) ly_prev[q] = gy[3][q];
+      } else
+#pragma unroll 1
+      for (int c0 = g0; c0 < g0 + 32 && c0 < W2 + D; c0 += 8) {
+        uint32_t (&ly)[4] = gy[0], (&cu)[2] = gu[0], (&cv)[2] = gv[0];
+        if (FAST && c0 >= 8 && c0 + 8 <= W2) {
+            fast_block(c0, ly, cu, cv, ly_prev);
         } else {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -892,8 +949,9 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
         lp_.pre_on = SPEC ? false : P.pre_on != 0; lp_.noise_on = SPEC ? true : P.noise_k != 0;
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
-        if (SPEC || P.ntsc) sweep_a<true, SPEC, SPEC && STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
-        else sweep_a<false, SPEC>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        if (SPEC || P.ntsc) sweep_a<true, SPEC, SPEC && STREAM, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q,
+                                                                        fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2]);
+        else sweep_a<false, SPEC, false, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q, fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2]);
     }
     F422_STAMP(0);
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 1      // timing-only A/B builds (WRONG frames): stop after a sweep

@@ -140,6 +140,9 @@ rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction c
 rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_pmc_summary_to_composite.txt` | `python bench.py --tool to_composite`, `tools/kstats.sh ... --tool to_composite --inflight 1`, `tools/pmc422.sh` | the same three for the YUV422P tool |\n" % (tag, tag, tag)
 rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- python tools/raw28_probe.py` | kernels of the raw-composite decoder on a 600-field capture (4 calls) |\n" % tag
 rd += "| `%s_bench_driver_cmd.json`, `%s_variant_sweeps.txt` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...`; `tools/sweep_times.py` | the driver's own window; wave-clock share of the YUV422P kernel's sweeps |\n" % (tag, tag)
+rd += "| `%s_decode_experiments.txt` | A/B builds (`tools/build_variants.sh`), `NTSCSIM_DEBUG_DECODE`, `--inflight` | what was tried on the dominant kernel this round and did not pay |\n" % tag
+rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_r03.sh` | one-off parity sweeps on the final build (random switch sets, the YUV422P family at random geometry, full size, raw captures) |\n" % tag
+rd += "| `%s_composite_range.txt`, `%s_raw28_front_pmc.txt` | `tools/comp_range_probe.py`; `rocprofv3 --pmc ... tools/raw28_probe.py` | value range of the composite plane (why it cannot be 16 bits wide); counters of the raw-composite front end (a lone wave issues one instruction per 8 cycles) |\n" % (tag, tag)
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (
@@ -148,8 +151,11 @@ drv = "gpurun_out/bench_%s_driver_cmd.json" % tag
 if os.path.exists(drv) and os.path.getsize(drv) > 10:
     dj = json.load(open(drv))
     rd += "With the driver's own window (`python bench.py --gpus 1 --steps 20 --warmup 5`, `%s_bench_driver_cmd.json`): %.0f frames/s -- 20 steps with four in flight include the pipeline's fill and drain.  " % (tag, dj["value"])
-rd += "`roofline.frac` = %.3f (k_decode, algorithmic HBM bytes / 8 TB/s); `roofline.valu.path_frac` = %.2f (cycle-weighted VALU issue, the bound that applies).  " % (
-    d["roofline"]["frac"], v.get("path_frac", 0))
+rd += ("`roofline.frac` = %.3f (k_decode, algorithmic HBM bytes / 8 TB/s; at most %.2f with the reference's fp64 arithmetic: "
+       "`roofline.valu.hbm_frac_ceiling_exact_mode`); `roofline.valu.path_frac_nominal` = %.2f of the VALU issue capacity at the "
+       "pipe's nominal 4 / 2 cycles per instruction, `path_frac` = %.2f at the probe's slowest-wave costs (cycle-weighted VALU "
+       "issue is the bound that applies).  " % (d["roofline"]["frac"], v.get("hbm_frac_ceiling_exact_mode") or 0,
+                                               v.get("path_frac_nominal") or 0, v.get("path_frac", 0)))
 cb = d.get("cpu_baseline", {})
 if cb:
     rd += "CPU beside it on the GPU box's host: the reference's own `composite_layer()` (`oracle/_ref`, 1 thread like the tool) %.1f fields/s => %.0fx; our port 1 core %.1f" % (
