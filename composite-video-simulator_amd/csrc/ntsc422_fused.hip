@@ -243,6 +243,73 @@ DEV void load_block8_al(const uint8_t *row, int x0, int ls, uint32_t (&w)[2])
     const v2 v = *(__attribute__((address_space(1))) const v2 *)(row + xa);
     w[0] = v.x; w[1] = v.y;
 }
+// A group's 64 + 32 + 32 bytes of 64 rows, loaded COOPERATIVELY (like fastenc::CoopLoader): four consecutive lanes
+// fetch the four 16- / 8-byte blocks of ONE row, 16 rows per load instruction -- contiguous 64- / 32-byte pieces
+// instead of 64 scattered 16- / 8-byte ones -- and the blocks go through an LDS tile from which every lane reads its
+// own row back.  The tile is the frame-row stage of the streamed pass, which is idle during sweep A.
+// Tile (words): luma [64][20] | U [64][12] | V [64][12].
+struct CoopRows {
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    const uint8_t *py[4], *pu[4], *pv[4];     // this lane's block of row group i (16 rows each), at x = 0
+    uint32_t *tile;
+    int lsy, lsu, lsv, blk, wy, wc, ry, rc;
+    DEV static const uint8_t *row_of(const uint8_t *mine, int from)
+    {
+        const unsigned lo = (unsigned)(uintptr_t)mine, hi = (unsigned)((uintptr_t)mine >> 32);
+        const unsigned l2 = (unsigned)__shfl((int)lo, from), h2 = (unsigned)__shfl((int)hi, from);
+        return (const uint8_t *)(((uintptr_t)h2 << 32) | l2);
+    }
+    DEV void begin(const uint8_t *fy, const uint8_t *fu, const uint8_t *fv, int ly, int lu, int lv, uint32_t *t, int lane)
+    {
+        tile = t; lsy = ly; lsu = lu; lsv = lv; blk = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int from = 16 * i + (lane >> 2);
+            py[i] = row_of(fy, from); pu[i] = row_of(fu, from); pv[i] = row_of(fv, from);
+        }
+        wy = (lane >> 2) * 20 + blk * 4; wc = (lane >> 2) * 12 + blk * 2;
+        ry = lane * 20; rc = lane * 12;
+    }
+    // luma bytes from x0 (64 per row), chroma bytes from c0 (32 per row); a block past the linesize re-reads the
+    // row's last one, like load_block16_al / load_block8_al
+    DEV void request(int x0, int c0, v4 (&qy)[4], v2 (&qu)[4], v2 (&qv)[4]) const
+    {
+        const int xb = x0 + 16 * blk, cb = c0 + 8 * blk;
+        const int xa = xb + 16 <= lsy ? xb : lsy - 16;
+        const int ua = cb + 8 <= lsu ? cb : lsu - 8, va = cb + 8 <= lsv ? cb : lsv - 8;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            qy[i] = *(__attribute__((address_space(1))) const v4 *)(py[i] + xa);
+            qu[i] = *(__attribute__((address_space(1))) const v2 *)(pu[i] + ua);
+            qv[i] = *(__attribute__((address_space(1))) const v2 *)(pv[i] + va);
+        }
+    }
+    DEV void deliver(const v4 (&qy)[4], const v2 (&qu)[4], const v2 (&qv)[4], uint32_t (&gy)[4][4], uint32_t (&gu)[4][2],
+                     uint32_t (&gv)[4][2]) const
+    {
+        uint32_t *tu = tile + 64 * 20, *tv = tile + 64 * 32;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            *reinterpret_cast<uint4 *>(&tile[16 * 20 * i + wy]) = make_uint4(qy[i].x, qy[i].y, qy[i].z, qy[i].w);
+            *reinterpret_cast<uint2 *>(&tu[16 * 12 * i + wc]) = make_uint2(qu[i].x, qu[i].y);
+            *reinterpret_cast<uint2 *>(&tv[16 * 12 * i + wc]) = make_uint2(qv[i].x, qv[i].y);
+        }
+        // (wave-private tile, lock-step wave: the reads below follow the writes above in LDS order)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(&tile[ry + 4 * b]);
+            gy[b][0] = v.x; gy[b][1] = v.y; gy[b][2] = v.z; gy[b][3] = v.w;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(&tu[rc + 4 * h]);
+            const uint4 c = *reinterpret_cast<const uint4 *>(&tv[rc + 4 * h]);
+            gu[2 * h][0] = a.x; gu[2 * h][1] = a.y; gu[2 * h + 1][0] = a.z; gu[2 * h + 1][1] = a.w;
+            gv[2 * h][0] = c.x; gv[2 * h][1] = c.y; gv[2 * h + 1][0] = c.z; gv[2 * h + 1][1] = c.w;
+        }
+    }
+};
 DEV int byte_of(uint32_t w, int b) { return (int)((w >> (8 * b)) & 0xFFu); }
 
 // composite_video_chroma_lowpass :353-393 as a stream: push(raw) returns the filtered value that
@@ -273,7 +340,8 @@ struct ChromaLpFull {
 // ALROWS (the streamed forms): rows aligned to 16 / 8 bytes, linesizes lsy / lsc known: branch-free loads.
 template <bool NTSC, bool ALIGNED, bool FAST = false, bool ALROWS = false>
 DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
-                 int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q, int lsy = 0, int lsu = 0, int lsv = 0)
+                 int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q, int lsy = 0, int lsu = 0, int lsv = 0,
+                 uint32_t *tile = nullptr)
 {
     constexpr int D = NTSC ? 4 : 2, DU = 2, DV = NTSC ? 4 : 2;
     const int W2 = W / 2;
@@ -328,22 +396,27 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
     // the "current block" registers.  Block c0 .. c0+7 modulates the 16 luma bytes from 2*(c0 - D):
     // the upper part of the previous luma block and the lower part of the current one.
     uint32_t gy[4][4], gu[4][2], gv[4][2], ny[4][4], nu[4][2], nv[4][2], ly_prev[4] = {0, 0, 0, 0};
+    CoopRows CR;
+    CoopRows::v4 qy[4];
+    CoopRows::v2 qu[4], qv[4];
+    if (ALROWS) {
+        CR.begin(fy, fu, fv, lsy, lsu, lsv, tile, post.lane);
+        CR.request(0, 0, qy, qu, qv);
+        CR.deliver(qy, qu, qv, gy, gu, gv);
+    }
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         if (ALROWS) {
-            load_block16_al(fy, 16 * b, lsy, gy[b]);
-            load_block8_al(fu, 8 * b, lsu, gu[b]); load_block8_al(fv, 8 * b, lsv, gv[b]);
         } else {
             load_block16(fy, 16 * b, W, al16, gy[b]);
             load_block8(fu, 8 * b, W2, al8, gu[b]); load_block8(fv, 8 * b, W2, al8, gv[b]);
         }
     }
     for (int g0 = 0; g0 < W2 + D; g0 += 32) {
+      if (ALROWS) CR.request(2 * g0 + 64, g0 + 32, qy, qu, qv);
 #pragma unroll
       for (int b = 0; b < 4; b++) {
           if (ALROWS) {
-              load_block16_al(fy, 2 * g0 + 64 + 16 * b, lsy, ny[b]);
-              load_block8_al(fu, g0 + 32 + 8 * b, lsu, nu[b]); load_block8_al(fv, g0 + 32 + 8 * b, lsv, nv[b]);
           } else {
               load_block16(fy, 2 * g0 + 64 + 16 * b, W, al16, ny[b]);
               load_block8(fu, g0 + 32 + 8 * b, W2, al8, nu[b]); load_block8(fv, g0 + 32 + 8 * b, W2, al8, nv[b]);
@@ -420,11 +493,14 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
             gv[b][0] = gv[b + 1][0]; gv[b][1] = gv[b + 1][1];
         }
       }
+      if (ALROWS) CR.deliver(qy, qu, qv, gy, gu, gv);
+      else {
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
+        for (int b = 0; b < 4; b++) {
 #pragma unroll
           for (int q = 0; q < 4; q++) gy[b][q] = ny[b][q];
           gu[b][0] = nu[b][0]; gu[b][1] = nu[b][1]; gv[b][0] = nv[b][0]; gv[b][1] = nv[b][1];
+        }
       }
     }
     oy.finish(W);
@@ -950,8 +1026,9 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
         if (SPEC || P.ntsc) sweep_a<true, SPEC, SPEC && STREAM, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q,
-                                                                        fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2]);
-        else sweep_a<false, SPEC, false, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q, fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2]);
+                                                                        fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2], fstage);
+        else sweep_a<false, SPEC, false, STREAM>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q, fd.dst_ls[0], fd.dst_ls[1],
+                                                 fd.dst_ls[2], fstage);
     }
     F422_STAMP(0);
 #if defined(F422_AB_STOP) && F422_AB_STOP <= 1      // timing-only A/B builds (WRONG frames): stop after a sweep
