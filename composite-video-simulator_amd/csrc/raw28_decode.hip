@@ -61,6 +61,7 @@ struct Buf {
 };
 
 struct FrontState { double p0, p1, p2, level; };
+typedef double lvpair __attribute__((ext_vector_type(2)));     // lv of two consecutive samples
 
 struct FrontConst {
     double alpha, a_fast, om_fast, a_slow, om_slow;   // a, 1.0 - a of the two follower rates (:563-570)
@@ -102,138 +103,263 @@ __device__ __forceinline__ int front_step(FrontState &s, const FrontConst &K, do
     return x;
 }
 
-// The same arithmetic as front_step(), software-pipelined over four consecutive samples: in one step
-// low-pass 0 works on sample t, low-pass 1 on t-1, low-pass 2 on t-2 and the follower on t-3, each
-// reading what its predecessor produced one step earlier.  Four independent dependency chains per
-// step instead of one long one -- a lone wavefront per SIMD is latency-bound on this kernel.
-struct FrontPipe {
-    double p0, p1, p2, level;      // serial state (p_k = last output of low-pass k)
-    double r0, r1, r2;             // p_k - p_k * alpha, the part of the next update that is already known
-    double l0, l1, l2;             // outputs waiting for the next stage
-    __device__ __forceinline__ void load(const FrontState &s, const FrontConst &K)
-    {
-        p0 = s.p0; p1 = s.p1; p2 = s.p2; level = s.level;
-        r0 = p0 - (p0 * K.alpha); r1 = p1 - (p1 * K.alpha); r2 = p2 - (p2 * K.alpha);
-        l0 = l1 = l2 = 0;
-    }
-    __device__ __forceinline__ FrontState state() const { return FrontState{p0, p1, p2, level}; }
-    // stages; call order within a step is D, C, B, A so that each reads its predecessor's OLD output
-    __device__ __forceinline__ void A(const FrontConst &K, double x) { l0 = (x * K.alpha) + r0; p0 = l0; r0 = l0 - (l0 * K.alpha); }
-    __device__ __forceinline__ void B(const FrontConst &K) { l1 = (l0 * K.alpha) + r1; p1 = l1; r1 = l1 - (l1 * K.alpha); }
-    __device__ __forceinline__ void C(const FrontConst &K) { l2 = (l1 * K.alpha) + r2; p2 = l2; r2 = l2 - (l2 * K.alpha); }
-    __device__ __forceinline__ int D(const FrontConst &K)
-    {
-        const double lv = l2;
-        level = follow(level, lv, K);
-        int x = (int)(lv - level);
-        return x < 0 ? 0 : (x > 255 ? 255 : x);
-    }
-};
-
-// samples [s0, s1) of the stream, s0 a multiple of 16; OUT: store hsync_dc_raw.  On return `st` is the
-// serial state after sample s1 - 1.
-template <bool OUT>
-__device__ __forceinline__ void front_span(FrontState &st, const FrontConst &K, const uint8_t *__restrict__ raw,
-                                           uint8_t *__restrict__ h, size_t s0, size_t s1)
+// ---- the front end as two sweeps over the new samples [o0, o1) -------------------------------------------
+// Grid: a0 = o0 rounded up to 16; chunk c = samples [a0 + c m, a0 + (c + 1) m), m a multiple of 16 Q; a chunk is
+// cut into Q sub-chunks of ms = m / Q samples for sweep 1.  The (at most 15) samples before a0 are walked by one
+// thread from the exact state before o0 (k_raw28_head), which leaves the exact state before a0 in st_a0.
+//
+// Sweep 1 (k_raw28_lp): the three low-passes, one lane per sub-chunk, warm-up of w1 samples from a guess
+// (state = the first sample), the link of every sub-chunk to its predecessor checked bitwise and repaired as
+// described at the top.  Its output, the fp64 lv of every sample, goes to a plane in HBM that is TRANSPOSED:
+// LV[t][c] = lv(a0 + c m + t).  All lanes of a wavefront (64 consecutive chunks, same sub-chunk number) are at
+// the same t at the same time, so every store is one contiguous 512-byte piece.
+// Sweep 2 (k_raw28_follow): the follower alone, one lane per chunk, `warm` samples of warm-up from 255.  Lane
+// c walks down its own column after the last rows of the columns before it; the lanes of a wavefront are
+// again at the same row at the same time, in consecutive columns: every load is one contiguous 512-byte
+// piece, requested two blocks of eight rows ahead.  The follower's chain is 9 instructions per sample against
+// the 23 of low-passes + follower, and the low-passes are no longer recomputed during the (46 times longer)
+// follower warm-up: that is the whole gain (18.7 ms -> see DESIGN.md section 7b), the run of one lane being a
+// single dependent chain whatever is done.
+__device__ __forceinline__ double lp3_step(double &p0, double &p1, double &p2, double alpha, double x)
 {
-    const size_t n = s1 - s0;
-    if (n < 12) {
-        for (size_t s = s0; s < s1; s++) { const int v = front_step(st, K, (double)raw[s]); if (OUT) h[s] = (uint8_t)v; }
-        return;
-    }
-    FrontPipe P;
-    P.load(st, K);
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    const uint32_t *rw = (const uint32_t *)(raw + s0);
-    const v4 *rv = (const v4 *)(raw + s0);         // (s0 is a multiple of 16; raw is padded by 64 bytes)
-    uint32_t *hw = (uint32_t *)(h + s0);
-    v4 cur = rv[0], nxt = rv[1];
-    // fill: steps 0, 1, 2
-    P.A(K, (double)(cur.x & 0xFFu));
-    P.B(K); P.A(K, (double)((cur.x >> 8) & 0xFFu));
-    P.C(K); P.B(K); P.A(K, (double)((cur.x >> 16) & 0xFFu));
-    // steady: iteration q runs steps 4q+3 .. 4q+6 (all four stages busy) and completes output word q
-#define FRONT_ITER(W, WN, O)                                                                         \
-    O = (uint32_t)P.D(K); P.C(K); P.B(K); P.A(K, (double)((W) >> 24));                                \
-    O |= (uint32_t)P.D(K) << 8; P.C(K); P.B(K); P.A(K, (double)((WN) & 0xFFu));                       \
-    O |= (uint32_t)P.D(K) << 16; P.C(K); P.B(K); P.A(K, (double)(((WN) >> 8) & 0xFFu));               \
-    O |= (uint32_t)P.D(K) << 24; P.C(K); P.B(K); P.A(K, (double)(((WN) >> 16) & 0xFFu));
-    const size_t nq = (n - 3) / 4;                 // steps up to 4*nq + 2 <= n - 1 feed stage A
-    size_t q = 0;
-    for (size_t g = 0; 4 * (g + 1) <= nq; g++, q += 4) {      // 16 samples; the next 16 bytes are already on their way
-        const v4 nn = rv[g + 2];
-        v4 o;
-        FRONT_ITER(cur.x, cur.y, o.x)
-        FRONT_ITER(cur.y, cur.z, o.y)
-        FRONT_ITER(cur.z, cur.w, o.z)
-        FRONT_ITER(cur.w, nxt.x, o.w)
-        if (OUT) *(v4 *)(hw + q) = o;
-        cur = nxt; nxt = nn;
-    }
-    for (; q < nq; q++) {
-        const uint32_t w = rw[q], wn = rw[q + 1];
-        uint32_t o;
-        FRONT_ITER(w, wn, o)
-        if (OUT) hw[q] = o;
-    }
-#undef FRONT_ITER
-    // drain: the remaining steps one at a time (stage X handles sample t - X while that sample exists)
-    for (size_t t = 4 * nq + 3; t < n + 3; t++) {
-        if (t >= 3) { const int v = P.D(K); if (OUT) h[s0 + t - 3] = (uint8_t)v; }
-        if (t - 2 < n) P.C(K);
-        if (t - 1 < n) P.B(K);
-        if (t < n) P.A(K, (double)raw[s0 + t]);
-    }
-    st = P.state();
+    double lv = (x * alpha) + (p0 - (p0 * alpha)); p0 = lv;            // LowpassFilter::lowpass :92-96
+    lv = (lv * alpha) + (p1 - (p1 * alpha)); p1 = lv;
+    lv = (lv * alpha) + (p2 - (p2 * alpha)); p2 = lv;
+    return lv;
 }
 
-// round 0 (speculative, all chunks) and repair rounds (flagged chunks, start = predecessor's end).  The
-// samples [o0, N) of the buffer are new (a stream is decoded push by push; o0 = 0 for a whole capture): the
-// state before sample o0 is `init`, exactly.  Chunk 0 = [o0, a0 + chunk), chunk c = [a0 + c chunk, a0 + (c + 1)
-// chunk) with a0 = o0 rounded up to the 16-sample grid of the vector loads.
-// Launched as 256-thread workgroups that each claim a whole CU's LDS (FRONT_PIN_LDS bytes of dynamic shared
-// memory nobody touches): one workgroup per CU, its four wavefronts on the CU's four SIMDs -- a lane's run
-// is a single dependent chain of warm-up + chunk samples, so the kernel takes as long as its most crowded
-// SIMD, and the default placement of 1,024 one-wave workgroups leaves some SIMDs with two or three waves
-// and others idle.
-constexpr int FRONT_WG = 256;
-constexpr size_t FRONT_PIN_LDS = 96 * 1024;        // > half of the CU's 160 KiB: a second workgroup cannot fit
-__global__ __launch_bounds__(FRONT_WG) void k_raw28_front(const uint8_t *__restrict__ raw, size_t N, uint8_t *__restrict__ h,
-                                                    size_t o0, int chunk, int warm, int nchunks, FrontConst K, FrontState init,
-                                                    FrontState *__restrict__ st_begin, FrontState *__restrict__ st_end,
-                                                    const FrontState *__restrict__ prev_end, const int *__restrict__ flags)
+__global__ void k_raw28_head(const uint8_t *__restrict__ raw, uint8_t *__restrict__ h, size_t o0, size_t e,
+                             FrontConst K, FrontState init, FrontState *__restrict__ st_a0)
 {
-    const int c = blockIdx.x * FRONT_WG + threadIdx.x;
-    if (c >= nchunks) return;
-    if (flags && !flags[c]) return;
-    const size_t a0 = (o0 + 15) & ~(size_t)15;
-    const size_t g0 = a0 + (size_t)c * (size_t)chunk;                      // on the 16-sample grid
-    const size_t s0 = c == 0 ? o0 : g0;
-    const size_t s1 = g0 + (size_t)chunk < N ? g0 + (size_t)chunk : N;
-    // the samples between o0 and the grid, one at a time (OUT: they belong to chunk 0)
-    auto head = [&](FrontState &st, bool out) {
-        const size_t e = a0 < N ? a0 : N;
-        for (size_t s = o0; s < e; s++) { const int v = front_step(st, K, (double)raw[s]); if (out) h[s] = (uint8_t)v; }
-    };
-    FrontState st;
-    if (flags) {
-        st = prev_end[c - 1];                      // repair: the true state before this chunk (so far)
-    } else if (c == 0) {
-        st = init;                                 // the state before the first new sample: exact
-    } else if (g0 - a0 <= (size_t)warm) {
-        st = init;                                 // close to the first new sample: walk there from the exact state
-        head(st, false);
-        front_span<false>(st, K, raw, h, a0, g0);
-    } else {
-        const size_t w0 = g0 - (size_t)warm;       // (warm and chunk are multiples of 16)
-        const double r0 = (double)raw[w0];
-        st.p0 = st.p1 = st.p2 = r0; st.level = 255.0;
-        front_span<false>(st, K, raw, h, w0, g0);
+    if (blockIdx.x || threadIdx.x) return;
+    FrontState st = init;
+    for (size_t s = o0; s < e; s++) h[s] = (uint8_t)front_step(st, K, (double)raw[s]);
+    *st_a0 = st;
+}
+
+// samples [s0, s1) through the three low-passes, s0 a multiple of 16 (raw is padded by 64 bytes); OUT: lv of
+// the sample pair (s0 + 2u, s0 + 2u + 1) to out[u * stride]
+template <bool OUT>
+__device__ __forceinline__ void lp_span(double &p0, double &p1, double &p2, double alpha, const uint8_t *__restrict__ raw,
+                                        size_t s0, size_t s1, lvpair *__restrict__ out, size_t stride)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const size_t n = s1 - s0, nb = n / 16;
+    const v4 *rv = (const v4 *)(raw + s0);
+    v4 cur = rv[0];
+    for (size_t b = 0; b < nb; b++) {
+        const v4 nxt = rv[b + 1];                  // (at most 16 bytes past s1: inside the padding)
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            lvpair pr;
+            pr.x = lp3_step(p0, p1, p2, alpha, (double)((w[j >> 2] >> (8 * (j & 3))) & 0xFFu));
+            pr.y = lp3_step(p0, p1, p2, alpha, (double)((w[j >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu));
+            if (OUT) out[(b * 8 + (size_t)(j >> 1)) * stride] = pr;
+        }
+        cur = nxt;
     }
-    st_begin[c] = st;
-    if (c == 0) { head(st, true); if (a0 < s1) front_span<true>(st, K, raw, h, a0, s1); }
-    else front_span<true>(st, K, raw, h, s0, s1);
-    st_end[c] = st;
+    for (size_t t = nb * 16; t < n; t += 2) {      // (the end of the stream: the second half of an odd pair is never read)
+        lvpair pr;
+        pr.x = lp3_step(p0, p1, p2, alpha, (double)raw[s0 + t]);
+        pr.y = t + 1 < n ? lp3_step(p0, p1, p2, alpha, (double)raw[s0 + t + 1]) : 0.0;
+        if (OUT) out[(t >> 1) * stride] = pr;
+    }
+}
+
+// Sub-chunk i = c Q + q (stream order) = samples [a0 + i ms, a0 + (i + 1) ms) cut at o1.  Block b covers
+// the 64 chunks (b % nwc) * 64 .. of sub-chunk number q = b / nwc.  Round 0: flags == nullptr, all sub-chunks;
+// repair rounds: the flagged ones, from prev_end[i - 1].
+__global__ __launch_bounds__(64) void k_raw28_lp(const uint8_t *__restrict__ raw, size_t a0, size_t o1, int m, int ms, int Q,
+                                                 int w1, int nchunks, int nsub, double alpha,
+                                                 const FrontState *__restrict__ st_a0, lvpair *__restrict__ LV2,
+                                                 FrontState *__restrict__ st_begin, FrontState *__restrict__ st_end,
+                                                 const FrontState *__restrict__ prev_end, const int *__restrict__ flags)
+{
+    const int nwc = (nchunks + 63) / 64;
+    const int q = blockIdx.x / nwc, c = (blockIdx.x - q * nwc) * 64 + threadIdx.x;
+    const int i = c * Q + q;
+    if (c >= nchunks || i >= nsub) return;
+    if (flags && !flags[i]) return;
+    const size_t g = a0 + (size_t)i * (size_t)ms;
+    const size_t e = g + (size_t)ms < o1 ? g + (size_t)ms : o1;
+    double p0, p1, p2;
+    if (flags) {
+        const FrontState s = prev_end[i - 1]; p0 = s.p0; p1 = s.p1; p2 = s.p2;
+    } else if (g - a0 <= (size_t)w1) {             // (i == 0 included) close to a0: walk there from the exact state
+        const FrontState s = *st_a0; p0 = s.p0; p1 = s.p1; p2 = s.p2;
+        lp_span<false>(p0, p1, p2, alpha, raw, a0, g, nullptr, 0);
+    } else {
+        const size_t w0 = g - (size_t)w1;          // (w1 and ms are multiples of 16)
+        p0 = p1 = p2 = (double)raw[w0];
+        lp_span<false>(p0, p1, p2, alpha, raw, w0, g, nullptr, 0);
+    }
+    st_begin[i] = FrontState{p0, p1, p2, 0.0};
+    lp_span<true>(p0, p1, p2, alpha, raw, g, e, LV2 + (size_t)q * (size_t)(ms / 2) * (size_t)nchunks + c, (size_t)nchunks);
+    st_end[i] = FrontState{p0, p1, p2, 0.0};
+}
+
+// hsync_dc_raw :588-593
+__device__ __forceinline__ uint32_t dc_byte(double lv, double level)
+{
+    const int x = (int)(lv - level);
+    return (uint32_t)(x < 0 ? 0 : (x > 255 ? 255 : x));
+}
+
+constexpr size_t FRONT_SEG = (size_t)1 << 29;     // samples per front-end segment (4 GiB of plane)
+constexpr int LP_WARM = 2048;                      // sweep 1's warm-up: 0.942^t t^2 is below an ulp after ~900 samples
+#ifndef RAW28_FOLLOW_FORM
+#define RAW28_FOLLOW_FORM 0       /* measured on the 600-field capture: form 0 7.1 ms, 1 7.6 ms, 2 7.8 ms (whole front end) */
+#endif
+constexpr int FOLLOW_BLK = 16;                     // samples per block of loads (8 loads of one sample pair)
+constexpr int FOLLOW_CK = 1024;                    // samples between the checkpoints a repair round compares with
+constexpr int FOLLOW_NB = 6;                       // blocks per lane in registers: five in flight while one is used
+constexpr size_t FOLLOW_PIN_LDS = 96 * 1024;       // > half of the CU's 160 KiB: one workgroup (= one wavefront) per CU
+
+// 16 follower steps over the samples of one block.  A lone wavefront gets one instruction through per ~5
+// cycles whatever its kind, so the step is written for the fewest instructions, exactly the tool's own
+// statement :563-570: compare, pick the rate a (two v_cndmask), 1.0 - a, two multiplies, one add.
+template <bool OUT>
+__device__ __forceinline__ void follow_block(double &level, const lvpair (&src)[FOLLOW_BLK / 2], const FrontConst &K, uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int j = 0; j < FOLLOW_BLK; j++) {
+        const double lv = (j & 1) ? src[j >> 1].y : src[j >> 1].x;
+#if RAW28_FOLLOW_FORM == 0       /* pick the rate, 7 instructions, 5 dependent */
+        const double a = level > lv ? K.a_fast : K.a_slow;
+        level = (level * (1.0 - a)) + (lv * a);
+#elif RAW28_FOLLOW_FORM == 1     /* pick rate and 1 - rate, 8 instructions, 4 dependent */
+        const bool fast = level > lv;
+        const double a = fast ? K.a_fast : K.a_slow, om = fast ? K.om_fast : K.om_slow;
+        level = (level * om) + (lv * a);
+#else                            /* both branches, pick the result: 9 instructions, 3 dependent */
+        const bool fast = level > lv;
+        const double cf = (level * K.om_fast) + (lv * K.a_fast);
+        const double cs = (level * K.om_slow) + (lv * K.a_slow);
+        level = fast ? cf : cs;
+#endif
+        if (OUT) o[j >> 2] |= dc_byte(lv, level) << (8 * (j & 3));
+    }
+}
+
+// Sweep 2.  One wavefront = 64 consecutive chunks.  With Kw = ceil(warm / m) and r0 = Kw m - warm, lane c
+// starts at row r0 of column c - Kw and walks to the end of column c - 1 (its warm-up, `warm` samples), then
+// its own column with output.  Columns before 0 do not exist: such a lane waits, with the exact level before
+// a0, until its walk reaches column 0.  Repair rounds (flags): the own column only, from prev_end[c - 1].
+// The plane holds sample PAIRS: LV2[t / 2][c] = (lv(t), lv(t + 1)), one 16-byte load per lane and pair.
+__global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ LV2, size_t a0, size_t o1, int m, int warm,
+                                                     int nchunks, FrontConst K, const FrontState *__restrict__ st_a0,
+                                                     uint8_t *__restrict__ h, double *__restrict__ lv_begin,
+                                                     double *__restrict__ lv_end, double *__restrict__ ckpt, int ncp,
+                                                     const double *__restrict__ prev_end, const int *__restrict__ flags)
+{
+    constexpr int NB = FOLLOW_NB, HB = FOLLOW_BLK / 2;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = c < nchunks;
+    const int cc = valid ? c : nchunks - 1;
+    const size_t ncols = (size_t)nchunks;
+    const size_t rstride = ncols * sizeof(lvpair);     // bytes from one row pair to the next
+    const int Kw = (warm + m - 1) / m;
+    double level = 255.0;
+    if ((size_t)cc * (size_t)m <= (size_t)warm) level = st_a0->level;
+    const bool repair = flags != nullptr;
+    const bool mine = valid && (!repair || flags[cc]);
+    if (repair) {
+        if (!__any(mine)) return;
+        if (mine) level = prev_end[cc - 1];
+    }
+    lvpair R[NB][HB];
+    uint32_t o[4] = {0, 0, 0, 0};
+    // a block of 8 row pairs: a uniform row pointer plus the lane's column (the loads take their base from
+    // scalar registers)
+    auto load_block = [&](lvpair (&dst)[HB], int row, int col) {
+        const unsigned coff = (unsigned)col * (unsigned)sizeof(lvpair);
+        const char *rowp = (const char *)(LV2 + (size_t)(row >> 1) * ncols);
+#pragma unroll
+        for (int j = 0; j < HB; j++) dst[j] = *(const lvpair *)(rowp + (size_t)j * rstride + coff);
+    };
+    // ---- warm-up: columns cc - Kw .. cc - 1, the first one from row r0
+    if (!repair) {
+        int row = Kw * m - warm, k = -Kw;          // wave-uniform position of the next block to use ...
+        int lrow = row, lk = k;                    // ... and of the next block to request
+        const long long nblk = (long long)warm / FOLLOW_BLK;                   // (warm and m are multiples of 16)
+        auto request = [&](lvpair (&dst)[HB]) {    // column clamped at 0 for the lanes that are still waiting
+            load_block(dst, lrow, cc + lk < 0 ? 0 : cc + lk);
+            lrow += FOLLOW_BLK;
+            if (lrow >= m) { lrow -= m; lk++; }
+        };
+        auto use = [&](const lvpair (&src)[HB]) {
+            if (cc + k >= 0) follow_block<false>(level, src, K, o);
+            row += FOLLOW_BLK;
+            if (row >= m) { row -= m; k++; }
+        };
+        // NB - 1 blocks in flight, no condition inside the loop (the compiler's wait counts stay exact)
+        long long b = 0;
+        if (nblk >= NB - 1) {
+#pragma unroll
+            for (int i = 0; i < NB - 1; i++) request(R[i]);
+            for (; b + 2 * NB - 1 <= nblk; b += NB) {
+#pragma unroll
+                for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB]); use(R[i]); }
+            }
+#pragma unroll
+            for (int i = 0; i < NB - 1; i++) use(R[i]);
+            b += NB - 1;
+        }
+        for (; b < nblk; b++) { request(R[0]); use(R[0]); }
+        if (valid) lv_begin[c] = level;
+    } else if (mine) {
+        lv_begin[c] = level;
+    }
+    // ---- the own column: rows 0 .. len - 1, 16 bytes of hsync_dc_raw per store
+    const size_t g = a0 + (size_t)cc * (size_t)m;
+    const int len = !mine ? 0 : (g + (size_t)m <= o1 ? m : (int)(o1 - g));
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    const int nbf = len / FOLLOW_BLK, nbm = m / FOLLOW_BLK;    // full blocks of this lane; blocks of a full column (uniform)
+    {
+        // (rows past `len` of the stream's last column hold nothing: they are loaded, never used)
+        auto request = [&](lvpair (&dst)[HB], int blk) { load_block(dst, (blk < nbm ? blk : nbm - 1) * FOLLOW_BLK, cc); };
+        // Every FOLLOW_CK samples the level is left in ckpt[c][.].  A repair round compares instead: once the repaired
+        // run meets the earlier one bitwise, everything after it (bytes, end level) is what the earlier run wrote.
+        bool done = !mine;
+        auto use = [&](const lvpair (&src)[HB], int blk) {
+            if (blk < nbf && !done) {
+                o[0] = o[1] = o[2] = o[3] = 0;
+                follow_block<true>(level, src, K, o);
+                *(v4 *)(h + g + (size_t)blk * FOLLOW_BLK) = v4{o[0], o[1], o[2], o[3]};
+                if ((blk + 1) % (FOLLOW_CK / FOLLOW_BLK) == 0) {
+                    double *cp = ckpt + (size_t)cc * (size_t)ncp + (size_t)((blk + 1) / (FOLLOW_CK / FOLLOW_BLK) - 1);
+                    if (repair && __double_as_longlong(*cp) == __double_as_longlong(level)) done = true;
+                    else *cp = level;
+                }
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < NB - 1; i++) request(R[i], i);
+        for (int b = 0; b < nbm; b += NB) {
+#pragma unroll
+            for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB], b + i + NB - 1); use(R[i], b + i); }
+            if (repair && __all(done)) return;
+        }
+        if (done) return;                          // (only repair rounds get here with `done` set by a comparison)
+    }
+    for (int t = nbf * FOLLOW_BLK; t < len; t++) {
+        const lvpair pr = LV2[(size_t)(t >> 1) * ncols + (size_t)cc];
+        const double lv = (t & 1) ? pr.y : pr.x;
+        level = follow(level, lv, K);
+        h[g + t] = (uint8_t)dc_byte(lv, level);
+    }
+    if (mine) lv_end[c] = level;
+}
+
+__global__ void k_raw28_links1(const double *__restrict__ lv_begin, const double *__restrict__ lv_end, int nchunks,
+                               int *__restrict__ flags, int *__restrict__ nbad)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int bad = c > 0 && __double_as_longlong(lv_begin[c]) != __double_as_longlong(lv_end[c - 1]);
+    flags[c] = bad;
+    if (bad) atomicAdd(nbad, 1);
 }
 
 __global__ void k_raw28_links(const FrontState *__restrict__ st_begin, const FrontState *__restrict__ st_end,
@@ -515,6 +641,7 @@ struct ntscsim_raw28 {
     bool chunk_forced = false;
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
+    int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)
     // decoder state: levels (:553-554), stream position; kept from push to push of a stream
     double blank = 0, white = 192;
     uint64_t read_pos = 0;
@@ -534,7 +661,8 @@ struct ntscsim_raw28 {
     size_t last_n = 0;
     // device scratch
     Buf<uint8_t> raw, h, raw_alt, h_alt, tmp;
-    Buf<FrontState> st_begin, st_end, st_prev;
+    Buf<FrontState> st_begin, st_end, st_prev, st_a0;
+    Buf<double> lvplane, lv_begin, lv_end, lv_prev, ckpt;
     Buf<int> flags, counters, tails_a, tails_b;
     Buf<unsigned long long> segcnt, segoff;
     Buf<uint32_t> rstart, rend;
@@ -651,6 +779,7 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.om_slow = 1.0 - d->K.a_slow;
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
+    if (const char *e = std::getenv("NTSCSIM_RAW28_CHUNKS")) { const int v = std::atoi(e); if (v >= 64) d->max_chunks = v; }
     *out = d;
     return NTSCSIM_OK;
 }
@@ -754,44 +883,96 @@ static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_devi
     d->last_n = N;
     R28CHK(d, d->counters.ensure(4));
 
-    // ---- (1) front end over the new samples [front_done, N)
-    // one lane per chunk, and no more chunks than one wavefront per SIMD can hold (1,024 x 64): a lane's
-    // run is warm-up + chunk samples long whatever the chunk count, so a second wavefront per SIMD would
-    // only double the time
+    // ---- (1) front end over the new samples [front_done, N), at most FRONT_SEG of them at a time (the fp64
+    // plane between the two sweeps is 8 bytes per sample)
     const int warm = (int)(((size_t)d->warm_lines * len + 15) & ~(size_t)15);
-    if (N > d->front_done) {
-        const size_t o0 = d->front_done, fresh = N - o0;
-        int chunk = d->chunk;
-        if (!d->chunk_forced && fresh / (size_t)chunk >= 65536) chunk = (int)((fresh / 65536 + 16) & ~(size_t)15);
+    while (N > d->front_done) {
+        const size_t o0 = d->front_done, o1 = std::min(N, o0 + FRONT_SEG), fresh = o1 - o0;
         const size_t a0 = (o0 + 15) & ~(size_t)15;
-        const int nchunks = a0 >= N ? 1 : (int)((N - a0 + (size_t)chunk - 1) / (size_t)chunk);
-        R28CHK(d, d->st_begin.ensure((size_t)nchunks));
-        R28CHK(d, d->st_end.ensure((size_t)nchunks));
-        R28CHK(d, d->st_prev.ensure((size_t)nchunks));
-        R28CHK(d, d->flags.ensure((size_t)nchunks));
-        const size_t pin = d->front_pin ? FRONT_PIN_LDS : 0;
-        if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
-        hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), pin, st, raw, N, d->h.p, o0, chunk, warm,
-                           nchunks, d->K, d->front_state, d->st_begin.p, d->st_end.p, (const FrontState *)nullptr, (const int *)nullptr);
-        for (;;) {
-            R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_raw28_links, dim3((nchunks + 255) / 256), dim3(256), 0, st, d->st_begin.p, d->st_end.p,
-                               nchunks, d->flags.p, d->counters.p);
-            int nbad = 0;
+        R28CHK(d, d->st_a0.ensure(1));
+        hipLaunchKernelGGL(k_raw28_head, dim3(1), dim3(64), 0, st, raw, d->h.p, o0, std::min(a0, o1), d->K, d->front_state, d->st_a0.p);
+        if (a0 >= o1) {
+            R28CHK(d, hipMemcpyAsync(&d->front_state, d->st_a0.p, sizeof(FrontState), hipMemcpyDeviceToHost, st));
+            R28CHK(d, hipStreamSynchronize(st));
+            d->front_done = o1;
+            continue;
+        }
+        // one lane per chunk in sweep 2: a lane's run is warm-up + chunk samples long whatever the chunk count and
+        // every lane reads warm-up + chunk values of the plane, so no more chunks than it takes to occupy the
+        // CUs with one wavefront each
+        size_t chunk = (size_t)d->chunk;
+        if (!d->chunk_forced && fresh / chunk >= (size_t)d->max_chunks) chunk = (fresh / (size_t)d->max_chunks + 128) & ~(size_t)127;
+        if (chunk > (size_t)INT_MAX / 2) { d->err = "front end: chunk too long"; return NTSCSIM_E_SIZE; }
+        const int m = (int)chunk;
+        const int nchunks = (int)((o1 - a0 + chunk - 1) / chunk);
+        int Q = 8;                                 // sub-chunks of sweep 1: about 2048 samples each
+        while (Q > 1 && (m % (16 * Q) != 0 || m / Q < 2048)) Q >>= 1;
+        const int ms = m / Q;
+        const int nsub = (int)((o1 - a0 + (size_t)ms - 1) / (size_t)ms);
+        const int w1 = std::min(warm, LP_WARM);
+        R28CHK(d, d->lvplane.ensure((size_t)nchunks * (size_t)m));
+        R28CHK(d, d->st_begin.ensure((size_t)nsub));
+        R28CHK(d, d->st_end.ensure((size_t)nsub));
+        R28CHK(d, d->st_prev.ensure((size_t)nsub));
+        R28CHK(d, d->flags.ensure((size_t)std::max(nsub, nchunks)));
+        R28CHK(d, d->lv_begin.ensure((size_t)nchunks));
+        R28CHK(d, d->lv_end.ensure((size_t)nchunks));
+        R28CHK(d, d->lv_prev.ensure((size_t)nchunks));
+        const int ncp = m / FOLLOW_CK + 1;
+        R28CHK(d, d->ckpt.ensure((size_t)nchunks * (size_t)ncp));
+        auto any_bad = [&](int &nbad) -> int {
             R28CHK(d, hipMemcpyAsync(&nbad, d->counters.p, sizeof(int), hipMemcpyDeviceToHost, st));
             R28CHK(d, hipStreamSynchronize(st));
+            return NTSCSIM_OK;
+        };
+        // sweep 1: the low-passes
+        const unsigned lp_blocks = (unsigned)(((nchunks + 63) / 64) * Q);
+        hipLaunchKernelGGL(k_raw28_lp, dim3(lp_blocks), dim3(64), 0, st, raw, a0, o1, m, ms, Q, w1, nchunks, nsub, d->K.alpha,
+                           (const FrontState *)d->st_a0.p, (lvpair *)d->lvplane.p, d->st_begin.p, d->st_end.p,
+                           (const FrontState *)nullptr, (const int *)nullptr);
+        for (;;) {
+            R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_raw28_links, dim3((nsub + 255) / 256), dim3(256), 0, st, d->st_begin.p, d->st_end.p,
+                               nsub, d->flags.p, d->counters.p);
+            int nbad = 0;
+            { const int rc = any_bad(nbad); if (rc != NTSCSIM_OK) return rc; }
             if (nbad == 0) break;
             d->stats[0]++; d->stats[1] += nbad;
-            // repair round: flagged chunks restart from their predecessor's end state as it is NOW
-            R28CHK(d, hipMemcpyAsync(d->st_prev.p, d->st_end.p, (size_t)nchunks * sizeof(FrontState), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_raw28_front, dim3((nchunks + FRONT_WG - 1) / FRONT_WG), dim3(FRONT_WG), 0, st, raw, N, d->h.p, o0, chunk, warm,
-                               nchunks, d->K, d->front_state, d->st_begin.p, d->st_end.p, (const FrontState *)d->st_prev.p,
-                               (const int *)d->flags.p);
+            // repair round: flagged sub-chunks restart from their predecessor's end state as it is NOW
+            R28CHK(d, hipMemcpyAsync(d->st_prev.p, d->st_end.p, (size_t)nsub * sizeof(FrontState), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_raw28_lp, dim3(lp_blocks), dim3(64), 0, st, raw, a0, o1, m, ms, Q, w1, nchunks, nsub, d->K.alpha,
+                               (const FrontState *)d->st_a0.p, (lvpair *)d->lvplane.p, d->st_begin.p, d->st_end.p,
+                               (const FrontState *)d->st_prev.p, (const int *)d->flags.p);
         }
-        // the exact state after the last sample: where the next push starts
-        R28CHK(d, hipMemcpyAsync(&d->front_state, d->st_end.p + (nchunks - 1), sizeof(FrontState), hipMemcpyDeviceToHost, st));
+        // sweep 2: the follower
+        const unsigned fw_blocks = (unsigned)((nchunks + 63) / 64);
+        const size_t pin = d->front_pin && fw_blocks <= 256 ? FOLLOW_PIN_LDS : 0;
+        if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_follow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
+        hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), pin, st, (const lvpair *)d->lvplane.p, a0, o1, m, warm, nchunks,
+                           d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p, d->lv_end.p, d->ckpt.p, ncp,
+                           (const double *)nullptr, (const int *)nullptr);
+        for (;;) {
+            R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_raw28_links1, dim3((nchunks + 255) / 256), dim3(256), 0, st, (const double *)d->lv_begin.p,
+                               (const double *)d->lv_end.p, nchunks, d->flags.p, d->counters.p);
+            int nbad = 0;
+            { const int rc = any_bad(nbad); if (rc != NTSCSIM_OK) return rc; }
+            if (nbad == 0) break;
+            d->stats[0]++; d->stats[1] += nbad;
+            R28CHK(d, hipMemcpyAsync(d->lv_prev.p, d->lv_end.p, (size_t)nchunks * sizeof(double), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), 0, st, (const lvpair *)d->lvplane.p, a0, o1, m, warm, nchunks,
+                               d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p, d->lv_end.p, d->ckpt.p, ncp,
+                               (const double *)d->lv_prev.p, (const int *)d->flags.p);
+        }
+        // the exact state after the last sample: where the next segment / push starts
+        FrontState fin;
+        double fin_level = 0;
+        R28CHK(d, hipMemcpyAsync(&fin, d->st_end.p + (nsub - 1), sizeof(FrontState), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipMemcpyAsync(&fin_level, d->lv_end.p + (nchunks - 1), sizeof(double), hipMemcpyDeviceToHost, st));
         R28CHK(d, hipStreamSynchronize(st));
-        d->front_done = N;
+        fin.level = fin_level;
+        d->front_state = fin;
+        d->front_done = o1;
     }
 
     lap(6);
