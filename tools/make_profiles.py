@@ -142,7 +142,7 @@ rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- pyth
 rd += "| `%s_bench_driver_cmd.json`, `%s_variant_sweeps.txt` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...`; `tools/sweep_times.py` | the driver's own window; wave-clock share of the YUV422P kernel's sweeps |\n" % (tag, tag)
 rd += "| `%s_decode_experiments.txt` | A/B builds (`tools/build_variants.sh`), `NTSCSIM_DEBUG_DECODE`, `--inflight` | what was tried on the dominant kernel this round and did not pay |\n" % tag
 rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_r03.sh` | one-off parity sweeps on the final build (random switch sets, the YUV422P family at random geometry, full size, raw captures) |\n" % tag
-rd += "| `%s_composite_range.txt`, `%s_raw28_front_pmc.txt` | `tools/comp_range_probe.py`; `rocprofv3 --pmc ... tools/raw28_probe.py` | value range of the composite plane (why it cannot be 16 bits wide); counters of the raw-composite front end (a lone wave issues one instruction per 8 cycles) |\n" % (tag, tag)
+rd += "| `%s_composite_range.txt`, `%s_raw28_front_pmc.txt` | `tools/comp_range_probe.py`; `tools/pmc_raw28.sh` | value range of the composite plane (why it cannot be 16 bits wide); counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront (`tools/pmc_raw28.sh`, `tools/follow_probe.hip`) |\n" % (tag, tag)
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (

@@ -23,6 +23,8 @@ if [ "$mode" = gpu ]; then
   ( export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/ks_${tag}_raw28; mkdir -p $O; cd /tmp;
     timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ks -- python $R/tools/raw28_probe.py > $O/probe.log 2>&1 < /dev/null;
     f=$(find $O -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv )
+  timeout 300 bash tools/pmc_raw28.sh gpurun_out/raw28_front_pmc_$tag.txt > /dev/null 2>&1
+  timeout 60 tools/bin/follow_probe > gpurun_out/follow_probe_$tag.txt 2>&1
   tail -c 600 gpurun_out/bench_$tag.json; tail -c 400 gpurun_out/bench_${tag}_tocomp.json
 else
   S=composite-video-simulator_amd/csrc
@@ -38,5 +40,6 @@ else
       gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
       gpurun_out/pmc422_$tag > /dev/null && echo "profiles/ assembled"
   [ -s gpurun_out/ks_${tag}_raw28/kernel_stats.csv ] && cp gpurun_out/ks_${tag}_raw28/kernel_stats.csv profiles/${tag}_kernel_stats_raw28.csv
+  [ -s gpurun_out/raw28_front_pmc_$tag.txt ] && { cat gpurun_out/raw28_front_pmc_$tag.txt; echo; echo "tools/follow_probe.hip (one follower step of a lone wavefront, from registers):"; grep -E "wave\(s\)|workgroup" gpurun_out/follow_probe_$tag.txt; } > profiles/${tag}_raw28_front_pmc.txt
   [ -s gpurun_out/bench_${tag}_driver_cmd.json ] && cp gpurun_out/bench_${tag}_driver_cmd.json profiles/${tag}_bench_driver_cmd.json
 fi
