@@ -15,7 +15,9 @@
 //      from their predecessor's end state, round after round, until every link holds.  At the
 //      fixed point chunk 0 started from the tool's initial state and every later chunk from the
 //      true state before it: the whole stream is the serial result.  (Worst case = as many rounds
-//      as chunks, i.e. the serial algorithm.)
+//      as chunks, i.e. the serial algorithm.)  The low-passes (which forget their state within a
+//      thousand samples) and the follower are run as two such sweeps, see "the front end as two
+//      sweeps" below.
 //  (2) The sync search of composite_layer() :622-693, :789-830 walks runs of "below threshold"
 //      samples.  The runs are extracted on the GPU (count | scan | scatter); the walk itself is a
 //      few hundred scalar steps per field over that run list and stays on the host, together with
@@ -110,16 +112,16 @@ __device__ __forceinline__ int front_step(FrontState &s, const FrontConst &K, do
 //
 // Sweep 1 (k_raw28_lp): the three low-passes, one lane per sub-chunk, warm-up of w1 samples from a guess
 // (state = the first sample), the link of every sub-chunk to its predecessor checked bitwise and repaired as
-// described at the top.  Its output, the fp64 lv of every sample, goes to a plane in HBM that is TRANSPOSED:
-// LV[t][c] = lv(a0 + c m + t).  All lanes of a wavefront (64 consecutive chunks, same sub-chunk number) are at
-// the same t at the same time, so every store is one contiguous 512-byte piece.
+// described at the top.  Its output, the fp64 lv of every sample, goes to a plane in HBM that is TRANSPOSED, as
+// sample pairs: LV2[t / 2][c] = lv of the samples a0 + c m + t, t + 1.  All lanes of a wavefront (64 consecutive
+// chunks, same sub-chunk number) are at the same t at the same time, so every store is one contiguous 1 KiB piece.
 // Sweep 2 (k_raw28_follow): the follower alone, one lane per chunk, `warm` samples of warm-up from 255.  Lane
 // c walks down its own column after the last rows of the columns before it; the lanes of a wavefront are
-// again at the same row at the same time, in consecutive columns: every load is one contiguous 512-byte
-// piece, requested two blocks of eight rows ahead.  The follower's chain is 9 instructions per sample against
+// again at the same row at the same time, in consecutive columns: every load is one contiguous 1 KiB piece,
+// five blocks of 16 samples in flight per lane.  The follower's chain is 7 instructions per sample against
 // the 23 of low-passes + follower, and the low-passes are no longer recomputed during the (46 times longer)
-// follower warm-up: that is the whole gain (18.7 ms -> see DESIGN.md section 7b), the run of one lane being a
-// single dependent chain whatever is done.
+// follower warm-up: that is the whole gain (18.7 ms -> 6.7 ms), the run of one lane being
+// a single dependent chain whatever is done.
 __device__ __forceinline__ double lp3_step(double &p0, double &p1, double &p2, double alpha, double x)
 {
     double lv = (x * alpha) + (p0 - (p0 * alpha)); p0 = lv;            // LowpassFilter::lowpass :92-96
