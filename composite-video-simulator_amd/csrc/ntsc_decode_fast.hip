@@ -134,6 +134,17 @@ struct PoleHp<float> {
 // C `/ 4` (truncating) for |n| < 2^30: the two top bits of a negative n are 11
 DEV int sdiv4s(int n) { return (n + (int)((unsigned)n >> 30)) >> 2; }
 
+// (c * 50) / subcarrier_amplitude_back, ffmpeg_ntsc.cpp:1544-1546 (C division: truncating, odd in c), for an
+// amplitude other than 50 (the pre-emphasis presets raise it): magnitude through the 31-bit magic multiplier,
+// sign put back with a mask.  |c| * 50 < 2^31 for every composite sample the encoder can make.
+DEV int scale_back50(int c, unsigned mul, unsigned shift)
+{
+    const int sg = c >> 31;
+    const unsigned a = (unsigned)((c ^ sg) - sg) * 50u;
+    const int q = (int)(__umulhi(a, mul) >> shift);
+    return (q ^ sg) - sg;
+}
+
 // ------------------------------------------------------------------ Y/C separation, raw windows
 // chroma_from_luma (ffmpeg_ntsc.cpp:1497-1567) with the half-cycle flip (:1539-1542) applied when
 // a sample is picked instead of when it is stored.  Valid for EVEN scanline phase xi in {0, 2}:
@@ -153,11 +164,13 @@ struct DemodR {
     }
     // steady state: every position inside the row.  ODD = x is odd; NEGS = 0 / -1 (x = 1 / 3 mod 4)
     // as a compile-time (NEG >= 0) or wave-uniform (sneg) value; hi = lane mask of xi == 2.
-    template <bool ODD, int NEG, bool LUMA>
-    DEV void push(int ct, bool hi, int sneg, int &Yo, int &Io, int &Qo)
+    // BK: the chroma sample is scaled by 50 / subcarrier_amplitude_back (bmul, bshift: its magic multiplier)
+    template <bool ODD, int NEG, bool LUMA, bool BK = false>
+    DEV void push(int ct, bool hi, int sneg, int &Yo, int &Io, int &Qo, unsigned bmul = 0, unsigned bshift = 0)
     {
         const int yb = sdiv4s(csum + ct);
-        const int ch = ct - yb;
+        int ch = ct - yb;
+        if (BK) ch = scale_back50(ch, bmul, bshift);
         csum = csum - c0 + ct;
         c0 = c1; c1 = c2; c2 = ct;
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
@@ -175,10 +188,13 @@ struct DemodR {
         }
     }
     // any position (row ends, pipeline fill and drain); t is wave-uniform, xi per lane
-    DEV void push_edge(int ct, int t, unsigned xi, bool hi, int W, int xe, int &Yo, int &Io, int &Qo)
+    template <bool BK = false>
+    DEV void push_edge(int ct, int t, unsigned xi, bool hi, int W, int xe, int &Yo, int &Io, int &Qo,
+                       unsigned bmul = 0, unsigned bshift = 0)
     {
         const int yb = sdiv4(c0 + c1 + c2 + ct);
-        const int ch = ct - yb;
+        int ch = ct - yb;
+        if (BK) ch = scale_back50(ch, bmul, bshift);
         csum = c1 + c2 + ct;
         c0 = c1; c1 = c2; c2 = ct;
         w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = ch;
@@ -219,9 +235,11 @@ struct State {
 
 // per-lane / per-launch constants.  WR: the head-switch displacement may wrap around the 1.1 W window
 // (address fix-up per load, see cs_load)
-template <class RT, bool WR = false>
+template <class RT, bool WR = false, bool BK = false>
 struct Const {
     static constexpr bool wraps = WR;
+    static constexpr bool back = BK;
+    unsigned bmul, bshift;    // BK: magic multiplier of subcarrier_amplitude_back
     int wrapoff;              // WR: byte offset of the wrapped index, -tw or +tw samples (sign of the shift)
     int wrapA, wrapS;         // WR: x wraps iff ((wrapA - x) ^ wrapS) < 0
     unsigned xi;
@@ -294,7 +312,7 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
 {
     constexpr bool odd1 = ((DP + J) & 1) != 0;
     int Yd, U, V;
-    S.D1.template push<odd1, -1, false>(pc, C.hi, sneg1, Yd, U, V);
+    S.D1.template push<odd1, -1, false, CT::back>(pc, C.hi, sneg1, Yd, U, V, C.bmul, C.bshift);
     // chroma noise :1719-1735
     U += S.nU; V += S.nV;
     S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
@@ -339,7 +357,7 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *
 {
     int Y, U, V;
     if constexpr (!VHS) {
-        S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(pc, C.hi, 0, Y, U, V);
+        S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true, CT::back>(pc, C.hi, 0, Y, U, V, C.bmul, C.bshift);
     } else {
         const int c2 = vcr_step<DP, J, RT, CT>(P, S, C, ring, pc, pl, sneg1);
         // ... and separate again at x3
@@ -365,7 +383,7 @@ DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
     const int W = C.W;
     const int pc = t < W ? cs_load(C, t) : 0;             // t is wave-uniform
     int Y, U, V;
-    S.D1.push_edge(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+    S.D1.template push_edge<CT::back>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
     const int x1 = t - 7;
     const bool in1 = x1 >= 0 && x1 < W;
     int fU = 0, fV = 0;
@@ -428,7 +446,7 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
         x3 = x2 - 7;
     } else {
         const int pc = t < W ? cs_load(C, t) : 0;         // t is wave-uniform
-        S.D1.push_edge(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+        S.D1.template push_edge<CT::back>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
     }
     if (x3 < 0 || x3 > W) return false;
     const bool in3 = x3 < W;
@@ -562,18 +580,14 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
 #define NTSC_FAST_WAVES 2
 #endif
 // WR (VHS form only): head-switch displacements beyond W/10 samples, e.g. PAL's 312.5-line field with
-// the default switching point (see cs_load)
-template <bool VHS, class RT, bool WR = false>
-__global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(DevParams P, GeomDev G,
-                                                     const FieldDev *__restrict__ fields,
-                                                     const int *__restrict__ comp,
-                                                     const uint32_t *__restrict__ rs_chroma,
-                                                     const int *__restrict__ n0_u,
-                                                     const int *__restrict__ n0_v,
-                                                     const int *__restrict__ hs_shift,
-                                                     const int *__restrict__ pn_noise,
-                                                     const int *__restrict__ dropout,
-                                                     int *__restrict__ tails)
+// the default switching point (see cs_load).  BK: subcarrier_amplitude_back other than 50 (the pre-emphasis
+// presets -comp-catv* raise it), see scale_back50.
+template <bool VHS, class RT, bool WR, bool BK>
+DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
+                          const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
+                          const int *__restrict__ n0_u, const int *__restrict__ n0_v,
+                          const int *__restrict__ hs_shift, const int *__restrict__ pn_noise,
+                          const int *__restrict__ dropout, int *__restrict__ tails)
 {
     using namespace fastdec;
     __shared__ uint32_t ring[31 * 64];
@@ -599,8 +613,9 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
     const size_t tcol = (size_t)blockIdx.x * 64 + lane;
     const size_t tstride = (size_t)gridDim.x * 64;
 
-    typedef Const<RT, WR> CT;
+    typedef Const<RT, WR, BK> CT;
     CT C;
+    C.bmul = P.m_amp_back.mul; C.bshift = P.m_amp_back.shift;
     C.xi = scan_phase(P, y, fd.fieldno);
     C.hi = (C.xi & 2u) != 0;
     C.W = W;
@@ -681,6 +696,37 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
             for (int q = xb; q <= xo; q++) ((g_u32_ptr)drow)[q] = ostage[lane * 20 + (q - xb)];
         }
     }
+}
+
+template <bool VHS, class RT, bool WR = false>
+__global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(DevParams P, GeomDev G,
+                                                     const FieldDev *__restrict__ fields,
+                                                     const int *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rs_chroma,
+                                                     const int *__restrict__ n0_u,
+                                                     const int *__restrict__ n0_v,
+                                                     const int *__restrict__ hs_shift,
+                                                     const int *__restrict__ pn_noise,
+                                                     const int *__restrict__ dropout,
+                                                     int *__restrict__ tails)
+{
+    decode_fast_body<VHS, RT, WR, false>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
+}
+
+// the same for a subcarrier_amplitude_back other than 50 (one form per preset: the VHS one takes the wrap-around loads)
+template <bool VHS, class RT>
+__global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast_bk(DevParams P, GeomDev G,
+                                                     const FieldDev *__restrict__ fields,
+                                                     const int *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rs_chroma,
+                                                     const int *__restrict__ n0_u,
+                                                     const int *__restrict__ n0_v,
+                                                     const int *__restrict__ hs_shift,
+                                                     const int *__restrict__ pn_noise,
+                                                     const int *__restrict__ dropout,
+                                                     int *__restrict__ tails)
+{
+    decode_fast_body<VHS, RT, VHS, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
 }
 
 // =============================================================================== k_vcr_front

@@ -34,6 +34,7 @@ struct EState {
     LaneRand rng;
 #endif
     int noise;
+    OnePoleT<RT> pre;     // PRE: the pre-emphasis high-pass :1610-1623
 };
 
 template <class RT>
@@ -42,6 +43,7 @@ struct EConst {
     int W, lane;
     int mL, mNL;          // -1 / 0 masks of (xi == 2) and its complement
     RT a_i, a_q;
+    RT a_pre, pre_gain;   // PRE
     __amdgpu_buffer_rsrc_t comp;
     int vcol;             // byte offset of this lane's column
     int rowbytes;
@@ -61,7 +63,16 @@ DEV void rgb_to_yiq256(uint32_t px, RT &dY, RT &Id, RT &Qd)
 // One steady-state step at unrolled position J of a 16-pixel chunk starting at t0 = 0 (mod 4):
 // consumes pixel t = t0 + J, emits composite sample x = t - 4 = J (mod 4).
 //   Yx = 256 * luma of pixel x, I2 = filtered I pushed two steps ago (index x).
-template <int J, class RT>
+// composite pre-emphasis :1610-1623 (the -comp-catv* presets), as in enc_step of ntsc_kernels.hip
+template <class RT>
+DEV int preemphasis(EState<RT> &S, const EConst<RT> &C, int Y)
+{
+    RT sd = (RT)Y;
+    sd += S.pre.hp(sd, C.a_pre) * C.pre_gain;
+    return (int)sd;
+}
+
+template <int J, class RT, bool PRE>
 DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
              RT Id, RT Qd, int Yx, int I2, int &fI_out)
 {
@@ -72,6 +83,7 @@ DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *r
     const int chroma = (J & 1) ? fQ : I2;
     const int mm = (J & 2) ? C.mNL : C.mL;
     int Y = Yx + ((chroma ^ mm) - mm);
+    if (PRE) Y = preemphasis<RT>(S, C, Y);
     // luma noise :1632-1644
     Y += S.noise;
     S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
@@ -79,7 +91,7 @@ DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *r
 }
 
 // One guarded step at any stream position t (wave-uniform): row start, row end, filter tails.
-template <class RT>
+template <class RT, bool PRE>
 DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
                    const uint32_t *srow, int t)
 {
@@ -103,6 +115,7 @@ DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint3
     int chroma = (s & 1u) ? Q1 : I1;
     if (s & 2u) chroma = -chroma;
     int Y = Yx + chroma;
+    if (PRE) Y = preemphasis<RT>(S, C, Y);
     Y += S.noise;
     S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
     __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)((unsigned)x * (unsigned)C.rowbytes), 0);
@@ -166,11 +179,9 @@ struct CoopLoader {
 
 } // namespace fastenc
 
-template <class RT>
-__global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev *__restrict__ fields,
-                                                    const uint32_t *__restrict__ rs_luma,
-                                                    const int *__restrict__ n0_luma,
-                                                    int *__restrict__ comp)
+template <class RT, bool PRE>
+DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ fields, const uint32_t *__restrict__ rs_luma,
+                          const int *__restrict__ n0_luma, int *__restrict__ comp)
 {
     using namespace fastenc;
     __shared__ uint32_t ring[31 * 64];
@@ -199,6 +210,7 @@ __global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev 
     C.mL = opaque_v((C.xi & 2u) ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
     C.a_i = (RT)P.a_in_i; C.a_q = (RT)P.a_in_q;
+    C.a_pre = (RT)P.a_pre; C.pre_gain = (RT)P.pre_gain;
     C.rowbytes = P.Rpad * 4;
     C.vcol = rho * 4;                  // rho < Rpad: lanes past the last row own padding columns
     C.comp = __builtin_amdgcn_make_buffer_rsrc(comp, 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
@@ -207,13 +219,14 @@ __global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev 
     S.rng.init(ring, rs_luma + rc, P.Rpad, lane);
     S.noise = n0_luma[rc];
     S.lpI.reset(0, C.a_i); S.lpQ.reset(0, C.a_q);
+    S.pre.p = 16;
 #pragma unroll
     for (int q = 0; q < 4; q++) { S.Yd[q] = 0; S.Ir[q] = 0; S.Qr[q] = 0; }
     S.fI[0] = S.fI[1] = 0;
 
     // ---------------- row start: pixels 0..3 fill the 4-sample look-ahead of the Q low-pass
     int t = 0;
-    for (; t < 4; t++) edge_step<RT>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < 4; t++) edge_step<RT, PRE>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
     // ---------------- steady state: 16-pixel chunks strictly inside the row
     if (t + 16 <= W) {
 #ifndef NTSC_ENC_NOCOOP
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev 
                 rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
-                const int Y = step<J, RT>(P, S, C, ring, Id_, Qd_, YX, IX, F[J]);                 \
+                const int Y = step<J, RT, PRE>(P, S, C, ring, Id_, Qd_, YX, IX, F[J]);                 \
                 __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
@@ -284,7 +297,26 @@ __global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev 
         for (int q = 0; q < 4; q++) { S.Ir[q] = (int)IdT[q]; S.Qr[q] = (int)QdT[q]; }
     }
     // ---------------- row end + drain
-    for (; t < W + 4; t++) edge_step<RT>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < W + 4; t++) edge_step<RT, PRE>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+}
+
+template <class RT>
+__global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev *__restrict__ fields,
+                                                    const uint32_t *__restrict__ rs_luma,
+                                                    const int *__restrict__ n0_luma,
+                                                    int *__restrict__ comp)
+{
+    encode_fast_body<RT, false>(P, fields, rs_luma, n0_luma, comp);
+}
+
+// the same with composite pre-emphasis (ffmpeg_ntsc.cpp:1614-1629; the -comp-catv* presets)
+template <class RT>
+__global__ __launch_bounds__(64) void k_encode_fast_pre(DevParams P, const FieldDev *__restrict__ fields,
+                                                        const uint32_t *__restrict__ rs_luma,
+                                                        const int *__restrict__ n0_luma,
+                                                        int *__restrict__ comp)
+{
+    encode_fast_body<RT, true>(P, fields, rs_luma, n0_luma, comp);
 }
 
 } // namespace ntscsim

@@ -624,12 +624,20 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     const bool hs_small = head_switch_is_small(D, W);
     const int hs_mode = !D.hs ? 0 : (hs_small ? 1 : 2);
     const bool small_plane = fast_plane_ok((size_t)D.Rpad, W, hs_mode);
+    // the same with composite pre-emphasis (the -comp-catv* presets): k_encode_fast_pre<RT>
+    const bool enc_preset_pre = !c->force_generic && D.in_lp && D.pre_on && D.noise_k != 0 && D.amp == 50;
     if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
         // hand-tuned encoder of the presets (ntsc_encode_fast.hip)
         note_kernel(c, fast ? "k_encode_fast<float>" : "k_encode_fast<double>");
         if (fast) hipLaunchKernelGGL((k_encode_fast<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
                                      fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
         else hipLaunchKernelGGL((k_encode_fast<double>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                                fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    } else if (enc_preset_pre && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
+        note_kernel(c, fast ? "k_encode_fast_pre<float>" : "k_encode_fast_pre<double>");
+        if (fast) hipLaunchKernelGGL((k_encode_fast_pre<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                                     fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+        else hipLaunchKernelGGL((k_encode_fast_pre<double>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
                                 fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
     } else if (enc_preset) { if (fast) NTSC_LAUNCH_ENCODE(F_LNOISE, float); else NTSC_LAUNCH_ENCODE(F_LNOISE, double); }
     else { if (fast) NTSC_LAUNCH_ENCODE(F_GENERIC, float); else NTSC_LAUNCH_ENCODE(F_GENERIC, double); }
@@ -644,8 +652,11 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         dec_in = c->comp_ghost.p;
     }
     if (evs) HIPCHK(c, hipEventRecord(evs->e[2], st));
-    const bool dec_common = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50 &&
-                            D.amp_back == 50;
+    // (the hand-tuned decoder also exists for a subcarrier_amplitude_back other than 50 -- what the pre-emphasis
+    // presets set -- as its BK forms; the template forms of the generic kernel fold (c * 50) / 50 away)
+    const bool back50 = D.amp_back == 50;
+    const bool dec_base = !c->force_generic && !D.nocolor && D.out_lp == 1 && D.amp == 50;
+    const bool dec_common = dec_base && back50;
 #define NTSC_LAUNCH_DECODE_RT(VHS, CO, F, RT)                                                   \
     do { note_kernel(c, ("k_decode<" #VHS "," #CO "," + std::to_string((unsigned)(F)) + "u," #RT ">").c_str()); \
     hipLaunchKernelGGL((k_decode<VHS, CO, F, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev,     \
@@ -657,10 +668,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     // hand-tuned decoder of the two presets (ntsc_decode_fast.hip) when its preconditions hold
     // (the one-launch VHS form also exists with wrap-around head-switch loads; every other fast form
     // needs the displacement to stay within W/10 samples)
-    const bool dec_fast = dec_common && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane;
+    const bool dec_fast = dec_base && (back50 || D.amp_back >= 2) && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane;
 #define NTSC_LAUNCH_FAST(VHS, RT)                                                                \
     do { note_kernel(c, "k_decode_fast<" #VHS "," #RT ">");                                      \
     hipLaunchKernelGGL((k_decode_fast<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
+                       c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
+                       c->dropout.p, c->tails.p); } while (0)
+#define NTSC_LAUNCH_FAST_BK(VHS, RT)                                                             \
+    do { note_kernel(c, "k_decode_fast_bk<" #VHS "," #RT ">");                                   \
+    hipLaunchKernelGGL((k_decode_fast_bk<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
 #define NTSC_LAUNCH_FAST_WR(RT)                                                                  \
@@ -668,7 +684,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_decode_fast<true, RT, true>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
-    if (dec_fast && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
+    if (dec_fast && back50 && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
         // VCR half -> second composite plane -> TV half (= the non-VHS decoder without head switching)
         HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
         note_kernel(c, fast ? "k_vcr_front<float>" : "k_vcr_front<double>");
@@ -688,15 +704,22 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
                                 tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                 c->pn_noise.p, c->dropout.p, c->tails.p);
-    } else if (dec_fast && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
+    } else if (dec_fast && back50 && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(true, float); else NTSC_LAUNCH_FAST(true, double);
-    } else if (dec_fast && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
+    } else if (dec_fast && back50 && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST_WR(float); else NTSC_LAUNCH_FAST_WR(double);
-    } else if (dec_fast && hs_small && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
+    } else if (dec_fast && !back50 && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k &&
+               fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0)) {
+        // (one form for both displacement ranges: the wrap-around loads cost a sign test per load)
+        if (fast) NTSC_LAUNCH_FAST_BK(true, float); else NTSC_LAUNCH_FAST_BK(true, double);
+    } else if (dec_fast && back50 && hs_small && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(false, float); else NTSC_LAUNCH_FAST(false, double);
+    } else if (dec_fast && !back50 && hs_small && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
+        if (fast) NTSC_LAUNCH_FAST_BK(false, float); else NTSC_LAUNCH_FAST_BK(false, double);
     } else
 #undef NTSC_LAUNCH_FAST
 #undef NTSC_LAUNCH_FAST_WR
+#undef NTSC_LAUNCH_FAST_BK
     if (!D.vhs) {
         if (dec_common && !D.cnoise_k && !D.pnoise_k) NTSC_LAUNCH_DECODE(false, false, 0u);
         else NTSC_LAUNCH_DECODE(false, false, F_GENERIC);

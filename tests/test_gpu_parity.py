@@ -326,6 +326,9 @@ def test_preset_and_generic_kernels_agree(flags, w, h):
     (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32, 2),
     # preconditions of the hand-tuned kernels NOT met -> they must fall back, results unchanged
     (["-vhs", "-comp-phase-offset", "1"], 96, 32, 0), (["-vhs", "-comp-phase", "90"], 96, 32, 0),
+    # the pre-emphasis presets (subcarrier_amplitude_back != 50): k_encode_fast_pre + k_decode_fast_bk
+    (["-vhs", "-comp-catv"], 96, 32, 3), (["-vhs", "-comp-catv2"], 96, 32, 3), (["-vhs", "-comp-catv4"], 64, 38, 3),
+    (["-vhs", "-comp-catv3", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32, 3),
 ])
 def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
     """The hand-tuned kernels (ntsc_encode_fast.hip / ntsc_decode_fast.hip, one- and two-launch VHS
@@ -355,8 +358,12 @@ def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
         sim.close()
         assert np.array_equal(got, e), mode
         dec = [k for k in ran if k.startswith(("k_decode", "k_vcr_front"))]
-        if mode == "generic":
+        if mode == "generic" or (fast_ok == 3 and mode == "template"):
+            # (with an amplitude other than 50 the template forms, which fold (c * 50) / 50 away, do not apply)
             assert len(dec) == 1 and dec[0].startswith("k_decode<") and dec[0].endswith(",1u,double>"), (mode, ran)
+        elif fast_ok == 3:
+            assert dec == ["k_decode_fast_bk<true,double>"], (mode, ran)
+            assert "k_encode_fast_pre<double>" in ran, ran
         elif mode == "template" or not fast_ok:
             # the template PRESET forms (every case here keeps the presets' filter switches; what the
             # not-fast_ok cases break is only a precondition of the hand-tuned kernels)
