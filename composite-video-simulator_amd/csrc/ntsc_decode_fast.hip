@@ -235,10 +235,11 @@ struct State {
 
 // per-lane / per-launch constants.  WR: the head-switch displacement may wrap around the 1.1 W window
 // (address fix-up per load, see cs_load)
-template <class RT, bool WR = false, bool BK = false>
+template <class RT, bool WR = false, bool BK = false, bool SV = false>
 struct Const {
     static constexpr bool wraps = WR;
     static constexpr bool back = BK;
+    static constexpr bool svideo = SV;     // VHS form with S-Video out: no re-modulation, no second separation
     unsigned bmul, bshift;    // BK: magic multiplier of subcarrier_amplitude_back
     int wrapoff;              // WR: byte offset of the wrapped index, -tw or +tw samples (sign of the shift)
     int wrapA, wrapS;         // WR: x wraps iff ((wrapA - x) ^ wrapS) < 0
@@ -306,9 +307,10 @@ DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
 // The VCR half of a steady step (VHS form): first demodulator at x1 = t - 7, chroma noise, phase
 // noise, VHS chroma / luma filters, vertical blend, re-modulation.  Returns the composite sample
 // the VCR puts out at x2 = x1 - d (ffmpeg_ntsc.cpp:1716-1888).
+// (Yv, Uv, Vv: the same signal as components, what the VCR's S-Video connector carries.)
 template <int DP, int J, class RT, class CT>
 DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *ring,
-                 int pc, int pl, int sneg1)
+                 int pc, int pl, int sneg1, int &Yv, int &Uv, int &Vv)
 {
     constexpr bool odd1 = ((DP + J) & 1) != 0;
     int Yd, U, V;
@@ -339,6 +341,7 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
     // second row, untouched for its first row / blend off (mask, carry and shift all 0)
     U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
     V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
+    Yv = Y; Uv = U; Vv = V;
     // composite out of the VCR :1885-1888: modulate at x2 (amplitude 50: (v*50)/50 == v)
     const int chroma = (J & 1) ? V : U;
     const int mm = (J & 2) ? C.mNL : C.mL;
@@ -359,9 +362,14 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *
     if constexpr (!VHS) {
         S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true, CT::back>(pc, C.hi, 0, Y, U, V, C.bmul, C.bshift);
     } else {
-        const int c2 = vcr_step<DP, J, RT, CT>(P, S, C, ring, pc, pl, sneg1);
-        // ... and separate again at x3
-        S.D2.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(c2, C.hi, 0, Y, U, V);
+        int Yv, Uv, Vv;
+        const int c2 = vcr_step<DP, J, RT, CT>(P, S, C, ring, pc, pl, sneg1, Yv, Uv, Vv);
+        if constexpr (CT::svideo) {
+            Y = Yv; U = Uv; V = Vv;                // -vhs-svideo: the components go on as they are :1885
+        } else {
+            // ... and separate again at x3
+            S.D2.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(c2, C.hi, 0, Y, U, V);
+        }
     }
     // dropout :1891-1901
     U &= C.dm; V &= C.dm;
@@ -378,7 +386,7 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *
 // The VCR half of a guarded step: returns the VCR's composite sample at x2 = t - 7 - d (0 outside
 // the row).
 template <class RT, class CT>
-DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *ring, int t)
+DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *ring, int t, int &Yv, int &Uv, int &Vv)
 {
     const int W = C.W;
     const int pc = t < W ? cs_load(C, t) : 0;             // t is wave-uniform
@@ -423,7 +431,9 @@ DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
     U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;
     V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
     int c2 = 0;
+    Yv = 0; Uv = 0; Vv = 0;
     if (in2) {
+        Yv = Y; Uv = U; Vv = V;
         const unsigned s = (C.xi + (unsigned)x2) & 3u;
         int chroma = (s & 1u) ? V : U;
         if (s & 2u) chroma = -chroma;
@@ -440,10 +450,16 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
     int Y, U, V;
     int x3 = t - 7;
     if constexpr (VHS) {
-        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t);
+        int Yv, Uv, Vv;
+        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t, Yv, Uv, Vv);
         const int x2 = t - 7 - C.d;
-        S.D2.push_edge(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
-        x3 = x2 - 7;
+        if constexpr (CT::svideo) {
+            Y = Yv; U = Uv; V = Vv;
+            x3 = x2;
+        } else {
+            S.D2.push_edge(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
+            x3 = x2 - 7;
+        }
     } else {
         const int pc = t < W ? cs_load(C, t) : 0;         // t is wave-uniform
         S.D1.template push_edge<CT::back>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
@@ -480,7 +496,8 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     const int SKT = C.SKT, LOFF = C.LOFF, lane = C.lane;
     if (t + 4 > t_end) return t;
     // sign of the first demodulator's picks: x1 = t - 7 = d + J (mod 4); negated iff x1 = 3 (mod 4)
-    const int dph = C.d & 3;
+    // (S-Video form: the pipeline is 7 stages shorter, SKT = 8 + d, so x1 = t - 7 = d + 1 + J (mod 4))
+    const int dph = (C.d + (CT::svideo ? 1 : 0)) & 3;
     const int sn0 = opaque_s(((dph + 0) & 3) == 3 ? -1 : 0), sn1 = opaque_s(((dph + 1) & 3) == 3 ? -1 : 0),
               sn2 = opaque_s(((dph + 2) & 3) == 3 ? -1 : 0), sn3 = opaque_s(((dph + 3) & 3) == 3 ? -1 : 0);
     // samples in flight per stream: one unrolled iteration
@@ -582,7 +599,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
 // WR (VHS form only): head-switch displacements beyond W/10 samples, e.g. PAL's 312.5-line field with
 // the default switching point (see cs_load).  BK: subcarrier_amplitude_back other than 50 (the pre-emphasis
 // presets -comp-catv* raise it), see scale_back50.
-template <bool VHS, class RT, bool WR, bool BK>
+template <bool VHS, class RT, bool WR, bool BK, bool SV = false>
 DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
                           const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                           const int *__restrict__ n0_u, const int *__restrict__ n0_v,
@@ -613,7 +630,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     const size_t tcol = (size_t)blockIdx.x * 64 + lane;
     const size_t tstride = (size_t)gridDim.x * 64;
 
-    typedef Const<RT, WR, BK> CT;
+    typedef Const<RT, WR, BK, SV> CT;
     CT C;
     C.bmul = P.m_amp_back.mul; C.bshift = P.m_amp_back.shift;
     C.xi = scan_phase(P, y, fd.fieldno);
@@ -622,7 +639,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     C.xe = (W & 1) ? W - 1 : W - 2;
     C.lane = lane;
     C.d = VHS ? P.cdelay : 0;
-    C.SKT = VHS ? 15 + C.d : 8;
+    C.SKT = VHS ? (CT::svideo ? 8 : 15) + C.d : 8;
     C.LOFF = 5 + C.d;
     C.mL = opaque_v(C.hi ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
@@ -677,7 +694,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
         (void)edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo);
     }
     // ---------------- steady state: 4 pixels per iteration, ends 16 samples before the row end
-    if (C.d & 1) t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
+    if ((C.d + (CT::svideo ? 1 : 0)) & 1) t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
     else t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
     // ---------------- row end, filter tails, pipeline drain
     for (; t < total; t++) {
@@ -727,6 +744,23 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast_b
                                                      int *__restrict__ tails)
 {
     decode_fast_body<VHS, RT, VHS, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
+}
+
+// the -vhs preset with S-Video out (-vhs-svideo 1): the VCR's components go to the TV stages directly, no
+// re-modulation and no second separation; 7 pipeline stages fewer (wrap-around loads: any displacement)
+template <class RT>
+__global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_sv(DevParams P, GeomDev G,
+                                                     const FieldDev *__restrict__ fields,
+                                                     const int *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rs_chroma,
+                                                     const int *__restrict__ n0_u,
+                                                     const int *__restrict__ n0_v,
+                                                     const int *__restrict__ hs_shift,
+                                                     const int *__restrict__ pn_noise,
+                                                     const int *__restrict__ dropout,
+                                                     int *__restrict__ tails)
+{
+    decode_fast_body<true, RT, true, false, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
 }
 
 // =============================================================================== k_vcr_front
@@ -818,7 +852,8 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     const unsigned rb = (unsigned)C.rowbytes;
     int t = 0;
     // ---------------- pipeline fill (no output: x2 < 0)
-    for (; t < SK1 && t < total; t++) (void)vcr_edge<RT, CT>(P, S, C, ring, t);
+    int yv_, uv_, vv_;                 // (components: only the S-Video form of the one-launch kernel uses them)
+    for (; t < SK1 && t < total; t++) (void)vcr_edge<RT, CT>(P, S, C, ring, t, yv_, uv_, vv_);
     // ---------------- steady state
     {
         const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
@@ -832,7 +867,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
             unsigned soff = (unsigned)(t - SK1) * rb;
 #define NTSC_VCR_STEP(DPV, J)                                                                     \
             {                                                                                     \
-                const int c2 = vcr_step<DPV, J, RT, CT>(P, S, C, ring, pc[J], pl[J], sn##J);      \
+                const int c2 = vcr_step<DPV, J, RT, CT>(P, S, C, ring, pc[J], pl[J], sn##J, yv_, uv_, vv_); \
                 pc[J] = cs_load(C, t + 4 + J);        /* reloaded right after its step consumed it */ \
                 pl[J] = cs_load(C, t + 4 + J - LOFF);                                             \
                 __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
@@ -850,7 +885,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     }
     // ---------------- row end, filter tails, drain
     for (; t < total; t++) {
-        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t);
+        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t, yv_, uv_, vv_);
         const int x2 = t - SK1;
         if (x2 >= 0) __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)((unsigned)x2 * rb), 0);
     }

@@ -712,6 +712,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0)) {
         // (one form for both displacement ranges: the wrap-around loads cost a sign test per load)
         if (fast) NTSC_LAUNCH_FAST_BK(true, float); else NTSC_LAUNCH_FAST_BK(true, double);
+    } else if (dec_fast && back50 && D.vhs && D.svideo && D.cnoise_k && D.pnoise_k &&
+               fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0)) {
+        note_kernel(c, fast ? "k_decode_fast_sv<float>" : "k_decode_fast_sv<double>");
+        if (fast) hipLaunchKernelGGL((k_decode_fast_sv<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                                     c->dropout.p, c->tails.p);
+        else hipLaunchKernelGGL((k_decode_fast_sv<double>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                                c->dropout.p, c->tails.p);
     } else if (dec_fast && back50 && hs_small && !D.vhs && !D.cnoise_k && !D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(false, float); else NTSC_LAUNCH_FAST(false, double);
     } else if (dec_fast && !back50 && hs_small && !D.vhs && !D.cnoise_k && !D.pnoise_k) {

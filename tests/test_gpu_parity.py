@@ -329,6 +329,9 @@ def test_preset_and_generic_kernels_agree(flags, w, h):
     # the pre-emphasis presets (subcarrier_amplitude_back != 50): k_encode_fast_pre + k_decode_fast_bk
     (["-vhs", "-comp-catv"], 96, 32, 3), (["-vhs", "-comp-catv2"], 96, 32, 3), (["-vhs", "-comp-catv4"], 64, 38, 3),
     (["-vhs", "-comp-catv3", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32, 3),
+    # S-Video out of the VCR: k_decode_fast_sv (no re-modulation / second separation, 7 stages fewer)
+    (["-vhs", "-vhs-svideo", "1"], 96, 32, 4), (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "ep"], 96, 32, 4),
+    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "lp"], 100, 38, 4), (["-tvstd", "pal", "-vhs", "-vhs-svideo", "1"], 96, 36, 4),
 ])
 def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
     """The hand-tuned kernels (ntsc_encode_fast.hip / ntsc_decode_fast.hip, one- and two-launch VHS
@@ -364,6 +367,10 @@ def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
         elif fast_ok == 3:
             assert dec == ["k_decode_fast_bk<true,double>"], (mode, ran)
             assert "k_encode_fast_pre<double>" in ran, ran
+        elif fast_ok == 4 and mode == "template":
+            assert dec == ["k_decode<true,false,1u,double>"], (mode, ran)
+        elif fast_ok == 4:
+            assert dec == ["k_decode_fast_sv<double>"], (mode, ran)
         elif mode == "template" or not fast_ok:
             # the template PRESET forms (every case here keeps the presets' filter switches; what the
             # not-fast_ok cases break is only a precondition of the hand-tuned kernels)

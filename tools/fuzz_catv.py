@@ -1,5 +1,6 @@
-"""Developer tool (GPU box): the pre-emphasis family of the BGRA tool (k_encode_fast_pre + k_decode_fast_bk)
-against the oracle at full size, seeded random members:  python tools/fuzz_catv.py 0 60"""
+"""Developer tool (GPU box): the pre-emphasis family of the BGRA tool (k_encode_fast_pre + k_decode_fast_bk), or its
+S-Video family (k_decode_fast_sv), against the oracle at full size, seeded random members:
+    python tools/fuzz_catv.py 0 60 [svideo]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
@@ -7,15 +8,16 @@ import numpy as np, ntscsim
 import cases
 import _libs as L
 s0, n = int(sys.argv[1]), int(sys.argv[2])
+family = sys.argv[3] if len(sys.argv) > 3 else "catv"
 t0, bad, forms = time.time(), [], {}
 for seed in range(s0, s0 + n):
     r = random.Random(70000 + seed)
-    f = ["-vhs", r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"])]
+    f = ["-vhs", r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"])] if family == "catv" else ["-vhs", "-vhs-svideo", "1"]
     if r.random() < 0.3: f = ["-tvstd", "pal"] + f
     if r.random() < 0.5: f += ["-vhs-speed", r.choice(["sp", "lp", "ep"])]
     if r.random() < 0.4: f += ["-noise", str(r.randint(1, 9))]
     if r.random() < 0.4: f += ["-chroma-noise", str(r.randint(1, 9))]
-    if r.random() < 0.3: f += ["-vhs-head-switching-point", "%.4f" % r.uniform(0.0, 0.12), "-vhs-head-switching-phase", "%.4f" % r.uniform(0.0, 0.01)]
+    if r.random() < 0.3: f += ["-vhs-head-switching-point", "%.4f" % r.uniform(0.001, 0.12), "-vhs-head-switching-phase", "%.4f" % r.uniform(0.0005, 0.01)]
     if r.random() < 0.2: f += ["-vhs-chroma-vblend", "0"]
     if r.random() < 0.2: f += ["-chroma-dropout", str(r.randint(2, 9))]
     pal = "pal" in f
@@ -34,7 +36,7 @@ for seed in range(s0, s0 + n):
     if not np.array_equal(got, want):
         bad.append((seed, f))
     sim.close()
-print("pre-emphasis family at full size: %d random members x 2 fields in %.0f s, %d failures" % (n, time.time() - t0, len(bad)))
+print(("pre-emphasis" if family == "catv" else "S-Video") + " family at full size: %d random members x 2 fields in %.0f s, %d failures" % (n, time.time() - t0, len(bad)))
 for k, v in sorted(forms.items(), key=lambda kv: -kv[1]):
     print("  %4d x %s" % (v, " + ".join(k)))
 for b in bad[:8]:

@@ -10,6 +10,8 @@ echo '$ python tools/fuzz_fullsize.py 5000 1500   # 720x486 / 720x480, random sw
 timeout 900 python tools/fuzz_fullsize.py 5000 1500 2>&1 | tail -3
 echo '$ python tools/fuzz_catv.py 1000 1500      # the BGRA tool'"'"'s pre-emphasis family at full size (k_encode_fast_pre + k_decode_fast_bk), forms listed'
 timeout 900 python tools/fuzz_catv.py 1000 1500 2>&1 | grep -v amdgpu.ids | tail -4
+echo '$ python tools/fuzz_catv.py 3000 1500 svideo   # the -vhs -vhs-svideo 1 family at full size (k_decode_fast_sv)'
+timeout 900 python tools/fuzz_catv.py 3000 1500 svideo 2>&1 | grep -v amdgpu.ids | tail -4
 echo '$ python tools/fuzz_raw28.py 5000 1000      # raw-composite decoder: random captures / switch sets / crippled speculation'
 timeout 900 python tools/fuzz_raw28.py 5000 1000 2>&1 | tail -3
 } > $O 2>&1
