@@ -21,7 +21,7 @@ fcall = ("  One field per synchronous `ntscsim_field()` call (the 1:1 drop-in on
 cli = ("  The raw-file CLI `ntsc_cli -vhs -i bars:3000 -o null:` runs at %.0fk fields/s (`end_to_end.cli`)." % (e["cli"] / 1e3)) if e.get("cli") else ""
 new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` preset, exact mode; every figure is\n"
        "a key of `profiles/%s_bench.json`, the line `python bench.py` prints; `profiles/README.md` maps the\n"
-       "rest; box-to-box spread ≈ ±4 %: 733k-790k for `value` on ten boxes%):\n"
+       "rest; box-to-box spread ≈ ±4 %%: 733k-790k for `value` on ten boxes):\n"
        "`value` **%dk fields/s** over %d steps with four steps in flight, `value_sustained` **%dk** over\n"
        "0.5 s (round 2: 729k, round 1: 542k).  CPU beside it on the GPU box's host: the reference's own `composite_layer()`\n"
        "(`oracle/_ref`, single-threaded like the tool) %.0f fields/s, our C port %.0f fields/s on one core and\n"
