@@ -490,13 +490,10 @@ __device__ __forceinline__ int equalised(const uint8_t *raw, const uint8_t *h, s
 
 // tail(y) from the last 32 positions of the scanline and tail(y-1): the 16 values the tool leaves in
 // int_chroma[len .. len+15] (:744-745 applied to int_chroma[len-16 .. len-1])
-__global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
-                              const LineRec *__restrict__ lines, int nlines, RenderConst R,
-                              const int *__restrict__ tin, int *__restrict__ tout, int *__restrict__ nchanged)
+// tail(y) = G(samples of scanline y, tail(y - 1)), :719-745 restricted to the 16 values that survive the scanline
+__device__ __forceinline__ void raw28_tail_of(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
+                                              const LineRec &L, const RenderConst &R, const int (&prev)[16], int (&out)[16])
 {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= nlines) return;
-    const LineRec L = lines[y];
     const int len = R.len;
     int S[20], C[32];                              // S: positions len-16 .. len+3; C: len-16 .. len+15
 #pragma unroll
@@ -504,21 +501,67 @@ __global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__
 #pragma unroll
     for (int k = 0; k < 16; k++) C[k] = S[k] - (S[k] + S[k + 4] + 1) / 2;     // :731-734
 #pragma unroll
-    for (int k = 0; k < 16; k++) C[16 + k] = tin[((ptrdiff_t)y - 1) * 16 + k];     // (row -1: the tail carried in, 0 at a stream's start)
+    for (int k = 0; k < 16; k++) C[16 + k] = prev[k];
 #pragma unroll
     for (int k = 0; k < 16; k++) C[k] = C[k] + C[k + 8] - C[k + 4] - C[k + 12];   // :736-737 (ascending, in place)
 #pragma unroll
     for (int it = 0; it < 4; it++)
 #pragma unroll
         for (int k = 0; k < 16; k++) C[k] -= (C[k] + C[k + 4]) / 2;                // :739-742
+#pragma unroll
+    for (int k = 0; k < 16; k++) out[k] = C[k] / 4;                                // :744-745
+}
+
+// One round of the fixed-point iteration: tout(y) = G(y, tin(y - 1)) for every scanline at once; counts the
+// scanlines whose value differs from the previous round's.  (Row -1 of the arrays: the tail carried in, 0 at a
+// stream's start.)
+__global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
+                              const LineRec *__restrict__ lines, int nlines, RenderConst R,
+                              const int *__restrict__ tin, int *__restrict__ tout, int *__restrict__ nchanged)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= nlines) return;
+    int prev[16], v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) prev[k] = tin[((ptrdiff_t)y - 1) * 16 + k];
+    raw28_tail_of(raw, h, N, lines[y], R, prev, v);
     int ch = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int v = C[k] / 4;                                                    // :744-745
-        ch |= (tin[(size_t)y * 16 + k] != v);      // against this scanline's value of the previous round
-        tout[(size_t)y * 16 + k] = v;
+        ch |= (tin[(size_t)y * 16 + k] != v[k]);   // against this scanline's value of the previous round
+        tout[(size_t)y * 16 + k] = v[k];
     }
     if (ch) atomicAdd(nchanged, 1);
+}
+
+// A first guess that is almost always the fixed point already: every thread walks TAIL_WU scanlines of warm-up
+// from a zero tail (the map divides what it inherits by 8 on the way through, so a tail forgets its
+// predecessors within a few scanlines; a walk that reaches row -1 starts from the carried tail, exactly) and
+// then its own TAIL_B scanlines serially.  2.5 rounds' worth of work in one launch instead of ~16 rounds; the
+// rounds of k_raw28_tails that follow confirm it (a round that changes nothing) or finish the job.
+constexpr int TAIL_B = 16, TAIL_WU = 24;
+__global__ void k_raw28_tails_scan(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
+                                   const LineRec *__restrict__ lines, int nlines, RenderConst R,
+                                   const int *__restrict__ carried, int *__restrict__ ta, int *__restrict__ tb)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = j * TAIL_B;
+    if (y0 >= nlines) return;
+    const int ys = y0 - TAIL_WU;
+    int T[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) T[k] = ys <= 0 ? carried[k] : 0;
+    const int ye = y0 + TAIL_B < nlines ? y0 + TAIL_B : nlines;
+    for (int y = ys < 0 ? 0 : ys; y < ye; y++) {
+        int v[16];
+        raw28_tail_of(raw, h, N, lines[y], R, T, v);
+#pragma unroll
+        for (int k = 0; k < 16; k++) T[k] = v[k];
+        if (y >= y0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { ta[(size_t)y * 16 + k] = v[k]; tb[(size_t)y * 16 + k] = v[k]; }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
@@ -641,6 +684,7 @@ struct ntscsim_raw28 {
     FrontConst K;
     FrontState init;
     bool chunk_forced = false;
+    bool tail_scan = true;         // comb tails: serial first guess before the rounds (NTSCSIM_RAW28_NOTAILSCAN=1: developer A/B switch)
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
     int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)
@@ -781,6 +825,7 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.om_slow = 1.0 - d->K.a_slow;
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
+    if (const char *e = std::getenv("NTSCSIM_RAW28_NOTAILSCAN")) d->tail_scan = std::atoi(e) == 0;
     if (const char *e = std::getenv("NTSCSIM_RAW28_CHUNKS")) { const int v = std::atoi(e); if (v >= 64) d->max_chunks = v; }
     *out = d;
     return NTSCSIM_OK;
@@ -1166,11 +1211,15 @@ static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_devi
             R28CHK(d, hipMemcpyAsync(d->tails_a.p, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
             R28CHK(d, hipMemcpyAsync(d->tails_b.p, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
             int *tin = d->tails_a.p + 16, *tout = d->tails_b.p + 16;
+            if (d->tail_scan)
+                hipLaunchKernelGGL(k_raw28_tails_scan, dim3(((nlines + TAIL_B - 1) / TAIL_B + 63) / 64), dim3(64), 0, st, raw, d->h.p, N,
+                                   d->lines.p, nlines, RC, (const int *)d->tails_a.p, tin, tout);
             for (int round = 0;;) {
                 // round r: tout(y) = G(samples of y, tin(y-1)); it ends when tout == tin everywhere, i.e.
                 // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = the carried tail: the serial result.
                 // Four rounds are enqueued between two looks at the counter of the last one.
-                for (int b4 = 0; b4 < 4; b4++, round++) {
+                const int batch = (round == 0 && d->tail_scan) ? 1 : 4;      // (after the scan one round usually confirms)
+                for (int b4 = 0; b4 < batch; b4++, round++) {
                     R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
                     hipLaunchKernelGGL(k_raw28_tails, dim3((nlines + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
                                        nlines, RC, (const int *)tin, tout, d->counters.p);

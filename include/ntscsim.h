@@ -534,7 +534,7 @@ int  ntscsim_raw28_stream_push(ntscsim_raw28 *dec, const void *samples, size_t n
 int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *white, uint64_t *read_pos);
 /* Test hooks.  warm-up scanlines of the speculative front end (default 112; 0 forces every chunk
  * through the exact repair rounds) and chunk size in samples (default 4096); results must not
- * change.  stats: [0] front-end repair rounds, [1] chunks repaired, [2] comb-tail rounds,
+ * change.  stats: [0] front-end repair rounds, [1] chunks repaired, [2] comb-tail rounds (after the serial first guess: 1 when it was the fixed point),
  * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call; [6..11] wall-clock
  * microseconds of its phases: front end, run extraction, sync walk, level calibration, comb tails
  * (incl. clearing the frames), rendering; [12] calibration pulses whose sums ran past the buffered
