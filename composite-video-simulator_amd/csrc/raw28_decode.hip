@@ -687,6 +687,7 @@ struct ntscsim_raw28 {
     bool tail_scan = true;         // comb tails: serial first guess before the rounds (NTSCSIM_RAW28_NOTAILSCAN=1: developer A/B switch)
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
+    size_t front_seg = FRONT_SEG;  // samples per front-end segment (NTSCSIM_RAW28_SEG: test hook, the segment loop on small captures)
     int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)
     // decoder state: levels (:553-554), stream position; kept from push to push of a stream
     double blank = 0, white = 192;
@@ -826,6 +827,7 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOTAILSCAN")) d->tail_scan = std::atoi(e) == 0;
+    if (const char *e = std::getenv("NTSCSIM_RAW28_SEG")) { const long long v = std::atoll(e); if (v >= 4096) d->front_seg = (size_t)v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_CHUNKS")) { const int v = std::atoi(e); if (v >= 64) d->max_chunks = v; }
     *out = d;
     return NTSCSIM_OK;
@@ -934,7 +936,7 @@ static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_devi
     // plane between the two sweeps is 8 bytes per sample)
     const int warm = (int)(((size_t)d->warm_lines * len + 15) & ~(size_t)15);
     while (N > d->front_done) {
-        const size_t o0 = d->front_done, o1 = std::min(N, o0 + FRONT_SEG), fresh = o1 - o0;
+        const size_t o0 = d->front_done, o1 = std::min(N, o0 + d->front_seg), fresh = o1 - o0;
         const size_t a0 = (o0 + 15) & ~(size_t)15;
         R28CHK(d, d->st_a0.ensure(1));
         hipLaunchKernelGGL(k_raw28_head, dim3(1), dim3(64), 0, st, raw, d->h.p, o0, std::min(a0, o1), d->K, d->front_state, d->st_a0.p);

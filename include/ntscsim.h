@@ -539,7 +539,11 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * microseconds of its phases: front end, run extraction, sync walk, level calibration, comb tails
  * (incl. clearing the frames), rendering; [12] calibration pulses whose sums ran past the buffered
  * stream, [13] never-filled records among them; [14] compactions of the device buffer (streams),
- * [15] the most samples the device buffer ever held.  Counters accumulate over the pushes of a stream. */
+ * [15] the most samples the device buffer ever held.  Counters accumulate over the pushes of a stream.
+ * Environment (read by ntscsim_raw28_create, developer / test switches; results never depend on them):
+ * NTSCSIM_RAW28_SEG = samples the front end takes per segment (default 2^29: 8 bytes of scratch per sample),
+ * NTSCSIM_RAW28_CHUNKS = chunk count of its second sweep on long streams, NTSCSIM_RAW28_NOTAILSCAN = 1: comb
+ * tails by rounds only. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
 void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */

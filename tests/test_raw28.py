@@ -200,6 +200,23 @@ def test_hip_front_end_equals_oracle_and_repairs_are_exact():
 
 
 @pytest.mark.gpu
+def test_hip_front_end_in_segments(monkeypatch):
+    """The front end works through at most 2^29 new samples at a time (8 bytes of fp64 plane per sample); with the
+    segment shrunk by its test hook the loop over segments runs on a small capture: odd segment sizes, segments
+    shorter than the warm-up, one that leaves fewer than 16 samples for the last segment -- same bytes, same frames."""
+    capture = L.raw28_capture(3, 21, 3, 777)
+    h, _ = L.raw28_oracle_front(L.raw28_oracle_opts(), capture)
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    for seg in (1000003, 65537, capture.size - 5, 4096):
+        monkeypatch.setenv("NTSCSIM_RAW28_SEG", str(seg))
+        got, lv2, st, dec = _hip_run([], capture)
+        assert np.array_equal(dec.read_front(capture.size), h), seg
+        assert np.array_equal(got, want) and lv2 == lv, seg
+        dec.close()
+    monkeypatch.delenv("NTSCSIM_RAW28_SEG")
+
+
+@pytest.mark.gpu
 def test_hip_reproduces_reference_hashes():
     gold = json.load(open(GOLD))
     for key, want in gold.items():
