@@ -475,17 +475,22 @@ struct RenderConst {
     int mark, no_equ, no_wequ, no_sc, show_sc;
     unsigned long long base;       // stream position of sample 0 of the buffer
 };
-__device__ __forceinline__ int equalised(const uint8_t *raw, const uint8_t *h, size_t N, const LineRec &L,
-                                         const RenderConst &R, int x)
+// black / white level equalisation of one sample value v = 0 .. 255 (:708-710)
+__device__ __forceinline__ int equalise_value(int v, const LineRec &L, const RenderConst &R)
 {
-    const size_t s = (size_t)L.pos + (size_t)x;
-    int v = s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark, R.base) : 0;     // int16 luma = raw :702
     if (!R.no_equ) {
         v = (int)((double)v - L.blank);                                 // :708
         if (!R.no_wequ) v = (int)((double)(v * 255) / (L.white - L.blank));   // :709
         v = (int)(int16_t)v;                                            // :710 (int16 member)
     }
     return v;
+}
+__device__ __forceinline__ int equalised(const uint8_t *raw, const uint8_t *h, size_t N, const LineRec &L,
+                                         const RenderConst &R, int x)
+{
+    const size_t s = (size_t)L.pos + (size_t)x;
+    const int v = s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark, R.base) : 0;     // int16 luma = raw :702
+    return equalise_value(v, L, R);
 }
 
 // tail(y) from the last 32 positions of the scanline and tail(y-1): the 16 values the tool leaves in
@@ -571,10 +576,18 @@ __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict_
 {
     extern __shared__ int lds[];
     const int len = R.len, n = len + 16;
-    int *S = lds, *A = lds + n, *B2 = lds + 2 * n;
+    int *S = lds, *A = lds + n;
     const int y = blockIdx.x;
     const LineRec L = lines[y];
-    for (int x = threadIdx.x; x < n; x += 256) S[x] = equalised(raw, h, N, L, R, x);
+    // a sample is one of 256 values and the levels are the scanline's: the equalisation (an fp64 division per
+    // sample, :708-710) is evaluated once per VALUE, by the workgroup's 256 threads, and looked up per sample
+    int *lut = lds + 2 * n;
+    lut[threadIdx.x] = equalise_value((int)threadIdx.x, L, R);
+    __syncthreads();
+    for (int x = threadIdx.x; x < n; x += 256) {
+        const size_t s = (size_t)L.pos + (size_t)x;
+        S[x] = lut[s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark, R.base) : 0];
+    }
     __syncthreads();
     uint32_t *dst = (uint32_t *)(frames + (size_t)L.field * frame_stride + (size_t)L.row * (size_t)linesize);
     if (R.no_sc) {
@@ -585,17 +598,40 @@ __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict_
         }
         return;
     }
-    for (int x = threadIdx.x; x < n; x += 256)
-        A[x] = x < len ? S[x] - (S[x] + S[x + 4] + 1) / 2 : tails[((ptrdiff_t)y - 1) * 16 + (x - len)];
-    __syncthreads();
-    for (int x = threadIdx.x; x < n; x += 256) B2[x] = x < len ? A[x] + A[x + 8] - A[x + 4] - A[x + 12] : A[x];
-    __syncthreads();
-    int *in = B2, *out = A;
-    for (int it = 0; it < 4; it++) {
-        for (int x = threadIdx.x; x < n; x += 256) out[x] = x < len ? in[x] - (in[x] + in[x + 4]) / 2 : in[x];
-        __syncthreads();
-        int *t = in; in = out; out = t;
+    // The comb :731-742 only ever combines samples 4 apart, so the scanline is four interleaved sequences; a thread
+    // takes eight consecutive positions of one of them (x = r + 4 j) through all six stages in registers, reading
+    // the 16 samples that reach them from the LDS once -- two barriers per scanline instead of seven.
+    //   A(x) = x < len ? S[x] - (S[x] + S[x + 4] + 1) / 2 : tail of the scanline before (x - len)        :731-734
+    //   B(x) = x < len ? A(x) + A(x + 8) - A(x + 4) - A(x + 12) : A(x)                                  :736-737
+    //   C(x) = x < len ? C(x) - (C(x) + C(x + 4)) / 2 : C(x), four times                                :739-742
+    // (every read of a position below len stays below n = len + 16; what lies past n feeds nothing)
+    {
+        const int r = threadIdx.x & 3, q = threadIdx.x >> 2;
+        const int *tl = tails + ((ptrdiff_t)y - 1) * 16;
+        for (int j0 = q * 8; r + 4 * j0 < n; j0 += 64 * 8) {
+            int v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) { const int x = r + 4 * (j0 + i); v[i] = x < n ? S[x] : 0; }
+            int tv[16];                            // tail values where the window reaches past len
+#pragma unroll
+            for (int i = 0; i < 16; i++) { const int x = r + 4 * (j0 + i); tv[i] = (x >= len && x < n) ? tl[x - len] : 0; }
+            // A: 15 values
+#pragma unroll
+            for (int i = 0; i < 15; i++) { const int x = r + 4 * (j0 + i); v[i] = x < len ? v[i] - (v[i] + v[i + 1] + 1) / 2 : tv[i]; }
+            // B: 12 values
+#pragma unroll
+            for (int i = 0; i < 12; i++) { const int x = r + 4 * (j0 + i); v[i] = x < len ? v[i] + v[i + 2] - v[i + 1] - v[i + 3] : v[i]; }
+            // C: 11, 10, 9, 8 values
+#pragma unroll
+            for (int it = 0; it < 4; it++)
+#pragma unroll
+                for (int i = 0; i < 11 - it; i++) { const int x = r + 4 * (j0 + i); v[i] = x < len ? v[i] - (v[i] + v[i + 1]) / 2 : v[i]; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int x = r + 4 * (j0 + i); if (x < n) A[x] = v[i]; }
+        }
     }
+    __syncthreads();
+    const int *in = A;
     // `in` = int_chroma before the shift :744; final chroma[x] = x < 16 ? in[x] : in[x - 16] / 4
     for (int x = threadIdx.x; x < R.width; x += 256) {
         int Y;
@@ -1240,7 +1276,7 @@ static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_devi
         }
         R28CHK(d, hipStreamSynchronize(st));
         lap(10);
-        const size_t lds = (size_t)3 * (len + 16) * sizeof(int);
+        const size_t lds = ((size_t)2 * (len + 16) + 256) * sizeof(int);
         hipLaunchKernelGGL(k_raw28_render, dim3((unsigned)nlines), dim3(256), lds, st, raw, d->h.p, N, d->lines.p, RC,
                            (const int *)tails, (uint8_t *)frames_dev, frame_stride, linesize);
     }
