@@ -122,6 +122,75 @@ def test_hip_equals_oracle_on_random_parameters(seed):
     sim.close()
 
 
+# The BGRA tool's hand-tuned families beside the two presets: -vhs with pre-emphasis (-comp-catv*: k_encode_fast_pre +
+# k_decode_fast_bk) and -vhs with S-Video out (k_decode_fast_sv), random tape speed / PAL / noise levels / head-switch
+# point / blend / dropout -- the draws of tools/fuzz_catv.py at small sizes with 16-byte aligned rows.
+N_BGRA_FAMILY = 48
+
+
+def draw_bgra_family(seed):
+    r = random.Random(90000 + seed)
+    sv = seed % 3 == 2
+    f = ["-vhs", "-vhs-svideo", "1"] if sv else ["-vhs", r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"])]
+    if r.random() < 0.3: f = ["-tvstd", "pal"] + f
+    if r.random() < 0.5: f += ["-vhs-speed", r.choice(["sp", "lp", "ep"])]
+    if r.random() < 0.4: f += ["-noise", str(r.randint(1, 9))]
+    if r.random() < 0.4: f += ["-chroma-noise", str(r.randint(1, 9))]
+    if r.random() < 0.3: f += ["-vhs-head-switching-point", "%.4f" % r.uniform(0.001, 0.12), "-vhs-head-switching-phase", "%.4f" % r.uniform(0.0005, 0.01)]
+    if r.random() < 0.2: f += ["-vhs-chroma-vblend", "0"]
+    if r.random() < 0.2: f += ["-chroma-dropout", str(r.randint(2, 9))]
+    w = r.choice([16, 32, 64, 96, 100, 128, 132])          # (4 w is a multiple of 16: the hand-tuned kernels' rows)
+    h = r.choice([2, 3, 7, 16, 31, 32, 38, 40])
+    n = r.randrange(1, 5)
+    kind = r.choice(["noise", "noise", "bars", "ramp"])
+    if kind == "ramp" and (w < 4 or h < 3):
+        kind = "noise"
+    return f, w, h, n, kind, ("k_decode_fast_sv<double>" if sv else "k_decode_fast_bk<true,double>")
+
+
+@pytest.mark.skipif(not L.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("seed", range(N_BGRA_FAMILY))
+def test_bgra_family_oracle_equals_reference(seed):
+    f, w, h, n, kind, _ = draw_bgra_family(seed)
+    p = L.make_params(f)
+    srcs = [cases.make_source(kind, w, h, j + seed) for j in range((n + 1) // 2)]
+    o, r = L.OracleStream(p), L.RefStream(p)
+    do = np.full((h, w, 4), 9, np.uint8)
+    dr = np.full((h, w, 4), 9, np.uint8)
+    for (si, field, fieldno) in cases.case_jobs(n):
+        if field >= h:
+            continue
+        r.field(dr, srcs[si], field, fieldno, 0, 0)
+        o.field(do, srcs[si], field, fieldno, 0, 0)
+        assert np.array_equal(do, dr), (f, w, h, fieldno)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(N_BGRA_FAMILY))
+def test_hip_bgra_family_equals_oracle(seed):
+    """the same draws on the GPU; the hand-tuned form the launcher must pick is asserted by name"""
+    import torch
+    import ntscsim
+    f, w, h, n, kind, form = draw_bgra_family(seed)
+    p = L.make_params(f)
+    srcs = [cases.make_source(kind, w, h, j + seed) for j in range((n + 1) // 2)]
+    o = L.OracleStream(p)
+    want = np.full((h, w, 4), 9, np.uint8)
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.full((1, h, w, 4), 9, dtype=torch.uint8, device="cuda")
+    for (si, field, fieldno) in cases.case_jobs(n):
+        if field >= h:
+            continue
+        o.field(want, srcs[si], field, fieldno, 0, 0)
+        sim.fields(src, dst, [(si, 0, field, fieldno)])
+        sim.sync()
+        assert np.array_equal(dst[0].cpu().numpy(), want), (f, w, h, fieldno)
+        assert form in sim.last_kernels(), (f, sim.last_kernels())
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
 # ------------------------------------------------------------- 8-bit YUV422P variant ----------
 N_REF422 = 120
 N_GPU422 = 120
