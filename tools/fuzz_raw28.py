@@ -1,5 +1,6 @@
 """Developer tool (GPU box): the raw-composite decoder against its oracle on seeded random captures
-(fields, noise level, starting sample, truncation) and random switch sets:  python tools/fuzz_raw28.py 0 100"""
+(fields, noise level, starting sample, truncation) and random switch sets, speculation settings, front-end segment
+sizes and -- a third of the time -- as a stream pushed in random pieces:  python tools/fuzz_raw28.py 0 100"""
 import os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
@@ -18,11 +19,31 @@ for seed in range(s0, s0 + n):
         if r.random() < 0.25:
             kw[k] = 1; flags.append(f)
     want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(**kw), cap)
+    if r.random() < 0.25:
+        os.environ["NTSCSIM_RAW28_SEG"] = str(r.choice([4096, 65537, 300001, 1000003]))
+    else:
+        os.environ.pop("NTSCSIM_RAW28_SEG", None)
     dec = ntscsim.Raw28Decoder(flags)
     if r.random() < 0.3:
         dec.set_speculation(r.choice([0, 8, 40]), r.choice([1024, 8192, 65536]))
     fr = torch.empty((want.shape[0] + 2, dec.height, dec.width * 4), dtype=torch.uint8, device="cuda")
-    nf = dec.decode(cap, fr)
+    if r.random() < 0.33:                          # a stream: random pieces, everything a push yields is collected
+        dec.stream_reset()
+        pos, nf, ring = 0, 0, torch.empty_like(fr)
+        while True:
+            step = r.choice([1, 4097, 200003, 700001, 3000001])
+            piece = cap[pos:pos + step]
+            pos += piece.size
+            final = pos >= cap.size
+            k = dec.stream_push(piece if piece.size else None, ring, final=final)
+            fr[nf:nf + k] = ring[:k]
+            nf += k
+            while k == ring.shape[0]:              # (never here: the ring holds every field of the capture)
+                k = dec.stream_push(None, ring, final=final); fr[nf:nf + k] = ring[:k]; nf += k
+            if final:
+                break
+    else:
+        nf = dec.decode(cap, fr)
     got = fr[:nf].cpu().numpy()
     if got.shape != want.shape or not np.array_equal(got, want) or dec.levels() != lv:
         bad.append((seed, flags, got.shape, want.shape))
