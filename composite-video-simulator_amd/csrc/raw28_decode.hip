@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
             for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB], b + i + NB - 1); use(R[i], b + i); }
             if (repair && __all(done)) return;
         }
-        if (done) return;                          // (only repair rounds get here with `done` set by a comparison)
+        if (done) return;                          // (lanes without a chunk; repair rounds: runs that met the earlier one)
     }
     for (int t = nbf * FOLLOW_BLK; t < len; t++) {
         const lvpair pr = LV2[(size_t)(t >> 1) * ncols + (size_t)cc];
