@@ -142,6 +142,7 @@ rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- pyth
 rd += "| `%s_bench_driver_cmd.json`, `%s_variant_sweeps.txt` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...`; `tools/sweep_times.py` | the driver's own window; wave-clock share of the YUV422P kernel's sweeps |\n" % (tag, tag)
 rd += "| `%s_decode_experiments.txt` | A/B builds (`tools/build_variants.sh`), `NTSCSIM_DEBUG_DECODE`, `--inflight` | what was tried on the dominant kernel this round and did not pay |\n" % tag
 rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_r03.sh` | one-off parity sweeps on the final build (random switch sets, the YUV422P family at random geometry, full size, raw captures) |\n" % tag
+rd += "| `%s_clock_under_load.txt` | `tools/clock_probe.sh` | shader clock under the bench's sustained load (2.31-2.32 GHz against the 2.4 GHz of the VALU peak) |\n" % tag
 rd += "| `%s_composite_range.txt`, `%s_raw28_front_pmc.txt` | `tools/comp_range_probe.py`; `tools/pmc_raw28.sh` | value range of the composite plane (why it cannot be 16 bits wide); counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront (`tools/pmc_raw28.sh`, `tools/follow_probe.hip`) |\n" % (tag, tag)
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
