@@ -62,6 +62,8 @@ struct Geometry {
 
 } // namespace
 
+struct SubmitEngine;      // ntscsim_submit.hip (included at the end of this file)
+
 struct ntscsim_ctx {
     ntscsim_params prm;
     int device = 0;
@@ -133,7 +135,10 @@ struct ntscsim_ctx {
     bool no_fast_decode = false;     // debug: keep the PRESET template kernels (A/B against k_decode_fast)
     bool no_stream422 = false;       // debug: the YUV422P preset kernel as four sweeps instead of A + one streamed pass
     int mode = NTSCSIM_MODE_EXACT;
+    SubmitEngine *sub = nullptr;     // ntscsim_submit() / ntscsim_wait(): created on first use
 };
+static void submit_engine_destroy(ntscsim_ctx *c);
+static int sub_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
 
 #define HIPCHK(ctx, call)                                                              \
     do {                                                                               \
@@ -359,6 +364,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    submit_engine_destroy(c);
     for (Geometry *e : c->geoms) {
         e->lskip.release(); e->pskip.release(); e->jrow.release(); e->sstart.release(); e->jwarm.release();
         delete e;
@@ -397,8 +403,9 @@ extern "C" int ntscsim_sync(ntscsim_ctx *c)
 {
     if (!c) return NTSCSIM_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    const int rc = c->sub ? sub_wait_ticket(c, NTSCSIM_TICKET_ALL) : NTSCSIM_OK;   // fields in flight: deliver them
     HIPCHK(c, hipDeviceSynchronize());
-    return NTSCSIM_OK;
+    return rc;
 }
 
 extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4], int *n_calls)
@@ -1357,6 +1364,10 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     if (field > 1) return NTSCSIM_E_ARG;
     if (W < 16 || H < 2) return NTSCSIM_E_SIZE;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->sub) {     // submitted fields come first: same order of dst writes as the synchronous sequence
+        const int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
+        if (rc != NTSCSIM_OK) return rc;
+    }
     const size_t pitch = (((size_t)W * 4 + 255) / 256) * 256;
     HIPCHK(c, c->fsrc.ensure(pitch * H));
     HIPCHK(c, c->fdst.ensure(pitch * H));
@@ -1636,3 +1647,6 @@ extern "C" int ntscsim_debug_read_composite(ntscsim_ctx *c, int32_t *out, size_t
         for (size_t x = 0; x < W; x++) out[r * W + x] = tmp[x * Rpad + r];
     return NTSCSIM_OK;
 }
+
+// ---- asynchronous host-frame drop-in: ntscsim_submit() / ntscsim_wait()
+#include "ntscsim_submit.hip"

@@ -1,0 +1,541 @@
+// ntscsim_submit.hip -- the asynchronous host-frame form of the drop-in: ntscsim_submit() / ntscsim_wait()
+// (include/ntscsim.h).  Included by ntscsim_hip.hip (one translation unit).
+//
+// What it replaces: the call `composite_layer(ring[idx], in.rgb, in, (current&1)^1, current)` at
+// ffmpeg_ntsc.cpp:2229 when the caller keeps its loop (:2202-2282) and its AVFrames, but lets `depth`
+// fields be in flight.  Structure:
+//
+//   submit   src frame --DMA (s_up)--> device source ring          (once per frame: NTSCSIM_SUBMIT_SAME_SRC)
+//            field recorded in `pending`; at `depth` fields: launch
+//   launch   one lane (child ctx: own stream + scratch) runs the ordinary batched kernel chain
+//            (ntscsim_fields_device) on the pending fields, then k_deliver writes every field's rows from the
+//            device destination ring straight into the caller's pinned frames (or one linear D2H into the
+//            staging ring for frames that are not pinned); an event closes the launch
+//   wait     synchronise on the launch's event, copy staged rows out, retire the launch
+//
+// Lanes exist because a launch of 32 fields is ~125 wavefronts on a chip with 2,048 slots and takes the same
+// ~0.5 ms as one of 600: three launches side by side hide that latency.  Fields carry explicit rand()
+// positions, so it does not matter which lane runs which launch.
+#include <deque>
+
+namespace {
+
+struct DeliverRec {
+    const uint8_t *dev;       // device frame (row 0)
+    uint8_t *host;            // device-visible address of the caller's frame (row 0)
+    int32_t dev_pitch, host_pitch;
+    int32_t row0, row_step, nrows, _pad;
+};
+
+// One workgroup per (row chunk, field): copies rows row0, row0+row_step, ... of a device frame into the
+// caller's (pinned, device-mapped) frame.  Stores go over the host link; 16-byte stores when every address is
+// 16-byte aligned.
+__global__ void k_deliver(const DeliverRec *__restrict__ recs, int row_bytes, int vec16)
+{
+    const DeliverRec r = recs[blockIdx.y];
+    for (int k = blockIdx.x; k < r.nrows; k += gridDim.x) {
+        const size_t y = (size_t)r.row0 + (size_t)k * r.row_step;
+        const uint8_t *s = r.dev + y * (size_t)r.dev_pitch;
+        uint8_t *d = r.host + y * (size_t)r.host_pitch;
+        if (vec16) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+            uint4 *d4 = reinterpret_cast<uint4 *>(d);
+            for (int i = threadIdx.x; i < row_bytes / 16; i += blockDim.x) d4[i] = s4[i];
+        } else {
+            const uint32_t *s1 = reinterpret_cast<const uint32_t *>(s);
+            uint32_t *d1 = reinterpret_cast<uint32_t *>(d);
+            for (int i = threadIdx.x; i < row_bytes / 4; i += blockDim.x) d1[i] = s1[i];
+        }
+    }
+}
+
+} // namespace
+
+struct SubmitEngine {
+    ntscsim_submit_opts o;
+    bool configured = false;
+    int W = 0, H = 0;
+    size_t pitch = 0, fbytes = 0;
+    int nslots = 0;
+    DevBuf<uint8_t> dsrc, ddst;
+    uint8_t *hsrc = nullptr, *hdst = nullptr;         // pinned staging rings (lazy, nslots frames each)
+    DeliverRec *recs = nullptr;                       // pinned, device-visible: nslots records
+    hipStream_t s_up = nullptr;
+    hipEvent_t ev_up = nullptr;
+    std::vector<ntscsim_ctx *> lanes;
+    unsigned lane_next = 0;
+
+    struct Item {
+        uint64_t ticket;
+        int src_slot, dst_slot;
+        uint8_t *host_dst;        // caller's frame
+        uint8_t *host_dst_dev;    // its device-visible address when pinned, else NULL (staged)
+        int dst_ls;
+        unsigned field;
+        uint32_t flags;
+        uint64_t fieldno, rng_pos;
+    };
+    std::vector<Item> pending;
+    struct Batch {
+        uint64_t first = 0, last = 0;
+        hipEvent_t up = nullptr, done = nullptr;
+        std::vector<Item> items;
+        int rc = NTSCSIM_OK;
+        bool launched_ok = false;
+    };
+    std::deque<Batch> inflight;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    uint64_t next_ticket = 1;         // next to issue
+    uint64_t done_ticket = 0;         // everything <= this has been delivered
+    // source ring
+    int src_cur = -1;                 // slot holding the frame of the previous submit
+    uint64_t src_ring_pos = 0;
+    std::vector<uint64_t> src_last_ticket;    // last ticket that reads the slot
+    // registrations of caller memory
+    struct Reg { uintptr_t p0, p1; uint8_t *dev; bool owned; };
+    std::vector<Reg> regs;
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int sticky_rc = NTSCSIM_OK;
+};
+
+extern "C" void ntscsim_submit_opts_init(ntscsim_submit_opts *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
+    o->depth = 32;
+    o->slots = 128;
+    o->lanes = 3;
+    o->pin_caller_buffers = 1;
+    o->min_pin_bytes = 256u << 10;
+}
+
+static int sub_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
+static int sub_launch(ntscsim_ctx *c);
+
+static SubmitEngine *sub_get(ntscsim_ctx *c)
+{
+    if (!c->sub) {
+        c->sub = new (std::nothrow) SubmitEngine();
+        if (c->sub) ntscsim_submit_opts_init(&c->sub->o);
+    }
+    return c->sub;
+}
+
+static void sub_release_geometry(SubmitEngine *e)
+{
+    e->dsrc.release(); e->ddst.release();
+    if (e->hsrc) (void)hipHostFree(e->hsrc);
+    if (e->hdst) (void)hipHostFree(e->hdst);
+    if (e->recs) (void)hipHostFree(e->recs);
+    e->hsrc = e->hdst = nullptr; e->recs = nullptr;
+    e->W = e->H = 0; e->nslots = 0;
+    e->src_cur = -1;
+    e->src_last_ticket.clear();
+}
+
+// everything in flight must have been waited for
+static void sub_unpin_all(SubmitEngine *e)
+{
+    for (auto &r : e->regs)
+        if (r.owned) (void)hipHostUnregister((void *)r.p0);
+    e->regs.clear();
+    (void)hipGetLastError();
+}
+
+static void submit_engine_destroy(ntscsim_ctx *c)
+{
+    SubmitEngine *e = c->sub;
+    if (!e) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &b : e->inflight) { if (b.up) (void)hipEventDestroy(b.up); if (b.done) (void)hipEventDestroy(b.done); }
+    for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (ntscsim_ctx *l : e->lanes) ntscsim_destroy(l);
+    sub_release_geometry(e);
+    sub_unpin_all(e);
+    if (e->s_up) (void)hipStreamDestroy(e->s_up);
+    if (e->ev_up) (void)hipEventDestroy(e->ev_up);
+    delete e;
+    c->sub = nullptr;
+}
+
+extern "C" int ntscsim_submit_configure(ntscsim_ctx *c, const ntscsim_submit_opts *o)
+{
+    if (!c || !o || o->struct_size != sizeof(ntscsim_submit_opts)) return NTSCSIM_E_ARG;
+    if (o->depth < 1 || o->depth > 4096 || o->lanes < 1 || o->lanes > 8) return NTSCSIM_E_ARG;
+    if (o->slots != 0 && o->slots < 2 * o->depth) return NTSCSIM_E_ARG;
+    if (o->slots > 65536) return NTSCSIM_E_ARG;
+    SubmitEngine *e = sub_get(c);
+    if (!e) return NTSCSIM_E_NOMEM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    if (rc != NTSCSIM_OK) return rc;
+    e->o = *o;
+    if (e->o.slots == 0) e->o.slots = 4 * e->o.depth;
+    while ((int)e->lanes.size() > e->o.lanes) { ntscsim_destroy(e->lanes.back()); e->lanes.pop_back(); }
+    sub_release_geometry(e);          // the rings are sized by `slots`
+    e->configured = true;
+    return NTSCSIM_OK;
+}
+
+static int sub_ensure_geometry(ntscsim_ctx *c, SubmitEngine *e, int W, int H)
+{
+    if (e->W == W && e->H == H && e->nslots == e->o.slots) return NTSCSIM_OK;
+    // another geometry: drain, then rebuild the rings
+    int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    if (rc != NTSCSIM_OK) return rc;
+    sub_release_geometry(e);
+    const size_t pitch = (((size_t)W * 4 + 15) / 16) * 16;
+    const size_t fbytes = ((pitch * (size_t)H + 255) / 256) * 256;
+    const int ns = e->o.slots;
+    HIPCHK(c, e->dsrc.ensure(fbytes * (size_t)ns));
+    HIPCHK(c, e->ddst.ensure(fbytes * (size_t)ns));
+    HIPCHK(c, hipHostMalloc((void **)&e->recs, sizeof(DeliverRec) * (size_t)ns, hipHostMallocDefault));
+    if (!e->s_up) HIPCHK(c, hipStreamCreateWithFlags(&e->s_up, hipStreamNonBlocking));
+    if (!e->ev_up) HIPCHK(c, hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming));
+    e->W = W; e->H = H; e->pitch = pitch; e->fbytes = fbytes; e->nslots = ns;
+    e->src_last_ticket.assign((size_t)ns, 0);
+    e->src_ring_pos = 0;
+    e->src_cur = -1;
+    return NTSCSIM_OK;
+}
+
+static int sub_ensure_staging(ntscsim_ctx *c, SubmitEngine *e, bool src)
+{
+    uint8_t **p = src ? &e->hsrc : &e->hdst;
+    if (*p) return NTSCSIM_OK;
+    HIPCHK(c, hipHostMalloc((void **)p, e->fbytes * (size_t)e->nslots, hipHostMallocDefault));
+    return NTSCSIM_OK;
+}
+
+// Device-visible address of caller memory [p, p+span), pinning it in place on first sight.  NULL = not pinned
+// (too small, shares a page with another registration, registration refused): the staging ring is used.
+static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_t span)
+{
+    (void)c;
+    if (!e->o.pin_caller_buffers || span < e->o.min_pin_bytes) return nullptr;
+    const uintptr_t a0 = (uintptr_t)p, a1 = a0 + span;
+    for (auto &r : e->regs)
+        if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
+    const uintptr_t PG = 4096;
+    const uintptr_t p0 = a0 & ~(PG - 1), p1 = (a1 + PG - 1) & ~(PG - 1);
+    for (auto &r : e->regs)
+        if (p0 < r.p1 && r.p0 < p1) return nullptr;          // partial overlap with a live registration
+    if (e->regs.size() >= 1024) return nullptr;
+    hipError_t er = hipHostRegister((void *)p0, p1 - p0, hipHostRegisterDefault);
+    bool owned = true;
+    if (er == hipErrorHostMemoryAlreadyRegistered) { owned = false; er = hipSuccess; }   // pinned by the caller
+    (void)hipGetLastError();
+    if (er != hipSuccess) return nullptr;
+    void *dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, (void *)p0, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        if (owned) (void)hipHostUnregister((void *)p0);
+        return nullptr;
+    }
+    e->regs.push_back({p0, p1, (uint8_t *)dev, owned});
+    e->stats[6] = e->regs.size();
+    return (uint8_t *)dev + (a0 - p0);
+}
+
+extern "C" int ntscsim_host_unpin(ntscsim_ctx *c, const void *base)
+{
+    if (!c) return NTSCSIM_E_ARG;
+    SubmitEngine *e = c->sub;
+    if (!e) return NTSCSIM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    HIPCHK(c, hipStreamSynchronize(e->s_up ? e->s_up : c->stream));
+    if (!base) sub_unpin_all(e);
+    else {
+        const uintptr_t a = (uintptr_t)base;
+        for (size_t i = 0; i < e->regs.size(); i++)
+            if (a >= e->regs[i].p0 && a < e->regs[i].p1) {
+                if (e->regs[i].owned) (void)hipHostUnregister((void *)e->regs[i].p0);
+                e->regs.erase(e->regs.begin() + (long)i);
+                break;
+            }
+    }
+    e->stats[6] = e->regs.size();
+    e->src_cur = -1;
+    return rc;
+}
+
+extern "C" void ntscsim_submit_stats(const ntscsim_ctx *c, uint64_t out[8])
+{
+    if (!out) return;
+    for (int i = 0; i < 8; i++) out[i] = (c && c->sub) ? c->sub->stats[i] : 0;
+}
+
+// rows the synchronous call + (optionally) the loop's line doubling write: first row, step, count
+static void sub_rows(int H, unsigned field, bool bob, int &row0, int &step, int &n)
+{
+    if (!bob) { row0 = (int)field; step = 2; n = (H - (int)field + 1) / 2; return; }
+    // ffmpeg_ntsc.cpp:2233-2257: field 1 copies odd row y onto y-1; field 0 copies row y+1 onto odd row y while
+    // y+1 < H -- every row except the last one when it has no partner
+    row0 = 0; step = 1;
+    const bool last_untouched = field ? (H & 1) != 0 : (H & 1) == 0;
+    n = last_untouched ? H - 1 : H;
+}
+
+// Retire the oldest launch: wait for it, hand staged rows to the caller, recycle its events.
+static int sub_retire_front(ntscsim_ctx *c, SubmitEngine *e)
+{
+    SubmitEngine::Batch &b = e->inflight.front();
+    int rc = b.rc;
+    if (b.launched_ok) {
+        hipError_t er = hipEventSynchronize(b.done);
+        if (er != hipSuccess) { c->err = std::string("hipEventSynchronize: ") + hipGetErrorString(er); rc = NTSCSIM_E_HIP; }
+        else
+            for (const auto &it : b.items) {
+                if (it.host_dst_dev) continue;
+                int row0, step, n;
+                sub_rows(e->H, it.field, (it.flags & NTSCSIM_DESC_BOB) != 0, row0, step, n);
+                const uint8_t *s = e->hdst + e->fbytes * (size_t)it.dst_slot;
+                const size_t rb = (size_t)e->W * 4;
+                if (step == 1 && (size_t)it.dst_ls == e->pitch)
+                    std::memcpy(it.host_dst, s, e->pitch * (size_t)(n - 1) + rb);
+                else
+                    for (int k = 0; k < n; k++) {
+                        const size_t y = (size_t)row0 + (size_t)k * step;
+                        std::memcpy(it.host_dst + y * (size_t)it.dst_ls, s + y * e->pitch, rb);
+                    }
+            }
+    }
+    e->done_ticket = b.last;
+    if (b.up && b.done) e->ev_pool.push_back({b.up, b.done});
+    e->inflight.pop_front();
+    if (rc != NTSCSIM_OK && e->sticky_rc == NTSCSIM_OK) e->sticky_rc = rc;
+    return rc;
+}
+
+static int sub_wait_ticket(ntscsim_ctx *c, uint64_t ticket)
+{
+    SubmitEngine *e = c->sub;
+    if (!e) return ticket == NTSCSIM_TICKET_ALL ? NTSCSIM_OK : NTSCSIM_E_ARG;
+    if (ticket == NTSCSIM_TICKET_ALL) ticket = e->next_ticket - 1;
+    if (ticket == 0) return NTSCSIM_OK;
+    if (ticket >= e->next_ticket) return NTSCSIM_E_ARG;
+    int rc = NTSCSIM_OK;
+    if (!e->pending.empty() && ticket >= e->pending.front().ticket) {
+        const int r = sub_launch(c);
+        if (r != NTSCSIM_OK) rc = r;
+    }
+    while (!e->inflight.empty() && e->inflight.front().first <= ticket) {
+        const int r = sub_retire_front(c, e);
+        if (r != NTSCSIM_OK && rc == NTSCSIM_OK) rc = r;
+    }
+    return rc;
+}
+
+// Enqueue the pending fields as one launch on the next lane.
+static int sub_launch(ntscsim_ctx *c)
+{
+    SubmitEngine *e = c->sub;
+    if (!e || e->pending.empty()) return NTSCSIM_OK;
+    SubmitEngine::Batch b;
+    b.first = e->pending.front().ticket;
+    b.last = e->pending.back().ticket;
+    b.items.swap(e->pending);
+    e->pending.clear();
+    const int n = (int)b.items.size();
+    auto finish = [&](int rc) {
+        b.rc = rc;
+        e->inflight.push_back(std::move(b));
+        return rc;
+    };
+    if (!e->ev_pool.empty()) { b.up = e->ev_pool.back().first; b.done = e->ev_pool.back().second; e->ev_pool.pop_back(); }
+    else if (hipEventCreateWithFlags(&b.up, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) {
+        c->err = "hipEventCreate failed";
+        return finish(NTSCSIM_E_HIP);
+    }
+    // the lane: a child ctx with the parent's parameters and switches
+    const unsigned li = e->lane_next++ % (unsigned)e->o.lanes;
+    while (e->lanes.size() <= li) {
+        ntscsim_ctx *l = nullptr;
+        const int rc = ntscsim_create(&c->prm, c->device, &l);
+        if (rc != NTSCSIM_OK) return finish(rc);
+        e->lanes.push_back(l);
+    }
+    ntscsim_ctx *lane = e->lanes[li];
+    lane->mode = c->mode; lane->force_generic = c->force_generic; lane->no_fast_decode = c->no_fast_decode;
+    lane->split_vhs = c->split_vhs;
+    if (lane->warm_override[0] != c->warm_override[0] || lane->warm_override[1] != c->warm_override[1])
+        ntscsim_debug_set_warmup(lane, c->warm_override[0], c->warm_override[1]);
+
+    std::vector<ntscsim_field_desc> descs((size_t)n);
+    bool any_staged = false, any_direct = false;
+    for (int i = 0; i < n; i++) {
+        const SubmitEngine::Item &it = b.items[(size_t)i];
+        ntscsim_field_desc &d = descs[(size_t)i];
+        std::memset(&d, 0, sizeof(d));
+        d.src_dev = e->dsrc.p + e->fbytes * (size_t)it.src_slot;
+        d.dst_dev = e->ddst.p + e->fbytes * (size_t)it.dst_slot;
+        d.src_linesize = d.dst_linesize = (int)e->pitch;
+        d.field = it.field;
+        d.flags = it.flags & (NTSCSIM_DESC_INTERLACED | NTSCSIM_DESC_TFF | NTSCSIM_DESC_BOB);
+        d.fieldno = it.fieldno;
+        d.rng_pos = it.rng_pos;
+        if (it.host_dst_dev) any_direct = true; else any_staged = true;
+    }
+    hipError_t er = hipEventRecord(b.up, e->s_up);
+    if (er == hipSuccess) er = hipStreamWaitEvent(lane->stream, b.up, 0);
+    if (er != hipSuccess) { c->err = std::string("submit launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    int rc = ntscsim_fields_device(lane, descs.data(), n, e->W, e->H, lane->stream);
+    if (rc != NTSCSIM_OK) { c->err = lane->err; return finish(rc); }
+    c->kernels = lane->kernels;
+    // delivery
+    if (any_direct) {
+        // records live in the slot-indexed pinned array (a slot's record is rewritten only after its launch
+        // retired); slots are handed out in ring order, so the pinned frames of a launch are a few runs of
+        // consecutive records: one k_deliver per run
+        bool vec16 = ((e->W * 4) & 15) == 0;
+        for (const auto &it : b.items) {
+            if (!it.host_dst_dev) continue;
+            DeliverRec &r = e->recs[it.dst_slot];
+            r.dev = e->ddst.p + e->fbytes * (size_t)it.dst_slot;
+            r.host = it.host_dst_dev;
+            r.dev_pitch = (int32_t)e->pitch; r.host_pitch = it.dst_ls;
+            sub_rows(e->H, it.field, (it.flags & NTSCSIM_DESC_BOB) != 0, r.row0, r.row_step, r.nrows);
+            r._pad = 0;
+            vec16 = vec16 && !(((uintptr_t)it.host_dst_dev | (uintptr_t)it.dst_ls) & 15);
+        }
+        size_t i = 0;
+        int nd = 0;
+        while (i < b.items.size()) {
+            if (!b.items[i].host_dst_dev) { i++; continue; }
+            size_t j = i + 1;
+            while (j < b.items.size() && b.items[j].host_dst_dev && b.items[j].dst_slot == b.items[j - 1].dst_slot + 1) j++;
+            hipLaunchKernelGGL(k_deliver, dim3(16, (unsigned)(j - i)), dim3(256), 0, lane->stream,
+                               e->recs + b.items[i].dst_slot, e->W * 4, vec16 ? 1 : 0);
+            nd += (int)(j - i);
+            i = j;
+        }
+        er = hipGetLastError();
+        if (er != hipSuccess) { c->err = std::string("k_deliver: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+        e->stats[4] += (uint64_t)nd;
+    }
+    if (any_staged) {
+        rc = sub_ensure_staging(c, e, false);
+        if (rc != NTSCSIM_OK) return finish(rc);
+        // whole frames, runs of consecutive slots as one linear copy
+        size_t i = 0;
+        while (i < b.items.size()) {
+            if (b.items[i].host_dst_dev) { i++; continue; }
+            size_t j = i + 1;
+            while (j < b.items.size() && !b.items[j].host_dst_dev && b.items[j].dst_slot == b.items[j - 1].dst_slot + 1) j++;
+            const size_t off = e->fbytes * (size_t)b.items[i].dst_slot;
+            er = hipMemcpyAsync(e->hdst + off, e->ddst.p + off, e->fbytes * (j - i), hipMemcpyDeviceToHost, lane->stream);
+            if (er != hipSuccess) { c->err = std::string("submit D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+            e->stats[5] += (uint64_t)(j - i);
+            i = j;
+        }
+    }
+    er = hipEventRecord(b.done, lane->stream);
+    if (er != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    b.launched_ok = true;
+    e->stats[1]++;
+    return finish(NTSCSIM_OK);
+}
+
+extern "C" int ntscsim_flush(ntscsim_ctx *c)
+{
+    if (!c) return NTSCSIM_E_ARG;
+    if (!c->sub) return NTSCSIM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return sub_launch(c);
+}
+
+extern "C" int ntscsim_wait(ntscsim_ctx *c, uint64_t ticket)
+{
+    if (!c) return NTSCSIM_E_ARG;
+    if (!c->sub) return ticket == NTSCSIM_TICKET_ALL ? NTSCSIM_OK : NTSCSIM_E_ARG;
+    if (ticket != NTSCSIM_TICKET_ALL && ticket <= c->sub->done_ticket && ticket != 0) return NTSCSIM_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    return sub_wait_ticket(c, ticket);
+}
+
+extern "C" int ntscsim_submit(ntscsim_ctx *c, const uint8_t *src, int src_ls, int src_interlaced, int src_tff,
+                              uint8_t *dst, int dst_ls, int W, int H, unsigned field, uint64_t fieldno,
+                              uint32_t flags, uint64_t *ticket)
+{
+    if (!c || !src || !dst) return NTSCSIM_E_ARG;                   // :1578-1579
+    if (src_ls < 4 * W || dst_ls < 4 * W) return NTSCSIM_E_SIZE;     // :1580-1581
+    if (field > 1) return NTSCSIM_E_ARG;
+    if (W < 16 || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
+    if (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)src_ls | (uintptr_t)dst_ls) & 3) return NTSCSIM_E_ARG;
+    if (flags & ~(NTSCSIM_DESC_BOB | NTSCSIM_SUBMIT_SAME_SRC | NTSCSIM_SUBMIT_SRC_STABLE)) return NTSCSIM_E_ARG;
+    SubmitEngine *e = sub_get(c);
+    if (!e) return NTSCSIM_E_NOMEM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = sub_ensure_geometry(c, e, W, H);
+    if (rc != NTSCSIM_OK) return rc;
+
+    // ring space: ticket t uses destination slot t mod nslots; the launch that held it must have retired
+    const uint64_t t = e->next_ticket;
+    if (t > (uint64_t)e->nslots && e->done_ticket < t - (uint64_t)e->nslots) {
+        e->stats[7]++;
+        rc = sub_wait_ticket(c, t - (uint64_t)e->nslots);
+        if (rc != NTSCSIM_OK) return rc;
+    }
+    const size_t rb = (size_t)W * 4;
+    // source frame
+    int sslot = e->src_cur;
+    if (!(flags & NTSCSIM_SUBMIT_SAME_SRC) || sslot < 0) {
+        sslot = (int)(e->src_ring_pos % (uint64_t)e->nslots);
+        const uint64_t last = e->src_last_ticket[(size_t)sslot];
+        if (last > e->done_ticket) {
+            // (cannot happen while sources <= fields in flight <= nslots, kept as a guard)
+            rc = sub_wait_ticket(c, last);
+            if (rc != NTSCSIM_OK) return rc;
+        }
+        uint8_t *dslot = e->dsrc.p + e->fbytes * (size_t)sslot;
+        const size_t span = (size_t)src_ls * (size_t)(H - 1) + rb;
+        const bool pinned = sub_pinned(c, e, src, span) != nullptr;
+        const uint8_t *from = src;
+        size_t from_ls = (size_t)src_ls;
+        if (!pinned) {
+            rc = sub_ensure_staging(c, e, true);
+            if (rc != NTSCSIM_OK) return rc;
+            uint8_t *hs = e->hsrc + e->fbytes * (size_t)sslot;
+            if ((size_t)src_ls == e->pitch) std::memcpy(hs, src, span);
+            else for (int y = 0; y < H; y++) std::memcpy(hs + e->pitch * (size_t)y, src + (size_t)src_ls * (size_t)y, rb);
+            from = hs; from_ls = e->pitch;
+            e->stats[3]++;
+        }
+        if (from_ls == e->pitch)
+            HIPCHK(c, hipMemcpyAsync(dslot, from, e->pitch * (size_t)(H - 1) + rb, hipMemcpyHostToDevice, e->s_up));
+        else
+            HIPCHK(c, hipMemcpy2DAsync(dslot, e->pitch, from, from_ls, rb, (size_t)H, hipMemcpyHostToDevice, e->s_up));
+        // the caller may rewrite src as soon as we return: the DMA must have read it
+        if (pinned && !(flags & NTSCSIM_SUBMIT_SRC_STABLE)) HIPCHK(c, hipStreamSynchronize(e->s_up));
+        e->src_ring_pos++;
+        e->src_cur = sslot;
+        e->stats[2]++;
+    }
+    // destination
+    int row0, step, nrows;
+    sub_rows(H, field, (flags & NTSCSIM_DESC_BOB) != 0, row0, step, nrows);
+    const size_t dspan = (size_t)dst_ls * (size_t)(H - 1) + rb;
+    SubmitEngine::Item it;
+    it.ticket = t;
+    it.src_slot = sslot;
+    it.dst_slot = (int)(t % (uint64_t)e->nslots);
+    it.host_dst = dst;
+    it.host_dst_dev = sub_pinned(c, e, dst, dspan);
+    it.dst_ls = dst_ls;
+    it.field = field;
+    it.flags = (flags & NTSCSIM_DESC_BOB) | (src_interlaced ? NTSCSIM_DESC_INTERLACED : 0u) | (src_tff ? NTSCSIM_DESC_TFF : 0u);
+    it.fieldno = fieldno;
+    it.rng_pos = c->rng_pos;
+    c->rng_pos += ntscsim_rng_calls_per_field(&c->prm, W, H, field);
+    e->src_last_ticket[(size_t)sslot] = t;
+    e->pending.push_back(it);
+    e->next_ticket++;
+    e->stats[0]++;
+    if (ticket) *ticket = t;
+    if ((int)e->pending.size() >= e->o.depth) return sub_launch(c);
+    return NTSCSIM_OK;
+}

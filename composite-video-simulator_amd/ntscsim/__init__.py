@@ -82,6 +82,47 @@ class FieldSimulator:
                                      dst.strides[0], w, h, int(field), int(fieldno))
         self._chk(rc, "ntscsim_field")
 
+    # ---- the asynchronous form of the same drop-in: ntscsim_submit() / ntscsim_wait() ------
+    def submit_configure(self, depth=32, slots=0, lanes=3, pin=True, min_pin_bytes=256 << 10):
+        o = _capi.SubmitOpts()
+        self._lib.ntscsim_submit_opts_init(C.byref(o))
+        o.depth, o.slots, o.lanes = int(depth), int(slots), int(lanes)
+        o.pin_caller_buffers, o.min_pin_bytes = int(bool(pin)), int(min_pin_bytes)
+        self._chk(self._lib.ntscsim_submit_configure(self._h, C.byref(o)), "ntscsim_submit_configure")
+
+    def submit(self, dst, src, field, fieldno, interlaced=0, tff=0, bob=False, same_src=False,
+               src_stable=False):
+        """As field_host(), asynchronously: returns a ticket; dst is complete after wait(ticket).
+        dst, src: numpy uint8 [H, W, 4] (rows contiguous; any row stride)."""
+        h, w = src.shape[:2]
+        assert src.shape == dst.shape and src.shape[2] == 4 and src.strides[1] == 4 and dst.strides[1] == 4
+        flags = (DESC_BOB if bob else 0) | (_capi.SUBMIT_SAME_SRC if same_src else 0) | \
+                (_capi.SUBMIT_SRC_STABLE if src_stable else 0)
+        t = C.c_uint64(0)
+        rc = self._lib.ntscsim_submit(self._h, src.ctypes.data, src.strides[0], int(interlaced), int(tff),
+                                      dst.ctypes.data, dst.strides[0], w, h, int(field), int(fieldno),
+                                      flags, C.byref(t))
+        self._chk(rc, "ntscsim_submit")
+        return int(t.value)
+
+    def wait(self, ticket=None):
+        self._chk(self._lib.ntscsim_wait(self._h, _capi.TICKET_ALL if ticket is None else int(ticket)),
+                  "ntscsim_wait")
+
+    def flush(self):
+        self._chk(self._lib.ntscsim_flush(self._h), "ntscsim_flush")
+
+    def host_unpin(self, array=None):
+        self._chk(self._lib.ntscsim_host_unpin(self._h, None if array is None else array.ctypes.data),
+                  "ntscsim_host_unpin")
+
+    def submit_stats(self):
+        out = (C.c_uint64 * 8)()
+        self._lib.ntscsim_submit_stats(self._h, out)
+        keys = ("submitted", "launches", "uploads", "uploads_staged", "delivered_direct", "delivered_staged",
+                "registrations", "ring_full_waits")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def frames_host(self, dst, src, first_fieldno=0, bob=True, chunk_frames=0, yuv=None):
         """The field loop over host frames: src numpy uint8 [N, H, W, 4], dst [2N, H, W, 4].
         yuv = "420" / "422": dst is uint8 [2N, frame_bytes], each frame Y|U|V planes packed at

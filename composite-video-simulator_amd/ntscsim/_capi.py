@@ -16,6 +16,8 @@ OK, E_ARG, E_SIZE, E_NODEV, E_HIP, E_NOMEM, E_PARAM, E_FLAG, E_HELP, E_INTERNAL 
 RNG_AUTO = 0xFFFFFFFFFFFFFFFF
 MODE_EXACT, MODE_FAST32 = 0, 1
 DESC_INTERLACED, DESC_TFF, DESC_BOB = 1, 2, 0x100
+SUBMIT_SAME_SRC, SUBMIT_SRC_STABLE = 0x10000, 0x20000
+TICKET_ALL = 0xFFFFFFFFFFFFFFFF
 
 # every symbol include/ntscsim.h declares
 EXPORTS = (
@@ -37,7 +39,15 @@ EXPORTS = (
     "ntscsim_raw28_stream_reset", "ntscsim_raw28_stream_push",
     "ntscsim_raw28_get_levels", "ntscsim_raw28_debug_set_speculation", "ntscsim_raw28_debug_stats",
     "ntscsim_raw28_debug_read_front",
+    "ntscsim_submit_opts_init", "ntscsim_submit_configure", "ntscsim_submit", "ntscsim_flush", "ntscsim_wait",
+    "ntscsim_host_unpin", "ntscsim_submit_stats",
 )
+
+
+class SubmitOpts(C.Structure):
+    """struct ntscsim_submit_opts -- keep in lock-step with include/ntscsim.h."""
+    _fields_ = [("struct_size", C.c_uint32), ("depth", C.c_int32), ("slots", C.c_int32), ("lanes", C.c_int32),
+                ("pin_caller_buffers", C.c_int32), ("_pad", C.c_int32), ("min_pin_bytes", C.c_size_t)]
 
 
 class Raw28Opts(C.Structure):
@@ -315,6 +325,21 @@ def lib():
     L.ntscsim_raw28_debug_stats.restype = None
     L.ntscsim_raw28_debug_read_front.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.ntscsim_raw28_debug_read_front.restype = C.c_int
+    L.ntscsim_submit_opts_init.argtypes = [C.POINTER(SubmitOpts)]
+    L.ntscsim_submit_opts_init.restype = None
+    L.ntscsim_submit_configure.argtypes = [C.c_void_p, C.POINTER(SubmitOpts)]
+    L.ntscsim_submit_configure.restype = C.c_int
+    L.ntscsim_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_uint, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.ntscsim_submit.restype = C.c_int
+    L.ntscsim_flush.argtypes = [C.c_void_p]
+    L.ntscsim_flush.restype = C.c_int
+    L.ntscsim_wait.argtypes = [C.c_void_p, C.c_uint64]
+    L.ntscsim_wait.restype = C.c_int
+    L.ntscsim_host_unpin.argtypes = [C.c_void_p, C.c_void_p]
+    L.ntscsim_host_unpin.restype = C.c_int
+    L.ntscsim_submit_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ntscsim_submit_stats.restype = None
     _lib = L
     return L
 

@@ -204,6 +204,88 @@ int ntscsim_field(ntscsim_ctx *ctx,
                   int width, int height, unsigned field, uint64_t fieldno);
 
 /*
+ * ASYNCHRONOUS drop-in for composite_layer() (ntscsim_submit / ntscsim_wait).
+ *
+ * The reference's loop calls composite_layer(ring[idx], in.rgb, in, (current&1)^1, current) at
+ * ffmpeg_ntsc.cpp:2229, then line-doubles (:2233-2257), converts (:2266) and encodes the frame before it
+ * composites the next field.  One synchronous field per call leaves the GPU 99 % idle (a field is four
+ * wavefronts of work).  ntscsim_submit() takes the same arguments, returns at once with a ticket, and the
+ * ctx coalesces submitted fields into launches of `depth` fields; ntscsim_wait(ticket) returns when that
+ * field's rows are in the caller's dst frame.  The caller moves everything it does with the frame after
+ * composite_layer() (bob, sws_scale, output_frame :2233-2280) behind a wait issued `depth` fields later
+ * (INTEGRATION.md section 1b shows the patch of the loop :2202-2282).
+ *
+ * Contract (what makes a sequence of submits + waits byte-identical to the same sequence of
+ * ntscsim_field() calls on the same pointers, rand() position included):
+ *   - src is SNAPSHOTTED by the call: when ntscsim_submit() returns the caller may overwrite src (the
+ *     reference rewrites in.rgb with the next decoded frame, InputFile::frame_copy_scale :544-613).
+ *     NTSCSIM_SUBMIT_SAME_SRC: src still holds the frame of the previous submit on this ctx (same
+ *     pointer, geometry and content -- e.g. the second field of a frame): the device copy is reused and
+ *     nothing is uploaded.  NTSCSIM_SUBMIT_SRC_STABLE: the caller promises to leave src alone until the
+ *     ticket has been waited for; the call then does not wait for its upload either.
+ *   - dst is written some time between submit and the return of ntscsim_wait(ticket): exactly the rows
+ *     composite_layer() writes (rows field, field+2, ... :1910-1916; alpha 0), or with NTSCSIM_DESC_BOB
+ *     in `flags` additionally the rows the loop's line doubling writes (:2233-2257: every row except, for
+ *     field 0 and an even height or field 1 and an odd height, the last one).  Other rows are not touched.
+ *     The caller must not read or write dst between submit and wait.  Fields in flight that share a dst
+ *     frame are delivered in submit order.
+ *   - tickets are issued in increasing order starting at 1; waiting for a ticket also completes every
+ *     earlier one.  NTSCSIM_TICKET_ALL waits for everything submitted so far.
+ *   - the rand() stream advances at SUBMIT time, in submit order (ntscsim_get_rng_pos() reflects it), so
+ *     the noise is the one the synchronous loop draws.  ntscsim_field() / ntscsim_sync() on a ctx with
+ *     fields in flight first wait for them; the other entry points must not be mixed in without
+ *     ntscsim_wait(ctx, NTSCSIM_TICKET_ALL).
+ *   - a launch happens when `depth` fields are pending, on ntscsim_flush(), or when a wait needs it; a
+ *     change of width/height flushes first.
+ * Host buffers: by default the engine pins the caller's frames IN PLACE the first time it sees them
+ * (hipHostRegister, whole pages, cached per ctx: AVFrame pools recycle a handful of buffers) and moves the
+ * pixels with DMA uploads and a GPU delivery kernel that writes the field rows straight into the caller's
+ * frame -- no host memcpy.  Buffers smaller than min_pin_bytes, buffers that share a page with another
+ * registration, or pin_caller_buffers = 0 go through a pinned staging ring instead (one memcpy each way).
+ * A pinned buffer must stay allocated until ntscsim_host_unpin() / ntscsim_destroy(): free()ing registered
+ * memory while the registration lives is undefined (HIP).
+ */
+typedef struct ntscsim_submit_opts {
+    uint32_t struct_size;          /* sizeof(ntscsim_submit_opts)                                       */
+    int32_t  depth;                /* fields per launch, 1..4096; default 32                              */
+    int32_t  slots;                /* fields that may be in flight (device frame ring), >= 2*depth;
+                                      default 4*depth.  ntscsim_submit() blocks (waits for the oldest
+                                      launch) when the ring is full                                       */
+    int32_t  lanes;                /* launches in flight side by side (own stream + scratch), 1..8; def. 3 */
+    int32_t  pin_caller_buffers;   /* default 1                                                           */
+    int32_t  _pad;
+    size_t   min_pin_bytes;        /* default 256 KiB                                                     */
+} ntscsim_submit_opts;
+void ntscsim_submit_opts_init(ntscsim_submit_opts *o);
+/* (Re)configure the engine; waits for everything in flight first.  Optional: the defaults apply otherwise. */
+int  ntscsim_submit_configure(ntscsim_ctx *ctx, const ntscsim_submit_opts *o);
+
+#define NTSCSIM_SUBMIT_SAME_SRC   0x10000u
+#define NTSCSIM_SUBMIT_SRC_STABLE 0x20000u
+#define NTSCSIM_TICKET_ALL        UINT64_MAX
+
+/* Arguments as ntscsim_field(); `flags`: NTSCSIM_DESC_BOB | NTSCSIM_SUBMIT_*.  *ticket (may be NULL)
+ * receives the ticket.  Errors are those of ntscsim_field(); a field that was refused consumes no ticket
+ * and no rand() draws. */
+int ntscsim_submit(ntscsim_ctx *ctx,
+                   const uint8_t *src_bgra, int src_linesize, int src_interlaced, int src_tff,
+                   uint8_t *dst_bgra, int dst_linesize,
+                   int width, int height, unsigned field, uint64_t fieldno,
+                   uint32_t flags, uint64_t *ticket);
+/* Launch what is pending without waiting for it. */
+int ntscsim_flush(ntscsim_ctx *ctx);
+/* Block until `ticket` (and every earlier one) has been delivered.  Returns the first error of the
+ * launches it had to complete (their fields are then lost), NTSCSIM_E_ARG for a ticket never issued. */
+int ntscsim_wait(ntscsim_ctx *ctx, uint64_t ticket);
+/* Drop the cached registration that covers `base` (NULL: all of them) after waiting for everything in
+ * flight: call before free()ing a frame buffer the engine has seen while the ctx lives on. */
+int ntscsim_host_unpin(ntscsim_ctx *ctx, const void *base);
+/* Counters since ntscsim_create(): [0] fields submitted, [1] launches, [2] source uploads, [3] uploads that
+ * went through the staging ring, [4] fields delivered by the GPU into pinned caller frames, [5] fields
+ * delivered through the staging ring, [6] live registrations, [7] submits that blocked on a full ring. */
+void ntscsim_submit_stats(const ntscsim_ctx *ctx, uint64_t out[8]);
+
+/*
  * The field loop (ffmpeg_ntsc.cpp:2202-2282) for a run of frames held in HOST memory, pipelined:
  * source frame j (j = 0..n_frames-1, BGRA, at src + j*src_frame_stride) produces output fields
  * first_fieldno + 2j and + 2j+1 (field parity (cur&1)^1, :2229), each into its own host frame at

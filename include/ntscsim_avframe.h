@@ -48,6 +48,25 @@ static inline int ntscsim_field_avframe(ntscsim_ctx *ctx, NTSCSIM_AVFRAME_T *dst
                          dstframe->width, dstframe->height, field, fieldno);
 }
 
+/* The same call, asynchronously (ntscsim_submit(), include/ntscsim.h): returns at once with a ticket; the rows
+ * are in dstframe after ntscsim_wait(ctx, *ticket).  srcframe is snapshotted by the call (the loop may
+ * sws_scale the next decoded frame into it right away, ffmpeg_ntsc.cpp:603); dstframe must not be touched
+ * until the wait.  `flags`: NTSCSIM_DESC_BOB (line doubling :2233-2257 done on the GPU as well) |
+ * NTSCSIM_SUBMIT_SAME_SRC (srcframe still holds the frame of the previous submit: second field of a frame). */
+static inline int ntscsim_submit_avframe(ntscsim_ctx *ctx, NTSCSIM_AVFRAME_T *dstframe,
+                                         const NTSCSIM_AVFRAME_T *srcframe, unsigned field,
+                                         uint64_t fieldno, uint32_t flags, uint64_t *ticket)
+{
+    if (dstframe == 0 || srcframe == 0) return NTSCSIM_E_ARG;
+    if (dstframe->data[0] == 0 || srcframe->data[0] == 0) return NTSCSIM_E_ARG;
+    if (dstframe->linesize[0] < dstframe->width * 4) return NTSCSIM_E_SIZE;
+    if (srcframe->linesize[0] < srcframe->width * 4) return NTSCSIM_E_SIZE;
+    if (dstframe->width != srcframe->width || dstframe->height != srcframe->height) return NTSCSIM_E_SIZE;
+    return ntscsim_submit(ctx, srcframe->data[0], srcframe->linesize[0], srcframe->interlaced_frame,
+                          srcframe->top_field_first, dstframe->data[0], dstframe->linesize[0],
+                          dstframe->width, dstframe->height, field, fieldno, flags, ticket);
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,7 +128,8 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
     structs = {"ntscsim_params": _capi.Params, "ntscsim_field_desc": _capi.FieldDesc,
                "ntscsim_field422_desc": _capi.Field422Desc, "ntscsim_out422_desc": _capi.Out422Desc,
                "ntscsim_yuv_desc": _capi.YuvDesc, "ntscsim_scale_desc": _capi.ScaleDesc,
-               "ntscsim_host_source": _capi.HostSource, "ntscsim_raw28_opts": _capi.Raw28Opts}
+               "ntscsim_host_source": _capi.HostSource, "ntscsim_raw28_opts": _capi.Raw28Opts,
+               "ntscsim_submit_opts": _capi.SubmitOpts}
     lines = ['#include "ntscsim.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, mirror in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -1,0 +1,263 @@
+"""ntscsim_submit() / ntscsim_wait(): the asynchronous host-frame form of the composite_layer() drop-in
+(include/ntscsim.h; the call site it replaces is ffmpeg_ntsc.cpp:2229 inside the loop :2202-2282).
+
+The contract under test: a sequence of submits + waits leaves the SAME BYTES in the caller's frames, and the
+ctx at the same rand() position, as the same sequence of synchronous ntscsim_field() calls on the same
+pointers -- which in turn equals the oracle's composite_layer() (+ the loop's line doubling with
+NTSCSIM_DESC_BOB).  Everything goes through ctypes -> C-ABI.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _libs as L
+import ntscsim
+from ntscsim import _capi
+
+
+def page_frame(h, w, fill=0):
+    """A [h, w, 4] uint8 frame that owns whole 4 KiB pages (like av_frame_get_buffer's large allocations): the
+    engine pins caller memory page-wise and will not pin a frame that shares a page with another registration."""
+    nbytes = h * w * 4
+    raw = np.empty(((nbytes + 4095) // 4096 + 2) * 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    a = raw[off:off + nbytes].reshape(h, w, 4)
+    a[:] = fill
+    return a
+
+
+def oracle_bob(frame, field):
+    h, w = frame.shape[:2]
+    L.oracle().ntsc_oracle_bob(L._ptr(frame), w * 4, w, h, field)
+
+
+def reference_loop(p, frames, n_fields, w, h, ring, bob, fill=0x5A):
+    """The loop of ffmpeg_ntsc.cpp:2202-2282 on the oracle: field k reads frame k//2, writes ring[k % len(ring)],
+    is line-doubled in place (:2233-2257) when `bob`; a snapshot of the ring frame is what the encoder got."""
+    o = L.OracleStream(p)
+    bufs = [np.full((h, w, 4), fill, np.uint8) for _ in range(ring)]
+    snaps = []
+    for k in range(n_fields):
+        field = (k & 1) ^ 1
+        d = bufs[k % ring]
+        o.field(d, frames[k // 2], field, k)
+        if bob:
+            oracle_bob(d, field)
+        snaps.append(d.copy())
+    return snaps, o.rng_pos
+
+
+def run_submit_loop(sim, frames, n_fields, w, h, ring, bob, lag, pad=0, same_src=True, fill=0x5A):
+    """The same loop with ntscsim_submit(): ONE source buffer that is rewritten for every new frame (the
+    reference's in.rgb), a ring of `ring` destination frames, wait + snapshot `lag` fields behind."""
+    src = page_frame(h, w + pad)
+    bufs = [page_frame(h, w + pad, fill) for _ in range(ring)]
+    snaps = [None] * n_fields
+    tickets = []
+    for k in range(n_fields):
+        field = (k & 1) ^ 1
+        new = (k & 1) == 0 or not same_src
+        if new:
+            src[:, :w] = frames[k // 2]
+        t = sim.submit(bufs[k % ring][:, :w], src[:, :w], field, k, bob=bob, same_src=not new)
+        tickets.append(t)
+        src[:, :w] = 0xEE              # the caller may rewrite src as soon as submit returns
+        j = k - lag
+        if j >= 0:
+            sim.wait(tickets[j])
+            snaps[j] = bufs[j % ring][:, :w].copy()
+            assert (bufs[j % ring][:, w:] == fill).all(), "padding bytes were written"
+    for j in range(max(0, n_fields - lag), n_fields):
+        sim.wait(tickets[j])
+        snaps[j] = bufs[j % ring][:, :w].copy()
+    assert tickets == list(range(tickets[0], tickets[0] + n_fields))
+    sim.host_unpin()       # the frames are about to be freed: drop the engine's registrations first
+    return snaps
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bob", [False, True])
+@pytest.mark.parametrize("pin", [False, True])
+def test_submit_wait_equals_the_synchronous_loop(bob, pin):
+    """Small frames, depth 4, a ring as deep as the lag: every snapshot == the oracle's loop, the rand()
+    position == the oracle's; both delivery paths (pinned in place / staging ring)."""
+    w, h, n = 96, 32, 26
+    p = L.make_params(["-vhs"])
+    frames = [L.noise_frame(w, h, 700 + j) for j in range(n // 2)]
+    ring, lag = 12, 9
+    exp, exp_pos = reference_loop(p, frames, n, w, h, ring, bob)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.submit_configure(depth=4, slots=16, lanes=2, pin=pin, min_pin_bytes=0)
+    got = run_submit_loop(sim, frames, n, w, h, ring, bob, lag, pad=8)
+    for k in range(n):
+        assert np.array_equal(got[k], exp[k]), "field %d" % k
+    assert sim.rng_pos == exp_pos
+    st = sim.submit_stats()
+    assert st["submitted"] == n and st["uploads"] == n // 2
+    if pin:
+        assert st["delivered_direct"] == n and st["delivered_staged"] == 0 and st["uploads_staged"] == 0
+    else:
+        assert st["delivered_staged"] == n and st["registrations"] == 0
+    # ... and the synchronous call continues the same stream on the same ctx
+    o = L.OracleStream(p)
+    o.skip(exp_pos)
+    a = np.zeros((h, w, 4), np.uint8)
+    b = np.zeros((h, w, 4), np.uint8)
+    sim.field_host(a, frames[0], 1, n)
+    o.field(b, frames[0], 1, n)
+    assert np.array_equal(a, b) and sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_submit_at_the_baseline_size_default_options():
+    """720x486 -vhs with the default engine (depth 32, pinned caller frames): 150 fields through a ring of
+    40 frames, bob on; compared with the oracle on a sample of fields and with the synchronous ntscsim_field()
+    loop on all of them."""
+    w, h, n = 720, 486, 150
+    p = L.make_params(["-vhs"])
+    frames = [L.bars(w, h, j) for j in range(n // 2)]
+    ring, lag = 40, 36
+    sim = ntscsim.FieldSimulator(params=p)
+    got = run_submit_loop(sim, frames, n, w, h, ring, True, lag)
+    st = sim.submit_stats()
+    assert st["delivered_direct"] == n and st["uploads_staged"] == 0, st
+    assert "k_decode_fast<true,double>" in sim.last_kernels()
+    pos_async = sim.rng_pos
+    sim.close()
+    # the synchronous loop on the product
+    sim2 = ntscsim.FieldSimulator(params=p)
+    bufs = [np.full((h, w, 4), 0x5A, np.uint8) for _ in range(ring)]
+    for k in range(n):
+        field = (k & 1) ^ 1
+        sim2.field_host(bufs[k % ring], frames[k // 2], field, k)
+        oracle_bob(bufs[k % ring], field)
+        assert np.array_equal(got[k], bufs[k % ring]), "field %d" % k
+    assert sim2.rng_pos == pos_async
+    sim2.close()
+    # the oracle on a few of them (explicit rand() positions)
+    from ntscsim import shard
+    for k in (0, 1, 77, n - 1):
+        o = L.OracleStream(p)
+        o.skip(shard.rng_pos_of_field(p, w, h, k))
+        e = got[k].copy()
+        field = (k & 1) ^ 1
+        rows = e[field::2].copy()
+        e[field::2] = 0
+        o.field(e, frames[k // 2], field, k)
+        assert np.array_equal(e[field::2], rows), "field %d vs oracle" % k
+
+
+@pytest.mark.gpu
+def test_two_fields_in_flight_share_one_destination_frame():
+    """Without bob the two fields of a frame write disjoint rows of ONE dst frame, as in the reference with
+    `-d 1`; in flight together they must both land, other rows untouched until their own field arrives."""
+    w, h, n = 96, 32, 12
+    p = L.make_params([])
+    frames = [L.noise_frame(w, h, 900 + j) for j in range(n // 2)]
+    exp, exp_pos = reference_loop(p, frames, n, w, h, 1, False)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.submit_configure(depth=2, slots=8, lanes=2, min_pin_bytes=0)
+    src = np.zeros((h, w, 4), np.uint8)
+    dst = np.full((h, w, 4), 0x5A, np.uint8)
+    for k in range(0, n, 2):
+        src[:] = frames[k // 2]
+        t0 = sim.submit(dst, src, (k & 1) ^ 1, k)
+        t1 = sim.submit(dst, src, ((k + 1) & 1) ^ 1, k + 1, same_src=True)
+        sim.wait(t1)
+        assert t1 == t0 + 1
+        assert np.array_equal(dst, exp[k + 1]), "pair %d" % k
+    assert sim.rng_pos == exp_pos
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_geometry_change_unaligned_rows_and_interlaced_source():
+    """A width whose rows are not 16-byte aligned (generic kernels, 4-byte delivery), then another geometry on
+    the same ctx (the engine drains and rebuilds its rings), interlaced source flags passed through."""
+    p = L.make_params(["-vhs", "-vhs-speed", "ep"])
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.submit_configure(depth=3, slots=6, lanes=1, min_pin_bytes=0)
+    o = L.OracleStream(p)
+    k = 0
+    for (w, h, inter, tff) in ((50, 21, 0, 0), (96, 32, 1, 1), (50, 21, 1, 0)):
+        fr = [L.noise_frame(w, h, 1000 + w + j) for j in range(4)]
+        exp = [np.full((h, w, 4), 7, np.uint8) for _ in range(8)]
+        got = [np.full((h, w, 4), 7, np.uint8) for _ in range(8)]
+        ts = []
+        for i in range(8):
+            field = (k & 1) ^ 1
+            o.field(exp[i], fr[i // 2], field, k, interlaced=inter, tff=tff)
+            ts.append(sim.submit(got[i], fr[i // 2].copy(), field, k, interlaced=inter, tff=tff))
+            k += 1
+        sim.wait()
+        for i in range(8):
+            assert np.array_equal(got[i], exp[i]), (w, h, i)
+        assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_submit_errors_consume_nothing_and_tickets_are_checked():
+    w, h = 96, 32
+    p = L.make_params([])
+    sim = ntscsim.FieldSimulator(params=p)
+    lib = sim._lib
+    a = np.zeros((h, w, 4), np.uint8)
+    b = np.zeros((h, w, 4), np.uint8)
+    t = C.c_uint64(99)
+    args = (a.ctypes.data, w * 4, 0, 0, b.ctypes.data, w * 4, w, h)
+    assert lib.ntscsim_submit(sim._h, None, w * 4, 0, 0, b.ctypes.data, w * 4, w, h, 0, 0, 0, C.byref(t)) == _capi.E_ARG
+    assert lib.ntscsim_submit(sim._h, a.ctypes.data, w * 4 - 4, 0, 0, b.ctypes.data, w * 4, w, h, 0, 0, 0, C.byref(t)) == _capi.E_SIZE
+    assert lib.ntscsim_submit(sim._h, *args, 2, 0, 0, C.byref(t)) == _capi.E_ARG            # field > 1
+    assert lib.ntscsim_submit(sim._h, *args, 0, 0, 0x4, C.byref(t)) == _capi.E_ARG          # unknown flag
+    assert t.value == 99 and sim.rng_pos == 0 and sim.submit_stats()["submitted"] == 0
+    assert lib.ntscsim_wait(sim._h, 1) == _capi.E_ARG                                       # never issued
+    assert lib.ntscsim_wait(sim._h, _capi.TICKET_ALL) == _capi.OK
+    assert lib.ntscsim_submit(sim._h, *args, 1, 0, 0, C.byref(t)) == _capi.OK and t.value == 1
+    assert lib.ntscsim_wait(sim._h, 2) == _capi.E_ARG
+    assert lib.ntscsim_flush(sim._h) == _capi.OK
+    assert lib.ntscsim_wait(sim._h, 1) == _capi.OK
+    assert lib.ntscsim_wait(sim._h, 1) == _capi.OK                                          # again: already done
+    o = _capi.SubmitOpts()
+    lib.ntscsim_submit_opts_init(C.byref(o))
+    assert (o.depth, o.slots, o.lanes, o.pin_caller_buffers) == (32, 128, 3, 1)
+    o.slots = o.depth          # < 2 * depth
+    assert lib.ntscsim_submit_configure(sim._h, C.byref(o)) == _capi.E_ARG
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_ring_full_blocks_and_unpin_releases():
+    """More submits than ring slots without a single wait: the engine retires the oldest launches itself (their
+    rows land in the caller's frames) and keeps going; ntscsim_host_unpin() drops the registrations."""
+    w, h, n = 96, 32, 40
+    p = L.make_params(["-vhs"])
+    frames = [L.noise_frame(w, h, 1200 + j) for j in range(n // 2)]
+    exp, exp_pos = reference_loop(p, frames, n, w, h, n, False)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.submit_configure(depth=4, slots=8, lanes=3, min_pin_bytes=0)
+    bufs = [page_frame(h, w, 0x5A) for _ in range(n)]
+    for k in range(n):
+        sim.submit(bufs[k], frames[k // 2], (k & 1) ^ 1, k, same_src=bool(k & 1))
+    sim.wait()
+    for k in range(n):
+        assert np.array_equal(bufs[k], exp[k]), k
+    st = sim.submit_stats()
+    assert st["ring_full_waits"] > 0 and st["registrations"] > 0
+    sim.host_unpin()
+    assert sim.submit_stats()["registrations"] == 0
+    assert sim.rng_pos == exp_pos
+    sim.close()
+
+
+def test_submit_opts_defaults_without_a_gpu():
+    """(CPU) the options POD and its defaults; submit on a NULL ctx is an argument error, not a crash."""
+    lib = ntscsim.lib()
+    o = _capi.SubmitOpts()
+    lib.ntscsim_submit_opts_init(C.byref(o))
+    assert o.struct_size == C.sizeof(_capi.SubmitOpts) and o.depth == 32 and o.min_pin_bytes == 256 << 10
+    assert lib.ntscsim_submit(None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, None) == _capi.E_ARG
+    assert lib.ntscsim_wait(None, 1) == _capi.E_ARG
+    assert lib.ntscsim_flush(None) == _capi.E_ARG
