@@ -200,6 +200,93 @@ def device_rate(torch, ntscsim, dev, local_rank, flags, w, h, n_frames, reps, in
     return len(jobs) / dt
 
 
+def device_stream_rate(torch, ntscsim, dev, local_rank, params, w, h, n_frames, steps, inflight, threads=2):
+    """A device-resident STREAM of fresh batches (not a replay of a prepared one): step s is the NEXT 2 * n_frames
+    fields of one long stream -- fieldno = s * nf + k, rand() position continuing where step s - 1 ended -- sent
+    through ntscsim_fields_device(), i.e. descriptor validation, rand() window derivation per field, record
+    upload and the kernel chain are all inside the clock.  `inflight` contexts (own stream, scratch, destination
+    clip) take the steps round-robin; `threads` host threads drive them (ctypes releases the GIL, a ctx is only
+    ever used by one thread), so the preparation of one step overlaps the GPU work of the others.
+    Returns (fields/s, verified): verified = the last step's output equals the same fields run as one
+    ordinary batch with explicit rand() positions on a fresh context."""
+    import threading
+    import numpy as np
+    from ntscsim import _capi
+    nf = 2 * n_frames
+    src = make_bars_clip(torch, n_frames, w, h, 0, 1, dev)
+    calls = [ntscsim.calls_per_field(params, w, h, 0), ntscsim.calls_per_field(params, w, h, 1)]
+    draws_per_step = sum(calls[(k & 1) ^ 1] for k in range(nf))
+    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("sls", "<i4"), ("dls", "<i4"), ("field", "<u4"),
+                   ("flags", "<u4"), ("fieldno", "<u8"), ("rng_pos", "<u8")])
+    assert dt.itemsize == C_sizeof_field_desc()
+    loc = [(k // 2, k // 2, (k & 1) ^ 1, k) for k in range(nf)]
+    ctxs = []
+    for q in range(inflight):
+        sm = ntscsim.FieldSimulator(params=params, device=local_rank)
+        d = torch.zeros((n_frames, h, w, 4), dtype=torch.uint8, device=dev)
+        arr = sm.build_descs(src, d, loc)                 # rng_pos: AUTO (continue after the previous descriptor)
+        view = np.frombuffer(arr, dtype=dt)
+        st = torch.cuda.Stream(dev)
+        ctxs.append((sm, d, arr, view, st, [None, None]))
+    k_idx = np.arange(nf, dtype=np.uint64)
+
+    def run_step(s):
+        sm, d, arr, view, st, evs = ctxs[s % inflight]
+        ev = evs[(s // inflight) & 1]
+        if ev is not None:
+            ev.synchronize()                              # at most two steps queued per context
+        view["fieldno"] = np.uint64(s * nf) + k_idx
+        view["rng_pos"][0] = s * draws_per_step           # explicit for the first field, the rest follow it
+        sm.run_descs(arr, w, h, stream=st.cuda_stream)
+        e = torch.cuda.Event()
+        e.record(st)
+        evs[(s // inflight) & 1] = e
+
+    def worker(j, first, count, bar):
+        torch.cuda.set_device(local_rank)
+        bar.wait()
+        for s in range(first, first + count):
+            if (s % inflight) % threads == j:
+                run_step(s)
+
+    def timed(first, count):
+        bar = threading.Barrier(threads + 1)
+        th = [threading.Thread(target=worker, args=(j, first, count, bar)) for j in range(threads)]
+        for t in th:
+            t.start()
+        torch.cuda.synchronize(dev)
+        bar.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    timed(0, 2 * inflight)                                # first-call allocations
+    el = timed(2 * inflight, steps)
+    last = 2 * inflight + steps - 1
+    got = ctxs[last % inflight][1]
+    chk = ntscsim.FieldSimulator(params=params, device=local_rank)
+    d2 = torch.zeros_like(got)
+    pos, rp = last * draws_per_step, []
+    for k in range(nf):
+        rp.append(pos)
+        pos += calls[(k & 1) ^ 1]
+    chk.fields(src, d2, [(k // 2, k // 2, (k & 1) ^ 1, last * nf + k) for k in range(nf)], rng_pos=rp)
+    chk.sync()
+    ok = bool(torch.equal(got, d2))
+    chk.close()
+    for sm, *_ in ctxs:
+        sm.close()
+    return steps * nf / el, ok
+
+
+def C_sizeof_field_desc():
+    import ctypes
+    import ntscsim
+    return ctypes.sizeof(ntscsim.FieldDesc)
+
+
 def variant_contexts(torch, ntscsim, dev, local_rank, args, nq):
     """The 8-bit YUV422P tool (ffmpeg_to_composite): nq contexts, each with 2 x frames colour-bars
     YUV422P frames resident in HBM (every field its own frame, processed in place), its descriptor
@@ -325,15 +412,18 @@ def main_to_composite(args):
         except Exception:
             pass
         out = {
-            "metric": "frames/sec (ffmpeg_to_composite: output frames = fields; 720x486 YUV422P, full VHS preset; "
-                      "steady-state pipelined throughput, %d steps in flight)" % nq,
+            "metric": "frames/sec (ffmpeg_to_composite: output frames = fields; %dx%d YUV422P, preset '%s'; "
+                      "steady-state pipelined throughput, %d steps in flight)" % (w, h, args.preset if args.preset.strip() else "default", nq),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%d YUV422P colour-bars frames, preset '%s': %d fields per GPU per step, every "
                                    "field its own frame, processed in place (composite_video_process per field)"
                                    % (w, h, args.preset, nf),
-                       "tool": "to_composite", "steps_in_flight": nq},
+                       "tool": "to_composite", "steps_in_flight": nq,
+                       "pre_roll": None if sustained is None else
+                           {"steps": sustained[0], "seconds": sustained[1],
+                            "note": "untimed steps of the same work before the W warm-up steps (= the value_sustained leg)"}},
             "roofline": {"bound": "hbm", "kernel": "k422_fused", "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms else 0.0,
@@ -574,6 +664,20 @@ def extras(torch, ntscsim, dev, local_rank, args):
         del cap_dev, fr
     except Exception as e:
         out["raw28_error"] = repr(e)
+    # ---- a device-resident stream of FRESH batches (the headline replays prepared ones)
+    try:
+        best, ok_all = 0.0, True
+        for _ in range(2):
+            v_, ok_ = device_stream_rate(torch, ntscsim, dev, local_rank, params, w, h, args.frames, 48, args.inflight, threads=2)
+            best, ok_all = max(best, v_), ok_all and ok_
+        out["device_stream"] = {
+            "value": best, "unit": "frames/s", "verified_last_step": ok_all,
+            "workload": "%dx%d, preset '%s': every step is the NEXT %d fields of one long stream (new fieldno and "
+                        "rand() position per field) through ntscsim_fields_device() -- descriptor validation, rand() "
+                        "window derivation, record upload and the kernel chain inside the clock; %d contexts, 2 host "
+                        "threads; 48 steps, best of 2" % (w, h, args.preset, 2 * args.frames, args.inflight)}
+    except Exception as e:
+        out["device_stream"] = {"error": repr(e)}
     # ---- other sizes / presets on the BGRA path
     out["sizes"] = {
         "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 136, 8, args.inflight),
@@ -898,8 +1002,9 @@ def main():
             deal = "one %d-frame clip (%d fields per step) dealt frame-round-robin over %d GPU(s)" % (
                 args.frames, 2 * args.frames, world)
         out = {
-            "metric": "frames/sec (output frames = fields; 720x486 NTSC, full VHS preset; steady-state "
-                      "pipelined throughput, %d steps in flight)" % nq,
+            "metric": "frames/sec (output frames = fields; %dx%d %s, preset '%s'; steady-state "
+                      "pipelined throughput, %d steps in flight)" % (w, h, "PAL" if params.tv_standard else "NTSC",
+                                                                      args.preset if args.preset.strip() else "default", nq),
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -916,6 +1021,12 @@ def main():
                 "fields_per_step_per_gpu": fields_all if world > 1 else fields_per_step_local,
                 "input_frames_per_sec": value / 2.0,
                 "steps_in_flight": nq,
+                "pre_roll": None if sustained is None else
+                    {"steps": sustained[0], "seconds": sustained[1],
+                     "note": "untimed steps of the same work BEFORE the W warm-up steps (= the value_sustained leg; "
+                             "--sustain-seconds 0 removes it): a GPU that has just left idle needs ~30 ms of load "
+                             "before its clocks settle, the driver's W is ~4 ms of work.  Numbers of earlier rounds "
+                             "measured without it (r01, r02) are ~4-6 % lower for that reason alone"},
                 "rank_checksums": allcs,
                 "rank_checksums_verified": verified,
                 "rank_checksums_note": None if dist is None else

@@ -1398,10 +1398,48 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
 // chunk slots, so the PCIe transfers of neighbouring chunks overlap the kernels (and each other:
 // the link is full duplex).  The caller's buffers are pinned in place (hipHostRegister) for the
 // duration of the call; if that fails the copies still work, just synchronously.
+// Pin two caller buffers in place for the duration of a call (whole pages, explicitly).  Small buffers are not
+// worth a registration, and two registrations must never share a page: small heap allocations often do, and
+// unpinning the first one then pulls the page from under the second (seen as sporadic aborts inside later,
+// unrelated hipMemcpy calls of the process).
+struct HostPins {
+    uintptr_t s0 = 0, d0 = 0;
+    bool pin_src = false, pin_dst = false;
+    void pin(const void *src, size_t src_span, void *dst, size_t dst_span, unsigned flags)
+    {
+        const uintptr_t PG = 4096, MIN_PIN = 1u << 20;
+        uintptr_t s1 = ((uintptr_t)src + src_span + PG - 1) & ~(PG - 1);
+        uintptr_t d1 = ((uintptr_t)dst + dst_span + PG - 1) & ~(PG - 1);
+        s0 = (uintptr_t)src & ~(PG - 1);
+        d0 = (uintptr_t)dst & ~(PG - 1);
+        bool want_src = src_span >= MIN_PIN, want_dst = dst_span >= MIN_PIN;
+        if (want_src && want_dst && s0 < d1 && d0 < s1) {          // page ranges touch: one registration
+            s0 = s0 < d0 ? s0 : d0; s1 = s1 > d1 ? s1 : d1;
+            want_dst = false;
+        } else if (s0 < d1 && d0 < s1) {
+            want_src = want_dst = false;                            // a small buffer inside the other's pages
+        }
+        pin_src = want_src && hipHostRegister((void *)s0, s1 - s0, flags) == hipSuccess;
+        pin_dst = want_dst && hipHostRegister((void *)d0, d1 - d0, flags) == hipSuccess;
+        (void)hipGetLastError();
+    }
+    void unpin()
+    {
+        if (pin_src) (void)hipHostUnregister((void *)s0);
+        if (pin_dst) (void)hipHostUnregister((void *)d0);
+        pin_src = pin_dst = false;
+    }
+};
+
+// Deal: the call works on the frames of blocks blk_index, blk_index + blk_count, ... (blocks of blk_frames frames) of
+// the run only -- the share of one context of a pool (ntscsim_pool_frames_host); blk_count = 1: all of them.  Every
+// block starts from its closed-form rand() position (the draws per field do not depend on the data), so the union of
+// the shares is the sequential run.  pin = false: the caller has pinned the buffers already.
 static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const uint8_t *src, size_t src_frame_stride,
                             int src_ls, int n_frames, uint8_t *dst, size_t dst_frame_stride,
                             int dst_ls, int W, int H, uint64_t first_fieldno, uint32_t flags,
-                            int chunk_frames)
+                            int chunk_frames, int blk_frames = 0, int blk_index = 0, int blk_count = 1,
+                            bool pin = true)
 {
     if (!c || !src || !dst || n_frames < 0) return NTSCSIM_E_ARG;
     if (n_frames == 0) return NTSCSIM_OK;
@@ -1446,23 +1484,8 @@ static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const 
                              : ((size_t)dst_ls == pitch && dst_frame_stride == fbytes);
     const size_t src_span = src_frame_stride * (size_t)(n_frames - 1) + (S ? S->frame_bytes : (size_t)src_ls * H);
     const size_t dst_span = dst_frame_stride * (size_t)(2 * n_frames - 1) + obytes_h;
-    // Pin the caller's buffers in place for the duration of the call (whole pages, explicitly).
-    // Small buffers are not worth a registration, and two registrations must never share a page:
-    // small heap allocations often do, and unpinning the first one then pulls the page from under
-    // the second (seen as sporadic aborts inside later, unrelated hipMemcpy calls of the process).
-    const uintptr_t PG = 4096, MIN_PIN = 1u << 20;
-    uintptr_t s0 = (uintptr_t)src & ~(PG - 1), s1 = ((uintptr_t)src + src_span + PG - 1) & ~(PG - 1);
-    uintptr_t d0 = (uintptr_t)dst & ~(PG - 1), d1 = ((uintptr_t)dst + dst_span + PG - 1) & ~(PG - 1);
-    bool want_src = src_span >= MIN_PIN, want_dst = dst_span >= MIN_PIN;
-    if (want_src && want_dst && s0 < d1 && d0 < s1) {          // page ranges touch: one registration
-        s0 = s0 < d0 ? s0 : d0; s1 = s1 > d1 ? s1 : d1;
-        want_dst = false;
-    } else if (s0 < d1 && d0 < s1) {
-        want_src = want_dst = false;                            // a small buffer inside the other's pages
-    }
-    const bool pin_src = want_src && hipHostRegister((void *)s0, s1 - s0, hipHostRegisterDefault) == hipSuccess;
-    const bool pin_dst = want_dst && hipHostRegister((void *)d0, d1 - d0, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
+    HostPins pins;
+    if (pin) pins.pin(src, src_span, dst, dst_span, hipHostRegisterDefault);
 
     struct Slot { uint8_t *dsrc = nullptr, *ddst = nullptr, *dyuv = nullptr, *draw = nullptr; YuvDev *yrec = nullptr; ScaleDev *srec = nullptr;
                   hipEvent_t up = nullptr, done = nullptr, down = nullptr; bool used = false; };
@@ -1522,11 +1545,27 @@ static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const 
     std::memset(&Dyuv, 0, sizeof(Dyuv));
     Dyuv.W = W; Dyuv.H = H;
     std::vector<ntscsim_field_desc> descs((size_t)chunk_frames * 2);
-    uint64_t cur = first_fieldno;
+    // the chunks of this call: all frames, or this context's blocks of a dealt run
+    std::vector<std::pair<int, int>> chunks;        // (first frame, frames)
+    const bool dealt = blk_count > 1 && blk_frames > 0;
+    if (!dealt)
+        for (int f0 = 0; f0 < n_frames; f0 += chunk_frames)
+            chunks.push_back({f0, (n_frames - f0 < chunk_frames) ? n_frames - f0 : chunk_frames});
+    else
+        for (int b0 = blk_index * blk_frames; b0 < n_frames; b0 += blk_count * blk_frames) {
+            const int bend = b0 + blk_frames < n_frames ? b0 + blk_frames : n_frames;
+            for (int f0 = b0; f0 < bend; f0 += chunk_frames)
+                chunks.push_back({f0, (bend - f0 < chunk_frames) ? bend - f0 : chunk_frames});
+        }
+    // rand() draws of one frame (two consecutive fields, whatever their order)
+    const uint64_t frame_draws = ntscsim_rng_calls_per_field(&c->prm, W, H, 0) + ntscsim_rng_calls_per_field(&c->prm, W, H, 1);
+    const uint64_t rng_base = c->rng_pos;
     int chunk_no = 0;
-    for (int f0 = 0; f0 < n_frames && rc == NTSCSIM_OK; f0 += chunk_frames, chunk_no++) {
+    for (size_t ci = 0; ci < chunks.size() && rc == NTSCSIM_OK; ci++, chunk_no++) {
         Slot &sl = slot[chunk_no & 1];
-        const int nf = (n_frames - f0 < chunk_frames) ? n_frames - f0 : chunk_frames;
+        const int f0 = chunks[ci].first, nf = chunks[ci].second;
+        uint64_t cur = first_fieldno + 2ull * (uint64_t)f0;
+        if (dealt) c->rng_pos = rng_base + (uint64_t)f0 * frame_draws;
         // the slot's previous download must have left the device buffers
         if (sl.used) { if (fail(hipEventSynchronize(sl.down), "hipEventSynchronize")) break; }
         // H2D: nf frames, row by row into the device pitch (or, for a scaled source, as they are)
@@ -1608,8 +1647,8 @@ static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const 
     (void)hipStreamSynchronize(s_up);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(s_dn);
-    if (pin_src) (void)hipHostUnregister((void *)s0);
-    if (pin_dst) (void)hipHostUnregister((void *)d0);
+    if (dealt && rc == NTSCSIM_OK) c->rng_pos = rng_base + (uint64_t)n_frames * frame_draws;   // the whole run's end
+    pins.unpin();
     return rc;
 }
 
@@ -1650,3 +1689,6 @@ extern "C" int ntscsim_debug_read_composite(ntscsim_ctx *c, int32_t *out, size_t
 
 // ---- asynchronous host-frame drop-in: ntscsim_submit() / ntscsim_wait()
 #include "ntscsim_submit.hip"
+
+// ---- a pool of contexts over several GPUs: ntscsim_pool_*()
+#include "ntscsim_pool.hip"

@@ -166,9 +166,12 @@ static int parse_argv_impl(ntscsim_params *p, ntscsim_cli *cli, int argc, const 
         } else if (tocomp && (!std::strcmp(a, "ss") || !std::strcmp(a, "se") || !std::strcmp(a, "t") ||
                               !std::strcmp(a, "a") || !std::strcmp(a, "v"))) {
             if (!next(v)) return NTSCSIM_E_FLAG;      // media-layer switches :1368-1392, not DSP
-        } else if (tocomp && (!std::strcmp(a, "an") || !std::strcmp(a, "vn") || !std::strcmp(a, "vi") ||
-                              !std::strcmp(a, "vp"))) {
-            // :1393-1404 stream selection / interlaced-vs-bob output: media layer
+        } else if (tocomp && !std::strcmp(a, "vi")) {
+            cli->output_video_as_interlaced = 1;                        // :1399-1401
+        } else if (tocomp && !std::strcmp(a, "vp")) {
+            cli->output_video_as_interlaced = 0;                        // :1402-1404
+        } else if (tocomp && (!std::strcmp(a, "an") || !std::strcmp(a, "vn"))) {
+            // :1393-1398 stream selection: media layer
         } else if (!std::strcmp(a, "o")) {
             if (!next(v)) return NTSCSIM_E_FLAG;
             cli->output_path = v;

@@ -49,6 +49,8 @@ void usage(const char *arg0)
         " (audio only, accepted: -preemphasis -deemphasis -audio-hiss -vhs-linear-video-crosstalk\n"
         "  -vhs-linear-high-boost)\n"
         " extra (not in the reference): --batch <fields per GPU batch, default 512> --height <n>\n"
+        "                               --gpus <n> | --devices <a,b,...>   (frames dealt round-robin in blocks of 32 over\n"
+        "                               n contexts, one per GPU; an ordinal may repeat; default: one context on GPU 0)\n"
         "                               --ghost <delay px>:<gain/256>  (multipath ghost tap, up to 4)\n",
         arg0);
 }
@@ -129,11 +131,22 @@ int main(int argc, char **argv)
     // pull out the two switches the reference does not have, pass the rest to the mirror parser
     int batch_fields = 512, height_override = 0;   // 512: the up / kernels / down pipeline of a batch has room to overlap
     int ghost_n = 0, ghost_d[4] = {0, 0, 0, 0}, ghost_g[4] = {0, 0, 0, 0};
+    int gpus = 1;
+    std::vector<int> devices;
     std::vector<const char *> av;
     av.push_back(argv[0]);
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) { batch_fields = std::atoi(argv[++i]); continue; }
         if (!std::strcmp(argv[i], "--height") && i + 1 < argc) { height_override = std::atoi(argv[++i]); continue; }
+        if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = std::atoi(argv[++i]); continue; }
+        if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {
+            for (const char *q = argv[++i]; *q;) {
+                devices.push_back(std::atoi(q));
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+            continue;
+        }
         if (!std::strcmp(argv[i], "--ghost") && i + 1 < argc) {       // extension: <delay>:<gain/256>
             int dd = 0, gg = 0;
             if (std::sscanf(argv[++i], "%d:%d", &dd, &gg) != 2 || ghost_n >= 4) { std::fprintf(stderr, "bad --ghost\n"); return 1; }
@@ -176,22 +189,30 @@ int main(int argc, char **argv)
         if (!out) { std::fprintf(stderr, "Failed to open %s\n", ospec.c_str()); return 1; }
     }
 
-    ntscsim_ctx *sim = nullptr;
-    rc = ntscsim_create(&prm, 0, &sim);
-    if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_create: %s\n", ntscsim_strerror(rc)); return 1; }
+    // one context per GPU (north_star: "partition the input stream frame-round-robin"): ntscsim_pool_*; the
+    // layered path below (several -i) composites on the pool's first context
+    if (gpus < 1 || gpus > 64) { std::fprintf(stderr, "--gpus 1..64\n"); return 1; }
+    if (devices.empty()) { int nd = 0; (void)hipGetDeviceCount(&nd); for (int g = 0; g < gpus; g++) devices.push_back(nd > 0 ? g % nd : 0); }
+    ntscsim_pool *pool = nullptr;
+    rc = ntscsim_pool_create(&prm, devices.data(), (int)devices.size(), &pool);
+    if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_pool_create: %s\n", ntscsim_strerror(rc)); return 1; }
+    ntscsim_ctx *sim = ntscsim_pool_ctx(pool, 0);
+    HIPOK(hipSetDevice(devices[0]));
 
     const int nframes_batch = batch_fields / 2;
     uint8_t *d_src = nullptr, *d_dst = nullptr, *h_srcs[2] = {nullptr, nullptr}, *h_dst = nullptr;
     HIPOK(hipMalloc((void **)&d_src, fbytes * nframes_batch));
     HIPOK(hipMalloc((void **)&d_dst, fbytes * batch_fields));
-    for (int i = 0; i < 2; i++) HIPOK(hipHostMalloc((void **)&h_srcs[i], fbytes * nframes_batch, hipHostMallocDefault));
-    HIPOK(hipHostMalloc((void **)&h_dst, fbytes * batch_fields, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++) HIPOK(hipHostMalloc((void **)&h_srcs[i], fbytes * nframes_batch, hipHostMallocPortable));
+    HIPOK(hipHostMalloc((void **)&h_dst, fbytes * batch_fields, hipHostMallocPortable));
     HIPOK(hipMemset(d_dst, 0, fbytes * batch_fields));   // ring frames start zeroed (:2088)
     {
         // one-off initialisation outside the clock: code objects, streams, chunk slots
-        const int nw = nframes_batch < 32 ? nframes_batch : 32;
+        int nw = 32 * ntscsim_pool_size(pool);           // one block per context
+        if (nw > nframes_batch) nw = nframes_batch;
         std::memset(h_srcs[0], 0, fbytes * nw);
-        (void)ntscsim_frames_host(sim, h_srcs[0], fbytes, W * 4, nw, h_dst, fbytes, W * 4, W, H, 0, NTSCSIM_DESC_BOB, 32);
+        (void)ntscsim_pool_frames_host(pool, h_srcs[0], fbytes, W * 4, nw, h_dst, fbytes, W * 4, W, H, 0, NTSCSIM_DESC_BOB, 32);
+        ntscsim_pool_set_rng_pos(pool, 0);
         ntscsim_set_rng_pos(sim, 0);
     }
 
@@ -246,7 +267,7 @@ int main(int argc, char **argv)
                     for (size_t li = 0; li + 1 < inputs.size(); li++)
                         any = read_frame(inputs[li], scratch.data(), W, H) || any;
                     uint8_t *dstf = buf + fbytes * nf;
-                    if (read_frame(top, dstf, W, H)) { any = true; std::memcpy(top_last.data(), dstf, fbytes); }
+                    if (read_frame(top, dstf, W, H)) { any = true; if (layered) std::memcpy(top_last.data(), dstf, fbytes); }
                     else std::memcpy(dstf, top_last.data(), fbytes);       // ended: its last frame (black if it never had one)
                     if (!any) { eof = true; break; }                       // every input has ended
                 }
@@ -256,7 +277,8 @@ int main(int argc, char **argv)
         }
     });
     // On the normal way out the reader has finished and is joined.  On an error return it may be sitting in
-    // fread() on a pipe nobody writes to any more: it is told to stop and detached, never waited for.
+    // fread() on a pipe nobody writes to any more, holding references into main()'s frame: the process ends
+    // right there (std::_Exit) instead of unwinding under it.
     struct Joiner {
         std::thread &t; std::mutex &m; std::condition_variable &c; bool &stop; bool done = false;
         ~Joiner()
@@ -264,7 +286,13 @@ int main(int argc, char **argv)
             { std::lock_guard<std::mutex> lk(m); stop = true; }
             c.notify_all();
             if (!t.joinable()) return;
-            if (done) t.join(); else t.detach();
+            if (done) t.join();
+            else {
+                // error return: the reader may be blocked in fread() on a pipe nobody writes to any more and it
+                // references main()'s stack -- never unwind under it: leave the process here
+                std::fflush(nullptr);
+                std::_Exit(1);
+            }
         }
     } joiner{reader, mu, cv, stop};
     for (int b = 0;; b ^= 1) {
@@ -278,10 +306,11 @@ int main(int argc, char **argv)
         if (!layered) {
             // one input: the library's own field loop over host frames (H2D | kernels | D2H pipelined
             // in chunks; field = (current & 1) ^ 1, fieldno = current, sequential rand() stream)
-            rc = ntscsim_frames_host(sim, h_src, fbytes, W * 4, nf, h_dst, fbytes, W * 4, W, H, current,
-                                     NTSCSIM_DESC_BOB, 32);
+            // (with more than one context: blocks of 32 frames dealt round-robin, each context its own pipeline)
+            rc = ntscsim_pool_frames_host(pool, h_src, fbytes, W * 4, nf, h_dst, fbytes, W * 4, W, H, current,
+                                          NTSCSIM_DESC_BOB, 32);
             if (rc != NTSCSIM_OK) {
-                std::fprintf(stderr, "ntscsim_frames_host: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim));
+                std::fprintf(stderr, "ntscsim_pool_frames_host: %s (%s)\n", ntscsim_strerror(rc), ntscsim_pool_last_error(pool));
                 return 1;
             }
         } else {
@@ -336,10 +365,10 @@ int main(int argc, char **argv)
     }
     joiner.done = true;
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::fprintf(stderr, "\n%llu fields in %.3f s (%.1f fields/s incl. host I/O)\n", total_fields, dt,
-                 dt > 0 ? total_fields / dt : 0.0);
+    std::fprintf(stderr, "\n%llu fields in %.3f s (%.1f fields/s incl. host I/O) on %d context(s)\n", total_fields, dt,
+                 dt > 0 ? total_fields / dt : 0.0, ntscsim_pool_size(pool));
     if (out && out != stdout) std::fclose(out);
-    ntscsim_destroy(sim);
+    ntscsim_pool_destroy(pool);
     (void)hipFree(d_src); (void)hipFree(d_dst); (void)hipHostFree(h_srcs[0]); (void)hipHostFree(h_srcs[1]); (void)hipHostFree(h_dst);
     return 0;
 }

@@ -11,7 +11,7 @@ from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, Field422Desc,
                     NtscsimError, Out422Desc, YuvDesc, ScaleDesc, HostSource, Params, lib, make_params,
                     make_params_to_composite)
 
-__all__ = ["FieldSimulator", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
+__all__ = ["FieldSimulator", "Pool", "Params", "FieldDesc", "make_params", "NtscsimError", "lib",
            "field_rows", "calls_per_field", "field_schedule"]
 
 
@@ -369,6 +369,59 @@ class FieldSimulator:
             self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size)
         self._chk(rc, "ntscsim_debug_read_composite")
         return a
+
+
+class Pool:
+    """ntscsim_pool_*: one context per GPU (an ordinal may repeat), a run of host frames dealt block-cyclically
+    over them -- byte-identical to one FieldSimulator.frames_host() over the whole run."""
+
+    def __init__(self, flags=(), devices=(0,), params=None, block_frames=None):
+        self.params = params if params is not None else make_params(flags)
+        self._lib = lib()
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.ntscsim_pool_create(C.byref(self.params), devs, len(devices), C.byref(h))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_pool_create(%r)" % (list(devices),))
+        self._h = h
+        if block_frames is not None:
+            rc = self._lib.ntscsim_pool_set_block(self._h, int(block_frames))
+            if rc != _capi.OK:
+                raise NtscsimError(rc, "ntscsim_pool_set_block")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ntscsim_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return int(self._lib.ntscsim_pool_size(self._h))
+
+    @property
+    def rng_pos(self):
+        return int(self._lib.ntscsim_pool_get_rng_pos(self._h))
+
+    @rng_pos.setter
+    def rng_pos(self, pos):
+        self._lib.ntscsim_pool_set_rng_pos(self._h, int(pos))
+
+    def frames_host(self, dst, src, first_fieldno=0, bob=True, chunk_frames=0):
+        """src numpy uint8 [N, H, W, 4], dst [2N, H, W, 4] (as FieldSimulator.frames_host)."""
+        n, h, w = src.shape[:3]
+        assert src.flags.c_contiguous and dst.flags.c_contiguous and dst.shape == (2 * n, h, w, 4)
+        u8p = C.POINTER(C.c_uint8)
+        rc = self._lib.ntscsim_pool_frames_host(self._h, src.ctypes.data_as(u8p), src.strides[0], src.strides[1], n,
+                                                dst.ctypes.data_as(u8p), dst.strides[0], dst.strides[1], w, h,
+                                                int(first_fieldno), DESC_BOB if bob else 0, int(chunk_frames))
+        if rc != _capi.OK:
+            raise NtscsimError(rc, "ntscsim_pool_frames_host: %s" % self._lib.ntscsim_pool_last_error(self._h).decode())
 
 
 class Raw28Decoder:

@@ -41,6 +41,8 @@ EXPORTS = (
     "ntscsim_raw28_debug_read_front",
     "ntscsim_submit_opts_init", "ntscsim_submit_configure", "ntscsim_submit", "ntscsim_flush", "ntscsim_wait",
     "ntscsim_host_unpin", "ntscsim_submit_stats",
+    "ntscsim_pool_create", "ntscsim_pool_destroy", "ntscsim_pool_size", "ntscsim_pool_ctx", "ntscsim_pool_set_block",
+    "ntscsim_pool_get_rng_pos", "ntscsim_pool_set_rng_pos", "ntscsim_pool_last_error", "ntscsim_pool_frames_host",
 )
 
 
@@ -340,6 +342,25 @@ def lib():
     L.ntscsim_host_unpin.restype = C.c_int
     L.ntscsim_submit_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ntscsim_submit_stats.restype = None
+    L.ntscsim_pool_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.ntscsim_pool_create.restype = C.c_int
+    L.ntscsim_pool_destroy.argtypes = [C.c_void_p]
+    L.ntscsim_pool_destroy.restype = None
+    L.ntscsim_pool_size.argtypes = [C.c_void_p]
+    L.ntscsim_pool_size.restype = C.c_int
+    L.ntscsim_pool_ctx.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_pool_ctx.restype = C.c_void_p
+    L.ntscsim_pool_set_block.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_pool_set_block.restype = C.c_int
+    L.ntscsim_pool_get_rng_pos.argtypes = [C.c_void_p]
+    L.ntscsim_pool_get_rng_pos.restype = C.c_uint64
+    L.ntscsim_pool_set_rng_pos.argtypes = [C.c_void_p, C.c_uint64]
+    L.ntscsim_pool_set_rng_pos.restype = None
+    L.ntscsim_pool_last_error.argtypes = [C.c_void_p]
+    L.ntscsim_pool_last_error.restype = C.c_char_p
+    L.ntscsim_pool_frames_host.argtypes = [C.c_void_p, _u8p, C.c_size_t, C.c_int, C.c_int, _u8p, C.c_size_t, C.c_int,
+                                           C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int]
+    L.ntscsim_pool_frames_host.restype = C.c_int
     _lib = L
     return L
 

@@ -115,6 +115,8 @@ typedef struct ntscsim_cli {
     /* audio-only flags are accepted for CLI compatibility and recorded, never used here */
     int32_t     emulating_preemphasis, emulating_deemphasis, output_vhs_hifi;
     double      output_audio_hiss_db, output_audio_linear_buzz, vhs_linear_high_boost;
+    int32_t     output_video_as_interlaced;      /* ffmpeg_to_composite -vi / -vp :1399-1404 (default 0: bob) */
+    int32_t     _pad;
 } ntscsim_cli;
 
 /* preset_NTSC() + the global initialisers (ffmpeg_ntsc.cpp:205-214, :756-809, :824-831). */
@@ -346,6 +348,30 @@ int ntscsim_frames_host_scaled(ntscsim_ctx *ctx, const ntscsim_host_source *sour
                                size_t src_frame_stride, int n_frames, uint8_t *dst,
                                size_t dst_frame_stride, int dst_linesize, int width, int height,
                                uint64_t first_fieldno, uint32_t flags, int chunk_frames);
+
+/* ---- several GPUs: a pool of contexts (BASELINE north_star: "partition the input stream
+ * frame-round-robin") ------------------------------------------------------------------------------------
+ * The loop :2202-2282 carries nothing from field to field but the position of the process-wide rand() stream,
+ * and the draws per composite_layer() call do not depend on the pixels (ntscsim_rng_calls_per_field), so every
+ * field's position is a closed form.  ntscsim_pool_frames_host() is ntscsim_frames_host() dealt over N
+ * contexts: block b of `block` frames (default 32; ntscsim_pool_set_block) goes to context b mod N, every context
+ * runs its own upload | kernels | download pipeline on its blocks from a host thread of its own, no data moves
+ * between GPUs, and the frames are byte-identical to one context processing the whole run.  `devices` lists the
+ * HIP ordinals, one context each (an ordinal may repeat: several contexts on one GPU -- how the tests run on a
+ * one-GPU box); devices = NULL: the first n_devices visible GPUs (n_devices = 0: all of them).  The pool keeps its
+ * own rand() position, advanced by every successful call like the ctx's.  One thread at a time per pool. */
+typedef struct ntscsim_pool ntscsim_pool;
+int  ntscsim_pool_create(const ntscsim_params *p, const int *devices, int n_devices, ntscsim_pool **out);
+void ntscsim_pool_destroy(ntscsim_pool *pool);
+int  ntscsim_pool_size(const ntscsim_pool *pool);
+ntscsim_ctx *ntscsim_pool_ctx(ntscsim_pool *pool, int i);       /* context i, e.g. for ntscsim_set_mode() */
+int  ntscsim_pool_set_block(ntscsim_pool *pool, int block_frames);
+uint64_t ntscsim_pool_get_rng_pos(const ntscsim_pool *pool);
+void ntscsim_pool_set_rng_pos(ntscsim_pool *pool, uint64_t pos);
+const char *ntscsim_pool_last_error(const ntscsim_pool *pool);
+int  ntscsim_pool_frames_host(ntscsim_pool *pool, const uint8_t *src, size_t src_frame_stride, int src_linesize,
+                              int n_frames, uint8_t *dst, size_t dst_frame_stride, int dst_linesize,
+                              int width, int height, uint64_t first_fieldno, uint32_t flags, int chunk_frames);
 
 /* ---- batched, device-resident form (what the field loop :2202-2282 becomes) -------------- */
 

@@ -1,0 +1,91 @@
+"""ntscsim_pool_*: the host-frame field loop dealt over several contexts ("frame round-robin, no
+data-path collective"), and `ntsc_cli --devices`.  The box has one GPU, so the contexts share it (an ordinal may
+repeat) -- the deal, the closed-form rand() positions, the per-context pipelines and the shared pinned buffers
+are the same code that runs with one context per GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _libs as L
+import ntscsim
+from ntscsim import _capi
+
+CLI = os.path.join(L.PKG, "ntsc_cli")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev,block", [(2, 4), (3, 2), (4, 32)])
+def test_pool_equals_one_context(ndev, block):
+    """720x486 -vhs, 41 frames (a ragged last block): pool of N contexts == one context, byte for byte, the
+    rand() position after the run included; a second call continues the stream."""
+    w, h, n = 720, 486, 41
+    p = L.make_params(["-vhs"])
+    src = np.stack([L.bars(w, h, j) for j in range(n)])
+    one = ntscsim.FieldSimulator(params=p)
+    exp = np.zeros((2 * n, h, w, 4), np.uint8)
+    one.frames_host(exp, src, first_fieldno=0, chunk_frames=8)
+    exp2 = np.zeros((2 * 5, h, w, 4), np.uint8)
+    one.frames_host(exp2, src[:5], first_fieldno=2 * n, chunk_frames=8)
+    pos = one.rng_pos
+    one.close()
+    pool = ntscsim.Pool(params=p, devices=[0] * ndev, block_frames=block)
+    assert pool.size == ndev
+    got = np.zeros_like(exp)
+    pool.frames_host(got, src, first_fieldno=0, chunk_frames=8)
+    assert np.array_equal(got, exp)
+    got2 = np.zeros_like(exp2)
+    pool.frames_host(got2, src[:5], first_fieldno=2 * n, chunk_frames=8)
+    assert np.array_equal(got2, exp2)
+    assert pool.rng_pos == pos
+    pool.close()
+
+
+@pytest.mark.gpu
+def test_pool_small_frames_against_the_oracle():
+    """96x33 (odd height: the fields of a frame draw different amounts), default preset + chroma noise: pool of 3 ==
+    the oracle's field loop with bob."""
+    w, h, n = 96, 33, 13
+    p = L.make_params(["-chroma-noise", "5", "-chroma-phase-noise", "3"], output_height=h)
+    frames = [L.noise_frame(w, h, 77 + j) for j in range(n)]
+    o = L.OracleStream(p)
+    exp = np.zeros((2 * n, h, w, 4), np.uint8)
+    for k in range(2 * n):
+        field = (k & 1) ^ 1
+        o.field(exp[k], frames[k // 2], field, k)
+        L.oracle().ntsc_oracle_bob(L._ptr(exp[k]), w * 4, w, h, field)
+    pool = ntscsim.Pool(params=p, devices=[0, 0, 0], block_frames=2)
+    got = np.zeros_like(exp)
+    pool.frames_host(got, np.stack(frames), chunk_frames=2)
+    assert np.array_equal(got, exp)
+    assert pool.rng_pos == o.rng_pos
+    pool.close()
+
+
+@pytest.mark.gpu
+def test_cli_on_three_contexts_writes_the_same_stream(tmp_path):
+    """ntsc_cli --devices 0,0,0 == ntsc_cli (one context): 70 noise frames, -vhs, batches of 64 fields."""
+    outs = []
+    for extra in ([], ["--devices", "0,0,0"], ["--gpus", "2"]):
+        outp = tmp_path / ("o%d.bgra" % len(outs))
+        r = subprocess.run([CLI, "-vhs", "-width", "96", "--height", "34", "-i", "noise:70", "-o", str(outp),
+                            "--batch", "64"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        outs.append(outp.read_bytes())
+    assert len(outs[0]) == 140 * 34 * 96 * 4
+    assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
+def test_pool_needs_a_gpu_and_checks_arguments():
+    lib = ntscsim.lib()
+    import ctypes as C
+    p = L.make_params([])
+    h = C.c_void_p()
+    assert lib.ntscsim_pool_create(None, None, 0, C.byref(h)) == _capi.E_ARG
+    assert lib.ntscsim_pool_create(C.byref(p), None, 65, C.byref(h)) == _capi.E_ARG
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.ntscsim_pool_create(C.byref(p), None, 0, C.byref(h)) == _capi.E_NODEV
+    assert lib.ntscsim_pool_size(None) == 0
+    assert lib.ntscsim_pool_frames_host(None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, 0) == _capi.E_ARG
