@@ -977,25 +977,43 @@ static int prepare422(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
     // rows are tighter than width + 2: the Y/C separator reads two bytes past its row (:496), i.e. the
     // first bytes of the OTHER field's row, which the tool has / has not processed yet depending on the
     // order of its sequential loop (:1783-1800).  Refuse both; separate calls are stream-ordered.
+    // (frames are compared by the byte range of their luma plane, not by base pointer: sub-frame views of one
+    // allocation and frames whose planes overlap partly race in the same way)
     if (n > 1) {
-        struct Key { uintptr_t dst; unsigned field; int ls; unsigned nocomp; };
+        struct Key { uintptr_t lo, hi; unsigned field; int ls; unsigned nocomp; };
         std::vector<Key> keys((size_t)n);
-        for (int i = 0; i < n; i++)
-            keys[(size_t)i] = {(uintptr_t)descs[i].dst_dev[0], descs[i].field & 1u, descs[i].dst_linesize[0],
+        for (int i = 0; i < n; i++) {
+            const uintptr_t lo = (uintptr_t)descs[i].dst_dev[0];
+            keys[(size_t)i] = {lo, lo + (uintptr_t)descs[i].dst_linesize[0] * (uintptr_t)(H - 1) + (uintptr_t)W,
+                               descs[i].field & 1u, descs[i].dst_linesize[0],
                                (descs[i].flags & NTSCSIM_422_NOCOMP) ? 1u : 0u};
+        }
         std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-            return a.dst != b.dst ? a.dst < b.dst : a.field < b.field; });
-        for (int i = 1; i < n; i++) {
-            const Key &a = keys[(size_t)i - 1], &b = keys[(size_t)i];
-            if (a.dst != b.dst) continue;
-            if (a.field == b.field) {
-                c->err = "descriptors of one batch share a destination frame and field";
-                return NTSCSIM_E_ARG;
+            return a.lo != b.lo ? a.lo < b.lo : a.field < b.field; });
+        // sweep: every descriptor against the ones whose range is still open
+        size_t open0 = 0;
+        for (size_t i = 1; i < keys.size(); i++) {
+            while (open0 < i && keys[open0].hi <= keys[i].lo) {
+                // (ranges sorted by start: one that ended before this start can still be followed by longer ones --
+                //  only skip a prefix of closed ranges, the inner loop tests the rest)
+                open0++;
             }
-            if ((a.ls < W + 2 || b.ls < W + 2) && !(a.nocomp && b.nocomp)) {
-                c->err = "both fields of one destination frame in one batch need dst_linesize[0] >= width + 2 "
-                         "(the Y/C separator reads two bytes past each luma row); use separate calls";
-                return NTSCSIM_E_ARG;
+            for (size_t j = open0; j < i; j++) {
+                const Key &a = keys[j], &b = keys[i];
+                if (a.hi <= b.lo) continue;
+                if (a.lo != b.lo || a.ls != b.ls) {
+                    c->err = "descriptors of one batch write overlapping destination frames that are not the same frame";
+                    return NTSCSIM_E_ARG;
+                }
+                if (a.field == b.field) {
+                    c->err = "descriptors of one batch share a destination frame and field";
+                    return NTSCSIM_E_ARG;
+                }
+                if ((a.ls < W + 2 || b.ls < W + 2) && !(a.nocomp && b.nocomp)) {
+                    c->err = "both fields of one destination frame in one batch need dst_linesize[0] >= width + 2 "
+                             "(the Y/C separator reads two bytes past each luma row); use separate calls";
+                    return NTSCSIM_E_ARG;
+                }
             }
         }
     }

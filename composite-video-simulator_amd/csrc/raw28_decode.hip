@@ -742,6 +742,8 @@ struct ntscsim_raw28 {
     uint64_t fields_total = 0;
     int64_t stats[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t last_n = 0;
+    bool mutated = false;        // the current push has changed the stream state
+    bool broken = false;         // a push failed after it had changed the state: only a reset helps
     // device scratch
     Buf<uint8_t> raw, h, raw_alt, h_alt, tmp;
     Buf<FrontState> st_begin, st_end, st_prev, st_a0;
@@ -911,6 +913,7 @@ static void raw28_stream_reset(ntscsim_raw28 *d)
     d->blank = (uint8_t)0; d->white = (uint8_t)192; d->read_pos = 0;              // :553-554
     std::memset(d->stats, 0, sizeof(d->stats));
     d->last_n = 0;
+    d->broken = false;
 }
 
 // make room for `need` bytes in a / b (same capacity policy), keeping the first `keep` bytes of both
@@ -934,10 +937,14 @@ static int raw28_grow(ntscsim_raw28 *d, size_t keep, size_t need, hipStream_t st
 // One push of a stream: `n` more samples (host or device memory), `final` = the stream ends with them.
 // Decodes every field the tool would have produced so far whose buffer window (:307, 2048 scanlines) is
 // complete -- at most max_fields of them; the rest come out of later pushes (n = 0 is allowed).
-static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_device, size_t n, bool final, void *frames_dev,
-                             size_t frame_stride, int linesize, int max_fields, int *n_fields)
+static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on_device, size_t n, bool final, void *frames_dev,
+                                  size_t frame_stride, int linesize, int max_fields, int *n_fields)
 {
     if (!d || (n > 0 && !samples) || !n_fields || max_fields < 0 || (max_fields > 0 && !frames_dev)) return NTSCSIM_E_ARG;
+    if (d->broken) {
+        d->err = "an earlier push of this stream failed half way: ntscsim_raw28_stream_reset() starts a new one";
+        return NTSCSIM_E_ARG;
+    }
     if (d->eof && n > 0) { d->err = "the stream has ended: ntscsim_raw28_stream_reset() starts a new one"; return NTSCSIM_E_ARG; }
     if (d->cnt + n >= 0xFFFFFFF0ull) return NTSCSIM_E_SIZE;
     if (max_fields > 0 && (linesize < d->width * 4 || (linesize & 3) || frame_stride < (size_t)linesize * (size_t)d->height))
@@ -946,6 +953,7 @@ static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_devi
     R28CHK(d, hipSetDevice(d->device));
     hipStream_t st = nullptr;
     const unsigned len = d->len;
+    d->mutated = true;           // from here on an error leaves the stream half advanced (see the wrapper)
     if (final) d->eof = true;
 
     // wall-clock split of the call (every phase ends in a stream synchronisation), stats[6..11] in us
@@ -1304,11 +1312,24 @@ static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_devi
             std::swap(d->h.p, d->h_alt.p); std::swap(d->h.cap, d->h_alt.cap);
             d->stats[14]++;
             d->base += keep; d->cnt -= keep; d->front_done -= keep;
+            d->last_n = d->cnt;      // (ntscsim_raw28_debug_read_front reads the compacted buffer)
             Bw -= keep; Rd -= keep; Ew -= keep;
             for (BufMap::Seg &g : bm.segs) g.abs0 -= keep;
         }
     }
     return NTSCSIM_OK;
+}
+
+// A push that fails after it has appended its samples (a HIP error, NTSCSIM_E_INTERNAL) leaves counters, the front-end
+// state and the end-of-stream mark half advanced: retrying it would append the samples twice.  Such a stream is marked
+// broken and refuses further pushes until ntscsim_raw28_stream_reset().
+static int raw28_stream_push(ntscsim_raw28 *d, const void *samples, bool on_device, size_t n, bool final, void *frames_dev,
+                             size_t frame_stride, int linesize, int max_fields, int *n_fields)
+{
+    if (d) d->mutated = false;
+    const int rc = raw28_stream_push_impl(d, samples, on_device, n, final, frames_dev, frame_stride, linesize, max_fields, n_fields);
+    if (d && rc != NTSCSIM_OK && d->mutated) d->broken = true;
+    return rc;
 }
 
 extern "C" int ntscsim_raw28_stream_reset(ntscsim_raw28 *d)

@@ -480,9 +480,16 @@ class Raw28Decoder:
         if samples is None:
             ptr, ns, dev = None, 0, 0
         elif hasattr(samples, "data_ptr"):
+            import torch
+            if samples.dtype != torch.uint8 or not samples.is_contiguous():
+                raise TypeError("stream_push: a CUDA tensor of samples must be contiguous uint8 (one byte per sample)")
             ptr, ns, dev = samples.data_ptr(), samples.numel(), 1
         else:
-            ptr, ns, dev = samples.ctypes.data, samples.size, 0
+            import numpy as np
+            keep = np.ascontiguousarray(samples)      # (a strided view would push the bytes in between)
+            if keep.dtype != np.uint8:
+                raise TypeError("stream_push: samples must be uint8 (one byte per sample), got %s" % keep.dtype)
+            ptr, ns, dev = keep.ctypes.data, keep.size, 0
         rc = self._lib.ntscsim_raw28_stream_push(self._h, C.c_void_p(ptr), ns, dev, 1 if final else 0,
                                                  C.c_void_p(frames.data_ptr()), frames.stride(0), frames.stride(1),
                                                  mf, C.byref(n))

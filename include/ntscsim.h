@@ -633,7 +633,9 @@ int  ntscsim_raw28_decode_device(ntscsim_raw28 *dec, const void *capture_dev, si
  *       *n_fields = fields written by this call.  The sequence of all fields is bit-identical to one
  *       ntscsim_raw28_decode() of the concatenated samples, whatever the push sizes.
  * The decoder keeps only what it can still need (about two windows of samples on the device), so the
- * stream may be far longer than 2^32 samples; one push must be shorter than that.
+ * stream may be far longer than 2^32 samples; one push must be shorter than that.  A push that fails after it has
+ * taken its samples (NTSCSIM_E_HIP, NTSCSIM_E_NOMEM, NTSCSIM_E_INTERNAL) leaves the stream half advanced: it is
+ * then refused (NTSCSIM_E_ARG) until ntscsim_raw28_stream_reset(); argument errors leave the stream as it was.
  * ntscsim_raw28_decode*() are a reset followed by one final push. */
 int  ntscsim_raw28_stream_reset(ntscsim_raw28 *dec);
 int  ntscsim_raw28_stream_push(ntscsim_raw28 *dec, const void *samples, size_t n, int on_device, int final,

@@ -381,6 +381,16 @@ def test_422_batch_refuses_racing_descriptors():
             sim.fields422(jobs, w, h)
         assert e.value.code == _capi.E_ARG
         assert sim.rng_pos == 0
+    # frames that overlap without being the same frame (here: a luma view that starts one row further down in the
+    # same allocation, the other field) race in the same way and are refused as well
+    wide = cases422.make_source422("noise", w, h + 1, 5, 16)
+    _, devw = to_dev_onebuf(torch, wide)
+    shifted = [devw[0][1:], devw[1][:h], devw[2][:h]]
+    same = [devw[0][:h], devw[1][:h], devw[2][:h]]
+    with pytest.raises(ntscsim.NtscsimError) as e:
+        sim.fields422([{"dst": same, "field": 1, "fieldno": 0, "rng_pos": 0},
+                       {"dst": shifted, "field": 0, "fieldno": 1, "rng_pos": pos1}], w, h)
+    assert e.value.code == _capi.E_ARG and sim.rng_pos == 0
     # padded rows: one batch with both fields == the oracle's sequential result
     padded = cases422.make_source422("noise", w, h, 5, 16)
     exp = padded.copy()
