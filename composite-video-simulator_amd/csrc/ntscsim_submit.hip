@@ -24,18 +24,22 @@ struct DeliverRec {
     const uint8_t *dev;       // device frame (row 0)
     uint8_t *host;            // device-visible address of the caller's frame (row 0)
     int32_t dev_pitch, host_pitch;
-    int32_t row0, row_step, nrows, _pad;
+    int32_t row0, row_step, nrows;
+    int32_t bob;              // 0: row y <- device row y;  1 + field: line doubling, row y <- the field's row beside it
 };
 
 // One workgroup per (row chunk, field): copies rows row0, row0+row_step, ... of a device frame into the
 // caller's (pinned, device-mapped) frame.  Stores go over the host link; 16-byte stores when every address is
-// 16-byte aligned.
+// 16-byte aligned.  With `bob` the loop's line doubling (ffmpeg_ntsc.cpp:2233-2257) happens on the way out: field 1
+// copies odd row y onto y - 1, field 0 copies row y + 1 onto odd row y -- destination row y takes the field's row
+// y | 1 (field 1) or (y + 1) & ~1 (field 0); the one row without a partner is not in [row0, row0 + nrows).
 __global__ void k_deliver(const DeliverRec *__restrict__ recs, int row_bytes, int vec16)
 {
     const DeliverRec r = recs[blockIdx.y];
     for (int k = blockIdx.x; k < r.nrows; k += gridDim.x) {
         const size_t y = (size_t)r.row0 + (size_t)k * r.row_step;
-        const uint8_t *s = r.dev + y * (size_t)r.dev_pitch;
+        const size_t ys = r.bob == 0 ? y : (r.bob == 2 ? (y | 1) : ((y + 1) & ~(size_t)1));
+        const uint8_t *s = r.dev + ys * (size_t)r.dev_pitch;
         uint8_t *d = r.host + y * (size_t)r.host_pitch;
         if (vec16) {
             const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
@@ -294,13 +298,12 @@ static int sub_retire_front(ntscsim_ctx *c, SubmitEngine *e)
                 sub_rows(e->H, it.field, (it.flags & NTSCSIM_DESC_BOB) != 0, row0, step, n);
                 const uint8_t *s = e->hdst + e->fbytes * (size_t)it.dst_slot;
                 const size_t rb = (size_t)e->W * 4;
-                if (step == 1 && (size_t)it.dst_ls == e->pitch)
-                    std::memcpy(it.host_dst, s, e->pitch * (size_t)(n - 1) + rb);
-                else
-                    for (int k = 0; k < n; k++) {
-                        const size_t y = (size_t)row0 + (size_t)k * step;
-                        std::memcpy(it.host_dst + y * (size_t)it.dst_ls, s + y * e->pitch, rb);
-                    }
+                const bool bob = (it.flags & NTSCSIM_DESC_BOB) != 0;
+                for (int k = 0; k < n; k++) {
+                    const size_t y = (size_t)row0 + (size_t)k * step;
+                    const size_t ys = !bob ? y : (it.field ? (y | 1) : ((y + 1) & ~(size_t)1));      // :2233-2257
+                    std::memcpy(it.host_dst + y * (size_t)it.dst_ls, s + ys * e->pitch, rb);
+                }
             }
     }
     e->done_ticket = b.last;
@@ -375,7 +378,9 @@ static int sub_launch(ntscsim_ctx *c)
         d.dst_dev = e->ddst.p + e->fbytes * (size_t)it.dst_slot;
         d.src_linesize = d.dst_linesize = (int)e->pitch;
         d.field = it.field;
-        d.flags = it.flags & (NTSCSIM_DESC_INTERLACED | NTSCSIM_DESC_TFF | NTSCSIM_DESC_BOB);
+        // (no NTSCSIM_DESC_BOB: the line doubling happens on the way out -- k_deliver's row map, or the host copy of a
+        //  staged frame -- so the device frame only ever holds the field's own rows)
+        d.flags = it.flags & (NTSCSIM_DESC_INTERLACED | NTSCSIM_DESC_TFF);
         d.fieldno = it.fieldno;
         d.rng_pos = it.rng_pos;
         if (it.host_dst_dev) any_direct = true; else any_staged = true;
@@ -399,7 +404,7 @@ static int sub_launch(ntscsim_ctx *c)
             r.host = it.host_dst_dev;
             r.dev_pitch = (int32_t)e->pitch; r.host_pitch = it.dst_ls;
             sub_rows(e->H, it.field, (it.flags & NTSCSIM_DESC_BOB) != 0, r.row0, r.row_step, r.nrows);
-            r._pad = 0;
+            r.bob = (it.flags & NTSCSIM_DESC_BOB) ? 1 + (int32_t)it.field : 0;
             vec16 = vec16 && !(((uintptr_t)it.host_dst_dev | (uintptr_t)it.dst_ls) & 15);
         }
         size_t i = 0;

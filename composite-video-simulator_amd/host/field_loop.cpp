@@ -137,12 +137,17 @@ int main(int argc, char **argv)
     std::vector<unsigned> ring_field((size_t)ring, 0);
 
     const long total = warmup + fields;
+    double us_new = 0, us_same = 0, us_wait = 0;        // host time inside the calls (timed part only)
+    long n_new = 0, n_same = 0, n_wait = 0;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     uint64_t hash = 0xcbf29ce484222325ull;
     long consumed = 0;
     auto consume = [&](long k) {                      // what the loop does with the frame after composite_layer()
         Frame *f = out_ring[(size_t)(k % ring)];
         if (async) {
+            const double ta = now_us();
             const int r = ntscsim_wait(sim, tickets[(size_t)(k % ring)]);
+            us_wait += now_us() - ta; n_wait++;
             if (r != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_wait: %s (%s)\n", ntscsim_strerror(r), ntscsim_last_error(sim)); std::exit(1); }
         }
         if (!do_bob) { /* the caller's own line doubling would go here (:2233-2257) */ }
@@ -169,6 +174,7 @@ int main(int argc, char **argv)
         while (consumed + ring <= current) consume(consumed);
         Frame *dst = out_ring[ring_idx];
         ring_field[ring_idx] = field;
+        const double ts = now_us();
         if (async) {
             rc = ntscsim_submit_avframe(sim, dst, &in_view, field, (uint64_t)current,
                                         (do_bob ? NTSCSIM_DESC_BOB : 0u) | (new_frame ? 0u : NTSCSIM_SUBMIT_SAME_SRC) |
@@ -177,6 +183,7 @@ int main(int argc, char **argv)
         } else {
             rc = ntscsim_field_avframe(sim, dst, &in_view, field, (uint64_t)current);
         }
+        if (current >= warmup) { if (new_frame) { us_new += now_us() - ts; n_new++; } else { us_same += now_us() - ts; n_same++; } }
         if (rc != NTSCSIM_OK) { std::fprintf(stderr, "field %ld: %s (%s)\n", current, ntscsim_strerror(rc), ntscsim_last_error(sim)); return 1; }
         ring_idx = (ring_idx + 1) % (size_t)ring;                                  // :2277
         while (consumed + lag <= current) consume(consumed);                       // `lag` fields behind
@@ -187,10 +194,12 @@ int main(int argc, char **argv)
     ntscsim_submit_stats(sim, st);
     std::printf("{\"mode\": \"%s\", \"fields\": %ld, \"seconds\": %.6f, \"fields_per_s\": %.1f, \"width\": %d, \"height\": %d, "
                 "\"depth\": %d, \"lanes\": %d, \"lag\": %d, \"ring\": %d, \"bob\": %d, \"pin\": %d, \"rewrite_src\": %d, \"src_stable\": %d, "
+                "\"host_us_per_call\": {\"new_frame\": %.1f, \"same_frame\": %.1f, \"wait\": %.1f}, "
                 "\"fnv1a\": \"%016llx\", \"rng_pos\": %llu, \"stats\": {\"submitted\": %llu, \"launches\": %llu, \"uploads\": %llu, "
                 "\"uploads_staged\": %llu, \"delivered_direct\": %llu, \"delivered_staged\": %llu, \"registrations\": %llu, "
                 "\"ring_full_waits\": %llu}}\n",
                 mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, depth, lanes, lag, ring, do_bob, pin, rewrite, src_stable && !rewrite,
+                n_new ? us_new / n_new : 0.0, n_same ? us_same / n_same : 0.0, n_wait ? us_wait / n_wait : 0.0,
                 (unsigned long long)(do_hash ? hash : 0), (unsigned long long)ntscsim_get_rng_pos(sim),
                 (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],
                 (unsigned long long)st[4], (unsigned long long)st[5], (unsigned long long)st[6], (unsigned long long)st[7]);
