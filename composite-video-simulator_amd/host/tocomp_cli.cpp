@@ -58,18 +58,18 @@ struct Planes {                 // one planar frame in one allocation
     uint8_t *p[3] = {nullptr, nullptr, nullptr};
     int ls[3] = {0, 0, 0}, rows[3] = {0, 0, 0};
     size_t bytes = 0;
-    void layout(uint8_t *base, int W, int H, bool c420, int pad)
+    void layout(uint8_t *base, int W, int H, bool c420, int pad, int extra_crows = 0)
     {
         ls[0] = W + pad; ls[1] = ls[2] = W / 2 + pad / 2;
-        rows[0] = H; rows[1] = rows[2] = c420 ? (H + 1) / 2 : H;
+        rows[0] = H; rows[1] = rows[2] = (c420 ? (H + 1) / 2 : H) + extra_crows;
         p[0] = base;
         p[1] = p[0] + (size_t)ls[0] * rows[0];
         p[2] = p[1] + (size_t)ls[1] * rows[1];
         bytes = (size_t)ls[0] * rows[0] + 2 * (size_t)ls[1] * rows[1];
     }
-    static size_t size(int W, int H, bool c420, int pad)
+    static size_t size(int W, int H, bool c420, int pad, int extra_crows = 0)
     {
-        const size_t cr = c420 ? ((size_t)H + 1) / 2 : (size_t)H;
+        const size_t cr = (c420 ? ((size_t)H + 1) / 2 : (size_t)H) + (size_t)extra_crows;
         return (size_t)(W + pad) * H + 2 * (size_t)(W / 2 + pad / 2) * cr;
     }
 };
@@ -153,10 +153,14 @@ int main(int argc, char **argv)
     HIPOK(hipHostMalloc((void **)&h_out, out_bytes * batch * 2, hipHostMallocDefault));
     HIPOK(hipMalloc((void **)&d_in, (in_bytes + 256) * batch));
     HIPOK(hipMalloc((void **)&d_frm, frm_bytes * batch));
-    HIPOK(hipMalloc((void **)&d_out, (out_bytes + 512) * batch * 2));
+    HIPOK(hipMalloc((void **)&d_out, (Planes::size(W, H, false, 0, 1) + 512) * batch * 2));
     HIPOK(hipMemset(d_frm, 0, frm_bytes * batch));          // av_frame_get_buffer + memset 16/128 would differ: see README
     if (feedback) { HIPOK(hipMalloc((void **)&d_flt, frm_bytes)); HIPOK(hipMemset(d_flt, 0, frm_bytes)); }
-    const size_t in_stride = (in_bytes + 255) / 256 * 256, out_stride = (out_bytes + 255) / 256 * 256;
+    // device output frames carry one spare chroma row: the tool's interlaced 4:2:0 repack writes chroma row
+    // (y & 1) + ((y & ~3) >> 1) for y = height - 1, which for a height of 2 mod 4 is row (height + 1) / 2 -- one past the
+    // plane (:1215-1223; in the tool it lands in the frame's padding).  It exists here and is not written out.
+    const int XC = 1;
+    const size_t in_stride = (in_bytes + 255) / 256 * 256, out_stride = (Planes::size(W, H, out420, 0, XC) + 255) / 256 * 256;
 
     hipStream_t st = nullptr;
     HIPOK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -170,13 +174,13 @@ int main(int argc, char **argv)
     std::vector<Emit> emits;
     auto run_emit = [&](const Emit &e, size_t slot, const Planes &frm) -> int {
         if (emit_frame_itself) {
-            Planes o; o.layout(d_out + out_stride * slot, W, H, false, 0);
+            Planes o; o.layout(d_out + out_stride * slot, W, H, false, 0, XC);
             for (int k = 0; k < 3; k++)
                 if (hipMemcpy2DAsync(o.p[k], (size_t)o.ls[k], frm.p[k], (size_t)frm.ls[k], k ? (size_t)W / 2 : (size_t)W, (size_t)H,
                                      hipMemcpyDeviceToDevice, st) != hipSuccess) return NTSCSIM_E_HIP;
             return NTSCSIM_OK;
         }
-        Planes o; o.layout(d_out + out_stride * slot, W, H, out420, 0);
+        Planes o; o.layout(d_out + out_stride * slot, W, H, out420, 0, XC);
         ntscsim_out422_desc od;
         std::memset(&od, 0, sizeof(od));
         for (int k = 0; k < 3; k++) {
@@ -266,8 +270,13 @@ int main(int argc, char **argv)
             }
         }
         // ---- download and write what output_frame() would have encoded
-        for (size_t k = 0; k < emits.size(); k++)
-            HIPOK(hipMemcpyAsync(h_out + out_bytes * k, d_out + out_stride * k, out_bytes, hipMemcpyDeviceToHost, st));
+        for (size_t k = 0; k < emits.size(); k++) {
+            Planes o, hpl;
+            o.layout(d_out + out_stride * k, W, H, out420 && !emit_frame_itself, 0, XC);
+            hpl.layout(h_out + out_bytes * k, W, H, out420 && !emit_frame_itself, 0);
+            for (int q = 0; q < 3; q++)
+                HIPOK(hipMemcpyAsync(hpl.p[q], o.p[q], (size_t)hpl.ls[q] * hpl.rows[q], hipMemcpyDeviceToHost, st));
+        }
         HIPOK(hipStreamSynchronize(st));
         for (size_t k = 0; k < emits.size(); k++) {
             if (out && std::fwrite(h_out + out_bytes * k, 1, out_bytes, out) != out_bytes) { std::fprintf(stderr, "write failed\n"); return 1; }

@@ -486,7 +486,10 @@ void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
  *   NTSCSIM_OUT422_INTERLACED420  4:2:0 with -interlaced (:1202, :1215-1223): luma copied 1:1,
  *                                 chroma rows interleaved per field
  * (4:2:2 interlaced output encodes the frame as is, :1158 -- nothing to do.)  The bob frame's
- * chroma planes need (height+1)/2 rows in the 4:2:0 modes.  Stream-ordered like the calls above.
+ * chroma planes need (height+1)/2 rows in the 4:2:0 modes -- and ONE MORE in NTSCSIM_OUT422_INTERLACED420 when
+ * height is 2 mod 4: the tool's repack writes chroma row (y & 1) + ((y & ~3) >> 1) for y = height - 1 then, one
+ * row past the plane (in the tool that lands in the frame's padding); the same row is written here.
+ * Stream-ordered like the calls above.
  */
 #define NTSCSIM_OUT422_BOB422        0u
 #define NTSCSIM_OUT422_BOB420        1u
