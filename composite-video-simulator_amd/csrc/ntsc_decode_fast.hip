@@ -45,29 +45,46 @@ typedef __attribute__((address_space(1))) const uint32_t *g_cu32_ptr;
 #define NTSC_STEP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-// ------------------------------------------------------------------ rand() with a prefetched ring word
-// LaneRand (ntsc_kernels.hip) whose NEXT ring word is requested one draw ahead: the LDS round trip
-// (~100 cycles) overlaps half a pipeline step of arithmetic instead of stalling the wave at an
-// s_waitcnt right behind the ds_read.  Slot k+1 was last written 30 draws ago: no hazard.
-struct LaneRandP {
-    uint32_t p3, p2, p1, pre;   // s[i-3], s[i-2], s[i-1]; pre = s[i-31] of the coming draw
-    int slot;                   // wave-uniform
-    DEV void init(uint32_t *ring, const uint32_t *state, int stride, int lane)
+// ------------------------------------------------------------------ rand() ring with static LDS offsets
+// LaneRand (ntsc_kernels.hip) keeps the 31-word window of glibc's r[i] = r[i-31] + r[i-3] in a 31-slot ring and needs
+// one address (slot << 8 | lane) per draw.  Here the ring has 32 slots plus a copy of slot 0 behind slot 31: the word
+// for draw i is written to slot i & 31, and r[i-31] sits in slot (i + 1) & 31 = the NEXT slot, or the copy when the
+// write slot is 31 -- so read and write of a draw are two immediate offsets from one address, and the eight draws of an
+// unrolled steady iteration are sixteen immediate offsets from the address of that iteration's first slot (a multiple
+// of 8: init() places the window so that the pipeline fill ends on one).  One address per iteration instead of eight.
+struct LaneRand32 {
+    uint32_t p3, p2, p1;   // r[i-3], r[i-2], r[i-1]
+    int pos;               // wave-uniform: slot of the next draw's word
+    DEV void init(uint32_t *ring, const uint32_t *state, int stride, int lane, int o)
     {
-        for (int j = 0; j < 31; j++) ring[j * 64 + lane] = state[(size_t)j * stride];
-        p3 = ring[28 * 64 + lane];
-        p2 = ring[29 * 64 + lane];
-        p1 = ring[30 * 64 + lane];
-        slot = 0;
-        pre = ring[lane];
+        for (int j = 0; j < 31; j++) {
+            const uint32_t w = state[(size_t)j * stride];
+            const int sl = (o + j) & 31;
+            ring[sl * 64 + lane] = w;
+            if (sl == 0) ring[32 * 64 + lane] = w;
+            if (j == 28) p3 = w;
+            if (j == 29) p2 = w;
+            if (j == 30) p1 = w;
+        }
+        pos = (o + 31) & 31;
     }
-    DEV uint32_t next(uint32_t *ring, int lane)
+    DEV uint32_t next(uint32_t *ring, int lane)               // any position
     {
-        const uint32_t v = pre + p3;
-        ring[slot * 64 + lane] = v;
+        const uint32_t v = ring[(pos + 1) * 64 + lane] + p3;  // r[i-31] + r[i-3]
+        ring[pos * 64 + lane] = v;
+        if (pos == 0) ring[32 * 64 + lane] = v;
         p3 = p2; p2 = p1; p1 = v;
-        slot = (slot == 30) ? 0 : slot + 1;
-        pre = ring[slot * 64 + lane];
+        pos = (pos + 1) & 31;
+        return v >> 1;
+    }
+    // draw K (0..7) of a steady iteration whose first slot is rb - lane column (a multiple of 8 slots)
+    template <int K>
+    DEV uint32_t draw(uint32_t *rb, bool first_slot_is_zero)
+    {
+        const uint32_t v = rb[(K + 1) * 64] + p3;
+        rb[K * 64] = v;
+        if (K == 0 && first_slot_is_zero) rb[32 * 64] = v;
+        p3 = p2; p2 = p1; p1 = v;
         return v >> 1;
     }
 };
@@ -218,6 +235,68 @@ struct DemodR {
     }
 };
 
+// The same separator in the form the STEADY loop runs (round 4: the instruction diet, profiles/r04_decode_census.txt).
+// Two things change, neither touches a result:
+//   * the four-tap box sum is kept as pair sums p(t) = c(t) + c(t-1): box(t) = p(t) + p(t-2).  One add less per
+//     sample than "running sum - oldest + newest", and the delay lines are 1 and 2 deep instead of 3 -- under the
+//     4x unrolled loop a 2-deep line is pure register renaming, a 3-deep one costs three v_mov at every back edge;
+//   * the raw chroma window is split by position parity.  Picks happen at every second position and take either
+//     (ch(q-4), ch(q-3)) or (ch(q-2), ch(q-1)): one sample of the pick's own parity and one of the other, each 1 or 2
+//     positions back IN ITS OWN PARITY STREAM.  Two 2-deep lines (e: the pick parity, o: the other) replace one
+//     6-deep window -- again renaming instead of six moves per iteration.
+// from(): the state the guarded steps (DemodR) left behind; `pick_next`: the next position is a pick (odd x).
+// to(): back into DemodR's layout for the guarded steps of the row end.
+struct DemodS {
+    int c1, pA, pB;               // c(t-1); p(t-1) = c(t-1)+c(t-2); p(t-2)
+    int e1, e2, o1, o2;           // raw chroma of the last two positions of the pick parity / of the other parity
+    int y0, y1, y2, y3, y4;       // box-filtered luma at q-5 .. q-1
+    int ieP, qeP, ieN, qeN;
+    DEV void from(const DemodR &D, bool pick_next)
+    {
+        c1 = D.c2; pA = D.c2 + D.c1; pB = D.c1 + D.c0;
+        // before the push at q: w5 = ch(q-1), w4 = ch(q-2), w3 = ch(q-3), w2 = ch(q-4)
+        if (pick_next) { e1 = D.w4; e2 = D.w2; o1 = D.w5; o2 = D.w3; }
+        else           { e1 = D.w5; e2 = D.w3; o1 = D.w4; o2 = D.w2; }
+        y0 = D.y0; y1 = D.y1; y2 = D.y2; y3 = D.y3; y4 = D.y4;
+        ieP = D.ieP; qeP = D.qeP; ieN = D.ieN; qeN = D.qeN;
+    }
+    DEV void to(DemodR &D, bool pick_next) const
+    {
+        D.c2 = c1; D.c1 = pA - c1; D.c0 = pB - D.c1; D.csum = D.c0 + D.c1 + D.c2;
+        D.w0 = 0; D.w1 = 0;       // (never picked again: a pick reads at most five positions back)
+        if (pick_next) { D.w4 = e1; D.w2 = e2; D.w5 = o1; D.w3 = o2; }
+        else           { D.w5 = e1; D.w3 = e2; D.w4 = o1; D.w2 = o2; }
+        D.y0 = y0; D.y1 = y1; D.y2 = y2; D.y3 = y3; D.y4 = y4;
+        D.ieP = ieP; D.qeP = qeP; D.ieN = ieN; D.qeN = qeN;
+    }
+    // PICK = x is odd; NEG = the picked pair is negated (x = 3 mod 4), compile time; hi = lane mask of xi == 2;
+    // dm = and-mask applied to the picked pair (dropout :1891-1901 folded into the pick: everything the separator
+    // puts out afterwards is an average or a copy of picked values; -1 where there is no dropout stage behind it)
+    template <bool PICK, bool NEG, bool LUMA, bool BK = false, bool MASK = false>
+    DEV void push(int ct, bool hi, int dm, int &Yo, int &Io, int &Qo, unsigned bmul = 0, unsigned bshift = 0)
+    {
+        const int p = ct + c1;
+        const int yb = sdiv4s(p + pB);
+        int ch = ct - yb;
+        if (BK) ch = scale_back50(ch, bmul, bshift);
+        c1 = ct; pB = pA; pA = p;
+        if (LUMA) { Yo = y0; y0 = y1; y1 = y2; y2 = y3; y3 = y4; y4 = yb; }
+        if (PICK) {
+            int a = hi ? e1 : e2, b = hi ? o1 : o2;
+            e2 = e1; e1 = ch;
+            if (NEG) { a = -a; b = -b; }
+            if (MASK) { a &= dm; b &= dm; }
+            ieN = a; qeN = b;
+            Io = (ieP + ieN) >> 1;
+            Qo = (qeP + qeN) >> 1;
+        } else {
+            o2 = o1; o1 = ch;
+            Io = ieN; Qo = qeN;
+            ieP = ieN; qeP = qeN;
+        }
+    }
+};
+
 template <bool VHS, class RT>
 struct State {
     DemodR D1, D2;
@@ -225,11 +304,7 @@ struct State {
     Casc3<RT> vl, vcU, vcV, sh, oU, oV;
     PoleHp<RT> vpre;
     int Yprev, Uraw, Vraw;                    // previous step's output-stage inputs
-#ifdef NTSC_RANDP
-    LaneRandP rng;
-#else
-    LaneRand rng;
-#endif
+    LaneRand32 rng;
     int nU, nV;
 };
 
@@ -283,12 +358,17 @@ DEV int opaque_s(int v) { return __builtin_amdgcn_readfirstlane(v); }   // (also
 
 DEV int wave_up(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 
+DEV uint32_t cvt_sat_u32(double x) { uint32_t r; asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+DEV uint32_t cvt_sat_u32(float x) { uint32_t r; asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+DEV uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
 template <class RT>
 DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
 {
     // YIQ_to_RGB :1385-1396: (int)(x / 256) then clamp; for the clamp's sake (int)x >> 8 is the
     // same (a negative quotient clamps to 0 whichever way it was rounded)
     const RT y = (RT)Yo;
+#ifdef NTSC_OLD_CLAMP
     int r = (int)((y + (RT(0.956) * fU)) + (RT(0.621) * fV)) >> 8;
     int g = (int)((y + (RT(-0.272) * fU)) + (RT(-0.647) * fV)) >> 8;
     int b = (int)((y + (RT(-1.106) * fU)) + (RT(1.703) * fV)) >> 8;
@@ -296,6 +376,15 @@ DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
     g = g < 0 ? 0 : (g > 255 ? 255 : g);
     b = b < 0 ? 0 : (b > 255 ? 255 : b);
     return (((uint32_t)r << 16) | (uint32_t)b) | ((uint32_t)g << 8);   // two v_lshl_or_b32
+#else
+    // the lower clamp is the conversion's own: v_cvt_u32 saturates (negative -> 0, too large -> 2^32 - 1), so
+    // clamp((int)x >> 8, 0, 255) == min((unsigned)x >> 8, 255) for every x -- a full-rate v_min_u32 per channel in
+    // place of a half-rate v_med3_i32 (C's conversion of a negative double to unsigned is undefined, hence the asm)
+    const uint32_t r = umin32(cvt_sat_u32((y + (RT(0.956) * fU)) + (RT(0.621) * fV)) >> 8, 255u);
+    const uint32_t g = umin32(cvt_sat_u32((y + (RT(-0.272) * fU)) + (RT(-0.647) * fV)) >> 8, 255u);
+    const uint32_t b = umin32(cvt_sat_u32((y + (RT(-1.106) * fU)) + (RT(1.703) * fV)) >> 8, 255u);
+    return ((r << 16) | b) | (g << 8);
+#endif
 }
 
 // One steady-state pipeline step at unrolled position J (t = SKT + 4n + J).  Position phases:
@@ -308,17 +397,29 @@ DEV uint32_t yiq_to_bgra(int Yo, RT fU, RT fV)
 // noise, VHS chroma / luma filters, vertical blend, re-modulation.  Returns the composite sample
 // the VCR puts out at x2 = x1 - d (ffmpeg_ntsc.cpp:1716-1888).
 // (Yv, Uv, Vv: the same signal as components, what the VCR's S-Video connector carries.)
-template <int DP, int J, class RT, class CT>
-DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *ring,
-                 int pc, int pl, int sneg1, int &Yv, int &Uv, int &Vv)
+// What the steady loop keeps beside State: the separators and the luma box in their steady form (DemodS), and the LDS
+// address of the iteration's first rand() slot.
+struct Steady {
+    DemodS D1, D2;
+    int lc1, lpA, lpB;          // VHS luma stream: c(t-1) and the pair sums (as DemodS)
+    uint32_t *rb;               // this lane's column of the iteration's first ring slot
+    bool rb0;                   // that slot is slot 0 (its copy behind slot 31 is written too)
+};
+
+// DPH = the first separator's position phase: x1 = t - 7 = DPH + J (mod 4) -- odd positions pick, x1 = 3 (mod 4)
+// negates (a compile-time property of the unrolled position since round 4: one instantiation per chroma delay mod 4).
+template <int DPH, int J, class RT, class CT>
+DEV int vcr_step(const DevParams &P, State<true, RT> &S, Steady &T, const CT &C,
+                 int pc, int pl, int &Yv, int &Uv, int &Vv)
 {
-    constexpr bool odd1 = ((DP + J) & 1) != 0;
+    constexpr bool pick1 = ((DPH + J) & 1) != 0;
+    constexpr bool neg1 = ((DPH + J) & 3) == 3;
     int Yd, U, V;
-    S.D1.template push<odd1, -1, false, CT::back>(pc, C.hi, sneg1, Yd, U, V, C.bmul, C.bshift);
+    T.D1.template push<pick1, neg1, false, CT::back, false>(pc, C.hi, -1, Yd, U, V, C.bmul, C.bshift);
     // chroma noise :1719-1735
     U += S.nU; V += S.nV;
-    S.nU = sdiv2(S.nU + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
-    S.nV = sdiv2(S.nV + (int)umod31(S.rng.next(ring, C.lane), P.m_cnoise) - P.cnoise_k);
+    S.nU = sdiv2(S.nU + (int)umod31(S.rng.template draw<2 * J>(T.rb, T.rb0), P.m_cnoise) - P.cnoise_k);
+    S.nV = sdiv2(S.nV + (int)umod31(S.rng.template draw<2 * J + 1>(T.rb, T.rb0), P.m_cnoise) - P.cnoise_k);
     // chroma phase noise :1748-1762; (double)(int)d == trunc(d) up to the sign of zero, which
     // no later stage can observe
     const RT u = (RT)U, v = (RT)V;
@@ -328,9 +429,9 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
     const int fU = (int)S.vcU.push(Ud, C.a_vc);
     const int fV = (int)S.vcV.push(Vd, C.a_vc);
     // luma at x2: box -> low-pass + emphasis :1793-1812 -> sharpen :1866-1883
-    const int yb = sdiv4s(S.lsum + pl);
-    S.lsum = S.lsum - S.l0 + pl;
-    S.l0 = S.l1; S.l1 = S.l2; S.l2 = pl;
+    const int lp = pl + T.lc1;
+    const int yb = sdiv4s(lp + T.lpB);
+    T.lc1 = pl; T.lpB = T.lpA; T.lpA = lp;
     RT m2;
     RT s = S.vl.push((RT)yb, C.a_vl, m2);
     s += S.vpre.hp(s, m2, C.a_vl) * RT(1.6);
@@ -349,30 +450,26 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
 }
 
 // One steady-state pipeline step at unrolled position J (t = SKT + 4n + J).  Position phases:
-//   second demodulator / output   x3 = t - 14 - d = 4n + J + 1     -> odd for even J, sign by J
+//   second demodulator / output   x3 = t - 14 - d = 4n + J + 1     -> odd for even J, negated for J = 2
 //   re-modulation                 x2 = x3 + 7     = 4n + J (mod 4) -> U for even J, sign by J & 2
-//   first demodulator             x1 = t - 7      = d + J (mod 4)  -> parity by DP = d & 1 (template),
-//                                                                     sign wave-uniform (sneg1)
+//   first demodulator             x1 = t - 7      = DPH + J (mod 4)
 // Non-VHS form: x3 = x1 = t - 7 = 4n + J + 1 (SKT = 8), one demodulator.
-template <bool VHS, int DP, int J, class RT, class CT>
-DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring,
-                  int pc, int pl, int sneg1)
+template <bool VHS, int DPH, int J, class RT, class CT>
+DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, Steady &T, const CT &C, int pc, int pl)
 {
     int Y, U, V;
     if constexpr (!VHS) {
-        S.D1.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true, CT::back>(pc, C.hi, 0, Y, U, V, C.bmul, C.bshift);
+        T.D1.template push<(J & 1) == 0, J == 2, true, CT::back, true>(pc, C.hi, C.dm, Y, U, V, C.bmul, C.bshift);
     } else {
         int Yv, Uv, Vv;
-        const int c2 = vcr_step<DP, J, RT, CT>(P, S, C, ring, pc, pl, sneg1, Yv, Uv, Vv);
+        const int c2 = vcr_step<DPH, J, RT, CT>(P, S, T, C, pc, pl, Yv, Uv, Vv);
         if constexpr (CT::svideo) {
-            Y = Yv; U = Uv; V = Vv;                // -vhs-svideo: the components go on as they are :1885
+            Y = Yv; U = Uv & C.dm; V = Vv & C.dm;  // -vhs-svideo: the components go on as they are :1885; dropout :1891
         } else {
-            // ... and separate again at x3
-            S.D2.template push<(J & 1) == 0, (J == 0 ? 0 : 1), true>(c2, C.hi, 0, Y, U, V);
+            // ... and separate again at x3 (dropout :1891-1901 is the and-mask on the picked pair)
+            T.D2.template push<(J & 1) == 0, J == 2, true, false, true>(c2, C.hi, C.dm, Y, U, V);
         }
     }
-    // dropout :1891-1901
-    U &= C.dm; V &= C.dm;
     // composite_lowpass_tv :1399-1427 (delay 1) and YIQ -> RGB for the previous position
     const RT fUd = rtrunc<RT>(S.oU.push((RT)U, C.a_tv));
     const RT fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_tv));
@@ -486,7 +583,7 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
 
 // Steady-state loop: every stage strictly inside the row.  Starts at t = SKT (mod 4), 4 pixels per
 // iteration, the next iteration's composite samples requested before the current ones are used.
-template <bool VHS, int DP, class RT, class CT>
+template <bool VHS, int DPH, class RT, class CT>
 DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring,
                uint32_t *ostage, const unsigned long long *orow, uint32_t *drow, bool is_out, int t)
 {
@@ -495,11 +592,20 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     const int t_end = C.W - (C.d > 7 ? C.d - 7 : 0);
     const int SKT = C.SKT, LOFF = C.LOFF, lane = C.lane;
     if (t + 4 > t_end) return t;
-    // sign of the first demodulator's picks: x1 = t - 7 = d + J (mod 4); negated iff x1 = 3 (mod 4)
-    // (S-Video form: the pipeline is 7 stages shorter, SKT = 8 + d, so x1 = t - 7 = d + 1 + J (mod 4))
-    const int dph = (C.d + (CT::svideo ? 1 : 0)) & 3;
-    const int sn0 = opaque_s(((dph + 0) & 3) == 3 ? -1 : 0), sn1 = opaque_s(((dph + 1) & 3) == 3 ? -1 : 0),
-              sn2 = opaque_s(((dph + 2) & 3) == 3 ? -1 : 0), sn3 = opaque_s(((dph + 3) & 3) == 3 ? -1 : 0);
+    // the rand() ring's static offsets need the iteration's first slot on a multiple of 8 (LaneRand32::init arranges
+    // that for a row wider than the pipeline is deep; otherwise the guarded steps do the whole row)
+    if (VHS && (S.rng.pos & 7)) return t;
+    // the separators and the luma box in their steady form: the next position is t; the first separator (x1 = t - 7 =
+    // DPH mod 4) picks there iff DPH is odd, the second one / the only one of the non-VHS form (x3 = 4n + 1) always
+    Steady T;
+    T.D1.from(S.D1, VHS ? (DPH & 1) != 0 : true);
+    T.D2.from(S.D2, true);
+    T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
+    // (the separator in front of the TV stages carries the dropout mask on everything it has picked: the guarded steps
+    //  apply it to their outputs instead, so what they left behind is masked here)
+    DemodS &Dout = (VHS && !CT::svideo) ? T.D2 : T.D1;
+    if (!(VHS && CT::svideo)) { Dout.ieP &= C.dm; Dout.qeP &= C.dm; Dout.ieN &= C.dm; Dout.qeN &= C.dm; }
+    int sbase = VHS ? S.rng.pos : 0;
     // samples in flight per stream: one unrolled iteration
     constexpr int PD = 4;
     int pc[PD], pl[PD];
@@ -557,8 +663,11 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
 #pragma unroll
             for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = VHS ? cs_load(C, t + 4 + j - LOFF) : 0; }
         }
+        T.rb = ring + sbase * 64 + lane;
+        T.rb0 = sbase == 0;
+        sbase = (sbase + 8) & 31;
 #define NTSC_FAST_STEP(J)                                                                         \
-        o[J] = step<VHS, DP, J, RT, CT>(P, S, C, ring, pc[J % PD], pl[J % PD], sn##J);            \
+        o[J] = step<VHS, DPH, J, RT, CT>(P, S, T, C, pc[J % PD], pl[J % PD]);                     \
         if (!PFTOP) {                                                                             \
             pc[J % PD] = cs_load(C, t + PD + J);                                                  \
             if (VHS) pl[J % PD] = cs_load(C, t + PD + J - LOFF);                                  \
@@ -582,6 +691,11 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     }
     NTSC_FAST_FLUSH()
 #undef NTSC_FAST_FLUSH
+    // back to the guarded steps' layout (t has advanced by a multiple of 4: the same position phases as at the entry)
+    T.D1.to(S.D1, VHS ? (DPH & 1) != 0 : true);
+    T.D2.to(S.D2, true);
+    S.l2 = T.lc1; S.l1 = T.lpA - T.lc1; S.l0 = T.lpB - S.l1; S.lsum = S.l0 + S.l1 + S.l2;
+    if (VHS) S.rng.pos = sbase;
     return t;
 }
 
@@ -607,7 +721,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
                           const int *__restrict__ dropout, int *__restrict__ tails)
 {
     using namespace fastdec;
-    __shared__ uint32_t ring[31 * 64];
+    __shared__ uint32_t ring[33 * 64];            // LaneRand32: 32 slots + the copy of slot 0
     __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
     __shared__ unsigned long long orow[64];       // every lane's output row (0 = none), for the cooperative stores
 
@@ -681,7 +795,10 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     S.Yprev = S.Uraw = S.Vraw = 0;
     S.nU = S.nV = 0;
     if (VHS) {
-        S.rng.init(ring, rs_chroma + rc, P.Rpad, lane);
+        // the pipeline fill draws twice at every step from x1 = 0 on (t = 7 .. SKT - 1): place the window so that the
+        // steady loop's first draw lands on a slot that is a multiple of 8
+        const int fill_draws = 2 * (C.SKT - 7);
+        S.rng.init(ring, rs_chroma + rc, P.Rpad, lane, (-(31 + fill_draws)) & 7);
         S.nU = n0_u[rc]; S.nV = n0_v[rc];
     }
 
@@ -694,8 +811,15 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
         (void)edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo);
     }
     // ---------------- steady state: 4 pixels per iteration, ends 16 samples before the row end
-    if ((C.d + (CT::svideo ? 1 : 0)) & 1) t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
-    else t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
+    // (one loop per position phase of the first separator, x1 = t - 7 = chroma delay (+ 1 with S-Video out) mod 4; the
+    //  non-VHS form has one separator at a fixed phase)
+    if constexpr (!VHS) t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
+    else switch ((C.d + (CT::svideo ? 1 : 0)) & 3) {
+        case 0: t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
+        case 1: t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
+        case 2: t = steady<VHS, 2, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
+        default: t = steady<VHS, 3, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
+    }
     // ---------------- row end, filter tails, pipeline drain
     for (; t < total; t++) {
         uint32_t px; int xo;
@@ -787,7 +911,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
                                                       int *__restrict__ tails)
 {
     using namespace fastdec;
-    __shared__ uint32_t ring[31 * 64];
+    __shared__ uint32_t ring[33 * 64];            // LaneRand32
     const int lane = threadIdx.x;
     const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
     const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
@@ -844,7 +968,7 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     S.vl.reset(16, C.a_vl); S.vpre.reset(16, C.a_vl); S.vcU.reset(0, C.a_vc); S.vcV.reset(0, C.a_vc);
     S.sh.reset(0, C.a_sh); S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv);
     S.Yprev = S.Uraw = S.Vraw = 0;
-    S.rng.init(ring, rs_chroma + rc, P.Rpad, lane);
+    S.rng.init(ring, rs_chroma + rc, P.Rpad, lane, (-(31 + 2 * (C.SKT - 7))) & 7);     // (as decode_fast_body)
     S.nU = n0_u[rc]; S.nV = n0_v[rc];
 
     const int SK1 = C.SKT, LOFF = C.LOFF;
@@ -857,17 +981,19 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     // ---------------- steady state
     {
         const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
-        if (t + 4 <= t_end) {
-            const int dph = C.d & 3;
-            const int sn0 = opaque_s(((dph + 0) & 3) == 3 ? -1 : 0), sn1 = opaque_s(((dph + 1) & 3) == 3 ? -1 : 0),
-                      sn2 = opaque_s(((dph + 2) & 3) == 3 ? -1 : 0), sn3 = opaque_s(((dph + 3) & 3) == 3 ? -1 : 0);
+        if (t + 4 <= t_end && !(S.rng.pos & 7)) {
+            Steady T;
+            T.D1.from(S.D1, (C.d & 1) != 0);
+            T.D2.from(S.D2, true);              // (unused by this half)
+            T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
+            int sbase = S.rng.pos;
             int pc[4], pl[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = cs_load(C, t + j - LOFF); }
             unsigned soff = (unsigned)(t - SK1) * rb;
 #define NTSC_VCR_STEP(DPV, J)                                                                     \
             {                                                                                     \
-                const int c2 = vcr_step<DPV, J, RT, CT>(P, S, C, ring, pc[J], pl[J], sn##J, yv_, uv_, vv_); \
+                const int c2 = vcr_step<DPV, J, RT, CT>(P, S, T, C, pc[J], pl[J], yv_, uv_, vv_); \
                 pc[J] = cs_load(C, t + 4 + J);        /* reloaded right after its step consumed it */ \
                 pl[J] = cs_load(C, t + 4 + J - LOFF);                                             \
                 __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
@@ -876,11 +1002,20 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
             }
 #define NTSC_VCR_ITER(DPV)                                                                        \
             for (; t + 4 <= t_end; t += 4) {                                                      \
+                T.rb = ring + sbase * 64 + lane; T.rb0 = sbase == 0; sbase = (sbase + 8) & 31;    \
                 NTSC_VCR_STEP(DPV, 0) NTSC_VCR_STEP(DPV, 1) NTSC_VCR_STEP(DPV, 2) NTSC_VCR_STEP(DPV, 3)  \
             }
-            if (C.d & 1) { NTSC_VCR_ITER(1) } else { NTSC_VCR_ITER(0) }
+            switch (C.d & 3) {
+                case 0: NTSC_VCR_ITER(0) break;
+                case 1: NTSC_VCR_ITER(1) break;
+                case 2: NTSC_VCR_ITER(2) break;
+                default: NTSC_VCR_ITER(3) break;
+            }
 #undef NTSC_VCR_ITER
 #undef NTSC_VCR_STEP
+            T.D1.to(S.D1, (C.d & 1) != 0);
+            S.l2 = T.lc1; S.l1 = T.lpA - T.lc1; S.l0 = T.lpB - S.l1; S.lsum = S.l0 + S.l1 + S.l2;
+            S.rng.pos = sbase;
         }
     }
     // ---------------- row end, filter tails, drain
