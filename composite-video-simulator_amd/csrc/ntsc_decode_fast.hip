@@ -220,8 +220,10 @@ struct DemodR {
         int I, Q;
         if (x & 1) {
             const bool m = (x + 1 + (int)xi + 1) < W;                    // :1550
-            const int a = hi ? w3 : w1, b = hi ? w4 : w2;
-            const bool pos = (x & 3) == 1;
+            // (any xi: after the shift w5 = ch(q), ..., w1 = ch(q-4); the pick is ch(q - 4 + xi), ch(q - 3 + xi))
+            const bool od = (xi & 1u) != 0;
+            const int a = hi ? (od ? w4 : w3) : (od ? w2 : w1), b = hi ? (od ? w5 : w4) : (od ? w3 : w2);
+            const bool pos = ((x + 1 + 2 * (int)xi) & 2) != 0;           // :1539-1542 through :1550-1553
             ieN = m ? (pos ? a : -a) : 0;
             qeN = m ? (pos ? b : -b) : 0;
             I = (ieP + ieN) >> 1;
@@ -272,8 +274,14 @@ struct DemodS {
     // PICK = x is odd; NEG = the picked pair is negated (x = 3 mod 4), compile time; hi = lane mask of xi == 2;
     // dm = and-mask applied to the picked pair (dropout :1891-1901 folded into the pick: everything the separator
     // puts out afterwards is an average or a copy of picked values; -1 where there is no dropout stage behind it)
-    template <bool PICK, bool NEG, bool LUMA, bool BK = false, bool MASK = false>
-    DEV void push(int ct, bool hi, int dm, int &Yo, int &Io, int &Qo, unsigned bmul = 0, unsigned bshift = 0)
+    // ANY: the scanline phase xi may be odd as well (-comp-phase 90 / 270, odd offsets; per lane).  The pick for the
+    // even position xe = x + 1 is raw chroma (xe + xi, xe + xi + 1) = the samples pushed (4 - xi, 3 - xi) positions ago
+    // -- for odd xi one position later than for xi - 1, i.e. out of the OTHER parity stream, the newest one being this
+    // step's own sample -- and the half-cycle flip :1539-1542 leaves it positive iff (xe + 2 xi) & 2: the even-phase sign
+    // (NEG) inverted on odd lanes (`mo`: -1 where xi is odd).
+    template <bool PICK, bool NEG, bool LUMA, bool BK = false, bool MASK = false, bool ANY = false>
+    DEV void push(int ct, bool hi, int dm, int &Yo, int &Io, int &Qo, unsigned bmul = 0, unsigned bshift = 0,
+                  bool odd = false, int mo = 0)
     {
         const int p = ct + c1;
         const int yb = sdiv4s(p + pB);
@@ -282,9 +290,18 @@ struct DemodS {
         c1 = ct; pB = pA; pA = p;
         if (LUMA) { Yo = y0; y0 = y1; y1 = y2; y2 = y3; y3 = y4; y4 = yb; }
         if (PICK) {
-            int a = hi ? e1 : e2, b = hi ? o1 : o2;
+            int a, b;
+            if (ANY) {
+                const int aL = odd ? o2 : e2, aH = odd ? o1 : e1;
+                const int bL = odd ? e1 : o2, bH = odd ? ch : o1;
+                a = hi ? aH : aL; b = hi ? bH : bL;
+                const int sg = NEG ? ~mo : mo;
+                a = (a ^ sg) - sg; b = (b ^ sg) - sg;
+            } else {
+                a = hi ? e1 : e2; b = hi ? o1 : o2;
+                if (NEG) { a = -a; b = -b; }
+            }
             e2 = e1; e1 = ch;
-            if (NEG) { a = -a; b = -b; }
             if (MASK) { a &= dm; b &= dm; }
             ieN = a; qeN = b;
             Io = (ieP + ieN) >> 1;
@@ -310,11 +327,15 @@ struct State {
 
 // per-lane / per-launch constants.  WR: the head-switch displacement may wrap around the 1.1 W window
 // (address fix-up per load, see cs_load)
-template <class RT, bool WR = false, bool BK = false, bool SV = false>
+template <class RT, bool WR = false, bool BK = false, bool SV = false, bool XA = false>
 struct Const {
     static constexpr bool wraps = WR;
     static constexpr bool back = BK;
     static constexpr bool svideo = SV;     // VHS form with S-Video out: no re-modulation, no second separation
+    static constexpr bool anyxi = XA;      // scanline phases of either parity (per lane): -comp-phase 90 / 270, odd offsets
+    bool odd;                 // XA: xi is odd
+    int mo;                   // XA: -1 where xi is odd
+    int ms[4];                // XA: sign of the re-modulated chroma at unrolled position J: -1 where (xi + J) & 2
     unsigned bmul, bshift;    // BK: magic multiplier of subcarrier_amplitude_back
     int wrapoff;              // WR: byte offset of the wrapped index, -tw or +tw samples (sign of the shift)
     int wrapA, wrapS;         // WR: x wraps iff ((wrapA - x) ^ wrapS) < 0
@@ -415,7 +436,7 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, Steady &T, const CT &C,
     constexpr bool pick1 = ((DPH + J) & 1) != 0;
     constexpr bool neg1 = ((DPH + J) & 3) == 3;
     int Yd, U, V;
-    T.D1.template push<pick1, neg1, false, CT::back, false>(pc, C.hi, -1, Yd, U, V, C.bmul, C.bshift);
+    T.D1.template push<pick1, neg1, false, CT::back, false, CT::anyxi>(pc, C.hi, -1, Yd, U, V, C.bmul, C.bshift, C.odd, C.mo);
     // chroma noise :1719-1735
     U += S.nU; V += S.nV;
     S.nU = sdiv2(S.nU + (int)umod31(S.rng.template draw<2 * J>(T.rb, T.rb0), P.m_cnoise) - P.cnoise_k);
@@ -444,6 +465,12 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, Steady &T, const CT &C,
     V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
     Yv = Y; Uv = U; Vv = V;
     // composite out of the VCR :1885-1888: modulate at x2 (amplitude 50: (v*50)/50 == v)
+    if constexpr (CT::anyxi) {
+        // U4 / V4 at (xi + x2) & 3, x2 = J (mod 4): the carrier's U / V role swaps on odd lanes, the sign is per lane
+        const int chroma = (J & 1) ? (C.odd ? U : V) : (C.odd ? V : U);
+        const int mm = C.ms[J];
+        return Y + ((chroma ^ mm) - mm);
+    }
     const int chroma = (J & 1) ? V : U;
     const int mm = (J & 2) ? C.mNL : C.mL;
     return Y + ((chroma ^ mm) - mm);
@@ -459,7 +486,7 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, Steady &T, const CT &C,
 {
     int Y, U, V;
     if constexpr (!VHS) {
-        T.D1.template push<(J & 1) == 0, J == 2, true, CT::back, true>(pc, C.hi, C.dm, Y, U, V, C.bmul, C.bshift);
+        T.D1.template push<(J & 1) == 0, J == 2, true, CT::back, true, CT::anyxi>(pc, C.hi, C.dm, Y, U, V, C.bmul, C.bshift, C.odd, C.mo);
     } else {
         int Yv, Uv, Vv;
         const int c2 = vcr_step<DPH, J, RT, CT>(P, S, T, C, pc, pl, Yv, Uv, Vv);
@@ -467,7 +494,7 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, Steady &T, const CT &C,
             Y = Yv; U = Uv & C.dm; V = Vv & C.dm;  // -vhs-svideo: the components go on as they are :1885; dropout :1891
         } else {
             // ... and separate again at x3 (dropout :1891-1901 is the and-mask on the picked pair)
-            T.D2.template push<(J & 1) == 0, J == 2, true, false, true>(c2, C.hi, C.dm, Y, U, V);
+            T.D2.template push<(J & 1) == 0, J == 2, true, false, true, CT::anyxi>(c2, C.hi, C.dm, Y, U, V, 0, 0, C.odd, C.mo);
         }
     }
     // composite_lowpass_tv :1399-1427 (delay 1) and YIQ -> RGB for the previous position
@@ -713,7 +740,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
 // WR (VHS form only): head-switch displacements beyond W/10 samples, e.g. PAL's 312.5-line field with
 // the default switching point (see cs_load).  BK: subcarrier_amplitude_back other than 50 (the pre-emphasis
 // presets -comp-catv* raise it), see scale_back50.
-template <bool VHS, class RT, bool WR, bool BK, bool SV = false>
+template <bool VHS, class RT, bool WR, bool BK, bool SV = false, bool XA = false>
 DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
                           const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                           const int *__restrict__ n0_u, const int *__restrict__ n0_v,
@@ -744,11 +771,15 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     const size_t tcol = (size_t)blockIdx.x * 64 + lane;
     const size_t tstride = (size_t)gridDim.x * 64;
 
-    typedef Const<RT, WR, BK, SV> CT;
+    typedef Const<RT, WR, BK, SV, XA> CT;
     CT C;
     C.bmul = P.m_amp_back.mul; C.bshift = P.m_amp_back.shift;
     C.xi = scan_phase(P, y, fd.fieldno);
     C.hi = (C.xi & 2u) != 0;
+    C.odd = (C.xi & 1u) != 0;
+    C.mo = opaque_v(C.odd ? -1 : 0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) C.ms[j] = opaque_v(((C.xi + (unsigned)j) & 2u) ? -1 : 0);
     C.W = W;
     C.xe = (W & 1) ? W - 1 : W - 2;
     C.lane = lane;
@@ -868,6 +899,23 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast_b
                                                      int *__restrict__ tails)
 {
     decode_fast_body<VHS, RT, VHS, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
+}
+
+// the -vhs family with scanline phases of either parity (-comp-phase 90 / 270, or an odd -comp-phase-offset): the picks
+// and the re-modulation take their per-lane forms (DemodS::push ANY, vcr_step); wrap-around loads (any displacement)
+template <class RT>
+__global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_xi(DevParams P, GeomDev G,
+                                                     const FieldDev *__restrict__ fields,
+                                                     const int *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rs_chroma,
+                                                     const int *__restrict__ n0_u,
+                                                     const int *__restrict__ n0_v,
+                                                     const int *__restrict__ hs_shift,
+                                                     const int *__restrict__ pn_noise,
+                                                     const int *__restrict__ dropout,
+                                                     int *__restrict__ tails)
+{
+    decode_fast_body<true, RT, true, false, false, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
 }
 
 // the -vhs preset with S-Video out (-vhs-svideo 1): the VCR's components go to the TV stages directly, no

@@ -42,6 +42,8 @@ struct EConst {
     unsigned xi;
     int W, lane;
     int mL, mNL;          // -1 / 0 masks of (xi == 2) and its complement
+    bool odd;             // XA (scanline phases of either parity): xi is odd
+    int ms[4];            // XA: sign of the modulated chroma at unrolled position J: -1 where (xi + J) & 2
     RT a_i, a_q;
     RT a_pre, pre_gain;   // PRE
     __amdgpu_buffer_rsrc_t comp;
@@ -72,7 +74,7 @@ DEV int preemphasis(EState<RT> &S, const EConst<RT> &C, int Y)
     return (int)sd;
 }
 
-template <int J, class RT, bool PRE>
+template <int J, class RT, bool PRE, bool XA = false>
 DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
              RT Id, RT Qd, int Yx, int I2, int &fI_out)
 {
@@ -80,8 +82,9 @@ DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *r
     const int fQ = (int)S.lpQ.push(Qd, C.a_q);      // lands at index t - 4 = x
     // chroma_into_luma :1460-1495, phase (xi + x) & 3 with xi in {0, 2}: I for even x, sign by
     // (x & 2) ^ (xi & 2)
-    const int chroma = (J & 1) ? fQ : I2;
-    const int mm = (J & 2) ? C.mNL : C.mL;
+    // XA: xi of either parity, per lane (-comp-phase 90 / 270, odd offsets): I / Q swap roles on odd lanes
+    const int chroma = XA ? ((J & 1) ? (C.odd ? I2 : fQ) : (C.odd ? fQ : I2)) : ((J & 1) ? fQ : I2);
+    const int mm = XA ? C.ms[J & 3] : ((J & 2) ? C.mNL : C.mL);
     int Y = Yx + ((chroma ^ mm) - mm);
     if (PRE) Y = preemphasis<RT>(S, C, Y);
     // luma noise :1632-1644
@@ -179,7 +182,7 @@ struct CoopLoader {
 
 } // namespace fastenc
 
-template <class RT, bool PRE>
+template <class RT, bool PRE, bool XA = false>
 DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ fields, const uint32_t *__restrict__ rs_luma,
                           const int *__restrict__ n0_luma, int *__restrict__ comp)
 {
@@ -209,6 +212,9 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
     C.lane = lane;
     C.mL = opaque_v((C.xi & 2u) ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
+    C.odd = (C.xi & 1u) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) C.ms[j] = fastdec::opaque_v(((C.xi + (unsigned)j) & 2u) ? -1 : 0);
     C.a_i = (RT)P.a_in_i; C.a_q = (RT)P.a_in_q;
     C.a_pre = (RT)P.a_pre; C.pre_gain = (RT)P.pre_gain;
     C.rowbytes = P.Rpad * 4;
@@ -258,7 +264,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
                 rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
-                const int Y = step<J, RT, PRE>(P, S, C, ring, Id_, Qd_, YX, IX, F[J]);                 \
+                const int Y = step<J, RT, PRE, XA>(P, S, C, ring, Id_, Qd_, YX, IX, F[J]);             \
                 __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
@@ -307,6 +313,16 @@ __global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev 
                                                     int *__restrict__ comp)
 {
     encode_fast_body<RT, false>(P, fields, rs_luma, n0_luma, comp);
+}
+
+// the same for scanline phases of either parity (-comp-phase 90 / 270, odd -comp-phase-offset)
+template <class RT>
+__global__ __launch_bounds__(64) void k_encode_fast_xi(DevParams P, const FieldDev *__restrict__ fields,
+                                                       const uint32_t *__restrict__ rs_luma,
+                                                       const int *__restrict__ n0_luma,
+                                                       int *__restrict__ comp)
+{
+    encode_fast_body<RT, false, true>(P, fields, rs_luma, n0_luma, comp);
 }
 
 // the same with composite pre-emphasis (ffmpeg_ntsc.cpp:1614-1629; the -comp-catv* presets)

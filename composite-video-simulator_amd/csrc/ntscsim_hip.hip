@@ -640,6 +640,13 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                                      fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
         else hipLaunchKernelGGL((k_encode_fast<double>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
                                 fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    } else if (enc_preset && !c->no_fast_decode && !even_phase && small_plane && D.src_al16) {
+        // ... with scanline phases of either parity
+        note_kernel(c, fast ? "k_encode_fast_xi<float>" : "k_encode_fast_xi<double>");
+        if (fast) hipLaunchKernelGGL((k_encode_fast_xi<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                                     fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+        else hipLaunchKernelGGL((k_encode_fast_xi<double>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
+                                fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
     } else if (enc_preset_pre && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
         note_kernel(c, fast ? "k_encode_fast_pre<float>" : "k_encode_fast_pre<double>");
         if (fast) hipLaunchKernelGGL((k_encode_fast_pre<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
@@ -676,6 +683,9 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     // (the one-launch VHS form also exists with wrap-around head-switch loads; every other fast form
     // needs the displacement to stay within W/10 samples)
     const bool dec_fast = dec_base && (back50 || D.amp_back >= 2) && !c->no_fast_decode && D.dst_al16 && even_phase && small_plane;
+    // the same family with scanline phases of either parity: its own form (any head-switch displacement)
+    const bool dec_fast_xi = dec_base && back50 && !c->no_fast_decode && D.dst_al16 && !even_phase && D.vhs && !D.svideo &&
+                             D.cnoise_k && D.pnoise_k && fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0);
 #define NTSC_LAUNCH_FAST(VHS, RT)                                                                \
     do { note_kernel(c, "k_decode_fast<" #VHS "," #RT ">");                                      \
     hipLaunchKernelGGL((k_decode_fast<VHS, RT>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
@@ -711,6 +721,14 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
                                 tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                 c->pn_noise.p, c->dropout.p, c->tails.p);
+    } else if (dec_fast_xi) {
+        note_kernel(c, fast ? "k_decode_fast_xi<float>" : "k_decode_fast_xi<double>");
+        if (fast) hipLaunchKernelGGL((k_decode_fast_xi<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                                     c->dropout.p, c->tails.p);
+        else hipLaunchKernelGGL((k_decode_fast_xi<double>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                                c->dropout.p, c->tails.p);
     } else if (dec_fast && back50 && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {
         if (fast) NTSC_LAUNCH_FAST(true, float); else NTSC_LAUNCH_FAST(true, double);
     } else if (dec_fast && back50 && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) {

@@ -324,8 +324,14 @@ def test_preset_and_generic_kernels_agree(flags, w, h):
     (["-tvstd", "pal", "-vhs"], 96, 36, 2), (["-tvstd", "pal", "-vhs"], 720, 576, 2),
     (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.0012"], 96, 32, 2),
     (["-vhs", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32, 2),
+    # scanline phases of either parity: the any-phase forms k_encode_fast_xi + k_decode_fast_xi (per-lane picks, signs
+    # and carrier roles); all four phases occur among the rows of these cases
+    (["-vhs", "-comp-phase-offset", "1"], 96, 32, 5), (["-vhs", "-comp-phase", "90"], 96, 32, 5),
+    (["-vhs", "-comp-phase", "270", "-comp-phase-offset", "3"], 100, 35, 5), (["-vhs", "-comp-phase", "90"], 720, 486, 5),
+    (["-vhs", "-comp-phase", "0", "-comp-phase-offset", "3", "-vhs-speed", "lp"], 96, 32, 5),
+    (["-tvstd", "pal", "-vhs", "-comp-phase", "90", "-chroma-dropout", "30000"], 96, 36, 5),
     # preconditions of the hand-tuned kernels NOT met -> they must fall back, results unchanged
-    (["-vhs", "-comp-phase-offset", "1"], 96, 32, 0), (["-vhs", "-comp-phase", "90"], 96, 32, 0),
+    (["-comp-phase", "90"], 96, 32, 0), (["-vhs", "-comp-phase", "90", "-nocolor-subcarrier"], 96, 32, 6),
     # the pre-emphasis presets (subcarrier_amplitude_back != 50): k_encode_fast_pre + k_decode_fast_bk
     (["-vhs", "-comp-catv"], 96, 32, 3), (["-vhs", "-comp-catv2"], 96, 32, 3), (["-vhs", "-comp-catv4"], 64, 38, 3),
     (["-vhs", "-comp-catv3", "-vhs-head-switching-point", "0.105", "-vhs-head-switching-phase", "0.002"], 96, 32, 3),
@@ -367,6 +373,11 @@ def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
         elif fast_ok == 3:
             assert dec == ["k_decode_fast_bk<true,double>"], (mode, ran)
             assert "k_encode_fast_pre<double>" in ran, ran
+        elif fast_ok == 6:
+            assert len(dec) == 1 and dec[0].startswith("k_decode<"), (mode, ran)
+        elif fast_ok == 5 and mode in ("hand-tuned", "two-launch"):
+            assert dec == ["k_decode_fast_xi<double>"], (mode, ran)
+            assert "k_encode_fast_xi<double>" in ran, ran
         elif fast_ok == 4 and mode == "template":
             assert dec == ["k_decode<true,false,1u,double>"], (mode, ran)
         elif fast_ok == 4:
