@@ -223,7 +223,10 @@ struct DemodR {
             // (any xi: after the shift w5 = ch(q), ..., w1 = ch(q-4); the pick is ch(q - 4 + xi), ch(q - 3 + xi))
             const bool od = (xi & 1u) != 0;
             const int a = hi ? (od ? w4 : w3) : (od ? w2 : w1), b = hi ? (od ? w5 : w4) : (od ? w3 : w2);
-            const bool pos = ((x + 1 + 2 * (int)xi) & 2) != 0;           // :1539-1542 through :1550-1553
+            // flipped (:1539-1542) and then negated (:1550-1553) = positive iff (xe + 2 xi) & 2, xe = x + 1 -- except the
+            // row's first pair with xi = 1: the flip loop starts at x = (4 - xi) & 3 = 3, so chroma[1], chroma[2] keep
+            // their sign although the pattern would flip them
+            const bool pos = (((x + 1 + 2 * (int)xi) & 2) != 0) && !(xi == 1u && x == -1);
             ieN = m ? (pos ? a : -a) : 0;
             qeN = m ? (pos ? b : -b) : 0;
             I = (ieP + ieN) >> 1;
