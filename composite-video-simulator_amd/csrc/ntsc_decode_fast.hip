@@ -324,14 +324,26 @@ struct State {
     Casc3<RT> vl, vcU, vcV, sh, oU, oV;
     PoleHp<RT> vpre;
     int Yprev, Uraw, Vraw;                    // previous step's output-stage inputs
+    // FO (full output low-pass), guarded steps: luma and raw chroma of the last four positions ([0] oldest), the
+    // filtered I of the last two
+    int Yd4[4], Ur4[4], Vr4[4];
+    RT Uf2[2];
     LaneRand32 rng;
     int nU, nV;
 };
 
 // per-lane / per-launch constants.  WR: the head-switch displacement may wrap around the 1.1 W window
 // (address fix-up per load, see cs_load)
-template <class RT, bool WR = false, bool BK = false, bool SV = false, bool XA = false>
+template <class RT, bool WR = false, bool BK = false, bool SV = false, bool XA = false, bool FO = false>
 struct Const {
+    // FO: the FULL output chroma low-pass (composite_lowpass :1429-1458 behind the VCR: -out-composite-lowpass-lite 0):
+    // I at 1.3 MHz landing 2 samples back, Q at 0.6 MHz landing 4 back, instead of the TV filter (2.6 MHz, 1 back, both).
+    // The pixel for position xo leaves at x3 = xo + 4 (3 steps later than with the TV filter): luma waits 4 steps, the
+    // filtered I 2 -- both delay lines a divisor of the 4x unroll -- and every position phase of the TV half moves by
+    // SH = 3 (the phases of the steady step are written in terms of it).
+    static constexpr bool fullout = FO;
+    static constexpr int SH = FO ? 3 : 0;
+    RT a_oi, a_oq;            // FO: alphas of the I / Q output filters
     static constexpr bool wraps = WR;
     static constexpr bool back = BK;
     static constexpr bool svideo = SV;     // VHS form with S-Video out: no re-modulation, no second separation
@@ -428,6 +440,8 @@ struct Steady {
     int lc1, lpA, lpB;          // VHS luma stream: c(t-1) and the pair sums (as DemodS)
     uint32_t *rb;               // this lane's column of the iteration's first ring slot
     bool rb0;                   // that slot is slot 0 (its copy behind slot 31 is written too)
+    int yd[4];                  // FO: luma of the last four positions, slot J rewritten at unrolled position J
+    double ud[2];               // FO: filtered I of the last two positions (as reals; float mode: exact in a double)
 };
 
 // DPH = the first separator's position phase: x1 = t - 7 = DPH + J (mod 4) -- odd positions pick, x1 = 3 (mod 4)
@@ -468,14 +482,15 @@ DEV int vcr_step(const DevParams &P, State<true, RT> &S, Steady &T, const CT &C,
     V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
     Yv = Y; Uv = U; Vv = V;
     // composite out of the VCR :1885-1888: modulate at x2 (amplitude 50: (v*50)/50 == v)
+    constexpr int J2 = (J + CT::SH) & 3;      // x2 = x3 + 7 = J + SH (mod 4)
     if constexpr (CT::anyxi) {
-        // U4 / V4 at (xi + x2) & 3, x2 = J (mod 4): the carrier's U / V role swaps on odd lanes, the sign is per lane
-        const int chroma = (J & 1) ? (C.odd ? U : V) : (C.odd ? V : U);
-        const int mm = C.ms[J];
+        // U4 / V4 at (xi + x2) & 3: the carrier's U / V role swaps on odd lanes, the sign is per lane
+        const int chroma = (J2 & 1) ? (C.odd ? U : V) : (C.odd ? V : U);
+        const int mm = C.ms[J2];
         return Y + ((chroma ^ mm) - mm);
     }
-    const int chroma = (J & 1) ? V : U;
-    const int mm = (J & 2) ? C.mNL : C.mL;
+    const int chroma = (J2 & 1) ? V : U;
+    const int mm = (J2 & 2) ? C.mNL : C.mL;
     return Y + ((chroma ^ mm) - mm);
 }
 
@@ -488,8 +503,11 @@ template <bool VHS, int DPH, int J, class RT, class CT>
 DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, Steady &T, const CT &C, int pc, int pl)
 {
     int Y, U, V;
+    // the TV half's separator sits at x3 = J + 1 + SH (mod 4): odd positions pick, 3 (mod 4) negates
+    constexpr bool pick3 = ((J + 1 + CT::SH) & 1) != 0;
+    constexpr bool neg3 = ((J + 1 + CT::SH) & 3) == 3;
     if constexpr (!VHS) {
-        T.D1.template push<(J & 1) == 0, J == 2, true, CT::back, true, CT::anyxi>(pc, C.hi, C.dm, Y, U, V, C.bmul, C.bshift, C.odd, C.mo);
+        T.D1.template push<pick3, neg3, true, CT::back, true, CT::anyxi>(pc, C.hi, C.dm, Y, U, V, C.bmul, C.bshift, C.odd, C.mo);
     } else {
         int Yv, Uv, Vv;
         const int c2 = vcr_step<DPH, J, RT, CT>(P, S, T, C, pc, pl, Yv, Uv, Vv);
@@ -497,15 +515,27 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, Steady &T, const CT &C,
             Y = Yv; U = Uv & C.dm; V = Vv & C.dm;  // -vhs-svideo: the components go on as they are :1885; dropout :1891
         } else {
             // ... and separate again at x3 (dropout :1891-1901 is the and-mask on the picked pair)
-            T.D2.template push<(J & 1) == 0, J == 2, true, false, true, CT::anyxi>(c2, C.hi, C.dm, Y, U, V, 0, 0, C.odd, C.mo);
+            T.D2.template push<pick3, neg3, true, false, true, CT::anyxi>(c2, C.hi, C.dm, Y, U, V, 0, 0, C.odd, C.mo);
         }
     }
-    // composite_lowpass_tv :1399-1427 (delay 1) and YIQ -> RGB for the previous position
-    const RT fUd = rtrunc<RT>(S.oU.push((RT)U, C.a_tv));
-    const RT fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_tv));
-    const int Yo = S.Yprev;
-    S.Yprev = Y;
-    return yiq_to_bgra<RT>(Yo, fUd, fVd);
+    if constexpr (CT::fullout) {
+        // composite_lowpass :1429-1458 as the output filter: I lands 2 positions back, Q 4; the pixel of position
+        // x3 - 4 takes the luma of four steps ago, the filtered I of two steps ago and this step's filtered Q
+        const RT fUn = rtrunc<RT>(S.oU.push((RT)U, C.a_oi));
+        const RT fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_oq));
+        const int Yo = T.yd[J];
+        T.yd[J] = Y;
+        const RT fUd = (RT)T.ud[J & 1];
+        T.ud[J & 1] = (double)fUn;
+        return yiq_to_bgra<RT>(Yo, fUd, fVd);
+    } else {
+        // composite_lowpass_tv :1399-1427 (delay 1) and YIQ -> RGB for the previous position
+        const RT fUd = rtrunc<RT>(S.oU.push((RT)U, C.a_tv));
+        const RT fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_tv));
+        const int Yo = S.Yprev;
+        S.Yprev = Y;
+        return yiq_to_bgra<RT>(Yo, fUd, fVd);
+    }
 }
 
 // One guarded step at any stream position t (wave-uniform): pipeline fill, row end, filter
@@ -591,6 +621,31 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
         const int pc = t < W ? cs_load(C, t) : 0;         // t is wave-uniform
         S.D1.template push_edge<CT::back>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
     }
+    if constexpr (CT::fullout) {
+        if (x3 < 0 || x3 >= W + 4) return false;
+        const bool in3f = x3 < W;
+        if (!in3f) { U = 0; V = 0; Y = 0; }
+        U &= C.dm; V &= C.dm;
+        RT fUn = 0, fVn = 0;
+        if (in3f) {
+            fUn = rtrunc<RT>(S.oU.push((RT)U, C.a_oi));
+            fVn = rtrunc<RT>(S.oV.push((RT)V, C.a_oq));
+        }
+        const int Yo4 = S.Yd4[0], Ur4 = S.Ur4[0], Vr4 = S.Vr4[0];      // position x3 - 4
+        const RT Uf = S.Uf2[0];                                        // filtered I pushed two steps ago
+#pragma unroll
+        for (int q = 0; q < 3; q++) { S.Yd4[q] = S.Yd4[q + 1]; S.Ur4[q] = S.Ur4[q + 1]; S.Vr4[q] = S.Vr4[q + 1]; }
+        S.Yd4[3] = Y; S.Ur4[3] = U; S.Vr4[3] = V;
+        S.Uf2[0] = S.Uf2[1]; S.Uf2[1] = fUn;
+        const int xof = x3 - 4;
+        if (xof < 0) return false;
+        // the last `delay` samples of a row keep their input :1448-1453
+        const RT Uo = xof < W - 2 ? Uf : (RT)Ur4;
+        const RT Vo = xof < W - 4 ? fVn : (RT)Vr4;
+        px = yiq_to_bgra<RT>(Yo4, Uo, Vo);
+        xo_out = xof;
+        return true;
+    }
     if (x3 < 0 || x3 > W) return false;
     const bool in3 = x3 < W;
     if (!in3) { U = 0; V = 0; Y = 0; }
@@ -628,9 +683,15 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     // the separators and the luma box in their steady form: the next position is t; the first separator (x1 = t - 7 =
     // DPH mod 4) picks there iff DPH is odd, the second one / the only one of the non-VHS form (x3 = 4n + 1) always
     Steady T;
-    T.D1.from(S.D1, VHS ? (DPH & 1) != 0 : true);
-    T.D2.from(S.D2, true);
+    constexpr bool pick3_next = ((1 + CT::SH) & 1) != 0;        // x3 = 1 + SH (mod 4) at J = 0
+    T.D1.from(S.D1, VHS ? (DPH & 1) != 0 : pick3_next);
+    T.D2.from(S.D2, pick3_next);
     T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
+    if constexpr (CT::fullout) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) T.yd[q] = S.Yd4[q];
+        T.ud[0] = (double)S.Uf2[0]; T.ud[1] = (double)S.Uf2[1];
+    }
     // (the separator in front of the TV stages carries the dropout mask on everything it has picked: the guarded steps
     //  apply it to their outputs instead, so what they left behind is masked here)
     DemodS &Dout = (VHS && !CT::svideo) ? T.D2 : T.D1;
@@ -722,8 +783,14 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     NTSC_FAST_FLUSH()
 #undef NTSC_FAST_FLUSH
     // back to the guarded steps' layout (t has advanced by a multiple of 4: the same position phases as at the entry)
-    T.D1.to(S.D1, VHS ? (DPH & 1) != 0 : true);
-    T.D2.to(S.D2, true);
+    T.D1.to(S.D1, VHS ? (DPH & 1) != 0 : pick3_next);
+    T.D2.to(S.D2, pick3_next);
+    if constexpr (CT::fullout) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) S.Yd4[q] = T.yd[q];
+        S.Uf2[0] = (RT)T.ud[0]; S.Uf2[1] = (RT)T.ud[1];
+        // (raw chroma of the last four positions: refilled by the >= 16 guarded steps before the row's tail reads it)
+    }
     S.l2 = T.lc1; S.l1 = T.lpA - T.lc1; S.l0 = T.lpB - S.l1; S.lsum = S.l0 + S.l1 + S.l2;
     if (VHS) S.rng.pos = sbase;
     return t;
@@ -743,7 +810,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
 // WR (VHS form only): head-switch displacements beyond W/10 samples, e.g. PAL's 312.5-line field with
 // the default switching point (see cs_load).  BK: subcarrier_amplitude_back other than 50 (the pre-emphasis
 // presets -comp-catv* raise it), see scale_back50.
-template <bool VHS, class RT, bool WR, bool BK, bool SV = false, bool XA = false>
+template <bool VHS, class RT, bool WR, bool BK, bool SV = false, bool XA = false, bool FO = false>
 DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
                           const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                           const int *__restrict__ n0_u, const int *__restrict__ n0_v,
@@ -774,7 +841,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     const size_t tcol = (size_t)blockIdx.x * 64 + lane;
     const size_t tstride = (size_t)gridDim.x * 64;
 
-    typedef Const<RT, WR, BK, SV, XA> CT;
+    typedef Const<RT, WR, BK, SV, XA, FO> CT;
     CT C;
     C.bmul = P.m_amp_back.mul; C.bshift = P.m_amp_back.shift;
     C.xi = scan_phase(P, y, fd.fieldno);
@@ -787,7 +854,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     C.xe = (W & 1) ? W - 1 : W - 2;
     C.lane = lane;
     C.d = VHS ? P.cdelay : 0;
-    C.SKT = VHS ? (CT::svideo ? 8 : 15) + C.d : 8;
+    C.SKT = (VHS ? (CT::svideo ? 8 : 15) + C.d : 8) + CT::SH;
     C.LOFF = 5 + C.d;
     C.mL = opaque_v(C.hi ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
@@ -802,6 +869,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
         C.cosv = (RT)G.ptab[2 * n]; C.sinv = (RT)G.ptab[2 * n + 1];
     }
     C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
+    C.a_oi = (RT)P.a_in_i; C.a_oq = (RT)P.a_in_q;     // (composite_lowpass :1429: the input filter's cutoffs)
     C.sharp2 = (RT)(P.sharpen * 2);            // (x * s) * 2 == x * (s * 2): scaling by 2 is exact
     C.tailU = tails + tcol;
     C.tailV = tails + 16 * tstride + tcol;
@@ -825,8 +893,13 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     S.D1.init(); S.D2.init();
     S.l0 = S.l1 = S.l2 = S.lsum = 0;
     S.vl.reset(16, C.a_vl); S.vpre.reset(16, C.a_vl); S.vcU.reset(0, C.a_vc); S.vcV.reset(0, C.a_vc);
-    S.sh.reset(0, C.a_sh); S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv);
+    S.sh.reset(0, C.a_sh);
+    if (CT::fullout) { S.oU.reset(0, C.a_oi); S.oV.reset(0, C.a_oq); }
+    else { S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv); }
     S.Yprev = S.Uraw = S.Vraw = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { S.Yd4[q] = 0; S.Ur4[q] = 0; S.Vr4[q] = 0; }
+    S.Uf2[0] = S.Uf2[1] = 0;
     S.nU = S.nV = 0;
     if (VHS) {
         // the pipeline fill draws twice at every step from x1 = 0 on (t = 7 .. SKT - 1): place the window so that the
@@ -845,10 +918,10 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
         (void)edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo);
     }
     // ---------------- steady state: 4 pixels per iteration, ends 16 samples before the row end
-    // (one loop per position phase of the first separator, x1 = t - 7 = chroma delay (+ 1 with S-Video out) mod 4; the
-    //  non-VHS form has one separator at a fixed phase)
+    // (one loop per position phase of the first separator, x1 = t - 7 = SKT - 7 (mod 4) at the loop's first position;
+    //  the non-VHS form has one separator at a fixed phase)
     if constexpr (!VHS) t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
-    else switch ((C.d + (CT::svideo ? 1 : 0)) & 3) {
+    else switch ((C.SKT - 7) & 3) {
         case 0: t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
         case 1: t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
         case 2: t = steady<VHS, 2, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
@@ -919,6 +992,22 @@ __global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_xi(DevParam
                                                      int *__restrict__ tails)
 {
     decode_fast_body<true, RT, true, false, false, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
+}
+
+// the -vhs family with the FULL output chroma low-pass (-out-composite-lowpass-lite 0; wrap-around loads)
+template <class RT>
+__global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_fo(DevParams P, GeomDev G,
+                                                     const FieldDev *__restrict__ fields,
+                                                     const int *__restrict__ comp,
+                                                     const uint32_t *__restrict__ rs_chroma,
+                                                     const int *__restrict__ n0_u,
+                                                     const int *__restrict__ n0_v,
+                                                     const int *__restrict__ hs_shift,
+                                                     const int *__restrict__ pn_noise,
+                                                     const int *__restrict__ dropout,
+                                                     int *__restrict__ tails)
+{
+    decode_fast_body<true, RT, true, false, false, false, true>(P, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, dropout, tails);
 }
 
 // the -vhs preset with S-Video out (-vhs-svideo 1): the VCR's components go to the TV stages directly, no

@@ -721,6 +721,16 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
                                 tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                 c->pn_noise.p, c->dropout.p, c->tails.p);
+    } else if (!c->force_generic && !D.nocolor && D.out_lp == 2 && D.amp == 50 && back50 && !c->no_fast_decode && D.dst_al16 &&
+               even_phase && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0)) {
+        // the -vhs family with the FULL output chroma low-pass
+        note_kernel(c, fast ? "k_decode_fast_fo<float>" : "k_decode_fast_fo<double>");
+        if (fast) hipLaunchKernelGGL((k_decode_fast_fo<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                                     c->dropout.p, c->tails.p);
+        else hipLaunchKernelGGL((k_decode_fast_fo<double>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                                c->dropout.p, c->tails.p);
     } else if (dec_fast_xi) {
         note_kernel(c, fast ? "k_decode_fast_xi<float>" : "k_decode_fast_xi<double>");
         if (fast) hipLaunchKernelGGL((k_decode_fast_xi<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,

@@ -330,6 +330,11 @@ def test_preset_and_generic_kernels_agree(flags, w, h):
     (["-vhs", "-comp-phase", "270", "-comp-phase-offset", "3"], 100, 35, 5), (["-vhs", "-comp-phase", "90"], 720, 486, 5),
     (["-vhs", "-comp-phase", "0", "-comp-phase-offset", "3", "-vhs-speed", "lp"], 96, 32, 5),
     (["-tvstd", "pal", "-vhs", "-comp-phase", "90", "-chroma-dropout", "30000"], 96, 36, 5),
+    # the FULL output chroma low-pass behind the VCR (I 2 samples back, Q 4): k_decode_fast_fo
+    (["-vhs", "-out-composite-lowpass-lite", "0"], 96, 32, 7), (["-vhs", "-out-composite-lowpass-lite", "0"], 720, 486, 7),
+    (["-vhs", "-out-composite-lowpass-lite", "0", "-vhs-speed", "lp"], 100, 35, 7),
+    (["-vhs", "-out-composite-lowpass-lite", "0", "-vhs-speed", "ep", "-chroma-dropout", "30000"], 64, 20, 7),
+    (["-tvstd", "pal", "-vhs", "-out-composite-lowpass-lite", "0"], 96, 36, 7),
     # preconditions of the hand-tuned kernels NOT met -> they must fall back, results unchanged
     (["-comp-phase", "90"], 96, 32, 0), (["-vhs", "-comp-phase", "90", "-nocolor-subcarrier"], 96, 32, 6),
     # the pre-emphasis presets (subcarrier_amplitude_back != 50): k_encode_fast_pre + k_decode_fast_bk
@@ -373,6 +378,10 @@ def test_every_decoder_path_agrees_with_the_oracle(flags, w, h, fast_ok):
         elif fast_ok == 3:
             assert dec == ["k_decode_fast_bk<true,double>"], (mode, ran)
             assert "k_encode_fast_pre<double>" in ran, ran
+        elif fast_ok == 7 and mode in ("hand-tuned", "two-launch"):
+            assert dec == ["k_decode_fast_fo<double>"], (mode, ran)
+        elif fast_ok == 7:
+            assert len(dec) == 1 and dec[0].startswith("k_decode<true,true,"), (mode, ran)
         elif fast_ok == 6:
             assert len(dec) == 1 and dec[0].startswith("k_decode<"), (mode, ran)
         elif fast_ok == 5 and mode in ("hand-tuned", "two-launch"):
