@@ -324,9 +324,8 @@ struct State {
     Casc3<RT> vl, vcU, vcV, sh, oU, oV;
     PoleHp<RT> vpre;
     int Yprev, Uraw, Vraw;                    // previous step's output-stage inputs
-    // FO (full output low-pass), guarded steps: luma and raw chroma of the last four positions ([0] oldest), the
-    // filtered I of the last two
-    int Yd4[4], Ur4[4], Vr4[4];
+    // FO (full output low-pass), guarded steps: the filtered I of the last two positions (luma and raw chroma of the
+    // last four live in LDS, Const::xs: registers are what this form has least of)
     RT Uf2[2];
     LaneRand32 rng;
     int nU, nV;
@@ -344,6 +343,7 @@ struct Const {
     static constexpr bool fullout = FO;
     static constexpr int SH = FO ? 3 : 0;
     RT a_oi, a_oq;            // FO: alphas of the I / Q output filters
+    uint32_t *xs;             // FO: this lane's column of 12 LDS slots -- luma, raw U, raw V of position p at slot (p & 3) (+4, +8)
     static constexpr bool wraps = WR;
     static constexpr bool back = BK;
     static constexpr bool svideo = SV;     // VHS form with S-Video out: no re-modulation, no second separation
@@ -363,7 +363,7 @@ struct Const {
     int dm;                   // dropout and-mask (0 = this row's chroma is dropped)
     RT cosv, sinv;
     RT a_vc, a_vl, a_sh, a_tv, sharp2;
-    int *tailU, *tailV;
+    int *tailU;               // this lane's column of the raw-chroma tail scratch: U at rows 0..15, V at rows 16..31
     size_t rstride;
     __amdgpu_buffer_rsrc_t comp;   // the whole composite plane; out-of-range reads return 0
     int vbase;                // byte offset of this lane's column (+ head-switch displacement)
@@ -441,7 +441,7 @@ struct Steady {
     uint32_t *rb;               // this lane's column of the iteration's first ring slot
     bool rb0;                   // that slot is slot 0 (its copy behind slot 31 is written too)
     int yd[4];                  // FO: luma of the last four positions, slot J rewritten at unrolled position J
-    double ud[2];               // FO: filtered I of the last two positions (as reals; float mode: exact in a double)
+    int ud[2];                  // FO: filtered I of the last two positions (already truncated: kept as integers)
 };
 
 // DPH = the first separator's position phase: x1 = t - 7 = DPH + J (mod 4) -- odd positions pick, x1 = 3 (mod 4)
@@ -521,12 +521,12 @@ DEV uint32_t step(const DevParams &P, State<VHS, RT> &S, Steady &T, const CT &C,
     if constexpr (CT::fullout) {
         // composite_lowpass :1429-1458 as the output filter: I lands 2 positions back, Q 4; the pixel of position
         // x3 - 4 takes the luma of four steps ago, the filtered I of two steps ago and this step's filtered Q
-        const RT fUn = rtrunc<RT>(S.oU.push((RT)U, C.a_oi));
+        const int fUn = (int)S.oU.push((RT)U, C.a_oi);
         const RT fVd = rtrunc<RT>(S.oV.push((RT)V, C.a_oq));
         const int Yo = T.yd[J];
         T.yd[J] = Y;
         const RT fUd = (RT)T.ud[J & 1];
-        T.ud[J & 1] = (double)fUn;
+        T.ud[J & 1] = fUn;
         return yiq_to_bgra<RT>(Yo, fUd, fVd);
     } else {
         // composite_lowpass_tv :1399-1427 (delay 1) and YIQ -> RGB for the previous position
@@ -563,7 +563,7 @@ DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
         fV = (int)S.vcV.push((RT)V, C.a_vc);
         if (x1 >= W - C.d) {                  // raw tail of the chroma low-pass :1830
             C.tailU[(size_t)(x1 & 15) * C.rstride] = U;
-            C.tailV[(size_t)(x1 & 15) * C.rstride] = V;
+            C.tailU[(size_t)(16 + (x1 & 15)) * C.rstride] = V;
         }
     }
     const int x2 = x1 - C.d;
@@ -576,7 +576,7 @@ DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
     if (in2) {
         if (x2 >= W - C.d) {
             fU = C.tailU[(size_t)(x2 & 15) * C.rstride];
-            fV = C.tailV[(size_t)(x2 & 15) * C.rstride];
+            fV = C.tailU[(size_t)(16 + (x2 & 15)) * C.rstride];
         }
         RT m2;
         RT s = S.vl.push((RT)yb, C.a_vl, m2);
@@ -631,11 +631,10 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
             fUn = rtrunc<RT>(S.oU.push((RT)U, C.a_oi));
             fVn = rtrunc<RT>(S.oV.push((RT)V, C.a_oq));
         }
-        const int Yo4 = S.Yd4[0], Ur4 = S.Ur4[0], Vr4 = S.Vr4[0];      // position x3 - 4
+        const int k3 = x3 & 3;                                         // (wave-uniform)
+        const int Yo4 = (int)C.xs[k3 * 64], Ur4 = (int)C.xs[(4 + k3) * 64], Vr4 = (int)C.xs[(8 + k3) * 64];   // position x3 - 4
+        C.xs[k3 * 64] = (uint32_t)Y; C.xs[(4 + k3) * 64] = (uint32_t)U; C.xs[(8 + k3) * 64] = (uint32_t)V;
         const RT Uf = S.Uf2[0];                                        // filtered I pushed two steps ago
-#pragma unroll
-        for (int q = 0; q < 3; q++) { S.Yd4[q] = S.Yd4[q + 1]; S.Ur4[q] = S.Ur4[q + 1]; S.Vr4[q] = S.Vr4[q + 1]; }
-        S.Yd4[3] = Y; S.Ur4[3] = U; S.Vr4[3] = V;
         S.Uf2[0] = S.Uf2[1]; S.Uf2[1] = fUn;
         const int xof = x3 - 4;
         if (xof < 0) return false;
@@ -669,7 +668,7 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
 // Steady-state loop: every stage strictly inside the row.  Starts at t = SKT (mod 4), 4 pixels per
 // iteration, the next iteration's composite samples requested before the current ones are used.
 template <bool VHS, int DPH, class RT, class CT>
-DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring,
+DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *ring, uint32_t *lring,
                uint32_t *ostage, const unsigned long long *orow, uint32_t *drow, bool is_out, int t)
 {
     // last steady position: every composite sample inside the row (t < W) and no raw chroma tail
@@ -688,9 +687,11 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     T.D2.from(S.D2, pick3_next);
     T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
     if constexpr (CT::fullout) {
+        // (x3 = 4 (mod 4) at J = 0: unrolled position J rewrites the slot of positions = J (mod 4); read before the
+        //  loop)
 #pragma unroll
-        for (int q = 0; q < 4; q++) T.yd[q] = S.Yd4[q];
-        T.ud[0] = (double)S.Uf2[0]; T.ud[1] = (double)S.Uf2[1];
+        for (int q = 0; q < 4; q++) T.yd[q] = (int)C.xs[q * 64];
+        T.ud[0] = (int)S.Uf2[0]; T.ud[1] = (int)S.Uf2[1];
     }
     // (the separator in front of the TV stages carries the dropout mask on everything it has picked: the guarded steps
     //  apply it to their outputs instead, so what they left behind is masked here)
@@ -702,6 +703,11 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     int pc[PD], pl[PD];
 #pragma unroll
     for (int j = 0; j < PD; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load(C, t + j - LOFF) : 0; }
+    // (The VCR's luma path reads every composite sample a second time, LOFF = 5 + d positions behind the chroma path.
+    //  Tried in round 4: an LDS ring of 20 + 3 slots that keeps each sample until the luma path wants it -- the second
+    //  pass over the plane disappears from the L2's memory side, but the ring takes the workgroup from 14 to 20 KB of
+    //  LDS, eight decoder workgroups then fill a CU's 160 KB, and the encoder waves of the neighbouring steps no longer
+    //  fit beside them: kernel 0.766 -> 0.776 ms, four steps in flight 769k -> 755k fields/s.  Not shipped.)
     // Where the registers allow it (non-VHS form) the next iteration's samples are requested at the
     // top of the current one: a whole iteration of arithmetic hides the HBM latency.  The one-launch
     // VHS form has no registers to spare and reloads each sample right after its step consumed it
@@ -787,10 +793,12 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     T.D2.to(S.D2, pick3_next);
     if constexpr (CT::fullout) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) S.Yd4[q] = T.yd[q];
+        for (int q = 0; q < 4; q++) C.xs[q * 64] = (uint32_t)T.yd[q];
         S.Uf2[0] = (RT)T.ud[0]; S.Uf2[1] = (RT)T.ud[1];
-        // (raw chroma of the last four positions: refilled by the >= 16 guarded steps before the row's tail reads it)
+        // (raw chroma of the last four positions, slots 4..11: stale by now -- the >= 16 guarded steps that follow
+        //  rewrite them long before the row's tail reads any)
     }
+    S.Uraw = 0; S.Vraw = 0;        // (likewise: only the row's last sample reads them, every guarded step rewrites them)
     S.l2 = T.lc1; S.l1 = T.lpA - T.lc1; S.l0 = T.lpB - S.l1; S.lsum = S.l0 + S.l1 + S.l2;
     if (VHS) S.rng.pos = sbase;
     return t;
@@ -819,6 +827,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
 {
     using namespace fastdec;
     __shared__ uint32_t ring[33 * 64];            // LaneRand32: 32 slots + the copy of slot 0
+    __shared__ uint32_t lring[FO ? 12 * 64 : 64]; // FO: luma and raw chroma of the last four positions (Const::xs)
     __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
     __shared__ unsigned long long orow[64];       // every lane's output row (0 = none), for the cooperative stores
 
@@ -872,7 +881,6 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     C.a_oi = (RT)P.a_in_i; C.a_oq = (RT)P.a_in_q;     // (composite_lowpass :1429: the input filter's cutoffs)
     C.sharp2 = (RT)(P.sharpen * 2);            // (x * s) * 2 == x * (s * 2): scaling by 2 is exact
     C.tailU = tails + tcol;
-    C.tailV = tails + 16 * tstride + tcol;
     C.rstride = tstride;
     C.rowbytes = P.Rpad * 4;
     // head switching :1687-1697: a per-lane byte offset plus the buffer bounds check (cs_load)
@@ -897,8 +905,9 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     if (CT::fullout) { S.oU.reset(0, C.a_oi); S.oV.reset(0, C.a_oq); }
     else { S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv); }
     S.Yprev = S.Uraw = S.Vraw = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) { S.Yd4[q] = 0; S.Ur4[q] = 0; S.Vr4[q] = 0; }
+    C.xs = lring + lane;
+    if (CT::fullout)
+        for (int q = 0; q < 12; q++) C.xs[q * 64] = 0;
     S.Uf2[0] = S.Uf2[1] = 0;
     S.nU = S.nV = 0;
     if (VHS) {
@@ -920,12 +929,12 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     // ---------------- steady state: 4 pixels per iteration, ends 16 samples before the row end
     // (one loop per position phase of the first separator, x1 = t - 7 = SKT - 7 (mod 4) at the loop's first position;
     //  the non-VHS form has one separator at a fixed phase)
-    if constexpr (!VHS) t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t);
+    if constexpr (!VHS) t = steady<VHS, 0, RT, CT>(P, S, C, ring, lring, ostage, orow, drow, is_out, t);
     else switch ((C.SKT - 7) & 3) {
-        case 0: t = steady<VHS, 0, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
-        case 1: t = steady<VHS, 1, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
-        case 2: t = steady<VHS, 2, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
-        default: t = steady<VHS, 3, RT, CT>(P, S, C, ring, ostage, orow, drow, is_out, t); break;
+        case 0: t = steady<VHS, 0, RT, CT>(P, S, C, ring, lring, ostage, orow, drow, is_out, t); break;
+        case 1: t = steady<VHS, 1, RT, CT>(P, S, C, ring, lring, ostage, orow, drow, is_out, t); break;
+        case 2: t = steady<VHS, 2, RT, CT>(P, S, C, ring, lring, ostage, orow, drow, is_out, t); break;
+        default: t = steady<VHS, 3, RT, CT>(P, S, C, ring, lring, ostage, orow, drow, is_out, t); break;
     }
     // ---------------- row end, filter tails, pipeline drain
     for (; t < total; t++) {
@@ -1090,7 +1099,6 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
     C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
     C.sharp2 = (RT)(P.sharpen * 2);
     C.tailU = tails + tcol;
-    C.tailV = tails + 16 * tstride + tcol;
     C.rstride = tstride;
     C.rowbytes = P.Rpad * 4;
     const int hs = P.hs ? hs_shift[rc] : 0;
