@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +35,32 @@ double alpha_for(double hz)
     const double timeInterval = 1.0 / rate;
     const double tau = 1 / (hz * 2 * M_PI);
     return timeInterval / (tau + timeInterval);
+}
+
+// Host-to-device upload of one of the library's own small tables.  The source is ordinary heap memory, and a
+// hipMemcpy from pageable memory breaks ("invalid argument") when its range straddles the edge of a hipHostRegister'ed
+// region -- which can happen once the library has pinned caller frames in place (ntscsim_frames_host,
+// ntscsim_submit): a heap block that starts in the last page of a registered frame is pinned at its head and pageable
+// behind it.  So every such upload goes through a pinned bounce buffer of the library's own.
+hipError_t upload_table(void *dst_dev, const void *src_host, size_t bytes)
+{
+    static std::mutex mu;
+    static unsigned char *bounce = nullptr;
+    static const size_t CAP = 1u << 20;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!bounce) {
+        const hipError_t e = hipHostMalloc((void **)&bounce, CAP, hipHostMallocPortable);
+        if (e != hipSuccess) { bounce = nullptr; return e; }
+    }
+    const unsigned char *s = static_cast<const unsigned char *>(src_host);
+    unsigned char *d = static_cast<unsigned char *>(dst_dev);
+    for (size_t off = 0; off < bytes; off += CAP) {
+        const size_t n = bytes - off < CAP ? bytes - off : CAP;
+        std::memcpy(bounce, s + off, n);
+        const hipError_t e = hipMemcpy(d + off, bounce, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 template <typename T>
@@ -305,11 +332,11 @@ static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
     HIPCHK(c, g.sstart.ensure(sstart.size()));
     HIPCHK(c, g.jrow.ensure(jrow.size()));
     HIPCHK(c, g.jwarm.ensure(jwarm.size()));
-    HIPCHK(c, hipMemcpy(g.lskip.p, lskip.data(), lskip.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g.pskip.p, pskip.data(), pskip.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g.sstart.p, sstart.data(), sstart.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g.jrow.p, jrow.data(), jrow.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(g.jwarm.p, jwarm.data(), jwarm.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, upload_table(g.lskip.p, lskip.data(), lskip.size() * 4));
+    HIPCHK(c, upload_table(g.pskip.p, pskip.data(), pskip.size() * 4));
+    HIPCHK(c, upload_table(g.sstart.p, sstart.data(), sstart.size() * 4));
+    HIPCHK(c, upload_table(g.jrow.p, jrow.data(), jrow.size() * 4));
+    HIPCHK(c, upload_table(g.jwarm.p, jwarm.data(), jwarm.size() * 4));
     g.W = W; g.H = H; g.variant = D.variant; g.valid = true;
     return NTSCSIM_OK;
 }
@@ -325,7 +352,7 @@ static int build_ptab(ntscsim_ctx *c)
         t[(size_t)(n + K) * 2 + 1] = std::sin(pi);
     }
     HIPCHK(c, c->ptab.ensure(t.size()));
-    HIPCHK(c, hipMemcpy(c->ptab.p, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, upload_table(c->ptab.p, t.data(), t.size() * sizeof(double)));
     c->ptab_ready = true;
     return NTSCSIM_OK;
 }
@@ -861,7 +888,7 @@ extern "C" int ntscsim_batch_create(ntscsim_ctx *c, const ntscsim_field_desc *de
     int rc = prepare_records(c, descs, n, W, H, b->D, host.data(), b->any_bob, b->rng_end);
     if (rc != NTSCSIM_OK) { delete b; return rc; }
     if (b->records.ensure((size_t)n) != hipSuccess ||
-        hipMemcpy(b->records.p, host.data(), (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice) !=
+        upload_table(b->records.p, host.data(), (size_t)n * sizeof(FieldDev)) !=
             hipSuccess) {
         b->records.release();
         delete b;
@@ -1235,8 +1262,8 @@ extern "C" int ntscsim_batch422_create(ntscsim_ctx *c, const ntscsim_field422_de
     const int rc = prepare422(c, descs, n, W, H, b->P, hf.data(), hf422.data());
     if (rc != NTSCSIM_OK) { delete b; return rc; }
     if (b->fields.ensure((size_t)n) != hipSuccess || b->fields422.ensure((size_t)n) != hipSuccess ||
-        hipMemcpy(b->fields.p, hf.data(), (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(b->fields422.p, hf422.data(), (size_t)n * sizeof(Field422Dev), hipMemcpyHostToDevice) != hipSuccess) {
+        upload_table(b->fields.p, hf.data(), (size_t)n * sizeof(FieldDev)) != hipSuccess ||
+        upload_table(b->fields422.p, hf422.data(), (size_t)n * sizeof(Field422Dev)) != hipSuccess) {
         b->fields.release(); b->fields422.release();
         delete b;
         c->err = "ntscsim_batch422_create: device allocation / upload failed";
@@ -1308,9 +1335,8 @@ extern "C" int ntscsim_output422_device(ntscsim_ctx *c, const ntscsim_out422_des
     D.W = W; D.H = H; D.variant = 1;
     HIPCHK(c, c->out422.ensure((size_t)n));
     // (pageable staging: synchronous with respect to the host vector, like ntscsim_fields422_device)
-    HIPCHK(c, hipMemcpyAsync(c->out422.p, c->host_out422.data(), (size_t)n * sizeof(Out422Dev),
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipStreamSynchronize(st));      // (the record buffer may still be read by the previous call's kernel)
+    HIPCHK(c, upload_table(c->out422.p, c->host_out422.data(), (size_t)n * sizeof(Out422Dev)));
     hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)n), dim3(256), 0, st, D, c->out422.p,
                        al4 ? 1 : 0);
     HIPCHK(c, hipGetLastError());
@@ -1346,9 +1372,8 @@ extern "C" int ntscsim_bgra_to_yuv_device(ntscsim_ctx *c, const ntscsim_yuv_desc
     std::memset(&D, 0, sizeof(D));
     D.W = W; D.H = H;
     HIPCHK(c, c->yuv.ensure((size_t)n));
-    HIPCHK(c, hipMemcpyAsync(c->yuv.p, c->host_yuv.data(), (size_t)n * sizeof(YuvDev),
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));      // (pageable staging vector)
+    HIPCHK(c, hipStreamSynchronize(st));      // (the record buffer may still be read by the previous call's kernel)
+    HIPCHK(c, upload_table(c->yuv.p, c->host_yuv.data(), (size_t)n * sizeof(YuvDev)));
     const int v420 = pix_fmt == NTSCSIM_PIX_YUV420P;
     const unsigned rows = v420 ? (unsigned)(H + 1) / 2 : (unsigned)H;
     hipLaunchKernelGGL(k_bgra_to_yuv, dim3((unsigned)((W / 8 + 1 + 127) / 128), rows, (unsigned)n),
@@ -1393,8 +1418,8 @@ extern "C" int ntscsim_scale_to_bgra_device(ntscsim_ctx *c, const ntscsim_scale_
         if (rc != NTSCSIM_OK) return rc;
     }
     HIPCHK(c, c->scale.ensure((size_t)n));
-    HIPCHK(c, hipMemcpyAsync(c->scale.p, c->host_scale.data(), (size_t)n * sizeof(ScaleDev), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));      // (pageable staging vector)
+    HIPCHK(c, hipStreamSynchronize(st));      // (the record buffer may still be read by the previous call's kernel)
+    HIPCHK(c, upload_table(c->scale.p, c->host_scale.data(), (size_t)n * sizeof(ScaleDev)));
     hipLaunchKernelGGL(k_scale_to_bgra, dim3((unsigned)((W + 127) / 128), (unsigned)H, (unsigned)n), dim3(128), 0, st,
                        c->scale.p, W, H);
     HIPCHK(c, hipGetLastError());
@@ -1568,7 +1593,7 @@ static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const 
                 o.dst = h.dsrc.p + fbytes * (size_t)k; o.dst_ls = (int32_t)pitch;
                 o.sw = S->width; o.sh = S->height; o.fmt = S->format;
             }
-            fail(hipMemcpy(h.srec.p, recs.data(), recs.size() * sizeof(ScaleDev), hipMemcpyHostToDevice), "hipMemcpy");
+            fail(upload_table(h.srec.p, recs.data(), recs.size() * sizeof(ScaleDev)), "hipMemcpy");
         }
         if (yuv && rc == NTSCSIM_OK) {
             // conversion records of this slot: fixed addresses, uploaded once per call
@@ -1583,8 +1608,7 @@ static int frames_host_impl(ntscsim_ctx *c, const ntscsim_host_source *S, const 
                 o.y = h.dyuv.p + obytes_d * (size_t)k; o.u = o.y + ybytes_d; o.v = o.u + cbytes_d;
                 o.y_ls = (int32_t)ypitch_d; o.u_ls = o.v_ls = (int32_t)cpitch_d;
             }
-            fail(hipMemcpy(h.yrec.p, yrec_host.data(), yrec_host.size() * sizeof(YuvDev),
-                           hipMemcpyHostToDevice), "hipMemcpy");
+            fail(upload_table(h.yrec.p, yrec_host.data(), yrec_host.size() * sizeof(YuvDev)), "hipMemcpy");
         }
     }
     DevParams Dyuv;

@@ -220,6 +220,13 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
     (void)c;
     if (!e->o.pin_caller_buffers || span < e->o.min_pin_bytes) return nullptr;
     const uintptr_t a0 = (uintptr_t)p, a1 = a0 + span;
+    // Registration is page-wise, so the frame's first and last page get pinned whole.  That is only harmless when
+    // nothing else lives in them: a foreign heap block that starts in a pinned page and runs on into pageable memory
+    // can no longer be the source of a hipMemcpy.  Frames from av_frame_get_buffer / posix_memalign / a large malloc
+    // are mmap'ed chunks of their own -- page-aligned plus the allocator's header and alignment padding, their tail
+    // page theirs as well; a frame that starts deeper than 128 bytes into a page is a block inside a shared heap and
+    // goes through the staging ring instead.
+    if ((a0 & 4095u) > 128u) return nullptr;
     for (auto &r : e->regs)
         if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
     const uintptr_t PG = 4096;

@@ -160,8 +160,8 @@ def test_two_fields_in_flight_share_one_destination_frame():
     exp, exp_pos = reference_loop(p, frames, n, w, h, 1, False)
     sim = ntscsim.FieldSimulator(params=p)
     sim.submit_configure(depth=2, slots=8, lanes=2, min_pin_bytes=0)
-    src = np.zeros((h, w, 4), np.uint8)
-    dst = np.full((h, w, 4), 0x5A, np.uint8)
+    src = page_frame(h, w)
+    dst = page_frame(h, w, 0x5A)
     for k in range(0, n, 2):
         src[:] = frames[k // 2]
         t0 = sim.submit(dst, src, (k & 1) ^ 1, k)
@@ -179,7 +179,7 @@ def test_geometry_change_unaligned_rows_and_interlaced_source():
     the same ctx (the engine drains and rebuilds its rings), interlaced source flags passed through."""
     p = L.make_params(["-vhs", "-vhs-speed", "ep"])
     sim = ntscsim.FieldSimulator(params=p)
-    sim.submit_configure(depth=3, slots=6, lanes=1, min_pin_bytes=0)
+    sim.submit_configure(depth=3, slots=6, lanes=1)          # (default threshold: these small heap arrays are staged)
     o = L.OracleStream(p)
     k = 0
     for (w, h, inter, tff) in ((50, 21, 0, 0), (96, 32, 1, 1), (50, 21, 1, 0)):
@@ -240,8 +240,13 @@ def test_ring_full_blocks_and_unpin_releases():
     sim = ntscsim.FieldSimulator(params=p)
     sim.submit_configure(depth=4, slots=8, lanes=3, min_pin_bytes=0)
     bufs = [page_frame(h, w, 0x5A) for _ in range(n)]
+    srcs = []
+    for f in frames:
+        s_ = page_frame(h, w)
+        s_[:] = f
+        srcs.append(s_)
     for k in range(n):
-        sim.submit(bufs[k], frames[k // 2], (k & 1) ^ 1, k, same_src=bool(k & 1))
+        sim.submit(bufs[k], srcs[k // 2], (k & 1) ^ 1, k, same_src=bool(k & 1))
     sim.wait()
     for k in range(n):
         assert np.array_equal(bufs[k], exp[k]), k
