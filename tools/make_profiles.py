@@ -73,12 +73,26 @@ for l in open("%s/%s_pmc_summary.txt" % (P, tag)):
 dec = pick(pm, "k_decode_fast<true")
 enc = pick(pm, "k_encode_fast")
 rs, fs = pick(pm, "k_row_states"), pick(pm, "k_field_setup")
+# FETCH_SIZE / WRITE_SIZE calibrated on this library's access shapes (tools/fetch_probe.hip, tools/fetch_calibrate.sh ->
+# profiles/r04_fetch_calibration.txt): bytes actually moved = counter x factor
+cal = {}
+for l in open("%s/r04_fetch_calibration.txt" % P):
+    if "known / counter" in l:
+        cal[l.split()[0]] = float(l.split("=")[-1])
+f_dec_rd, f_enc_rd = cal["k_read4_stream"], cal["k_read16_rows"]      # comp[x][row] loads | CoopLoader frame rows
+f_dec_wr, f_enc_wr = cal["k_write16_rows"], cal["k_write4_stream"]    # cooperative pixel bursts | comp[x][row] stores
+dec_b = (dec["FETCH_SIZE"] * f_dec_rd + dec["WRITE_SIZE"] * f_dec_wr) * 1024
+enc_b = (enc["FETCH_SIZE"] * f_enc_rd + enc["WRITE_SIZE"] * f_enc_wr) * 1024
 traffic = {"720x486 -vhs": {
     "fields_per_launch": 600,
-    "k_decode_hbm_bytes_per_launch": (dec["FETCH_SIZE"] + dec["WRITE_SIZE"]) * 1024,
-    "k_decode_fetch_KiB": dec["FETCH_SIZE"], "k_decode_write_KiB": dec["WRITE_SIZE"],
-    "k_encode_fetch_KiB_raw": enc["FETCH_SIZE"], "k_encode_write_KiB": enc["WRITE_SIZE"],
-    "path_hbm_bytes_per_launch_lower_bound": (dec["FETCH_SIZE"] + dec["WRITE_SIZE"] + enc["FETCH_SIZE"] + enc["WRITE_SIZE"]) * 1024,
+    "k_decode_hbm_bytes_per_launch": dec_b,
+    "k_decode_fetch_KiB_raw": dec["FETCH_SIZE"], "k_decode_write_KiB_raw": dec["WRITE_SIZE"],
+    "k_encode_fetch_KiB_raw": enc["FETCH_SIZE"], "k_encode_write_KiB_raw": enc["WRITE_SIZE"],
+    "calibration": {"k_decode_fetch": f_dec_rd, "k_decode_write": f_dec_wr, "k_encode_fetch": f_enc_rd, "k_encode_write": f_enc_wr,
+                    "source": "profiles/r04_fetch_calibration.txt (tools/fetch_probe.hip: known bytes / counter per access shape)"},
+    "k_encode_hbm_bytes_per_launch": enc_b,
+    "path_hbm_bytes_per_launch": dec_b + enc_b,
+    "path_over_algorithmic": (dec_b + enc_b) / (8.0 * 720 * 243 * 600),
     "valu": {
         "k_decode": {"wave_insts_per_launch": dec["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_decode"]["mean_cycles_per_valu"],
                      "mean_cycles_per_inst_nominal": cen["k_decode"]["mean_cycles_per_valu_nominal"]},
@@ -89,12 +103,12 @@ traffic = {"720x486 -vhs": {
         "k_field_setup": {"wave_insts_per_launch": fs["SQ_INSTS_VALU"], "mean_cycles_per_inst": cen["k_field_setup"]["mean_cycles_per_valu"],
                      "mean_cycles_per_inst_nominal": cen["k_field_setup"]["mean_cycles_per_valu_nominal"]},
     },
-    "note": "rocprofv3 --pmc, separate passes (tools/pmc.sh), bench.py --inflight 1; FETCH_SIZE / WRITE_SIZE in "
-            "KiB; WRITE_SIZE is calibrated by the encoder, whose only stores are the composite plane "
-            "(%d KiB vs 720*145800*4 B = 410062.5 KiB); k_decode loads are 4 B/lane (no wide-load "
-            "correction applies); k_encode loads are 16 B/lane, for which the guide prescribes a x2 "
-            "correction of FETCH_SIZE on gfx950 -- the raw figure is kept here and the encoder's fetch "
-            "is therefore a lower bound" % enc["WRITE_SIZE"],
+    "note": "rocprofv3 --pmc, separate passes (tools/pmc.sh), bench.py --inflight 1; raw FETCH_SIZE / WRITE_SIZE in "
+            "KiB, bytes = counter x the factor measured for the kernel's access shape (a 4 B/lane streaming read is "
+            "reported at half its bytes like the guide's 16 B/lane one; four-lanes-per-row 64-byte pieces at 1 / %.3f; "
+            "writes at face value).  k_decode's fetch is about twice its 420 MB composite plane: the VCR's luma path "
+            "re-reads every sample 5 + d positions behind the chroma path, and that second read misses the L2 "
+            "(an LDS ring that removes it was built and measured slower, csrc/ntsc_decode_fast.hip steady())" % f_enc_rd,
 }}
 tc = None
 if tocomp and os.path.exists(tocomp[0]) and os.path.getsize(tocomp[0]) > 10:
@@ -198,10 +212,11 @@ rd += ("* `k_decode_fast<true,double>`: 2315 waves x 744 pipeline steps; steady 
            cd["valu_per_step"], cd["fp64_per_step"], cd["half_rate_int_per_step"], cd["full_rate_per_step"], cd["valu_pipe_cycles_per_step"], tag, dec["SQ_INSTS_VALU"], k["decode"]))
 rd += ("* `k_encode_fast<double>`: 2279 waves x 724 steps; steady step = %.0f VALU instructions = %.0f pipe cycles; %.3g wave-instructions per launch.  76 VGPRs; with 2.2 waves per SIMD in one launch it "
        "runs latency-bound (each wave ~410 cycles per step), with more waves resident (steps in flight) it approaches its pipe cost.\n" % (ce["valu_per_step"], ce["valu_pipe_cycles_per_step"], enc["SQ_INSTS_VALU"]))
-rd += ("* HBM (PMC): k_decode %.0f MB fetched + %.0f MB written, k_encode >= %.0f MB fetched (raw counter, see traffic.json) + %.0f MB written per 600 fields; algorithmic 839.8 MB.  "
-       "At %.2f ms per step that is ~%.1f TB/s of physical traffic against 6.3 TB/s achievable: the path is VALU-bound.\n" % (
-           dec["FETCH_SIZE"] * 1024 / 1e6, dec["WRITE_SIZE"] * 1024 / 1e6, enc["FETCH_SIZE"] * 1024 / 1e6, enc["WRITE_SIZE"] * 1024 / 1e6,
-           d["ms_per_step"], traffic["720x486 -vhs"]["path_hbm_bytes_per_launch_lower_bound"] / (d["ms_per_step"] * 1e-3) / 1e12))
+rd += ("* HBM (PMC, calibrated counters: `r04_fetch_calibration.txt`): k_decode %.0f MB fetched + %.0f MB written, k_encode %.0f MB fetched + %.0f MB written per 600 fields = %.2f x the algorithmic 839.8 MB.  "
+       "At %.2f ms per step that is ~%.1f TB/s of traffic on the L2's memory side against 6.3 TB/s achievable: the path is VALU-bound.\n" % (
+           dec["FETCH_SIZE"] * f_dec_rd * 1024 / 1e6, dec["WRITE_SIZE"] * f_dec_wr * 1024 / 1e6, enc["FETCH_SIZE"] * f_enc_rd * 1024 / 1e6, enc["WRITE_SIZE"] * f_enc_wr * 1024 / 1e6,
+           traffic["720x486 -vhs"]["path_over_algorithmic"],
+           d["ms_per_step"], traffic["720x486 -vhs"]["path_hbm_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e12))
 if tc:
     b4 = tc["bench"]
     ks = pick(tc["stats"], "k422_fused")

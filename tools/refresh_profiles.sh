@@ -25,6 +25,9 @@ if [ "$mode" = gpu ]; then
     f=$(find $O -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv )
   timeout 300 bash tools/pmc_raw28.sh gpurun_out/raw28_front_pmc_$tag.txt > /dev/null 2>&1
   timeout 60 tools/bin/follow_probe > gpurun_out/follow_probe_$tag.txt 2>&1
+  timeout 200 bash tools/fetch_calibrate.sh > /dev/null 2>&1       # -> gpurun_out/fetch_calibration.txt
+  timeout 300 sh tools/submit_probe.sh > /dev/null 2>&1            # -> gpurun_out/submit_probe.txt
+  timeout 120 bash tools/dryrun_two_ranks_one_gpu.sh nccl > /dev/null 2>&1   # -> gpurun_out/dryrun_two_ranks.txt
   tail -c 600 gpurun_out/bench_$tag.json; tail -c 400 gpurun_out/bench_${tag}_tocomp.json
 else
   S=composite-video-simulator_amd/csrc
@@ -35,6 +38,7 @@ else
     python tools/isa_cost.py /tmp/census_$tag/ntscsim.s "${k%%:*}" --steps "${k##*:}" --json "/tmp/census_$tag/${k%%:*}.json" | head -1
   done
   (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s 'k422_fusedILb1ELb1E' --mean > /tmp/census_$tag/k422_fused.json)
+  [ -s gpurun_out/fetch_calibration.txt ] && cp gpurun_out/fetch_calibration.txt profiles/r04_fetch_calibration.txt
   python tools/make_profiles.py $tag gpurun_out/bench_$tag.json gpurun_out/ks_${tag}_default gpurun_out/ks_${tag}_if1 \
       gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
       gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
@@ -42,4 +46,9 @@ else
   [ -s gpurun_out/ks_${tag}_raw28/kernel_stats.csv ] && cp gpurun_out/ks_${tag}_raw28/kernel_stats.csv profiles/${tag}_kernel_stats_raw28.csv
   [ -s gpurun_out/raw28_front_pmc_$tag.txt ] && { cat gpurun_out/raw28_front_pmc_$tag.txt; echo; echo "tools/follow_probe.hip (one follower step of a lone wavefront, from registers):"; grep -E "wave\(s\)|workgroup" gpurun_out/follow_probe_$tag.txt; } > profiles/${tag}_raw28_front_pmc.txt
   [ -s gpurun_out/bench_${tag}_driver_cmd.json ] && cp gpurun_out/bench_${tag}_driver_cmd.json profiles/${tag}_bench_driver_cmd.json
+  [ -s gpurun_out/submit_probe.txt ] && cp gpurun_out/submit_probe.txt profiles/${tag}_submit_probe.txt
+  [ -s gpurun_out/dryrun_two_ranks.txt ] && cp gpurun_out/dryrun_two_ranks.txt profiles/${tag}_dryrun_two_ranks.txt
+  # opcode histograms of the hand-tuned decoder forms' steady loops (the per-stage census: profiles/${tag}_decode_census.txt)
+  { for k in 'k_decode_fastILb1EdLb0EE' 'k_decode_fast_xiIdE' 'k_decode_fast_foIdE' 'k_decode_fast_svIdE'; do
+      echo "== $k"; (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s "$k" --hist | awk 'NR % 2 == 1 || 1' | cut -c1-1400 | grep -A1 "VALU [67][0-9][0-9] " | head -2); done; } > profiles/${tag}_loop_histograms.txt 2>/dev/null
 fi
