@@ -1,6 +1,6 @@
 """Developer tool (GPU box): the pre-emphasis family of the BGRA tool (k_encode_fast_pre + k_decode_fast_bk), or its
 S-Video family (k_decode_fast_sv), against the oracle at full size, seeded random members:
-    python tools/fuzz_catv.py 0 60 [svideo]"""
+    python tools/fuzz_catv.py 0 60 [svideo | phase | fullout]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
@@ -12,7 +12,12 @@ family = sys.argv[3] if len(sys.argv) > 3 else "catv"
 t0, bad, forms = time.time(), [], {}
 for seed in range(s0, s0 + n):
     r = random.Random(70000 + seed)
-    f = ["-vhs", r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"])] if family == "catv" else ["-vhs", "-vhs-svideo", "1"]
+    if family == "catv": f = ["-vhs", r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"])]
+    elif family == "svideo": f = ["-vhs", "-vhs-svideo", "1"]
+    elif family == "phase":     # scanline phases of either parity: k_encode_fast_xi + k_decode_fast_xi
+        f = ["-vhs", "-comp-phase", r.choice(["0", "90", "180", "270"]), "-comp-phase-offset", str(r.choice([1, 3]) if r.random() < 0.5 else r.randint(0, 3))]
+        if f[2] in ("0", "180") and int(f[4]) % 2 == 0: f[4] = str(int(f[4]) + 1)
+    else: f = ["-vhs", "-out-composite-lowpass-lite", "0"]          # the full output low-pass: k_decode_fast_fo
     if r.random() < 0.3: f = ["-tvstd", "pal"] + f
     if r.random() < 0.5: f += ["-vhs-speed", r.choice(["sp", "lp", "ep"])]
     if r.random() < 0.4: f += ["-noise", str(r.randint(1, 9))]
@@ -36,7 +41,7 @@ for seed in range(s0, s0 + n):
     if not np.array_equal(got, want):
         bad.append((seed, f))
     sim.close()
-print(("pre-emphasis" if family == "catv" else "S-Video") + " family at full size: %d random members x 2 fields in %.0f s, %d failures" % (n, time.time() - t0, len(bad)))
+print({"catv": "pre-emphasis", "svideo": "S-Video", "phase": "any-phase", "fullout": "full output low-pass"}[family] + " family at full size: %d random members x 2 fields in %.0f s, %d failures" % (n, time.time() - t0, len(bad)))
 for k, v in sorted(forms.items(), key=lambda kv: -kv[1]):
     print("  %4d x %s" % (v, " + ".join(k)))
 for b in bad[:8]:
