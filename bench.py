@@ -568,7 +568,7 @@ def extras(torch, ntscsim, dev, local_rank, args):
                            "of 2 runs)" % args.preset)
     # ---- the asynchronous 1:1 drop-in: ntscsim_submit() / ntscsim_wait() from the reference-shaped loop of
     # host/field_loop.cpp (AVFrame-shaped pageable frames; the call at ffmpeg_ntsc.cpp:2229 replaced, the frame
-    # consumed 2 * depth fields later)
+    # consumed 4 * depth fields later)
     floop = os.path.join(ROOT, "composite-video-simulator_amd", "field_loop")
     if os.path.exists(floop):
         import json as _json
@@ -599,7 +599,7 @@ def extras(torch, ntscsim, dev, local_rank, args):
             "depth32_staging_ring": run_loop("--mode", "submit", "--depth", "32", "--pin", "0", "--rewrite-src", "1", *big),
             "note": "host/field_loop.cpp: the loop of ffmpeg_ntsc.cpp:2202-2282 on AVFrame-shaped pageable frames "
                     "(posix_memalign, linesize rounded to 64) with composite_layer() :2229 replaced by "
-                    "ntscsim_submit_avframe() and the frame consumed behind ntscsim_wait() 2 * depth fields later; "
+                    "ntscsim_submit_avframe() and the frame consumed behind ntscsim_wait() 4 * depth fields later; "
                     "field_submit = depth 32, ONE source frame (in.rgb) rewritten by a memcpy for every new frame "
                     "(the stand-in for sws_scale :603), snapshot semantics (submit returns after the DMA read "
                     "it); decoder_frames = the source is re-pointed at one of 8 frames instead (no host copy); "

@@ -815,6 +815,15 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
 #ifndef NTSC_FAST_WAVES
 #define NTSC_FAST_WAVES 2
 #endif
+// FAST32 (RT = float): its arithmetic is full-rate opcodes (2 cycles per wave64 instruction), which two waves per SIMD do not
+// keep busy the way they do the 4-cycle fp64 pipe (a lone wave gets an instruction through per ~5 cycles), so a third wave
+// would pay -- but at the 168 registers of three waves every VHS form except the S-Video one spills (58-147 registers,
+// scratch in the kernel: -DNTSC_FAST_WAVES_F32=3, round 4), so the float forms stay at two as well.
+#ifndef NTSC_FAST_WAVES_F32
+#define NTSC_FAST_WAVES_F32 2
+#endif
+template <class RT> struct FastWaves { static constexpr int n = NTSC_FAST_WAVES; };
+template <> struct FastWaves<float> { static constexpr int n = NTSC_FAST_WAVES_F32; };
 // WR (VHS form only): head-switch displacements beyond W/10 samples, e.g. PAL's 312.5-line field with
 // the default switching point (see cs_load).  BK: subcarrier_amplitude_back other than 50 (the pre-emphasis
 // presets -comp-catv* raise it), see scale_back50.
@@ -956,7 +965,7 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
 }
 
 template <bool VHS, class RT, bool WR = false>
-__global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, VHS ? FastWaves<RT>::n : 4) void k_decode_fast(DevParams P, GeomDev G,
                                                      const FieldDev *__restrict__ fields,
                                                      const int *__restrict__ comp,
                                                      const uint32_t *__restrict__ rs_chroma,
@@ -972,7 +981,7 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast(D
 
 // the same for a subcarrier_amplitude_back other than 50 (one form per preset: the VHS one takes the wrap-around loads)
 template <bool VHS, class RT>
-__global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast_bk(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, VHS ? FastWaves<RT>::n : 4) void k_decode_fast_bk(DevParams P, GeomDev G,
                                                      const FieldDev *__restrict__ fields,
                                                      const int *__restrict__ comp,
                                                      const uint32_t *__restrict__ rs_chroma,
@@ -989,7 +998,7 @@ __global__ __launch_bounds__(64, VHS ? NTSC_FAST_WAVES : 4) void k_decode_fast_b
 // the -vhs family with scanline phases of either parity (-comp-phase 90 / 270, or an odd -comp-phase-offset): the picks
 // and the re-modulation take their per-lane forms (DemodS::push ANY, vcr_step); wrap-around loads (any displacement)
 template <class RT>
-__global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_xi(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, FastWaves<RT>::n) void k_decode_fast_xi(DevParams P, GeomDev G,
                                                      const FieldDev *__restrict__ fields,
                                                      const int *__restrict__ comp,
                                                      const uint32_t *__restrict__ rs_chroma,
@@ -1005,7 +1014,7 @@ __global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_xi(DevParam
 
 // the -vhs family with the FULL output chroma low-pass (-out-composite-lowpass-lite 0; wrap-around loads)
 template <class RT>
-__global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_fo(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, FastWaves<RT>::n) void k_decode_fast_fo(DevParams P, GeomDev G,
                                                      const FieldDev *__restrict__ fields,
                                                      const int *__restrict__ comp,
                                                      const uint32_t *__restrict__ rs_chroma,
@@ -1022,7 +1031,7 @@ __global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_fo(DevParam
 // the -vhs preset with S-Video out (-vhs-svideo 1): the VCR's components go to the TV stages directly, no
 // re-modulation and no second separation; 7 pipeline stages fewer (wrap-around loads: any displacement)
 template <class RT>
-__global__ __launch_bounds__(64, NTSC_FAST_WAVES) void k_decode_fast_sv(DevParams P, GeomDev G,
+__global__ __launch_bounds__(64, FastWaves<RT>::n) void k_decode_fast_sv(DevParams P, GeomDev G,
                                                      const FieldDev *__restrict__ fields,
                                                      const int *__restrict__ comp,
                                                      const uint32_t *__restrict__ rs_chroma,

@@ -83,6 +83,8 @@ struct SubmitEngine {
     struct Batch {
         uint64_t first = 0, last = 0;
         hipEvent_t up = nullptr, done = nullptr;
+        hipEvent_t t0 = nullptr, t1 = nullptr;    // NTSCSIM_SUBMIT_TIMING: GPU time stamps around the launch
+        unsigned lane = 0;
         std::vector<Item> items;
         int rc = NTSCSIM_OK;
         bool launched_ok = false;
@@ -100,6 +102,8 @@ struct SubmitEngine {
     std::vector<Reg> regs;
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int sticky_rc = NTSCSIM_OK;
+    bool timing = std::getenv("NTSCSIM_SUBMIT_TIMING") != nullptr;      // developer switch: print every launch's GPU span
+    hipEvent_t tref = nullptr;
 };
 
 extern "C" void ntscsim_submit_opts_init(ntscsim_submit_opts *o)
@@ -108,7 +112,7 @@ extern "C" void ntscsim_submit_opts_init(ntscsim_submit_opts *o)
     std::memset(o, 0, sizeof(*o));
     o->struct_size = (uint32_t)sizeof(*o);
     o->depth = 32;
-    o->slots = 128;
+    o->slots = 256;
     o->lanes = 3;
     o->pin_caller_buffers = 1;
     o->min_pin_bytes = 256u << 10;
@@ -176,7 +180,7 @@ extern "C" int ntscsim_submit_configure(ntscsim_ctx *c, const ntscsim_submit_opt
     int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
     if (rc != NTSCSIM_OK) return rc;
     e->o = *o;
-    if (e->o.slots == 0) e->o.slots = 4 * e->o.depth;
+    if (e->o.slots == 0) e->o.slots = 8 * e->o.depth;
     while ((int)e->lanes.size() > e->o.lanes) { ntscsim_destroy(e->lanes.back()); e->lanes.pop_back(); }
     sub_release_geometry(e);          // the rings are sized by `slots`
     e->configured = true;
@@ -313,6 +317,14 @@ static int sub_retire_front(ntscsim_ctx *c, SubmitEngine *e)
                 }
             }
     }
+    if (e->timing && b.t0 && b.t1) {
+        float a = 0, z = 0;
+        (void)hipEventSynchronize(b.t1);
+        (void)hipEventElapsedTime(&a, e->tref, b.t0); (void)hipEventElapsedTime(&z, e->tref, b.t1);
+        std::fprintf(stderr, "launch tickets %llu..%llu lane %u: GPU %.3f .. %.3f ms (%.3f)\n", (unsigned long long)b.first,
+                     (unsigned long long)b.last, b.lane, a, z, z - a);
+        (void)hipEventDestroy(b.t0); (void)hipEventDestroy(b.t1);
+    }
     e->done_ticket = b.last;
     if (b.up && b.done) e->ev_pool.push_back({b.up, b.done});
     e->inflight.pop_front();
@@ -394,6 +406,12 @@ static int sub_launch(ntscsim_ctx *c)
     }
     hipError_t er = hipEventRecord(b.up, e->s_up);
     if (er == hipSuccess) er = hipStreamWaitEvent(lane->stream, b.up, 0);
+    b.lane = li;
+    if (e->timing) {
+        if (!e->tref) { (void)hipEventCreate(&e->tref); (void)hipEventRecord(e->tref, lane->stream); }
+        (void)hipEventCreate(&b.t0); (void)hipEventCreate(&b.t1);
+        (void)hipEventRecord(b.t0, lane->stream);
+    }
     if (er != hipSuccess) { c->err = std::string("submit launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     int rc = ntscsim_fields_device(lane, descs.data(), n, e->W, e->H, lane->stream);
     if (rc != NTSCSIM_OK) { c->err = lane->err; return finish(rc); }
@@ -445,6 +463,7 @@ static int sub_launch(ntscsim_ctx *c)
             i = j;
         }
     }
+    if (e->timing) (void)hipEventRecord(b.t1, lane->stream);
     er = hipEventRecord(b.done, lane->stream);
     if (er != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;

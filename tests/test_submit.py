@@ -223,7 +223,7 @@ def test_submit_errors_consume_nothing_and_tickets_are_checked():
     assert lib.ntscsim_wait(sim._h, 1) == _capi.OK                                          # again: already done
     o = _capi.SubmitOpts()
     lib.ntscsim_submit_opts_init(C.byref(o))
-    assert (o.depth, o.slots, o.lanes, o.pin_caller_buffers) == (32, 128, 3, 1)
+    assert (o.depth, o.slots, o.lanes, o.pin_caller_buffers) == (32, 256, 3, 1)
     o.slots = o.depth          # < 2 * depth
     assert lib.ntscsim_submit_configure(sim._h, C.byref(o)) == _capi.E_ARG
     sim.close()
