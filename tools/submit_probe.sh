@@ -24,5 +24,16 @@ $FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32 --rewrite-src 1
 $FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32 --pin 0
 $FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32 --pin 0 --bob 1
 $FL --mode submit --fields 20000 --warmup 2000 --depth 32
+echo "# how far behind the submits the loop waits (default 4 x depth), and more hardware queues for the lanes"
+for lag in 64 96 128 256; do
+  $FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32 --lag $lag
+done
+GPU_MAX_HW_QUEUES=8 $FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32
+GPU_MAX_HW_QUEUES=8 $FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32 --src-stable 1
+$FL -vhs --mode submit --fields 20000 --warmup 2000 --depth 32 --src-stable 1
+echo "# GPU spans of consecutive launches (NTSCSIM_SUBMIT_TIMING=1)"
+NTSCSIM_SUBMIT_TIMING=1 $FL -vhs --mode submit --fields 640 --warmup 640 --depth 32 2>&1 | grep "^launch" | tail -8
+echo "# the link (tools/link_probe.hip)"
+tools/bin/link_probe
 } > $OUT 2>&1
 cat $OUT
