@@ -4,7 +4,7 @@ profiles/ (run after tools/refresh_profiles.sh local <tag>):  python tools/readm
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 d = json.load(open("profiles/%s_bench.json" % tag))
 t = json.load(open("profiles/%s_bench_to_composite.json" % tag))
 f = json.load(open("profiles/%s_bench_fast32.json" % tag))
@@ -19,31 +19,50 @@ raw28 = ("  The raw-composite decoder (`ffmpeg_raw28ntsc`, `raw28`): a 600-field
          "%.1fk fields/s (the reference text on one host core: %.0f)." % (r28["value"] / 1e3, r28["cpu_1core"]["value"])) if r28 else ""
 fcall = ("  One field per synchronous `ntscsim_field()` call (the 1:1 drop-in on host frames): %.0f fields/s." % e["field_call"]) if e.get("field_call") else ""
 cli = ("  The raw-file CLI `ntsc_cli -vhs -i bars:3000 -o null:` runs at %.0fk fields/s (`end_to_end.cli`)." % (e["cli"] / 1e3)) if e.get("cli") else ""
+ds = d.get("device_stream", {})
+fs = e.get("field_submit_detail", {})
+def fps(k):
+    x = fs.get(k) or {}
+    return (x.get("fields_per_s") or 0) / 1e3
+pre = (d["config"].get("pre_roll") or {})
 new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` preset, exact mode; every figure is\n"
        "a key of `profiles/%s_bench.json`, the line `python bench.py` prints; `profiles/README.md` maps the\n"
-       "rest; box-to-box spread ≈ ±4 %%: 733k-790k for `value` on ten boxes):\n"
-       "`value` **%dk fields/s** over %d steps with four steps in flight, `value_sustained` **%dk** over\n"
-       "0.5 s (round 2: 729k, round 1: 542k).  CPU beside it on the GPU box's host: the reference's own `composite_layer()`\n"
+       "rest; box-to-box spread ≈ ±4 %%):\n"
+       "`value_sustained` **%dk fields/s** (the same 600-field step repeated for %.2f s, four steps in flight) and `value` **%dk** over the %d\n"
+       "timed steps that follow it (`config.pre_roll`: the sustained leg runs BEFORE the W warm-up steps, so the timed steps see a GPU at its\n"
+       "working clocks; rounds 1 and 2 were measured without it and read 4-6 %% lower for that reason alone).  With the driver's own\n"
+       "window (`--steps 20 --warmup 5`): %dk (`profiles/%s_bench_driver_cmd.json`).  A device-resident STREAM of fresh batches -- every step the next\n"
+       "600 fields, descriptor validation, `rand()` windows and record upload inside the clock -- runs at %dk (`device_stream`, %.2f × `value`).\n"
+       "CPU beside it on the GPU box's host: the reference's own `composite_layer()`\n"
        "(`oracle/_ref`, single-threaded like the tool) %.0f fields/s, our C port %.0f fields/s on one core and\n"
        "%d fields/s on the %d CPUs the box's cgroup allows.  `sizes`: 1920×1080 %.1fk, 3840×2160 %.1fk\n"
-       "fields/s; `presets.default`: %dk fields/s; other switch sets (`presets.vhs_*`; catv2 and svideo run hand-tuned forms of their own, the rest the generic kernels): %s;\n"
+       "fields/s; `presets.default`: %dk fields/s; other switch sets, each on a hand-tuned form of its own, as a fraction of the `-vhs` preset measured the same way (`presets.*.frac_of_preset`): %s;\n"
        "the YUV422P tool (`python bench.py --tool to_composite`,\n"
-       "`profiles/%s_bench_to_composite.json`): **%dk frames/s** (round 2: 654k, round 1: 262k).  The path is VALU-issue\n"
-       "bound, not HBM bound: `roofline.frac` (HBM, algorithmic bytes) = %.2f, and %.2f is the most a kernel chain with the\n"
+       "`profiles/%s_bench_to_composite.json`): **%dk frames/s** sustained, %dk over the timed steps.  The path is VALU-issue\n"
+       "bound, not HBM bound: `roofline.frac` (HBM, algorithmic bytes) = %.3f, and %.2f is the most a kernel chain with the\n"
        "reference's fp64 arithmetic could reach (`roofline.valu.hbm_frac_ceiling_exact_mode`); `roofline.valu.path_frac_nominal` =\n"
        "%.2f of the VALU issue capacity at the pipe's nominal 4 / 2 cycles per instruction (%.2f at the measured slowest-wave\n"
-       "costs; PMC instruction counts × each kernel's instruction mix ÷ measured time) — see `profiles/README.md` and DESIGN.md §5 for what\n"
-       "was measured and what is derived.  PCIe-inclusive (`end_to_end`, `ntscsim_frames_host`): %.0fk\n"
-       "fields/s BGRA out, %.0fk with YUV420P made on the GPU, %.0fk with YUV420P in as well.%s%s%s  Optional `NTSCSIM_MODE_FAST32` (fp32 filters,\n"
+       "costs; PMC instruction counts × each kernel's instruction mix ÷ measured time) — see `profiles/README.md`, `profiles/%s_decode_census.txt` and DESIGN.md §5 for what\n"
+       "was measured and what is derived.  The drop-in on HOST frames: one synchronous `ntscsim_field()` per `composite_layer()` call %.1fk fields/s; the\n"
+       "same loop with `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`, pageable AVFrame-shaped buffers pinned in place) **%.0fk** with ONE\n"
+       "source frame rewritten per decoded frame, %.0fk with the source re-pointed at decoded frames, %.0fk with the line doubling delivered too, %.0fk at depth 128\n"
+       "(`end_to_end.field_submit*`; %.0f × the reference on one core).  Whole clips from host memory (`ntscsim_frames_host`): %.0fk\n"
+       "fields/s BGRA out, %.0fk with YUV420P made on the GPU, %.0fk with YUV420P in as well.%s%s  Optional `NTSCSIM_MODE_FAST32` (fp32 filters,\n"
        "≤1 LSB, not bit-exact): %dk fields/s (`profiles/%s_bench_fast32.json`).\n\n" % (
-           tag[1:].lstrip("0"), tag, round(d["value"] / 1e3), d["steps"], round(d["value_sustained"] / 1e3), cb["value"], cb["port_1core"],
+           tag[1:].lstrip("0"), tag, round(d["value_sustained"] / 1e3), (d.get("sustained") or {}).get("seconds", 0.5), round(d["value"] / 1e3), d["steps"],
+           round(json.load(open("profiles/%s_bench_driver_cmd.json" % tag))["value"] / 1e3), tag,
+           round(ds.get("value", 0) / 1e3), ds.get("value", 0) / d["value"],
+           cb["value"], cb["port_1core"],
            round(cb["port_all_cores"]["value"]), cb["port_all_cores"]["cores"],
            d["sizes"]["1920x1080"]["value"] / 1e3, d["sizes"]["3840x2160"]["value"] / 1e3,
            round(d["presets"]["default"]["value"] / 1e3),
-           ", ".join("%s %dk" % (k[4:], round(x["value"] / 1e3)) for k, x in p_.items() if k.startswith("vhs_") and "value" in x),
-           tag, round(t["value"] / 1e3), d["roofline"]["frac"], v["hbm_frac_ceiling_exact_mode"],
-           v["path_frac_nominal"], v["path_frac"], e["bgra_pinned"] / 1e3, e["yuv420p_pinned"] / 1e3,
-           e.get("yuv420p_in_yuv420p_out_pinned", 0) / 1e3, fcall, cli, raw28,
+           ", ".join("%s %dk (%.2f)" % (k[4:], round(x["value"] / 1e3), x.get("frac_of_preset") or 0) for k, x in p_.items() if k.startswith("vhs_") and "value" in x),
+           tag, round(t["value_sustained"] / 1e3), round(t["value"] / 1e3), d["roofline"]["frac"], v["hbm_frac_ceiling_exact_mode"],
+           v["path_frac_nominal"], v["path_frac"], tag, e["field_call"] / 1e3,
+           e.get("field_submit", 0) / 1e3, fps("depth32_decoder_frames"), fps("depth32_bob"), fps("depth128"),
+           e.get("field_submit", 0) / cb["value"],
+           e["bgra_pinned"] / 1e3, e["yuv420p_pinned"] / 1e3,
+           e.get("yuv420p_in_yuv420p_out_pinned", 0) / 1e3, cli, raw28,
            round(f["value"] / 1e3), tag))
 open("README.md", "w").write(s[:a] + new + s[b:])
 print(new)
