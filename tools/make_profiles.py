@@ -142,9 +142,9 @@ json.dump(traffic, open("%s/traffic.json" % P, "w"), indent=1)
 v = d["roofline"].get("valu") or {}
 e2e = d.get("end_to_end", {})
 rd = "# profiles/ -- round %s (MI355X, gfx950, ROCm 7.2)\n\n" % tag[1:]
-rd += "Everything here comes from `python bench.py` (BASELINE configs[1]: 720x486, 600 fields per step, `-vhs`) and the probes in `tools/`; `tools/refresh_profiles.sh` shows the commands, `tools/make_profiles.py` assembles this directory.  Round-1 files (`r01_*`) are kept for comparison.\n\n"
+rd += "Everything here comes from `python bench.py` (BASELINE configs[1]: 720x486, 600 fields per step, `-vhs`) and the probes in `tools/`; `tools/refresh_profiles.sh` shows the commands, `tools/make_profiles.py` assembles this directory.  Files of earlier rounds (`r01_*` … `r03_*`) are kept for comparison.\n\n"
 rd += "| file | command | what |\n|---|---|---|\n"
-rd += "| `%s_bench.json` | `python bench.py` | the bench line: value, value_sustained, roofline (+ cycle-weighted `valu`), cpu_baseline, end_to_end, variant422, sizes, presets |\n" % tag
+rd += "| `%s_bench.json` | `python bench.py` | the bench line: value, value_sustained, roofline (+ cycle-weighted `valu`, calibrated `traffic`), cpu_baseline, device_stream, end_to_end (incl. `field_submit`), variant422, raw28, sizes, presets |\n" % tag
 rd += "| `%s_kernel_stats_default_cmd.csv` | `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-fields 0 --no-extras` | 4 steps in flight: kernels of different steps share the GPU, wall durations stretch; **Min** = un-shared duration |\n" % tag
 rd += "| `%s_kernel_stats_inflight1.csv` | `... --inflight 1` | one step at a time: per-kernel durations without overlap |\n" % tag
 rd += "| `%s_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--inflight 1`) | FETCH_SIZE, WRITE_SIZE, SQ counters per kernel (mean per launch) |\n" % tag
@@ -153,11 +153,14 @@ rd += "| `%s_chain_probe.txt` | `tools/chain_probe.hip` | cost of dependent fp64
 rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction census of each kernel's steady loop |\n" % tag
 rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_pmc_summary_to_composite.txt` | `python bench.py --tool to_composite`, `tools/kstats.sh ... --tool to_composite --inflight 1`, `tools/pmc422.sh` | the same three for the YUV422P tool |\n" % (tag, tag, tag)
 rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- python tools/raw28_probe.py` | kernels of the raw-composite decoder on a 600-field capture (4 calls) |\n" % tag
-rd += "| `%s_bench_driver_cmd.json`, `%s_variant_sweeps.txt` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...`; `tools/sweep_times.py` | the driver's own window; wave-clock share of the YUV422P kernel's sweeps |\n" % (tag, tag)
-rd += "| `%s_decode_experiments.txt` | A/B builds (`tools/build_variants.sh`), `NTSCSIM_DEBUG_DECODE`, `--inflight` | what was tried on the dominant kernel this round and did not pay |\n" % tag
-rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_r03.sh` | one-off parity sweeps on the final build (random switch sets, the YUV422P family at random geometry, full size, raw captures) |\n" % tag
-rd += "| `%s_clock_under_load.txt` | `tools/clock_probe.sh` | shader clock under the bench's sustained load (2.31-2.32 GHz against the 2.4 GHz of the VALU peak) |\n" % tag
-rd += "| `%s_composite_range.txt`, `%s_raw28_front_pmc.txt` | `tools/comp_range_probe.py`; `tools/pmc_raw28.sh` | value range of the composite plane (why it cannot be 16 bits wide); counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront (`tools/pmc_raw28.sh`, `tools/follow_probe.hip`) |\n" % (tag, tag)
+rd += "| `%s_bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...` | the driver's own window |\n" % tag
+rd += "| `%s_decode_census.txt`, `%s_loop_histograms.txt` | `tools/loop_census.py --hist` on `hipcc -S`; source accounting | where the VALU instructions of `k_decode_fast` go, stage by stage; what the round-4 diet removed; what was measured and not done (noise pre-pass, LDS luma ring, packed fp32); opcode histograms of the steady loops of the hand-tuned decoder forms |\n" % (tag, tag)
+rd += "| `r04_fetch_calibration.txt` | `tools/fetch_calibrate.sh` (`tools/fetch_probe.hip`) | FETCH_SIZE / WRITE_SIZE against known byte counts for this library's access shapes: the factors `traffic.json` applies |\n"
+rd += "| `%s_submit_probe.txt` | `tools/submit_probe.sh` (`host/field_loop.cpp`, `tools/link_probe.hip`) | `ntscsim_submit()` / `ntscsim_wait()` against the synchronous call: byte identity (FNV-1a of every consumed frame), fields/s by depth / lanes / line doubling / source handling / delivery path / lag, GPU spans of consecutive launches, the host link's rates |\n" % tag
+rd += "| `%s_dryrun_two_ranks.txt` | `tools/dryrun_two_ranks_one_gpu.sh` | `bench.py` with two ranks on the one GPU: RCCL refuses two ranks on one device, the same run with gloo verifies every rank's checksum |\n" % tag
+rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_%s.sh` | one-off parity sweeps on the final build (random switch sets of both tools, full size, the any-phase / full-output-low-pass / pre-emphasis / S-Video families at full size with the kernel forms listed) |\n" % (tag, tag)
+rd += "| `r03_decode_experiments.txt`, `r03_clock_under_load.txt`, `r03_composite_range.txt`, `r03_variant_sweeps.txt` | (round 3) | A/B experiments on the dominant kernel; shader clock under load (2.31-2.32 GHz); value range of the composite plane; wave-clock share of the YUV422P kernel's sweeps |\n"
+rd += "| `%s_raw28_front_pmc.txt` | `tools/pmc_raw28.sh`, `tools/follow_probe.hip` | counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront |\n" % tag
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (
@@ -183,8 +186,18 @@ if e2e:
         e2e.get("bgra_pinned", 0), e2e.get("bgra_pageable", 0), e2e.get("yuv420p_pinned", 0))
     if e2e.get("field_call"):
         rd += "One field per `ntscsim_field()` call (the 1:1 drop-in, synchronous, pageable host frames): %.0f fields/s.  " % e2e["field_call"]
+    if e2e.get("field_submit"):
+        fsd = e2e.get("field_submit_detail", {})
+        rd += ("The same loop with `ntscsim_submit()` / `ntscsim_wait()` (`host/field_loop.cpp`, depth 32, pageable AVFrame-shaped buffers pinned in place): %.0f fields/s with one source frame "
+               "rewritten per decoded frame (`end_to_end.field_submit`), %.0f with the source re-pointed at decoded frames, %.0f with the line doubling delivered as well, %.0f at depth 128, "
+               "%.0f through the staging ring.  " % (e2e["field_submit"], (fsd.get("depth32_decoder_frames") or {}).get("fields_per_s", 0),
+                                                     (fsd.get("depth32_bob") or {}).get("fields_per_s", 0), (fsd.get("depth128") or {}).get("fields_per_s", 0),
+                                                     (fsd.get("depth32_staging_ring") or {}).get("fields_per_s", 0)))
     if e2e.get("cli"):
         rd += "`ntsc_cli -vhs -i bars:3000 -o null:` %.0f fields/s (`end_to_end.cli`).  " % e2e["cli"]
+if "device_stream" in d and "value" in d["device_stream"]:
+    rd += "\n\nA device-resident stream of fresh batches (`device_stream`: every step the next 600 fields through `ntscsim_fields_device()`, preparation inside the clock): %.0f frames/s = %.2f x `value`, last step verified: %s.  " % (
+        d["device_stream"]["value"], d["device_stream"]["value"] / d["value"], d["device_stream"].get("verified_last_step"))
 if "variant422" in d:
     rd += "YUV422P tool: %.0f frames/s.  " % d["variant422"]["value"]
 if "raw28" in d:
@@ -207,10 +220,10 @@ rd += "## Where the time goes\n\n"
 cd = cen["k_decode"]
 ce = cen["k_encode"]
 rd += ("* `k_decode_fast<true,double>`: 2315 waves x 744 pipeline steps; steady step = %.0f VALU instructions (%.0f fp64, %.0f other half-rate, %.0f full-rate) = %.0f SIMD pipe cycles "
-       "(`%s_isa_cost.json`); %.3g wave-instructions per launch (SQ_INSTS_VALU).  256 VGPRs, 2 waves per SIMD: 2048 wave slots for 2315 waves, so an isolated launch pays a second, "
+       "(`%s_isa_cost.json`); %.3g wave-instructions per launch (SQ_INSTS_VALU).  248 VGPRs, 2 waves per SIMD: 2048 wave slots for 2315 waves, so an isolated launch pays a second, "
        "one-wave-per-SIMD round (a lone wave needs ~1150 cycles per step, a pair ~1750): that is why `kernel_ms` (%.3f ms) is far above the launch's share of a saturated step.\n" % (
            cd["valu_per_step"], cd["fp64_per_step"], cd["half_rate_int_per_step"], cd["full_rate_per_step"], cd["valu_pipe_cycles_per_step"], tag, dec["SQ_INSTS_VALU"], k["decode"]))
-rd += ("* `k_encode_fast<double>`: 2279 waves x 724 steps; steady step = %.0f VALU instructions = %.0f pipe cycles; %.3g wave-instructions per launch.  76 VGPRs; with 2.2 waves per SIMD in one launch it "
+rd += ("* `k_encode_fast<double>`: 2279 waves x 724 steps; steady step = %.0f VALU instructions = %.0f pipe cycles; %.3g wave-instructions per launch.  110 VGPRs; with 2.2 waves per SIMD in one launch it "
        "runs latency-bound (each wave ~410 cycles per step), with more waves resident (steps in flight) it approaches its pipe cost.\n" % (ce["valu_per_step"], ce["valu_pipe_cycles_per_step"], enc["SQ_INSTS_VALU"]))
 rd += ("* HBM (PMC, calibrated counters: `r04_fetch_calibration.txt`): k_decode %.0f MB fetched + %.0f MB written, k_encode %.0f MB fetched + %.0f MB written per 600 fields = %.2f x the algorithmic 839.8 MB.  "
        "At %.2f ms per step that is ~%.1f TB/s of traffic on the L2's memory side against 6.3 TB/s achievable: the path is VALU-bound.\n" % (
