@@ -205,7 +205,7 @@ struct DemodR {
         }
     }
     // any position (row ends, pipeline fill and drain); t is wave-uniform, xi per lane
-    template <bool BK = false>
+    template <bool BK = false, bool ANY = false>
     DEV void push_edge(int ct, int t, unsigned xi, bool hi, int W, int xe, int &Yo, int &Io, int &Qo,
                        unsigned bmul = 0, unsigned bshift = 0)
     {
@@ -220,13 +220,13 @@ struct DemodR {
         int I, Q;
         if (x & 1) {
             const bool m = (x + 1 + (int)xi + 1) < W;                    // :1550
-            // (any xi: after the shift w5 = ch(q), ..., w1 = ch(q-4); the pick is ch(q - 4 + xi), ch(q - 3 + xi))
-            const bool od = (xi & 1u) != 0;
+            // (after the shift w5 = ch(q), ..., w1 = ch(q-4); the pick is ch(q - 4 + xi), ch(q - 3 + xi); ANY: xi may be odd)
+            const bool od = ANY && (xi & 1u) != 0;
             const int a = hi ? (od ? w4 : w3) : (od ? w2 : w1), b = hi ? (od ? w5 : w4) : (od ? w3 : w2);
-            // flipped (:1539-1542) and then negated (:1550-1553) = positive iff (xe + 2 xi) & 2, xe = x + 1 -- except the
-            // row's first pair with xi = 1: the flip loop starts at x = (4 - xi) & 3 = 3, so chroma[1], chroma[2] keep
-            // their sign although the pattern would flip them
-            const bool pos = (((x + 1 + 2 * (int)xi) & 2) != 0) && !(xi == 1u && x == -1);
+            // flipped (:1539-1542) and then negated (:1550-1553) = positive iff (xe + 2 xi) & 2, xe = x + 1 (even xi: iff
+            // x = 1 mod 4) -- except the row's first pair with xi = 1: the flip loop starts at x = (4 - xi) & 3 = 3, so
+            // chroma[1], chroma[2] keep their sign although the pattern would flip them
+            const bool pos = ANY ? ((((x + 1 + 2 * (int)xi) & 2) != 0) && !(xi == 1u && x == -1)) : ((x & 3) == 1);
             ieN = m ? (pos ? a : -a) : 0;
             qeN = m ? (pos ? b : -b) : 0;
             I = (ieP + ieN) >> 1;
@@ -548,7 +548,7 @@ DEV int vcr_edge(const DevParams &P, State<true, RT> &S, const CT &C, uint32_t *
     const int W = C.W;
     const int pc = t < W ? cs_load(C, t) : 0;             // t is wave-uniform
     int Y, U, V;
-    S.D1.template push_edge<CT::back>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
+    S.D1.template push_edge<CT::back, CT::anyxi>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
     const int x1 = t - 7;
     const bool in1 = x1 >= 0 && x1 < W;
     int fU = 0, fV = 0;
@@ -614,12 +614,12 @@ DEV bool edge_step(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t 
             Y = Yv; U = Uv; V = Vv;
             x3 = x2;
         } else {
-            S.D2.push_edge(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
+            S.D2.template push_edge<false, CT::anyxi>(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
             x3 = x2 - 7;
         }
     } else {
         const int pc = t < W ? cs_load(C, t) : 0;         // t is wave-uniform
-        S.D1.template push_edge<CT::back>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
+        S.D1.template push_edge<CT::back, CT::anyxi>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
     }
     if constexpr (CT::fullout) {
         if (x3 < 0 || x3 >= W + 4) return false;
@@ -865,9 +865,11 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     C.xi = scan_phase(P, y, fd.fieldno);
     C.hi = (C.xi & 2u) != 0;
     C.odd = (C.xi & 1u) != 0;
-    C.mo = opaque_v(C.odd ? -1 : 0);
+    if constexpr (XA) {
+        C.mo = opaque_v(C.odd ? -1 : 0);
 #pragma unroll
-    for (int j = 0; j < 4; j++) C.ms[j] = opaque_v(((C.xi + (unsigned)j) & 2u) ? -1 : 0);
+        for (int j = 0; j < 4; j++) C.ms[j] = opaque_v(((C.xi + (unsigned)j) & 2u) ? -1 : 0);
+    }
     C.W = W;
     C.xe = (W & 1) ? W - 1 : W - 2;
     C.lane = lane;
@@ -931,6 +933,9 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
     const int total = W + SKT;
     int t = 0;
     // ---------------- pipeline fill
+#ifdef NTSC_EDGE_UNROLL
+#pragma unroll NTSC_EDGE_UNROLL
+#endif
     for (; t < SKT && t < total; t++) {
         uint32_t px; int xo;
         (void)edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo);
@@ -946,6 +951,9 @@ DEV void decode_fast_body(const DevParams &P, const GeomDev &G, const FieldDev *
         default: t = steady<VHS, 3, RT, CT>(P, S, C, ring, lring, ostage, orow, drow, is_out, t); break;
     }
     // ---------------- row end, filter tails, pipeline drain
+#ifdef NTSC_EDGE_UNROLL
+#pragma unroll NTSC_EDGE_UNROLL
+#endif
     for (; t < total; t++) {
         uint32_t px; int xo;
         if (!edge_step<VHS, RT, CT>(P, S, C, ring, t, px, xo)) continue;
