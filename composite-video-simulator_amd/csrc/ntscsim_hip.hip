@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unistd.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -1484,6 +1485,10 @@ struct HostPins {
         s0 = (uintptr_t)src & ~(PG - 1);
         d0 = (uintptr_t)dst & ~(PG - 1);
         bool want_src = src_span >= MIN_PIN, want_dst = dst_span >= MIN_PIN;
+        // (never memory of the brk heap: its pages are trimmed and recycled by the allocator)
+        const uintptr_t brk = (uintptr_t)sbrk(0);
+        want_src = want_src && (uintptr_t)src >= brk;
+        want_dst = want_dst && (uintptr_t)dst >= brk;
         if (want_src && want_dst && s0 < d1 && d0 < s1) {          // page ranges touch: one registration
             s0 = s0 < d0 ? s0 : d0; s1 = s1 > d1 ? s1 : d1;
             want_dst = false;

@@ -17,6 +17,7 @@
 // ~0.5 ms as one of 600: three launches side by side hide that latency.  Fields carry explicit rand()
 // positions, so it does not matter which lane runs which launch.
 #include <deque>
+#include <unistd.h>
 
 namespace {
 
@@ -231,6 +232,11 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
     // page theirs as well; a frame that starts deeper than 128 bytes into a page is a block inside a shared heap and
     // goes through the staging ring instead.
     if ((a0 & 4095u) > 128u) return nullptr;
+    // ... and never memory of the brk heap, whatever it looks like: the allocator trims and recycles those pages under a
+    // registration (seen as aborts inside later, unrelated hipMemcpy calls once such a registration had been dropped and
+    // the pages reused).  Blocks with a mapping of their own (what malloc / posix_memalign hand out for frame-sized
+    // requests unless the process has raised the mmap threshold) live far above the program break.
+    if (span < (64u << 10) || a0 < (uintptr_t)sbrk(0)) return nullptr;
     for (auto &r : e->regs)
         if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
     const uintptr_t PG = 4096;

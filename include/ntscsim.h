@@ -242,7 +242,8 @@ int ntscsim_field(ntscsim_ctx *ctx,
  * Host buffers: by default the engine pins the caller's frames IN PLACE the first time it sees them
  * (hipHostRegister, whole pages, cached per ctx: AVFrame pools recycle a handful of buffers) and moves the
  * pixels with DMA uploads and a GPU delivery kernel that writes the field rows straight into the caller's
- * frame -- no host memcpy.  Buffers smaller than min_pin_bytes, buffers that start more than 128 bytes into a page
+ * frame -- no host memcpy.  Buffers smaller than min_pin_bytes (and never smaller than 64 KiB), memory of the brk heap
+ * (below sbrk(0): the allocator trims and recycles those pages), buffers that start more than 128 bytes into a page
  * (a block inside a shared heap rather than an allocation of its own: pinning its edge pages would pin its
  * neighbours' bytes), buffers that share a page with another registration, or pin_caller_buffers = 0 go through a
  * pinned staging ring instead (one memcpy each way).

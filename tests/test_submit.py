@@ -17,12 +17,13 @@ from ntscsim import _capi
 
 
 def page_frame(h, w, fill=0):
-    """A [h, w, 4] uint8 frame that owns whole 4 KiB pages (like av_frame_get_buffer's large allocations): the
-    engine pins caller memory page-wise and will not pin a frame that shares a page with another registration."""
+    """A [h, w, 4] uint8 frame with a mapping of its own (anonymous mmap, page aligned) -- what malloc / posix_memalign
+    hand out for frame-sized requests, made deterministic: the engine pins caller memory page-wise, and only memory
+    that is an allocation of its own (never blocks inside the brk heap, never frames under 64 KiB)."""
+    import mmap
     nbytes = h * w * 4
-    raw = np.empty(((nbytes + 4095) // 4096 + 2) * 4096, np.uint8)
-    off = (-raw.ctypes.data) % 4096
-    a = raw[off:off + nbytes].reshape(h, w, 4)
+    m = mmap.mmap(-1, (nbytes + 4095) // 4096 * 4096)
+    a = np.frombuffer(m, np.uint8, nbytes).reshape(h, w, 4)
     a[:] = fill
     return a
 
@@ -83,7 +84,8 @@ def run_submit_loop(sim, frames, n_fields, w, h, ring, bob, lag, pad=0, same_src
 def test_submit_wait_equals_the_synchronous_loop(bob, pin, h):
     """Small frames, depth 4, a ring as deep as the lag: every snapshot == the oracle's loop, the rand()
     position == the oracle's; both delivery paths (pinned in place / staging ring)."""
-    w, n = 96, 26            # (h = 33: the line doubling leaves a different row alone for each field parity)
+    w, n = (192 if pin else 96), 26    # (pinned in place: frames of at least 64 KiB; h = 33: the line doubling leaves a
+    h = h * 3 if pin else h            #  different row alone for each field parity)
     p = L.make_params(["-vhs"], output_height=h)
     frames = [L.noise_frame(w, h, 700 + j) for j in range(n // 2)]
     ring, lag = 12, 9
@@ -154,7 +156,7 @@ def test_submit_at_the_baseline_size_default_options():
 def test_two_fields_in_flight_share_one_destination_frame():
     """Without bob the two fields of a frame write disjoint rows of ONE dst frame, as in the reference with
     `-d 1`; in flight together they must both land, other rows untouched until their own field arrives."""
-    w, h, n = 96, 32, 12
+    w, h, n = 192, 96, 12
     p = L.make_params([])
     frames = [L.noise_frame(w, h, 900 + j) for j in range(n // 2)]
     exp, exp_pos = reference_loop(p, frames, n, w, h, 1, False)
@@ -233,7 +235,7 @@ def test_submit_errors_consume_nothing_and_tickets_are_checked():
 def test_ring_full_blocks_and_unpin_releases():
     """More submits than ring slots without a single wait: the engine retires the oldest launches itself (their
     rows land in the caller's frames) and keeps going; ntscsim_host_unpin() drops the registrations."""
-    w, h, n = 96, 32, 40
+    w, h, n = 192, 96, 40
     p = L.make_params(["-vhs"])
     frames = [L.noise_frame(w, h, 1200 + j) for j in range(n // 2)]
     exp, exp_pos = reference_loop(p, frames, n, w, h, n, False)
