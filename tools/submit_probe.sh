@@ -7,9 +7,9 @@ FL=composite-video-simulator_amd/field_loop
 {
 echo "# byte identity (FNV-1a over every consumed frame, same ring): sync vs submit, bob off/on"
 for bob in 0 1; do
-  $FL -vhs --mode sync   --fields 300 --warmup 0 --ring 70 --bob $bob --hash 1
-  $FL -vhs --mode submit --fields 300 --warmup 0 --ring 70 --bob $bob --hash 1 --depth 32
-  $FL -vhs --mode submit --fields 300 --warmup 0 --ring 70 --bob $bob --hash 1 --depth 32 --pin 0
+  $FL -vhs --mode sync   --fields 300 --warmup 0 --ring 140 --bob $bob --hash 1
+  $FL -vhs --mode submit --fields 300 --warmup 0 --ring 140 --bob $bob --hash 1 --depth 32
+  $FL -vhs --mode submit --fields 300 --warmup 0 --ring 140 --bob $bob --hash 1 --depth 32 --pin 0
 done
 echo "# throughput, 720x486 -vhs"
 $FL -vhs --mode sync --fields 1500 --warmup 100
