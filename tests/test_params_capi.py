@@ -173,14 +173,21 @@ int main(void) {
     static uint8_t buf[64 * 4 * 8];
     struct my_frame a = {{buf}, {64 * 4}, 64, 8, 0, 0, 0}, b = a, c = a, d = a;
     c.width = 32; d.linesize[0] = 100;
-    int r[5];
+    int r[10];
+    uint64_t ticket = 77;
     r[0] = ntscsim_field_avframe(0, 0, &a, 0, 0);
     r[1] = ntscsim_field_avframe(0, &a, &c, 0, 0);
     r[2] = ntscsim_field_avframe(0, &d, &b, 0, 0);
     r[3] = ntscsim_field_avframe(0, &a, &b, 0, 0) != NTSCSIM_OK;
+    /* the asynchronous form maps the same guards (and a NULL ctx is an argument error, no ticket is issued) */
+    r[5] = ntscsim_submit_avframe(0, 0, &a, 0, 0, 0, &ticket);
+    r[6] = ntscsim_submit_avframe(0, &a, &c, 0, 0, NTSCSIM_DESC_BOB, &ticket);
+    r[7] = ntscsim_submit_avframe(0, &d, &b, 0, 0, NTSCSIM_SUBMIT_SAME_SRC, &ticket);
+    r[8] = ntscsim_submit_avframe(0, &a, &b, 0, 0, 0, &ticket);
+    r[9] = ticket == 77 && ntscsim_wait(0, 1) == NTSCSIM_E_ARG && ntscsim_flush(0) == NTSCSIM_E_ARG;
     b.data[0] = 0;
     r[4] = ntscsim_field_avframe(0, &a, &b, 0, 0);
-    printf("%d %d %d %d %d\n", r[0], r[1], r[2], r[3], r[4]);
+    printf("%d %d %d %d %d %d %d %d %d %d\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9]);
     return 0;
 }
 ''')
@@ -189,7 +196,8 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe),
                            "-L", L.PKG, "-lntscsim", "-Wl,-rpath," + L.PKG])
     out = subprocess.check_output([str(exe)]).decode().split()
-    assert [int(x) for x in out] == [_capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, 1, _capi.E_ARG]
+    assert [int(x) for x in out] == [_capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, 1, _capi.E_ARG,
+                                     _capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, _capi.E_ARG, 1]
     if shutil.which("g++"):
         cpp = tmp_path / "av.cpp"
         cpp.write_text(src.read_text())
