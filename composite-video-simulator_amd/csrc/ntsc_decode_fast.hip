@@ -77,7 +77,8 @@ struct LaneRand32 {
         pos = (pos + 1) & 31;
         return v >> 1;
     }
-    // draw K (0..7) of a steady iteration whose first slot is rb - lane column (a multiple of 8 slots)
+    // draw K of a steady iteration whose first slot is rb's (a multiple of 8 slots for 8 draws per iteration, of 16 for 16:
+    // slot K + 1 <= 32 must exist)
     template <int K>
     DEV uint32_t draw(uint32_t *rb, bool first_slot_is_zero)
     {

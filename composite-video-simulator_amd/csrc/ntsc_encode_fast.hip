@@ -28,11 +28,7 @@ struct EState {
     int Yd[4];            // 256 * luma of pixels t-4 .. t-1
     int Ir[4], Qr[4];     // raw I, Q of pixels t-4 .. t-1 (row tail :1447-1455), edge steps only
     int fI[2];            // filtered I pushed at t-2, t-1
-#ifdef NTSC_RANDP
-    fastdec::LaneRandP rng;
-#else
-    LaneRand rng;
-#endif
+    fastdec::LaneRand32 rng;   // 32 slots + a copy of slot 0: the 16 draws of a chunk are immediate LDS offsets from one address
     int noise;
     OnePoleT<RT> pre;     // PRE: the pre-emphasis high-pass :1610-1623
 };
@@ -55,7 +51,14 @@ struct EConst {
 template <class RT>
 DEV void rgb_to_yiq256(uint32_t px, RT &dY, RT &Id, RT &Qd)
 {
+#ifdef NTSC_ENC_SHIFT_EXTRACT
     const RT r = (RT)((px >> 8) & 0xFF00u), g = (RT)(px & 0xFF00u), b = (RT)((px << 8) & 0xFF00u);
+#else
+    // 256 * channel = the channel's byte moved to byte 1 of an otherwise zero word: one v_perm_b32 each for R (byte 2) and
+    // B (byte 0) instead of shift + mask (selector 0x0c = constant zero), G is in place already
+    const RT r = (RT)__builtin_amdgcn_perm(0u, px, 0x0c0c020cu), g = (RT)(px & 0xFF00u),
+             b = (RT)__builtin_amdgcn_perm(0u, px, 0x0c0c000cu);
+#endif
     dY = ((RT(0.30) * r) + (RT(0.59) * g)) + (RT(0.11) * b);
     const RT bd = b - dY, rd = r - dY;
     Id = rtrunc<RT>((RT(-0.27) * bd) + (RT(0.74) * rd));
@@ -75,7 +78,7 @@ DEV int preemphasis(EState<RT> &S, const EConst<RT> &C, int Y)
 }
 
 template <int J, class RT, bool PRE, bool XA = false>
-DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
+DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *rb, bool rb0,
              RT Id, RT Qd, int Yx, int I2, int &fI_out)
 {
     fI_out = (int)S.lpI.push(Id, C.a_i);            // lands at index t - 2
@@ -89,7 +92,7 @@ DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *r
     if (PRE) Y = preemphasis<RT>(S, C, Y);
     // luma noise :1632-1644
     Y += S.noise;
-    S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
+    S.noise = sdiv2(S.noise + (int)umod31(S.rng.template draw<J>(rb, rb0), P.m_noise) - P.noise_k);
     return Y;
 }
 
@@ -187,7 +190,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
                           const int *__restrict__ n0_luma, int *__restrict__ comp)
 {
     using namespace fastenc;
-    __shared__ uint32_t ring[31 * 64];
+    __shared__ uint32_t ring[33 * 64];            // LaneRand32
 #ifndef NTSC_ENC_NOCOOP
     __shared__ __attribute__((aligned(16))) uint32_t ltile[64 * 20];
 #endif
@@ -222,7 +225,9 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
     C.comp = __builtin_amdgcn_make_buffer_rsrc(comp, 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
 
     EState<RT> S;
-    S.rng.init(ring, rs_luma + rc, P.Rpad, lane);
+    // (no draw before the steady loop -- the row's first four steps only fill the look-ahead -- so the window is placed
+    //  with its first draw on slot 0: the loop's 16 draws per chunk start on a multiple of 16)
+    S.rng.init(ring, rs_luma + rc, P.Rpad, lane, 1);
     S.noise = n0_luma[rc];
     S.lpI.reset(0, C.a_i); S.lpQ.reset(0, C.a_q);
     S.pre.p = 16;
@@ -249,8 +254,12 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
         int Y0 = S.Yd[0], Y1 = S.Yd[1], Y2 = S.Yd[2], Y3 = S.Yd[3];   // luma of pixels t-4 .. t-1
         int I0 = S.fI[0], I1 = S.fI[1];                               // filtered I of indices t-4, t-3
         RT IdT[4], QdT[4];     // raw I, Q of the chunk's last four pixels (row tail)
+        int sbase = S.rng.pos;          // 0: see init
         for (; t + 16 <= W; t += 16) {
             const bool more = t + 32 <= W;
+            uint32_t *const rb = ring + sbase * 64 + lane;
+            const bool rb0 = sbase == 0;
+            sbase = (sbase + 16) & 31;
 #ifndef NTSC_ENC_NOCOOP
             if (more) L.request(t + 16, nq);
 #else
@@ -264,7 +273,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
                 rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
-                const int Y = step<J, RT, PRE, XA>(P, S, C, ring, Id_, Qd_, YX, IX, F[J]);             \
+                const int Y = step<J, RT, PRE, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]);          \
                 __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
@@ -296,6 +305,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
             }
 #endif
         }
+        S.rng.pos = sbase;
         // hand the delay lines back to the guarded steps
         S.Yd[0] = Y0; S.Yd[1] = Y1; S.Yd[2] = Y2; S.Yd[3] = Y3;
         S.fI[0] = I0; S.fI[1] = I1;
