@@ -67,6 +67,7 @@ typedef double lvpair __attribute__((ext_vector_type(2)));     // lv of two cons
 
 struct FrontConst {
     double alpha, a_fast, om_fast, a_slow, om_slow;   // a, 1.0 - a of the two follower rates (:563-570)
+    double om_slow_sb;                                // om_slow ^ FOLLOW_SB: the cheap part of sweep 2's warm-up
     int thr;
 };
 
@@ -141,14 +142,19 @@ __global__ void k_raw28_head(const uint8_t *__restrict__ raw, uint8_t *__restric
 
 // samples [s0, s1) through the three low-passes, s0 a multiple of 16 (raw is padded by 64 bytes); OUT: lv of
 // the sample pair (s0 + 2u, s0 + 2u + 1) to out[u * stride]
+// With `sum` (OUT only; s0 is then a multiple of FOLLOW_SB = 64 within its column): one record per 64 samples for the
+// cheap part of sweep 2's warm-up, sum[u * stride] = (min lv, a_slow * SUM lv_i om_slow^(63 - i)) -- what 64 steps of
+// the follower's slow branch add to om_slow^64 * level.  A GUESS feeds on it, nothing exact: fused multiply-add is fine.
 template <bool OUT>
 __device__ __forceinline__ void lp_span(double &p0, double &p1, double &p2, double alpha, const uint8_t *__restrict__ raw,
-                                        size_t s0, size_t s1, lvpair *__restrict__ out, size_t stride)
+                                        size_t s0, size_t s1, lvpair *__restrict__ out, size_t stride,
+                                        lvpair *__restrict__ sum = nullptr, double a_slow = 0.0, double om_slow = 0.0)
 {
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     const size_t n = s1 - s0, nb = n / 16;
     const v4 *rv = (const v4 *)(raw + s0);
     v4 cur = rv[0];
+    double acc = 0.0, mn = 1e300;
     for (size_t b = 0; b < nb; b++) {
         const v4 nxt = rv[b + 1];                  // (at most 16 bytes past s1: inside the padding)
         const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -158,6 +164,16 @@ __device__ __forceinline__ void lp_span(double &p0, double &p1, double &p2, doub
             pr.x = lp3_step(p0, p1, p2, alpha, (double)((w[j >> 2] >> (8 * (j & 3))) & 0xFFu));
             pr.y = lp3_step(p0, p1, p2, alpha, (double)((w[j >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu));
             if (OUT) out[(b * 8 + (size_t)(j >> 1)) * stride] = pr;
+            if (OUT && sum) {
+                acc = __builtin_fma(acc, om_slow, pr.x);
+                acc = __builtin_fma(acc, om_slow, pr.y);
+                mn = __builtin_fmin(mn, __builtin_fmin(pr.x, pr.y));
+            }
+        }
+        if (OUT && sum && (b & 3) == 3) {
+            lvpair rec; rec.x = mn; rec.y = acc * a_slow;
+            sum[(b >> 2) * stride] = rec;
+            acc = 0.0; mn = 1e300;
         }
         cur = nxt;
     }
@@ -176,7 +192,8 @@ __global__ __launch_bounds__(64) void k_raw28_lp(const uint8_t *__restrict__ raw
                                                  int w1, int nchunks, int nsub, double alpha,
                                                  const FrontState *__restrict__ st_a0, lvpair *__restrict__ LV2,
                                                  FrontState *__restrict__ st_begin, FrontState *__restrict__ st_end,
-                                                 const FrontState *__restrict__ prev_end, const int *__restrict__ flags)
+                                                 const FrontState *__restrict__ prev_end, const int *__restrict__ flags,
+                                                 lvpair *__restrict__ SUM, double a_slow, double om_slow)
 {
     const int nwc = (nchunks + 63) / 64;
     const int q = blockIdx.x / nwc, c = (blockIdx.x - q * nwc) * 64 + threadIdx.x;
@@ -197,15 +214,19 @@ __global__ __launch_bounds__(64) void k_raw28_lp(const uint8_t *__restrict__ raw
         lp_span<false>(p0, p1, p2, alpha, raw, w0, g, nullptr, 0);
     }
     st_begin[i] = FrontState{p0, p1, p2, 0.0};
-    lp_span<true>(p0, p1, p2, alpha, raw, g, e, LV2 + (size_t)q * (size_t)(ms / 2) * (size_t)nchunks + c, (size_t)nchunks);
+    lp_span<true>(p0, p1, p2, alpha, raw, g, e, LV2 + (size_t)q * (size_t)(ms / 2) * (size_t)nchunks + c, (size_t)nchunks,
+                  SUM ? SUM + (size_t)q * (size_t)(ms / 64) * (size_t)nchunks + c : nullptr, a_slow, om_slow);
     st_end[i] = FrontState{p0, p1, p2, 0.0};
 }
 
 // hsync_dc_raw :588-593
 __device__ __forceinline__ uint32_t dc_byte(double lv, double level)
 {
-    const int x = (int)(lv - level);
-    return (uint32_t)(x < 0 ? 0 : (x > 255 ? 255 : x));
+    // clamp((int)(lv - level), 0, 255): the conversion to unsigned saturates at 0 and truncates like (int) above it
+    // (both values are bounded by the 8-bit samples), which leaves one full-rate v_min_u32 of the clamp
+    uint32_t u;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(u) : "v"(lv - level));
+    return u < 255u ? u : 255u;
 }
 
 constexpr size_t FRONT_SEG = (size_t)1 << 29;     // samples per front-end segment (4 GiB of plane)
@@ -216,7 +237,12 @@ constexpr int LP_WARM = 2048;                      // sweep 1's warm-up: 0.942^t
 constexpr int FOLLOW_BLK = 16;                     // samples per block of loads (8 loads of one sample pair)
 constexpr int FOLLOW_CK = 1024;                    // samples between the checkpoints a repair round compares with
 constexpr int FOLLOW_NB = 6;                       // blocks per lane in registers: five in flight while one is used
-constexpr size_t FOLLOW_PIN_LDS = 96 * 1024;       // > half of the CU's 160 KiB: one workgroup (= one wavefront) per CU
+constexpr size_t FOLLOW_PIN_LDS = 80 * 1024;       // with the 16 KiB of `sums` > half of the CU's 160 KiB: one workgroup (= one wavefront) per CU
+#ifndef RAW28_SLOW_BLOCKS
+#define RAW28_SLOW_BLOCKS 0
+#endif
+constexpr int FOLLOW_SB = 64;                      // samples per record of the summary plane (the cheap part of the warm-up)
+constexpr int FOLLOW_SG = 16;                      // records per batch: fetched one batch ahead, parked in LDS
 
 // 16 follower steps over the samples of one block.  A lone wavefront gets one instruction through per ~5
 // cycles whatever its kind, so the step is written for the fewest instructions, exactly the tool's own
@@ -244,21 +270,51 @@ __device__ __forceinline__ void follow_block(double &level, const lvpair (&src)[
     }
 }
 
+// 16 steps of the slow branch alone -- level = level (1.0 - a_slow) + lv a_slow, the tool's own expression :568-569 with
+// 1.0 - a_slow the same rounded constant -- for a block of which the caller KNOWS that no step takes the fast branch:
+// 3 instructions per sample instead of 7.
+template <bool OUT>
+__device__ __forceinline__ void slow_block(double &level, const lvpair (&src)[FOLLOW_BLK / 2], const FrontConst &K, uint32_t (&o)[4])
+{
+#pragma unroll
+    for (int j = 0; j < FOLLOW_BLK; j++) {
+        const double lv = (j & 1) ? src[j >> 1].y : src[j >> 1].x;
+        level = (level * K.om_slow) + (lv * K.a_slow);
+        if (OUT) o[j >> 2] |= dc_byte(lv, level) << (8 * (j & 3));
+    }
+}
+// That knowledge: sweep 1's record of the 64-sample superblock around the block holds the smallest lv in it; a level
+// more than 0.0625 below it stays below every lv of the block (16 slow steps lift it by less than 16 a_slow 255 =
+// 0.015), so `hsync_dc_level > lv` :563 is false 16 times.  Taken by a wavefront only if it holds for all its lanes.
+__device__ __forceinline__ bool block_is_slow(double level, const lvpair &rec) { return level + 0.0625 < rec.x; }
+
 // Sweep 2.  One wavefront = 64 consecutive chunks.  With Kw = ceil(warm / m) and r0 = Kw m - warm, lane c
 // starts at row r0 of column c - Kw and walks to the end of column c - 1 (its warm-up, `warm` samples), then
 // its own column with output.  Columns before 0 do not exist: such a lane waits, with the exact level before
 // a0, until its walk reaches column 0.  Repair rounds (flags): the own column only, from prev_end[c - 1].
 // The plane holds sample PAIRS: LV2[t / 2][c] = (lv(t), lv(t + 1)), one 16-byte load per lane and pair.
-__global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ LV2, size_t a0, size_t o1, int m, int warm,
+//
+// The warm-up only has to produce a GUESS of the level before the chunk (the link check is what makes the result
+// exact), so its first `cheap` samples (round 4) are not walked sample by sample: where the level is below every
+// lv of a 64-sample superblock by more than the slow branch can lift it in 64 steps (0.0625 > 64 a_slow 255), all 64
+// steps take the slow branch, and they amount to level = om_slow^64 level + B with the B sweep 1 left in SUM -- one
+// fused multiply-add and 16 bytes instead of 448 instructions and 512 bytes.  That holds for ~94 % of the superblocks
+// (everything but the sync tips); the others are walked exactly.  The closed form differs from 64 rounded steps by a
+// few ulp, so the guess is ~1e-12 off the true level (it would be 1e-14 with exact steps) and the last `warm - cheap`
+// samples, walked exactly, have to close that: 16 scanlines leave ~5 % of the links open (tools/follow_guess_probe.c),
+// which a repair round closes in a few scanlines' walk.
+__global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ LV2, const lvpair *__restrict__ SUM, size_t a0,
+                                                     size_t o1, int m, int warm, int cheap,
                                                      int nchunks, FrontConst K, const FrontState *__restrict__ st_a0,
                                                      uint8_t *__restrict__ h, double *__restrict__ lv_begin,
                                                      double *__restrict__ lv_end, double *__restrict__ ckpt, int ncp,
-                                                     const double *__restrict__ prev_end, const int *__restrict__ flags)
+                                                     const double *__restrict__ prev_end, const int *__restrict__ flags, int lpw)
 {
     constexpr int NB = FOLLOW_NB, HB = FOLLOW_BLK / 2;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = c < nchunks;
-    const int cc = valid ? c : nchunks - 1;
+    // lpw chunks per wavefront: the other lanes mirror the first one (same addresses, no stores)
+    const int c = blockIdx.x * lpw + threadIdx.x;
+    const bool valid = (int)threadIdx.x < lpw && c < nchunks;
+    const int cc = valid ? c : (int)blockIdx.x * lpw;
     const size_t ncols = (size_t)nchunks;
     const size_t rstride = ncols * sizeof(lvpair);     // bytes from one row pair to the next
     const int Kw = (warm + m - 1) / m;
@@ -271,6 +327,10 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
         if (mine) level = prev_end[cc - 1];
     }
     lvpair R[NB][HB];
+    lvpair Sr[NB];                                 // the superblock record that goes with each block (SUM != nullptr)
+    // (measured: the per-block branch between slow_block and follow_block costs the loads their pipelining -- the
+    // compiler waits for ALL of them at every block -- and the sweep 3.5 -> 4.4 ms: off until the loops are split)
+    const bool have_sum = RAW28_SLOW_BLOCKS && SUM != nullptr;
     uint32_t o[4] = {0, 0, 0, 0};
     // a block of 8 row pairs: a uniform row pointer plus the lane's column (the loads take their base from
     // scalar registers)
@@ -283,15 +343,62 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
     // ---- warm-up: columns cc - Kw .. cc - 1, the first one from row r0
     if (!repair) {
         int row = Kw * m - warm, k = -Kw;          // wave-uniform position of the next block to use ...
+        if (cheap > 0) {                           // (the host: SUM exists; m, warm, cheap are multiples of 64)
+            __shared__ lvpair sums[FOLLOW_SG][64];
+            const int lane = (int)threadIdx.x;
+            const int nsb = cheap / FOLLOW_SB;
+            int frow = row, fk = k;                // where the next record to fetch lies
+            lvpair tmp[FOLLOW_SG];
+            auto fetch = [&]() {                   // (runs up to a batch past the cheap part: columns clamped, never used)
+#pragma unroll
+                for (int j = 0; j < FOLLOW_SG; j++) {
+                    int col = cc + fk;
+                    col = col < 0 ? 0 : (col >= nchunks ? nchunks - 1 : col);
+                    tmp[j] = SUM[(size_t)(frow / FOLLOW_SB) * ncols + (size_t)col];
+                    frow += FOLLOW_SB;
+                    if (frow >= m) { frow -= m; fk++; }
+                }
+            };
+            fetch();
+            for (int sb = 0; sb < nsb; sb += FOLLOW_SG) {
+#pragma unroll
+                for (int j = 0; j < FOLLOW_SG; j++) sums[j][lane] = tmp[j];    // (every lane reads back its own records only)
+                fetch();                           // the next batch is in flight while this one is walked
+                const int nb = nsb - sb < FOLLOW_SG ? nsb - sb : FOLLOW_SG;
+                lvpair Snext = sums[0][lane];
+                for (int j = 0; j < nb; j++) {
+                    const lvpair S = Snext;
+                    Snext = sums[j + 1 < FOLLOW_SG ? j + 1 : j][lane];       // (the LDS read is off the level's chain)
+                    const bool waiting = cc + k < 0;
+                    if (__all(waiting || block_is_slow(level, S))) {
+                        if (!waiting) level = __builtin_fma(level, K.om_slow_sb, S.y);
+                    } else {
+                        const int col = waiting ? 0 : cc + k;
+#pragma unroll
+                        for (int i = 0; i < FOLLOW_SB / FOLLOW_BLK; i++) load_block(R[i], row + i * FOLLOW_BLK, col);
+#pragma unroll
+                        for (int i = 0; i < FOLLOW_SB / FOLLOW_BLK; i++)
+                            if (!waiting) follow_block<false>(level, R[i], K, o);
+                    }
+                    row += FOLLOW_SB;
+                    if (row >= m) { row -= m; k++; }
+                }
+            }
+        }
         int lrow = row, lk = k;                    // ... and of the next block to request
-        const long long nblk = (long long)warm / FOLLOW_BLK;                   // (warm and m are multiples of 16)
-        auto request = [&](lvpair (&dst)[HB]) {    // column clamped at 0 for the lanes that are still waiting
-            load_block(dst, lrow, cc + lk < 0 ? 0 : cc + lk);
+        const long long nblk = (long long)(warm - cheap) / FOLLOW_BLK;         // (warm and m are multiples of 16)
+        auto request = [&](lvpair (&dst)[HB], lvpair &rec) {    // column clamped at 0 for the lanes that are still waiting
+            const int col = cc + lk < 0 ? 0 : cc + lk;
+            load_block(dst, lrow, col);
+            if (have_sum) rec = SUM[(size_t)(lrow / FOLLOW_SB) * ncols + (size_t)col];
             lrow += FOLLOW_BLK;
             if (lrow >= m) { lrow -= m; lk++; }
         };
-        auto use = [&](const lvpair (&src)[HB]) {
-            if (cc + k >= 0) follow_block<false>(level, src, K, o);
+        auto use = [&](const lvpair (&src)[HB], const lvpair &rec) {
+            const bool act = cc + k >= 0;
+            if (have_sum && __all(!act || block_is_slow(level, rec))) {
+                if (act) slow_block<false>(level, src, K, o);
+            } else if (act) follow_block<false>(level, src, K, o);
             row += FOLLOW_BLK;
             if (row >= m) { row -= m; k++; }
         };
@@ -299,16 +406,16 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
         long long b = 0;
         if (nblk >= NB - 1) {
 #pragma unroll
-            for (int i = 0; i < NB - 1; i++) request(R[i]);
+            for (int i = 0; i < NB - 1; i++) request(R[i], Sr[i]);
             for (; b + 2 * NB - 1 <= nblk; b += NB) {
 #pragma unroll
-                for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB]); use(R[i]); }
+                for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB], Sr[(i + NB - 1) % NB]); use(R[i], Sr[i]); }
             }
 #pragma unroll
-            for (int i = 0; i < NB - 1; i++) use(R[i]);
+            for (int i = 0; i < NB - 1; i++) use(R[i], Sr[i]);
             b += NB - 1;
         }
-        for (; b < nblk; b++) { request(R[0]); use(R[0]); }
+        for (; b < nblk; b++) { request(R[0], Sr[0]); use(R[0], Sr[0]); }
         if (valid) lv_begin[c] = level;
     } else if (mine) {
         lv_begin[c] = level;
@@ -320,14 +427,22 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
     const int nbf = len / FOLLOW_BLK, nbm = m / FOLLOW_BLK;    // full blocks of this lane; blocks of a full column (uniform)
     {
         // (rows past `len` of the stream's last column hold nothing: they are loaded, never used)
-        auto request = [&](lvpair (&dst)[HB], int blk) { load_block(dst, (blk < nbm ? blk : nbm - 1) * FOLLOW_BLK, cc); };
+        auto request = [&](lvpair (&dst)[HB], lvpair &rec, int blk) {
+            const int r = (blk < nbm ? blk : nbm - 1) * FOLLOW_BLK;
+            load_block(dst, r, cc);
+            if (have_sum) rec = SUM[(size_t)(r / FOLLOW_SB) * ncols + (size_t)cc];
+        };
         // Every FOLLOW_CK samples the level is left in ckpt[c][.].  A repair round compares instead: once the repaired
         // run meets the earlier one bitwise, everything after it (bytes, end level) is what the earlier run wrote.
         bool done = !mine;
-        auto use = [&](const lvpair (&src)[HB], int blk) {
-            if (blk < nbf && !done) {
+        auto use = [&](const lvpair (&src)[HB], const lvpair &rec, int blk) {
+            // (a record exists for whole superblocks only: the last, cut one of the stream has none)
+            const bool act = blk < nbf && !done;
+            const bool slow = have_sum && __all(!act || ((blk | (FOLLOW_SB / FOLLOW_BLK - 1)) < nbf && block_is_slow(level, rec)));
+            if (act) {
                 o[0] = o[1] = o[2] = o[3] = 0;
-                follow_block<true>(level, src, K, o);
+                if (slow) slow_block<true>(level, src, K, o);
+                else follow_block<true>(level, src, K, o);
                 *(v4 *)(h + g + (size_t)blk * FOLLOW_BLK) = v4{o[0], o[1], o[2], o[3]};
                 if ((blk + 1) % (FOLLOW_CK / FOLLOW_BLK) == 0) {
                     double *cp = ckpt + (size_t)cc * (size_t)ncp + (size_t)((blk + 1) / (FOLLOW_CK / FOLLOW_BLK) - 1);
@@ -337,10 +452,10 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
             }
         };
 #pragma unroll
-        for (int i = 0; i < NB - 1; i++) request(R[i], i);
+        for (int i = 0; i < NB - 1; i++) request(R[i], Sr[i], i);
         for (int b = 0; b < nbm; b += NB) {
 #pragma unroll
-            for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB], b + i + NB - 1); use(R[i], b + i); }
+            for (int i = 0; i < NB; i++) { request(R[(i + NB - 1) % NB], Sr[(i + NB - 1) % NB], b + i + NB - 1); use(R[i], Sr[i], b + i); }
             if (repair && __all(done)) return;
         }
         if (done) return;                          // (lanes without a chunk; repair rounds: runs that met the earlier one)
@@ -723,6 +838,8 @@ struct ntscsim_raw28 {
     bool tail_scan = true;         // comb tails: serial first guess before the rounds (NTSCSIM_RAW28_NOTAILSCAN=1: developer A/B switch)
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
+    int exact_lines = 16;          // the last scanlines of that warm-up walked sample by sample (NTSCSIM_RAW28_EXACT; >= warm_lines: all)
+    int follow_lanes = 16;         // chunks per wavefront of sweep 2 (NTSCSIM_RAW28_LANES: 1..64)
     size_t front_seg = FRONT_SEG;  // samples per front-end segment (NTSCSIM_RAW28_SEG: test hook, the segment loop on small captures)
     int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)
     // decoder state: levels (:553-554), stream position; kept from push to push of a stream
@@ -747,7 +864,7 @@ struct ntscsim_raw28 {
     // device scratch
     Buf<uint8_t> raw, h, raw_alt, h_alt, tmp;
     Buf<FrontState> st_begin, st_end, st_prev, st_a0;
-    Buf<double> lvplane, lv_begin, lv_end, lv_prev, ckpt;
+    Buf<double> lvplane, sumplane, lv_begin, lv_end, lv_prev, ckpt;
     Buf<int> flags, counters, tails_a, tails_b;
     Buf<unsigned long long> segcnt, segoff;
     Buf<uint32_t> rstart, rend;
@@ -862,11 +979,14 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.om_fast = 1.0 - d->K.a_fast;
     d->K.a_slow = 1.0 / (d->one_frame_time * 0.6);                                // :568
     d->K.om_slow = 1.0 - d->K.a_slow;
+    d->K.om_slow_sb = std::pow(d->K.om_slow, (double)FOLLOW_SB);
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOTAILSCAN")) d->tail_scan = std::atoi(e) == 0;
     if (const char *e = std::getenv("NTSCSIM_RAW28_SEG")) { const long long v = std::atoll(e); if (v >= 4096) d->front_seg = (size_t)v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_CHUNKS")) { const int v = std::atoi(e); if (v >= 64) d->max_chunks = v; }
+    if (const char *e = std::getenv("NTSCSIM_RAW28_EXACT")) { const int v = std::atoi(e); if (v >= 0) d->exact_lines = v; }
+    if (const char *e = std::getenv("NTSCSIM_RAW28_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->follow_lanes = v; }
     *out = d;
     return NTSCSIM_OK;
 }
@@ -978,7 +1098,8 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
 
     // ---- (1) front end over the new samples [front_done, N), at most FRONT_SEG of them at a time (the fp64
     // plane between the two sweeps is 8 bytes per sample)
-    const int warm = (int)(((size_t)d->warm_lines * len + 15) & ~(size_t)15);
+    const int warm = (int)(((size_t)d->warm_lines * len + 63) & ~(size_t)63);
+    const int warm_exact = (int)std::min((size_t)warm, ((size_t)d->exact_lines * len + 63) & ~(size_t)63);
     while (N > d->front_done) {
         const size_t o0 = d->front_done, o1 = std::min(N, o0 + d->front_seg), fresh = o1 - o0;
         const size_t a0 = (o0 + 15) & ~(size_t)15;
@@ -994,16 +1115,41 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         // every lane reads warm-up + chunk values of the plane, so no more chunks than it takes to occupy the
         // CUs with one wavefront each
         size_t chunk = (size_t)d->chunk;
-        if (!d->chunk_forced && fresh / chunk >= (size_t)d->max_chunks) chunk = (fresh / (size_t)d->max_chunks + 128) & ~(size_t)127;
+        int Q = 0;
+        if (!d->chunk_forced) {
+            // The cheap part of sweep 2's warm-up pays where all 64 lanes of a wavefront (64 consecutive chunks, at the
+            // same row of their columns) are outside the sync tips together, i.e. where the chunk is a whole number of
+            // scanlines long (nominal ones: a capture whose lines are longer or shorter drifts by that much per lane and
+            // takes the exact walk more often, nothing else).  It also has to be Q sub-chunks of whole 64-sample
+            // superblocks, about 2048 samples each, for sweep 1: the best such length near stream / max_chunks.
+            const double target = std::max((double)fresh / (double)d->max_chunks, 16.0 * d->one_scanline_time);
+            double best = 1e300;
+            for (int q = 1; q <= 16; q++)
+                for (int sub = 2048; sub <= 4096; sub += FOLLOW_SB) {
+                    const double len_c = (double)q * (double)sub;
+                    if (len_c < 0.55 * target || len_c > 2.0 * target) continue;
+                    const double lines = len_c / d->one_scanline_time;
+                    const double drift = std::fabs(lines - std::nearbyint(lines)) * d->one_scanline_time;   // samples per lane
+                    const double cost = 64.0 * drift + 100.0 * std::fabs(std::log(len_c / target)) - q;
+                    if (cost < best) { best = cost; chunk = (size_t)q * (size_t)sub; Q = q; }
+                }
+        }
         if (chunk > (size_t)INT_MAX / 2) { d->err = "front end: chunk too long"; return NTSCSIM_E_SIZE; }
         const int m = (int)chunk;
         const int nchunks = (int)((o1 - a0 + chunk - 1) / chunk);
-        int Q = 8;                                 // sub-chunks of sweep 1: about 2048 samples each
-        while (Q > 1 && (m % (16 * Q) != 0 || m / Q < 2048)) Q >>= 1;
+        if (Q == 0) {                              // a forced chunk length: sub-chunks of sweep 1 of about 2048 samples each
+            Q = 8;
+            while (Q > 1 && (m % (16 * Q) != 0 || m / Q < 2048)) Q >>= 1;
+        }
         const int ms = m / Q;
         const int nsub = (int)((o1 - a0 + (size_t)ms - 1) / (size_t)ms);
         const int w1 = std::min(warm, LP_WARM);
         R28CHK(d, d->lvplane.ensure((size_t)nchunks * (size_t)m));
+        // the cheap part of sweep 2's warm-up needs whole 64-sample superblocks in every sub-chunk
+        const bool have_sum = ms % FOLLOW_SB == 0;
+        const int cheap = (have_sum && warm > warm_exact) ? warm - warm_exact : 0;
+        if (have_sum) R28CHK(d, d->sumplane.ensure((size_t)nchunks * (size_t)(m / FOLLOW_SB) * 2));
+        lvpair *const SUM = have_sum ? (lvpair *)d->sumplane.p : nullptr;
         R28CHK(d, d->st_begin.ensure((size_t)nsub));
         R28CHK(d, d->st_end.ensure((size_t)nsub));
         R28CHK(d, d->st_prev.ensure((size_t)nsub));
@@ -1022,7 +1168,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         const unsigned lp_blocks = (unsigned)(((nchunks + 63) / 64) * Q);
         hipLaunchKernelGGL(k_raw28_lp, dim3(lp_blocks), dim3(64), 0, st, raw, a0, o1, m, ms, Q, w1, nchunks, nsub, d->K.alpha,
                            (const FrontState *)d->st_a0.p, (lvpair *)d->lvplane.p, d->st_begin.p, d->st_end.p,
-                           (const FrontState *)nullptr, (const int *)nullptr);
+                           (const FrontState *)nullptr, (const int *)nullptr, SUM, d->K.a_slow, d->K.om_slow);
         for (;;) {
             R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_raw28_links, dim3((nsub + 255) / 256), dim3(256), 0, st, d->st_begin.p, d->st_end.p,
@@ -1035,15 +1181,21 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
             R28CHK(d, hipMemcpyAsync(d->st_prev.p, d->st_end.p, (size_t)nsub * sizeof(FrontState), hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(k_raw28_lp, dim3(lp_blocks), dim3(64), 0, st, raw, a0, o1, m, ms, Q, w1, nchunks, nsub, d->K.alpha,
                                (const FrontState *)d->st_a0.p, (lvpair *)d->lvplane.p, d->st_begin.p, d->st_end.p,
-                               (const FrontState *)d->st_prev.p, (const int *)d->flags.p);
+                               (const FrontState *)d->st_prev.p, (const int *)d->flags.p, SUM, d->K.a_slow, d->K.om_slow);
         }
         // sweep 2: the follower
-        const unsigned fw_blocks = (unsigned)((nchunks + 63) / 64);
-        const size_t pin = d->front_pin && fw_blocks <= 256 ? FOLLOW_PIN_LDS : 0;
+        // Few chunks per wavefront where the warm-up has a cheap part: a superblock is taken in closed form only if ALL
+        // lanes of the wavefront can, and a lane inside a field's broad sync pulses cannot for lines on end (1.1 % of
+        // the scanlines: with 64 lanes 16 scanlines apart one of them nearly always is).  The walk is one dependent
+        // chain per wavefront whatever its lane count, and there are SIMDs to spare: one wavefront per SIMD.
+        const int lpw = have_sum ? d->follow_lanes : 64;
+        const unsigned fw_blocks = (unsigned)((nchunks + lpw - 1) / lpw);
+        const size_t pin = !d->front_pin ? 0 : fw_blocks <= 256 ? FOLLOW_PIN_LDS : fw_blocks <= 1024 ? 20 * 1024 : 0;
         if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_follow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
-        hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), pin, st, (const lvpair *)d->lvplane.p, a0, o1, m, warm, nchunks,
+        hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), pin, st, (const lvpair *)d->lvplane.p, (const lvpair *)SUM, a0, o1, m, warm,
+                           cheap, nchunks,
                            d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p, d->lv_end.p, d->ckpt.p, ncp,
-                           (const double *)nullptr, (const int *)nullptr);
+                           (const double *)nullptr, (const int *)nullptr, lpw);
         for (;;) {
             R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_raw28_links1, dim3((nchunks + 255) / 256), dim3(256), 0, st, (const double *)d->lv_begin.p,
@@ -1053,9 +1205,10 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
             if (nbad == 0) break;
             d->stats[0]++; d->stats[1] += nbad;
             R28CHK(d, hipMemcpyAsync(d->lv_prev.p, d->lv_end.p, (size_t)nchunks * sizeof(double), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), 0, st, (const lvpair *)d->lvplane.p, a0, o1, m, warm, nchunks,
+            hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), 0, st, (const lvpair *)d->lvplane.p, (const lvpair *)SUM, a0, o1, m, warm,
+                               cheap, nchunks,
                                d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p, d->lv_end.p, d->ckpt.p, ncp,
-                               (const double *)d->lv_prev.p, (const int *)d->flags.p);
+                               (const double *)d->lv_prev.p, (const int *)d->flags.p, lpw);
         }
         // the exact state after the last sample: where the next segment / push starts
         FrontState fin;

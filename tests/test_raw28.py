@@ -195,7 +195,27 @@ def test_hip_front_end_equals_oracle_and_repairs_are_exact():
         if warm == 0:
             assert st["front_rounds"] >= 1 and st["chunks_repaired"] >= 1
         if warm is None:
-            assert st["front_rounds"] <= 1, st               # the default warm-up (nearly) always suffices here
+            assert st["front_rounds"] <= 3, st               # the default warm-up leaves a few links to one or two repair rounds
+        dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exact", [0, 3, 16, 1000])
+def test_hip_front_end_cheap_warm_up_is_only_a_guess(monkeypatch, exact):
+    """The follower's warm-up takes its first scanlines in closed form from sweep 1's 64-sample records (round 4) and
+    only the last NTSCSIM_RAW28_EXACT scanlines sample by sample.  Whatever the split -- no exact part at all (every link
+    is then closed by the repair rounds), a short one, the default, all of it exact (the round-3 walk) -- the bytes,
+    frames and levels are the oracle's; also with chunks that are not a multiple of 64 (no records, exact walk)."""
+    monkeypatch.setenv("NTSCSIM_RAW28_EXACT", str(exact))
+    capture = L.raw28_capture(5, 31, 4, 1234)
+    h, _ = L.raw28_oracle_front(L.raw28_oracle_opts(), capture)
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    for warm, chunk in ((None, None), (None, 8192), (40, 16384), (None, 4112), (112, 64 * 37)):
+        got, lv2, st, dec = _hip_run([], capture, warm=warm, chunk=chunk)
+        assert np.array_equal(dec.read_front(capture.size), h), (exact, warm, chunk, st)
+        assert np.array_equal(got, want) and lv2 == lv, (exact, warm, chunk)
+        if exact == 0 and chunk != 4112:
+            assert st["chunks_repaired"] >= 1, st            # a closed-form guess is a few ulp off: the links cannot all hold
         dec.close()
 
 

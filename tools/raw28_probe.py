@@ -8,6 +8,8 @@ import _libs as L
 base = L.raw28_capture(30, 5, 3, 0)
 capture = np.ascontiguousarray(np.tile(base[:30 * 477750], 20)[250000:])
 dec = ntscsim.Raw28Decoder([])
+if os.environ.get("RAW28_PROBE_WARM"):  # warm-up scanlines only (the chunk length stays the decoder's choice)
+    dec.set_speculation(int(os.environ["RAW28_PROBE_WARM"]), 0)
 if len(sys.argv) > 2:      # raw28_probe.py <warm-up scanlines> <chunk samples>: speculation settings (results must not change)
     dec.set_speculation(int(sys.argv[1]), int(sys.argv[2]))
 cap = torch.from_numpy(capture).cuda()
