@@ -301,8 +301,13 @@ __device__ __forceinline__ bool block_is_slow(double level, const lvpair &rec) {
 // fused multiply-add and 16 bytes instead of 448 instructions and 512 bytes.  That holds for ~94 % of the superblocks
 // (everything but the sync tips); the others are walked exactly.  The closed form differs from 64 rounded steps by a
 // few ulp, so the guess is ~1e-12 off the true level (it would be 1e-14 with exact steps) and the last `warm - cheap`
-// samples, walked exactly, have to close that: 16 scanlines leave ~5 % of the links open (tools/follow_guess_probe.c),
-// which a repair round closes in a few scanlines' walk.
+// samples, walked exactly, have to close that: the median guess is bit-identical after 8 scanlines, one in a thousand
+// needs more than 25 (tools/follow_guess_probe.c); with the default 30 a chunk or two of ten thousand are left to a
+// repair round (measured, profiles/r04_raw28_sweep.txt: 12 scanlines 1,394 chunks, 16: 347, 20: 86, 24: 28, 30: 1).
+// "All lanes" is the catch: a lane inside a field's broad sync pulses is fast for lines on end, lanes that are not a
+// whole number of scanlines apart see their sync tips at different times.  Hence the host's choice of the chunk length
+// (16 scanlines: the only multiple of 64 samples that is a whole number of 1820-sample lines) and of 16 chunks per
+// wavefront, and the way out below when hardly any superblock turns out slow.
 __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ LV2, const lvpair *__restrict__ SUM, size_t a0,
                                                      size_t o1, int m, int warm, int cheap,
                                                      int nchunks, FrontConst K, const FrontState *__restrict__ st_a0,
@@ -360,7 +365,12 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
                 }
             };
             fetch();
+            int walked = 0, done_sb = 0;           // superblocks that had to be walked exactly / superblocks behind us
             for (int sb = 0; sb < nsb; sb += FOLLOW_SG) {
+                // lanes that are out of step (a capture whose scanlines are not the nominal length, a forced chunk
+                // length): hardly any superblock is slow for all of them at once, and fetching the samples on demand
+                // is slower than the pipelined exact walk below, which then takes over
+                if (sb >= 16 * FOLLOW_SG && 2 * walked > sb) break;
 #pragma unroll
                 for (int j = 0; j < FOLLOW_SG; j++) sums[j][lane] = tmp[j];    // (every lane reads back its own records only)
                 fetch();                           // the next batch is in flight while this one is walked
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
                     if (__all(waiting || block_is_slow(level, S))) {
                         if (!waiting) level = __builtin_fma(level, K.om_slow_sb, S.y);
                     } else {
+                        walked++;
                         const int col = waiting ? 0 : cc + k;
 #pragma unroll
                         for (int i = 0; i < FOLLOW_SB / FOLLOW_BLK; i++) load_block(R[i], row + i * FOLLOW_BLK, col);
@@ -383,7 +394,9 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
                     row += FOLLOW_SB;
                     if (row >= m) { row -= m; k++; }
                 }
+                done_sb += nb;
             }
+            cheap = done_sb * FOLLOW_SB;           // (what is left of the warm-up is walked exactly)
         }
         int lrow = row, lk = k;                    // ... and of the next block to request
         const long long nblk = (long long)(warm - cheap) / FOLLOW_BLK;         // (warm and m are multiples of 16)
@@ -838,7 +851,7 @@ struct ntscsim_raw28 {
     bool tail_scan = true;         // comb tails: serial first guess before the rounds (NTSCSIM_RAW28_NOTAILSCAN=1: developer A/B switch)
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
-    int exact_lines = 16;          // the last scanlines of that warm-up walked sample by sample (NTSCSIM_RAW28_EXACT; >= warm_lines: all)
+    int exact_lines = 30;          // the last scanlines of that warm-up walked sample by sample (NTSCSIM_RAW28_EXACT; >= warm_lines: all)
     int follow_lanes = 16;         // chunks per wavefront of sweep 2 (NTSCSIM_RAW28_LANES: 1..64)
     size_t front_seg = FRONT_SEG;  // samples per front-end segment (NTSCSIM_RAW28_SEG: test hook, the segment loop on small captures)
     int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)

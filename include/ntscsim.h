@@ -661,7 +661,9 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * Environment (read by ntscsim_raw28_create, developer / test switches; results never depend on them):
  * NTSCSIM_RAW28_SEG = samples the front end takes per segment (default 2^29: 8 bytes of scratch per sample),
  * NTSCSIM_RAW28_CHUNKS = chunk count of its second sweep on long streams, NTSCSIM_RAW28_NOTAILSCAN = 1: comb
- * tails by rounds only. */
+ * tails by rounds only, NTSCSIM_RAW28_EXACT = scanlines at the end of the second sweep's warm-up that are walked sample
+ * by sample (default 30; the ones before are taken in closed form where that is known to be safe; >= 112: all),
+ * NTSCSIM_RAW28_LANES = chunks per wavefront of that sweep (default 16). */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
 void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */
