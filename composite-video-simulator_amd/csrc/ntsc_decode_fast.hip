@@ -32,6 +32,16 @@ namespace fastdec {
 // (the rand() ring, the pixel staging) also waits for the HBM round trip.  Frames are global
 // memory: say so, and the accesses become global_load / global_store (vmcnt only).
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+// Cache hints (round 4, tools/nt_probe.sh, profiles/r04_nt_probe.txt): the output rows leave as 64-byte halves of
+// 128-byte lines, 16 pixels per iteration; as plain stores the halves wait in the L2 for each other, crowd out the
+// composite samples the VCR's luma path re-reads 5 + d positions behind the chroma path, and a fifth of them is
+// written back twice.  As streaming (nt) stores: WRITE_SIZE of k_decode_fast 1.28 -> 1.05 x the output, FETCH_SIZE
+// -11 %, and -17 % with the re-read itself marked nt (its line is dead afterwards).
+#ifdef NTSC_PLAIN_OUT_STORES        /* A/B: the round-3 stores */
+#define NTSC_OUT_STORE(p, v) (*(p) = (v))
+#else
+#define NTSC_OUT_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 typedef __attribute__((address_space(1))) v4u *g_v4u_ptr;
 typedef __attribute__((address_space(1))) const v4u *g_cv4u_ptr;
 DEV v4u to_v4u(const uint4 &a) { return v4u{a.x, a.y, a.z, a.w}; }
@@ -377,7 +387,10 @@ struct Const {
 // (|shift| <= W/10) the displaced index is x + shift and one bounds-checked load does it.  With wrap it
 // is x + shift - tw from x = tw - shift on (shift > 0), x + shift + tw below x = -shift (shift < 0):
 // one sign test per load, as mask arithmetic on full-rate opcodes, moves the offset by -+ tw samples.
-template <class CT>
+#ifndef NTSC_COMP_LOAD2_AUX
+#define NTSC_COMP_LOAD2_AUX 2       /* nt on the VCR luma path's (second, trailing) read of every sample; 0 = plain (A/B) */
+#endif
+template <int AUX = 0, class CT>
 DEV int cs_load(const CT &C, int x)
 {
 #ifdef NTSC_AB_NOLOAD      // timing-only A/B build (WRONG pixels): no composite loads
@@ -385,7 +398,7 @@ DEV int cs_load(const CT &C, int x)
 #endif
     unsigned off = (unsigned)C.vbase + (unsigned)x * (unsigned)C.rowbytes;
     if constexpr (CT::wraps) off += (unsigned)((((C.wrapA - x) ^ C.wrapS) >> 31) & C.wrapoff);
-    return __builtin_amdgcn_raw_buffer_load_b32(C.comp, (int)off, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b32(C.comp, (int)off, 0, AUX);
 }
 
 // Masks built from per-lane / wave-uniform booleans are laundered through an empty asm so that the
@@ -703,7 +716,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
     constexpr int PD = 4;
     int pc[PD], pl[PD];
 #pragma unroll
-    for (int j = 0; j < PD; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load(C, t + j - LOFF) : 0; }
+    for (int j = 0; j < PD; j++) { pc[j] = cs_load(C, t + j); pl[j] = VHS ? cs_load<NTSC_COMP_LOAD2_AUX>(C, t + j - LOFF) : 0; }
     // (The VCR's luma path reads every composite sample a second time, LOFF = 5 + d positions behind the chroma path.
     //  Tried in round 4: an LDS ring of 20 + 3 slots that keeps each sample until the luma path wants it -- the second
     //  pass over the plane disappears from the L2's memory side, but the ring takes the workgroup from 14 to 20 KB of
@@ -736,7 +749,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
             const int r = 16 * k + (lane >> 2);                                                   \
             const unsigned long long rp = orow[r];                                                \
             const uint4 v = *reinterpret_cast<const uint4 *>(&ostage[r * 20 + (lane & 3) * 4]);   \
-            if (rp) *(g_v4u_ptr)(rp + 4ull * (unsigned)(pend_x + (lane & 3) * 4)) = to_v4u(v);    \
+            if (rp) NTSC_OUT_STORE((g_v4u_ptr)(rp + 4ull * (unsigned)(pend_x + (lane & 3) * 4)), to_v4u(v)); \
         }                                                                                         \
         pend_x = -1;                                                                              \
     }
@@ -759,7 +772,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
         int nc[4] = {0, 0, 0, 0}, nl[4] = {0, 0, 0, 0};
         if (PFTOP) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = VHS ? cs_load(C, t + 4 + j - LOFF) : 0; }
+            for (int j = 0; j < 4; j++) { nc[j] = cs_load(C, t + 4 + j); nl[j] = VHS ? cs_load<NTSC_COMP_LOAD2_AUX>(C, t + 4 + j - LOFF) : 0; }
         }
         T.rb = ring + sbase * 64 + lane;
         T.rb0 = sbase == 0;
@@ -768,7 +781,7 @@ DEV int steady(const DevParams &P, State<VHS, RT> &S, const CT &C, uint32_t *rin
         o[J] = step<VHS, DPH, J, RT, CT>(P, S, T, C, pc[J % PD], pl[J % PD]);                     \
         if (!PFTOP) {                                                                             \
             pc[J % PD] = cs_load(C, t + PD + J);                                                  \
-            if (VHS) pl[J % PD] = cs_load(C, t + PD + J - LOFF);                                  \
+            if (VHS) pl[J % PD] = cs_load<NTSC_COMP_LOAD2_AUX>(C, t + PD + J - LOFF);                                  \
         }                                                                                         \
         NTSC_STEP_SCHED_BARRIER();
         NTSC_FAST_STEP(0)
@@ -1155,13 +1168,13 @@ __global__ __launch_bounds__(64, NTSC_FRONT_WAVES) void k_vcr_front(DevParams P,
             int sbase = S.rng.pos;
             int pc[4], pl[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = cs_load(C, t + j - LOFF); }
+            for (int j = 0; j < 4; j++) { pc[j] = cs_load(C, t + j); pl[j] = cs_load<NTSC_COMP_LOAD2_AUX>(C, t + j - LOFF); }
             unsigned soff = (unsigned)(t - SK1) * rb;
 #define NTSC_VCR_STEP(DPV, J)                                                                     \
             {                                                                                     \
                 const int c2 = vcr_step<DPV, J, RT, CT>(P, S, T, C, pc[J], pl[J], yv_, uv_, vv_); \
                 pc[J] = cs_load(C, t + 4 + J);        /* reloaded right after its step consumed it */ \
-                pl[J] = cs_load(C, t + 4 + J - LOFF);                                             \
+                pl[J] = cs_load<NTSC_COMP_LOAD2_AUX>(C, t + 4 + J - LOFF);                                             \
                 __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
                 soff += rb;                                                                       \
                 NTSC_STEP_SCHED_BARRIER();                                                        \

@@ -16,6 +16,18 @@
 // amplitude 50, even scanline phase, 16-byte aligned source rows, composite plane below 4 GiB.
 #pragma clang fp contract(off)
 
+// Cache hints (round 4, tools/nt_probe.sh): the composite plane is written here and read back by another kernel long
+// after the L2 has forgotten it, so its stores are streaming (nt) ones -- they no longer push the source rows of the
+// cooperative loader out of the L2 before their second half is read (FETCH_SIZE of this kernel -12 %).
+#ifndef NTSC_COMP_STORE_AUX
+#define NTSC_COMP_STORE_AUX 2      /* 0 = plain stores (A/B) */
+#endif
+#ifdef NTSC_ENC_LOAD_NT            /* A/B: streaming loads of the source pixels -- measured WORSE (fetch x 2, kernel 0.26 -> 0.33 ms):
+                                      each 128-byte source line is read as two 64-byte halves a chunk apart */
+#define NTSC_ENC_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define NTSC_ENC_LOAD(p) (*(p))
+#endif
 namespace ntscsim {
 namespace fastenc {
 
@@ -124,7 +136,7 @@ DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint3
     if (PRE) Y = preemphasis<RT>(S, C, Y);
     Y += S.noise;
     S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
-    __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)((unsigned)x * (unsigned)C.rowbytes), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)((unsigned)x * (unsigned)C.rowbytes), NTSC_COMP_STORE_AUX);
 }
 
 DEV void load_chunk(const uint8_t *srow, int t0, uint32_t (&px)[16])
@@ -167,7 +179,7 @@ struct CoopLoader {
     DEV void request(int t0, fastdec::v4u (&q)[4]) const
     {
 #pragma unroll
-        for (int i = 0; i < 4; i++) q[i] = *(fastdec::g_cv4u_ptr)(ptr[i] + 4 * (size_t)t0);
+        for (int i = 0; i < 4; i++) q[i] = NTSC_ENC_LOAD((fastdec::g_cv4u_ptr)(ptr[i] + 4 * (size_t)t0));
     }
     // pieces -> tile -> this lane's 16 pixels
     DEV void deliver(const fastdec::v4u (&q)[4], uint32_t (&px)[16]) const
@@ -274,7 +286,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
                 const int Y = step<J, RT, PRE, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]);          \
-                __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
+                __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, NTSC_COMP_STORE_AUX);          \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
             NTSC_ENC_STEP(0, Y0, I0)
