@@ -107,6 +107,13 @@ struct RowWriter {
 // ones that the L2 has often evicted before the rest of their line arrives (measured: 2.4x the bytes
 // written).  NB = words per store instruction (4: rows aligned to 16 bytes, 2: to 8); NW = words per burst
 // (16: 64 bytes, 8: 32 bytes).  Aligned rows only.
+#ifdef NTSC_422_NT_STORES          /* A/B: streaming stores of the finished bursts -- measured WORSE here (profiles/r04_nt_probe.txt:
+                                      0.647 -> 0.660 ms per step, WRITE_SIZE + 42 %: the bursts are 64-byte halves of lines whose other half
+                                      follows a chunk later, and the rows are rewritten in place) */
+#define NTSC_422_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define NTSC_422_STORE(p, v) (*(p) = (v))
+#endif
 template <int NB, int NW>
 struct BurstWriter {
     typedef uint32_t vec __attribute__((ext_vector_type(NB)));
@@ -131,7 +138,7 @@ struct BurstWriter {
 #pragma unroll
             for (int i = 0; i < NW / NB; i++) t[i] = sp[i];
 #pragma unroll
-            for (int i = 0; i < NW / NB; i++) dp[i] = t[i];
+            for (int i = 0; i < NW / NB; i++) NTSC_422_STORE(dp + i, t[i]);
         }
     }
     DEV void finish(int n)        // n bytes were put: flush the incomplete burst
