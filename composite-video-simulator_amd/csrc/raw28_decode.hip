@@ -68,6 +68,7 @@ typedef double lvpair __attribute__((ext_vector_type(2)));     // lv of two cons
 struct FrontConst {
     double alpha, a_fast, om_fast, a_slow, om_slow;   // a, 1.0 - a of the two follower rates (:563-570)
     double om_slow_sb;                                // om_slow ^ FOLLOW_SB: the cheap part of sweep 2's warm-up
+    double slow_margin;                               // more than FOLLOW_SB slow steps can lift the level: 1.1 * 64 * a_slow * 255
     int thr;
 };
 
@@ -286,7 +287,7 @@ __device__ __forceinline__ void slow_block(double &level, const lvpair (&src)[FO
 // That knowledge: sweep 1's record of the 64-sample superblock around the block holds the smallest lv in it; a level
 // more than 0.0625 below it stays below every lv of the block (16 slow steps lift it by less than 16 a_slow 255 =
 // 0.015), so `hsync_dc_level > lv` :563 is false 16 times.  Taken by a wavefront only if it holds for all its lanes.
-__device__ __forceinline__ bool block_is_slow(double level, const lvpair &rec) { return level + 0.0625 < rec.x; }
+__device__ __forceinline__ bool block_is_slow(double level, const lvpair &rec, const FrontConst &K) { return level + K.slow_margin < rec.x; }
 
 // Sweep 2.  One wavefront = 64 consecutive chunks.  With Kw = ceil(warm / m) and r0 = Kw m - warm, lane c
 // starts at row r0 of column c - Kw and walks to the end of column c - 1 (its warm-up, `warm` samples), then
@@ -296,7 +297,7 @@ __device__ __forceinline__ bool block_is_slow(double level, const lvpair &rec) {
 //
 // The warm-up only has to produce a GUESS of the level before the chunk (the link check is what makes the result
 // exact), so its first `cheap` samples (round 4) are not walked sample by sample: where the level is below every
-// lv of a 64-sample superblock by more than the slow branch can lift it in 64 steps (0.0625 > 64 a_slow 255), all 64
+// lv of a 64-sample superblock by more than the slow branch can lift it in 64 steps (K.slow_margin > 64 a_slow 255), all 64
 // steps take the slow branch, and they amount to level = om_slow^64 level + B with the B sweep 1 left in SUM -- one
 // fused multiply-add and 16 bytes instead of 448 instructions and 512 bytes.  That holds for ~94 % of the superblocks
 // (everything but the sync tips); the others are walked exactly.  The closed form differs from 64 rounded steps by a
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
                     const lvpair S = Snext;
                     Snext = sums[j + 1 < FOLLOW_SG ? j + 1 : j][lane];       // (the LDS read is off the level's chain)
                     const bool waiting = cc + k < 0;
-                    if (__all(waiting || block_is_slow(level, S))) {
+                    if (__all(waiting || block_is_slow(level, S, K))) {
                         if (!waiting) level = __builtin_fma(level, K.om_slow_sb, S.y);
                     } else {
                         walked++;
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
         };
         auto use = [&](const lvpair (&src)[HB], const lvpair &rec) {
             const bool act = cc + k >= 0;
-            if (have_sum && __all(!act || block_is_slow(level, rec))) {
+            if (have_sum && __all(!act || block_is_slow(level, rec, K))) {
                 if (act) slow_block<false>(level, src, K, o);
             } else if (act) follow_block<false>(level, src, K, o);
             row += FOLLOW_BLK;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
         auto use = [&](const lvpair (&src)[HB], const lvpair &rec, int blk) {
             // (a record exists for whole superblocks only: the last, cut one of the stream has none)
             const bool act = blk < nbf && !done;
-            const bool slow = have_sum && __all(!act || ((blk | (FOLLOW_SB / FOLLOW_BLK - 1)) < nbf && block_is_slow(level, rec)));
+            const bool slow = have_sum && __all(!act || ((blk | (FOLLOW_SB / FOLLOW_BLK - 1)) < nbf && block_is_slow(level, rec, K)));
             if (act) {
                 o[0] = o[1] = o[2] = o[3] = 0;
                 if (slow) slow_block<true>(level, src, K, o);
@@ -993,6 +994,7 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.a_slow = 1.0 / (d->one_frame_time * 0.6);                                // :568
     d->K.om_slow = 1.0 - d->K.a_slow;
     d->K.om_slow_sb = std::pow(d->K.om_slow, (double)FOLLOW_SB);
+    d->K.slow_margin = 1.1 * (double)FOLLOW_SB * d->K.a_slow * 255.0;            // (0.0626 at 8 x fsc)
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOTAILSCAN")) d->tail_scan = std::atoi(e) == 0;
@@ -1204,11 +1206,13 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         const int lpw = have_sum ? d->follow_lanes : 64;
         const unsigned fw_blocks = (unsigned)((nchunks + lpw - 1) / lpw);
         const size_t pin = !d->front_pin ? 0 : fw_blocks <= 256 ? FOLLOW_PIN_LDS : fw_blocks <= 1024 ? 20 * 1024 : 0;
+        auto launch_follow = [&](size_t lds, const double *prev, const int *fl) {
+            hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), lds, st, (const lvpair *)d->lvplane.p, (const lvpair *)SUM,
+                               a0, o1, m, warm, cheap, nchunks, d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p,
+                               d->lv_end.p, d->ckpt.p, ncp, prev, fl, lpw);
+        };
         if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_follow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
-        hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), pin, st, (const lvpair *)d->lvplane.p, (const lvpair *)SUM, a0, o1, m, warm,
-                           cheap, nchunks,
-                           d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p, d->lv_end.p, d->ckpt.p, ncp,
-                           (const double *)nullptr, (const int *)nullptr, lpw);
+        launch_follow(pin, (const double *)nullptr, (const int *)nullptr);
         for (;;) {
             R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_raw28_links1, dim3((nchunks + 255) / 256), dim3(256), 0, st, (const double *)d->lv_begin.p,
@@ -1218,10 +1222,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
             if (nbad == 0) break;
             d->stats[0]++; d->stats[1] += nbad;
             R28CHK(d, hipMemcpyAsync(d->lv_prev.p, d->lv_end.p, (size_t)nchunks * sizeof(double), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_raw28_follow, dim3(fw_blocks), dim3(64), 0, st, (const lvpair *)d->lvplane.p, (const lvpair *)SUM, a0, o1, m, warm,
-                               cheap, nchunks,
-                               d->K, (const FrontState *)d->st_a0.p, d->h.p, d->lv_begin.p, d->lv_end.p, d->ckpt.p, ncp,
-                               (const double *)d->lv_prev.p, (const int *)d->flags.p, lpw);
+            launch_follow(0, (const double *)d->lv_prev.p, (const int *)d->flags.p);
         }
         // the exact state after the last sample: where the next segment / push starts
         FrontState fin;
