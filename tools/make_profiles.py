@@ -106,9 +106,12 @@ traffic = {"720x486 -vhs": {
     "note": "rocprofv3 --pmc, separate passes (tools/pmc.sh), bench.py --inflight 1; raw FETCH_SIZE / WRITE_SIZE in "
             "KiB, bytes = counter x the factor measured for the kernel's access shape (a 4 B/lane streaming read is "
             "reported at half its bytes like the guide's 16 B/lane one; four-lanes-per-row 64-byte pieces at 1 / %.3f; "
-            "writes at face value).  k_decode's fetch is about twice its 420 MB composite plane: the VCR's luma path "
-            "re-reads every sample 5 + d positions behind the chroma path, and that second read misses the L2 "
-            "(an LDS ring that removes it was built and measured slower, csrc/ntsc_decode_fast.hip steady())" % f_enc_rd,
+            "writes at face value).  k_decode's fetch is more than its 420 MB composite plane because the VCR's luma path "
+            "re-reads every sample 5 + d positions behind the chroma path and part of those reads miss the L2: all of "
+            "them with plain stores of the output pixels (2.0 planes, round 3), about two thirds since the output and "
+            "the composite plane are written with streaming stores and the re-read is marked nt "
+            "(profiles/r04_nt_probe.txt; an LDS ring that removes the re-read was built and measured slower, "
+            "csrc/ntsc_decode_fast.hip steady())" % f_enc_rd,
 }}
 tc = None
 if tocomp and os.path.exists(tocomp[0]) and os.path.getsize(tocomp[0]) > 10:
