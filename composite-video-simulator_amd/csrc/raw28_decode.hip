@@ -231,7 +231,9 @@ __device__ __forceinline__ uint32_t dc_byte(double lv, double level)
 }
 
 constexpr size_t FRONT_SEG = (size_t)1 << 29;     // samples per front-end segment (4 GiB of plane)
-constexpr int LP_WARM = 2048;                      // sweep 1's warm-up: 0.942^t t^2 is below an ulp after ~900 samples
+constexpr int LP_WARM = 2048;                      // sweep 1's warm-up: 0.942^t t^2 is below an ulp after ~900 samples (measured, round 4:
+                                                   // 1280 / 1024 leave every link intact too and the sweep at 0.77 / 0.82 instead of 0.83 ms -- it is
+                                                   // bound by the 2.3 GB of plane it writes, not by the walk; 896 needs a repair round)
 #ifndef RAW28_FOLLOW_FORM
 #define RAW28_FOLLOW_FORM 0       /* measured on the 600-field capture: form 0 7.1 ms, 1 7.6 ms, 2 7.8 ms (whole front end) */
 #endif
@@ -698,6 +700,11 @@ __global__ void k_raw28_tails_scan(const uint8_t *__restrict__ raw, const uint8_
     }
 }
 
+#ifdef RAW28_PLAIN_FRAME_STORES    /* A/B: the round-3 stores */
+#define RAW28_FRAME_STORE(p, v) (*(p) = (v))
+#else                              /* the frames are written once and not read again here: streaming stores */
+#define RAW28_FRAME_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#endif
 __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
                                                       const LineRec *__restrict__ lines, RenderConst R,
                                                       const int *__restrict__ tails, uint8_t *__restrict__ frames,
@@ -771,7 +778,7 @@ __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict_
             Y = R.show_sc ? 128 : S[x];            // past the comb's range: luma as equalised, chroma 0
         }
         Y = Y < 0 ? 0 : (Y > 255 ? 255 : Y);
-        dst[x] = (uint32_t)Y * 0x010101u;          // RGBTRIPLET :366, alpha 0
+        RAW28_FRAME_STORE(dst + x, (uint32_t)Y * 0x010101u);       // RGBTRIPLET :366, alpha 0
     }
 }
 
