@@ -14,5 +14,7 @@ echo '$ python tools/fuzz_catv.py 7000 700           # the pre-emphasis family (
 timeout 900 python tools/fuzz_catv.py 7000 700 2>&1 | grep -v amdgpu.ids | tail -4
 echo '$ python tools/fuzz_catv.py 8000 700 svideo    # the S-Video family (k_decode_fast_sv)'
 timeout 900 python tools/fuzz_catv.py 8000 700 svideo 2>&1 | grep -v amdgpu.ids | tail -4
+echo '$ python tools/fuzz_raw28.py 9000 600       # raw-composite decoder: random captures / switch sets / streams / speculation settings (exact part of the warm-up, chunks per wavefront)'
+timeout 900 python tools/fuzz_raw28.py 9000 600 2>&1 | grep -v amdgpu.ids | tail -3
 } > $O 2>&1
 cat $O

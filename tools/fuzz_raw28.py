@@ -1,6 +1,6 @@
 """Developer tool (GPU box): the raw-composite decoder against its oracle on seeded random captures
-(fields, noise level, starting sample, truncation) and random switch sets, speculation settings, front-end segment
-sizes and -- a third of the time -- as a stream pushed in random pieces:  python tools/fuzz_raw28.py 0 100"""
+(fields, noise level, starting sample, truncation) and random switch sets, speculation settings (warm-up, chunk length, exact
+part of the warm-up, chunks per wavefront), front-end segment sizes and -- a third of the time -- as a stream pushed in random pieces:  python tools/fuzz_raw28.py 0 100"""
 import os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "composite-video-simulator_amd"))
@@ -23,6 +23,12 @@ for seed in range(s0, s0 + n):
         os.environ["NTSCSIM_RAW28_SEG"] = str(r.choice([4096, 65537, 300001, 1000003]))
     else:
         os.environ.pop("NTSCSIM_RAW28_SEG", None)
+    for var, choices in (("NTSCSIM_RAW28_EXACT", [None, None, 0, 2, 12, 1000]), ("NTSCSIM_RAW28_LANES", [None, None, 5, 64])):
+        v = r.choice(choices)              # round 4: how much of the follower's warm-up is exact, chunks per wavefront
+        if v is None:
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = str(v)
     dec = ntscsim.Raw28Decoder(flags)
     if r.random() < 0.3:
         dec.set_speculation(r.choice([0, 8, 40]), r.choice([1024, 8192, 65536]))
