@@ -39,7 +39,7 @@ int main(int argc,char**argv){
     double L=255.0; long s=s0; long cheap_end=(s0*SB+(long)CL*LEN)/SB;
     for(;s<cheap_end;s++){
       if(L+margin<bmin[s]){L=fma(L,omSB,B[s]);tot_ok++;}
-      else{tot_non++;for(int j=0;j<SB;j++){double x=lv[s*SB+j]; if(L>x)L=(L*(1.0-aF))+(x*aF); else L=(L*(1.0-aS))+(x*aS);}}
+      else{tot_non++;for(int j=0;j<SB;j++){double x=lv[s*SB+j]; double dl=x-L; L=fma(dl,(dl<0?aF:aS),L);}}   /* the kernel's guess_block: one fma per step */
     }
     long i=s*SB; double err=fabs(L-tr[i-1]);
     if(CL==100 && err>worst_err)worst_err=err;

@@ -4,8 +4,7 @@
 cd "$(dirname "$0")/.."
 run() { echo "# $*"; env "$@" python tools/raw28_probe.py 2>&1 | tail -1 | cut -c1-330; }
 run NTSCSIM_RAW28_EXACT=1000 NTSCSIM_RAW28_LANES=64
-run NTSCSIM_RAW28_EXACT=20 NTSCSIM_RAW28_LANES=64
-for l in 32 16 12 10; do run NTSCSIM_RAW28_EXACT=20 NTSCSIM_RAW28_LANES=$l; done
-for e in 12 16 24 30; do run NTSCSIM_RAW28_EXACT=$e NTSCSIM_RAW28_LANES=16; done
+for l in 64 32 16 12; do run NTSCSIM_RAW28_LANES=$l; done
+for e in 12 16 20 24 30 36; do run NTSCSIM_RAW28_EXACT=$e; done
 echo "# chunks that are NOT a whole number of scanlines (forced 17472 samples): the walk falls back to exact steps"
 python tools/raw28_probe.py 112 17472 2>&1 | tail -1 | cut -c1-330
