@@ -908,6 +908,8 @@ struct ntscsim_raw28 {
     Buf<CalRange> cal_rg;
     Buf<CalSums> cal_out;
     Buf<LineRec> lines;
+    hipEvent_t ev_cal = nullptr;   // behind the calibration sums' way back: the host goes on while the frames are being cleared
+    ~ntscsim_raw28() { if (ev_cal) (void)hipEventDestroy(ev_cal); }
 };
 
 #define R28CHK(d, call)                                                                    \
@@ -1388,6 +1390,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
     lap(8);
     // ---- (4) black / white levels :661-688: sums on the GPU, the eight-tap recurrence here
     std::vector<CalSums> sums(cal_zero.size(), CalSums{0, 0, 0, 0});
+    bool frames_cleared = false;
     if (!cal.empty()) {
         std::vector<CalSums> part(cal.size());
         R28CHK(d, d->cal_rg.ensure(cal.size()));
@@ -1396,7 +1399,15 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         hipLaunchKernelGGL(k_raw28_cal, dim3((unsigned)cal.size()), dim3(64), 0, st, raw, d->h.p, d->cal_rg.p,
                            d->cal_out.p, d->D, d->K.thr, d->o.mark_sync ? 1 : 0, (unsigned long long)d->base);
         R28CHK(d, hipMemcpyAsync(part.data(), d->cal_out.p, cal.size() * sizeof(CalSums), hipMemcpyDeviceToHost, st));
-        R28CHK(d, hipStreamSynchronize(st));
+        // the tool's memset before every composite_layer() :1016, all frames at once -- queued here, behind the sums, so
+        // that it runs while the host does the level recurrence below (0.15 ms for 600 frames)
+        if (!d->ev_cal) R28CHK(d, hipEventCreateWithFlags(&d->ev_cal, hipEventDisableTiming));
+        R28CHK(d, hipEventRecord(d->ev_cal, st));
+        if (nf > 0) {
+            R28CHK(d, hipMemset2DAsync(frames_dev, frame_stride, 0, (size_t)linesize * (size_t)d->height, (size_t)nf, st));
+            frames_cleared = true;
+        }
+        R28CHK(d, hipEventSynchronize(d->ev_cal));
         for (size_t k = 0; k < cal.size(); k++) {
             CalSums &t = sums[cal[k].pulse];
             t.mina += part[k].mina; t.mind += part[k].mind; t.maxa += part[k].maxa; t.maxd += part[k].maxd;
@@ -1423,7 +1434,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
 
     lap(9);
     // ---- (5) comb tails to their fixed point, then every scanline at once
-    if (nf > 0)                                    // the tool's memset before every composite_layer() :1016, all frames at once
+    if (nf > 0 && !frames_cleared)                 // the tool's memset before every composite_layer() :1016, all frames at once
         R28CHK(d, hipMemset2DAsync(frames_dev, frame_stride, 0, (size_t)linesize * (size_t)d->height, (size_t)nf, st));
     const int nlines = (int)lines.size();
     if (nlines > 0) {
