@@ -62,6 +62,23 @@ struct Buf {
     ~Buf() { if (p) (void)hipFree(p); }
 };
 
+// pinned host memory, grow-only (contents are not kept)
+template <class T>
+struct HostBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const hipError_t e = hipHostMalloc((void **)&p, n * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    ~HostBuf() { if (p) (void)hipHostFree(p); }
+};
+
 struct FrontState { double p0, p1, p2, level; };
 typedef double lvpair __attribute__((ext_vector_type(2)));     // lv of two consecutive samples
 
@@ -691,7 +708,10 @@ __global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__
 // predecessors within a few scanlines; a walk that reaches row -1 starts from the carried tail, exactly) and
 // then its own TAIL_B scanlines serially.  2.5 rounds' worth of work in one launch instead of ~16 rounds; the
 // rounds of k_raw28_tails that follow confirm it (a round that changes nothing) or finish the job.
-constexpr int TAIL_B = 16, TAIL_WU = 24;
+// (Round 4: 24 + 16 scanlines per thread became 8 + 4 -- the launch lasts as long as ONE thread's serial walk, 0.23 ms
+// whatever the number of scanlines, and it now runs once per group of fields behind the sync walk; an inherited value is
+// divided by 8 per scanline and truncated, so 8 scanlines of warm-up forget anything a tail can hold.)
+constexpr int TAIL_B = 4, TAIL_WU = 8;
 __global__ void k_raw28_tails_scan(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
                                    const LineRec *__restrict__ lines, int nlines, RenderConst R,
                                    const int *__restrict__ carried, int *__restrict__ ta, int *__restrict__ tb)
@@ -876,6 +896,8 @@ struct ntscsim_raw28 {
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
     int exact_lines = 30;          // the last scanlines of that warm-up walked sample by sample (NTSCSIM_RAW28_EXACT; >= warm_lines: all)
+    bool force_tail_rounds = false;    // NTSCSIM_RAW28_TAILROUNDS=1, test hook: take the path of a first guess that did not settle
+    int group_fields = 192;        // fields per group of the back half's pipeline (NTSCSIM_RAW28_GROUP: developer A/B switch)
     int follow_lanes = 16;         // chunks per wavefront of sweep 2 (NTSCSIM_RAW28_LANES: 1..64)
     size_t front_seg = FRONT_SEG;  // samples per front-end segment (NTSCSIM_RAW28_SEG: test hook, the segment loop on small captures)
     int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)
@@ -908,8 +930,12 @@ struct ntscsim_raw28 {
     Buf<CalRange> cal_rg;
     Buf<CalSums> cal_out;
     Buf<LineRec> lines;
-    hipEvent_t ev_cal = nullptr;   // behind the calibration sums' way back: the host goes on while the frames are being cleared
-    ~ntscsim_raw28() { if (ev_cal) (void)hipEventDestroy(ev_cal); }
+    hipEvent_t ev_cal = nullptr, ev_cal2 = nullptr;    // behind a group's calibration sums on their way back (two groups in flight)
+    HostBuf<LineRec> lines_h;      // pinned: what the walk writes and the copies read while it goes on
+    HostBuf<CalRange> cal_h;
+    HostBuf<CalSums> part_h;
+    Buf<int> gcount;               // per group of fields: scanlines whose comb tail the confirming round changed
+    ~ntscsim_raw28() { if (ev_cal) (void)hipEventDestroy(ev_cal); if (ev_cal2) (void)hipEventDestroy(ev_cal2); }
 };
 
 #define R28CHK(d, call)                                                                    \
@@ -1026,6 +1052,8 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     if (const char *e = std::getenv("NTSCSIM_RAW28_SEG")) { const long long v = std::atoll(e); if (v >= 4096) d->front_seg = (size_t)v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_CHUNKS")) { const int v = std::atoi(e); if (v >= 64) d->max_chunks = v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_EXACT")) { const int v = std::atoi(e); if (v >= 0) d->exact_lines = v; }
+    if (const char *e = std::getenv("NTSCSIM_RAW28_TAILROUNDS")) d->force_tail_rounds = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NTSCSIM_RAW28_GROUP")) { const int v = std::atoi(e); if (v >= 1) d->group_fields = v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) d->follow_lanes = v; }
     *out = d;
     return NTSCSIM_OK;
@@ -1292,18 +1320,150 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
     }
 
     lap(7);
-    // ---- (3) the walk: field loop main() :1006-1019 around composite_layer()'s searches
+    // ---- (3) the walk: field loop main() :1006-1019 around composite_layer()'s searches -- with (4) (5) and the rendering
+    // of the fields it has finished running on the GPU BEHIND it (round 4): the walk is 1.2 ms of strictly serial host
+    // work for 600 fields (7 ns per sync run) during which the GPU used to wait.  Every GROUP_FIELDS fields the
+    // calibration ranges of the group go out (k_raw28_cal, sums back through pinned memory, an event); a group later --
+    // the sums have long arrived -- the host does the group's level recurrence and queues its scanline records, the
+    // clearing of its frames, its comb tails (the serial first guess + ONE confirming round) and its rendering.  Whether
+    // every group's round did confirm is looked at once, at the end; if one did not (never seen), the tails are redone by
+    // rounds over all scanlines and everything is rendered again.
     RunWalk W;
     W.rs = rs.data(); W.re = re.data(); W.nruns = rs.size();
     const size_t CAP = (size_t)len * 2048;                                        // open_src :353
     const size_t L30 = (size_t)(int)(len * 0.3), L06 = (size_t)(int)(len * 0.06), L02 = (size_t)(int)(len * 0.02);
     size_t &Bw = d->Bw, &Rd = d->Rd, &Ew = d->Ew;   // buffer begin, read position, buffer end (relative to base)
     BufMap &bm = d->bm;
-    std::vector<LineRec> lines;
-    std::vector<CalRange> cal;                     // pieces of the calibration ranges, in pulse order
+    const int GROUP_FIELDS = d->group_fields;
+    RenderConst RC;
+    RC.len = (int)len; RC.width = d->width; RC.D = d->D; RC.thr = d->K.thr;
+    RC.mark = d->o.mark_sync ? 1 : 0; RC.no_equ = d->o.disable_equalization ? 1 : 0;
+    RC.no_wequ = d->o.disable_wp_equ ? 1 : 0; RC.no_sc = d->o.disable_subcarrier ? 1 : 0;
+    RC.show_sc = d->o.show_subcarrier ? 1 : 0;
+    RC.base = (unsigned long long)d->base;
+    const size_t render_lds = ((size_t)2 * (len + 16) + 256) * sizeof(int);
+    // capacities known before the walk (nothing may move while copies are in flight): a field advances the read position
+    // by at least 240 scanlines (:836-845) and holds at most `height` of them; every calibration range stems from a run
+    const size_t nf_cap = std::min<size_t>((size_t)max_fields, (N > Rd ? N - Rd : 0) / ((size_t)len * 240) + 2);
+    const size_t lines_cap = nf_cap * (size_t)d->height;
+    R28CHK(d, d->lines_h.ensure(lines_cap + 1));
+    R28CHK(d, d->lines.ensure(lines_cap + 1));
+    LineRec *const lines_h = d->lines_h.p;
+    size_t nlines = 0;
+    size_t cal_cap = 2 * rs.size() + 4096, ncal = 0;
+    R28CHK(d, d->cal_h.ensure(cal_cap));
+    R28CHK(d, d->part_h.ensure(cal_cap));
+    R28CHK(d, d->cal_rg.ensure(cal_cap));
+    R28CHK(d, d->cal_out.ensure(cal_cap));
     std::vector<int> cal_zero;                     // per pulse: never-filled records inside its range
     std::vector<int> cal_field;                    // number of pulses seen before each field is rendered
+    std::vector<CalSums> sums;                     // per pulse
+    const size_t max_groups = nf_cap / (size_t)GROUP_FIELDS + 2;
+    R28CHK(d, d->gcount.ensure(max_groups));
+    R28CHK(d, hipMemsetAsync(d->gcount.p, 0, max_groups * sizeof(int), st));
+    int *tails_a = nullptr, *tails_b = nullptr;    // row 0 = the tail carried in; row y + 1 = the tail of scanline y
+    if (!RC.no_sc && lines_cap > 0) {
+        const size_t trows = lines_cap + 1;
+        R28CHK(d, d->tails_a.ensure(trows * 16));
+        R28CHK(d, d->tails_b.ensure(trows * 16));
+        tails_a = d->tails_a.p; tails_b = d->tails_b.p;
+        R28CHK(d, hipMemsetAsync(tails_a, 0, trows * 16 * sizeof(int), st));
+        R28CHK(d, hipMemsetAsync(tails_b, 0, trows * 16 * sizeof(int), st));
+        R28CHK(d, hipMemcpyAsync(tails_a, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
+        R28CHK(d, hipMemcpyAsync(tails_b, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
+    }
+    if (!d->ev_cal) R28CHK(d, hipEventCreateWithFlags(&d->ev_cal, hipEventDisableTiming));
+    if (!d->ev_cal2) R28CHK(d, hipEventCreateWithFlags(&d->ev_cal2, hipEventDisableTiming));
+    struct Group { int idx, f0, f1; size_t l0, l1, c0, c1, p0, p1; };
+    Group grp{0, 0, 0, 0, 0, 0, 0, 0, 0}, pending{-1, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t ci_done = 0;                            // pulses the level recurrence has consumed
+    // a calibration range joins the list (the list grows only with nothing in flight)
+    auto cal_push = [&](const CalRange &r) -> int {
+        if (ncal == cal_cap) {
+            R28CHK(d, hipStreamSynchronize(st));
+            const size_t ncap = cal_cap * 2;
+            std::vector<CalRange> keep(d->cal_h.p, d->cal_h.p + ncal);
+            std::vector<CalSums> keepp(d->part_h.p, d->part_h.p + ncal);
+            R28CHK(d, d->cal_h.ensure(ncap));
+            R28CHK(d, d->part_h.ensure(ncap));
+            R28CHK(d, d->cal_rg.ensure(ncap));
+            R28CHK(d, d->cal_out.ensure(ncap));
+            std::memcpy(d->cal_h.p, keep.data(), ncal * sizeof(CalRange));
+            std::memcpy(d->part_h.p, keepp.data(), ncal * sizeof(CalSums));
+            cal_cap = ncap;
+        }
+        d->cal_h.p[ncal++] = r;
+        return NTSCSIM_OK;
+    };
+    // (4a) the sums of a group's calibration pulses :661-676 start on the GPU
+    auto submit_levels = [&](const Group &g) -> int {
+        if (g.c1 > g.c0) {
+            const size_t n = g.c1 - g.c0;
+            R28CHK(d, hipMemcpyAsync(d->cal_rg.p + g.c0, d->cal_h.p + g.c0, n * sizeof(CalRange), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_raw28_cal, dim3((unsigned)n), dim3(64), 0, st, raw, d->h.p, d->cal_rg.p + g.c0,
+                               d->cal_out.p + g.c0, d->D, d->K.thr, d->o.mark_sync ? 1 : 0, (unsigned long long)d->base);
+            R28CHK(d, hipMemcpyAsync(d->part_h.p + g.c0, d->cal_out.p + g.c0, n * sizeof(CalSums), hipMemcpyDeviceToHost, st));
+        }
+        R28CHK(d, hipEventRecord((g.idx & 1) ? d->ev_cal2 : d->ev_cal, st));
+        return NTSCSIM_OK;
+    };
+    // (4b) (5) the eight-tap level recurrence :683-688 of a group on the host, then everything else of it on the GPU
+    auto complete_group = [&](const Group &g) -> int {
+        R28CHK(d, hipEventSynchronize((g.idx & 1) ? d->ev_cal2 : d->ev_cal));
+        sums.resize(g.p1, CalSums{0, 0, 0, 0});
+        for (size_t k = g.c0; k < g.c1; k++) {
+            CalSums &t = sums[d->cal_h.p[k].pulse];
+            const CalSums &q = d->part_h.p[k];
+            t.mina += q.mina; t.mind += q.mind; t.maxa += q.maxa; t.maxd += q.maxd;
+        }
+        for (size_t k = g.p0; k < g.p1; k++) sums[k].mind += cal_zero[k];       // zero records: below threshold, raw 0
+        size_t li = g.l0;
+        for (int f = g.f0; f < g.f1; f++) {
+            for (; ci_done < (size_t)cal_field[(size_t)f]; ci_done++) {
+                int mina = sums[ci_done].mina, maxa = sums[ci_done].maxa;
+                if (sums[ci_done].mind > 0) mina /= sums[ci_done].mind;
+                if (sums[ci_done].maxd > 0) maxa /= sums[ci_done].maxd;
+                int t = (int)(maxa + ((maxa - mina) / (0.25 + 0.125)));
+                t = std::min(std::max(t, maxa + 1), 240);
+                const int nwhite = (uint8_t)t, nblack = maxa;
+                const double a = 1.0 / 8.0;
+                d->white = (d->white * (1.0 - a)) + (nwhite * a);
+                d->blank = (d->blank * (1.0 - a)) + (nblack * a);
+            }
+            for (; li < g.l1 && lines_h[li].field == f; li++) { lines_h[li].blank = d->blank; lines_h[li].white = d->white; }
+        }
+        // the tool's memset before every composite_layer() :1016, the group's frames at once
+        R28CHK(d, hipMemset2DAsync((uint8_t *)frames_dev + (size_t)g.f0 * frame_stride, frame_stride, 0,
+                                   (size_t)linesize * (size_t)d->height, (size_t)(g.f1 - g.f0), st));
+        const int nl = (int)(g.l1 - g.l0);
+        if (nl > 0) {
+            R28CHK(d, hipMemcpyAsync(d->lines.p + g.l0, lines_h + g.l0, (size_t)nl * sizeof(LineRec), hipMemcpyHostToDevice, st));
+            const int *tails = nullptr;
+            if (tails_a) {
+                // rows relative to the group: row -1 = the tail of the scanline before it (both arrays hold it once the
+                // group before has settled); the serial first guess writes both arrays, the round reads a and writes b
+                int *ta = tails_a + (g.l0 + 1) * 16, *tb = tails_b + (g.l0 + 1) * 16;
+                hipLaunchKernelGGL(k_raw28_tails_scan, dim3(((nl + TAIL_B - 1) / TAIL_B + 63) / 64), dim3(64), 0, st, raw, d->h.p, N,
+                                   d->lines.p + g.l0, nl, RC, (const int *)(tails_a + g.l0 * 16), ta, tb);
+                hipLaunchKernelGGL(k_raw28_tails, dim3((nl + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p + g.l0,
+                                   nl, RC, (const int *)ta, tb, d->gcount.p + g.idx);
+                tails = tb;
+            }
+            hipLaunchKernelGGL(k_raw28_render, dim3((unsigned)nl), dim3(256), render_lds, st, raw, d->h.p, N, d->lines.p + g.l0, RC,
+                               tails, (uint8_t *)frames_dev, frame_stride, linesize);
+        }
+        return NTSCSIM_OK;
+    };
     int nf = 0;
+    // the fields walked since the last group: their sums start now, the group before them is completed
+    auto close_group = [&]() -> int {
+        grp.f1 = nf; grp.l1 = nlines; grp.c1 = ncal; grp.p1 = cal_zero.size();
+        { const int rc = submit_levels(grp); if (rc != NTSCSIM_OK) return rc; }
+        if (pending.idx >= 0) { const int rc = complete_group(pending); if (rc != NTSCSIM_OK) return rc; }
+        pending = grp;
+        grp = Group{grp.idx + 1, nf, nf, nlines, nlines, ncal, ncal, cal_zero.size(), cal_zero.size()};
+        return NTSCSIM_OK;
+    };
     while (nf < max_fields) {
         // the tool blocks in read() until its buffer is full; here a field whose window is not complete yet
         // waits for the next push (nothing is changed before that is known)
@@ -1328,16 +1488,18 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
                 else if (synclen >= L02) {
                     i = si + L30; if (i < ei) i = ei; vsb++;
                     const uint32_t pulse = (uint32_t)cal_zero.size();
-                    cal.push_back(CalRange{(uint32_t)si, (uint32_t)std::min(i, E), pulse, 0});
+                    { const int rc = cal_push(CalRange{(uint32_t)si, (uint32_t)std::min(i, E), pulse, 0}); if (rc != NTSCSIM_OK) return rc; }
                     size_t zeros = 0;
+                    int lookup_rc = NTSCSIM_OK;
                     if (i > E) {                   // records past the buffered stream: what the array still holds
                         const size_t k1 = std::min(i - Bw, CAP);          // (past the array itself: undefined in the tool, zero here)
                         zeros = (i - Bw) - k1;
                         if (E - Bw < k1)
                             zeros += bm.lookup(E - Bw, k1, [&](size_t a, size_t b) {
-                                cal.push_back(CalRange{(uint32_t)a, (uint32_t)b, pulse, 0});
+                                if (lookup_rc == NTSCSIM_OK) lookup_rc = cal_push(CalRange{(uint32_t)a, (uint32_t)b, pulse, 0});
                             });
                     }
+                    if (lookup_rc != NTSCSIM_OK) return lookup_rc;
                     if (i > E) { d->stats[12]++; d->stats[13] += (int64_t)zeros; }
                     cal_zero.push_back((int)zeros);
                 }
@@ -1349,7 +1511,8 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         for (unsigned y = 0; y < (unsigned)d->height && (scan + (size_t)len * 2) < E; y++) {      // :700
             LineRec L;
             L.pos = (uint32_t)scan; L.field = nf; L.row = (int)y; L.blank = 0; L.white = 0;
-            lines.push_back(L);
+            if (nlines == lines_cap) { d->err = "sync walk: more scanlines than the stream can hold"; return NTSCSIM_E_INTERNAL; }
+            lines_h[nlines++] = L;
             scan += len;                            // :777-787 (one_scanline_width is integral: err stays 0)
             if (scan > E) scan = E;
             if (!d->o.disable_sync) {              // :789-830
@@ -1379,116 +1542,59 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
             if (Rd < should) Rd = should;
         }
         nf++;
+        if (nf - grp.f0 >= GROUP_FIELDS) {         // a group of fields is complete: its GPU work starts while the walk goes on
+            const int rc = close_group();
+            if (rc != NTSCSIM_OK) return rc;
+        }
     }
     d->read_pos = d->base + Rd;
     d->stats[15] = (int64_t)std::max<size_t>((size_t)d->stats[15], N);      // most samples ever held at once
-    d->stats[4] += (int64_t)lines.size();
+    d->stats[4] += (int64_t)nlines;
     d->stats[5] += (int64_t)cal_zero.size();
     d->fields_total += (uint64_t)nf;
     *n_fields = nf;
 
     lap(8);
-    // ---- (4) black / white levels :661-688: sums on the GPU, the eight-tap recurrence here
-    std::vector<CalSums> sums(cal_zero.size(), CalSums{0, 0, 0, 0});
-    bool frames_cleared = false;
-    if (!cal.empty()) {
-        std::vector<CalSums> part(cal.size());
-        R28CHK(d, d->cal_rg.ensure(cal.size()));
-        R28CHK(d, d->cal_out.ensure(cal.size()));
-        R28CHK(d, hipMemcpyAsync(d->cal_rg.p, cal.data(), cal.size() * sizeof(CalRange), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_raw28_cal, dim3((unsigned)cal.size()), dim3(64), 0, st, raw, d->h.p, d->cal_rg.p,
-                           d->cal_out.p, d->D, d->K.thr, d->o.mark_sync ? 1 : 0, (unsigned long long)d->base);
-        R28CHK(d, hipMemcpyAsync(part.data(), d->cal_out.p, cal.size() * sizeof(CalSums), hipMemcpyDeviceToHost, st));
-        // the tool's memset before every composite_layer() :1016, all frames at once -- queued here, behind the sums, so
-        // that it runs while the host does the level recurrence below (0.15 ms for 600 frames)
-        if (!d->ev_cal) R28CHK(d, hipEventCreateWithFlags(&d->ev_cal, hipEventDisableTiming));
-        R28CHK(d, hipEventRecord(d->ev_cal, st));
-        if (nf > 0) {
-            R28CHK(d, hipMemset2DAsync(frames_dev, frame_stride, 0, (size_t)linesize * (size_t)d->height, (size_t)nf, st));
-            frames_cleared = true;
-        }
-        R28CHK(d, hipEventSynchronize(d->ev_cal));
-        for (size_t k = 0; k < cal.size(); k++) {
-            CalSums &t = sums[cal[k].pulse];
-            t.mina += part[k].mina; t.mind += part[k].mind; t.maxa += part[k].maxa; t.maxd += part[k].maxd;
-        }
-    }
-    for (size_t k = 0; k < cal_zero.size(); k++) sums[k].mind += cal_zero[k];   // zero records: below threshold, raw 0
-    {
-        size_t ci = 0, li = 0;
-        for (int f = 0; f < nf; f++) {
-            for (; ci < (size_t)cal_field[(size_t)f]; ci++) {
-                int mina = sums[ci].mina, maxa = sums[ci].maxa;
-                if (sums[ci].mind > 0) mina /= sums[ci].mind;
-                if (sums[ci].maxd > 0) maxa /= sums[ci].maxd;
-                int t = (int)(maxa + ((maxa - mina) / (0.25 + 0.125)));
-                t = std::min(std::max(t, maxa + 1), 240);
-                const int nwhite = (uint8_t)t, nblack = maxa;
-                const double a = 1.0 / 8.0;
-                d->white = (d->white * (1.0 - a)) + (nwhite * a);
-                d->blank = (d->blank * (1.0 - a)) + (nblack * a);
-            }
-            for (; li < lines.size() && lines[li].field == f; li++) { lines[li].blank = d->blank; lines[li].white = d->white; }
-        }
-    }
-
+    // ---- (4) (5) what the walk has left: the last, incomplete group and the one before it
+    if (nf > grp.f0) { const int rc = close_group(); if (rc != NTSCSIM_OK) return rc; }
+    if (pending.idx >= 0) { const int rc = complete_group(pending); if (rc != NTSCSIM_OK) return rc; }
+    const int ngroups = grp.idx;
     lap(9);
-    // ---- (5) comb tails to their fixed point, then every scanline at once
-    if (nf > 0 && !frames_cleared)                 // the tool's memset before every composite_layer() :1016, all frames at once
-        R28CHK(d, hipMemset2DAsync(frames_dev, frame_stride, 0, (size_t)linesize * (size_t)d->height, (size_t)nf, st));
-    const int nlines = (int)lines.size();
-    if (nlines > 0) {
-        RenderConst RC;
-        RC.len = (int)len; RC.width = d->width; RC.D = d->D; RC.thr = d->K.thr;
-        RC.mark = d->o.mark_sync ? 1 : 0; RC.no_equ = d->o.disable_equalization ? 1 : 0;
-        RC.no_wequ = d->o.disable_wp_equ ? 1 : 0; RC.no_sc = d->o.disable_subcarrier ? 1 : 0;
-        RC.show_sc = d->o.show_subcarrier ? 1 : 0;
-        RC.base = (unsigned long long)d->base;
-        R28CHK(d, d->lines.ensure((size_t)nlines));
-        R28CHK(d, hipMemcpyAsync(d->lines.p, lines.data(), (size_t)nlines * sizeof(LineRec), hipMemcpyHostToDevice, st));
-        int *tails = nullptr;
-        if (!RC.no_sc) {
-            // row 0 of both arrays = the tail of the last scanline of the previous push (zeros at a stream's
-            // start); the kernels see the arrays from row 1 on and read row y - 1
-            const size_t trows = (size_t)nlines + 1;
-            R28CHK(d, d->tails_a.ensure(trows * 16));
-            R28CHK(d, d->tails_b.ensure(trows * 16));
-            R28CHK(d, hipMemsetAsync(d->tails_a.p, 0, trows * 16 * sizeof(int), st));
-            R28CHK(d, hipMemsetAsync(d->tails_b.p, 0, trows * 16 * sizeof(int), st));
-            R28CHK(d, hipMemcpyAsync(d->tails_a.p, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
-            R28CHK(d, hipMemcpyAsync(d->tails_b.p, d->tail_carry, sizeof(d->tail_carry), hipMemcpyHostToDevice, st));
-            int *tin = d->tails_a.p + 16, *tout = d->tails_b.p + 16;
-            if (d->tail_scan)
-                hipLaunchKernelGGL(k_raw28_tails_scan, dim3(((nlines + TAIL_B - 1) / TAIL_B + 63) / 64), dim3(64), 0, st, raw, d->h.p, N,
-                                   d->lines.p, nlines, RC, (const int *)d->tails_a.p, tin, tout);
+    if (nlines > 0 && tails_a) {
+        // did every group's round confirm its first guess?  (b holds the rounds' results, a the guesses)
+        std::vector<int> nch((size_t)ngroups, 0);
+        R28CHK(d, hipMemcpyAsync(nch.data(), d->gcount.p, (size_t)ngroups * sizeof(int), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipMemcpyAsync(d->tail_carry, tails_b + nlines * 16, sizeof(d->tail_carry), hipMemcpyDeviceToHost, st));
+        R28CHK(d, hipStreamSynchronize(st));
+        d->stats[2]++;
+        bool settled = true;
+        for (int v : nch) settled = settled && v == 0;
+        if (d->force_tail_rounds) settled = false;             // (test hook: the rounds over all scanlines + a second rendering)
+        lap(10);
+        if (!settled) {
+            // round r: tout(y) = G(samples of y, tin(y-1)); it ends when tout == tin everywhere, i.e. tail(y) =
+            // G(y, tail(y-1)) for every y with tail(-1) = the carried tail: the serial result.  From the guesses in a.
+            const int nl = (int)nlines;
+            int *tin = tails_a + 16, *tout = tails_b + 16;
             for (int round = 0;;) {
-                // round r: tout(y) = G(samples of y, tin(y-1)); it ends when tout == tin everywhere, i.e.
-                // tail(y) = G(y, tail(y-1)) for every y with tail(-1) = the carried tail: the serial result.
-                // Four rounds are enqueued between two looks at the counter of the last one.
-                const int batch = (round == 0 && d->tail_scan) ? 1 : 4;      // (after the scan one round usually confirms)
-                for (int b4 = 0; b4 < batch; b4++, round++) {
+                for (int b4 = 0; b4 < 4; b4++, round++) {
                     R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
-                    hipLaunchKernelGGL(k_raw28_tails, dim3((nlines + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
-                                       nlines, RC, (const int *)tin, tout, d->counters.p);
+                    hipLaunchKernelGGL(k_raw28_tails, dim3((nl + 127) / 128), dim3(128), 0, st, raw, d->h.p, N, d->lines.p,
+                                       nl, RC, (const int *)tin, tout, d->counters.p);
                     d->stats[2]++;
                     std::swap(tin, tout);
                 }
-                int nch = 0;
-                R28CHK(d, hipMemcpyAsync(&nch, d->counters.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                int left = 0;
+                R28CHK(d, hipMemcpyAsync(&left, d->counters.p, sizeof(int), hipMemcpyDeviceToHost, st));
                 R28CHK(d, hipStreamSynchronize(st));
-                if (nch == 0) break;
-                if (round > nlines + 8) { d->err = "comb tails did not settle"; return NTSCSIM_E_INTERNAL; }
+                if (left == 0) break;
+                if (round > nl + 8) { d->err = "comb tails did not settle"; return NTSCSIM_E_INTERNAL; }
             }
-            // both arrays now hold the fixed point
-            tails = tin;
-            R28CHK(d, hipMemcpyAsync(d->tail_carry, tin + (size_t)(nlines - 1) * 16, sizeof(d->tail_carry), hipMemcpyDeviceToHost, st));
+            R28CHK(d, hipMemcpyAsync(d->tail_carry, tin + (size_t)(nl - 1) * 16, sizeof(d->tail_carry), hipMemcpyDeviceToHost, st));
+            hipLaunchKernelGGL(k_raw28_render, dim3((unsigned)nl), dim3(256), render_lds, st, raw, d->h.p, N, d->lines.p, RC,
+                               (const int *)tin, (uint8_t *)frames_dev, frame_stride, linesize);
         }
-        R28CHK(d, hipStreamSynchronize(st));
-        lap(10);
-        const size_t lds = ((size_t)2 * (len + 16) + 256) * sizeof(int);
-        hipLaunchKernelGGL(k_raw28_render, dim3((unsigned)nlines), dim3(256), lds, st, raw, d->h.p, N, d->lines.p, RC,
-                           (const int *)tails, (uint8_t *)frames_dev, frame_stride, linesize);
-    }
+    } else lap(10);
     R28CHK(d, hipGetLastError());
     R28CHK(d, hipStreamSynchronize(st));
     lap(11);

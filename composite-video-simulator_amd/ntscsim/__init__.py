@@ -509,7 +509,7 @@ class Raw28Decoder:
         a = (C.c_int64 * 16)()
         self._lib.ntscsim_raw28_debug_stats(self._h, a)
         return dict(zip(("front_rounds", "chunks_repaired", "tail_rounds", "sync_runs", "scanlines", "cal_pulses",
-                         "us_front", "us_runs", "us_walk", "us_levels", "us_tails", "us_render",
+                         "us_front", "us_runs", "us_walk", "us_queue", "us_wait", "us_redo",
                          "pulses_past_stream", "zero_records", "compactions", "max_samples_held"), list(a)))
 
     def read_front(self, n):

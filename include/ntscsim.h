@@ -654,8 +654,10 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * through the exact repair rounds) and chunk size in samples (default 4096); results must not
  * change.  stats: [0] front-end repair rounds, [1] chunks repaired, [2] comb-tail rounds (after the serial first guess: 1 when it was the fixed point),
  * [3] sync runs, [4] rendered scanlines, [5] calibration pulses of the last call; [6..11] wall-clock
- * microseconds of its phases: front end, run extraction, sync walk, level calibration, comb tails
- * (incl. clearing the frames), rendering; [12] calibration pulses whose sums ran past the buffered
+ * microseconds of its phases: front end, run extraction, sync walk (level calibration, comb tails and rendering of
+ * the groups of fields it has finished run on the GPU behind it), queuing the same for the last two groups, waiting
+ * for the GPU to finish them, redoing the comb tails by rounds + a second rendering (0 unless a group's first guess
+ * of the tails did not settle); [12] calibration pulses whose sums ran past the buffered
  * stream, [13] never-filled records among them; [14] compactions of the device buffer (streams),
  * [15] the most samples the device buffer ever held.  Counters accumulate over the pushes of a stream.
  * Environment (read by ntscsim_raw28_create, developer / test switches; results never depend on them):
@@ -663,7 +665,9 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * NTSCSIM_RAW28_CHUNKS = chunk count of its second sweep on long streams, NTSCSIM_RAW28_NOTAILSCAN = 1: comb
  * tails by rounds only, NTSCSIM_RAW28_EXACT = scanlines at the end of the second sweep's warm-up that are walked sample
  * by sample (default 30; the ones before are taken in closed form where that is known to be safe; >= 112: all),
- * NTSCSIM_RAW28_LANES = chunks per wavefront of that sweep (default 16). */
+ * NTSCSIM_RAW28_LANES = chunks per wavefront of that sweep (default 16), NTSCSIM_RAW28_GROUP = fields per group of the
+ * back half's pipeline behind the sync walk (default 192), NTSCSIM_RAW28_TAILROUNDS = 1: test hook, take the path of
+ * comb tails whose first guess did not settle. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
 void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */

@@ -220,6 +220,29 @@ def test_hip_front_end_cheap_warm_up_is_only_a_guess(monkeypatch, exact):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("group,rounds", [(1, 0), (3, 0), (192, 1), (2, 1)])
+def test_hip_back_half_in_groups_behind_the_walk(monkeypatch, group, rounds):
+    """Levels, comb tails and rendering run per group of fields on the GPU while the host's sync walk goes on (round 4):
+    whatever the group size -- one field per group puts every field boundary on a group boundary -- and also when the
+    comb tails' first guess is declared unsettled (test hook: rounds over all scanlines, everything rendered again),
+    frames and levels are the oracle's; as a stream in pieces too."""
+    monkeypatch.setenv("NTSCSIM_RAW28_GROUP", str(group))
+    monkeypatch.setenv("NTSCSIM_RAW28_TAILROUNDS", str(rounds))
+    capture = L.raw28_capture(6, 17, 3, 4000)
+    for kw, flags in (({}, []), ({"disable_subcarrier": 1}, ["-nosc"]), ({"mark_sync": 1, "show_subcarrier": 1}, ["-marksig", "-showsc"])):
+        want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(**kw), capture)
+        got, lv2, st, dec = _hip_run(flags, capture)
+        assert got.shape == want.shape and np.array_equal(got, want), (group, rounds, flags, st)
+        assert lv2 == lv
+        if rounds and "-nosc" not in flags:
+            assert st["tail_rounds"] >= 5, st                  # the first look + at least one batch of four rounds
+        dec.close()
+        got, lv3, _, dec2 = _hip_stream(flags, capture, [700001, 1, 250000])
+        assert np.array_equal(got, want) and lv3 == lv, (group, rounds, flags)
+        dec2.close()
+
+
+@pytest.mark.gpu
 def test_hip_front_end_in_segments(monkeypatch):
     """The front end works through at most 2^29 new samples at a time (8 bytes of fp64 plane per sample); with the
     segment shrunk by its test hook the loop over segments runs on a small capture: odd segment sizes, segments
