@@ -160,6 +160,15 @@ __global__ void k_raw28_head(const uint8_t *__restrict__ raw, uint8_t *__restric
 
 // samples [s0, s1) through the three low-passes, s0 a multiple of 16 (raw is padded by 64 bytes); OUT: lv of
 // the sample pair (s0 + 2u, s0 + 2u + 1) to out[u * stride]
+// The fp64 plane between the two sweeps (2.3 GB for 600 fields) is written once and read long after the L2 has forgotten
+// it: streaming (nt) stores and loads (round 4: k_raw28_lp 0.85 -> 0.75 ms, the front end 4.68 -> 4.54 ms).
+#ifdef RAW28_PLAIN_PLANE            /* A/B: plain stores / loads */
+#define RAW28_PLANE_STORE(p, v) (*(p) = (v))
+#define RAW28_PLANE_LOAD(p) (*(p))
+#else
+#define RAW28_PLANE_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#define RAW28_PLANE_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 // With `sum` (OUT only; s0 is then a multiple of FOLLOW_SB = 64 within its column): one record per 64 samples for the
 // cheap part of sweep 2's warm-up, sum[u * stride] = (min lv, a_slow * SUM lv_i om_slow^(63 - i)) -- what 64 steps of
 // the follower's slow branch add to om_slow^64 * level.  A GUESS feeds on it, nothing exact: fused multiply-add is fine.
@@ -181,7 +190,7 @@ __device__ __forceinline__ void lp_span(double &p0, double &p1, double &p2, doub
             lvpair pr;
             pr.x = lp3_step(p0, p1, p2, alpha, (double)((w[j >> 2] >> (8 * (j & 3))) & 0xFFu));
             pr.y = lp3_step(p0, p1, p2, alpha, (double)((w[j >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu));
-            if (OUT) out[(b * 8 + (size_t)(j >> 1)) * stride] = pr;
+            if (OUT) RAW28_PLANE_STORE(&out[(b * 8 + (size_t)(j >> 1)) * stride], pr);
             if (OUT && sum) {
                 acc = __builtin_fma(acc, om_slow, pr.x);
                 acc = __builtin_fma(acc, om_slow, pr.y);
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(64) void k_raw28_follow(const lvpair *__restrict__ 
         const unsigned coff = (unsigned)col * (unsigned)sizeof(lvpair);
         const char *rowp = (const char *)(LV2 + (size_t)(row >> 1) * ncols);
 #pragma unroll
-        for (int j = 0; j < HB; j++) dst[j] = *(const lvpair *)(rowp + (size_t)j * rstride + coff);
+        for (int j = 0; j < HB; j++) dst[j] = RAW28_PLANE_LOAD((const lvpair *)(rowp + (size_t)j * rstride + coff));
     };
     // ---- warm-up: columns cc - Kw .. cc - 1, the first one from row r0
     if (!repair) {
