@@ -956,6 +956,28 @@ struct ntscsim_raw28 {
         }                                                                                  \
     } while (0)
 
+// The chunk length of sweep 2 (see raw28_stream_push_impl): q sub-chunks of whole 64-sample superblocks, about 2048
+// samples each, near `target` samples, as close to a whole number of (nominal) scanlines as such a length gets.
+static void raw28_pick_chunk(double line_t, double target, int *chunk, int *q_out)
+{
+    target = std::max(target, 16.0 * line_t);
+    double best = 1e300;
+    *chunk = 0; *q_out = 0;
+    for (int q = 1; q <= 16; q++)
+        for (int sub = 2048; sub <= 4096; sub += FOLLOW_SB) {
+            const double len_c = (double)q * (double)sub;
+            if (len_c < 0.55 * target || len_c > 2.0 * target) continue;
+            const double lines = len_c / line_t;
+            const double drift = std::fabs(lines - std::nearbyint(lines)) * line_t;       // samples per lane
+            const double cost = 64.0 * drift + 100.0 * std::fabs(std::log(len_c / target)) - q;
+            if (cost < best) { best = cost; *chunk = q * sub; *q_out = q; }
+        }
+}
+extern "C" void ntscsim_raw28_debug_pick_chunk(double scanline_samples, double target_samples, int *chunk, int *subchunks)
+{
+    if (chunk && subchunks) raw28_pick_chunk(scanline_samples, target_samples, chunk, subchunks);
+}
+
 static void raw28_geometry(const ntscsim_raw28_opts &o, double &rate, double &frame_t, double &line_t,
                            unsigned &len, int &width, int &height)
 {
@@ -1199,17 +1221,9 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
             // scanlines long (nominal ones: a capture whose lines are longer or shorter drifts by that much per lane and
             // takes the exact walk more often, nothing else).  It also has to be Q sub-chunks of whole 64-sample
             // superblocks, about 2048 samples each, for sweep 1: the best such length near stream / max_chunks.
-            const double target = std::max((double)fresh / (double)d->max_chunks, 16.0 * d->one_scanline_time);
-            double best = 1e300;
-            for (int q = 1; q <= 16; q++)
-                for (int sub = 2048; sub <= 4096; sub += FOLLOW_SB) {
-                    const double len_c = (double)q * (double)sub;
-                    if (len_c < 0.55 * target || len_c > 2.0 * target) continue;
-                    const double lines = len_c / d->one_scanline_time;
-                    const double drift = std::fabs(lines - std::nearbyint(lines)) * d->one_scanline_time;   // samples per lane
-                    const double cost = 64.0 * drift + 100.0 * std::fabs(std::log(len_c / target)) - q;
-                    if (cost < best) { best = cost; chunk = (size_t)q * (size_t)sub; Q = q; }
-                }
+            int pm = 0, pq = 0;
+            raw28_pick_chunk(d->one_scanline_time, (double)fresh / (double)d->max_chunks, &pm, &pq);
+            if (pq > 0) { chunk = (size_t)pm; Q = pq; }
         }
         if (chunk > (size_t)INT_MAX / 2) { d->err = "front end: chunk too long"; return NTSCSIM_E_SIZE; }
         const int m = (int)chunk;

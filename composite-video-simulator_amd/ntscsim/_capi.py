@@ -37,7 +37,7 @@ EXPORTS = (
     "ntscsim_raw28_opts_init", "ntscsim_raw28_parse_argv", "ntscsim_raw28_geometry", "ntscsim_raw28_create",
     "ntscsim_raw28_destroy", "ntscsim_raw28_last_error", "ntscsim_raw28_decode", "ntscsim_raw28_decode_device",
     "ntscsim_raw28_stream_reset", "ntscsim_raw28_stream_push",
-    "ntscsim_raw28_get_levels", "ntscsim_raw28_debug_set_speculation", "ntscsim_raw28_debug_stats",
+    "ntscsim_raw28_get_levels", "ntscsim_raw28_debug_set_speculation", "ntscsim_raw28_debug_stats", "ntscsim_raw28_debug_pick_chunk",
     "ntscsim_raw28_debug_read_front",
     "ntscsim_submit_opts_init", "ntscsim_submit_configure", "ntscsim_submit", "ntscsim_flush", "ntscsim_wait",
     "ntscsim_host_unpin", "ntscsim_submit_stats",
@@ -323,6 +323,8 @@ def lib():
     L.ntscsim_raw28_get_levels.restype = C.c_int
     L.ntscsim_raw28_debug_set_speculation.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.ntscsim_raw28_debug_set_speculation.restype = None
+    L.ntscsim_raw28_debug_pick_chunk.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.ntscsim_raw28_debug_pick_chunk.restype = None
     L.ntscsim_raw28_debug_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.ntscsim_raw28_debug_stats.restype = None
     L.ntscsim_raw28_debug_read_front.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

@@ -670,6 +670,9 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * comb tails whose first guess did not settle. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
 void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
+/* Debug tap (host only, no GPU): the chunk length the front end's second sweep picks for a stream of `target_samples` x
+ * 16,384 samples -- `subchunks` pieces of whole 64-sample blocks near a whole number of scanlines */
+void ntscsim_raw28_debug_pick_chunk(double scanline_samples, double target_samples, int *chunk, int *subchunks);
 /* Debug tap: the front end's hsync_dc_raw of every sample of the last call, to host memory */
 int  ntscsim_raw28_debug_read_front(ntscsim_raw28 *dec, uint8_t *hsync_dc_raw, size_t n);
 

@@ -436,3 +436,25 @@ def test_raw28_cli_equals_oracle(tmp_path):
     empty.write_bytes(b"")
     r = subprocess.run([RAW28_CLI, "-i", str(empty), "-o", "null:"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0 and b"0 fields of 1820x262" in r.stderr
+
+
+def test_front_end_chunk_length_is_whole_scanlines_of_whole_superblocks():
+    """The chunk length of the front end's second sweep (host logic, no GPU): sub-chunks of whole 64-sample superblocks
+    of about 2048 samples, as near a whole number of scanlines as that allows -- 16 scanlines of 1820 samples at 8 x fsc
+    whatever the stream length the default chunk count divides -- and sensible lengths for other line lengths."""
+    import ctypes as C
+    lib = _capi.lib()
+    def pick(line, target):
+        m, q = C.c_int(), C.c_int()
+        lib.ntscsim_raw28_debug_pick_chunk(C.c_double(line), C.c_double(target), C.byref(m), C.byref(q))
+        return m.value, q.value
+    for target in (1000.0, 8000.0, 17480.0, 29120.0, 32768.0):
+        assert pick(1820.0, target) == (29120, 13), target
+    for line in (1820.0, 1820.3, 2542.2, 1135.0, 910.0, 3640.0):
+        for target in (500.0, 17480.0, 30000.0):
+            m, q = pick(line, target)
+            assert q >= 1 and m % (64 * q) == 0 and 2048 <= m // q <= 4096, (line, target, m, q)
+            t = max(target, 16 * line)
+            assert 0.55 * t <= m <= 2.0 * t, (line, target, m)
+            lines = m / line
+            assert abs(lines - round(lines)) * line <= 16.0, (line, target, m)      # at most a quarter superblock per lane
