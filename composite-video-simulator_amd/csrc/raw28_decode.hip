@@ -765,9 +765,29 @@ __global__ __launch_bounds__(256) void k_raw28_render(const uint8_t *__restrict_
     int *lut = lds + 2 * n;
     lut[threadIdx.x] = equalise_value((int)threadIdx.x, L, R);
     __syncthreads();
-    for (int x = threadIdx.x; x < n; x += 256) {
+    // four samples per thread: one (unaligned) 32-bit load of the delayed raw bytes where all four exist, one 128-bit
+    // store into the LDS (n = len + 16 is a multiple of 4 for the even line lengths the geometry allows; odd ones and the
+    // ends of the stream take the sample-by-sample form)
+    for (int x = 4 * (int)threadIdx.x; x < n; x += 4 * 256) {
         const size_t s = (size_t)L.pos + (size_t)x;
-        S[x] = lut[s < N ? raw_delayed(raw, h, s, R.D, R.thr, R.mark, R.base) : 0];
+        if (x + 3 < n && s + 3 < N && R.base + s >= (unsigned long long)R.D) {
+            uint32_t w, hw = 0xFFFFFFFFu;
+            __builtin_memcpy(&w, raw + (s - (size_t)R.D), 4);
+            if (R.mark) __builtin_memcpy(&hw, h + s, 4);
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int b = (int)((w >> (8 * k)) & 0xFFu);
+                if (R.mark && (int)((hw >> (8 * k)) & 0xFFu) < R.thr) b = 255;     // :590-591
+                v[k] = lut[b];
+            }
+            *reinterpret_cast<int4 *>(&S[x]) = make_int4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int k = 0; k < 4 && x + k < n; k++) {
+                const size_t sk = s + (size_t)k;
+                S[x + k] = lut[sk < N ? raw_delayed(raw, h, sk, R.D, R.thr, R.mark, R.base) : 0];
+            }
+        }
     }
     __syncthreads();
     uint32_t *dst = (uint32_t *)(frames + (size_t)L.field * frame_stride + (size_t)L.row * (size_t)linesize);
