@@ -962,6 +962,7 @@ struct ntscsim_raw28 {
     hipEvent_t ev_cal = nullptr, ev_cal2 = nullptr;    // behind a group's calibration sums on their way back (two groups in flight)
     HostBuf<LineRec> lines_h;      // pinned: what the walk writes and the copies read while it goes on
     HostBuf<CalRange> cal_h;
+    HostBuf<uint32_t> rs_h, re_h;  // the sync runs (pinned)
     HostBuf<CalSums> part_h;
     Buf<int> gcount;               // per group of fields: scanlines whose comb tail the confirming round changed
     ~ntscsim_raw28() { if (ev_cal) (void)hipEventDestroy(ev_cal); if (ev_cal2) (void)hipEventDestroy(ev_cal2); }
@@ -1334,7 +1335,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
     lap(6);
     // ---- (2) runs of h < thr over the buffer
     const size_t nseg = (N + RUN_BLOCK - 1) / RUN_BLOCK;
-    std::vector<uint32_t> rs, re;
+    size_t nruns_h = 0;                            // the runs on the host: pinned, the walk reads them in place
     if (nseg > 0) {
         R28CHK(d, d->segcnt.ensure(nseg + 1));
         R28CHK(d, d->segoff.ensure(nseg + 1));
@@ -1354,10 +1355,12 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
             R28CHK(d, d->rend.ensure(nruns));
             hipLaunchKernelGGL(k_raw28_run_scatter, dim3((unsigned)nseg), dim3(RUN_T), 0, st, d->h.p, N, d->K.thr,
                                d->segoff.p, d->rstart.p, d->rend.p);
-            rs.resize(nruns); re.resize(nruns);
-            R28CHK(d, hipMemcpyAsync(rs.data(), d->rstart.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            R28CHK(d, hipMemcpyAsync(re.data(), d->rend.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            R28CHK(d, d->rs_h.ensure(nruns));
+            R28CHK(d, d->re_h.ensure(nruns));
+            R28CHK(d, hipMemcpyAsync(d->rs_h.p, d->rstart.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            R28CHK(d, hipMemcpyAsync(d->re_h.p, d->rend.p, nruns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             R28CHK(d, hipStreamSynchronize(st));
+            nruns_h = nruns;
         }
         d->stats[3] += (int64_t)nruns;
     }
@@ -1372,7 +1375,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
     // every group's round did confirm is looked at once, at the end; if one did not (never seen), the tails are redone by
     // rounds over all scanlines and everything is rendered again.
     RunWalk W;
-    W.rs = rs.data(); W.re = re.data(); W.nruns = rs.size();
+    W.rs = d->rs_h.p; W.re = d->re_h.p; W.nruns = nruns_h;
     const size_t CAP = (size_t)len * 2048;                                        // open_src :353
     const size_t L30 = (size_t)(int)(len * 0.3), L06 = (size_t)(int)(len * 0.06), L02 = (size_t)(int)(len * 0.02);
     size_t &Bw = d->Bw, &Rd = d->Rd, &Ew = d->Ew;   // buffer begin, read position, buffer end (relative to base)
@@ -1393,7 +1396,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
     R28CHK(d, d->lines.ensure(lines_cap + 1));
     LineRec *const lines_h = d->lines_h.p;
     size_t nlines = 0;
-    size_t cal_cap = 2 * rs.size() + 4096, ncal = 0;
+    size_t cal_cap = 2 * nruns_h + 4096, ncal = 0;
     R28CHK(d, d->cal_h.ensure(cal_cap));
     R28CHK(d, d->part_h.ensure(cal_cap));
     R28CHK(d, d->cal_rg.ensure(cal_cap));
