@@ -926,7 +926,7 @@ struct ntscsim_raw28 {
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
     int exact_lines = 30;          // the last scanlines of that warm-up walked sample by sample (NTSCSIM_RAW28_EXACT; >= warm_lines: all)
     bool force_tail_rounds = false;    // NTSCSIM_RAW28_TAILROUNDS=1, test hook: take the path of a first guess that did not settle
-    int group_fields = 192;        // fields per group of the back half's pipeline (NTSCSIM_RAW28_GROUP: developer A/B switch)
+    int group_fields = 160;        // fields per group of the back half's pipeline (NTSCSIM_RAW28_GROUP: developer A/B switch)
     int follow_lanes = 16;         // chunks per wavefront of sweep 2 (NTSCSIM_RAW28_LANES: 1..64)
     size_t front_seg = FRONT_SEG;  // samples per front-end segment (NTSCSIM_RAW28_SEG: test hook, the segment loop on small captures)
     int max_chunks = 16384;        // sweep 2: 256 wavefronts (NTSCSIM_RAW28_CHUNKS: developer A/B switch)

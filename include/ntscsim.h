@@ -666,7 +666,7 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * tails by rounds only, NTSCSIM_RAW28_EXACT = scanlines at the end of the second sweep's warm-up that are walked sample
  * by sample (default 30; the ones before are taken in closed form where that is known to be safe; >= 112: all),
  * NTSCSIM_RAW28_LANES = chunks per wavefront of that sweep (default 16), NTSCSIM_RAW28_GROUP = fields per group of the
- * back half's pipeline behind the sync walk (default 192), NTSCSIM_RAW28_TAILROUNDS = 1: test hook, take the path of
+ * back half's pipeline behind the sync walk (default 160), NTSCSIM_RAW28_TAILROUNDS = 1: test hook, take the path of
  * comb tails whose first guess did not settle. */
 void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *dec, int warm_lines, int chunk_samples);
 void ntscsim_raw28_debug_stats(const ntscsim_raw28 *dec, int64_t out[16]);
