@@ -220,6 +220,20 @@ def test_hip_front_end_cheap_warm_up_is_only_a_guess(monkeypatch, exact):
 
 
 @pytest.mark.gpu
+def test_hip_front_end_on_a_very_noisy_capture():
+    """At the generator's noise level 24 the follower's default warm-up leaves most links open (profiles/r04_raw28_noise.txt):
+    several repair rounds in a row, with the closed-form warm-up and without it, and the bytes are still the oracle's."""
+    capture = L.raw28_capture(5, 41, 24, 999)
+    h, _ = L.raw28_oracle_front(L.raw28_oracle_opts(), capture)
+    want, lv = L.raw28_oracle_run(L.raw28_oracle_opts(), capture)
+    for warm, chunk in ((None, None), (20, None), (None, 8192)):
+        got, lv2, st, dec = _hip_run([], capture, warm=warm, chunk=chunk)
+        assert np.array_equal(dec.read_front(capture.size), h), (warm, chunk, st)
+        assert np.array_equal(got, want) and lv2 == lv, (warm, chunk)
+        dec.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("group,rounds", [(1, 0), (3, 0), (192, 1), (2, 1)])
 def test_hip_back_half_in_groups_behind_the_walk(monkeypatch, group, rounds):
     """Levels, comb tails and rendering run per group of fields on the GPU while the host's sync walk goes on (round 4):
