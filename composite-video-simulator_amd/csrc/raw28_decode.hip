@@ -717,10 +717,18 @@ __global__ void k_raw28_tails(const uint8_t *__restrict__ raw, const uint8_t *__
 // predecessors within a few scanlines; a walk that reaches row -1 starts from the carried tail, exactly) and
 // then its own TAIL_B scanlines serially.  2.5 rounds' worth of work in one launch instead of ~16 rounds; the
 // rounds of k_raw28_tails that follow confirm it (a round that changes nothing) or finish the job.
-// (Round 4: 24 + 16 scanlines per thread became 8 + 4 -- the launch lasts as long as ONE thread's serial walk, 0.23 ms
-// whatever the number of scanlines, and it now runs once per group of fields behind the sync walk; an inherited value is
-// divided by 8 per scanline and truncated, so 8 scanlines of warm-up forget anything a tail can hold.)
-constexpr int TAIL_B = 4, TAIL_WU = 8;
+// (Round 4: 24 + 16 scanlines per thread became 16 + 4 -- the launch lasts as long as ONE thread's serial walk whatever
+// the number of scanlines, and it now runs once per group of fields behind the sync walk.  Measured against the
+// capture's noise, tools/raw28_noise_probe.py: 8 scanlines of warm-up settle a clean capture and no longer one of noise
+// level 6, 12 do up to 6, 16 at every level tried (24); where the guess does not settle the rounds over all scanlines and
+// a second rendering cost 0.8-0.95 ms.)
+#ifndef RAW28_TAIL_B
+#define RAW28_TAIL_B 4
+#endif
+#ifndef RAW28_TAIL_WU
+#define RAW28_TAIL_WU 16
+#endif
+constexpr int TAIL_B = RAW28_TAIL_B, TAIL_WU = RAW28_TAIL_WU;
 __global__ void k_raw28_tails_scan(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ h, size_t N,
                                    const LineRec *__restrict__ lines, int nlines, RenderConst R,
                                    const int *__restrict__ carried, int *__restrict__ ta, int *__restrict__ tb)

@@ -21,6 +21,6 @@ for noise in [int(v) for v in os.environ.get("RAW28_PROBE_NOISE", "0,3,6,12,24")
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     st = dec.stats()
-    print("noise %2d: %d fields in %.2f ms = %.0f fields/s; repair rounds %d, chunks repaired %d, front end %d us" %
-          (noise, n, dt * 1e3, n / dt, st["front_rounds"], st["chunks_repaired"], st["us_front"]))
+    print("noise %2d: %d fields in %.2f ms = %.0f fields/s; repair rounds %d, chunks repaired %d, front end %d us; %d sync runs, walk %d us, tail rounds %d, redo %d us" %
+          (noise, n, dt * 1e3, n / dt, st["front_rounds"], st["chunks_repaired"], st["us_front"], st["sync_runs"], st["us_walk"], st["tail_rounds"], st["us_redo"]))
     dec.close()
