@@ -932,6 +932,8 @@ struct ntscsim_raw28 {
     bool tail_scan = true;         // comb tails: serial first guess before the rounds (NTSCSIM_RAW28_NOTAILSCAN=1: developer A/B switch)
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
+    int warm_boost = 0;            // scanlines of warm-up added after passes that left many links open (see the front end)
+    bool warm_forced = false;      // the warm-up was set through ntscsim_raw28_debug_set_speculation(): no boost
     int exact_lines = 30;          // the last scanlines of that warm-up walked sample by sample (NTSCSIM_RAW28_EXACT; >= warm_lines: all)
     bool force_tail_rounds = false;    // NTSCSIM_RAW28_TAILROUNDS=1, test hook: take the path of a first guess that did not settle
     int group_fields = 160;        // fields per group of the back half's pipeline (NTSCSIM_RAW28_GROUP: developer A/B switch)
@@ -1132,7 +1134,7 @@ extern "C" int ntscsim_raw28_get_levels(const ntscsim_raw28 *d, double *blank, d
 extern "C" void ntscsim_raw28_debug_set_speculation(ntscsim_raw28 *d, int warm_lines, int chunk_samples)
 {
     if (!d) return;
-    if (warm_lines >= 0) d->warm_lines = warm_lines;
+    if (warm_lines >= 0) { d->warm_lines = warm_lines; d->warm_forced = true; d->warm_boost = 0; }
     if (chunk_samples >= 64) { d->chunk = (chunk_samples + 15) & ~15; d->chunk_forced = true; }
 }
 extern "C" void ntscsim_raw28_debug_stats(const ntscsim_raw28 *d, int64_t out[16])
@@ -1226,7 +1228,8 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
 
     // ---- (1) front end over the new samples [front_done, N), at most FRONT_SEG of them at a time (the fp64
     // plane between the two sweeps is 8 bytes per sample)
-    const int warm = (int)(((size_t)d->warm_lines * len + 63) & ~(size_t)63);
+    // (warm_boost: scanlines added by earlier front-end passes of this decoder that left many links open -- a noisy source)
+    const int warm = (int)(((size_t)(d->warm_lines + d->warm_boost) * len + 63) & ~(size_t)63);
     const int warm_exact = (int)std::min((size_t)warm, ((size_t)d->exact_lines * len + 63) & ~(size_t)63);
     while (N > d->front_done) {
         const size_t o0 = d->front_done, o1 = std::min(N, o0 + d->front_seg), fresh = o1 - o0;
@@ -1318,12 +1321,17 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         };
         if (pin) R28CHK(d, hipFuncSetAttribute((const void *)k_raw28_follow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pin));
         launch_follow(pin, (const double *)nullptr, (const int *)nullptr);
-        for (;;) {
+        for (int round = 0;; round++) {
             R28CHK(d, hipMemsetAsync(d->counters.p, 0, sizeof(int), st));
             hipLaunchKernelGGL(k_raw28_links1, dim3((nchunks + 255) / 256), dim3(256), 0, st, (const double *)d->lv_begin.p,
                                (const double *)d->lv_end.p, nchunks, d->flags.p, d->counters.p);
             int nbad = 0;
             { const int rc = any_bad(nbad); if (rc != NTSCSIM_OK) return rc; }
+            // A warm-up that leaves more than one link in a hundred open is too short for this source (its noise slows the
+            // follower's contraction: profiles/r04_raw28_noise.txt); its closed-form part costs 15 us per scanline, a
+            // repaired chunk far more: the next passes of this decoder get 16 scanlines more, up to 64.  (Speed only.)
+            if (round == 0 && cheap > 0 && !d->warm_forced && nchunks >= 256 && nbad * 100 > nchunks && d->warm_boost < 64)
+                d->warm_boost += 16;
             if (nbad == 0) break;
             d->stats[0]++; d->stats[1] += nbad;
             R28CHK(d, hipMemcpyAsync(d->lv_prev.p, d->lv_end.p, (size_t)nchunks * sizeof(double), hipMemcpyDeviceToDevice, st));

@@ -660,6 +660,8 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * of the tails did not settle); [12] calibration pulses whose sums ran past the buffered
  * stream, [13] never-filled records among them; [14] compactions of the device buffer (streams),
  * [15] the most samples the device buffer ever held.  Counters accumulate over the pushes of a stream.
+ * (A decoder whose front end leaves more than one chunk link in a hundred open after its speculative pass -- a noisy
+ * source -- lengthens the warm-up of its later passes by 16 scanlines, up to 64: speed only.)
  * Environment (read by ntscsim_raw28_create, developer / test switches; results never depend on them):
  * NTSCSIM_RAW28_SEG = samples the front end takes per segment (default 2^29: 8 bytes of scratch per sample),
  * NTSCSIM_RAW28_CHUNKS = chunk count of its second sweep on long streams, NTSCSIM_RAW28_NOTAILSCAN = 1: comb
