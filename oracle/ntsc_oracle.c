@@ -624,3 +624,50 @@ void ntsc_oracle_bgra_to_yuv(const uint8_t *bgra, int bgra_linesize, int width, 
         }
     }
 }
+
+/* ---- unit entry points for the stand-in-free pin (tests/test_oracle_pure_pins.py): the primitives above
+ * over arrays, so that they can be compared one by one with the reference's own text compiled by
+ * build_ref_pure.sh with libc headers alone. */
+void ntsc_oracle_unit_filter(double rate, double hz, double reset, int highpass, const double *in, size_t n,
+                             double *out, double *alpha)
+{
+    onepole f;
+    size_t i;
+    onepole_set(&f, rate, hz, reset);
+    if (alpha) *alpha = f.alpha;
+    for (i = 0; i < n; i++) out[i] = highpass ? onepole_hp(&f, in[i]) : onepole_lp(&f, in[i]);
+}
+
+void ntsc_oracle_unit_rgb_to_yiq(const int32_t *rgb, size_t n, int32_t *yiq)
+{
+    size_t i;
+    for (i = 0; i < n; i++) rgb_to_yiq(&yiq[3 * i], &yiq[3 * i + 1], &yiq[3 * i + 2], rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]);
+}
+
+uint64_t ntsc_oracle_unit_rgb_to_yiq_cube(int32_t *yiq_or_null)
+{
+    uint64_t h = 0xcbf29ce484222325ULL;
+    size_t k = 0;
+    int r, g, b, c, s;
+    for (r = 0; r < 256; r++)
+        for (g = 0; g < 256; g++)
+            for (b = 0; b < 256; b++) {
+                int32_t v[3];
+                rgb_to_yiq(&v[0], &v[1], &v[2], r, g, b);
+                for (c = 0; c < 3; c++) {
+                    uint32_t w = (uint32_t)v[c];
+                    for (s = 0; s < 4; s++) { h ^= (w >> (8 * s)) & 0xff; h *= 0x100000001b3ULL; }
+                    if (yiq_or_null) yiq_or_null[k++] = v[c];
+                }
+            }
+    return h;
+}
+
+void ntsc_oracle_unit_yiq_to_rgb(const int32_t *yiq, size_t n, int32_t *rgb)
+{
+    size_t i;
+    for (i = 0; i < n; i++) {
+        uint32_t px = yiq_to_rgb_pixel(yiq[3 * i], yiq[3 * i + 1], yiq[3 * i + 2]);
+        rgb[3 * i] = (int32_t)((px >> 16) & 255); rgb[3 * i + 1] = (int32_t)((px >> 8) & 255); rgb[3 * i + 2] = (int32_t)(px & 255);
+    }
+}

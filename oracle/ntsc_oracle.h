@@ -75,6 +75,13 @@ void ntsc_oracle_bgra_to_yuv(const uint8_t *bgra, int bgra_linesize, int width, 
                              uint8_t *y, int y_linesize, uint8_t *u, int u_linesize,
                              uint8_t *v, int v_linesize, int is420);
 
+/* unit entry points for the stand-in-free pin (oracle/build_ref_pure.sh, tests/test_oracle_pure_pins.py) */
+void ntsc_oracle_unit_filter(double rate, double hz, double reset, int highpass, const double *in, size_t n,
+                             double *out, double *alpha);
+void ntsc_oracle_unit_rgb_to_yiq(const int32_t *rgb, size_t n, int32_t *yiq);
+uint64_t ntsc_oracle_unit_rgb_to_yiq_cube(int32_t *yiq_or_null);   /* FNV-1a over all 2^24 triples */
+void ntsc_oracle_unit_yiq_to_rgb(const int32_t *yiq, size_t n, int32_t *rgb);
+
 #ifdef __cplusplus
 }
 #endif

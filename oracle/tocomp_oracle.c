@@ -447,3 +447,27 @@ void tocomp_oracle_output_frame(tocomp_planes *bob, const tocomp_planes *frame, 
                        frame->data[p] + (size_t)frame->linesize[p] * sy, W / 2);
     }
 }
+
+/* ---- unit entry points for the stand-in-free pin (tests/test_oracle_pure_pins.py) */
+void tocomp_oracle_unit_filter(double rate, double hz, double reset, int highpass, const double *in, size_t n,
+                               double *out, double *alpha)
+{
+    onepole f;
+    size_t i;
+    op_set(&f, rate, hz, reset);
+    if (alpha) *alpha = f.alpha;
+    for (i = 0; i < n; i++) out[i] = highpass ? op_hp(&f, in[i]) : op_lp(&f, in[i]);
+}
+
+void tocomp_oracle_unit_clampu8(const int32_t *x, size_t n, int32_t *out)
+{
+    size_t i;
+    for (i = 0; i < n; i++) out[i] = clampu8(x[i]);
+}
+
+void tocomp_oracle_unit_black_key(int level, int wchroma, uint8_t *d, uint8_t *f, size_t n)
+{
+    size_t i;
+    for (i = 0; i < n; i++)
+        black_key(level, d + 3 * i, d + 3 * i + 1, d + 3 * i + 2, f + 3 * i, f + 3 * i + 1, f + 3 * i + 2, wchroma);
+}

@@ -50,6 +50,12 @@ void tocomp_oracle_black_key_feedback(tocomp_planes *dst, tocomp_planes *flt, un
 void tocomp_oracle_output_frame(tocomp_planes *bob, const tocomp_planes *frame, unsigned field,
                                 int mode);
 
+/* unit entry points for the stand-in-free pin (oracle/build_ref_pure.sh, tests/test_oracle_pure_pins.py) */
+void tocomp_oracle_unit_filter(double rate, double hz, double reset, int highpass, const double *in, size_t n,
+                               double *out, double *alpha);
+void tocomp_oracle_unit_clampu8(const int32_t *x, size_t n, int32_t *out);
+void tocomp_oracle_unit_black_key(int level, int wchroma, uint8_t *d, uint8_t *f, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,10 @@ Three shared objects are involved:
              ntscsim_create() then fails with NTSCSIM_E_NODEV.
   * ORACLE   oracle/libntsc_oracle.so -- our CPU restatement (test infrastructure only).
   * REF      oracle/_ref/libntsc_ref.so -- the reference's own hot-path text compiled by
-             oracle/build_ref.sh; exists only where /root/reference does (never on the GPU box).
+             oracle/build_ref.sh.  It can only be BUILT where /root/reference exists; the built,
+             git-ignored binary (GPL-2 text in compiled form) travels to the GPU box inside the gpurun
+             snapshot and is loaded there by the checker side of the tests and by bench.py's
+             cpu_baseline leg -- never by the product.
 """
 import ctypes as C
 import os
