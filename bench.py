@@ -740,6 +740,8 @@ def valu_roofline(w, h, preset, fields_per_step, tm_ms, ms_per_step):
                 for k, v in kern.items()}
     out = {
         "bound": "valu-issue (cycle-weighted)",
+        "source": "needed cycles: REPLAYED from profiles/traffic.json (SQ_INSTS_VALU per launch of a PMC pass x the ISA "
+                  "census' mean issue cost); the fractions divide them by THIS run's live times (ms_per_step, kernel_ms)",
         "unit": "SIMD pipe cycles/s",
         "peak": peak,
         "pipe_cycles_per_step": need,
@@ -1050,6 +1052,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # which of these fields were measured in THIS run and which are replayed from a tracked profile
+                "live_fields": ["achieved", "frac", "kernel_ms", "kernel_ms_all", "path_achieved",
+                                "valu.path_frac", "valu.path_frac_nominal", "valu.k_decode_frac", "valu.k_decode_frac_nominal"],
+                "traffic_source": None if traffic is None else
+                    "REPLAYED, not measured in this run: profiles/traffic.json (PMC passes of tools/pmc.sh, calibrated with "
+                    "tools/fetch_probe.hip; the profile's round is in its 'round' key), scaled to this run's fields per launch",
                 "algorithmic_bytes_per_launch": alg_bytes_launch,
                 "kernel_ms": dec_ms,
                 "note": "the exact path is bound by VALU issue, not by HBM (DESIGN.md, `valu` below): "

@@ -157,7 +157,7 @@ struct Out422Dev {
     int32_t frame_ls[3], bob_ls[3];
     uint32_t field, mode;
 };
-enum : uint32_t { OUT422_BOB422 = 0u, OUT422_BOB420 = 1u, OUT422_INTERLACED420 = 2u };
+enum : uint32_t { OUT422_BOB422 = 0u, OUT422_BOB420 = 1u, OUT422_INTERLACED420 = 2u, OUT422_FRAME = 3u };
 
 DEV void copy_row422(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, int nbytes, bool al4)
 {
@@ -174,9 +174,10 @@ DEV void copy_row422(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, int
 __global__ void k422_output(DevParams P, const Out422Dev *__restrict__ outs, int al4)
 {
     const Out422Dev &o = outs[blockIdx.y];
+    if (o.mode > OUT422_FRAME) return;                             // (a record of the host engine's ring with no output_frame)
     const unsigned y = blockIdx.x, H = (unsigned)P.H;
     unsigned sy;
-    if (o.mode == OUT422_INTERLACED420) sy = y;                    // :1202-1203
+    if (o.mode == OUT422_INTERLACED420 || o.mode == OUT422_FRAME) sy = y;     // :1202-1203; :1158 the frame as it is
     else if (o.field) sy = y | 1u;                                 // 1, 1, 3, 3, ...  :1181-1184
     else sy = (y + 1u) & ~1u;                                      // 0, 2, 2, 4, 4, ...
     if (sy >= H) sy -= 2u;                                         // :1186-1187

@@ -91,6 +91,7 @@ struct Geometry {
 } // namespace
 
 struct SubmitEngine;      // ntscsim_submit.hip (included at the end of this file)
+struct Host422Engine;     // ntscsim_host422.hip (likewise)
 
 struct ntscsim_ctx {
     ntscsim_params prm;
@@ -164,9 +165,13 @@ struct ntscsim_ctx {
     bool no_stream422 = false;       // debug: the YUV422P preset kernel as four sweeps instead of A + one streamed pass
     int mode = NTSCSIM_MODE_EXACT;
     SubmitEngine *sub = nullptr;     // ntscsim_submit() / ntscsim_wait(): created on first use
+    Host422Engine *h422 = nullptr;   // ntscsim_field422() / ntscsim_submit422(): created on first use
 };
 static void submit_engine_destroy(ntscsim_ctx *c);
 static int sub_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
+static void host422_engine_destroy(ntscsim_ctx *c);
+static int h422_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
+static int h422_launch(ntscsim_ctx *c);
 
 #define HIPCHK(ctx, call)                                                              \
     do {                                                                               \
@@ -393,6 +398,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     submit_engine_destroy(c);
+    host422_engine_destroy(c);
     for (Geometry *e : c->geoms) {
         e->lskip.release(); e->pskip.release(); e->jrow.release(); e->sstart.release(); e->jwarm.release();
         delete e;
@@ -1317,7 +1323,7 @@ extern "C" int ntscsim_output422_device(ntscsim_ctx *c, const ntscsim_out422_des
     bool al4 = true;
     for (int i = 0; i < n; i++) {
         const ntscsim_out422_desc &d = descs[i];
-        if (d.field > 1 || d.mode > NTSCSIM_OUT422_INTERLACED420) return NTSCSIM_E_ARG;
+        if (d.field > 1 || d.mode > NTSCSIM_OUT422_FRAME) return NTSCSIM_E_ARG;
         Out422Dev &o = c->host_out422[(size_t)i];
         std::memset(&o, 0, sizeof(o));
         for (int k = 0; k < 3; k++) {
@@ -1764,6 +1770,7 @@ extern "C" int ntscsim_debug_read_composite(ntscsim_ctx *c, int32_t *out, size_t
 
 // ---- asynchronous host-frame drop-in: ntscsim_submit() / ntscsim_wait()
 #include "ntscsim_submit.hip"
+#include "ntscsim_host422.hip"
 
 // ---- a pool of contexts over several GPUs: ntscsim_pool_*()
 #include "ntscsim_pool.hip"

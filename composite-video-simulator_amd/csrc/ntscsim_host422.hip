@@ -1,0 +1,628 @@
+// ntscsim_host422.hip -- the YUV422P tool's loop on HOST frames: ntscsim_field422() / ntscsim_submit422()
+// (include/ntscsim.h; SURVEY.md 8(b), VERDICT r04 "missing" 1).  Included by ntscsim_hip.hip (one translation unit).
+//
+// What it replaces: one iteration of do_video_decode_and_render()'s loop, ffmpeg_to_composite.cpp:1783-1800 --
+//     render_field(frame, input_frame, field, video_field, tgt_pts);                          :1784
+//     if (black_key_level_feedback >= 0) black_key_feedback(frame, filter_frame, field, ..);  :1787
+//     if (enable_composite_emulation) composite_video_process(frame, field, video_field);     :1790
+//     output_frame(frame, ...)  -- its pixel work, the bob / repack copy :1177-1236           :1793-1796
+// -- on the tool's own AVFrames (host memory), synchronously or with `depth` iterations in flight.
+//
+// The tool works IN PLACE on ONE persistent frame.  Two ways of running an iteration on the device:
+//   FAST    the iteration renders its field from a source (render_field rewrites every row of the field, :1076-1128),
+//           the luma rows carry two bytes of padding (linesize >= width + 2) and there is no black-key feedback:
+//           what the iteration computes then depends on the frame only through the two bytes behind each of its
+//           rows that the Y/C separator reads (:496) -- padding nobody writes.  The field gets a device frame of
+//           its own (shared with the other field of its pair when that one is still pending), those bytes are
+//           snapshotted at submit, and up to `depth` iterations run as ONE batch of ntscsim_fields422_device().
+//   SERIAL  everything else (no source, tight rows, black-key feedback -- a frame-to-frame recurrence :974-999 --,
+//           an interlaced repack whose other field did not come through the same device frame): the iteration
+//           runs alone, in order, on a device MIRROR of the caller's frame that has the caller's own linesizes
+//           (so the separator's read past a tight row meets the same bytes as in the tool).
+// Both deliver the rows of `field` of the frame (and of the filter frame), and the encoder frame when one was
+// given, back into the caller's memory at ntscsim_wait(), in submit order.  Everything runs on the ctx's stream;
+// sources are snapshotted into a pinned staging ring by the submitting thread and uploaded on a copy stream.
+#include <deque>
+
+namespace {
+
+struct CopyRec422 {               // rows src -> dst on the device side of the link (k422_rows)
+    const uint8_t *src;
+    uint8_t *dst;
+    int32_t sp, dp, rowbytes, nrows;
+};
+struct PadRec422 {                // the two bytes behind every row of the field (k422_pad)
+    uint8_t *y;                   // luma plane of the device frame
+    const uint8_t *pad;           // [nrows][2], pinned host memory
+    int32_t ls, W, field, nrows;
+};
+
+// grid (row chunks, records): copy nrows rows of rowbytes bytes; records with nrows == 0 are skipped
+__global__ void k422_rows(const CopyRec422 *__restrict__ recs)
+{
+    const CopyRec422 r = recs[blockIdx.y];
+    for (int k = blockIdx.x; k < r.nrows; k += gridDim.x) {
+        const uint8_t *s = r.src + (size_t)k * (size_t)r.sp;
+        uint8_t *d = r.dst + (size_t)k * (size_t)r.dp;
+        if (!(((uintptr_t)s | (uintptr_t)d | (uintptr_t)r.rowbytes) & 3)) {
+            const uint32_t *s4 = reinterpret_cast<const uint32_t *>(s);
+            uint32_t *d4 = reinterpret_cast<uint32_t *>(d);
+            for (int i = threadIdx.x; i < r.rowbytes / 4; i += blockDim.x) d4[i] = s4[i];
+        } else
+            for (int i = threadIdx.x; i < r.rowbytes; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+__global__ void k422_pad(const PadRec422 *__restrict__ recs)
+{
+    const PadRec422 r = recs[blockIdx.x];
+    for (int k = threadIdx.x; k < r.nrows; k += blockDim.x) {
+        uint8_t *row = r.y + (size_t)r.ls * (size_t)(r.field + 2 * k);
+        row[r.W] = r.pad[2 * k];
+        row[r.W + 1] = r.pad[2 * k + 1];
+    }
+}
+
+} // namespace
+
+struct Host422Engine {
+    int depth = 32, nslots = 128;
+    // geometry of the rings
+    int W = 0, H = 0, L = 0;
+    int lsd[3] = {0, 0, 0};
+    size_t foff[3] = {0, 0, 0}, fbytes = 0;             // device frame of a FAST iteration
+    size_t dn_frm = 0, dn_flt = 0, dn_out = 0, dbytes = 0;   // delivery record of one iteration (device and staging)
+    size_t sbytes = 0;                                  // capacity of one source slot
+    DevBuf<uint8_t> dfrm, dsrc, ddn;
+    uint8_t *hsrc = nullptr, *hdn = nullptr;            // pinned staging
+    PadRec422 *prec = nullptr;                          // pinned, device-visible, one per slot
+    CopyRec422 *crec = nullptr;                         // 6 per slot
+    Out422Dev *orec = nullptr;                          // 1 per slot
+    uint8_t *pads = nullptr;                            // [nslots][2 * L]
+    hipStream_t s_up = nullptr;
+
+    struct Mirror {
+        const uint8_t *host[3]; int ls[3]; int H;
+        DevBuf<uint8_t> dev; size_t off[3];
+        bool stale = true;
+    };
+    std::vector<Mirror *> mirrors;
+
+    struct Item {
+        uint64_t ticket = 0;
+        int slot = 0, fslot = 0, sslot = -1;
+        bool serial = false;
+        ntscsim_loop422 it;
+        Mirror *mfrm = nullptr, *mflt = nullptr;
+        uint64_t rng_pos = 0;
+    };
+    std::vector<Item> pending;
+    struct Batch {
+        uint64_t first = 0, last = 0;
+        hipEvent_t done = nullptr;
+        std::vector<Item> items;
+        int rc = NTSCSIM_OK;
+        bool launched_ok = false;
+    };
+    std::deque<Batch> inflight;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_up = nullptr;
+    uint64_t next_ticket = 1, done_ticket = 0;
+    int src_cur = -1;
+    uint64_t src_ring_pos = 0;
+    std::vector<uint64_t> src_last_ticket;
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] submitted [1] launches [2] uploads [3] FAST [4] SERIAL [5] mirror uploads
+};
+
+static int h422_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
+static int h422_launch(ntscsim_ctx *c);
+
+static Host422Engine *h422_get(ntscsim_ctx *c)
+{
+    if (!c->h422) c->h422 = new (std::nothrow) Host422Engine();
+    return c->h422;
+}
+
+static void h422_release_rings(Host422Engine *e)
+{
+    e->dfrm.release(); e->dsrc.release(); e->ddn.release();
+    if (e->hsrc) (void)hipHostFree(e->hsrc);
+    if (e->hdn) (void)hipHostFree(e->hdn);
+    if (e->prec) (void)hipHostFree(e->prec);
+    if (e->crec) (void)hipHostFree(e->crec);
+    if (e->orec) (void)hipHostFree(e->orec);
+    if (e->pads) (void)hipHostFree(e->pads);
+    e->hsrc = e->hdn = e->pads = nullptr; e->prec = nullptr; e->crec = nullptr; e->orec = nullptr;
+    e->W = e->H = 0; e->sbytes = 0;
+    e->src_cur = -1;
+    e->src_last_ticket.clear();
+}
+
+static void host422_engine_destroy(ntscsim_ctx *c)
+{
+    Host422Engine *e = c->h422;
+    if (!e) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &b : e->inflight) if (b.done) (void)hipEventDestroy(b.done);
+    for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+    for (auto *m : e->mirrors) { m->dev.release(); delete m; }
+    h422_release_rings(e);
+    if (e->s_up) (void)hipStreamDestroy(e->s_up);
+    if (e->ev_up) (void)hipEventDestroy(e->ev_up);
+    delete e;
+    c->h422 = nullptr;
+}
+
+static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+// rings for this geometry; `src_need` = bytes of the largest source frame seen so far
+static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, size_t src_need)
+{
+    if (e->W == W && e->H == H && e->sbytes >= src_need) return NTSCSIM_OK;
+    int rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    if (rc != NTSCSIM_OK) return rc;
+    const size_t keep_src = e->sbytes > src_need ? e->sbytes : src_need;
+    h422_release_rings(e);
+    const int ns = e->nslots, L = (H + 1) / 2, W2 = W / 2;
+    e->lsd[0] = (W + 16 + 63) / 64 * 64;
+    e->lsd[1] = e->lsd[2] = (W2 + 8 + 31) / 32 * 32;
+    e->foff[0] = 0;
+    e->foff[1] = up256((size_t)e->lsd[0] * H);
+    e->foff[2] = e->foff[1] + up256((size_t)e->lsd[1] * H);
+    e->fbytes = e->foff[2] + up256((size_t)e->lsd[2] * H);
+    // delivery record: [frame rows of the field: Y L x W, U, V L x W/2][filter rows, same][encoder frame: Y H x W,
+    // U, V (H + 1) x W/2 -- 4:2:2 uses H chroma rows, 4:2:0 (H + 1) / 2 and the repack's one spare row :1215-1223]
+    e->dn_frm = 0;
+    e->dn_flt = up256((size_t)L * W * 2);
+    e->dn_out = e->dn_flt + up256((size_t)L * W * 2);
+    e->dbytes = e->dn_out + up256((size_t)H * W + 2 * (size_t)(H + 1) * W2);
+    e->sbytes = up256(keep_src);
+    HIPCHK(c, e->dfrm.ensure(e->fbytes * (size_t)ns));
+    HIPCHK(c, e->dsrc.ensure(e->sbytes * (size_t)ns));
+    HIPCHK(c, e->ddn.ensure(e->dbytes * (size_t)ns));
+    // (device frames start zeroed: rows of the other field that no iteration ever rendered read as 0 in an
+    //  interlaced repack's source -- a case the FAST path does not take, see h422_classify)
+    HIPCHK(c, hipMemsetAsync(e->dfrm.p, 0, e->fbytes * (size_t)ns, c->stream));
+    HIPCHK(c, hipHostMalloc((void **)&e->hsrc, e->sbytes * (size_t)ns, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&e->hdn, e->dbytes * (size_t)ns, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&e->prec, sizeof(PadRec422) * (size_t)ns, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&e->crec, sizeof(CopyRec422) * 6 * (size_t)ns, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&e->orec, sizeof(Out422Dev) * (size_t)ns, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void **)&e->pads, (size_t)2 * L * (size_t)ns, hipHostMallocDefault));
+    if (!e->s_up) HIPCHK(c, hipStreamCreateWithFlags(&e->s_up, hipStreamNonBlocking));
+    if (!e->ev_up) HIPCHK(c, hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming));
+    e->W = W; e->H = H; e->L = L;
+    e->src_last_ticket.assign((size_t)ns, 0);
+    e->src_ring_pos = 0;
+    e->src_cur = -1;
+    return NTSCSIM_OK;
+}
+
+static int h422_field_rows(int H, unsigned field) { return H > (int)field ? (H - (int)field + 1) / 2 : 0; }
+
+// chroma rows of the encoder frame that output_frame() writes inside the plane (:1177-1236)
+static int h422_out_chroma_rows(int H, uint32_t mode) { return (mode == NTSCSIM_OUT422_BOB422 || mode == NTSCSIM_OUT422_FRAME) ? H : (H + 1) / 2; }
+
+static Host422Engine::Mirror *h422_mirror(ntscsim_ctx *c, Host422Engine *e, const ntscsim_frame422 &f, int H)
+{
+    for (auto *m : e->mirrors)
+        if (m->host[0] == f.data[0] && m->host[1] == f.data[1] && m->host[2] == f.data[2] && m->ls[0] == f.linesize[0] &&
+            m->ls[1] == f.linesize[1] && m->ls[2] == f.linesize[2] && m->H == H) return m;
+    if (e->mirrors.size() >= 64) {           // (a tool has one frame and one filter frame; keep the table bounded)
+        if (h422_wait_ticket(c, NTSCSIM_TICKET_ALL) != NTSCSIM_OK) return nullptr;
+        (void)hipStreamSynchronize(c->stream);
+        for (auto *m : e->mirrors) { m->dev.release(); delete m; }
+        e->mirrors.clear();
+    }
+    auto *m = new (std::nothrow) Host422Engine::Mirror();
+    if (!m) return nullptr;
+    for (int k = 0; k < 3; k++) { m->host[k] = f.data[k]; m->ls[k] = f.linesize[k]; }
+    m->H = H;
+    m->off[0] = 0;
+    m->off[1] = up256((size_t)m->ls[0] * H + 16);
+    m->off[2] = m->off[1] + up256((size_t)m->ls[1] * H + 16);
+    if (m->dev.ensure(m->off[2] + up256((size_t)m->ls[2] * H + 16)) != hipSuccess) {
+        c->err = "hipMalloc failed (frame mirror)";
+        delete m;
+        return nullptr;
+    }
+    m->stale = true;
+    e->mirrors.push_back(m);
+    return m;
+}
+
+// bring a mirror up to date with the caller's frame: everything in flight is delivered first
+static int h422_refresh_mirror(ntscsim_ctx *c, Host422Engine *e, Host422Engine::Mirror *m, int W)
+{
+    if (!m->stale) return NTSCSIM_OK;
+    int rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    if (rc != NTSCSIM_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 3; k++) {
+        // the plane as the tool's contract has it: height * linesize bytes, of which the last row's are only
+        // touched as far as the separator reads (width + 2) / the pixels reach
+        const size_t need = k == 0 ? (size_t)W + 2 : (size_t)W / 2;
+        const size_t last = need < (size_t)m->ls[k] ? need : (size_t)m->ls[k];
+        const size_t bytes = (size_t)m->ls[k] * (size_t)(m->H - 1) + last;
+        for (size_t off = 0; off < bytes; off += (1u << 20)) {
+            const size_t n = bytes - off < (1u << 20) ? bytes - off : (1u << 20);
+            const hipError_t er = upload_table(m->dev.p + m->off[k] + off, m->host[k] + off, n);
+            if (er != hipSuccess) { c->err = std::string("mirror upload: ") + hipGetErrorString(er); return NTSCSIM_E_HIP; }
+        }
+    }
+    m->stale = false;
+    e->stats[5]++;
+    return NTSCSIM_OK;
+}
+
+static int h422_retire_front(ntscsim_ctx *c, Host422Engine *e)
+{
+    Host422Engine::Batch &b = e->inflight.front();
+    int rc = b.rc;
+    if (b.launched_ok) {
+        const hipError_t er = hipEventSynchronize(b.done);
+        if (er != hipSuccess) { c->err = std::string("hipEventSynchronize: ") + hipGetErrorString(er); rc = NTSCSIM_E_HIP; }
+        else {
+            const int W = e->W, H = e->H, W2 = W / 2;
+            for (const auto &it : b.items) {
+                const uint8_t *st = e->hdn + e->dbytes * (size_t)it.slot;
+                const int n = h422_field_rows(H, it.it.field);
+                auto rows_out = [&](const ntscsim_frame422 &f, const uint8_t *s) {
+                    for (int k = 0; k < 3; k++) {
+                        const size_t rb = k ? (size_t)W2 : (size_t)W;
+                        for (int r = 0; r < n; r++)
+                            std::memcpy(f.data[k] + (size_t)f.linesize[k] * (size_t)(it.it.field + 2 * r), s + rb * (size_t)r, rb);
+                        s += rb * (size_t)n;
+                    }
+                };
+                rows_out(it.it.frame, st + e->dn_frm);
+                if (it.serial && it.mflt) rows_out(it.it.filter, st + e->dn_flt);
+                if (it.it.out.data[0]) {
+                    const uint8_t *s = st + e->dn_out;
+                    const int ch = h422_out_chroma_rows(H, it.it.out_mode);
+                    for (int k = 0; k < 3; k++) {
+                        const size_t rb = k ? (size_t)W2 : (size_t)W;
+                        const int nr = k ? ch : H;
+                        if ((size_t)it.it.out.linesize[k] == rb) std::memcpy(it.it.out.data[k], s, rb * (size_t)nr);
+                        else for (int r = 0; r < nr; r++)
+                            std::memcpy(it.it.out.data[k] + (size_t)it.it.out.linesize[k] * (size_t)r, s + rb * (size_t)r, rb);
+                        s += rb * (size_t)(k ? H + 1 : H);
+                    }
+                }
+            }
+        }
+    }
+    e->done_ticket = b.last;
+    if (b.done) e->ev_pool.push_back(b.done);
+    e->inflight.pop_front();
+    return rc;
+}
+
+static int h422_wait_ticket(ntscsim_ctx *c, uint64_t ticket)
+{
+    Host422Engine *e = c->h422;
+    if (!e) return ticket == NTSCSIM_TICKET_ALL ? NTSCSIM_OK : NTSCSIM_E_ARG;
+    if (ticket == NTSCSIM_TICKET_ALL) ticket = e->next_ticket - 1;
+    if (ticket == 0) return NTSCSIM_OK;
+    if (ticket >= e->next_ticket) return NTSCSIM_E_ARG;
+    int rc = NTSCSIM_OK;
+    if (!e->pending.empty() && ticket >= e->pending.front().ticket) {
+        const int r = h422_launch(c);
+        if (r != NTSCSIM_OK) rc = r;
+    }
+    while (!e->inflight.empty() && e->inflight.front().first <= ticket) {
+        const int r = h422_retire_front(c, e);
+        if (r != NTSCSIM_OK && rc == NTSCSIM_OK) rc = r;
+    }
+    return rc;
+}
+
+// Enqueue the pending iterations (all FAST, or one SERIAL) as one launch on the ctx's stream.
+static int h422_launch(ntscsim_ctx *c)
+{
+    Host422Engine *e = c->h422;
+    if (!e || e->pending.empty()) return NTSCSIM_OK;
+    Host422Engine::Batch b;
+    b.first = e->pending.front().ticket;
+    b.last = e->pending.back().ticket;
+    b.items.swap(e->pending);
+    e->pending.clear();
+    const int n = (int)b.items.size();
+    auto finish = [&](int rc) {
+        b.rc = rc;
+        e->inflight.push_back(std::move(b));
+        return rc;
+    };
+    if (!e->ev_pool.empty()) { b.done = e->ev_pool.back(); e->ev_pool.pop_back(); }
+    else if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) {
+        c->err = "hipEventCreate failed";
+        return finish(NTSCSIM_E_HIP);
+    }
+    const int W = e->W, H = e->H, W2 = W / 2;
+    hipStream_t st = c->stream;
+    // uploads of this launch's sources have been enqueued on the copy stream
+    hipError_t er = hipEventRecord(e->ev_up, e->s_up);
+    if (er == hipSuccess) er = hipStreamWaitEvent(st, e->ev_up, 0);
+    if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+
+    std::vector<ntscsim_field422_desc> descs((size_t)n);
+    bool any_pad = false, any_out = false;
+    bool al4 = (W2 & 3) == 0;
+    for (int i = 0; i < n; i++) {
+        const Host422Engine::Item &it = b.items[(size_t)i];
+        const ntscsim_loop422 &L = it.it;
+        ntscsim_field422_desc &d = descs[(size_t)i];
+        std::memset(&d, 0, sizeof(d));
+        uint8_t *frm[3]; int fls[3];
+        if (it.serial) for (int k = 0; k < 3; k++) { frm[k] = it.mfrm->dev.p + it.mfrm->off[k]; fls[k] = it.mfrm->ls[k]; }
+        else for (int k = 0; k < 3; k++) { frm[k] = e->dfrm.p + e->fbytes * (size_t)it.fslot + e->foff[k]; fls[k] = e->lsd[k]; }
+        const bool c420 = (L.flags & NTSCSIM_422_SRC420) != 0;
+        const size_t src_crows = c420 ? ((size_t)L.src_height + 1) / 2 : (size_t)L.src_height;
+        for (int k = 0; k < 3; k++) {
+            al4 = al4 && !(((uintptr_t)frm[k] | (uintptr_t)fls[k]) & 3);
+            d.dst_dev[k] = frm[k]; d.dst_linesize[k] = fls[k];
+            if (it.sslot >= 0) {
+                uint8_t *s = e->dsrc.p + e->sbytes * (size_t)it.sslot;
+                d.src_dev[k] = k == 0 ? s : s + (size_t)W * L.src_height + (k == 2 ? (size_t)W2 * src_crows : 0);
+                d.src_linesize[k] = k ? W2 : W;
+            }
+            if (it.mflt) { d.flt_dev[k] = it.mflt->dev.p + it.mflt->off[k]; d.flt_linesize[k] = it.mflt->ls[k]; }
+        }
+        d.src_height = L.src_height;
+        d.field = L.field;
+        d.flags = L.flags;
+        d.fieldno = L.fieldno;
+        d.rng_pos = it.rng_pos;
+        const int nr = h422_field_rows(H, L.field);
+        // the separator's two bytes behind each row of the field (FAST: the device frame's rows are wider than the
+        // caller's; the bytes were snapshotted at submit)
+        PadRec422 &p = e->prec[it.slot];
+        p.y = frm[0]; p.pad = e->pads + (size_t)2 * e->L * (size_t)it.slot; p.ls = fls[0]; p.W = W;
+        p.field = (int32_t)L.field; p.nrows = it.serial ? 0 : nr;
+        any_pad = any_pad || !it.serial;
+        // delivery: the field's rows of the frame (and of the filter frame) -> the delivery record
+        uint8_t *dn = e->ddn.p + e->dbytes * (size_t)it.slot;
+        CopyRec422 *cr = e->crec + 6 * (size_t)it.slot;
+        size_t o = e->dn_frm;
+        for (int k = 0; k < 3; k++) {
+            const int rb = k ? W2 : W;
+            cr[k] = {frm[k] + (size_t)fls[k] * L.field, dn + o, 2 * fls[k], rb, rb, nr};
+            o += (size_t)rb * nr;
+        }
+        o = e->dn_flt;
+        for (int k = 0; k < 3; k++) {
+            const int rb = k ? W2 : W;
+            if (it.mflt) cr[3 + k] = {it.mflt->dev.p + it.mflt->off[k] + (size_t)it.mflt->ls[k] * L.field, dn + o, 2 * it.mflt->ls[k], rb, rb, nr};
+            else cr[3 + k] = {nullptr, nullptr, 0, 0, 0, 0};
+            o += (size_t)rb * nr;
+        }
+        // output_frame's copy, straight into the delivery record
+        Out422Dev &orc = e->orec[it.slot];
+        std::memset(&orc, 0, sizeof(orc));
+        orc.mode = 0xFFFFFFFFu;            // = none
+        if (L.out.data[0]) {
+            any_out = true;
+            for (int k = 0; k < 3; k++) {
+                orc.frame[k] = frm[k]; orc.frame_ls[k] = fls[k];
+                orc.bob[k] = dn + e->dn_out + (k == 0 ? 0 : (size_t)W * H + (k == 2 ? (size_t)W2 * (H + 1) : 0));
+                orc.bob_ls[k] = k ? W2 : W;
+            }
+            orc.field = L.out_field; orc.mode = L.out_mode;
+        }
+    }
+    // slot runs: tickets are consecutive, slots = ticket mod nslots -> at most two runs
+    const int s0 = b.items.front().slot;
+    const int run0 = s0 + n <= e->nslots ? n : e->nslots - s0;
+    if (any_pad) {
+        hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, st, e->prec + s0);
+        if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, st, e->prec);
+    }
+    const uint64_t keep_pos = c->rng_pos;           // the stream advanced at submit; descriptors carry positions
+    int rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
+    c->rng_pos = keep_pos;
+    if (rc != NTSCSIM_OK) return finish(rc);
+    DevParams D;
+    std::memset(&D, 0, sizeof(D));
+    D.W = W; D.H = H; D.variant = 1;
+    if (any_out) {
+        hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)run0), dim3(256), 0, st, D, e->orec + s0, al4 ? 1 : 0);
+        if (run0 < n) hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)(n - run0)), dim3(256), 0, st, D, e->orec, al4 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * run0)), dim3(256), 0, st, e->crec + 6 * (size_t)s0);
+    if (run0 < n) hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * (n - run0))), dim3(256), 0, st, e->crec);
+    er = hipGetLastError();
+    if (er != hipSuccess) { c->err = std::string("submit422 kernels: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    er = hipMemcpyAsync(e->hdn + e->dbytes * (size_t)s0, e->ddn.p + e->dbytes * (size_t)s0, e->dbytes * (size_t)run0,
+                        hipMemcpyDeviceToHost, st);
+    if (er == hipSuccess && run0 < n)
+        er = hipMemcpyAsync(e->hdn, e->ddn.p, e->dbytes * (size_t)(n - run0), hipMemcpyDeviceToHost, st);
+    if (er == hipSuccess) er = hipEventRecord(b.done, st);
+    if (er != hipSuccess) { c->err = std::string("submit422 D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    b.launched_ok = true;
+    e->stats[1]++;
+    return finish(NTSCSIM_OK);
+}
+
+static int h422_validate(const ntscsim_ctx *c, const ntscsim_loop422 *L)
+{
+    if (!c || !L || L->struct_size != sizeof(ntscsim_loop422)) return NTSCSIM_E_ARG;
+    const int W = L->width, H = L->height;
+    if (W < 16 || (W & 1) || H < 2 || W > 16384 || H > 16384) return NTSCSIM_E_SIZE;
+    if (L->field > 1 || L->out_field > 1) return NTSCSIM_E_ARG;
+    if (L->flags & ~(NTSCSIM_422_INTERLACED | NTSCSIM_422_TFF | NTSCSIM_422_SRC420 | NTSCSIM_422_SECOND | NTSCSIM_422_NOCOMP))
+        return NTSCSIM_E_ARG;
+    auto planes = [&](const ntscsim_frame422 &f, int rows_c_min) -> int {
+        (void)rows_c_min;
+        for (int k = 0; k < 3; k++) {
+            if (!f.data[k]) return NTSCSIM_E_ARG;
+            if (f.linesize[k] < (k ? W / 2 : W)) return NTSCSIM_E_SIZE;
+        }
+        return NTSCSIM_OK;
+    };
+    int rc = planes(L->frame, H);
+    if (rc != NTSCSIM_OK) return rc;
+    if (L->src.data[0]) {
+        rc = planes(L->src, 0);
+        if (rc != NTSCSIM_OK) return rc;
+        if (L->src_height < ((L->flags & NTSCSIM_422_INTERLACED) ? 4 : 2) || L->src_height > 16384) return NTSCSIM_E_SIZE;
+    }
+    if (L->filter.data[0]) { rc = planes(L->filter, H); if (rc != NTSCSIM_OK) return rc; }
+    if (L->out.data[0]) {
+        rc = planes(L->out, 0);
+        if (rc != NTSCSIM_OK) return rc;
+        if (L->out_mode > NTSCSIM_OUT422_FRAME) return NTSCSIM_E_ARG;
+    }
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags, uint64_t *ticket)
+{
+    int rc = h422_validate(c, L);
+    if (rc != NTSCSIM_OK) return rc;
+    if (flags & ~(NTSCSIM_SUBMIT_SAME_SRC | NTSCSIM_SUBMIT422_DIRTY)) return NTSCSIM_E_ARG;
+    Host422Engine *e = h422_get(c);
+    if (!e) return NTSCSIM_E_NOMEM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int W = L->width, H = L->height, W2 = W / 2;
+    const bool have_src = L->src.data[0] != nullptr;
+    const bool c420 = (L->flags & NTSCSIM_422_SRC420) != 0;
+    const size_t src_crows = c420 ? ((size_t)L->src_height + 1) / 2 : (size_t)L->src_height;
+    const size_t src_bytes = have_src ? (size_t)W * L->src_height + 2 * (size_t)W2 * src_crows : 0;
+    rc = h422_ensure_rings(c, e, W, H, src_bytes);
+    if (rc != NTSCSIM_OK) return rc;
+
+    if (flags & NTSCSIM_SUBMIT422_DIRTY) {
+        // the caller wrote into frame / filter: deliver what is in flight (it lands in those frames), read them again
+        rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
+        if (rc != NTSCSIM_OK) return rc;
+        for (auto *m : e->mirrors)
+            if (m->host[0] == L->frame.data[0] || m->host[0] == L->filter.data[0]) m->stale = true;
+    }
+    // ring space: ticket t uses slot t mod nslots; its previous user and that one's pair partner must have retired
+    const uint64_t t = e->next_ticket;
+    if (t + 1 > (uint64_t)e->nslots && e->done_ticket < t + 1 - (uint64_t)e->nslots) {
+        e->stats[7]++;
+        rc = h422_wait_ticket(c, t + 1 - (uint64_t)e->nslots);
+        if (rc != NTSCSIM_OK) return rc;
+    }
+    const bool bkey = c->prm.black_key_level_feedback >= 0 && L->filter.data[0] != nullptr;
+    // ---- FAST or SERIAL (see the head of this file)
+    bool serial = !have_src || bkey || L->frame.linesize[0] < W + 2;
+    int fslot = (int)(t % (uint64_t)e->nslots);
+    bool paired = false;
+    if (!serial && !e->pending.empty()) {
+        const Host422Engine::Item &pv = e->pending.back();
+        if (!pv.serial && pv.ticket + 1 == t && pv.it.field != L->field && pv.fslot == pv.slot &&
+            pv.it.frame.data[0] == L->frame.data[0] && pv.it.frame.data[1] == L->frame.data[1] &&
+            pv.it.frame.data[2] == L->frame.data[2] && pv.it.frame.linesize[0] == L->frame.linesize[0]) {
+            fslot = pv.fslot;
+            paired = true;
+        }
+    }
+    // the interlaced repack reads BOTH fields of the frame (:1202-1223): only exact on a device frame that holds
+    // the other field as well
+    // (likewise a bob of the OTHER field's rows: -vi hands output_frame the previous field's parity :1792-1793)
+    if (!serial && L->out.data[0] && (L->out_mode == NTSCSIM_OUT422_INTERLACED420 || L->out_mode == NTSCSIM_OUT422_FRAME || L->out_field != L->field) && !paired)
+        serial = true;
+
+    Host422Engine::Item it;
+    it.ticket = t;
+    it.slot = (int)(t % (uint64_t)e->nslots);
+    it.fslot = fslot;
+    it.serial = serial;
+    it.it = *L;
+    if (serial) {
+        // in order, alone: what is pending goes first
+        rc = h422_launch(c);
+        if (rc != NTSCSIM_OK) return rc;
+        it.mfrm = h422_mirror(c, e, L->frame, H);
+        if (!it.mfrm) return NTSCSIM_E_NOMEM;
+        rc = h422_refresh_mirror(c, e, it.mfrm, W);
+        if (rc != NTSCSIM_OK) return rc;
+        if (bkey) {
+            it.mflt = h422_mirror(c, e, L->filter, H);
+            if (!it.mflt) return NTSCSIM_E_NOMEM;
+            rc = h422_refresh_mirror(c, e, it.mflt, W);
+            if (rc != NTSCSIM_OK) return rc;
+        }
+    } else {
+        // the caller's frame moves on without its mirror
+        for (auto *m : e->mirrors)
+            if (m->host[0] == L->frame.data[0]) m->stale = true;
+        uint8_t *pad = e->pads + (size_t)2 * e->L * (size_t)it.slot;
+        const int nr = h422_field_rows(H, L->field);
+        for (int k = 0; k < nr; k++) {
+            const uint8_t *row = L->frame.data[0] + (size_t)L->frame.linesize[0] * (size_t)(L->field + 2 * k);
+            pad[2 * k] = row[W]; pad[2 * k + 1] = row[W + 1];
+        }
+    }
+    // ---- source snapshot
+    if (have_src) {
+        int sslot = e->src_cur;
+        if (!(flags & NTSCSIM_SUBMIT_SAME_SRC) || sslot < 0) {
+            sslot = (int)(e->src_ring_pos % (uint64_t)e->nslots);
+            const uint64_t last = e->src_last_ticket[(size_t)sslot];
+            if (last > e->done_ticket) {
+                rc = h422_wait_ticket(c, last);
+                if (rc != NTSCSIM_OK) return rc;
+            }
+            uint8_t *hs = e->hsrc + e->sbytes * (size_t)sslot;
+            uint8_t *o = hs;
+            for (int k = 0; k < 3; k++) {
+                const size_t rb = k ? (size_t)W2 : (size_t)W, nr = k ? src_crows : (size_t)L->src_height;
+                if ((size_t)L->src.linesize[k] == rb) std::memcpy(o, L->src.data[k], rb * nr);
+                else for (size_t r = 0; r < nr; r++) std::memcpy(o + rb * r, L->src.data[k] + (size_t)L->src.linesize[k] * r, rb);
+                o += rb * nr;
+            }
+            HIPCHK(c, hipMemcpyAsync(e->dsrc.p + e->sbytes * (size_t)sslot, hs, src_bytes, hipMemcpyHostToDevice, e->s_up));
+            e->src_ring_pos++;
+            e->src_cur = sslot;
+            e->stats[2]++;
+        }
+        it.sslot = sslot;
+        e->src_last_ticket[(size_t)sslot] = t;
+    }
+    it.rng_pos = c->rng_pos;
+    if (!(L->flags & NTSCSIM_422_NOCOMP)) c->rng_pos += ntscsim_rng_calls_per_field_422(&c->prm, W, H, L->field);
+    e->pending.push_back(it);
+    e->next_ticket++;
+    e->stats[0]++;
+    e->stats[serial ? 4 : 3]++;
+    if (ticket) *ticket = t;
+    if (serial) return h422_launch(c);
+    // a launch at `depth` iterations -- but not between the two fields of a pair (the second one shares the first
+    // one's device frame while that is still pending)
+    const size_t np = e->pending.size();
+    if ((int)np >= e->depth && (L->field == 0 || (int)np > e->depth)) return h422_launch(c);
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_field422(ntscsim_ctx *c, const ntscsim_loop422 *L)
+{
+    uint64_t t = 0;
+    int rc = ntscsim_submit422(c, L, 0, &t);
+    if (rc != NTSCSIM_OK) return rc;
+    return h422_wait_ticket(c, t);
+}
+
+extern "C" int ntscsim_submit422_configure(ntscsim_ctx *c, int depth, int slots)
+{
+    if (!c || depth < 1 || depth > 4096) return NTSCSIM_E_ARG;
+    if (slots == 0) slots = 4 * depth;
+    if (slots < 2 * depth + 2 || slots > 65536) return NTSCSIM_E_ARG;
+    Host422Engine *e = h422_get(c);
+    if (!e) return NTSCSIM_E_NOMEM;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    if (rc != NTSCSIM_OK) return rc;
+    h422_release_rings(e);
+    e->depth = depth; e->nslots = slots;
+    return NTSCSIM_OK;
+}
+
+extern "C" void ntscsim_submit422_stats(const ntscsim_ctx *c, uint64_t out[8])
+{
+    if (!out) return;
+    for (int i = 0; i < 8; i++) out[i] = (c && c->h422) ? c->h422->stats[i] : 0;
+}

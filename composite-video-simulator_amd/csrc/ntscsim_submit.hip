@@ -75,12 +75,16 @@ struct SubmitEngine {
         int src_slot, dst_slot;
         uint8_t *host_dst;        // caller's frame
         uint8_t *host_dst_dev;    // its device-visible address when pinned, else NULL (staged)
+        bool direct;              // the decoder writes its rows straight into the caller's pinned frame (no ring, no k_deliver)
         int dst_ls;
         unsigned field;
         uint32_t flags;
         uint64_t fieldno, rng_pos;
     };
     std::vector<Item> pending;
+    std::vector<uint64_t> pending_deps;   // first tickets of launches in flight that the pending one must follow (shared dst rows)
+    // NTSCSIM_SUBMIT_DIRECT=0: A/B switch back to the device destination ring + k_deliver for every field
+    bool direct_ok = !(std::getenv("NTSCSIM_SUBMIT_DIRECT") && std::getenv("NTSCSIM_SUBMIT_DIRECT")[0] == '0');
     struct Batch {
         uint64_t first = 0, last = 0;
         hipEvent_t up = nullptr, done = nullptr;
@@ -239,6 +243,16 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
     if (span < (64u << 10) || a0 < (uintptr_t)sbrk(0)) return nullptr;
     for (auto &r : e->regs)
         if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
+    // ... nor a block inside one of glibc's non-main arenas or a pool of the caller's (they sit above the break too and
+    // can start near a page boundary by chance): a block that does not start ON a page boundary must carry the header
+    // of a chunk with a mapping of its own -- glibc keeps IS_MMAPPED (bit 1) in the size word in front of the pointer
+    // malloc / posix_memalign returned, for aligned blocks as well.  (Page-aligned buffers own their first page by
+    // construction.)  Anything that fails the test is staged, which is always safe.
+    if ((a0 & 4095u) >= sizeof(size_t)) {
+        size_t hdr;
+        std::memcpy(&hdr, (const void *)(a0 - sizeof(size_t)), sizeof(hdr));
+        if (!(hdr & 2u)) return nullptr;
+    } else if (a0 & 4095u) return nullptr;
     const uintptr_t PG = 4096;
     const uintptr_t p0 = a0 & ~(PG - 1), p1 = (a1 + PG - 1) & ~(PG - 1);
     for (auto &r : e->regs)
@@ -254,6 +268,15 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
         (void)hipGetLastError();
         if (owned) (void)hipHostUnregister((void *)p0);
         return nullptr;
+    }
+    if (!owned) {
+        // pinned by the caller: trust it only if its registration is seen to cover the frame's last page as well, at the
+        // same offset
+        void *dev_last = nullptr;
+        if (hipHostGetDevicePointer(&dev_last, (void *)(p1 - PG), 0) != hipSuccess || dev_last != (uint8_t *)dev + (p1 - PG - p0)) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
     }
     e->regs.push_back({p0, p1, (uint8_t *)dev, owned});
     e->stats[6] = e->regs.size();
@@ -288,6 +311,21 @@ extern "C" void ntscsim_submit_stats(const ntscsim_ctx *c, uint64_t out[8])
     if (!out) return;
     for (int i = 0; i < 8; i++) out[i] = (c && c->sub) ? c->sub->stats[i] : 0;
 }
+
+// Do two fields in flight write the same bytes of a caller frame?  (rows: 0 / 1 = the rows of that parity, 2 = every
+// row: line doubling.)  The two fields of one frame do not; anything else that overlaps is ordered by the engine:
+// the header promises delivery in submit order.
+static bool sub_dst_conflict(const uint8_t *a, int a_ls, unsigned a_rows, const uint8_t *b, int b_ls, unsigned b_rows,
+                             int W, int H)
+{
+    const uintptr_t a0 = (uintptr_t)a, a1 = a0 + (size_t)a_ls * (size_t)(H - 1) + (size_t)W * 4;
+    const uintptr_t b0 = (uintptr_t)b, b1 = b0 + (size_t)b_ls * (size_t)(H - 1) + (size_t)W * 4;
+    if (a1 <= b0 || b1 <= a0) return false;
+    if (a_rows == 2u || b_rows == 2u) return true;
+    if (a0 == b0 && a_ls == b_ls) return a_rows == b_rows;
+    return true;          // overlapping views that are not the same frame: assume the worst
+}
+static unsigned sub_item_rows(uint32_t flags, unsigned field) { return (flags & NTSCSIM_DESC_BOB) ? 2u : (field & 1u); }
 
 // rows the synchronous call + (optionally) the loop's line doubling write: first row, step, count
 static void sub_rows(int H, unsigned field, bool bob, int &row0, int &step, int &n)
@@ -394,24 +432,34 @@ static int sub_launch(ntscsim_ctx *c)
         ntscsim_debug_set_warmup(lane, c->warm_override[0], c->warm_override[1]);
 
     std::vector<ntscsim_field_desc> descs((size_t)n);
-    bool any_staged = false, any_direct = false;
+    bool any_staged = false, any_direct = false;     // any_direct: pinned frames served by k_deliver (line doubling, unaligned)
+    int n_direct = 0;                                // pinned frames the decoder writes itself
     for (int i = 0; i < n; i++) {
         const SubmitEngine::Item &it = b.items[(size_t)i];
         ntscsim_field_desc &d = descs[(size_t)i];
         std::memset(&d, 0, sizeof(d));
         d.src_dev = e->dsrc.p + e->fbytes * (size_t)it.src_slot;
-        d.dst_dev = e->ddst.p + e->fbytes * (size_t)it.dst_slot;
-        d.src_linesize = d.dst_linesize = (int)e->pitch;
+        d.src_linesize = (int)e->pitch;
+        if (it.direct) { d.dst_dev = it.host_dst_dev; d.dst_linesize = it.dst_ls; }      // rows leave the decoder over the link
+        else { d.dst_dev = e->ddst.p + e->fbytes * (size_t)it.dst_slot; d.dst_linesize = (int)e->pitch; }
         d.field = it.field;
         // (no NTSCSIM_DESC_BOB: the line doubling happens on the way out -- k_deliver's row map, or the host copy of a
         //  staged frame -- so the device frame only ever holds the field's own rows)
         d.flags = it.flags & (NTSCSIM_DESC_INTERLACED | NTSCSIM_DESC_TFF);
         d.fieldno = it.fieldno;
         d.rng_pos = it.rng_pos;
-        if (it.host_dst_dev) any_direct = true; else any_staged = true;
+        if (it.direct) n_direct++;
+        else if (it.host_dst_dev) any_direct = true;
+        else any_staged = true;
     }
     hipError_t er = hipEventRecord(b.up, e->s_up);
     if (er == hipSuccess) er = hipStreamWaitEvent(lane->stream, b.up, 0);
+    // launches in flight that write the same rows of the same caller frame come first (delivery in submit order)
+    for (uint64_t dep : e->pending_deps)
+        for (const auto &ob : e->inflight)
+            if (ob.first == dep && ob.launched_ok && ob.lane != li && er == hipSuccess)
+                er = hipStreamWaitEvent(lane->stream, ob.done, 0);
+    e->pending_deps.clear();
     b.lane = li;
     if (e->timing) {
         if (!e->tref) { (void)hipEventCreate(&e->tref); (void)hipEventRecord(e->tref, lane->stream); }
@@ -429,7 +477,7 @@ static int sub_launch(ntscsim_ctx *c)
         // consecutive records: one k_deliver per run
         bool vec16 = ((e->W * 4) & 15) == 0;
         for (const auto &it : b.items) {
-            if (!it.host_dst_dev) continue;
+            if (!it.host_dst_dev || it.direct) continue;
             DeliverRec &r = e->recs[it.dst_slot];
             r.dev = e->ddst.p + e->fbytes * (size_t)it.dst_slot;
             r.host = it.host_dst_dev;
@@ -440,10 +488,11 @@ static int sub_launch(ntscsim_ctx *c)
         }
         size_t i = 0;
         int nd = 0;
+        auto via_kernel = [](const SubmitEngine::Item &x) { return x.host_dst_dev && !x.direct; };
         while (i < b.items.size()) {
-            if (!b.items[i].host_dst_dev) { i++; continue; }
+            if (!via_kernel(b.items[i])) { i++; continue; }
             size_t j = i + 1;
-            while (j < b.items.size() && b.items[j].host_dst_dev && b.items[j].dst_slot == b.items[j - 1].dst_slot + 1) j++;
+            while (j < b.items.size() && via_kernel(b.items[j]) && b.items[j].dst_slot == b.items[j - 1].dst_slot + 1) j++;
             hipLaunchKernelGGL(k_deliver, dim3(16, (unsigned)(j - i)), dim3(256), 0, lane->stream,
                                e->recs + b.items[i].dst_slot, e->W * 4, vec16 ? 1 : 0);
             nd += (int)(j - i);
@@ -453,6 +502,7 @@ static int sub_launch(ntscsim_ctx *c)
         if (er != hipSuccess) { c->err = std::string("k_deliver: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
         e->stats[4] += (uint64_t)nd;
     }
+    e->stats[4] += (uint64_t)n_direct;
     if (any_staged) {
         rc = sub_ensure_staging(c, e, false);
         if (rc != NTSCSIM_OK) return finish(rc);
@@ -480,14 +530,25 @@ static int sub_launch(ntscsim_ctx *c)
 extern "C" int ntscsim_flush(ntscsim_ctx *c)
 {
     if (!c) return NTSCSIM_E_ARG;
-    if (!c->sub) return NTSCSIM_OK;
+    if (!c->sub && !c->h422) return NTSCSIM_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    return sub_launch(c);
+    int rc = c->sub ? sub_launch(c) : NTSCSIM_OK;
+    if (c->h422) { const int r = h422_launch(c); if (rc == NTSCSIM_OK) rc = r; }
+    return rc;
 }
 
 extern "C" int ntscsim_wait(ntscsim_ctx *c, uint64_t ticket)
 {
     if (!c) return NTSCSIM_E_ARG;
+    // a ctx serves one of the two tools: tickets of ntscsim_submit422() (ntscsim_host422.hip) are waited for here too
+    if (c->h422) {
+        HIPCHK(c, hipSetDevice(c->device));
+        if (!c->sub) return h422_wait_ticket(c, ticket);
+        if (ticket != NTSCSIM_TICKET_ALL) return NTSCSIM_E_ARG;      // two ticket sequences on one ctx: only "all" is unambiguous
+        const int r = h422_wait_ticket(c, ticket);
+        const int r2 = sub_wait_ticket(c, ticket);
+        return r != NTSCSIM_OK ? r : r2;
+    }
     if (!c->sub) return ticket == NTSCSIM_TICKET_ALL ? NTSCSIM_OK : NTSCSIM_E_ARG;
     if (ticket != NTSCSIM_TICKET_ALL && ticket <= c->sub->done_ticket && ticket != 0) return NTSCSIM_OK;
     HIPCHK(c, hipSetDevice(c->device));
@@ -563,6 +624,29 @@ extern "C" int ntscsim_submit(ntscsim_ctx *c, const uint8_t *src, int src_ls, in
     it.host_dst = dst;
     it.host_dst_dev = sub_pinned(c, e, dst, dspan);
     it.dst_ls = dst_ls;
+    // the decoder's 64-byte row bursts go straight into a pinned, 16-byte aligned frame; line doubling (every row written
+    // twice) and unaligned frames keep the device ring + k_deliver
+    it.direct = e->direct_ok && it.host_dst_dev && !(flags & NTSCSIM_DESC_BOB) &&
+                !(((uintptr_t)it.host_dst_dev | (uintptr_t)dst_ls) & 15);
+    {
+        // delivery in submit order for fields that write the same rows of the same frame: the pending launch goes out
+        // first, and the next one waits for every launch in flight that holds such a field
+        const unsigned rows = sub_item_rows(flags, field);
+        bool clash = false;
+        for (const auto &pi : e->pending)
+            if (sub_dst_conflict(dst, dst_ls, rows, pi.host_dst, pi.dst_ls, sub_item_rows(pi.flags, pi.field), W, H)) { clash = true; break; }
+        if (clash) {
+            rc = sub_launch(c);
+            if (rc != NTSCSIM_OK) return rc;
+        }
+        for (const auto &ob : e->inflight) {
+            bool hit = false;
+            for (const auto &oi : ob.items)
+                if (sub_dst_conflict(dst, dst_ls, rows, oi.host_dst, oi.dst_ls, sub_item_rows(oi.flags, oi.field), W, H)) { hit = true; break; }
+            if (hit && std::find(e->pending_deps.begin(), e->pending_deps.end(), ob.first) == e->pending_deps.end())
+                e->pending_deps.push_back(ob.first);
+        }
+    }
     it.field = field;
     it.flags = (flags & NTSCSIM_DESC_BOB) | (src_interlaced ? NTSCSIM_DESC_INTERLACED : 0u) | (src_tff ? NTSCSIM_DESC_TFF : 0u);
     it.fieldno = fieldno;

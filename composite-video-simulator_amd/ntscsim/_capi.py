@@ -41,6 +41,7 @@ EXPORTS = (
     "ntscsim_raw28_debug_read_front",
     "ntscsim_submit_opts_init", "ntscsim_submit_configure", "ntscsim_submit", "ntscsim_flush", "ntscsim_wait",
     "ntscsim_host_unpin", "ntscsim_submit_stats",
+    "ntscsim_field422", "ntscsim_submit422", "ntscsim_submit422_configure", "ntscsim_submit422_stats",
     "ntscsim_pool_create", "ntscsim_pool_destroy", "ntscsim_pool_size", "ntscsim_pool_ctx", "ntscsim_pool_set_block",
     "ntscsim_pool_get_rng_pos", "ntscsim_pool_set_rng_pos", "ntscsim_pool_last_error", "ntscsim_pool_frames_host",
 )
@@ -50,6 +51,22 @@ class SubmitOpts(C.Structure):
     """struct ntscsim_submit_opts -- keep in lock-step with include/ntscsim.h."""
     _fields_ = [("struct_size", C.c_uint32), ("depth", C.c_int32), ("slots", C.c_int32), ("lanes", C.c_int32),
                 ("pin_caller_buffers", C.c_int32), ("_pad", C.c_int32), ("min_pin_bytes", C.c_size_t)]
+
+
+class Frame422(C.Structure):
+    """struct ntscsim_frame422 -- keep in lock-step with include/ntscsim.h."""
+    _fields_ = [("data", C.c_void_p * 3), ("linesize", C.c_int32 * 3), ("_pad", C.c_int32)]
+
+
+class Loop422(C.Structure):
+    """struct ntscsim_loop422 -- keep in lock-step with include/ntscsim.h."""
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32), ("src_height", C.c_int32),
+                ("frame", Frame422), ("src", Frame422), ("filter", Frame422), ("out", Frame422),
+                ("field", C.c_uint32), ("flags", C.c_uint32), ("out_mode", C.c_uint32), ("out_field", C.c_uint32),
+                ("fieldno", C.c_uint64)]
+
+
+SUBMIT422_DIRTY = 0x40000
 
 
 class Raw28Opts(C.Structure):
@@ -150,7 +167,7 @@ class Out422Desc(C.Structure):
     ]
 
 
-OUT422_BOB422, OUT422_BOB420, OUT422_INTERLACED420 = 0, 1, 2
+OUT422_BOB422, OUT422_BOB420, OUT422_INTERLACED420, OUT422_FRAME = 0, 1, 2, 3
 
 
 class YuvDesc(C.Structure):
@@ -344,6 +361,14 @@ def lib():
     L.ntscsim_host_unpin.restype = C.c_int
     L.ntscsim_submit_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ntscsim_submit_stats.restype = None
+    L.ntscsim_field422.argtypes = [C.c_void_p, C.POINTER(Loop422)]
+    L.ntscsim_field422.restype = C.c_int
+    L.ntscsim_submit422.argtypes = [C.c_void_p, C.POINTER(Loop422), C.c_uint32, C.POINTER(C.c_uint64)]
+    L.ntscsim_submit422.restype = C.c_int
+    L.ntscsim_submit422_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ntscsim_submit422_configure.restype = C.c_int
+    L.ntscsim_submit422_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ntscsim_submit422_stats.restype = None
     L.ntscsim_pool_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
     L.ntscsim_pool_create.restype = C.c_int
     L.ntscsim_pool_destroy.argtypes = [C.c_void_p]

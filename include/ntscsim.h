@@ -481,6 +481,77 @@ int  ntscsim_batch422_create(ntscsim_ctx *ctx, const ntscsim_field422_desc *desc
 int  ntscsim_batch422_run(ntscsim_batch422 *batch, void *hip_stream);
 void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
 
+/*
+ * The same loop iteration on HOST frames -- the drop-in for the tool's own call sequence
+ *     render_field(output_avstream_video_frame, output_avstream_video_input_frame, field, video_field, tgt_pts);  :1784
+ *     if (black_key_level_feedback >= 0) black_key_feedback(frame, output_avstream_video_filter_frame, ...);      :1787
+ *     if (enable_composite_emulation) composite_video_process(frame, field, video_field);   :1790 (signature :629)
+ *     output_frame(frame, video_field, field);          :1793 / :1796 -- its pixel work, the copy loops :1177-1236
+ * of ffmpeg_to_composite.cpp:1783-1800, on the planes an AVFrame holds (data[0..2], linesize[0..2]).
+ * ntscsim_field422() is synchronous; ntscsim_submit422() returns at once with a ticket and ntscsim_wait(ctx,
+ * ticket) / ntscsim_flush(ctx) (above) complete / launch it -- a ctx serves ONE of the two tools, its tickets
+ * come from one sequence.  include/ntscsim_avframe.h wraps both for real AVFrames; INTEGRATION.md section 5
+ * has the patch of the loop and host/field_loop422.cpp is that loop in C++.
+ *
+ * Contract (what makes submits + waits byte-identical to the same sequence of synchronous calls, and those to
+ * the tool's own calls on the same buffers; rand() position included):
+ *   - `frame` is the tool's ONE persistent YUV422P frame, processed in place: the rows of `field` are written
+ *     (render, key, composite emulation), the separator's read of two bytes behind each luma row (:496) sees
+ *     the caller's own bytes as in ntscsim_fields422_device().  The engine keeps device copies of the frames it
+ *     has seen: between calls the caller must not modify `frame` / `filter` -- or pass NTSCSIM_SUBMIT422_DIRTY
+ *     with the next call (everything in flight is then delivered first and the frames are read again).
+ *   - `src` (render_field's source: output_width wide, src_height rows, 4:2:2 or with NTSCSIM_422_SRC420 4:2:0)
+ *     is SNAPSHOTTED by the call; data[0] == NULL: no render_field (the frame is processed as it stands).
+ *     NTSCSIM_SUBMIT_SAME_SRC: src still holds the frame of the previous submit422 (second field of a frame).
+ *   - `filter`: the black-key feedback frame, used when params.black_key_level_feedback >= 0 and data[0] != NULL;
+ *     its rows of `field` are updated like the tool's.
+ *   - `out` (data[0] == NULL: no output_frame call): the frame output_frame() hands to its encoder -- YUV422P
+ *     (NTSCSIM_OUT422_BOB422) or YUV420P, chroma planes (height + 1) / 2 rows -- written per `out_mode` from
+ *     the rows of `out_field` (the tool passes video_field's parity, or with -vi the previous field's, :1792-1796).
+ *     Rows inside the planes only: the interlaced 4:2:0 repack's one chroma row past the plane for a height of
+ *     2 mod 4 (:1215-1223, lands in the AVFrame's padding in the tool) is not written.
+ *   - results are in the caller's memory when ntscsim_wait(ticket) returns, delivered in submit order; frame,
+ *     filter and out must not be touched between submit and wait.  With one persistent `frame` and several
+ *     fields in flight the frame holds the LAST delivered version of each row -- consume `out` (a ring of
+ *     encoder frames) rather than `frame`, as the tool does.
+ *   - iterations that render from a source into rows padded by >= 2 bytes, without black-key feedback, run
+ *     `depth` at a time (default 32); everything else (no source, linesize[0] < width + 2, feedback: a
+ *     frame-to-frame recurrence, an interlaced repack whose other field was not submitted right before it)
+ *     runs one at a time, in order -- exact, and as slow as the synchronous call.
+ * Errors: as ntscsim_fields422_device(); a refused call consumes no ticket and no rand() draws.
+ */
+typedef struct ntscsim_frame422 {    /* AVFrame::data[0..2] / linesize[0..2] of a planar YUV frame in host memory */
+    uint8_t *data[3];
+    int32_t  linesize[3];
+    int32_t  _pad;
+} ntscsim_frame422;
+
+typedef struct ntscsim_loop422 {
+    uint32_t struct_size;            /* sizeof(ntscsim_loop422)                                          */
+    int32_t  width, height;          /* output_width x output_height: the size of frame, filter, out     */
+    int32_t  src_height;             /* rows of src (its width is `width`)                               */
+    ntscsim_frame422 frame;          /* output_avstream_video_frame                                      */
+    ntscsim_frame422 src;            /* output_avstream_video_input_frame, or data[0] == NULL            */
+    ntscsim_frame422 filter;         /* output_avstream_video_filter_frame, or data[0] == NULL           */
+    ntscsim_frame422 out;            /* output_avstream_video_bob_frame / the encoder frame, or NULL     */
+    uint32_t field;                  /* (video_field & 1) ^ 1                                            */
+    uint32_t flags;                  /* NTSCSIM_422_*                                                    */
+    uint32_t out_mode;               /* NTSCSIM_OUT422_* (below)                                         */
+    uint32_t out_field;              /* output_frame()'s `field` argument                                */
+    uint64_t fieldno;                /* video_field                                                      */
+} ntscsim_loop422;
+
+#define NTSCSIM_SUBMIT422_DIRTY 0x40000u   /* the caller changed frame / filter since the engine last saw them */
+
+int ntscsim_field422(ntscsim_ctx *ctx, const ntscsim_loop422 *it);
+int ntscsim_submit422(ntscsim_ctx *ctx, const ntscsim_loop422 *it, uint32_t submit_flags, uint64_t *ticket);
+/* Optional: iterations per launch (1..4096, default 32) and iterations that may be in flight (0: 4 * depth;
+ * >= 2 * depth + 2).  Waits for everything in flight first. */
+int ntscsim_submit422_configure(ntscsim_ctx *ctx, int depth, int slots);
+/* [0] submitted [1] launches [2] source uploads [3] batched iterations [4] one-at-a-time iterations
+ * [5] frame (re)uploads [7] submits that blocked on a full ring */
+void ntscsim_submit422_stats(const ntscsim_ctx *ctx, uint64_t out[8]);
+
 
 /*
  * The pixel work of output_frame() ffmpeg_to_composite.cpp:1131, lines :1177-1236: line-double
@@ -499,6 +570,8 @@ void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
 #define NTSCSIM_OUT422_BOB422        0u
 #define NTSCSIM_OUT422_BOB420        1u
 #define NTSCSIM_OUT422_INTERLACED420 2u
+#define NTSCSIM_OUT422_FRAME         3u   /* 4:2:2 with -interlaced: the tool encodes the processed frame itself (:1158);
+                                             a 1:1 copy, for callers that keep several fields in flight (ntscsim_submit422) */
 
 typedef struct ntscsim_out422_desc {
     const void *frame_dev[3];       /* processed YUV422P frame (the dst of ntscsim_fields422_device) */

@@ -67,6 +67,74 @@ static inline int ntscsim_submit_avframe(ntscsim_ctx *ctx, NTSCSIM_AVFRAME_T *ds
                           dstframe->width, dstframe->height, field, fieldno, flags, ticket);
 }
 
+/* ---- the YUV422P tool, ffmpeg_to_composite.cpp:1783-1800 on its own AVFrames -------------------------------
+ * One loop iteration -- render_field :1784, black_key_feedback :1787, composite_video_process :1790 (signature
+ * :629: AVFrame *dst, unsigned field, unsigned long long fieldno) and the copy loops of output_frame :1793-1796
+ * (:1177-1236) -- as ONE call.  Arguments are the tool's own objects:
+ *   frame        output_avstream_video_frame (YUV422P)
+ *   input_frame  output_avstream_video_input_frame (what sws_scale wrote, :1770-1778; 4:2:0 when the decoder's
+ *                format is, :1707-1719 -- pass src_is_420 accordingly) or NULL for "no render"
+ *   filter_frame output_avstream_video_filter_frame, or NULL
+ *   enc_frame    the frame output_frame() fills for its encoder (output_avstream_video_bob_frame), or NULL
+ *   second       field_number - src_pts >= ticks_per_frame / 2 (:1035): second field of the source frame
+ *   out_mode / out_field: NTSCSIM_OUT422_* and output_frame()'s `field` argument
+ * ntscsim_loop422_from_avframes() fills the POD; ntscsim_field422_avframe() / ntscsim_submit422_avframe() call it. */
+static inline int ntscsim_loop422_from_avframes(ntscsim_loop422 *it, NTSCSIM_AVFRAME_T *frame,
+                                                const NTSCSIM_AVFRAME_T *input_frame, int src_is_420, int second,
+                                                NTSCSIM_AVFRAME_T *filter_frame, NTSCSIM_AVFRAME_T *enc_frame,
+                                                uint32_t out_mode, unsigned out_field, int nocomp,
+                                                unsigned field, uint64_t fieldno)
+{
+    int k;
+    if (it == 0 || frame == 0) return NTSCSIM_E_ARG;
+    for (k = 0; k < (int)sizeof(*it); k++) ((unsigned char *)it)[k] = 0;
+    it->struct_size = (uint32_t)sizeof(*it);
+    it->width = frame->width; it->height = frame->height;
+    for (k = 0; k < 3; k++) { it->frame.data[k] = frame->data[k]; it->frame.linesize[k] = frame->linesize[k]; }
+    if (input_frame != 0) {
+        if (input_frame->width != frame->width) return NTSCSIM_E_SIZE;
+        it->src_height = input_frame->height;
+        for (k = 0; k < 3; k++) { it->src.data[k] = input_frame->data[k]; it->src.linesize[k] = input_frame->linesize[k]; }
+        it->flags |= (input_frame->interlaced_frame ? NTSCSIM_422_INTERLACED : 0u) |
+                     (input_frame->top_field_first ? NTSCSIM_422_TFF : 0u) | (src_is_420 ? NTSCSIM_422_SRC420 : 0u) |
+                     (second ? NTSCSIM_422_SECOND : 0u);
+    }
+    if (nocomp) it->flags |= NTSCSIM_422_NOCOMP;
+    if (filter_frame != 0)
+        for (k = 0; k < 3; k++) { it->filter.data[k] = filter_frame->data[k]; it->filter.linesize[k] = filter_frame->linesize[k]; }
+    if (enc_frame != 0) {
+        if (enc_frame->width != frame->width || enc_frame->height != frame->height) return NTSCSIM_E_SIZE;
+        for (k = 0; k < 3; k++) { it->out.data[k] = enc_frame->data[k]; it->out.linesize[k] = enc_frame->linesize[k]; }
+    }
+    it->out_mode = out_mode; it->out_field = out_field;
+    it->field = field; it->fieldno = fieldno;
+    return NTSCSIM_OK;
+}
+
+static inline int ntscsim_field422_avframe(ntscsim_ctx *ctx, NTSCSIM_AVFRAME_T *frame,
+                                           const NTSCSIM_AVFRAME_T *input_frame, int src_is_420, int second,
+                                           NTSCSIM_AVFRAME_T *filter_frame, NTSCSIM_AVFRAME_T *enc_frame,
+                                           uint32_t out_mode, unsigned out_field, int nocomp,
+                                           unsigned field, uint64_t fieldno)
+{
+    ntscsim_loop422 it;
+    const int rc = ntscsim_loop422_from_avframes(&it, frame, input_frame, src_is_420, second, filter_frame, enc_frame,
+                                                 out_mode, out_field, nocomp, field, fieldno);
+    return rc != NTSCSIM_OK ? rc : ntscsim_field422(ctx, &it);
+}
+
+static inline int ntscsim_submit422_avframe(ntscsim_ctx *ctx, NTSCSIM_AVFRAME_T *frame,
+                                            const NTSCSIM_AVFRAME_T *input_frame, int src_is_420, int second,
+                                            NTSCSIM_AVFRAME_T *filter_frame, NTSCSIM_AVFRAME_T *enc_frame,
+                                            uint32_t out_mode, unsigned out_field, int nocomp,
+                                            unsigned field, uint64_t fieldno, uint32_t submit_flags, uint64_t *ticket)
+{
+    ntscsim_loop422 it;
+    const int rc = ntscsim_loop422_from_avframes(&it, frame, input_frame, src_is_420, second, filter_frame, enc_frame,
+                                                 out_mode, out_field, nocomp, field, fieldno);
+    return rc != NTSCSIM_OK ? rc : ntscsim_submit422(ctx, &it, submit_flags, ticket);
+}
+
 #ifdef __cplusplus
 }
 #endif

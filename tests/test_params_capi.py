@@ -129,7 +129,8 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
                "ntscsim_field422_desc": _capi.Field422Desc, "ntscsim_out422_desc": _capi.Out422Desc,
                "ntscsim_yuv_desc": _capi.YuvDesc, "ntscsim_scale_desc": _capi.ScaleDesc,
                "ntscsim_host_source": _capi.HostSource, "ntscsim_raw28_opts": _capi.Raw28Opts,
-               "ntscsim_submit_opts": _capi.SubmitOpts}
+               "ntscsim_submit_opts": _capi.SubmitOpts, "ntscsim_frame422": _capi.Frame422,
+               "ntscsim_loop422": _capi.Loop422}
     lines = ['#include "ntscsim.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
     for cname, mirror in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -173,8 +174,22 @@ int main(void) {
     static uint8_t buf[64 * 4 * 8];
     struct my_frame a = {{buf}, {64 * 4}, 64, 8, 0, 0, 0}, b = a, c = a, d = a;
     c.width = 32; d.linesize[0] = 100;
-    int r[10];
+    int r[16];
     uint64_t ticket = 77;
+    /* the YUV422P tool's iteration on AVFrames (ffmpeg_to_composite.cpp:1783-1800) */
+    static uint8_t yuv[3][64 * 8];
+    struct my_frame f = {{yuv[0], yuv[1], yuv[2]}, {64, 32, 32}, 64, 8, 0, 1, 1}, g = f;
+    ntscsim_loop422 it;
+    g.width = 32;
+    r[10] = ntscsim_loop422_from_avframes(&it, &f, &f, 1, 1, 0, &f, NTSCSIM_OUT422_BOB420, 1, 1, 1, 7);
+    r[11] = it.struct_size == sizeof(it) && it.width == 64 && it.height == 8 && it.src_height == 8 &&
+            it.frame.data[2] == yuv[2] && it.src.linesize[1] == 32 && it.out.data[0] == yuv[0] && it.filter.data[0] == 0 &&
+            it.flags == (NTSCSIM_422_INTERLACED | NTSCSIM_422_TFF | NTSCSIM_422_SRC420 | NTSCSIM_422_SECOND | NTSCSIM_422_NOCOMP) &&
+            it.out_mode == NTSCSIM_OUT422_BOB420 && it.out_field == 1 && it.field == 1 && it.fieldno == 7;
+    r[12] = ntscsim_field422_avframe(0, &f, &g, 0, 0, 0, 0, 0, 0, 0, 1, 0);        /* source of another width */
+    r[13] = ntscsim_submit422_avframe(0, &f, 0, 0, 0, 0, &g, 0, 0, 0, 1, 0, 0, &ticket);   /* encoder frame of another size */
+    r[14] = ntscsim_field422_avframe(0, &f, &f, 0, 0, 0, 0, 0, 0, 0, 1, 0);        /* NULL ctx */
+    r[15] = ntscsim_field422_avframe(0, 0, &f, 0, 0, 0, 0, 0, 0, 0, 1, 0);
     r[0] = ntscsim_field_avframe(0, 0, &a, 0, 0);
     r[1] = ntscsim_field_avframe(0, &a, &c, 0, 0);
     r[2] = ntscsim_field_avframe(0, &d, &b, 0, 0);
@@ -187,7 +202,8 @@ int main(void) {
     r[9] = ticket == 77 && ntscsim_wait(0, 1) == NTSCSIM_E_ARG && ntscsim_flush(0) == NTSCSIM_E_ARG;
     b.data[0] = 0;
     r[4] = ntscsim_field_avframe(0, &a, &b, 0, 0);
-    printf("%d %d %d %d %d %d %d %d %d %d\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9]);
+    printf("%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9],
+           r[10], r[11], r[12], r[13], r[14], r[15]);
     return 0;
 }
 ''')
@@ -197,7 +213,8 @@ int main(void) {
                            "-L", L.PKG, "-lntscsim", "-Wl,-rpath," + L.PKG])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert [int(x) for x in out] == [_capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, 1, _capi.E_ARG,
-                                     _capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, _capi.E_ARG, 1]
+                                     _capi.E_ARG, _capi.E_SIZE, _capi.E_SIZE, _capi.E_ARG, 1,
+                                     _capi.OK, 1, _capi.E_SIZE, _capi.E_SIZE, _capi.E_ARG, _capi.E_ARG]
     if shutil.which("g++"):
         cpp = tmp_path / "av.cpp"
         cpp.write_text(src.read_text())

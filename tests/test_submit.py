@@ -176,6 +176,35 @@ def test_two_fields_in_flight_share_one_destination_frame():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bob", [False, True])
+@pytest.mark.parametrize("lanes,pin", [(1, True), (3, True), (3, False)])
+def test_fields_in_flight_on_one_frame_land_in_submit_order(bob, lanes, pin):
+    """The header's promise: fields in flight that write the same rows of ONE dst frame -- every field
+    with line doubling, every second field without -- are delivered in submit order, whatever lane their launch
+    ran on: after the last wait the frame is the synchronous loop's (the reference with `-d 1` :2070, :2277)."""
+    w, h, n = 192, 96, 30
+    p = L.make_params(["-vhs"], output_height=h)
+    frames = [L.noise_frame(w, h, 40 + j) for j in range(n // 2)]
+    exp, exp_pos = reference_loop(p, frames, n, w, h, 1, bob)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.submit_configure(depth=3, slots=32, lanes=lanes, pin=pin, min_pin_bytes=0)
+    src = page_frame(h, w)
+    dst = page_frame(h, w, 0x5A)
+    for k in range(n):
+        if k % 2 == 0:
+            src[:] = frames[k // 2]
+        sim.submit(dst, src, (k & 1) ^ 1, k, bob=bob, same_src=(k % 2 == 1))
+        if k == 17:                  # somewhere in the middle the frame is looked at: everything up to here, in order
+            sim.wait()
+            assert np.array_equal(dst, exp[k]), "after field %d" % k
+    sim.wait()
+    assert np.array_equal(dst, exp[n - 1])
+    assert sim.rng_pos == exp_pos
+    sim.host_unpin()
+    sim.close()
+
+
+@pytest.mark.gpu
 def test_geometry_change_unaligned_rows_and_interlaced_source():
     """A width whose rows are not 16-byte aligned (generic kernels, 4-byte delivery), then another geometry on
     the same ctx (the engine drains and rebuilds its rings), interlaced source flags passed through."""

@@ -600,7 +600,7 @@ def test_hip_output_frame_batch_unaligned():
         for i in range(3):
             assert np.array_equal(j["bob"][i].cpu().numpy(), b.plane(i)), i
     with pytest.raises(ntscsim.NtscsimError) as e:
-        sim.output422([dict(jobs[0], mode=3)], w, h)
+        sim.output422([dict(jobs[0], mode=4)], w, h)
     assert e.value.code == _capi.E_ARG
     with pytest.raises(ntscsim.NtscsimError) as e:
         sim.output422(jobs[:1], w + 62, h)
