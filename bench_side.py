@@ -1,0 +1,484 @@
+"""bench_side.py -- the side benchmarks of bench.py (N = 1, rank 0, `--no-extras` skips them): the numbers README /
+DESIGN quote BESIDE the contract's headline value -- PCIe-inclusive host-frame rates, the drop-in loops of host/*.cpp,
+the 8-bit YUV422P tool, the raw-composite decoder, other sizes and switch sets -- and the helpers they share with the
+headline (synthetic clips, device-resident contexts).  bench.py owns the contract line, the roofline and the CPU
+baseline; nothing here is part of `value`."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "composite-video-simulator_amd"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_bars_clip(torch, n_frames, w, h, first_frame, stride, device):
+    """Frames first_frame, first_frame+stride, ...: BGRA 8-bar 75% bars rotated by the frame
+    index; alpha 0.  uint8 [n, h, w, 4] in HBM."""
+    table = torch.tensor([0xC0C0C0, 0xC0C000, 0x00C0C0, 0x00C000,
+                          0xC000C0, 0xC00000, 0x0000C0, 0x000000], dtype=torch.int64, device=device)
+    x = torch.arange(w, device=device, dtype=torch.int64)
+    rot = (first_frame + stride * torch.arange(n_frames, device=device, dtype=torch.int64))
+    sx = (x[None, :] + rot[:, None]) % w
+    px = table[(8 * sx) // w]                                   # [n, w] 0xRRGGBB
+    row = torch.stack([px & 0xFF, (px >> 8) & 0xFF, (px >> 16) & 0xFF, torch.zeros_like(px)],
+                      dim=-1).to(torch.uint8)                   # B, G, R, A
+    return row[:, None, :, :].expand(n_frames, h, w, 4).contiguous()
+
+
+def time_steps(torch, dev, fn, reps):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        fn(i)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / reps
+
+
+def device_rate(torch, ntscsim, dev, local_rank, flags, w, h, n_frames, reps, inflight=3, params=None, kernels=None):
+    """fields/s of the BGRA path on a resident bars clip of n_frames frames (both fields each).
+    kernels: a list that receives the kernel forms the step enqueued (ntscsim_debug_last_kernels)."""
+    from ntscsim import shard
+    if params is None:
+        params = ntscsim.make_params(flags)
+    jobs = shard.jobs_for_rank(params, w, h, 2 * n_frames, 0, 1)
+    src = make_bars_clip(torch, n_frames, w, h, 0, 1, dev)
+    loc = [(cur // 2, cur // 2, field, fieldno) for (cur, field, fieldno, _) in jobs]
+    sims, plans, dsts, streams = [], [], [], []
+    for _ in range(inflight):
+        sm = ntscsim.FieldSimulator(params=params, device=local_rank)
+        d = torch.zeros((n_frames, h, w, 4), dtype=torch.uint8, device=dev)
+        plans.append(sm.prepare(sm.build_descs(src, d, loc, rng_pos=[j[3] for j in jobs]), w, h))
+        sims.append(sm); dsts.append(d); streams.append(torch.cuda.Stream(dev))
+    def step(i):
+        q = i % inflight
+        sims[q].run_prepared(plans[q], stream=streams[q].cuda_stream)
+    for i in range(inflight):
+        step(i)
+    dt = time_steps(torch, dev, step, reps)
+    if kernels is not None:
+        kernels.extend(sims[0].last_kernels())
+    for sm, pl in zip(sims, plans):
+        sm.free_prepared(pl); sm.close()
+    return len(jobs) / dt
+
+
+def device_stream_rate(torch, ntscsim, dev, local_rank, params, w, h, n_frames, steps, inflight, threads=2):
+    """A device-resident STREAM of fresh batches (not a replay of a prepared one): step s is the NEXT 2 * n_frames
+    fields of one long stream -- fieldno = s * nf + k, rand() position continuing where step s - 1 ended -- sent
+    through ntscsim_fields_device(), i.e. descriptor validation, rand() window derivation per field, record
+    upload and the kernel chain are all inside the clock.  `inflight` contexts (own stream, scratch, destination
+    clip) take the steps round-robin; `threads` host threads drive them (ctypes releases the GIL, a ctx is only
+    ever used by one thread), so the preparation of one step overlaps the GPU work of the others.
+    Returns (fields/s, verified): verified = the last step's output equals the same fields run as one
+    ordinary batch with explicit rand() positions on a fresh context."""
+    import threading
+    import numpy as np
+    from ntscsim import _capi
+    nf = 2 * n_frames
+    src = make_bars_clip(torch, n_frames, w, h, 0, 1, dev)
+    calls = [ntscsim.calls_per_field(params, w, h, 0), ntscsim.calls_per_field(params, w, h, 1)]
+    draws_per_step = sum(calls[(k & 1) ^ 1] for k in range(nf))
+    dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("sls", "<i4"), ("dls", "<i4"), ("field", "<u4"),
+                   ("flags", "<u4"), ("fieldno", "<u8"), ("rng_pos", "<u8")])
+    assert dt.itemsize == C_sizeof_field_desc()
+    loc = [(k // 2, k // 2, (k & 1) ^ 1, k) for k in range(nf)]
+    ctxs = []
+    for q in range(inflight):
+        sm = ntscsim.FieldSimulator(params=params, device=local_rank)
+        d = torch.zeros((n_frames, h, w, 4), dtype=torch.uint8, device=dev)
+        arr = sm.build_descs(src, d, loc)                 # rng_pos: AUTO (continue after the previous descriptor)
+        view = np.frombuffer(arr, dtype=dt)
+        st = torch.cuda.Stream(dev)
+        ctxs.append((sm, d, arr, view, st, [None, None]))
+    k_idx = np.arange(nf, dtype=np.uint64)
+
+    def run_step(s):
+        sm, d, arr, view, st, evs = ctxs[s % inflight]
+        ev = evs[(s // inflight) & 1]
+        if ev is not None:
+            ev.synchronize()                              # at most two steps queued per context
+        view["fieldno"] = np.uint64(s * nf) + k_idx
+        view["rng_pos"][0] = s * draws_per_step           # explicit for the first field, the rest follow it
+        sm.run_descs(arr, w, h, stream=st.cuda_stream)
+        e = torch.cuda.Event()
+        e.record(st)
+        evs[(s // inflight) & 1] = e
+
+    def worker(j, first, count, bar):
+        torch.cuda.set_device(local_rank)
+        bar.wait()
+        for s in range(first, first + count):
+            if (s % inflight) % threads == j:
+                run_step(s)
+
+    def timed(first, count):
+        bar = threading.Barrier(threads + 1)
+        th = [threading.Thread(target=worker, args=(j, first, count, bar)) for j in range(threads)]
+        for t in th:
+            t.start()
+        torch.cuda.synchronize(dev)
+        bar.wait()
+        t0 = time.perf_counter()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0
+
+    timed(0, 2 * inflight)                                # first-call allocations
+    el = timed(2 * inflight, steps)
+    last = 2 * inflight + steps - 1
+    got = ctxs[last % inflight][1]
+    chk = ntscsim.FieldSimulator(params=params, device=local_rank)
+    d2 = torch.zeros_like(got)
+    pos, rp = last * draws_per_step, []
+    for k in range(nf):
+        rp.append(pos)
+        pos += calls[(k & 1) ^ 1]
+    chk.fields(src, d2, [(k // 2, k // 2, (k & 1) ^ 1, last * nf + k) for k in range(nf)], rng_pos=rp)
+    chk.sync()
+    ok = bool(torch.equal(got, d2))
+    chk.close()
+    for sm, *_ in ctxs:
+        sm.close()
+    return steps * nf / el, ok
+
+
+def C_sizeof_field_desc():
+    import ctypes
+    import ntscsim
+    return ctypes.sizeof(ntscsim.FieldDesc)
+
+
+def variant_contexts(torch, ntscsim, dev, local_rank, args, nq):
+    """The 8-bit YUV422P tool (ffmpeg_to_composite): nq contexts, each with 2 x frames colour-bars
+    YUV422P frames resident in HBM (every field its own frame, processed in place), its descriptor
+    array and its stream.  Returns (simulators, step(i), frames of context 0)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs as L
+    w, h = args.width, args.height
+    p422 = ntscsim.make_params_to_composite(args.preset.split())
+    lib = ntscsim.lib()
+    base = L.yuv_bars(w, h, 0, pad=16)
+    nf = 2 * args.frames
+    sims, arrs, streams, frames = [], [], [], []
+    for q in range(nq):
+        sm = ntscsim.FieldSimulator(params=p422, device=local_rank)
+        fr = [[torch.from_numpy(base.plane(i).copy()).to(dev) for i in range(3)] for _ in range(nf)]
+        jobs, pos = [], 0
+        for k in range(nf):
+            field = (k & 1) ^ 1
+            jobs.append({"dst": fr[k], "field": field, "fieldno": k, "rng_pos": pos})
+            pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p422), w, h, field)
+        sims.append(sm); arrs.append(sm.build_descs422(jobs)); frames.append(fr)
+        streams.append(torch.cuda.Stream(dev))
+    plans = [sm.prepare422(a, w, h) for sm, a in zip(sims, arrs)]       # prepared batches: a step is only the launches
+
+    def vstep(i):
+        q = i % nq
+        sims[q].run_prepared422(plans[q], stream=streams[q].cuda_stream)
+    vstep.keep = (arrs, frames, streams, plans)
+    return sims, vstep, frames[0]
+
+
+def extras(torch, ntscsim, dev, local_rank, args):
+    """The numbers README / DESIGN quote beside the headline value (N = 1, rank 0)."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _libs as L
+    out = {}
+    w, h = args.width, args.height
+    # ---- PCIe-inclusive: ntscsim_frames_host, 300 host frames in -> 600 bob frames out
+    n = args.frames
+    params = ntscsim.make_params(args.preset.split())
+    one = L.bars(w, h, 0)
+    src_pin = torch.empty((n, h, w, 4), dtype=torch.uint8).pin_memory()
+    for j in range(n):
+        src_pin[j] = torch.from_numpy(np.roll(one, -j, axis=1))
+    dst_pin = torch.empty((2 * n, h, w, 4), dtype=torch.uint8).pin_memory()
+    fb = w * h + 2 * (w // 2) * ((h + 1) // 2)
+    yuv_pin = torch.empty((2 * n, fb), dtype=torch.uint8).pin_memory()
+    src_pg, dst_pg = src_pin.numpy().copy(), np.zeros((2 * n, h, w, 4), np.uint8)
+    sim = ntscsim.FieldSimulator(params=params, device=local_rank)
+    sim.frames_host(dst_pin.numpy()[:8], src_pin.numpy()[:4])
+    e2e = {}
+    for name, d, s_, kw in (("bgra_pinned", dst_pin.numpy(), src_pin.numpy(), {}),
+                            ("bgra_pageable", dst_pg, src_pg, {}),
+                            ("yuv420p_pinned", yuv_pin.numpy(), src_pin.numpy(), {"yuv": "420"})):
+        best = 0.0
+        for _ in range(2):
+            sim.rng_pos = 0
+            t0 = time.perf_counter()
+            sim.frames_host(d, s_, first_fieldno=0, chunk_frames=32, **kw)
+            best = max(best, 2 * n / (time.perf_counter() - t0))
+        e2e[name] = best
+    # ---- YUV420P in -> YUV420P out: 1.5 bytes per pixel each way over the link (the decoder's and the
+    # encoder's pixel format; both conversions on the GPU)
+    try:
+        from ntscsim import _capi as _c
+        hs = _c.HostSource()
+        cw, chh = w // 2, (h + 1) // 2
+        hs.format, hs.width, hs.height, hs.frame_bytes = _c.SRC_YUV420P, w, h, fb
+        for k_, (ls_, off_) in enumerate(((w, 0), (cw, w * h), (cw, w * h + cw * chh))):
+            hs.linesize[k_], hs.plane_offset[k_] = ls_, off_
+        yin = torch.empty((n, (fb + 15) // 16 * 16), dtype=torch.uint8).pin_memory()
+        ybars = L.yuv_bars(w, h, 0)
+        yin_np = yin.numpy()
+        for j in range(n):          # Y | U(4:2:0) | V(4:2:0) of the colour-bars frame rotated by j
+            yin_np[j, :w * h] = np.roll(ybars.pix(0), -j, axis=1).reshape(-1)
+            yin_np[j, w * h:w * h + cw * chh] = np.roll(ybars.pix(1)[::2], -(j // 2), axis=1).reshape(-1)
+            yin_np[j, w * h + cw * chh:fb] = np.roll(ybars.pix(2)[::2], -(j // 2), axis=1).reshape(-1)
+        best = 0.0
+        for _ in range(2):
+            sim.rng_pos = 0
+            t0 = time.perf_counter()
+            sim.frames_host_scaled(yuv_pin.numpy(), yin_np[:, :fb], hs, w, h, first_fieldno=0, chunk_frames=32, yuv="420")
+            best = max(best, 2 * n / (time.perf_counter() - t0))
+        e2e["yuv420p_in_yuv420p_out_pinned"] = best
+        del yin
+    except Exception as e:
+        e2e["yuv420p_in_error"] = repr(e)
+    # ---- the 1:1 drop-in: one composite_layer() call per ntscsim_field() call, host frames in and out
+    one_dst = np.zeros((h, w, 4), np.uint8)
+    sim.rng_pos = 0
+    for k in range(4):
+        sim.field_host(one_dst, one, (k & 1) ^ 1, k)
+    t0 = time.perf_counter()
+    nfc = 200
+    for k in range(nfc):
+        sim.field_host(one_dst, one, (k & 1) ^ 1, k)
+    e2e["field_call"] = nfc / (time.perf_counter() - t0)
+    sim.close()
+    e2e["unit"] = "frames/s"
+    e2e["note"] = ("ntscsim_frames_host: %d host frames in, %d bob frames out through H2D | kernels | D2H "
+                   "on three streams, chunks of 32 frames; pageable = the call pins the caller's buffers "
+                   "in place first; yuv420p = the encoder's pixel format made on the GPU (1.5 B/pixel "
+                   "back instead of 4); field_call = ntscsim_field(), the synchronous one-field-per-call drop-in (its asynchronous form: field_submit) "
+                   "for composite_layer() on pageable host frames (upload, three kernels on 4 wavefronts, download)" % (n, 2 * n))
+    # ---- the ffmpeg_ntsc-compatible command line host (synthetic source, discarded output)
+    cli = os.path.join(ROOT, "composite-video-simulator_amd", "ntsc_cli")
+    if os.path.exists(cli) and (w, h) == (720, 486):
+        import re
+        import subprocess
+        best = 0.0
+        for _ in range(2):
+            pr = subprocess.run([cli] + args.preset.split() + ["-i", "bars:3000", "-o", "null:"],
+                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
+            m = re.search(r"\(([0-9.]+) fields/s incl", pr.stderr.decode(errors="replace"))
+            if m:
+                best = max(best, float(m.group(1)))
+        e2e["cli"] = best
+        e2e["cli_note"] = ("ntsc_cli %s -i bars:3000 -o null: (6000 fields; the tool's own figure for its field loop: host frame "
+                           "synthesis, upload, kernels, download; one-off initialisation is outside its clock; best "
+                           "of 2 runs)" % args.preset)
+    # ---- the asynchronous 1:1 drop-in: ntscsim_submit() / ntscsim_wait() from the reference-shaped loop of
+    # host/field_loop.cpp (AVFrame-shaped pageable frames; the call at ffmpeg_ntsc.cpp:2229 replaced, the frame
+    # consumed 4 * depth fields later)
+    floop = os.path.join(ROOT, "composite-video-simulator_amd", "field_loop")
+    if os.path.exists(floop):
+        import json as _json
+        import subprocess
+        def run_loop(*extra):
+            best = None
+            for _ in range(2):
+                pr = subprocess.run([floop] + args.preset.split() + ["--height", str(h), "-width", str(w)] + list(extra),
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+                try:
+                    r = _json.loads(pr.stdout.decode().strip().splitlines()[-1])
+                except Exception:
+                    return {"error": pr.stderr.decode(errors="replace")[-300:]}
+                if best is None or r["fields_per_s"] > best["fields_per_s"]:
+                    best = r
+            return best
+        big = ["--fields", "20000", "--warmup", "2000"]
+        sync = run_loop("--mode", "sync", "--fields", "1500", "--warmup", "100")
+        sub = run_loop("--mode", "submit", "--depth", "32", "--rewrite-src", "1", *big)
+        e2e["field_submit"] = sub.get("fields_per_s", 0.0)
+        e2e["field_submit_detail"] = {
+            "loop_sync_fields_per_s": sync.get("fields_per_s"),
+            "depth32_in_rgb_rewritten": sub,
+            "depth32_decoder_frames": run_loop("--mode", "submit", "--depth", "32", *big),
+            "depth32_bob": run_loop("--mode", "submit", "--depth", "32", "--bob", "1", *big),
+            "depth128": run_loop("--mode", "submit", "--depth", "128", *big),
+            "depth32_src_stable": run_loop("--mode", "submit", "--depth", "32", "--src-stable", "1", *big),
+            "depth32_staging_ring": run_loop("--mode", "submit", "--depth", "32", "--pin", "0", "--rewrite-src", "1", *big),
+            "note": "host/field_loop.cpp: the loop of ffmpeg_ntsc.cpp:2202-2282 on AVFrame-shaped pageable frames "
+                    "(posix_memalign, linesize rounded to 64) with composite_layer() :2229 replaced by "
+                    "ntscsim_submit_avframe() and the frame consumed behind ntscsim_wait() 4 * depth fields later; "
+                    "field_submit = depth 32, ONE source frame (in.rgb) rewritten by a memcpy for every new frame "
+                    "(the stand-in for sws_scale :603), snapshot semantics (submit returns after the DMA read "
+                    "it); decoder_frames = the source is re-pointed at one of 8 frames instead (no host copy); "
+                    "src_stable = the caller promises not to touch the source until the wait; staging_ring = "
+                    "pin_caller_buffers 0 (one host memcpy each way); loop_sync = the same loop with "
+                    "ntscsim_field_avframe() (= field_call from C++)"}
+    # ---- the YUV422P tool's loop on host frames (ffmpeg_to_composite.cpp:1783-1800 with its four calls replaced by
+    # one): host/field_loop422.cpp, synchronous and with iterations in flight
+    floop422 = os.path.join(ROOT, "composite-video-simulator_amd", "field_loop422")
+    if os.path.exists(floop422):
+        import json as _json
+        import subprocess
+
+        def run_loop422(*extra):
+            best = None
+            for _ in range(2):
+                pr = subprocess.run([floop422] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+                try:
+                    r = _json.loads(pr.stdout.decode().strip().splitlines()[-1])
+                except Exception:
+                    return {"error": pr.stderr.decode(errors="replace")[-300:]}
+                if best is None or r["fields_per_s"] > best["fields_per_s"]:
+                    best = r
+            return best
+        big = ["--fields", "6000", "--warmup", "600"]
+        sub422 = run_loop422("-vhs", "--mode", "submit", "--depth", "32", *big)
+        e2e["field_submit422"] = sub422.get("fields_per_s", 0.0)
+        e2e["field_submit422_detail"] = {
+            "loop_sync_fields_per_s": run_loop422("-vhs", "--mode", "sync", "--fields", "600", "--warmup", "100").get("fields_per_s"),
+            "depth32_vhs": sub422,
+            "depth32_default_preset": run_loop422("--mode", "submit", "--depth", "32", *big),
+            "depth32_vhs_422_interlaced": run_loop422("-vhs", "-vi", "-422", "--mode", "submit", "--depth", "32", *big),
+            "depth32_vhs_page_frames": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
+            "depth32_vhs_422_page_frames": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
+            "tight_rows_704_one_at_a_time": run_loop422("-vhs", "-width", "704", "--mode", "submit", "--fields", "600", "--warmup", "100"),
+            "note": "host/field_loop422.cpp: the loop of ffmpeg_to_composite.cpp:1783-1800 (720x480, the tool's default "
+                    "geometry) on AVFrame-shaped pageable frames (linesize = width rounded up to 32, like "
+                    "av_frame_get_buffer) with render_field / black_key_feedback / composite_video_process / output_frame's "
+                    "copy replaced by ONE ntscsim_submit422_avframe() and the encoder frame consumed behind ntscsim_wait() "
+                    "2 * depth fields later; the input frame is rewritten by a memcpy per source frame (the stand-in for "
+                    "sws_scale :1770-1778).  page_frames = every plane a mapping of its own (what a get_buffer2 callback over page-aligned "
+                    "memory hands out): the engine pins such planes in place, uploads by DMA and delivers with kernels; the default "
+                    "posix_memalign'ed planes are blocks inside the C library's heap once the process has raised its mmap threshold "
+                    "and go through the staging rings (one memcpy each way on the caller's thread).  loop_sync = the same loop with ntscsim_field422_avframe(); tight rows "
+                    "(linesize == width) run one iteration at a time on a device mirror (include/ntscsim.h)"}
+    # ---- one process per GPU with the C++ host and rccl.h (host/rank_bench.cpp): here with the one rank this box has
+    rb = os.path.join(ROOT, "composite-video-simulator_amd", "rank_bench")
+    if os.path.exists(rb) and (w, h) == (720, 486):
+        import json as _json
+        import subprocess
+        try:
+            pr = subprocess.run([rb] + args.preset.split() + ["--spawn", "1", "--frames", str(args.frames), "--steps", "40", "--warmup", "8"],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+            r = _json.loads([l for l in pr.stdout.decode().splitlines() if l.startswith("{")][-1])
+            out["multi_gpu_cpp_host"] = {k_: r.get(k_) for k_ in ("value", "unit", "n_gpus", "ms_per_step", "steps_in_flight", "scaling",
+                                                                  "collectives", "rank_checksums_verified")}
+            out["multi_gpu_cpp_host"]["note"] = ("host/rank_bench.cpp --spawn 1: frame-round-robin shards, prepared batches, RCCL (rccl.h) "
+                                                 "for the barriers, the MAX of the elapsed times and the all-gather of {checksum, fields, "
+                                                 "elapsed}; tools/run_multi_gpu.sh runs it at N = 1, 2, 4, 8 on a node that has the GPUs")
+        except Exception as e:
+            out["multi_gpu_cpp_host"] = {"error": repr(e)}
+    out["end_to_end"] = e2e
+    del src_pin, dst_pin, yuv_pin, src_pg, dst_pg
+    # ---- the 8-bit YUV422P tool (ffmpeg_to_composite), 600 fields, every field its own frame
+    nf = 2 * args.frames
+    nq = max(1, args.inflight)
+    sims, vstep, _ = variant_contexts(torch, ntscsim, dev, local_rank, args, nq)
+    for i in range(4 * nq):
+        vstep(i)
+    dt = time_steps(torch, dev, vstep, 12 * nq)
+    for sm in sims:
+        sm.close()
+    out["variant422"] = {"value": nf / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+                         "workload": "%dx%d YUV422P, preset '%s', %d fields per step (every field its own frame, "
+                                     "processed in place), %d steps in flight" % (w, h, args.preset, nf, nq)}
+    # ---- the raw-composite decoder (ffmpeg_raw28ntsc): a synthetic 8 x fsc capture resident in HBM
+    try:
+        # 600 fields (a 10 s capture) = a 30-field synthetic capture repeated 20 times
+        nfr = 600
+        base = L.raw28_capture(30, 5, 3, 0)
+        capture = np.ascontiguousarray(np.tile(base[:30 * 477750], 20)[250000:])
+        dec = ntscsim.Raw28Decoder([], device=local_rank)
+        cap_dev = torch.from_numpy(capture).to(dev)
+        fr = torch.empty((nfr + 2, dec.height, dec.width * 4), dtype=torch.uint8, device=dev)
+        nout = dec.decode(cap_dev, fr)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            dec.decode(cap_dev, fr)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        st = dec.stats()
+        # CPU beside it: the reference text (oracle/_ref) or the port, first 12 fields of the same capture
+        sub = np.ascontiguousarray(capture[:14 * 477750])
+        t0 = time.perf_counter()
+        if L.have_raw28_ref():
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                ref_frames, _ = L.raw28_ref_run(L.raw28_oracle_opts(), sub, os.path.join(td, "cap.u8"))
+            kind = "reference"
+        else:
+            ref_frames, _ = L.raw28_oracle_run(L.raw28_oracle_opts(), sub)
+            kind = "port"
+        cpu_dt = time.perf_counter() - t0
+        ncmp = min(8, ref_frames.shape[0])
+        same = bool(np.array_equal(fr[:ncmp].cpu().numpy().reshape(ncmp, dec.height, -1), ref_frames[:ncmp]))
+        out["raw28"] = {"value": nout / dt, "unit": "fields/s", "ms_per_capture": dt * 1e3, "fields": nout,
+                        "workload": "ffmpeg_raw28ntsc decoder: synthetic %d-field capture at 8 x fsc (%.0f MB, 8 bit) "
+                                    "resident in HBM -> %d grey BGRA frames of %dx%d; whole call incl. the host's "
+                                    "sync walk" % (nfr, capture.size / 1e6, nout, dec.width, dec.height),
+                        "stats": st,
+                        "cpu_1core": {"value": ref_frames.shape[0] / cpu_dt, "kind": kind,
+                                      "sample": "%d fields of the same capture incl. the tool's start-up filter run" % ref_frames.shape[0]},
+                        "first_%d_fields_equal_cpu" % ncmp: same}
+        dec.close()
+        del cap_dev, fr
+    except Exception as e:
+        out["raw28_error"] = repr(e)
+    # ---- a device-resident stream of FRESH batches (the headline replays prepared ones)
+    try:
+        best, ok_all = 0.0, True
+        for _ in range(2):
+            v_, ok_ = device_stream_rate(torch, ntscsim, dev, local_rank, params, w, h, args.frames, 48, args.inflight, threads=2)
+            best, ok_all = max(best, v_), ok_all and ok_
+        out["device_stream"] = {
+            "value": best, "unit": "frames/s", "verified_last_step": ok_all,
+            "workload": "%dx%d, preset '%s': every step is the NEXT %d fields of one long stream (new fieldno and "
+                        "rand() position per field) through ntscsim_fields_device() -- descriptor validation, rand() "
+                        "window derivation, record upload and the kernel chain inside the clock; %d contexts, 2 host "
+                        "threads; 48 steps, best of 2" % (w, h, args.preset, 2 * args.frames, args.inflight)}
+    except Exception as e:
+        out["device_stream"] = {"error": repr(e)}
+    # ---- other sizes / presets on the BGRA path
+    out["sizes"] = {
+        "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 136, 8, args.inflight),
+                      "unit": "frames/s", "workload": "preset '%s', 272 fields (146,880 scanlines) per step, %d steps in flight" % (args.preset, args.inflight)},
+        "3840x2160": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 3840, 2160, 68, 8, args.inflight),
+                      "unit": "frames/s", "workload": "preset '%s', 136 fields (146,880 scanlines) per step, %d steps in flight" % (args.preset, args.inflight)},
+    }
+    out["presets"] = {
+        "default": {"value": device_rate(torch, ntscsim, dev, local_rank, [], w, h, args.frames, 24, args.inflight),
+                    "unit": "frames/s", "workload": "%dx%d, default preset (BASELINE configs[0] on the GPU), %d fields per step" % (w, h, 2 * args.frames)},
+    }
+    # the headline preset measured the way the legs below are (24 steps after one per context, no pre-roll): the
+    # reference point of their `frac_of_preset`
+    ref_rate = device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), w, h, args.frames, 24, args.inflight)
+    out["presets"]["preset_same_method"] = {"value": ref_rate, "unit": "frames/s",
+                                            "workload": "%dx%d, preset '%s', %d fields per step, 24 steps" % (w, h, args.preset, 2 * args.frames)}
+    # switch sets that fall off the hand-tuned kernels' preconditions (the GENERIC / template forms run):
+    # which decoder form each one took is recorded beside its rate
+    for name, fl in (("vhs_catv2", ["-vhs", "-comp-catv2"]), ("vhs_phase90", ["-vhs", "-comp-phase", "90"]),
+                     ("vhs_svideo", ["-vhs", "-vhs-svideo", "1"]),
+                     ("vhs_full_outlp", ["-vhs", "-out-composite-lowpass-lite", "0"]),
+                     ("vhs_ghost2", None)):
+        try:
+            kn = []
+            if fl is None:          # extension (absent from the reference, parity unpinned): two echo taps
+                prm = ntscsim.make_params(["-vhs"])
+                prm.ghost_taps = 2
+                prm.ghost_delay[0], prm.ghost_delay[1] = 12, 31
+                prm.ghost_gain[0], prm.ghost_gain[1] = 64, -32
+                v_ = device_rate(torch, ntscsim, dev, local_rank, None, w, h, args.frames, 24, args.inflight, params=prm, kernels=kn)
+                what = "-vhs + ghosting extension (2 taps: 12 samples x 64/256, 31 samples x -32/256; absent from the reference, parity unpinned)"
+            else:
+                v_ = device_rate(torch, ntscsim, dev, local_rank, fl, w, h, args.frames, 24, args.inflight, kernels=kn)
+                what = "preset '%s'" % " ".join(fl)
+            out["presets"][name] = {"value": v_, "unit": "frames/s", "frac_of_preset": v_ / ref_rate if ref_rate else None,
+                                    "kernels": [k_ for k_ in kn if not k_.startswith(("k_field", "k_row"))],
+                                    "workload": "%dx%d, %s, %d fields per step" % (w, h, what, 2 * args.frames)}
+        except Exception as e:
+            out["presets"][name] = {"error": repr(e)}
+    return out

@@ -601,8 +601,9 @@ typedef FrameSinkT<BurstWriter<4, 16>, BurstWriter<2, 16>> FrameSinkBurst;
 
 // composite_ntsc_to_yuv :480-553 in one sweep over scratch plane R.Y (see demodulate422).  LUMA:
 // the separated luma goes through the VHS luma chain and back to R.Y, chroma to R.U / R.V.  SINK:
-// everything goes to the frame through `sink`.
-template <bool SINK>
+// everything goes to the frame through `sink`.  POST: the chroma pair passes the chroma / phase noise on its way
+// (the first separation of the path; SINK + POST = the whole decode side of a switch set WITHOUT the VCR, k422_direct).
+template <bool SINK, bool POST = !SINK>
 DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA, int oob0, int oob1,
                ChromaPost422 &cpost_in, LumaVhs &lv_in, FrameSink &sink_in)
 {
@@ -636,7 +637,7 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
             else {
                 const int a = ch_even, b = ch;
                 int u = (xi & 1u) ? 255 - b : 255 - a, v = (xi & 1u) ? 255 - a : 255 - b;
-                if (!SINK) chroma_post422(P, cpost, u, v);
+                if (POST) chroma_post422(P, cpost, u, v);      // chroma noise :738-754, phase noise :755-781
                 if (SINK) sink.chroma(xo >> 1, u, v);
                 else { ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
             }
@@ -650,9 +651,14 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
 // VHS chroma low-pass :834-855 (output lands d samples back, the last d keep their input) ->
 // vertical blend :862-882 -> chroma sharpen :904-924 -> modulate onto the luma in R.Y :926-928.
 // DS: the chroma delay as a constant (4 = SP tape speed), 0 = read it from P
-template <int DS>
-DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k, double a_sh_c, double sharpen_c)
+// SV (S-Video out of the VCR, -vhs-svideo 1 :926: no re-modulation, no second separation): luma as B1 left it and the
+// chroma of this sweep go to the frame through `sink` (dropout :932-942, output low-pass :948-951) instead.
+template <int DS, bool SV = false>
+DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k, double a_sh_c, double sharpen_c,
+                  FrameSink *sink_in = nullptr)
 {
+    FrameSink sink;
+    if constexpr (SV) sink = *sink_in;
     const int W2 = W / 2;
     const int d = DS ? DS : P.cdelay;
     const bool blend = P.vblend && P.ntsc;
@@ -696,15 +702,18 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 #pragma unroll
             for (int sx = 0; sx < 2; sx++) {
                 const int lx = 2 * xo + sx;
+                if constexpr (SV) { sink.luma(lx, ry.get(lj + sx)); continue; }
                 const unsigned ph = (xi + (unsigned)lx) & 3u;
                 int chroma = ((ph & 1u) ? v - 128 : u - 128) * P.amp;
                 if (ph & 2u) chroma = -chroma;
                 oy.put(lx, clampu8(ry.get(lj + sx) + chroma / 50));
             }
+            if constexpr (SV) sink.chroma(xo, u, v);
         }
         if (j_ == BK - 1 || x == W2 + d - 1) rv.advance();
     SWEEP_END
-    oy.finish(W);
+    if constexpr (SV) sink.finish(W);
+    else oy.finish(W);
 }
 
 
@@ -1154,6 +1163,117 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
         demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);
     }
     F422_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------- the short forms
+// The two switch-set families beside the VCR-with-composite-output one, in two / three sweeps instead of the
+// twelve of k422_process (same sweeps, same arithmetic, same scratch planes as k422_fused<false>):
+//   SV = false  "k422_direct": NO VCR (the tool's default preset, ffmpeg_to_composite.cpp:267-333): A, then ONE
+//               decode sweep -- Y/C separation :480-553 -> chroma noise :738-754 -> phase noise :755-781 -> dropout
+//               :932-942 -> output chroma low-pass :948-951 -> the frame row
+//   SV = true   "k422_fused_sv": the VCR with S-Video out (-vhs-svideo 1): A, B1 (separation, noises, VHS luma
+//               low-pass + emphasis + sharpen), then B2 without its re-modulation :926-929 -- chroma low-pass, blend,
+//               sharpen and the luma of B1 go through dropout and the output low-pass to the frame row
+// Preconditions as k422_fused (launcher): colour subcarrier on, input chroma low-pass on, no
+// -nocolor-subcarrier-after-yc-sep, no extra -yc-recomb passes.
+template <bool SV>
+__global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDev G,
+                                                 const Field422Dev *__restrict__ fields,
+                                                 Scratch422 Sc,
+                                                 const uint32_t *__restrict__ rs_luma,
+                                                 const int *__restrict__ n0_luma,
+                                                 const uint32_t *__restrict__ rs_chroma,
+                                                 const int *__restrict__ n0_u,
+                                                 const int *__restrict__ n0_v,
+                                                 const int *__restrict__ hs_shift,
+                                                 const int *__restrict__ pn_noise,
+                                                 const int *__restrict__ dropout,
+                                                 double a_hp_i, double a_hp_q, double a_sh_c,
+                                                 double sharpen_c)
+{
+    using namespace fused422;
+    __shared__ uint32_t ring[31 * 64];
+    const int lane = threadIdx.x;
+    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above: the VCR's vertical blend)
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const Field422Dev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok && !(fd.flags & F422_NOCOMP);
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const unsigned xi = scan_phase422(P, y, fd.fieldno);
+    const int W = P.W;
+    const size_t slot = (size_t)blockIdx.x * 64 + lane;
+    Row422 R;
+    R.Y.p = Sc.Y + slot; R.T.p = Sc.T + slot; R.U.p = Sc.U + slot; R.V.p = Sc.V + slot;
+    R.Y.S = R.T.S = R.U.S = R.V.S = Sc.S;
+    uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
+    uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
+    uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    int oob0 = 16, oob1 = 16;                             // the separator's two bytes past the row (:496)
+    {
+        const size_t off = (size_t)fd.dst_ls[0] * y + (size_t)W, end = (size_t)fd.dst_ls[0] * (size_t)P.H;
+        if (off < end) oob0 = fy[W];
+        if (off + 1 < end) oob1 = fy[W + 1];
+    }
+    // ---- A: frame row -> composite bytes
+    {
+        LumaPost422 lp_;
+        lp_.pre_on = P.pre_on != 0; lp_.noise_on = P.noise_k != 0;
+        lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
+        if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
+        if (P.ntsc) sweep_a<true, false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        else sweep_a<false, false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+    }
+    // ---- head switching :669-732 (as in k422_fused)
+    if (P.hs) {
+        const int hs = hs_shift[rc];
+        if (__any(hs != 0)) {
+            const int tw = W + W / 10;
+            Packer422 o; o.begin(R.T);
+            constexpr int HB = 16;
+            for (int x0 = 0; x0 < W; x0 += HB) {
+                int v[HB], ix[HB];
+#pragma unroll
+                for (int j = 0; j < HB; j++) {
+                    int idx = x0 + j + hs;
+                    idx += (idx >> 31) & tw;
+                    idx -= (idx >= tw) ? tw : 0;
+                    ix[j] = idx;
+                    v[j] = R.Y.byte_at(idx < W ? idx : W - 1);
+                }
+#pragma unroll
+                for (int j = 0; j < HB; j++)
+                    if (x0 + j < W) o.put(x0 + j, ix[j] < W ? v[j] : 16);
+            }
+            o.finish(W);
+            { const Plane422 t = R.Y; R.Y = R.T; R.T = t; }
+        }
+    }
+    ChromaPost422 cp_;
+    cp_.noise_on = P.cnoise_k != 0; cp_.phase_on = P.pnoise_k != 0;
+    cp_.nU = cp_.nV = 0; cp_.cosv = 1; cp_.sinv = 0; cp_.ring = ring; cp_.lane = lane;
+    if (cp_.noise_on) { cp_.rng.init(ring, rs_chroma + rc, P.Rpad, lane); cp_.nU = n0_u[rc]; cp_.nV = n0_v[rc]; }
+    if (cp_.phase_on) {
+        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+        cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
+    }
+    FrameSink sink;
+    sink.begin(P, false, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+    if constexpr (!SV) {
+        // ---- the whole decode side in one sweep
+        LumaVhs nolv;
+        demod<true, true>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, sink);
+    } else {
+        // ---- B1, then B2 to the frame
+        LumaVhs lv;
+        lv.begin(P.a_vl, P.a_sh, P.sharpen);
+        FrameSink none;
+        demod<false>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, lv, none);
+        sweep_b2<0, true>(P, R, W, xi, k, a_sh_c, sharpen_c, &sink);
+    }
 }
 
 } // namespace ntscsim

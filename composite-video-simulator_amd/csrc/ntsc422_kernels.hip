@@ -156,6 +156,7 @@ struct Out422Dev {
     uint8_t *bob[3];
     int32_t frame_ls[3], bob_ls[3];
     uint32_t field, mode;
+    uint32_t crows, _pad;       // chroma rows of the bob frame that may be written (0: no limit), see OUT422_INTERLACED420
 };
 enum : uint32_t { OUT422_BOB422 = 0u, OUT422_BOB420 = 1u, OUT422_INTERLACED420 = 2u, OUT422_FRAME = 3u };
 
@@ -186,6 +187,7 @@ __global__ void k422_output(DevParams P, const Out422Dev *__restrict__ outs, int
     unsigned cy = y;
     if (o.mode == OUT422_BOB420) { chroma = (y & 1u) == 0u; cy = y >> 1; }                   // :1225-1226
     else if (o.mode == OUT422_INTERLACED420) { chroma = (y & 2u) == 0u; cy = (y & 1u) + ((y & ~3u) >> 1); }  // :1215-1216
+    if (o.crows && cy >= o.crows) chroma = false;    // (the repack's row past a 4:2:0 plane, :1215-1223, when the frame has no room for it)
     if (chroma)
         for (int p = 1; p <= 2; p++)
             copy_row422(o.bob[p] + (size_t)o.bob_ls[p] * cy, o.frame[p] + (size_t)o.frame_ls[p] * sy,

@@ -1148,8 +1148,12 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // empty, "decode" = the one kernel that does composite_video_process)
     if (evs) { HIPCHK(c, hipEventRecord(evs->e[1], st)); HIPCHK(c, hipEventRecord(evs->e[2], st)); }
     // four-sweep form (ntsc422_fused.hip) for the VHS family of option sets, twelve-sweep form otherwise
-    const bool fused = !c->no_fast_decode && D.vhs && !D.svideo && !D.nocolor && D.in_lp &&
-                       !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
+    const bool family = !c->no_fast_decode && !D.nocolor && D.in_lp &&
+                        !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
+    const bool fused = family && D.vhs && !D.svideo;
+    // the two families beside it (round 5): no VCR at all -- the tool's default preset -- in two sweeps, the VCR with
+    // S-Video out in three (k422_short, ntsc422_fused.hip)
+    const bool direct = family && !D.vhs, fused_sv = family && D.vhs && D.svideo;
     // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
     // = what `ffmpeg_to_composite -vhs` runs: NTSC, SP, no pre-emphasis, all three noises and the FULL
     // output chroma low-pass (ffmpeg_to_composite.cpp:278 default true, selection :948-951)
@@ -1164,7 +1168,7 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // (aligned frame rows: the 64-byte frame bursts), per chroma delay of the tape speed
     const bool stream_gen = fused && !stream && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 &&
                             D.cdelay >= 4 && D.cdelay <= 6;
-    note_kernel(c, !fused ? "k422_process"
+    note_kernel(c, direct ? "k422_direct" : fused_sv ? "k422_fused_sv" : !fused ? "k422_process"
                           : stream ? "k422_fused<true,true,4>"
                           : stream_gen ? (D.cdelay == 4 ? "k422_fused<false,true,4>" : D.cdelay == 5 ? "k422_fused<false,true,5>" : "k422_fused<false,true,6>")
                           : spec ? "k422_fused<true,false,4>" : "k422_fused<false,false,4>");
@@ -1172,7 +1176,17 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     hipLaunchKernelGGL((k422_fused<__VA_ARGS__>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma)
-    if (fused && stream) NTSC_LAUNCH_422(true, true, 4);
+    if (direct || fused_sv) {
+        if (direct)
+            hipLaunchKernelGGL(k422_short<false>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+        else
+            hipLaunchKernelGGL(k422_short<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    }
+    else if (fused && stream) NTSC_LAUNCH_422(true, true, 4);
     else if (stream_gen && D.cdelay == 4) NTSC_LAUNCH_422(false, true, 4);
     else if (stream_gen && D.cdelay == 5) NTSC_LAUNCH_422(false, true, 5);
     else if (stream_gen) NTSC_LAUNCH_422(false, true, 6);

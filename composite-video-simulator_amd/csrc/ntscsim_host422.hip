@@ -79,7 +79,12 @@ struct Host422Engine {
     CopyRec422 *crec = nullptr;                         // 6 per slot
     Out422Dev *orec = nullptr;                          // 1 per slot
     uint8_t *pads = nullptr;                            // [nslots][2 * L]
-    hipStream_t s_up = nullptr;
+    hipStream_t s_up = nullptr, s_dn = nullptr;
+    hipEvent_t ev_k = nullptr;
+    // caller frames pinned in place (hipHostRegister, cached): sources are then uploaded by DMA straight out of the
+    // caller's planes, and the rows of frame / filter / encoder frame are written by the delivery kernels straight into
+    // them -- no staging copy on the caller's thread.  NTSCSIM_SUBMIT422_PIN=0: everything through the staging rings.
+    PinCache pins;
 
     struct Mirror {
         const uint8_t *host[3]; int ls[3]; int H;
@@ -95,6 +100,13 @@ struct Host422Engine {
         ntscsim_loop422 it;
         Mirror *mfrm = nullptr, *mflt = nullptr;
         uint64_t rng_pos = 0;
+        uint8_t *frm_dev[3] = {nullptr, nullptr, nullptr};    // device-visible addresses of the caller's planes when pinned
+        uint8_t *flt_dev[3] = {nullptr, nullptr, nullptr};
+        uint8_t *out_dev[3] = {nullptr, nullptr, nullptr};
+        // set at launch -- how each of the three results reaches the caller: 0 through the staging record (copied at
+        // ntscsim_wait), 1 written by the delivery kernels into the pinned frame, 2 not at all (a later iteration of the same
+        // launch writes the same rows of the same pinned frame)
+        int frm_how = 0, flt_how = 0, out_how = 0;
     };
     std::vector<Item> pending;
     struct Batch {
@@ -111,7 +123,7 @@ struct Host422Engine {
     int src_cur = -1;
     uint64_t src_ring_pos = 0;
     std::vector<uint64_t> src_last_ticket;
-    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] submitted [1] launches [2] uploads [3] FAST [4] SERIAL [5] mirror uploads
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] submitted [1] launches [2] uploads [3] FAST [4] SERIAL [5] mirror uploads [6] uploads by DMA out of pinned caller planes
 };
 
 static int h422_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
@@ -119,8 +131,28 @@ static int h422_launch(ntscsim_ctx *c);
 
 static Host422Engine *h422_get(ntscsim_ctx *c)
 {
-    if (!c->h422) c->h422 = new (std::nothrow) Host422Engine();
+    if (!c->h422) {
+        c->h422 = new (std::nothrow) Host422Engine();
+        if (c->h422) {
+            const char *ev = std::getenv("NTSCSIM_SUBMIT422_PIN");
+            c->h422->pins.enabled = !(ev && ev[0] == '0');
+            c->h422->pins.min_bytes = 64u << 10;        // (the floor of pin_lookup: a 4:2:0 chroma plane of 720x480 is 86 KiB)
+        }
+    }
     return c->h422;
+}
+
+// all three planes of a caller frame pinned in place?  (`rows_c` chroma rows; one plane that cannot be pinned sends
+// the whole frame through the staging ring)
+static bool h422_pin_frame(Host422Engine *e, const ntscsim_frame422 &f, int W, int H, int rows_c, uint8_t *dev[3])
+{
+    if (!f.data[0]) return false;
+    for (int k = 0; k < 3; k++) {
+        const size_t rb = k ? (size_t)W / 2 : (size_t)W, rows = k ? (size_t)rows_c : (size_t)H;
+        dev[k] = pin_lookup(e->pins, f.data[k], (size_t)f.linesize[k] * (rows - 1) + rb);
+        if (!dev[k]) { dev[0] = dev[1] = dev[2] = nullptr; return false; }
+    }
+    return true;
 }
 
 static void h422_release_rings(Host422Engine *e)
@@ -148,8 +180,11 @@ static void host422_engine_destroy(ntscsim_ctx *c)
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto *m : e->mirrors) { m->dev.release(); delete m; }
     h422_release_rings(e);
+    pin_release_all(e->pins);
     if (e->s_up) (void)hipStreamDestroy(e->s_up);
+    if (e->s_dn) (void)hipStreamDestroy(e->s_dn);
     if (e->ev_up) (void)hipEventDestroy(e->ev_up);
+    if (e->ev_k) (void)hipEventDestroy(e->ev_k);
     delete e;
     c->h422 = nullptr;
 }
@@ -171,12 +206,14 @@ static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, siz
     e->foff[1] = up256((size_t)e->lsd[0] * H);
     e->foff[2] = e->foff[1] + up256((size_t)e->lsd[1] * H);
     e->fbytes = e->foff[2] + up256((size_t)e->lsd[2] * H);
-    // delivery record: [frame rows of the field: Y L x W, U, V L x W/2][filter rows, same][encoder frame: Y H x W,
-    // U, V (H + 1) x W/2 -- 4:2:2 uses H chroma rows, 4:2:0 (H + 1) / 2 and the repack's one spare row :1215-1223]
+    // delivery record: [frame rows of the field: Y L x W, U, V L x W/2][encoder frame: Y H x W, U, V `h422_out_chroma_alloc`
+    // rows x W/2 -- 4:2:2 has H chroma rows, 4:2:0 (H + 1) / 2 and the repack's one spare row :1215-1223][filter rows]
+    // (in this order: a launch downloads the head of every record -- as far as its iterations filled them -- with ONE
+    //  pitched copy; the filter rows, which only the feedback path has, come last)
     e->dn_frm = 0;
-    e->dn_flt = up256((size_t)L * W * 2);
-    e->dn_out = e->dn_flt + up256((size_t)L * W * 2);
-    e->dbytes = e->dn_out + up256((size_t)H * W + 2 * (size_t)(H + 1) * W2);
+    e->dn_out = up256((size_t)L * W * 2);
+    e->dn_flt = e->dn_out + up256((size_t)H * W + 2 * (size_t)(H + 1) * W2);
+    e->dbytes = e->dn_flt + up256((size_t)L * W * 2);
     e->sbytes = up256(keep_src);
     HIPCHK(c, e->dfrm.ensure(e->fbytes * (size_t)ns));
     HIPCHK(c, e->dsrc.ensure(e->sbytes * (size_t)ns));
@@ -191,7 +228,9 @@ static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, siz
     HIPCHK(c, hipHostMalloc((void **)&e->orec, sizeof(Out422Dev) * (size_t)ns, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc((void **)&e->pads, (size_t)2 * L * (size_t)ns, hipHostMallocDefault));
     if (!e->s_up) HIPCHK(c, hipStreamCreateWithFlags(&e->s_up, hipStreamNonBlocking));
+    if (!e->s_dn) HIPCHK(c, hipStreamCreateWithFlags(&e->s_dn, hipStreamNonBlocking));
     if (!e->ev_up) HIPCHK(c, hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming));
+    if (!e->ev_k) HIPCHK(c, hipEventCreateWithFlags(&e->ev_k, hipEventDisableTiming));
     e->W = W; e->H = H; e->L = L;
     e->src_last_ticket.assign((size_t)ns, 0);
     e->src_ring_pos = 0;
@@ -203,6 +242,11 @@ static int h422_field_rows(int H, unsigned field) { return H > (int)field ? (H -
 
 // chroma rows of the encoder frame that output_frame() writes inside the plane (:1177-1236)
 static int h422_out_chroma_rows(int H, uint32_t mode) { return (mode == NTSCSIM_OUT422_BOB422 || mode == NTSCSIM_OUT422_FRAME) ? H : (H + 1) / 2; }
+
+// ... and the rows the record keeps per chroma plane (the interlaced repack writes one row past a 4:2:0 plane for a
+// height of 2 mod 4, :1215-1223: it has room here and is not delivered)
+static int h422_out_chroma_alloc(int H, uint32_t mode) { return h422_out_chroma_rows(H, mode) + 1; }
+static size_t h422_out_bytes(int W, int H, uint32_t mode) { return (size_t)W * H + 2 * (size_t)(W / 2) * (size_t)h422_out_chroma_alloc(H, mode); }
 
 static Host422Engine::Mirror *h422_mirror(ntscsim_ctx *c, Host422Engine *e, const ntscsim_frame422 &f, int H)
 {
@@ -276,9 +320,9 @@ static int h422_retire_front(ntscsim_ctx *c, Host422Engine *e)
                         s += rb * (size_t)n;
                     }
                 };
-                rows_out(it.it.frame, st + e->dn_frm);
-                if (it.serial && it.mflt) rows_out(it.it.filter, st + e->dn_flt);
-                if (it.it.out.data[0]) {
+                if (it.frm_how == 0) rows_out(it.it.frame, st + e->dn_frm);
+                if (it.serial && it.mflt && it.flt_how == 0) rows_out(it.it.filter, st + e->dn_flt);
+                if (it.it.out.data[0] && it.out_how == 0) {
                     const uint8_t *s = st + e->dn_out;
                     const int ch = h422_out_chroma_rows(H, it.it.out_mode);
                     for (int k = 0; k < 3; k++) {
@@ -287,7 +331,7 @@ static int h422_retire_front(ntscsim_ctx *c, Host422Engine *e)
                         if ((size_t)it.it.out.linesize[k] == rb) std::memcpy(it.it.out.data[k], s, rb * (size_t)nr);
                         else for (int r = 0; r < nr; r++)
                             std::memcpy(it.it.out.data[k] + (size_t)it.it.out.linesize[k] * (size_t)r, s + rb * (size_t)r, rb);
-                        s += rb * (size_t)(k ? H + 1 : H);
+                        s += rb * (size_t)(k ? h422_out_chroma_alloc(H, it.it.out_mode) : H);
                     }
                 }
             }
@@ -346,9 +390,27 @@ static int h422_launch(ntscsim_ctx *c)
     if (er == hipSuccess) er = hipStreamWaitEvent(st, e->ev_up, 0);
     if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
 
+    // Delivery by the kernels into pinned caller frames.  The iterations of a launch run concurrently, so of several that
+    // write the same rows of the same caller frame (ONE persistent frame: every second field) only the LAST delivers them
+    // -- the frame then holds what the in-order loop leaves after this launch; launches are stream-ordered among themselves.
+    for (int i = 0; i < n; i++) {
+        Host422Engine::Item &it = b.items[(size_t)i];
+        it.frm_how = it.frm_dev[0] ? 1 : 0; it.flt_how = it.flt_dev[0] ? 1 : 0; it.out_how = it.out_dev[0] ? 1 : 0;
+    }
+    for (int i = 0; i < n; i++) {
+        Host422Engine::Item &a = b.items[(size_t)i];
+        for (int j = i + 1; j < n; j++) {
+            const Host422Engine::Item &z = b.items[(size_t)j];
+            if (a.frm_how == 1 && z.frm_dev[0] && z.it.frame.data[0] == a.it.frame.data[0] && z.it.field == a.it.field) a.frm_how = 2;
+            if (a.flt_how == 1 && z.flt_dev[0] && z.it.filter.data[0] == a.it.filter.data[0] && z.it.field == a.it.field) a.flt_how = 2;
+            if (a.out_how == 1 && z.out_dev[0] && z.it.out.data[0] == a.it.out.data[0]) a.out_how = 2;
+        }
+    }
     std::vector<ntscsim_field422_desc> descs((size_t)n);
     bool any_pad = false, any_out = false;
     bool al4 = (W2 & 3) == 0;
+    size_t dn_need = e->dn_out;                      // bytes at the head of every delivery record that this launch fills
+    bool any_staged = false, flt_staged = false;     // anything for the staging ring at all?
     for (int i = 0; i < n; i++) {
         const Host422Engine::Item &it = b.items[(size_t)i];
         const ntscsim_loop422 &L = it.it;
@@ -387,28 +449,45 @@ static int h422_launch(ntscsim_ctx *c)
         size_t o = e->dn_frm;
         for (int k = 0; k < 3; k++) {
             const int rb = k ? W2 : W;
-            cr[k] = {frm[k] + (size_t)fls[k] * L.field, dn + o, 2 * fls[k], rb, rb, nr};
+            const uint8_t *from = frm[k] + (size_t)fls[k] * L.field;
+            if (it.frm_how == 1) cr[k] = {from, it.frm_dev[k] + (size_t)L.frame.linesize[k] * L.field, 2 * fls[k], 2 * L.frame.linesize[k], rb, nr};
+            else if (it.frm_how == 0) { cr[k] = {from, dn + o, 2 * fls[k], rb, rb, nr}; any_staged = true; }
+            else cr[k] = {nullptr, nullptr, 0, 0, 0, 0};
             o += (size_t)rb * nr;
         }
         o = e->dn_flt;
         for (int k = 0; k < 3; k++) {
             const int rb = k ? W2 : W;
-            if (it.mflt) cr[3 + k] = {it.mflt->dev.p + it.mflt->off[k] + (size_t)it.mflt->ls[k] * L.field, dn + o, 2 * it.mflt->ls[k], rb, rb, nr};
-            else cr[3 + k] = {nullptr, nullptr, 0, 0, 0, 0};
+            if (it.mflt && it.flt_how != 2) {
+                const uint8_t *from = it.mflt->dev.p + it.mflt->off[k] + (size_t)it.mflt->ls[k] * L.field;
+                if (it.flt_how == 1) cr[3 + k] = {from, it.flt_dev[k] + (size_t)L.filter.linesize[k] * L.field, 2 * it.mflt->ls[k], 2 * L.filter.linesize[k], rb, nr};
+                else { cr[3 + k] = {from, dn + o, 2 * it.mflt->ls[k], rb, rb, nr}; flt_staged = true; }
+            } else cr[3 + k] = {nullptr, nullptr, 0, 0, 0, 0};
             o += (size_t)rb * nr;
         }
         // output_frame's copy, straight into the delivery record
         Out422Dev &orc = e->orec[it.slot];
         std::memset(&orc, 0, sizeof(orc));
         orc.mode = 0xFFFFFFFFu;            // = none
-        if (L.out.data[0]) {
+        if (L.out.data[0] && it.out_how != 2) {
             any_out = true;
             for (int k = 0; k < 3; k++) {
                 orc.frame[k] = frm[k]; orc.frame_ls[k] = fls[k];
-                orc.bob[k] = dn + e->dn_out + (k == 0 ? 0 : (size_t)W * H + (k == 2 ? (size_t)W2 * (H + 1) : 0));
-                orc.bob_ls[k] = k ? W2 : W;
+                if (it.out_how == 1) { orc.bob[k] = it.out_dev[k]; orc.bob_ls[k] = L.out.linesize[k]; }
+                else {
+                    orc.bob[k] = dn + e->dn_out + (k == 0 ? 0 : (size_t)W * H + (k == 2 ? (size_t)W2 * (size_t)h422_out_chroma_alloc(H, L.out_mode) : 0));
+                    orc.bob_ls[k] = k ? W2 : W;
+                }
+                al4 = al4 && !(((uintptr_t)orc.bob[k] | (uintptr_t)orc.bob_ls[k]) & 3);
             }
             orc.field = L.out_field; orc.mode = L.out_mode;
+            // (the caller's planes end where they end: the repack's row past a 4:2:0 plane is not written there)
+            orc.crows = it.out_how == 1 ? (uint32_t)h422_out_chroma_rows(H, L.out_mode) : 0u;
+            if (it.out_how == 0) {
+                any_staged = true;
+                const size_t end = e->dn_out + h422_out_bytes(W, H, L.out_mode);
+                if (end > dn_need) dn_need = end;
+            }
         }
     }
     // slot runs: tickets are consecutive, slots = ticket mod nslots -> at most two runs
@@ -433,11 +512,18 @@ static int h422_launch(ntscsim_ctx *c)
     if (run0 < n) hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * (n - run0))), dim3(256), 0, st, e->crec);
     er = hipGetLastError();
     if (er != hipSuccess) { c->err = std::string("submit422 kernels: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
-    er = hipMemcpyAsync(e->hdn + e->dbytes * (size_t)s0, e->ddn.p + e->dbytes * (size_t)s0, e->dbytes * (size_t)run0,
-                        hipMemcpyDeviceToHost, st);
-    if (er == hipSuccess && run0 < n)
-        er = hipMemcpyAsync(e->hdn, e->ddn.p, e->dbytes * (size_t)(n - run0), hipMemcpyDeviceToHost, st);
-    if (er == hipSuccess) er = hipEventRecord(b.done, st);
+    // the download runs on a copy stream of its own behind the kernels: the next launch's kernels do not wait for it
+    er = hipEventRecord(e->ev_k, st);
+    if (er == hipSuccess) er = hipStreamWaitEvent(e->s_dn, e->ev_k, 0);
+    if (flt_staged) { dn_need = e->dbytes; any_staged = true; }
+    dn_need = (dn_need + 255) / 256 * 256;
+    if (!any_staged) dn_need = 0;                    // everything went straight into pinned caller frames
+    if (er == hipSuccess && dn_need)
+        er = hipMemcpy2DAsync(e->hdn + e->dbytes * (size_t)s0, e->dbytes, e->ddn.p + e->dbytes * (size_t)s0, e->dbytes, dn_need,
+                              (size_t)run0, hipMemcpyDeviceToHost, e->s_dn);
+    if (er == hipSuccess && run0 < n && dn_need)
+        er = hipMemcpy2DAsync(e->hdn, e->dbytes, e->ddn.p, e->dbytes, dn_need, (size_t)(n - run0), hipMemcpyDeviceToHost, e->s_dn);
+    if (er == hipSuccess) er = hipEventRecord(b.done, e->s_dn);
     if (er != hipSuccess) { c->err = std::string("submit422 D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;
     e->stats[1]++;
@@ -532,6 +618,10 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
     it.fslot = fslot;
     it.serial = serial;
     it.it = *L;
+    // pinned caller frames: results are written in place by the delivery kernels
+    (void)h422_pin_frame(e, L->frame, W, H, H, it.frm_dev);
+    if (bkey) (void)h422_pin_frame(e, L->filter, W, H, H, it.flt_dev);
+    if (L->out.data[0]) (void)h422_pin_frame(e, L->out, W, H, h422_out_chroma_rows(H, L->out_mode), it.out_dev);
     if (serial) {
         // in order, alone: what is pending goes first
         rc = h422_launch(c);
@@ -567,6 +657,21 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
                 rc = h422_wait_ticket(c, last);
                 if (rc != NTSCSIM_OK) return rc;
             }
+            uint8_t *sdev[3];
+            if (h422_pin_frame(e, L->src, W, L->src_height, (int)src_crows, sdev)) {
+                // DMA straight out of the caller's planes; the caller may rewrite them when we return (snapshot)
+                uint8_t *o = e->dsrc.p + e->sbytes * (size_t)sslot;
+                for (int k = 0; k < 3; k++) {
+                    const size_t rb = k ? (size_t)W2 : (size_t)W, nr = k ? src_crows : (size_t)L->src_height;
+                    if ((size_t)L->src.linesize[k] == rb)
+                        HIPCHK(c, hipMemcpyAsync(o, L->src.data[k], rb * nr, hipMemcpyHostToDevice, e->s_up));
+                    else
+                        HIPCHK(c, hipMemcpy2DAsync(o, rb, L->src.data[k], (size_t)L->src.linesize[k], rb, nr, hipMemcpyHostToDevice, e->s_up));
+                    o += rb * nr;
+                }
+                HIPCHK(c, hipStreamSynchronize(e->s_up));
+                e->stats[6]++;
+            } else {
             uint8_t *hs = e->hsrc + e->sbytes * (size_t)sslot;
             uint8_t *o = hs;
             for (int k = 0; k < 3; k++) {
@@ -576,6 +681,7 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
                 o += rb * nr;
             }
             HIPCHK(c, hipMemcpyAsync(e->dsrc.p + e->sbytes * (size_t)sslot, hs, src_bytes, hipMemcpyHostToDevice, e->s_up));
+            }
             e->src_ring_pos++;
             e->src_cur = sslot;
             e->stats[2]++;
@@ -625,4 +731,18 @@ extern "C" void ntscsim_submit422_stats(const ntscsim_ctx *c, uint64_t out[8])
 {
     if (!out) return;
     for (int i = 0; i < 8; i++) out[i] = (c && c->h422) ? c->h422->stats[i] : 0;
+}
+
+// ntscsim_host_unpin() for the frames this engine has pinned: everything in flight is delivered first
+static int h422_host_unpin(ntscsim_ctx *c, const void *base)
+{
+    Host422Engine *e = c->h422;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
+    if (e->s_up) HIPCHK(c, hipStreamSynchronize(e->s_up));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!base) pin_release_all(e->pins);
+    else (void)pin_release(e->pins, base);
+    e->src_cur = -1;
+    return rc;
 }

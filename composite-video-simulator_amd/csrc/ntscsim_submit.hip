@@ -56,6 +56,32 @@ __global__ void k_deliver(const DeliverRec *__restrict__ recs, int row_bytes, in
 
 } // namespace
 
+// registrations of caller memory (hipHostRegister in place), cached: a tool recycles a handful of frame buffers
+struct PinCache {
+    struct Reg { uintptr_t p0, p1; uint8_t *dev; bool owned; };
+    std::vector<Reg> regs;
+    bool enabled = true;
+    size_t min_bytes = 256u << 10;
+};
+static void pin_release_all(PinCache &pc)      // everything that uses the registrations must have completed
+{
+    for (auto &r : pc.regs)
+        if (r.owned) (void)hipHostUnregister((void *)r.p0);
+    pc.regs.clear();
+    (void)hipGetLastError();
+}
+static bool pin_release(PinCache &pc, const void *base)
+{
+    const uintptr_t a = (uintptr_t)base;
+    for (size_t i = 0; i < pc.regs.size(); i++)
+        if (a >= pc.regs[i].p0 && a < pc.regs[i].p1) {
+            if (pc.regs[i].owned) (void)hipHostUnregister((void *)pc.regs[i].p0);
+            pc.regs.erase(pc.regs.begin() + (long)i);
+            return true;
+        }
+    return false;
+}
+
 struct SubmitEngine {
     ntscsim_submit_opts o;
     bool configured = false;
@@ -102,9 +128,7 @@ struct SubmitEngine {
     int src_cur = -1;                 // slot holding the frame of the previous submit
     uint64_t src_ring_pos = 0;
     std::vector<uint64_t> src_last_ticket;    // last ticket that reads the slot
-    // registrations of caller memory
-    struct Reg { uintptr_t p0, p1; uint8_t *dev; bool owned; };
-    std::vector<Reg> regs;
+    PinCache pins;                    // registrations of caller memory
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int sticky_rc = NTSCSIM_OK;
     bool timing = std::getenv("NTSCSIM_SUBMIT_TIMING") != nullptr;      // developer switch: print every launch's GPU span
@@ -148,13 +172,7 @@ static void sub_release_geometry(SubmitEngine *e)
 }
 
 // everything in flight must have been waited for
-static void sub_unpin_all(SubmitEngine *e)
-{
-    for (auto &r : e->regs)
-        if (r.owned) (void)hipHostUnregister((void *)r.p0);
-    e->regs.clear();
-    (void)hipGetLastError();
-}
+static void sub_unpin_all(SubmitEngine *e) { pin_release_all(e->pins); }
 
 static void submit_engine_destroy(ntscsim_ctx *c)
 {
@@ -224,10 +242,9 @@ static int sub_ensure_staging(ntscsim_ctx *c, SubmitEngine *e, bool src)
 
 // Device-visible address of caller memory [p, p+span), pinning it in place on first sight.  NULL = not pinned
 // (too small, shares a page with another registration, registration refused): the staging ring is used.
-static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_t span)
+static uint8_t *pin_lookup(PinCache &pc, const void *p, size_t span)
 {
-    (void)c;
-    if (!e->o.pin_caller_buffers || span < e->o.min_pin_bytes) return nullptr;
+    if (!pc.enabled || span < pc.min_bytes) return nullptr;
     const uintptr_t a0 = (uintptr_t)p, a1 = a0 + span;
     // Registration is page-wise, so the frame's first and last page get pinned whole.  That is only harmless when
     // nothing else lives in them: a foreign heap block that starts in a pinned page and runs on into pageable memory
@@ -241,7 +258,7 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
     // the pages reused).  Blocks with a mapping of their own (what malloc / posix_memalign hand out for frame-sized
     // requests unless the process has raised the mmap threshold) live far above the program break.
     if (span < (64u << 10) || a0 < (uintptr_t)sbrk(0)) return nullptr;
-    for (auto &r : e->regs)
+    for (auto &r : pc.regs)
         if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
     // ... nor a block inside one of glibc's non-main arenas or a pool of the caller's (they sit above the break too and
     // can start near a page boundary by chance): a block that does not start ON a page boundary must carry the header
@@ -255,9 +272,9 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
     } else if (a0 & 4095u) return nullptr;
     const uintptr_t PG = 4096;
     const uintptr_t p0 = a0 & ~(PG - 1), p1 = (a1 + PG - 1) & ~(PG - 1);
-    for (auto &r : e->regs)
+    for (auto &r : pc.regs)
         if (p0 < r.p1 && r.p0 < p1) return nullptr;          // partial overlap with a live registration
-    if (e->regs.size() >= 1024) return nullptr;
+    if (pc.regs.size() >= 1024) return nullptr;
     hipError_t er = hipHostRegister((void *)p0, p1 - p0, hipHostRegisterDefault);
     bool owned = true;
     if (er == hipErrorHostMemoryAlreadyRegistered) { owned = false; er = hipSuccess; }   // pinned by the caller
@@ -278,30 +295,33 @@ static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_
             return nullptr;
         }
     }
-    e->regs.push_back({p0, p1, (uint8_t *)dev, owned});
-    e->stats[6] = e->regs.size();
+    pc.regs.push_back({p0, p1, (uint8_t *)dev, owned});
     return (uint8_t *)dev + (a0 - p0);
 }
 
+static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_t span)
+{
+    (void)c;
+    e->pins.enabled = e->o.pin_caller_buffers != 0;
+    e->pins.min_bytes = e->o.min_pin_bytes;
+    uint8_t *d = pin_lookup(e->pins, p, span);
+    e->stats[6] = e->pins.regs.size();
+    return d;
+}
+
+static int h422_host_unpin(ntscsim_ctx *c, const void *base);      // ntscsim_host422.hip
 extern "C" int ntscsim_host_unpin(ntscsim_ctx *c, const void *base)
 {
     if (!c) return NTSCSIM_E_ARG;
+    if (c->h422) { const int r = h422_host_unpin(c, base); if (r != NTSCSIM_OK || !c->sub) return r; }
     SubmitEngine *e = c->sub;
     if (!e) return NTSCSIM_OK;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
     HIPCHK(c, hipStreamSynchronize(e->s_up ? e->s_up : c->stream));
     if (!base) sub_unpin_all(e);
-    else {
-        const uintptr_t a = (uintptr_t)base;
-        for (size_t i = 0; i < e->regs.size(); i++)
-            if (a >= e->regs[i].p0 && a < e->regs[i].p1) {
-                if (e->regs[i].owned) (void)hipHostUnregister((void *)e->regs[i].p0);
-                e->regs.erase(e->regs.begin() + (long)i);
-                break;
-            }
-    }
-    e->stats[6] = e->regs.size();
+    else (void)pin_release(e->pins, base);
+    e->stats[6] = e->pins.regs.size();
     e->src_cur = -1;
     return rc;
 }

@@ -3,7 +3,7 @@
 // ntscsim_field422_avframe) and section 5b (asynchronous: ntscsim_submit422_avframe + ntscsim_wait `lag` fields later).
 //
 //   field_loop422 [ffmpeg_to_composite switches] [--mode sync|submit] [--fields N] [--depth K] [--lag G] [--warmup N]
-//                 [--hash 0|1] [--height H] [--align A]
+//                 [--hash 0|1] [--height H] [--align A] [--page-frames 0|1]
 //
 // The loop owns, like the tool: ONE decoded-and-scaled input frame (output_avstream_video_input_frame, rewritten by a
 // memcpy per source frame -- the stand-in for sws_scale :1770-1778), ONE persistent processing frame
@@ -12,8 +12,14 @@
 // fields behind the submits (--hash 1: FNV-1a over each, the stand-in for the encoder).  Frames are allocated like
 // av_frame_get_buffer(f, A) does: linesize = width rounded up to A (default 32), so 720 -> 736 (padded rows: the
 // batched path) and 704 -> 704 (tight rows: one iteration at a time).  -vi / -422 as in the tool (:1792-1797, :1158).
+// Plane memory comes from posix_memalign like av_malloc's (a block inside the C library's heap once the process has
+// raised its mmap threshold -- the engine then stages it) or, with --page-frames 1, from a mapping of its own per plane
+// (what a get_buffer2 callback over page-aligned memory gives: the engine pins such planes in place and moves the pixels
+// with DMA uploads and delivery kernels, no copy on the caller's thread).
 // Prints one JSON line: fields/s over the timed fields, the FNV of all consumed frames (equal between the two modes =
 // byte-identical frames in the same order), the rand() position, the engine's counters.
+#include <sys/mman.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +39,8 @@ struct Frame {           // the AVFrame members the four calls read (ffmpeg_to_c
 
 namespace {
 
+bool g_page_frames = false;
+
 Frame *frame_alloc(int W, int H, bool c420, int align, int fill)      // av_frame_alloc + av_frame_get_buffer(f, align)
 {
     Frame *f = new Frame();
@@ -42,7 +50,11 @@ Frame *frame_alloc(int W, int H, bool c420, int align, int fill)      // av_fram
         const int w = k ? W / 2 : W, rows = (k && c420) ? (H + 1) / 2 : H;
         f->linesize[k] = ((w + align - 1) / align) * align;
         void *p = nullptr;
-        if (posix_memalign(&p, 64, (size_t)f->linesize[k] * rows + 64) != 0) return nullptr;
+        const size_t bytes = (size_t)f->linesize[k] * rows + 64;
+        if (g_page_frames) {
+            p = mmap(nullptr, (bytes + 4095) / 4096 * 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (p == MAP_FAILED) return nullptr;
+        } else if (posix_memalign(&p, 64, bytes) != 0) return nullptr;
         f->data[k] = (uint8_t *)p;
         std::memset(p, k ? 128 : fill, (size_t)f->linesize[k] * rows + 64);
     }
@@ -97,6 +109,7 @@ int main(int argc, char **argv)
         if (opt("--hash")) { do_hash = std::atoi(argv[++i]); continue; }
         if (opt("--height")) { height = std::atoi(argv[++i]); continue; }
         if (opt("--align")) { align = std::atoi(argv[++i]); continue; }
+        if (opt("--page-frames")) { g_page_frames = std::atoi(argv[++i]) != 0; continue; }
         av.push_back(argv[i]);
     }
     av.push_back("-i"); av.push_back("unused"); av.push_back("-o"); av.push_back("unused");   // (the parser insists, :1634)
@@ -142,10 +155,16 @@ int main(int argc, char **argv)
     const long total = warmup + fields;
     uint64_t hash = 0xcbf29ce484222325ull;
     long consumed = 0;
+    double us_new = 0, us_same = 0, us_wait = 0;        // host time inside the calls (timed part only)
+    long n_new = 0, n_same = 0, n_wait = 0;
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    bool timing = false;
     auto consume = [&](long k) {                      // what output_frame() does after its copy loops: encode (:1237-1250)
         const size_t ri = (size_t)(k % ring);
         if (async) {
+            const double ta = now_us();
             const int r = ntscsim_wait(sim, tickets[ri]);
+            if (timing) { us_wait += now_us() - ta; n_wait++; }
             if (r != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_wait: %s (%s)\n", ntscsim_strerror(r), ntscsim_last_error(sim)); std::exit(1); }
         }
         if (do_hash && has_out[ri]) hash = fnv1a(enc_ring[ri], !out422, hash);
@@ -156,6 +175,7 @@ int main(int argc, char **argv)
         if (video_field == warmup) {
             for (long k = consumed; k < video_field; k++) consume(k);
             t0 = std::chrono::steady_clock::now();
+            timing = true;
         }
         const unsigned field = (unsigned)((video_field & 1) ^ 1);              // :1784
         const bool new_frame = (video_field & 1) == 0;
@@ -170,12 +190,14 @@ int main(int argc, char **argv)
         const unsigned out_field = interlaced_out ? (unsigned)(((video_field - 1) & 1) ^ 1) : field;
         Frame *enc = emit ? enc_ring[ri] : nullptr;
         has_out[ri] = emit ? 1 : 0;
+        const double ts = now_us();
         if (async)
             rc = ntscsim_submit422_avframe(sim, frame, input_frame, 0, new_frame ? 0 : 1, filter, enc, out_mode, out_field, nocomp,
                                            field, (uint64_t)video_field, new_frame ? 0u : NTSCSIM_SUBMIT_SAME_SRC, &tickets[ri]);
         else
             rc = ntscsim_field422_avframe(sim, frame, input_frame, 0, new_frame ? 0 : 1, filter, enc, out_mode, out_field, nocomp,
                                           field, (uint64_t)video_field);
+        if (timing) { if (new_frame) { us_new += now_us() - ts; n_new++; } else { us_same += now_us() - ts; n_same++; } }
         if (rc != NTSCSIM_OK) { std::fprintf(stderr, "field %ld: %s (%s)\n", video_field, ntscsim_strerror(rc), ntscsim_last_error(sim)); return 1; }
         while (consumed + lag <= video_field) consume(consumed);               // `lag` fields behind
     }
@@ -184,13 +206,15 @@ int main(int argc, char **argv)
     uint64_t st[8];
     ntscsim_submit422_stats(sim, st);
     std::printf("{\"mode\": \"%s\", \"fields\": %ld, \"seconds\": %.6f, \"fields_per_s\": %.1f, \"width\": %d, \"height\": %d, "
-                "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, "
+                "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, \"page_frames\": %d, "
+                "\"host_us_per_call\": {\"new_frame\": %.1f, \"same_frame\": %.1f, \"wait\": %.1f}, "
                 "\"fnv1a\": \"%016llx\", \"rng_pos\": %llu, \"stats\": {\"submitted\": %llu, \"launches\": %llu, \"uploads\": %llu, "
-                "\"batched\": %llu, \"one_at_a_time\": %llu, \"frame_uploads\": %llu, \"ring_full_waits\": %llu}}\n",
-                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0,
+                "\"batched\": %llu, \"one_at_a_time\": %llu, \"frame_uploads\": %llu, \"dma_uploads\": %llu, \"ring_full_waits\": %llu}}\n",
+                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0, g_page_frames ? 1 : 0,
+                n_new ? us_new / n_new : 0.0, n_same ? us_same / n_same : 0.0, n_wait ? us_wait / n_wait : 0.0,
                 (unsigned long long)(do_hash ? hash : 0), (unsigned long long)ntscsim_get_rng_pos(sim),
                 (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],
-                (unsigned long long)st[4], (unsigned long long)st[5], (unsigned long long)st[7]);
+                (unsigned long long)st[4], (unsigned long long)st[5], (unsigned long long)st[6], (unsigned long long)st[7]);
     ntscsim_destroy(sim);
     return 0;
 }

@@ -5,11 +5,13 @@
 //
 //   rank_bench [reference switches] [--spawn N | (RANK / WORLD_SIZE / LOCAL_RANK from the environment, e.g. torchrun)]
 //              [--frames F] [--steps K] [--warmup W] [--scaling weak|strong] [--verify 0|1] [--width W --height H]
-//              [--one-device 0|1]
+//              [--one-device 0|1] [--inflight Q]
 //
 // Every rank owns the frames g = rank, rank + N, ... of the clip (weak: the clip has N x F frames, strong: F), keeps
 // its source and destination frames in ITS GPU's HBM and runs ONE prepared batch per step (ntscsim_batch_run: the
-// kernel chain only).  Frame g produces fields 2g and 2g + 1; the rand() position of field k is a closed form
+// kernel chain only); like bench.py it keeps Q steps in flight (default 4: Q contexts with a stream, scratch and a
+// destination clip each, the steps rotate over them -- a lone 600-field launch leaves a second round of one wave per
+// SIMD).  Frame g produces fields 2g and 2g + 1; the rand() position of field k is a closed form
 // (the draws of a composite_layer() call do not depend on the pixels, ffmpeg_ntsc.cpp:1632-1764):
 //     pos(k) = (k / 2) * (draws(parity 1) + draws(parity 0)) + (k & 1) * draws(parity 1)
 // so the union of the ranks' outputs is the one-GPU run byte for byte, and no data moves between GPUs.
@@ -132,7 +134,7 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
 {
     g_rank = rank;
     long frames = 300, steps = 20, warmup = 5;
-    int verify = 1, width = 0, height = 486, one_device = 0;
+    int verify = 1, width = 0, height = 486, one_device = 0, inflight = 4;
     std::string scaling = "weak";
     std::vector<const char *> av;
     av.push_back(argv[0]);
@@ -147,6 +149,7 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
         if (opt("--width")) { width = std::atoi(argv[++i]); continue; }
         if (opt("--height")) { height = std::atoi(argv[++i]); continue; }
         if (opt("--one-device")) { one_device = std::atoi(argv[++i]); continue; }
+        if (opt("--inflight")) { inflight = std::atoi(argv[++i]); continue; }
         av.push_back(argv[i]);
     }
     ntscsim_params prm;
@@ -197,14 +200,18 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
     };
 
     const long total_frames = scaling == "strong" ? frames : frames * world;
-    Share S;
-    if (build_share(S, prm, device, W, H, rank, world, total_frames)) return 1;
-    for (long i = 0; i < warmup; i++) { rc = run_share(S); if (rc != NTSCSIM_OK) return 1; }
+    if (inflight < 1) inflight = 1;
+    if (inflight > 16) inflight = 16;
+    std::vector<Share> Q((size_t)inflight);
+    for (auto &q : Q) if (build_share(q, prm, device, W, H, rank, world, total_frames)) return 1;
+    Share &S = Q[0];
+    for (auto &q : Q) { rc = run_share(q); if (rc != NTSCSIM_OK) return 1; }          // first-call allocations of every context
+    for (long i = 0; i < warmup; i++) { rc = run_share(Q[(size_t)(i % inflight)]); if (rc != NTSCSIM_OK) return 1; }
     HIPOK(hipDeviceSynchronize());
     if (barrier()) return 1;
     const auto t0 = std::chrono::steady_clock::now();
     for (long i = 0; i < steps; i++) {
-        rc = run_share(S);
+        rc = run_share(Q[(size_t)(i % inflight)]);
         if (rc != NTSCSIM_OK) { std::fprintf(stderr, "[rank %d] step %ld: %s (%s)\n", rank, i, ntscsim_strerror(rc), ntscsim_last_error(S.sim)); return 1; }
     }
     HIPOK(hipDeviceSynchronize());
@@ -252,11 +259,11 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
         }
         std::printf("{\"metric\": \"frames/sec (output frames = fields; %dx%d, C++ host, one process per GPU, RCCL barrier / max / all-gather)\", "
                     "\"value\": %.1f, \"unit\": \"frames/s\", \"n_gpus\": %d, \"steps\": %ld, \"warmup\": %ld, \"ms_per_step\": %.4f, "
-                    "\"higher_is_better\": true, \"scaling\": \"%s\", \"dtype\": \"f64\", \"data\": \"synthetic\", "
+                    "\"higher_is_better\": true, \"scaling\": \"%s\", \"dtype\": \"f64\", \"data\": \"synthetic\", \"steps_in_flight\": %d, "
                     "\"fields_per_step\": %llu, \"collectives\": [\"ncclAllReduce(sum) x2 as barriers\", \"ncclAllReduce(max) of the elapsed time\", "
                     "\"ncclAllGather of {checksum, fields, elapsed}\"], \"rank_checksums_verified\": %s, \"ranks\": [",
                     W, H, max_s > 0 ? (double)fields_per_step * steps / max_s : 0.0, world, steps, warmup, max_s / steps * 1e3,
-                    scaling.c_str(), fields_per_step, verified < 0 ? "null" : (verified ? "true" : "false"));
+                    scaling.c_str(), inflight, fields_per_step, verified < 0 ? "null" : (verified ? "true" : "false"));
         for (int r = 0; r < world; r++) {
             double el; std::memcpy(&el, &all[(size_t)3 * r + 2], sizeof(double));
             std::printf("%s{\"rank\": %d, \"checksum\": %llu, \"fields_per_step\": %llu, \"seconds\": %.6f}", r ? ", " : "", r,
@@ -267,7 +274,7 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
         if (verified == 0) ret = 2;
         std::remove(id_file.c_str());
     }
-    free_share(S);
+    for (auto &q : Q) free_share(q);
     (void)hipFree(xbuf);
     (void)hipStreamDestroy(cs);
     ncclCommDestroy(comm);

@@ -27,6 +27,35 @@ def f422(fr):
     return o
 
 
+class PagedYuv(L.Yuv422):
+    """A YUV422P frame whose three planes each start on a page of their own inside ONE anonymous mapping -- what
+    av_frame_get_buffer's per-plane buffers look like to the engine, made deterministic: planes of >= 64 KiB that start
+    on a page boundary are pinned in place (hipHostRegister) and take the DMA upload / kernel delivery paths."""
+
+    def __init__(self, w, h, pad=0, fill=0):
+        import mmap
+        self.w, self.h = w, h
+        self.ls = [w + pad, w // 2 + pad, w // 2 + pad]
+        sizes = [(self.ls[i] * h + 64 + 4095) // 4096 * 4096 for i in range(3)]
+        self._m = mmap.mmap(-1, sum(sizes))
+        self.buf = np.frombuffer(self._m, np.uint8)
+        self.buf[:] = fill
+        self.off = [0, sizes[0], sizes[0] + sizes[1]]
+
+    def copy(self):
+        o = PagedYuv(self.w, self.h, self.ls[0] - self.w)
+        o.buf[:] = self.buf
+        return o
+
+
+def paged_noise(w, h, seed, pad=0):
+    f = PagedYuv(w, h, pad)
+    src = L.yuv_noise(w, h, seed, pad)
+    for k in range(3):
+        f.plane(k)[:] = src.plane(k)
+    return f
+
+
 class Ctx:
     def __init__(self, params, depth=None):
         self.lib = L.product()
@@ -75,6 +104,9 @@ class Ctx:
         a = (C.c_uint64 * 8)()
         self.lib.ntscsim_submit422_stats(self.h, a)
         return list(a)
+
+    def unpin(self):
+        assert self.lib.ntscsim_host_unpin(self.h, None) == 0
 
 
 def enc_frame(w, h, mode, fill=0):
@@ -307,6 +339,51 @@ def test_full_size_stream_equals_sync_and_golden_hash():
     run_loop(p, w, h, 48, 20, OUT_BOB420, "submit", depth=32)
 
 
+@pytest.mark.parametrize("mode", ["sync", "submit"])
+@pytest.mark.parametrize("flags,out_mode,bkey", [(["-vhs"], OUT_BOB422, False), ([], OUT_BOB422, False),
+                                                  (["-bkey-feedback", "40"], OUT_BOB422, True)])
+def test_pinned_planes_take_the_dma_and_kernel_delivery_paths(flags, out_mode, bkey, mode):
+    """Frames whose planes can be pinned in place (page-aligned, >= 64 KiB: 720x480): sources go up by DMA out of the
+    caller's planes, frame / filter / encoder rows are written by the delivery kernels straight into them -- same
+    bytes as the oracle's loop on identical buffers, whole buffers; with ONE persistent frame and 8 iterations per
+    launch only the last writer of each row set delivers it."""
+    w, h, pad, n_src = 720, 480, 16, 6
+    p = L.make_params_tocomp(flags)
+    srcs = [paged_noise(w, h, 300 + j) for j in range(n_src)]
+    frame_o = paged_noise(w, h, 5, pad)
+    random_padding(frame_o, 6)
+    flt_o = paged_noise(w, h, 7, pad) if bkey else None
+    frame_g, flt_g = frame_o.copy(), (flt_o.copy() if bkey else None)
+    o = L.TocompOracleStream(p, oob=L.OOB_MEMORY)
+    ctx = Ctx(p, depth=8 if mode == "submit" else None)
+    exp, got, tickets = [], [], []
+    vf = 0
+    for s_ in srcs:
+        for sub in (0, 1):
+            field = (vf & 1) ^ 1
+            eo, go = PagedYuv(w, h, 0, 7), PagedYuv(w, h, 0, 7)
+            oracle_iteration(o, p, frame_o, s_, field, vf, F_SECOND if sub else 0, flt_o, eo, out_mode, field)
+            it = ctx.loop(frame_g, s_, field, vf, F_SECOND if sub else 0, flt_g, go, out_mode, field)
+            if mode == "sync":
+                ctx.field(it)
+            else:
+                tickets.append(ctx.submit(it, _capi.SUBMIT_SAME_SRC if sub else 0))
+            exp.append(eo)
+            got.append(go)
+            vf += 1
+    ctx.wait()
+    st = ctx.stats()
+    assert ctx.rng_pos == o.rng_pos
+    assert st[6] == n_src * (1 if mode == "submit" else 2)        # every upload was a DMA out of the caller's planes
+    ctx.unpin()
+    ctx.close()
+    same_frames(frame_g, frame_o, "frame")
+    if bkey:
+        same_frames(flt_g, flt_o, "filter frame")
+    for i, (a, b) in enumerate(zip(got, exp)):
+        same_out(a, b, h, out_mode, "encoder frame %d" % i)
+
+
 def test_error_codes():
     w, h = 96, 36
     p = L.make_params_tocomp(["-vhs", "-width", str(w)], output_height=h)
@@ -342,9 +419,10 @@ import subprocess  # noqa: E402
 LOOP = os.path.join(L.PKG, "field_loop422")
 
 
-def run_cpp(mode, flags, fields=60, depth=8, extra=()):
+def run_cpp(mode, flags, fields=60, depth=8, extra=(), env=None):
     r = subprocess.run([LOOP, "--mode", mode, "--fields", str(fields), "--warmup", "0", "--hash", "1", "--depth", str(depth)] +
-                       list(flags) + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                       list(flags) + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr.decode()
     return json.loads(r.stdout.decode().strip().splitlines()[-1])
 
@@ -362,6 +440,14 @@ def test_cpp_loop_submit_equals_sync(flags, extra, batched):
     a = run_cpp("sync", flags, extra=extra)
     b = run_cpp("submit", flags, extra=extra)
     assert a["fnv1a"] == b["fnv1a"] != "0000000000000000" and a["rng_pos"] == b["rng_pos"]
+    # ... and the staging rings (the path the oracle comparisons above go through) deliver what the pinned paths do
+    c = run_cpp("submit", flags, extra=list(extra) + ["--page-frames", "1"], env={"NTSCSIM_SUBMIT422_PIN": "0"})
+    assert c["fnv1a"] == b["fnv1a"] and c["rng_pos"] == b["rng_pos"] and c["stats"]["dma_uploads"] == 0
+    # planes with a mapping of their own are pinned in place (full-size planes only: the engine leaves planes under 64 KiB alone)
+    d = run_cpp("submit", flags, extra=list(extra) + ["--page-frames", "1"])
+    assert d["fnv1a"] == b["fnv1a"] and d["rng_pos"] == b["rng_pos"]
+    if "--height" not in extra:
+        assert d["stats"]["dma_uploads"] == d["stats"]["uploads"] > 0, d["stats"]
     assert b["stats"]["submitted"] == 60
     if batched:
         assert b["stats"]["batched"] == 60 and b["stats"]["launches"] <= 9, b["stats"]

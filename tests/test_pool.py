@@ -89,3 +89,48 @@ def test_pool_needs_a_gpu_and_checks_arguments():
         assert lib.ntscsim_pool_create(C.byref(p), None, 0, C.byref(h)) == _capi.E_NODEV
     assert lib.ntscsim_pool_size(None) == 0
     assert lib.ntscsim_pool_frames_host(None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, 0) == _capi.E_ARG
+
+
+# ---- the C++ rank-per-GPU harness over rccl.h (host/rank_bench.cpp; VERDICT r04 "missing" 4) -------------------------
+@pytest.mark.gpu
+def test_rank_bench_runs_through_rccl_with_one_rank_and_matches_one_context():
+    """One rank on the one GPU we have: the communicator is built from a ncclUniqueId that travelled through a file,
+    the barriers, the MAX all-reduce and the all-gather run through RCCL, rank 0 verifies the gathered checksum by
+    recomputing the share -- and the checksum equals the byte sum of the same fields through the Python veneer."""
+    import json
+    import subprocess
+    exe = os.path.join(L.PKG, "rank_bench")
+    assert os.path.exists(exe)
+    w, h, frames = 720, 486, 12
+    r = subprocess.run([exe, "-vhs", "--spawn", "1", "--frames", str(frames), "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rank_checksums_verified"] is True and line["fields_per_step"] == 2 * frames
+    assert line["value"] > 0 and len(line["ranks"]) == 1
+    # the same fields through the ordinary batched call
+    import torch
+    p = L.make_params(["-vhs"])
+    sim = ntscsim.FieldSimulator(params=p)
+    src = torch.from_numpy(np.stack([L.bars(w, h, j) for j in range(frames)])).cuda()
+    dst = torch.zeros((frames, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, dst, [(k // 2, k // 2, (k & 1) ^ 1, k) for k in range(2 * frames)])
+    sim.sync()
+    assert int(dst.to(torch.int64).sum().item()) == line["ranks"][0]["checksum"]
+    sim.close()
+
+
+@pytest.mark.gpu
+def test_rank_bench_strong_scaling_share_of_rank_1_of_2_is_the_odd_frames():
+    """what rank 1 of 2 would compute (frames 1, 3, 5, ... with their closed-form rand() positions) == those frames of
+    the one-context run: run as world 1 with the second rank's share through the --verify path is not possible on one
+    GPU (RCCL refuses two ranks on one device), so the closed form is checked against the serial stream here"""
+    import ctypes as C
+    w, h = 720, 486
+    p = L.make_params(["-vhs"])
+    c1 = L.product().ntscsim_rng_calls_per_field(C.byref(p), w, h, 1)
+    c0 = L.product().ntscsim_rng_calls_per_field(C.byref(p), w, h, 0)
+    pos, k = 0, 0
+    for k in range(9):
+        assert pos == (k // 2) * (c1 + c0) + (k & 1) * c1          # rank_bench.cpp's closed form
+        pos += c1 if ((k & 1) ^ 1) else c0

@@ -308,15 +308,21 @@ _FORM_CASES = [
     # as four sweeps it is still the preset instantiation, which does not use those identities)
     (["-vhs", "-comp-phase", "90", "-subcarrier-amp", "30"], "k422_fused<false,true,4>|k422_fused<true,false,4>"),
     (["-vhs", "-chroma-dropout", "50000", "-chroma-phase-noise", "0"], "k422_fused<false,true,4>"),
-    (["-vhs", "-vhs-svideo", "1"], "k422_process"),
-    ([], "k422_process"),
+    (["-vhs", "-vhs-svideo", "1"], "k422_fused_sv"),                             # round 5: three sweeps
+    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "lp", "-chroma-dropout", "30000"], "k422_fused_sv"),
+    ([], "k422_direct"),                                                          # round 5: the default preset, two sweeps
+    (["-chroma-noise", "8", "-chroma-phase-noise", "6", "-comp-catv", "-vhs-head-switching", "1"], "k422_direct"),
+    (["-tvstd", "pal", "-out-composite-lowpass", "0"], "k422_direct"),
+    (["-yc-recomb", "1"], "k422_process"),                                        # what stays on the twelve sweeps
+    (["-nocolor-subcarrier"], "k422_process"),
 ]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,form", _FORM_CASES,
                          ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-lp", "vhs-ep", "pal-vhs", "pal-vhs-ep", "vhs-catv",
-                              "vhs-nonoise", "vhs-phase90-amp30", "vhs-dropout", "vhs-svideo", "default"])
+                              "vhs-nonoise", "vhs-phase90-amp30", "vhs-dropout", "vhs-svideo", "vhs-svideo-lp-dropout", "default",
+                              "default-noises-catv-hs", "pal-default-lite", "yc-recomb", "nocolor"])
 @pytest.mark.parametrize("mode", [0, 1, 2, 4], ids=["default", "twelve-sweep", "general-fused", "preset-four-sweep"])
 def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
     """The kernel forms of the -vhs family (streamed: k422_fused<true,true,4> for the preset's own switch
@@ -335,7 +341,7 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
     sim = ntscsim.FieldSimulator(params=p)
     sim.debug_no_fast_decode(mode)
     form, _, four = form.partition("|")
-    preset, fam = form == "k422_fused<true,true,4>" or four == "k422_fused<true,false,4>", form.startswith("k422_fused")
+    preset, fam = form == "k422_fused<true,true,4>" or four == "k422_fused<true,false,4>", form.startswith("k422_fused<")
     want = form
     if mode == 1:
         want = "k422_process"
@@ -352,7 +358,7 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
         sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
         sim.sync()
         ran = sim.last_kernels()
-        assert want in ran and sum(x.startswith(("k422_fused", "k422_process")) for x in ran) == 1, ran
+        assert want in ran and sum(x.startswith(("k422_fused", "k422_process", "k422_direct")) for x in ran) == 1, ran
         got = whole.cpu().numpy()
         bad = (got != frame.buf) & mask
         assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))

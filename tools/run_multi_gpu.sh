@@ -28,3 +28,9 @@ print(b)
 PY
 )
 done
+# ... and the same deal with the C++ host (host/rank_bench.cpp: rccl.h directly, no torch): one JSON line per N
+for n in 1 2 4 8; do
+  [ "$n" -le "$max" ] || break
+  composite-video-simulator_amd/rank_bench -vhs --spawn "$n" --frames 300 --steps 20 --warmup 5 2> /tmp/rank_bench_$n.err | grep '^{' | tail -1 \
+    || { echo "rank_bench N=$n FAILED (see /tmp/rank_bench_$n.err)"; tail -3 /tmp/rank_bench_$n.err; }
+done
