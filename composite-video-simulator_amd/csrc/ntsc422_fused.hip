@@ -603,14 +603,14 @@ typedef FrameSinkT<BurstWriter<4, 16>, BurstWriter<2, 16>> FrameSinkBurst;
 // the separated luma goes through the VHS luma chain and back to R.Y, chroma to R.U / R.V.  SINK:
 // everything goes to the frame through `sink`.  POST: the chroma pair passes the chroma / phase noise on its way
 // (the first separation of the path; SINK + POST = the whole decode side of a switch set WITHOUT the VCR, k422_direct).
-template <bool SINK, bool POST = !SINK>
+template <bool SINK, bool POST = !SINK, class SINKT = FrameSink>
 DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA, int oob0, int oob1,
-               ChromaPost422 &cpost_in, LumaVhs &lv_in, FrameSink &sink_in)
+               ChromaPost422 &cpost_in, LumaVhs &lv_in, SINKT &sink_in)
 {
     // private copies: the states live in registers for the whole sweep
     ChromaPost422 cpost = cpost_in;
     LumaVhs lv = lv_in;
-    FrameSink sink = sink_in;
+    SINKT sink = sink_in;
     const int W2 = W / 2;
     unsigned d0 = 16, d1 = 16, d2 = 0, d3 = 0, sum = 0;
     int ch_even = 0;
@@ -1176,7 +1176,11 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
 //               sharpen and the luma of B1 go through dropout and the output low-pass to the frame row
 // Preconditions as k422_fused (launcher): colour subcarrier on, input chroma low-pass on, no
 // -nocolor-subcarrier-after-yc-sep, no extra -yc-recomb passes.
-template <bool SV>
+// FASTA (launcher: NTSC, no pre-emphasis, luma noise on, even scanline phase, subcarrier amplitude 50, frame rows aligned
+// to 16 / 8 bytes -- the tool's default preset qualifies): sweep A in the streamed preset's form (cooperative 64-byte row
+// loads through an LDS tile, guard-free blocks inside the row), and the decode sweep of the no-VCR form writes the frame in
+// 64-byte bursts staged in the same tile.
+template <bool SV, bool FASTA = false>
 __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDev G,
                                                  const Field422Dev *__restrict__ fields,
                                                  Scratch422 Sc,
@@ -1193,6 +1197,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
 {
     using namespace fused422;
     __shared__ uint32_t ring[31 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t fstage[FASTA ? 64 * 16 * 3 : 4];
     const int lane = threadIdx.x;
     const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above: the VCR's vertical blend)
     const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
@@ -1223,7 +1228,9 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
         lp_.pre_on = P.pre_on != 0; lp_.noise_on = P.noise_k != 0;
         lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring; lp_.lane = lane;
         if (lp_.noise_on) { lp_.rng.init(ring, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
-        if (P.ntsc) sweep_a<true, false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
+        if constexpr (FASTA) sweep_a<true, true, true, true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q, fd.dst_ls[0], fd.dst_ls[1],
+                                                              fd.dst_ls[2], fstage);
+        else if (P.ntsc) sweep_a<true, false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
         else sweep_a<false, false>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q);
     }
     // ---- head switching :669-732 (as in k422_fused)
@@ -1262,7 +1269,14 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
     }
     FrameSink sink;
     sink.begin(P, false, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
-    if constexpr (!SV) {
+    if constexpr (!SV && FASTA) {
+        // ---- the whole decode side in one sweep, the frame row leaving in 64-byte bursts (aligned rows)
+        FrameSinkBurst bs;
+        bs.begin(P, true, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        bs.wy.st = fstage + lane * 16; bs.wu.st = fstage + (64 + lane) * 16; bs.wv.st = fstage + (128 + lane) * 16;
+        LumaVhs nolv;
+        demod<true, true, FrameSinkBurst>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, bs);
+    } else if constexpr (!SV) {
         // ---- the whole decode side in one sweep
         LumaVhs nolv;
         demod<true, true>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, sink);

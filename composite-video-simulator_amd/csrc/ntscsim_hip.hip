@@ -1168,7 +1168,11 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // (aligned frame rows: the 64-byte frame bursts), per chroma delay of the tape speed
     const bool stream_gen = fused && !stream && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 &&
                             D.cdelay >= 4 && D.cdelay <= 6;
-    note_kernel(c, direct ? "k422_direct" : fused_sv ? "k422_fused_sv" : !fused ? "k422_process"
+    // sweep A of the short forms in the streamed preset's shape where its identities hold (the default preset does)
+    const bool fasta = (direct || fused_sv) && !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && even422 && D.amp == 50 &&
+                       D.src_al16 && D.dst_al16;
+    note_kernel(c, direct ? (fasta ? "k422_direct_fast" : "k422_direct") : fused_sv ? (fasta ? "k422_fused_sv_fast" : "k422_fused_sv")
+                          : !fused ? "k422_process"
                           : stream ? "k422_fused<true,true,4>"
                           : stream_gen ? (D.cdelay == 4 ? "k422_fused<false,true,4>" : D.cdelay == 5 ? "k422_fused<false,true,5>" : "k422_fused<false,true,6>")
                           : spec ? "k422_fused<true,false,4>" : "k422_fused<false,false,4>");
@@ -1176,7 +1180,17 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     hipLaunchKernelGGL((k422_fused<__VA_ARGS__>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma)
-    if (direct || fused_sv) {
+    if (fasta) {
+        if (direct)
+            hipLaunchKernelGGL((k422_short<false, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+        else
+            hipLaunchKernelGGL((k422_short<true, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+    }
+    else if (direct || fused_sv) {
         if (direct)
             hipLaunchKernelGGL(k422_short<false>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
                                c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,

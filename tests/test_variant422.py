@@ -308,9 +308,10 @@ _FORM_CASES = [
     # as four sweeps it is still the preset instantiation, which does not use those identities)
     (["-vhs", "-comp-phase", "90", "-subcarrier-amp", "30"], "k422_fused<false,true,4>|k422_fused<true,false,4>"),
     (["-vhs", "-chroma-dropout", "50000", "-chroma-phase-noise", "0"], "k422_fused<false,true,4>"),
-    (["-vhs", "-vhs-svideo", "1"], "k422_fused_sv"),                             # round 5: three sweeps
-    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "lp", "-chroma-dropout", "30000"], "k422_fused_sv"),
-    ([], "k422_direct"),                                                          # round 5: the default preset, two sweeps
+    (["-vhs", "-vhs-svideo", "1"], "k422_fused_sv_fast"),                        # round 5: three sweeps
+    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "lp", "-chroma-dropout", "30000"], "k422_fused_sv_fast"),
+    (["-vhs", "-vhs-svideo", "1", "-comp-phase", "90"], "k422_fused_sv"),          # (odd scanline phases: the general sweep A)
+    ([], "k422_direct_fast"),                                                     # round 5: the default preset, two sweeps
     (["-chroma-noise", "8", "-chroma-phase-noise", "6", "-comp-catv", "-vhs-head-switching", "1"], "k422_direct"),
     (["-tvstd", "pal", "-out-composite-lowpass", "0"], "k422_direct"),
     (["-yc-recomb", "1"], "k422_process"),                                        # what stays on the twelve sweeps
@@ -321,7 +322,8 @@ _FORM_CASES = [
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,form", _FORM_CASES,
                          ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-lp", "vhs-ep", "pal-vhs", "pal-vhs-ep", "vhs-catv",
-                              "vhs-nonoise", "vhs-phase90-amp30", "vhs-dropout", "vhs-svideo", "vhs-svideo-lp-dropout", "default",
+                              "vhs-nonoise", "vhs-phase90-amp30", "vhs-dropout", "vhs-svideo", "vhs-svideo-lp-dropout", "vhs-svideo-phase90",
+                              "default",
                               "default-noises-catv-hs", "pal-default-lite", "yc-recomb", "nocolor"])
 @pytest.mark.parametrize("mode", [0, 1, 2, 4], ids=["default", "twelve-sweep", "general-fused", "preset-four-sweep"])
 def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
@@ -349,6 +351,8 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
         want = "k422_fused<false,false,4>"
     elif mode == 4 and fam:
         want = "k422_fused<true,false,4>" if preset else "k422_fused<false,false,4>"
+    elif mode == 2 and form.endswith("_fast"):
+        want = form[:-5]                       # (the same debug bit keeps the general sweep A of the short forms)
     whole, dev = to_dev_onebuf(torch, frame)
     for k in range(n):
         field = (k & 1) ^ 1
