@@ -1064,6 +1064,14 @@ static int prepare422(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
                 const Key &a = keys[j], &b = keys[i];
                 if (a.hi <= b.lo) continue;
                 if (a.lo != b.lo || a.ls != b.ls) {
+                    // views of one allocation with the same linesize whose pixel columns (plus the separator's two bytes
+                    // behind each row) never meet -- side-by-side tiles, row-interleaved frames with a doubled linesize --
+                    // write disjoint bytes: no race
+                    if (a.ls == b.ls && a.ls > 0) {
+                        const uintptr_t d = (b.lo - a.lo) % (uintptr_t)a.ls;       // b's first column inside a's rows
+                        const uintptr_t span = (uintptr_t)W + 2u;
+                        if (d >= span && d + span <= (uintptr_t)a.ls) continue;
+                    }
                     c->err = "descriptors of one batch write overlapping destination frames that are not the same frame";
                     return NTSCSIM_E_ARG;
                 }

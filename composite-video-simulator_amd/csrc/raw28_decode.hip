@@ -929,7 +929,6 @@ struct ntscsim_raw28 {
     FrontConst K;
     FrontState init;
     bool chunk_forced = false;
-    bool tail_scan = true;         // comb tails: serial first guess before the rounds (NTSCSIM_RAW28_NOTAILSCAN=1: developer A/B switch)
     bool front_pin = true;         // one front-end workgroup per CU (NTSCSIM_RAW28_NOPIN=1: developer A/B switch)
     int warm_lines = 112, chunk = 4096;    // measured: a start 230 levels too high meets the truth after ~100 noisy scanlines
     int warm_boost = 0;            // scanlines of warm-up added after passes that left many links open (see the front end)
@@ -1110,7 +1109,6 @@ extern "C" int ntscsim_raw28_create(const ntscsim_raw28_opts *o, int device, nts
     d->K.slow_margin = 1.1 * (double)FOLLOW_SB * d->K.a_slow * 255.0;            // (0.0626 at 8 x fsc)
     d->K.thr = (int)(uint8_t)(192 * 0.25 * 0.5);                                  // :553
     if (const char *e = std::getenv("NTSCSIM_RAW28_NOPIN")) d->front_pin = std::atoi(e) == 0;
-    if (const char *e = std::getenv("NTSCSIM_RAW28_NOTAILSCAN")) d->tail_scan = std::atoi(e) == 0;
     if (const char *e = std::getenv("NTSCSIM_RAW28_SEG")) { const long long v = std::atoll(e); if (v >= 4096) d->front_seg = (size_t)v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_CHUNKS")) { const int v = std::atoi(e); if (v >= 64) d->max_chunks = v; }
     if (const char *e = std::getenv("NTSCSIM_RAW28_EXACT")) { const int v = std::atoi(e); if (v >= 0) d->exact_lines = v; }

@@ -737,8 +737,7 @@ int  ntscsim_raw28_get_levels(const ntscsim_raw28 *dec, double *blank, double *w
  * source -- lengthens the warm-up of its later passes by 16 scanlines, up to 64: speed only.)
  * Environment (read by ntscsim_raw28_create, developer / test switches; results never depend on them):
  * NTSCSIM_RAW28_SEG = samples the front end takes per segment (default 2^29: 8 bytes of scratch per sample),
- * NTSCSIM_RAW28_CHUNKS = chunk count of its second sweep on long streams, NTSCSIM_RAW28_NOTAILSCAN = 1: comb
- * tails by rounds only, NTSCSIM_RAW28_EXACT = scanlines at the end of the second sweep's warm-up that are walked sample
+ * NTSCSIM_RAW28_CHUNKS = chunk count of its second sweep on long streams, NTSCSIM_RAW28_EXACT = scanlines at the end of the second sweep's warm-up that are walked sample
  * by sample (default 30; the ones before are taken in closed form where that is known to be safe; >= 112: all),
  * NTSCSIM_RAW28_LANES = chunks per wavefront of that sweep (default 16), NTSCSIM_RAW28_GROUP = fields per group of the
  * back half's pipeline behind the sync walk (default 160), NTSCSIM_RAW28_TAILROUNDS = 1: test hook, take the path of

@@ -372,6 +372,49 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
 
 
 @pytest.mark.gpu
+def test_422_batch_accepts_views_of_one_allocation_that_never_meet():
+    """Side-by-side tiles of one wide allocation (same linesize, pixel columns -- and the separator's two bytes behind
+    each row, :496 -- that never meet) write disjoint bytes: one batch, even with the same field parity, == the oracle
+    on each view (the byte-range test alone refused them)."""
+    import torch
+    w, h = 64, 16
+    pad = w + 32                                   # luma linesize 2w + 32, chroma linesize w/2 + w + 32
+    p = L.make_params_tocomp(["-vhs"])
+    lib = L.product()
+    pos1 = lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, 1)
+    wide = cases422.make_source422("noise", w, h, 11, pad)
+    rng = np.random.RandomState(4)
+    wide.buf[:] = rng.randint(16, 236, size=wide.buf.size, dtype=np.uint8)     # both tiles (and the gaps) hold pixels
+    cols = [w + 16, w // 2 + 16, w // 2 + 16]      # where tile B starts in each plane's rows
+
+    class View:                                    # tile B for the oracle: the same buffer, planes shifted by `cols`
+        pass
+    vb = View()
+    vb.w, vb.h, vb.ls, vb.buf = w, h, list(wide.ls), wide.buf
+    vb.off = [wide.off[i] + cols[i] for i in range(3)]
+    vb.cplanes = lambda: L.Yuv422.cplanes(vb)
+    exp = wide.copy()
+    vb_exp = View()
+    vb_exp.w, vb_exp.h, vb_exp.ls, vb_exp.buf, vb_exp.off = w, h, list(exp.ls), exp.buf, list(vb.off)
+    vb_exp.cplanes = lambda: L.Yuv422.cplanes(vb_exp)
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    o.process(exp, 1, 0)
+    o.process(vb_exp, 1, 1)
+    whole = torch.from_numpy(wide.buf.copy()).cuda()
+    full = [whole[wide.off[i]:wide.off[i] + wide.ls[i] * h].view(h, wide.ls[i]) for i in range(3)]
+    tile_a = [full[i][:, :(w if i == 0 else w // 2)] for i in range(3)]
+    tile_b = [full[i][:, cols[i]:cols[i] + (w if i == 0 else w // 2)] for i in range(3)]
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.fields422([{"dst": tile_a, "field": 1, "fieldno": 0, "rng_pos": 0},
+                   {"dst": tile_b, "field": 1, "fieldno": 1, "rng_pos": pos1}], w, h)
+    sim.sync()
+    got = whole.cpu().numpy()
+    assert np.array_equal(got, exp.buf), int((got != exp.buf).sum())
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
 def test_422_batch_refuses_racing_descriptors():
     """Two descriptors of one call on the same destination frame: same field = write-write race; both
     fields with luma rows tighter than width + 2 = the Y/C separator of one field would read bytes the
