@@ -147,7 +147,7 @@ e2e = d.get("end_to_end", {})
 rd = "# profiles/ -- round %s (MI355X, gfx950, ROCm 7.2)\n\n" % tag[1:]
 rd += "Everything here comes from `python bench.py` (BASELINE configs[1]: 720x486, 600 fields per step, `-vhs`) and the probes in `tools/`; `tools/refresh_profiles.sh` shows the commands, `tools/make_profiles.py` assembles this directory.  Files of earlier rounds (`r01_*` … `r03_*`) are kept for comparison.\n\n"
 rd += "| file | command | what |\n|---|---|---|\n"
-rd += "| `%s_bench.json` | `python bench.py` | the bench line: value, value_sustained, roofline (+ cycle-weighted `valu`, calibrated `traffic`), cpu_baseline, device_stream, end_to_end (incl. `field_submit`), variant422, raw28, sizes, presets |\n" % tag
+rd += "| `%s_bench.json` | `python bench.py` | the bench line: value, value_sustained, roofline (+ cycle-weighted `valu`, calibrated `traffic`), cpu_baseline, device_stream, end_to_end (incl. `field_submit`, `field_submit422`), multi_gpu_cpp_host, variant422, raw28, sizes, presets |\n" % tag
 rd += "| `%s_kernel_stats_default_cmd.csv` | `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-fields 0 --no-extras` | 4 steps in flight: kernels of different steps share the GPU, wall durations stretch; **Min** = un-shared duration |\n" % tag
 rd += "| `%s_kernel_stats_inflight1.csv` | `... --inflight 1` | one step at a time: per-kernel durations without overlap |\n" % tag
 rd += "| `%s_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--inflight 1`) | FETCH_SIZE, WRITE_SIZE, SQ counters per kernel (mean per launch) |\n" % tag
@@ -157,15 +157,18 @@ rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction c
 rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_pmc_summary_to_composite.txt` | `python bench.py --tool to_composite`, `tools/kstats.sh ... --tool to_composite --inflight 1`, `tools/pmc422.sh` | the same three for the YUV422P tool |\n" % (tag, tag, tag)
 rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- python tools/raw28_probe.py` | kernels of the raw-composite decoder on a 600-field capture (4 calls) |\n" % tag
 rd += "| `%s_bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...` | the driver's own window |\n" % tag
-rd += "| `%s_decode_census.txt`, `%s_loop_histograms.txt` | `tools/loop_census.py --hist` on `hipcc -S`; source accounting | where the VALU instructions of `k_decode_fast` go, stage by stage; what the round-4 diet removed; what was measured and not done (noise pre-pass, LDS luma ring, packed fp32); opcode histograms of the steady loops of the hand-tuned decoder forms |\n" % (tag, tag)
+rd += "| `r04_decode_census.txt`, `%s_loop_histograms.txt` | `tools/loop_census.py --hist` on `hipcc -S`; source accounting | where the VALU instructions of `k_decode_fast` go, stage by stage; what the round-4 diet removed; what was measured and not done (noise pre-pass, LDS luma ring, packed fp32) -- the kernel is unchanged since; opcode histograms of the steady loops of the hand-tuned decoder forms on this round's build |\n" % tag
 rd += "| `r04_fetch_calibration.txt` | `tools/fetch_calibrate.sh` (`tools/fetch_probe.hip`) | FETCH_SIZE / WRITE_SIZE against known byte counts for this library's access shapes: the factors `traffic.json` applies |\n"
 rd += "| `%s_submit_probe.txt` | `tools/submit_probe.sh` (`host/field_loop.cpp`, `tools/link_probe.hip`) | `ntscsim_submit()` / `ntscsim_wait()` against the synchronous call: byte identity (FNV-1a of every consumed frame), fields/s by depth / lanes / line doubling / source handling / delivery path / lag, GPU spans of consecutive launches, the host link's rates |\n" % tag
 rd += "| `%s_dryrun_two_ranks.txt` | `tools/dryrun_two_ranks_one_gpu.sh` | `bench.py` with two ranks on the one GPU: RCCL refuses two ranks on one device, the same run with gloo verifies every rank's checksum |\n" % tag
-rd += "| `%s_nt_probe.txt` | `tools/nt_probe.sh`, `tools/nt422_probe.sh` | A/B builds on one box: streaming (nt) stores / loads on the path's planes -- fields/s, kernel times, raw FETCH_SIZE / WRITE_SIZE per launch (shipped: output pixels, composite plane, the luma path's re-read; not shipped: the encoder's source loads, the YUV422P burst writer) |\n" % tag
-rd += "| `%s_raw28_sweep.txt`, `%s_raw28_noise.txt` | `tools/raw28_sweep_r04.sh`, `tools/raw28_noise_probe.py` (`tools/follow_guess_probe.c` for the CPU side) | the raw-composite decoder against the switches of its second sweep (exact scanlines behind the closed-form warm-up, chunks per wavefront, the fall-back when lanes are out of step, the run-based form that was dropped) and against the capture's noise level (links left to the repair rounds, warm-up lengths that close them) |\n" % (tag, tag)
-rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_%s.sh` | one-off parity sweeps on the final build (random switch sets of both tools, full size, the any-phase / full-output-low-pass / pre-emphasis / S-Video families at full size with the kernel forms listed; the raw-composite decoder on random captures / streams / speculation settings) |\n" % (tag, tag)
+rd += "| `r04_nt_probe.txt` | `tools/nt_probe.sh`, `tools/nt422_probe.sh` | A/B builds on one box: streaming (nt) stores / loads on the path's planes -- fields/s, kernel times, raw FETCH_SIZE / WRITE_SIZE per launch (shipped: output pixels, composite plane, the luma path's re-read; not shipped: the encoder's source loads, the YUV422P burst writer) |\n"
+rd += "| `r04_raw28_sweep.txt`, `r04_raw28_noise.txt` | `tools/raw28_sweep_r04.sh`, `tools/raw28_noise_probe.py` (`tools/follow_guess_probe.c` for the CPU side) | the raw-composite decoder against the switches of its second sweep (exact scanlines behind the closed-form warm-up, chunks per wavefront, the fall-back when lanes are out of step, the run-based form that was dropped) and against the capture's noise level (links left to the repair rounds, warm-up lengths that close them) |\n"
+rd += "| `r04_fuzz_sweep.txt` | `tools/fuzz_r04.sh` | one-off parity sweeps on the final build (random switch sets of both tools, full size, the any-phase / full-output-low-pass / pre-emphasis / S-Video families at full size with the kernel forms listed; the raw-composite decoder on random captures / streams / speculation settings); the kernels those sweeps cover are unchanged since |\n"
 rd += "| `r03_decode_experiments.txt`, `r03_clock_under_load.txt`, `r03_composite_range.txt`, `r03_variant_sweeps.txt` | (round 3) | A/B experiments on the dominant kernel; shader clock under load (2.31-2.32 GHz); value range of the composite plane; wave-clock share of the YUV422P kernel's sweeps |\n"
 rd += "| `%s_raw28_front_pmc.txt` | `tools/pmc_raw28.sh`, `tools/follow_probe.hip` | counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront |\n" % tag
+rd += "| `%s_host422_loop_probe.txt` | `tools/host422_loop_probe.sh` (`host/field_loop422.cpp`) | (round 5) the YUV422P tool's loop on host frames, `ntscsim_field422()` / `ntscsim_submit422()`: byte identity (FNV-1a of every encoder frame) across sync / submit / staging rings / page-owned planes for six switch sets, fields/s by switch set, depth and frame allocation, host time inside the calls |\n" % tag
+rd += "| `%s_sync_call_stats.csv` | `rocprofv3 --kernel-trace --memory-copy-trace --stats -- field_loop -vhs --mode sync` | (round 5) where the 0.54 ms of one synchronous `ntscsim_field()` call go, kernel by kernel |\n" % tag
+rd += "| `%s_rank_bench.json` | `rank_bench -vhs --spawn 1 --frames 300 --steps 40 --warmup 8` | (round 5) the C++ rank-per-GPU harness over `rccl.h` with the one rank this box has |\n" % tag
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
 rd += "`value` = %.0f frames/s (fields/s; %d steps, %.3f ms per 600-field step), `value_sustained` = %.0f (the same step for %.2f s).  " % (
@@ -200,6 +203,17 @@ if e2e:
                                                      (fsd.get("depth32_staging_ring") or {}).get("fields_per_s", 0)))
     if e2e.get("cli"):
         rd += "`ntsc_cli -vhs -i bars:3000 -o null:` %.0f fields/s (`end_to_end.cli`).  " % e2e["cli"]
+if e2e.get("field_submit422"):
+    f4 = e2e.get("field_submit422_detail", {})
+    g = lambda k_: (f4.get(k_) or {}).get("fields_per_s", 0) if isinstance(f4.get(k_), dict) else (f4.get(k_) or 0)
+    rd += ("\n\nThe YUV422P tool's loop on host frames (`host/field_loop422.cpp`, 720x480, depth 32; `end_to_end.field_submit422*`): %.0f fields/s with `-vhs` "
+           "(posix_memalign'ed planes: staging rings), %.0f on page-owned planes (pinned in place), %.0f with `-vhs -422` on page-owned planes, %.0f with the default preset, "
+           "%.0f one iteration at a time (tight rows, 704 wide), %.0f for the synchronous `ntscsim_field422()`.  " % (
+               e2e["field_submit422"], g("depth32_vhs_page_frames"), g("depth32_vhs_422_page_frames"), g("depth32_default_preset"),
+               g("tight_rows_704_one_at_a_time"), g("loop_sync_fields_per_s")))
+mg = d.get("multi_gpu_cpp_host") or {}
+if mg.get("value"):
+    rd += "`rank_bench --spawn 1` (C++ host, `rccl.h`): %.0f fields/s, checksums verified: %s.  " % (mg["value"], mg.get("rank_checksums_verified"))
 if "device_stream" in d and "value" in d["device_stream"]:
     rd += "\n\nA device-resident stream of fresh batches (`device_stream`: every step the next 600 fields through `ntscsim_fields_device()`, preparation inside the clock): %.0f frames/s = %.2f x `value`, last step verified: %s.  " % (
         d["device_stream"]["value"], d["device_stream"]["value"] / d["value"], d["device_stream"].get("verified_last_step"))
@@ -249,5 +263,9 @@ if tc:
                kname, tag, b4["roofline"]["kernel_ms"] * 1e3, ks[1], b4["roofline"]["frac"], b4["roofline"]["algorithmic_bytes_per_launch"] / 1e6,
                tc["pmc"]["FETCH_SIZE"] * 1024 / 1e6, tc["pmc"]["WRITE_SIZE"] * 1024 / 1e6, tag, tc["pmc"]["SQ_INSTS_VALU"],
                b4.get("cpu_baseline", {}).get("value", 0), b4.get("cpu_baseline", {}).get("kind", "-"), b4.get("speedup_vs_cpu_1core", 0)))
+    pr4 = b4.get("presets") or {}
+    if pr4:
+        rd += "\nSwitch-set families (`presets`, 24 steps after one per context, no pre-roll): " + "; ".join(
+            "`%s` %.0f frames/s on `%s`" % (k_, v_.get("value", 0), ", ".join(v_.get("kernels", []))) for k_, v_ in pr4.items() if "value" in v_) + ".\n"
 open("%s/README.md" % P, "w").write(rd)
 print(rd)

@@ -4,7 +4,7 @@ profiles/ (run after tools/refresh_profiles.sh local <tag>):  python tools/readm
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 d = json.load(open("profiles/%s_bench.json" % tag))
 t = json.load(open("profiles/%s_bench_to_composite.json" % tag))
 f = json.load(open("profiles/%s_bench_fast32.json" % tag))
@@ -25,6 +25,25 @@ def fps(k):
     x = fs.get(k) or {}
     return (x.get("fields_per_s") or 0) / 1e3
 pre = (d["config"].get("pre_roll") or {})
+f4 = e.get("field_submit422_detail") or {}
+def f4ps(k):
+    x = f4.get(k)
+    return ((x.get("fields_per_s") or 0) if isinstance(x, dict) else (x or 0)) / 1e3
+tp = t.get("presets") or {}
+v422 = ""
+if e.get("field_submit422"):
+    v422 = ("  The YUV422P tool on HOST frames (`ntscsim_field422()` / `ntscsim_submit422()`, `host/field_loop422.cpp`: the loop of "
+            "ffmpeg_to_composite.cpp:1783-1800 with its four calls replaced by one, 720×480, depth 32): %.0fk fields/s on page-owned planes "
+            "(pinned in place; `-vhs -422`), %.0fk through the staging rings (`-vhs`, posix_memalign'ed planes), %.1fk one iteration at a time "
+            "(tight rows), %.1fk synchronous (`end_to_end.field_submit422*`)." % (
+                f4ps("depth32_vhs_422_page_frames"), e["field_submit422"] / 1e3, f4ps("tight_rows_704_one_at_a_time"), f4ps("loop_sync_fields_per_s")))
+    if tp.get("default", {}).get("value"):
+        v422 += ("  Its switch-set families on the device (`bench.py --tool to_composite` → `presets`): default preset %dk frames/s (`%s`), "
+                 "`-vhs -vhs-svideo 1` %dk (`%s`)." % (round(tp["default"]["value"] / 1e3), ", ".join(tp["default"].get("kernels", [])),
+                                                     round(tp.get("vhs_svideo", {}).get("value", 0) / 1e3), ", ".join(tp.get("vhs_svideo", {}).get("kernels", []))))
+mg = d.get("multi_gpu_cpp_host") or {}
+mgpu = ("  One process per GPU with the C++ host over `rccl.h` (`host/rank_bench.cpp`, here with the one rank this box has): %dk fields/s, checksums verified."
+        % round(mg["value"] / 1e3)) if mg.get("value") else ""
 new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` preset, exact mode; every figure is\n"
        "a key of `profiles/%s_bench.json`, the line `python bench.py` prints; `profiles/README.md` maps the\n"
        "rest; box-to-box spread ≈ ±4 %%):\n"
@@ -42,13 +61,13 @@ new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` pres
        "bound, not HBM bound: `roofline.frac` (HBM, algorithmic bytes) = %.3f, and %.2f is the most a kernel chain with the\n"
        "reference's fp64 arithmetic could reach (`roofline.valu.hbm_frac_ceiling_exact_mode`); `roofline.valu.path_frac_nominal` =\n"
        "%.2f of the VALU issue capacity at the pipe's nominal 4 / 2 cycles per instruction (%.2f at the measured slowest-wave\n"
-       "costs; PMC instruction counts × each kernel's instruction mix ÷ measured time) — see `profiles/README.md`, `profiles/%s_decode_census.txt` and DESIGN.md §5 for what\n"
+       "costs; PMC instruction counts × each kernel's instruction mix ÷ measured time) — see `profiles/README.md`, `profiles/r04_decode_census.txt` and DESIGN.md §5 for what\n"
        "was measured and what is derived.  The drop-in on HOST frames: one synchronous `ntscsim_field()` per `composite_layer()` call %.1fk fields/s; the\n"
        "same loop with `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`, pageable AVFrame-shaped buffers pinned in place) **%.0fk** with ONE\n"
        "source frame rewritten per decoded frame, %.0fk with the source re-pointed at decoded frames, %.0fk with the line doubling delivered too, %.0fk at depth 128\n"
        "(`end_to_end.field_submit*`; %.0f × the reference on one core).  Whole clips from host memory (`ntscsim_frames_host`): %.0fk\n"
-       "fields/s BGRA out, %.0fk with YUV420P made on the GPU, %.0fk with YUV420P in as well.%s%s  Optional `NTSCSIM_MODE_FAST32` (fp32 filters,\n"
-       "≤1 LSB, not bit-exact): %dk fields/s (`profiles/%s_bench_fast32.json`).\n\n" % (
+       "fields/s BGRA out, %.0fk with YUV420P made on the GPU, %.0fk with YUV420P in as well.%s%s%s%s  Not a headline: the optional\n"
+       "`NTSCSIM_MODE_FAST32` (the same kernels with fp32 filter states, ≤1 LSB, not bit-exact) runs %dk fields/s (`profiles/%s_bench_fast32.json`).\n\n" % (
            tag[1:].lstrip("0"), tag, round(d["value_sustained"] / 1e3), (d.get("sustained") or {}).get("seconds", 0.5), round(d["value"] / 1e3), d["steps"],
            round(json.load(open("profiles/%s_bench_driver_cmd.json" % tag))["value"] / 1e3), tag,
            round(ds.get("value", 0) / 1e3), ds.get("value", 0) / d["value"],
@@ -58,11 +77,11 @@ new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` pres
            round(d["presets"]["default"]["value"] / 1e3),
            ", ".join("%s %dk (%.2f)" % (k[4:], round(x["value"] / 1e3), x.get("frac_of_preset") or 0) for k, x in p_.items() if k.startswith("vhs_") and "value" in x),
            tag, round(t["value_sustained"] / 1e3), round(t["value"] / 1e3), d["roofline"]["frac"], v["hbm_frac_ceiling_exact_mode"],
-           v["path_frac_nominal"], v["path_frac"], tag, e["field_call"] / 1e3,
+           v["path_frac_nominal"], v["path_frac"], e["field_call"] / 1e3,
            e.get("field_submit", 0) / 1e3, fps("depth32_decoder_frames"), fps("depth32_bob"), fps("depth128"),
            e.get("field_submit", 0) / cb["value"],
            e["bgra_pinned"] / 1e3, e["yuv420p_pinned"] / 1e3,
-           e.get("yuv420p_in_yuv420p_out_pinned", 0) / 1e3, cli, raw28,
+           e.get("yuv420p_in_yuv420p_out_pinned", 0) / 1e3, cli, raw28, v422, mgpu,
            round(f["value"] / 1e3), tag))
 open("README.md", "w").write(s[:a] + new + s[b:])
 print(new)

@@ -13,13 +13,13 @@ if [ "$mode" = gpu ]; then
   timeout 250 tools/kstats.sh ks_${tag}_default --no-extras --sustain-seconds 0 > /dev/null
   timeout 120 tools/bin/valu_rate_probe > gpurun_out/valu_rates_$tag.txt 2>&1
   timeout 120 tools/bin/chain_probe > gpurun_out/chain_probe_$tag.txt 2>&1
-  timeout 500 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
+  timeout 900 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
   timeout 200 python bench.py --mode fast32 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_fast32.json 2>> gpurun_out/bench_$tag.err
   # the command the driver runs at round end (its own K / W)
   timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_driver_cmd.json 2>> gpurun_out/bench_$tag.err
   timeout 500 bash tools/pmc422.sh pmc422_$tag > /dev/null 2>&1
   timeout 250 tools/kstats.sh ks_${tag}_tocomp --tool to_composite --inflight 1 --steps 20 --sustain-seconds 0 > /dev/null
-  timeout 300 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
+  timeout 600 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
   ( export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/ks_${tag}_raw28; mkdir -p $O; cd /tmp;
     timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ks -- python $R/tools/raw28_probe.py > $O/probe.log 2>&1 < /dev/null;
     f=$(find $O -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv )
@@ -28,6 +28,13 @@ if [ "$mode" = gpu ]; then
   timeout 200 bash tools/fetch_calibrate.sh > /dev/null 2>&1       # -> gpurun_out/fetch_calibration.txt
   timeout 300 sh tools/submit_probe.sh > /dev/null 2>&1            # -> gpurun_out/submit_probe.txt
   timeout 120 bash tools/dryrun_two_ranks_one_gpu.sh nccl > /dev/null 2>&1   # -> gpurun_out/dryrun_two_ranks.txt
+  timeout 400 sh tools/host422_loop_probe.sh > /dev/null 2>&1      # -> gpurun_out/host422_loop_probe.txt  (round 5)
+  # the synchronous one-field call under the kernel trace: where its 0.54 ms go (round 5)
+  ( export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/ks_${tag}_sync; mkdir -p $O; cd /tmp;
+    timeout 120 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $O -o ks -- $R/composite-video-simulator_amd/field_loop -vhs --mode sync --fields 300 --warmup 50 > $O/probe.log 2>&1 < /dev/null;
+    f=$(find $O -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv;
+    f=$(find $O -name "*memory_copy_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/memory_copy_stats.csv )
+  timeout 120 composite-video-simulator_amd/rank_bench -vhs --spawn 1 --frames 300 --steps 40 --warmup 8 > gpurun_out/rank_bench_$tag.txt 2>&1
   tail -c 600 gpurun_out/bench_$tag.json; tail -c 400 gpurun_out/bench_${tag}_tocomp.json
 else
   S=composite-video-simulator_amd/csrc
@@ -48,6 +55,9 @@ else
   [ -s gpurun_out/bench_${tag}_driver_cmd.json ] && cp gpurun_out/bench_${tag}_driver_cmd.json profiles/${tag}_bench_driver_cmd.json
   [ -s gpurun_out/submit_probe.txt ] && cp gpurun_out/submit_probe.txt profiles/${tag}_submit_probe.txt
   [ -s gpurun_out/dryrun_two_ranks.txt ] && cp gpurun_out/dryrun_two_ranks.txt profiles/${tag}_dryrun_two_ranks.txt
+  [ -s gpurun_out/host422_loop_probe.txt ] && cp gpurun_out/host422_loop_probe.txt profiles/${tag}_host422_loop_probe.txt
+  [ -s gpurun_out/ks_${tag}_sync/kernel_stats.csv ] && { cat gpurun_out/ks_${tag}_sync/kernel_stats.csv; echo; cat gpurun_out/ks_${tag}_sync/memory_copy_stats.csv; } > profiles/${tag}_sync_call_stats.csv
+  [ -s gpurun_out/rank_bench_$tag.txt ] && grep '^{' gpurun_out/rank_bench_$tag.txt > profiles/${tag}_rank_bench.json
   # opcode histograms of the hand-tuned decoder forms' steady loops (the per-stage census: profiles/${tag}_decode_census.txt)
   { for k in 'k_decode_fastILb1EdLb0EE' 'k_decode_fast_xiIdE' 'k_decode_fast_foIdE' 'k_decode_fast_svIdE'; do
       echo "== $k"; (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s "$k" --hist | awk 'NR % 2 == 1 || 1' | cut -c1-1400 | grep -A1 "VALU [67][0-9][0-9] " | head -2); done; } > profiles/${tag}_loop_histograms.txt 2>/dev/null
