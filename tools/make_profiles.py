@@ -140,6 +140,9 @@ if tocomp and os.path.exists(tocomp[0]) and os.path.getsize(tocomp[0]) > 10:
         "note": "tools/pmc422.sh (tools/variant_probe.py: one 600-field launch per call); FETCH/WRITE include the "
                 "packed composite-byte plane sweep A hands to the streamed pass (1 B/pixel each way)"}
     traffic["720x486 -vhs to_composite"]["k422_kernel"] = [k for k in pm2 if "k422_fused" in k][0]
+for k_ in traffic:
+    if isinstance(traffic[k_], dict):
+        traffic[k_]["round"] = tag        # which measurement round these counters come from (bench.py: roofline.traffic_source)
 json.dump(traffic, open("%s/traffic.json" % P, "w"), indent=1)
 
 v = d["roofline"].get("valu") or {}
