@@ -128,6 +128,9 @@ static void ntsc_to_yuv(const ntscsim_params *p, tocomp_planes *d, unsigned fiel
         for (x = 0; x < W; x++) {
             uint8_t c;
             if (x + 2 < W || oob_mode == TOCOMP_OOB_MEMORY) c = Y[x + 2];   /* :496 reads past the row */
+            else if (oob_mode == TOCOMP_OOB_PLANE &&
+                     (size_t)y * (size_t)d->linesize[0] + (size_t)x + 2 < (size_t)d->linesize[0] * (size_t)d->height)
+                c = Y[x + 2];                      /* ... but stays inside the luma plane: the caller's own bytes */
             else c = 16;
             sum -= dl[0];
             dl[0] = dl[1]; dl[1] = dl[2]; dl[2] = dl[3]; dl[3] = c;

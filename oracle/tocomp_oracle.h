@@ -11,7 +11,11 @@
  *   TOCOMP_OOB_DEFINED (0): the value 16 (black), the box filter's own pre-charge value -- this is
  *                           the semantics of the product and of all GPU parity tests;
  *   TOCOMP_OOB_MEMORY  (1): whatever follows the row in the caller's buffer, like the reference --
- *                           used only to pin this restatement against the reference extract.
+ *                           used to pin this restatement against the reference extract;
+ *   TOCOMP_OOB_PLANE   (2): the product's documented contract (include/ntscsim.h): the caller's bytes where the read
+ *                           stays inside the luma plane (height * linesize bytes: padding, or the next row's first
+ *                           pixels), 16 where it would leave it (the last row of a plane with linesize < width + 2,
+ *                           where the reference reads memory it does not own).  == MEMORY wherever both are defined.
  * The out-of-array writes are dropped in both modes (they never feed a read).
  */
 #ifndef TOCOMP_ORACLE_H
@@ -22,7 +26,7 @@
 extern "C" {
 #endif
 
-enum { TOCOMP_OOB_DEFINED = 0, TOCOMP_OOB_MEMORY = 1 };
+enum { TOCOMP_OOB_DEFINED = 0, TOCOMP_OOB_MEMORY = 1, TOCOMP_OOB_PLANE = 2 };
 
 typedef struct tocomp_planes {
     uint8_t *data[3];       /* Y, U, V  (4:2:2: U,V are width/2 wide, full height) */

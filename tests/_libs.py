@@ -185,7 +185,7 @@ class RefStream:
 
 # ------------------------------------------------------------------ 8-bit YUV422P variant -----
 TOCOMP_REF_SO = os.path.join(ROOT, "oracle", "_ref", "libtocomp_ref.so")
-OOB_DEFINED, OOB_MEMORY = 0, 1
+OOB_DEFINED, OOB_MEMORY, OOB_PLANE = 0, 1, 2
 
 
 class TocompPlanes(C.Structure):

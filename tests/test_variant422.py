@@ -179,6 +179,30 @@ def test_oracle_reproduces_reference_golden(m):
         assert np.array_equal(fr.buf, _GOLD422["%s__after%d" % (name, k)]), "field %d" % k
 
 
+def test_oracle_plane_mode_is_memory_mode_inside_the_plane():
+    """TOCOMP_OOB_PLANE -- the product's contract for the separator's read past a row (:496): the caller's bytes where
+    they lie inside the luma plane, 16 where they do not -- equals the reference's literal read (MEMORY mode) on padded
+    rows everywhere, and on tight rows everywhere except the right margin of the frame's last row."""
+    for flags in (["-vhs"], [], ["-vhs", "-vhs-speed", "ep", "-vhs-svideo", "1"]):
+        p = L.make_params_tocomp(flags)
+        for pad in (0, 1, 2, 32):
+            a = cases422.make_source422("noise", 96, 20, 3, pad)
+            b = a.copy()
+            oa, ob = L.TocompOracleStream(p, L.OOB_MEMORY), L.TocompOracleStream(p, L.OOB_PLANE)
+            for k in range(4):
+                oa.process(a, (k & 1) ^ 1, k)
+                ob.process(b, (k & 1) ^ 1, k)
+            assert oa.rng_pos == ob.rng_pos
+            if pad >= 2:
+                assert np.array_equal(a.buf, b.buf), (flags, pad)
+            else:
+                diff = a.buf != b.buf
+                for i in range(3):
+                    n = a.ls[i] * a.h
+                    d = diff[a.off[i]:a.off[i] + n].reshape(a.h, a.ls[i])
+                    assert not d[:a.h - 1].any(), (flags, pad, i)          # only the last row may differ
+
+
 def test_to_composite_flag_mirror():
     p = L.make_params_tocomp([])
     assert p.vhs_head_switching_phase == 1.0 - ((4.5 + 0.01) / 262.5)          # :274
