@@ -651,14 +651,9 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
 // VHS chroma low-pass :834-855 (output lands d samples back, the last d keep their input) ->
 // vertical blend :862-882 -> chroma sharpen :904-924 -> modulate onto the luma in R.Y :926-928.
 // DS: the chroma delay as a constant (4 = SP tape speed), 0 = read it from P
-// SV (S-Video out of the VCR, -vhs-svideo 1 :926: no re-modulation, no second separation): luma as B1 left it and the
-// chroma of this sweep go to the frame through `sink` (dropout :932-942, output low-pass :948-951) instead.
-template <int DS, bool SV = false>
-DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k, double a_sh_c, double sharpen_c,
-                  FrameSink *sink_in = nullptr)
+template <int DS>
+DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k, double a_sh_c, double sharpen_c)
 {
-    FrameSink sink;
-    if constexpr (SV) sink = *sink_in;
     const int W2 = W / 2;
     const int d = DS ? DS : P.cdelay;
     const bool blend = P.vblend && P.ntsc;
@@ -702,18 +697,15 @@ DEV void sweep_b2(const DevParams &P, const Row422 &R, int W, unsigned xi, int k
 #pragma unroll
             for (int sx = 0; sx < 2; sx++) {
                 const int lx = 2 * xo + sx;
-                if constexpr (SV) { sink.luma(lx, ry.get(lj + sx)); continue; }
                 const unsigned ph = (xi + (unsigned)lx) & 3u;
                 int chroma = ((ph & 1u) ? v - 128 : u - 128) * P.amp;
                 if (ph & 2u) chroma = -chroma;
                 oy.put(lx, clampu8(ry.get(lj + sx) + chroma / 50));
             }
-            if constexpr (SV) sink.chroma(xo, u, v);
         }
         if (j_ == BK - 1 || x == W2 + d - 1) rv.advance();
     SWEEP_END
-    if constexpr (SV) sink.finish(W);
-    else oy.finish(W);
+    oy.finish(W);
 }
 
 
@@ -801,7 +793,9 @@ struct StreamB {
         }
     }
     // c0, c1: composite bytes 2i, 2i+1 after head switching (past the row: the caller's two bytes, then unused)
-    template <bool EDGE>
+    // SV (S-Video out of the VCR, -vhs-svideo 1, :926: no re-modulation and no second separation): the VCR's luma and
+    // chroma of sample m2 go to the frame sink as they are -- luma 2 m2, 2 m2 + 1 out of the delay line, chroma m2.
+    template <bool EDGE, bool SV = false>
     DEV void iter(const DevParams &P, int i, int c0, int c1)
     {
         // ---- main stream: separation 1 at x = 2i, 2i+1
@@ -858,6 +852,15 @@ struct StreamB {
             s = v;
             ts = sV.push(s, a_sh_c);
             v = clampu8((int)(s + ((s - ts) * sharpen_c)));
+            if constexpr (SV) {
+                sink.luma(2 * m2, yq[0]);
+                sink.luma(2 * m2 + 1, yq[1]);
+                if (EDGE) sink.chroma(m2, u, v);
+                else {
+                    if (sink.drop) { u = 128; v = 128; }
+                    sink.chroma_inner(m2, u, v);
+                }
+            } else {
             // re-modulate :434-477 onto the VCR luma of 2 m2, 2 m2 + 1, separate again
 #pragma unroll
             for (int sx = 0; sx < 2; sx++) {
@@ -867,7 +870,8 @@ struct StreamB {
                 if (ph & 2u) chroma = -chroma;
                 sep2<EDGE>(P, lx, clampu8(yq[sx] + chroma / 50));
             }
-        } else if (EDGE) {
+            }
+        } else if (EDGE && !SV) {
             // lanes must stay in step for the wave shift of the blend: nothing to shift here (m2 is wave-uniform)
             if (m2 == W2) { sep2<true>(P, W, oob0); sep2<true>(P, W + 1, oob1); }   // Y[x+2] past the row :496
         }
@@ -986,7 +990,9 @@ struct StreamB {
 // STREAM: sweeps B1-B3 as the one streamed pass of StreamB above (aligned frame rows; DD = the chroma delay
 // of the tape speed).  With SPEC its steady loop is the preset's iter_fast, otherwise the guard-free form of
 // the general iteration with the switches read at run time.
-template <bool SPEC, bool STREAM = false, int DD = 4>
+// SVID (with STREAM, not SPEC): the VCR with S-Video out -- the streamed pass without its re-modulation / second
+// separation (StreamB::iter<EDGE, true>): "k422_fused_sv<D>".
+template <bool SPEC, bool STREAM = false, int DD = 4, bool SVID = false>
 __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevParams P, GeomDev G,
                                                  const Field422Dev *__restrict__ fields,
                                                  Scratch422 Sc,
@@ -1100,7 +1106,7 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
         const int W2 = W / 2, NIT = W2 + DD + 2;
         auto in_byte = [&](int x) -> int { return x < W ? R.Y.byte_at(x) : (x == W ? oob0 : (x == W + 1 ? oob1 : 0)); };
         int i = 0;
-        for (; i < 8 && i < NIT; i++) B.template iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        for (; i < 8 && i < NIT; i++) B.template iter<true, SVID>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
         // steady iterations: every stage inside the row, and none of the last DD + 1 chroma inputs of the row
         // (those refill the row-tail windows of the low-passes, which only the guarded iteration maintains)
         if (i == 8 && i + 3 <= W2 - 2 - DD) {
@@ -1115,15 +1121,15 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
                     B.template iter_fast<2>(P, i, byte_of(w1, 0), byte_of(w1, 1));
                     B.template iter_fast<3>(P, i, byte_of(w1, 2), byte_of(w1, 3));
                 } else {
-                    B.template iter<false>(P, i, byte_of(w0, 0), byte_of(w0, 1));
-                    B.template iter<false>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
-                    B.template iter<false>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
-                    B.template iter<false>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
+                    B.template iter<false, SVID>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                    B.template iter<false, SVID>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
+                    B.template iter<false, SVID>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
+                    B.template iter<false, SVID>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
                 }
                 w0 = n0; w1 = n1;
             }
         }
-        for (; i < NIT; i++) B.template iter<true>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        for (; i < NIT; i++) B.template iter<true, SVID>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
         B.sink.finish(W);
         F422_STAMP(4);
         return;
@@ -1165,22 +1171,21 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
     F422_STAMP(4);
 }
 
-// ---------------------------------------------------------------------------------- the short forms
-// The two switch-set families beside the VCR-with-composite-output one, in two / three sweeps instead of the
-// twelve of k422_process (same sweeps, same arithmetic, same scratch planes as k422_fused<false>):
-//   SV = false  "k422_direct": NO VCR (the tool's default preset, ffmpeg_to_composite.cpp:267-333): A, then ONE
-//               decode sweep -- Y/C separation :480-553 -> chroma noise :738-754 -> phase noise :755-781 -> dropout
-//               :932-942 -> output chroma low-pass :948-951 -> the frame row
-//   SV = true   "k422_fused_sv": the VCR with S-Video out (-vhs-svideo 1): A, B1 (separation, noises, VHS luma
-//               low-pass + emphasis + sharpen), then B2 without its re-modulation :926-929 -- chroma low-pass, blend,
-//               sharpen and the luma of B1 go through dropout and the output low-pass to the frame row
+// ---------------------------------------------------------------------------------- the short form
+// A switch set WITHOUT the VCR (the tool's default preset, ffmpeg_to_composite.cpp:267-333) in two sweeps instead of the
+// twelve of k422_process (same sweeps, same arithmetic, same scratch plane as k422_fused<false>): A, then ONE decode
+// sweep -- Y/C separation :480-553 -> chroma noise :738-754 -> phase noise :755-781 -> dropout :932-942 -> output
+// chroma low-pass :948-951 -> the frame row ("k422_direct").
+// (The VCR with S-Video out, -vhs-svideo 1, is the streamed pass without its re-modulation: k422_fused<false,true,D,true>.
+//  A three-sweep form of it -- A, B1, B2 to the frame -- was built in round 5 and measured SLOWER than the twelve sweeps of
+//  k422_process, 608k against 631k frames/s: its sweeps use 166-220 registers and wait on the scratch planes; dropped.)
 // Preconditions as k422_fused (launcher): colour subcarrier on, input chroma low-pass on, no
 // -nocolor-subcarrier-after-yc-sep, no extra -yc-recomb passes.
 // FASTA (launcher: NTSC, no pre-emphasis, luma noise on, even scanline phase, subcarrier amplitude 50, frame rows aligned
 // to 16 / 8 bytes -- the tool's default preset qualifies): sweep A in the streamed preset's form (cooperative 64-byte row
-// loads through an LDS tile, guard-free blocks inside the row), and the decode sweep of the no-VCR form writes the frame in
-// 64-byte bursts staged in the same tile.
-template <bool SV, bool FASTA = false>
+// loads through an LDS tile, guard-free blocks inside the row), and the decode sweep writes the frame in 64-byte bursts
+// staged in the same tile ("k422_direct_fast").
+template <bool FASTA = false>
 __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDev G,
                                                  const Field422Dev *__restrict__ fields,
                                                  Scratch422 Sc,
@@ -1199,7 +1204,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
     __shared__ uint32_t ring[31 * 64];
     __shared__ __attribute__((aligned(16))) uint32_t fstage[FASTA ? 64 * 16 * 3 : 4];
     const int lane = threadIdx.x;
-    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above: the VCR's vertical blend)
+    const int gidx = blockIdx.x * 63 + lane - 1;          // (the VCR forms' row mapping, halo lane included: one launcher)
     const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
     const int f = rc / P.Lslot, k = rc - f * P.Lslot;
     const Field422Dev &fd = fields[f];
@@ -1267,27 +1272,21 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
         n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
         cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
     }
-    FrameSink sink;
-    sink.begin(P, false, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
-    if constexpr (!SV && FASTA) {
+    if constexpr (FASTA) {
         // ---- the whole decode side in one sweep, the frame row leaving in 64-byte bursts (aligned rows)
         FrameSinkBurst bs;
         bs.begin(P, true, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
         bs.wy.st = fstage + lane * 16; bs.wu.st = fstage + (64 + lane) * 16; bs.wv.st = fstage + (128 + lane) * 16;
         LumaVhs nolv;
         demod<true, true, FrameSinkBurst>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, bs);
-    } else if constexpr (!SV) {
+    } else {
         // ---- the whole decode side in one sweep
+        FrameSink sink;
+        sink.begin(P, false, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
         LumaVhs nolv;
         demod<true, true>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, sink);
-    } else {
-        // ---- B1, then B2 to the frame
-        LumaVhs lv;
-        lv.begin(P.a_vl, P.a_sh, P.sharpen);
-        FrameSink none;
-        demod<false>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, lv, none);
-        sweep_b2<0, true>(P, R, W, xi, k, a_sh_c, sharpen_c, &sink);
     }
+    (void)a_sh_c; (void)sharpen_c;
 }
 
 } // namespace ntscsim

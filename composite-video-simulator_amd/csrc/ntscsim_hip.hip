@@ -437,7 +437,8 @@ extern "C" int ntscsim_sync(ntscsim_ctx *c)
 {
     if (!c) return NTSCSIM_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    const int rc = c->sub ? sub_wait_ticket(c, NTSCSIM_TICKET_ALL) : NTSCSIM_OK;   // fields in flight: deliver them
+    int rc = c->sub ? sub_wait_ticket(c, NTSCSIM_TICKET_ALL) : NTSCSIM_OK;         // fields in flight: deliver them
+    if (c->h422) { const int r = h422_wait_ticket(c, NTSCSIM_TICKET_ALL); if (rc == NTSCSIM_OK) rc = r; }
     HIPCHK(c, hipDeviceSynchronize());
     return rc;
 }
@@ -1159,8 +1160,8 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     const bool family = !c->no_fast_decode && !D.nocolor && D.in_lp &&
                         !p.nocolor_subcarrier_after_yc_sep && p.video_yc_recombine == 0;
     const bool fused = family && D.vhs && !D.svideo;
-    // the two families beside it (round 5): no VCR at all -- the tool's default preset -- in two sweeps, the VCR with
-    // S-Video out in three (k422_short, ntsc422_fused.hip)
+    // the two families beside it (round 5): no VCR at all -- the tool's default preset -- in two sweeps (k422_short), the
+    // VCR with S-Video out as the streamed pass without its re-modulation (k422_fused<false,true,D,true>)
     const bool direct = family && !D.vhs, fused_sv = family && D.vhs && D.svideo;
     // the '-vhs' preset's switch set has its own instantiation (debug bit 1 keeps the general one)
     // = what `ffmpeg_to_composite -vhs` runs: NTSC, SP, no pre-emphasis, all three noises and the FULL
@@ -1176,10 +1177,13 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // (aligned frame rows: the 64-byte frame bursts), per chroma delay of the tape speed
     const bool stream_gen = fused && !stream && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 &&
                             D.cdelay >= 4 && D.cdelay <= 6;
-    // sweep A of the short forms in the streamed preset's shape where its identities hold (the default preset does)
-    const bool fasta = (direct || fused_sv) && !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && even422 && D.amp == 50 &&
+    // sweep A of the no-VCR form in the streamed preset's shape where its identities hold (the default preset does)
+    const bool fasta = direct && !c->split_vhs && D.ntsc && !D.pre_on && D.noise_k && even422 && D.amp == 50 &&
                        D.src_al16 && D.dst_al16;
-    note_kernel(c, direct ? (fasta ? "k422_direct_fast" : "k422_direct") : fused_sv ? (fasta ? "k422_fused_sv_fast" : "k422_fused_sv")
+    // the VCR with S-Video out: the streamed pass without its re-modulation (aligned rows), else the twelve sweeps
+    const bool stream_sv = fused_sv && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 && D.cdelay >= 4 && D.cdelay <= 6;
+    note_kernel(c, direct ? (fasta ? "k422_direct_fast" : "k422_direct")
+                          : stream_sv ? (D.cdelay == 4 ? "k422_fused_sv<4>" : D.cdelay == 5 ? "k422_fused_sv<5>" : "k422_fused_sv<6>")
                           : !fused ? "k422_process"
                           : stream ? "k422_fused<true,true,4>"
                           : stream_gen ? (D.cdelay == 4 ? "k422_fused<false,true,4>" : D.cdelay == 5 ? "k422_fused<false,true,5>" : "k422_fused<false,true,6>")
@@ -1188,26 +1192,19 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     hipLaunchKernelGGL((k422_fused<__VA_ARGS__>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma)
-    if (fasta) {
-        if (direct)
-            hipLaunchKernelGGL((k422_short<false, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
-                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
-        else
-            hipLaunchKernelGGL((k422_short<true, true>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
-                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
-    }
-    else if (direct || fused_sv) {
-        if (direct)
-            hipLaunchKernelGGL(k422_short<false>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
-                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
-                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
-        else
+    if (direct) {
+        if (fasta)
             hipLaunchKernelGGL(k422_short<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
                                c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
+        else
+            hipLaunchKernelGGL(k422_short<false>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
+                               c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
+                               c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma);
     }
+    else if (stream_sv && D.cdelay == 4) NTSC_LAUNCH_422(false, true, 4, true);
+    else if (stream_sv && D.cdelay == 5) NTSC_LAUNCH_422(false, true, 5, true);
+    else if (stream_sv) NTSC_LAUNCH_422(false, true, 6, true);
     else if (fused && stream) NTSC_LAUNCH_422(true, true, 4);
     else if (stream_gen && D.cdelay == 4) NTSC_LAUNCH_422(false, true, 4);
     else if (stream_gen && D.cdelay == 5) NTSC_LAUNCH_422(false, true, 5);

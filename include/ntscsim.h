@@ -518,6 +518,14 @@ void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
  *     `depth` at a time (default 32); everything else (no source, linesize[0] < width + 2, feedback: a
  *     frame-to-frame recurrence, an interlaced repack whose other field was not submitted right before it)
  *     runs one at a time, in order -- exact, and as slow as the synchronous call.
+ *   - ntscsim_sync() delivers everything in flight first; the device-pointer entry points
+ *     (ntscsim_fields422_device() ...) must not be mixed in without ntscsim_wait(ctx, NTSCSIM_TICKET_ALL).
+ *     ntscsim_host_unpin(ctx, base) drops the engine's registration of a frame the caller is about to free.
+ * Host buffers: planes that are allocations of their own -- at least 64 KiB, starting on a page boundary or carrying
+ * glibc's header of a chunk with a mapping of its own -- are pinned in place (hipHostRegister, cached): the source is
+ * uploaded by DMA out of the caller's planes and the results are written into the caller's planes by the delivery
+ * kernels.  Everything else (small planes, blocks inside the C library's heap, NTSCSIM_SUBMIT422_PIN=0 in the
+ * environment) goes through pinned staging rings with one memcpy each way on the calling thread.  Same bytes either way.
  * Errors: as ntscsim_fields422_device(); a refused call consumes no ticket and no rand() draws.
  */
 typedef struct ntscsim_frame422 {    /* AVFrame::data[0..2] / linesize[0..2] of a planar YUV frame in host memory */

@@ -332,9 +332,9 @@ _FORM_CASES = [
     # as four sweeps it is still the preset instantiation, which does not use those identities)
     (["-vhs", "-comp-phase", "90", "-subcarrier-amp", "30"], "k422_fused<false,true,4>|k422_fused<true,false,4>"),
     (["-vhs", "-chroma-dropout", "50000", "-chroma-phase-noise", "0"], "k422_fused<false,true,4>"),
-    (["-vhs", "-vhs-svideo", "1"], "k422_fused_sv_fast"),                        # round 5: three sweeps
-    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "lp", "-chroma-dropout", "30000"], "k422_fused_sv_fast"),
-    (["-vhs", "-vhs-svideo", "1", "-comp-phase", "90"], "k422_fused_sv"),          # (odd scanline phases: the general sweep A)
+    (["-vhs", "-vhs-svideo", "1"], "k422_fused_sv<4>"),                          # round 5: the streamed pass without its re-modulation
+    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "lp", "-chroma-dropout", "30000"], "k422_fused_sv<5>"),
+    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "ep", "-comp-phase", "90", "-out-composite-lowpass", "0"], "k422_fused_sv<6>"),
     ([], "k422_direct_fast"),                                                     # round 5: the default preset, two sweeps
     (["-chroma-noise", "8", "-chroma-phase-noise", "6", "-comp-catv", "-vhs-head-switching", "1"], "k422_direct"),
     (["-tvstd", "pal", "-out-composite-lowpass", "0"], "k422_direct"),
@@ -376,7 +376,9 @@ def test_every_variant_kernel_form_agrees_with_the_oracle(flags, form, mode):
     elif mode == 4 and fam:
         want = "k422_fused<true,false,4>" if preset else "k422_fused<false,false,4>"
     elif mode == 2 and form.endswith("_fast"):
-        want = form[:-5]                       # (the same debug bit keeps the general sweep A of the short forms)
+        want = form[:-5]                       # (the same debug bit keeps the general sweep A of the no-VCR form)
+    elif mode in (2, 4) and form.startswith("k422_fused_sv"):
+        want = "k422_process"                  # (no streamed pass: the S-Video family falls back to the twelve sweeps)
     whole, dev = to_dev_onebuf(torch, frame)
     for k in range(n):
         field = (k & 1) ^ 1

@@ -1,4 +1,4 @@
-"""Developer tool (GPU box): the YUV422P tool's short kernel forms (k422_short: no VCR / S-Video out, round 5) against
+"""Developer tool (GPU box): the YUV422P tool's round-5 kernel forms (k422_short: no VCR; k422_fused_sv<D>: S-Video out) against
 the oracle on random switch sets, geometries and row alignments, with a census of the forms that ran.
     python tools/fuzz_short422.py 60000 1500"""
 import os, random, sys, time
