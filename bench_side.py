@@ -341,6 +341,7 @@ def extras(torch, ntscsim, dev, local_rank, args):
             "depth32_vhs": sub422,
             "depth32_default_preset": run_loop422("--mode", "submit", "--depth", "32", *big),
             "depth32_vhs_422_interlaced": run_loop422("-vhs", "-vi", "-422", "--mode", "submit", "--depth", "32", *big),
+            "depth32_vhs_heap_planes": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--mmap-threshold", "0", *big),
             "depth32_vhs_page_frames": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
             "depth32_vhs_422_page_frames": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
             "tight_rows_704_one_at_a_time": run_loop422("-vhs", "-width", "704", "--mode", "submit", "--fields", "600", "--warmup", "100"),
@@ -349,10 +350,12 @@ def extras(torch, ntscsim, dev, local_rank, args):
                     "av_frame_get_buffer) with render_field / black_key_feedback / composite_video_process / output_frame's "
                     "copy replaced by ONE ntscsim_submit422_avframe() and the encoder frame consumed behind ntscsim_wait() "
                     "2 * depth fields later; the input frame is rewritten by a memcpy per source frame (the stand-in for "
-                    "sws_scale :1770-1778).  page_frames = every plane a mapping of its own (what a get_buffer2 callback over page-aligned "
-                    "memory hands out): the engine pins such planes in place, uploads by DMA and delivers with kernels; the default "
-                    "posix_memalign'ed planes are blocks inside the C library's heap once the process has raised its mmap threshold "
-                    "and go through the staging rings (one memcpy each way on the caller's thread).  loop_sync = the same loop with ntscsim_field422_avframe(); tight rows "
+                    "sws_scale :1770-1778).  The loop's first statement is mallopt(M_MMAP_THRESHOLD, 64 KiB) (INTEGRATION.md 5b): glibc then "
+                    "gives every frame plane a mapping of its own and the engine pins it in place (DMA uploads, delivery kernels); "
+                    "heap_planes = without it (--mmap-threshold 0): once the GPU runtime's start-up has raised glibc's dynamic "
+                    "threshold, 353 / 177 KiB planes are blocks inside the heap "
+                    "and go through the staging rings (one memcpy each way on the caller's thread); page_frames = every plane allocated by "
+                    "mmap (a get_buffer2 callback over page-aligned memory).  loop_sync = the same loop with ntscsim_field422_avframe(); tight rows "
                     "(linesize == width) run one iteration at a time on a device mirror (include/ntscsim.h)"}
     # ---- one process per GPU with the C++ host and rccl.h (host/rank_bench.cpp): here with the one rank this box has
     rb = os.path.join(ROOT, "composite-video-simulator_amd", "rank_bench")

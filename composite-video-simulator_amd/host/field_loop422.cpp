@@ -3,7 +3,7 @@
 // ntscsim_field422_avframe) and section 5b (asynchronous: ntscsim_submit422_avframe + ntscsim_wait `lag` fields later).
 //
 //   field_loop422 [ffmpeg_to_composite switches] [--mode sync|submit] [--fields N] [--depth K] [--lag G] [--warmup N]
-//                 [--hash 0|1] [--height H] [--align A] [--page-frames 0|1]
+//                 [--hash 0|1] [--height H] [--align A] [--page-frames 0|1] [--mmap-threshold BYTES]
 //
 // The loop owns, like the tool: ONE decoded-and-scaled input frame (output_avstream_video_input_frame, rewritten by a
 // memcpy per source frame -- the stand-in for sws_scale :1770-1778), ONE persistent processing frame
@@ -12,12 +12,17 @@
 // fields behind the submits (--hash 1: FNV-1a over each, the stand-in for the encoder).  Frames are allocated like
 // av_frame_get_buffer(f, A) does: linesize = width rounded up to A (default 32), so 720 -> 736 (padded rows: the
 // batched path) and 704 -> 704 (tight rows: one iteration at a time).  -vi / -422 as in the tool (:1792-1797, :1158).
-// Plane memory comes from posix_memalign like av_malloc's (a block inside the C library's heap once the process has
-// raised its mmap threshold -- the engine then stages it) or, with --page-frames 1, from a mapping of its own per plane
-// (what a get_buffer2 callback over page-aligned memory gives: the engine pins such planes in place and moves the pixels
-// with DMA uploads and delivery kernels, no copy on the caller's thread).
+// Plane memory comes from posix_memalign like av_malloc's.  Whether such a block is an allocation with a mapping of its own
+// (which the engine pins in place: DMA uploads, delivery kernels, no copy on the caller's thread) or a block inside the C
+// library's heap (which it must stage: pinning the edge pages of a heap block would pin its neighbours' bytes) is glibc's
+// decision: blocks above M_MMAP_THRESHOLD get a mapping, and that threshold starts at 128 KiB but RISES whenever a larger
+// mapped block is freed -- which the GPU runtime's start-up does.  The one-line remedy INTEGRATION.md recommends is the first
+// statement here: mallopt(M_MMAP_THRESHOLD, 64 KiB) pins the threshold (--mmap-threshold 0 leaves glibc's dynamic default,
+// i.e. the staging rings for 353 / 177 KiB planes).  --page-frames 1 allocates every plane by mmap instead (what a
+// get_buffer2 callback over page-aligned memory gives).
 // Prints one JSON line: fields/s over the timed fields, the FNV of all consumed frames (equal between the two modes =
 // byte-identical frames in the same order), the rand() position, the engine's counters.
+#include <malloc.h>
 #include <sys/mman.h>
 
 #include <chrono>
@@ -97,6 +102,7 @@ int main(int argc, char **argv)
     std::string mode = "submit";
     long fields = 2000, warmup = 200;
     int depth = 32, lag = -1, do_hash = 0, height = 0, align = 32;
+    long mmap_threshold = 64 << 10;
     std::vector<const char *> av;
     av.push_back(argv[0]);
     for (int i = 1; i < argc; i++) {
@@ -110,8 +116,10 @@ int main(int argc, char **argv)
         if (opt("--height")) { height = std::atoi(argv[++i]); continue; }
         if (opt("--align")) { align = std::atoi(argv[++i]); continue; }
         if (opt("--page-frames")) { g_page_frames = std::atoi(argv[++i]) != 0; continue; }
+        if (opt("--mmap-threshold")) { mmap_threshold = std::atol(argv[++i]); continue; }
         av.push_back(argv[i]);
     }
+    if (mmap_threshold > 0) mallopt(M_MMAP_THRESHOLD, (int)mmap_threshold);     // frame planes keep mappings of their own
     av.push_back("-i"); av.push_back("unused"); av.push_back("-o"); av.push_back("unused");   // (the parser insists, :1634)
     const bool async = mode == "submit";
     if (!async && mode != "sync") { std::fprintf(stderr, "--mode sync|submit\n"); return 1; }
@@ -206,11 +214,11 @@ int main(int argc, char **argv)
     uint64_t st[8];
     ntscsim_submit422_stats(sim, st);
     std::printf("{\"mode\": \"%s\", \"fields\": %ld, \"seconds\": %.6f, \"fields_per_s\": %.1f, \"width\": %d, \"height\": %d, "
-                "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, \"page_frames\": %d, "
+                "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, \"page_frames\": %d, \"mmap_threshold\": %ld, "
                 "\"host_us_per_call\": {\"new_frame\": %.1f, \"same_frame\": %.1f, \"wait\": %.1f}, "
                 "\"fnv1a\": \"%016llx\", \"rng_pos\": %llu, \"stats\": {\"submitted\": %llu, \"launches\": %llu, \"uploads\": %llu, "
                 "\"batched\": %llu, \"one_at_a_time\": %llu, \"frame_uploads\": %llu, \"dma_uploads\": %llu, \"ring_full_waits\": %llu}}\n",
-                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0, g_page_frames ? 1 : 0,
+                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0, g_page_frames ? 1 : 0, mmap_threshold,
                 n_new ? us_new / n_new : 0.0, n_same ? us_same / n_same : 0.0, n_wait ? us_wait / n_wait : 0.0,
                 (unsigned long long)(do_hash ? hash : 0), (unsigned long long)ntscsim_get_rng_pos(sim),
                 (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],

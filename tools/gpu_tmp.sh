@@ -1,5 +1,12 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_variant422.py tests/test_tocomp_cli.py tests/test_host422.py tests/test_fuzz_params.py -q -m gpu -x 2>&1 | tail -10 > gpurun_out/t_sv.log
-timeout 600 python tools/fuzz_short422.py 60000 3000 2>&1 | grep -v amdgpu.ids | tail -6 >> gpurun_out/t_sv.log
-timeout 600 python bench.py --tool to_composite --steps 20 --warmup 5 --cpu-fields 0 > gpurun_out/bench422_sv.json 2> gpurun_out/bench422_sv.err
+timeout 600 python -m pytest tests/test_host422.py -q -m gpu 2>&1 | tail -4 > gpurun_out/t_mm.log
+timeout 400 sh tools/host422_loop_probe.sh > /dev/null 2>&1
+grep -A30 "# throughput" gpurun_out/host422_loop_probe.txt | python3 -c "
+import sys,json
+for l in sys.stdin:
+    l=l.strip()
+    if l.startswith('{'):
+        d=json.loads(l); print(d['mode'],round(d['fields_per_s']),'out',d['out_mode'],'depth',d['depth'],'pf',d['page_frames'],'mm',d['mmap_threshold'],d['host_us_per_call'],d['stats']['dma_uploads'])
+    else: print(l)
+" >> gpurun_out/t_mm.log

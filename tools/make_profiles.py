@@ -211,9 +211,9 @@ if e2e.get("field_submit422"):
     f4 = e2e.get("field_submit422_detail", {})
     g = lambda k_: (f4.get(k_) or {}).get("fields_per_s", 0) if isinstance(f4.get(k_), dict) else (f4.get(k_) or 0)
     rd += ("\n\nThe YUV422P tool's loop on host frames (`host/field_loop422.cpp`, 720x480, depth 32; `end_to_end.field_submit422*`): %.0f fields/s with `-vhs` "
-           "(posix_memalign'ed planes: staging rings), %.0f on page-owned planes (pinned in place), %.0f with `-vhs -422` on page-owned planes, %.0f with the default preset, "
+           "(posix_memalign'ed planes under mallopt(M_MMAP_THRESHOLD, 64 KiB): pinned in place), %.0f without the mallopt (heap blocks: staging rings), %.0f with `-vhs -422` on page-owned planes, %.0f with the default preset, "
            "%.0f one iteration at a time (tight rows, 704 wide), %.0f for the synchronous `ntscsim_field422()`.  " % (
-               e2e["field_submit422"], g("depth32_vhs_page_frames"), g("depth32_vhs_422_page_frames"), g("depth32_default_preset"),
+               e2e["field_submit422"], g("depth32_vhs_heap_planes"), g("depth32_vhs_422_page_frames"), g("depth32_default_preset"),
                g("tight_rows_704_one_at_a_time"), g("loop_sync_fields_per_s")))
 mg = d.get("multi_gpu_cpp_host") or {}
 if mg.get("value"):

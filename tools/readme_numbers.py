@@ -33,10 +33,10 @@ tp = t.get("presets") or {}
 v422 = ""
 if e.get("field_submit422"):
     v422 = ("  The YUV422P tool on HOST frames (`ntscsim_field422()` / `ntscsim_submit422()`, `host/field_loop422.cpp`: the loop of "
-            "ffmpeg_to_composite.cpp:1783-1800 with its four calls replaced by one, 720×480, depth 32): %.0fk fields/s on page-owned planes "
-            "(pinned in place; `-vhs -422`), %.0fk through the staging rings (`-vhs`, posix_memalign'ed planes), %.1fk one iteration at a time "
+            "ffmpeg_to_composite.cpp:1783-1800 with its four calls replaced by one, 720×480, depth 32): %.0fk fields/s with `-vhs` "
+            "(frame planes pinned in place), %.0fk through the staging rings (heap-block planes: no `mallopt`), %.1fk one iteration at a time "
             "(tight rows), %.1fk synchronous (`end_to_end.field_submit422*`)." % (
-                f4ps("depth32_vhs_422_page_frames"), e["field_submit422"] / 1e3, f4ps("tight_rows_704_one_at_a_time"), f4ps("loop_sync_fields_per_s")))
+                e["field_submit422"] / 1e3, f4ps("depth32_vhs_heap_planes"), f4ps("tight_rows_704_one_at_a_time"), f4ps("loop_sync_fields_per_s")))
     if tp.get("default", {}).get("value"):
         v422 += ("  Its switch-set families on the device (`bench.py --tool to_composite` → `presets`): default preset %dk frames/s (`%s`), "
                  "`-vhs -vhs-svideo 1` %dk (`%s`)." % (round(tp["default"]["value"] / 1e3), ", ".join(tp["default"].get("kernels", [])),
