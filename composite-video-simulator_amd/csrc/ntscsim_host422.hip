@@ -81,9 +81,9 @@ struct Host422Engine {
     uint8_t *pads = nullptr;                            // [nslots][2 * L]
     hipStream_t s_up = nullptr, s_dn = nullptr;
     hipEvent_t ev_k = nullptr;
-    // caller frames pinned in place (hipHostRegister, cached): sources are then uploaded by DMA straight out of the
-    // caller's planes, and the rows of frame / filter / encoder frame are written by the delivery kernels straight into
-    // them -- no staging copy on the caller's thread.  NTSCSIM_SUBMIT422_PIN=0: everything through the staging rings.
+    // caller frames pinned in place (hipHostRegister, cached): the rows of frame / filter / encoder frame are written by
+    // the delivery kernels straight into them -- no staging copy on the caller's thread at ntscsim_wait().
+    // NTSCSIM_SUBMIT422_PIN=0: everything through the staging rings.
     PinCache pins;
 
     struct Mirror {
@@ -123,7 +123,7 @@ struct Host422Engine {
     int src_cur = -1;
     uint64_t src_ring_pos = 0;
     std::vector<uint64_t> src_last_ticket;
-    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] submitted [1] launches [2] uploads [3] FAST [4] SERIAL [5] mirror uploads [6] uploads by DMA out of pinned caller planes
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] submitted [1] launches [2] uploads [3] FAST [4] SERIAL [5] mirror uploads [6] iterations with a result written by the delivery kernels into pinned caller planes
 };
 
 static int h422_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
@@ -406,6 +406,10 @@ static int h422_launch(ntscsim_ctx *c)
             if (a.out_how == 1 && z.out_dev[0] && z.it.out.data[0] == a.it.out.data[0]) a.out_how = 2;
         }
     }
+    for (int i = 0; i < n; i++) {
+        const Host422Engine::Item &it = b.items[(size_t)i];
+        if (it.frm_how == 1 || it.out_how == 1 || it.flt_how == 1) e->stats[6]++;
+    }
     std::vector<ntscsim_field422_desc> descs((size_t)n);
     bool any_pad = false, any_out = false;
     bool al4 = (W2 & 3) == 0;
@@ -658,8 +662,12 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
                 if (rc != NTSCSIM_OK) return rc;
             }
             uint8_t *sdev[3];
-            if (h422_pin_frame(e, L->src, W, L->src_height, (int)src_crows, sdev)) {
-                // DMA straight out of the caller's planes; the caller may rewrite them when we return (snapshot)
+            // The source is SNAPSHOTTED: by a memcpy into the pinned staging ring (default: 25-30 us per 720x480 frame on the
+            // calling thread, nothing to wait for), or -- NTSCSIM_SUBMIT422_SRCDMA=1, developer A/B -- by DMA straight out of
+            // pinned caller planes, which the call then has to WAIT for (three plane copies + a stream synchronisation:
+            // 46-50 us measured, and the engine's launches are no faster for it: profiles/r05_host422_loop_probe.txt)
+            static const bool src_dma = std::getenv("NTSCSIM_SUBMIT422_SRCDMA") && std::getenv("NTSCSIM_SUBMIT422_SRCDMA")[0] == '1';
+            if (src_dma && h422_pin_frame(e, L->src, W, L->src_height, (int)src_crows, sdev)) {
                 uint8_t *o = e->dsrc.p + e->sbytes * (size_t)sslot;
                 for (int k = 0; k < 3; k++) {
                     const size_t rb = k ? (size_t)W2 : (size_t)W, nr = k ? src_crows : (size_t)L->src_height;
@@ -670,7 +678,6 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
                     o += rb * nr;
                 }
                 HIPCHK(c, hipStreamSynchronize(e->s_up));
-                e->stats[6]++;
             } else {
             uint8_t *hs = e->hsrc + e->sbytes * (size_t)sslot;
             uint8_t *o = hs;

@@ -217,7 +217,7 @@ int main(int argc, char **argv)
                 "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, \"page_frames\": %d, \"mmap_threshold\": %ld, "
                 "\"host_us_per_call\": {\"new_frame\": %.1f, \"same_frame\": %.1f, \"wait\": %.1f}, "
                 "\"fnv1a\": \"%016llx\", \"rng_pos\": %llu, \"stats\": {\"submitted\": %llu, \"launches\": %llu, \"uploads\": %llu, "
-                "\"batched\": %llu, \"one_at_a_time\": %llu, \"frame_uploads\": %llu, \"dma_uploads\": %llu, \"ring_full_waits\": %llu}}\n",
+                "\"batched\": %llu, \"one_at_a_time\": %llu, \"frame_uploads\": %llu, \"delivered_direct\": %llu, \"ring_full_waits\": %llu}}\n",
                 mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0, g_page_frames ? 1 : 0, mmap_threshold,
                 n_new ? us_new / n_new : 0.0, n_same ? us_same / n_same : 0.0, n_wait ? us_wait / n_wait : 0.0,
                 (unsigned long long)(do_hash ? hash : 0), (unsigned long long)ntscsim_get_rng_pos(sim),

@@ -522,9 +522,9 @@ void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
  *     (ntscsim_fields422_device() ...) must not be mixed in without ntscsim_wait(ctx, NTSCSIM_TICKET_ALL).
  *     ntscsim_host_unpin(ctx, base) drops the engine's registration of a frame the caller is about to free.
  * Host buffers: planes that are allocations of their own -- at least 64 KiB, starting on a page boundary or carrying
- * glibc's header of a chunk with a mapping of its own -- are pinned in place (hipHostRegister, cached): the source is
- * uploaded by DMA out of the caller's planes and the results are written into the caller's planes by the delivery
- * kernels.  Everything else (small planes, blocks inside the C library's heap, NTSCSIM_SUBMIT422_PIN=0 in the
+ * glibc's header of a chunk with a mapping of its own -- are pinned in place (hipHostRegister, cached) and the results
+ * are written into them by the delivery kernels (the source is snapshotted by one memcpy into a pinned ring: cheaper for
+ * the calling thread than waiting for a DMA out of its planes).  Everything else (small planes, blocks inside the C library's heap, NTSCSIM_SUBMIT422_PIN=0 in the
  * environment) goes through pinned staging rings with one memcpy each way on the calling thread.  Same bytes either way.
  * Errors: as ntscsim_fields422_device(); a refused call consumes no ticket and no rand() draws.
  */
@@ -557,7 +557,7 @@ int ntscsim_submit422(ntscsim_ctx *ctx, const ntscsim_loop422 *it, uint32_t subm
  * >= 2 * depth + 2).  Waits for everything in flight first. */
 int ntscsim_submit422_configure(ntscsim_ctx *ctx, int depth, int slots);
 /* [0] submitted [1] launches [2] source uploads [3] batched iterations [4] one-at-a-time iterations
- * [5] frame (re)uploads [7] submits that blocked on a full ring */
+ * [5] frame (re)uploads [6] iterations delivered by kernels into pinned caller planes [7] submits that blocked on a full ring */
 void ntscsim_submit422_stats(const ntscsim_ctx *ctx, uint64_t out[8]);
 
 

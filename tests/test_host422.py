@@ -346,8 +346,8 @@ def test_full_size_stream_equals_sync_and_golden_hash():
 @pytest.mark.parametrize("flags,out_mode,bkey", [(["-vhs"], OUT_BOB422, False), ([], OUT_BOB422, False),
                                                   (["-bkey-feedback", "40"], OUT_BOB422, True)])
 def test_pinned_planes_take_the_dma_and_kernel_delivery_paths(flags, out_mode, bkey, mode):
-    """Frames whose planes can be pinned in place (page-aligned, >= 64 KiB: 720x480): sources go up by DMA out of the
-    caller's planes, frame / filter / encoder rows are written by the delivery kernels straight into them -- same
+    """Frames whose planes can be pinned in place (page-aligned, >= 64 KiB: 720x480): frame / filter / encoder rows are
+    written by the delivery kernels straight into them -- same
     bytes as the oracle's loop on identical buffers, whole buffers; with ONE persistent frame and 8 iterations per
     launch only the last writer of each row set delivers it."""
     w, h, pad, n_src = 720, 480, 16, 6
@@ -377,7 +377,7 @@ def test_pinned_planes_take_the_dma_and_kernel_delivery_paths(flags, out_mode, b
     ctx.wait()
     st = ctx.stats()
     assert ctx.rng_pos == o.rng_pos
-    assert st[6] == n_src * (1 if mode == "submit" else 2)        # every upload was a DMA out of the caller's planes
+    assert st[6] >= 2 * n_src - (3 if mode == "submit" else 0)    # the delivery kernels wrote into the pinned planes
     ctx.unpin()
     ctx.close()
     same_frames(frame_g, frame_o, "frame")
@@ -445,12 +445,15 @@ def test_cpp_loop_submit_equals_sync(flags, extra, batched):
     assert a["fnv1a"] == b["fnv1a"] != "0000000000000000" and a["rng_pos"] == b["rng_pos"]
     # ... and the staging rings (the path the oracle comparisons above go through) deliver what the pinned paths do
     c = run_cpp("submit", flags, extra=list(extra) + ["--page-frames", "1"], env={"NTSCSIM_SUBMIT422_PIN": "0"})
-    assert c["fnv1a"] == b["fnv1a"] and c["rng_pos"] == b["rng_pos"] and c["stats"]["dma_uploads"] == 0
+    assert c["fnv1a"] == b["fnv1a"] and c["rng_pos"] == b["rng_pos"] and c["stats"]["delivered_direct"] == 0
     # planes with a mapping of their own are pinned in place (full-size planes only: the engine leaves planes under 64 KiB alone)
     d = run_cpp("submit", flags, extra=list(extra) + ["--page-frames", "1"])
     assert d["fnv1a"] == b["fnv1a"] and d["rng_pos"] == b["rng_pos"]
     if "--height" not in extra:
-        assert d["stats"]["dma_uploads"] == d["stats"]["uploads"] > 0, d["stats"]
+        assert d["stats"]["delivered_direct"] > 0, d["stats"]
+    # ... and the source snapshot by DMA out of the pinned planes (developer switch) is the same stream of frames
+    e2 = run_cpp("submit", flags, extra=list(extra) + ["--page-frames", "1"], env={"NTSCSIM_SUBMIT422_SRCDMA": "1"})
+    assert e2["fnv1a"] == b["fnv1a"] and e2["rng_pos"] == b["rng_pos"]
     assert b["stats"]["submitted"] == 60
     if batched:
         assert b["stats"]["batched"] == 60 and b["stats"]["launches"] <= 9, b["stats"]

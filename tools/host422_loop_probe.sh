@@ -19,6 +19,9 @@ for pf in 0 1; do
     $FL $fl --mode submit --fields 6000 --warmup 600 --depth 32 --page-frames $pf
   done
 done
+echo "# source snapshot by DMA out of the pinned planes instead of the memcpy (NTSCSIM_SUBMIT422_SRCDMA=1)"
+NTSCSIM_SUBMIT422_SRCDMA=1 $FL -vhs -422 --mode submit --fields 6000 --warmup 600 --depth 32
+NTSCSIM_SUBMIT422_SRCDMA=1 $FL -vhs -422 --mode submit --fields 6000 --warmup 600 --depth 64
 echo "# without mallopt(M_MMAP_THRESHOLD, 64 KiB): planes are heap blocks, staged"
 $FL -vhs --mode submit --fields 6000 --warmup 600 --depth 32 --mmap-threshold 0
 $FL -vhs -422 --mode submit --fields 6000 --warmup 600 --depth 32 --mmap-threshold 0
