@@ -341,6 +341,8 @@ def extras(torch, ntscsim, dev, local_rank, args):
             "depth32_vhs": sub422,
             "depth32_default_preset": run_loop422("--mode", "submit", "--depth", "32", *big),
             "depth32_vhs_422_interlaced": run_loop422("-vhs", "-vi", "-422", "--mode", "submit", "--depth", "32", *big),
+            "depth64_vhs": run_loop422("-vhs", "--mode", "submit", "--depth", "64", *big),
+            "depth64_vhs_422": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "64", *big),
             "depth32_vhs_heap_planes": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--mmap-threshold", "0", *big),
             "depth32_vhs_page_frames": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
             "depth32_vhs_422_page_frames": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
