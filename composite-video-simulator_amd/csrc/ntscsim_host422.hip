@@ -505,29 +505,35 @@ static int h422_launch(ntscsim_ctx *c)
     int rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
     c->rng_pos = keep_pos;
     if (rc != NTSCSIM_OK) return finish(rc);
+    // Delivery -- output_frame's copy, the rows of the field, the download of what is staged -- runs on a stream of its own
+    // behind the batch's kernels: the NEXT launch's kernels do not wait for it (batched iterations own their device frames
+    // and delivery records).  An iteration on a mirror is different: the next one modifies the rows this one delivers from,
+    // so the ctx's stream waits for its delivery (below).
+    hipStream_t sd = e->s_dn;
+    er = hipEventRecord(e->ev_k, st);
+    if (er == hipSuccess) er = hipStreamWaitEvent(sd, e->ev_k, 0);
+    if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     DevParams D;
     std::memset(&D, 0, sizeof(D));
     D.W = W; D.H = H; D.variant = 1;
     if (any_out) {
-        hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)run0), dim3(256), 0, st, D, e->orec + s0, al4 ? 1 : 0);
-        if (run0 < n) hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)(n - run0)), dim3(256), 0, st, D, e->orec, al4 ? 1 : 0);
+        hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)run0), dim3(256), 0, sd, D, e->orec + s0, al4 ? 1 : 0);
+        if (run0 < n) hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)(n - run0)), dim3(256), 0, sd, D, e->orec, al4 ? 1 : 0);
     }
-    hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * run0)), dim3(256), 0, st, e->crec + 6 * (size_t)s0);
-    if (run0 < n) hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * (n - run0))), dim3(256), 0, st, e->crec);
+    hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * run0)), dim3(256), 0, sd, e->crec + 6 * (size_t)s0);
+    if (run0 < n) hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * (n - run0))), dim3(256), 0, sd, e->crec);
     er = hipGetLastError();
     if (er != hipSuccess) { c->err = std::string("submit422 kernels: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
-    // the download runs on a copy stream of its own behind the kernels: the next launch's kernels do not wait for it
-    er = hipEventRecord(e->ev_k, st);
-    if (er == hipSuccess) er = hipStreamWaitEvent(e->s_dn, e->ev_k, 0);
     if (flt_staged) { dn_need = e->dbytes; any_staged = true; }
     dn_need = (dn_need + 255) / 256 * 256;
     if (!any_staged) dn_need = 0;                    // everything went straight into pinned caller frames
-    if (er == hipSuccess && dn_need)
+    if (dn_need)
         er = hipMemcpy2DAsync(e->hdn + e->dbytes * (size_t)s0, e->dbytes, e->ddn.p + e->dbytes * (size_t)s0, e->dbytes, dn_need,
-                              (size_t)run0, hipMemcpyDeviceToHost, e->s_dn);
+                              (size_t)run0, hipMemcpyDeviceToHost, sd);
     if (er == hipSuccess && run0 < n && dn_need)
-        er = hipMemcpy2DAsync(e->hdn, e->dbytes, e->ddn.p, e->dbytes, dn_need, (size_t)(n - run0), hipMemcpyDeviceToHost, e->s_dn);
-    if (er == hipSuccess) er = hipEventRecord(b.done, e->s_dn);
+        er = hipMemcpy2DAsync(e->hdn, e->dbytes, e->ddn.p, e->dbytes, dn_need, (size_t)(n - run0), hipMemcpyDeviceToHost, sd);
+    if (er == hipSuccess) er = hipEventRecord(b.done, sd);
+    if (er == hipSuccess && b.items.front().serial) er = hipStreamWaitEvent(st, b.done, 0);
     if (er != hipSuccess) { c->err = std::string("submit422 D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;
     e->stats[1]++;
@@ -747,6 +753,7 @@ static int h422_host_unpin(ntscsim_ctx *c, const void *base)
     HIPCHK(c, hipSetDevice(c->device));
     const int rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
     if (e->s_up) HIPCHK(c, hipStreamSynchronize(e->s_up));
+    if (e->s_dn) HIPCHK(c, hipStreamSynchronize(e->s_dn));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!base) pin_release_all(e->pins);
     else (void)pin_release(e->pins, base);
