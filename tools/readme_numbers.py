@@ -65,7 +65,8 @@ new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` pres
        "was measured and what is derived.  The drop-in on HOST frames: one synchronous `ntscsim_field()` per `composite_layer()` call %.1fk fields/s; the\n"
        "same loop with `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`, pageable AVFrame-shaped buffers pinned in place) **%.0fk** with ONE\n"
        "source frame rewritten per decoded frame, %.0fk with the source re-pointed at decoded frames, %.0fk with the line doubling delivered too, %.0fk at depth 128\n"
-       "(`end_to_end.field_submit*`; %.0f × the reference on one core).  Whole clips from host memory (`ntscsim_frames_host`): %.0fk\n"
+       "(`end_to_end.field_submit*`; %.0f × the reference on one core; these are the host link's rates, not the GPU's -- 0.7 MB up and 0.7 MB down per field, "
+       "1.4 MB down with the line doubling: DESIGN.md §1b).  Whole clips from host memory (`ntscsim_frames_host`): %.0fk\n"
        "fields/s BGRA out, %.0fk with YUV420P made on the GPU, %.0fk with YUV420P in as well.%s%s%s%s  Not a headline: the optional\n"
        "`NTSCSIM_MODE_FAST32` (the same kernels with fp32 filter states, ≤1 LSB, not bit-exact) runs %dk fields/s (`profiles/%s_bench_fast32.json`).\n\n" % (
            tag[1:].lstrip("0"), tag, round(d["value_sustained"] / 1e3), (d.get("sustained") or {}).get("seconds", 0.5), round(d["value"] / 1e3), d["steps"],
