@@ -120,11 +120,11 @@ def test_rank_bench_runs_through_rccl_with_one_rank_and_matches_one_context():
     sim.close()
 
 
-@pytest.mark.gpu
-def test_rank_bench_strong_scaling_share_of_rank_1_of_2_is_the_odd_frames():
-    """what rank 1 of 2 would compute (frames 1, 3, 5, ... with their closed-form rand() positions) == those frames of
-    the one-context run: run as world 1 with the second rank's share through the --verify path is not possible on one
-    GPU (RCCL refuses two ranks on one device), so the closed form is checked against the serial stream here"""
+def test_rank_bench_closed_form_positions_are_the_serial_stream():
+    """rank_bench.cpp's closed form pos(k) = (k / 2) (draws(parity 1) + draws(parity 0)) + (k & 1) draws(parity 1) -- what lets
+    rank r of N start at frame r without its predecessors -- against the serial walk of the loop (field k has parity
+    (k & 1) ^ 1, ffmpeg_ntsc.cpp:2229).  CPU: the draw counts come from the library's host side, no GPU involved; two ranks
+    on one GPU are refused by RCCL, so this is the part of the N > 1 deal that can be checked here."""
     import ctypes as C
     w, h = 720, 486
     p = L.make_params(["-vhs"])
