@@ -477,7 +477,7 @@ def extras(torch, ntscsim, dev, local_rank, args):
                 prm.ghost_delay[0], prm.ghost_delay[1] = 12, 31
                 prm.ghost_gain[0], prm.ghost_gain[1] = 64, -32
                 v_ = device_rate(torch, ntscsim, dev, local_rank, None, w, h, args.frames, 24, args.inflight, params=prm, kernels=kn)
-                what = "-vhs + ghosting extension (2 taps: 12 samples x 64/256, 31 samples x -32/256; absent from the reference, parity unpinned)"
+                what = "-vhs + ghosting extension (2 taps: 12 samples x 64/256, 31 samples x -32/256; absent from the reference, parity unpinned; delays below 64 samples: folded into the encoder)"
             else:
                 v_ = device_rate(torch, ntscsim, dev, local_rank, fl, w, h, args.frames, 24, args.inflight, kernels=kn)
                 what = "preset '%s'" % " ".join(fl)

@@ -108,10 +108,52 @@ DEV int step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *r
     return Y;
 }
 
+// EXTENSION (ghosting, see ntscsim.h) folded into the encoder: k_ghost (ntsc_kernels.hip) reads the raw plane 1 + taps
+// times and writes a second one, a pass longer than the encoder itself.  Here every lane keeps the last 64 raw samples of
+// its scanline in an LDS ring (slot x & 63, one column per lane) and stores the ghosted sample only:
+//   out[x] = raw[x] + (sum_k gain_k * raw[x - delay_k]) / 256,  raw[< 0] = 0
+// -- the same integer expression (|raw| < 2^16 + 2^17 + noise_k <= 1.25 M, so four products of at most 256 * that stay
+// below 2^31: no overflow, the order of the sum does not matter).  The ring starts
+// zeroed, so a tap that reaches before the row start reads a slot not yet written (delay <= 63 < 64).  GT = taps of the
+// form (2 or 4; unused ones run with gain 0, delay 1: no branch in the step), 0 = no ghosting.  The products are 24-bit
+// ones (full-rate v_mad_i32_i24 instead of the quarter-rate 32-bit multiply): |gain| <= 256 by ntscsim_params_validate,
+// |raw| < 2^23 because 256 * luma < 2^16, the low-passed chroma stays inside its input range (< 2^17) and the luma noise
+// inside +-noise_k.  Launcher: every delay <= NTSC_GHOST_RING - 1, noise_k <= 2^20.
+#define NTSC_GHOST_RING 64
+template <int GT>
+struct GhostRing {
+    uint32_t *col;            // this lane's column of the ring: slot s at col[64 * s]
+    int delay[GT > 0 ? GT : 1], gain[GT > 0 ? GT : 1];
+    DEV void begin(const DevParams &P, uint32_t *lds, int lane)
+    {
+        if (GT == 0) return;
+        col = lds + lane;
+#pragma unroll
+        for (int k = 0; k < GT; k++) {
+            const bool on = k < P.ghost_taps;
+            delay[k] = on ? P.ghost_delay[k] : 1;
+            gain[k] = on ? P.ghost_gain[k] : 0;
+        }
+#pragma unroll 8
+        for (int s = 0; s < NTSC_GHOST_RING; s++) col[64 * s] = 0u;
+    }
+    // raw sample of position x (wave-uniform) -> the sample the decoder sees
+    DEV int emit(int x, int Y) const
+    {
+        if (GT == 0) return Y;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < GT; k++)
+            acc += __mul24(gain[k], (int)col[64 * ((x - delay[k]) & (NTSC_GHOST_RING - 1))]);
+        col[64 * (x & (NTSC_GHOST_RING - 1))] = (uint32_t)Y;
+        return Y + acc / 256;
+    }
+};
+
 // One guarded step at any stream position t (wave-uniform): row start, row end, filter tails.
-template <class RT, bool PRE>
+template <class RT, bool PRE, int GH = 0>
 DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
-                   const uint32_t *srow, int t)
+                   const uint32_t *srow, int t, const GhostRing<GH> &gh = GhostRing<GH>())
 {
     const int W = C.W;
     const uint32_t px = t < W ? ((fastdec::g_cu32_ptr)srow)[t] : 0u;
@@ -136,6 +178,7 @@ DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint3
     if (PRE) Y = preemphasis<RT>(S, C, Y);
     Y += S.noise;
     S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
+    Y = gh.emit(x, Y);
     __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)((unsigned)x * (unsigned)C.rowbytes), NTSC_COMP_STORE_AUX);
 }
 
@@ -197,7 +240,7 @@ struct CoopLoader {
 
 } // namespace fastenc
 
-template <class RT, bool PRE, bool XA = false>
+template <class RT, bool PRE, bool XA = false, int GH = 0>
 DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ fields, const uint32_t *__restrict__ rs_luma,
                           const int *__restrict__ n0_luma, int *__restrict__ comp)
 {
@@ -206,6 +249,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
 #ifndef NTSC_ENC_NOCOOP
     __shared__ __attribute__((aligned(16))) uint32_t ltile[64 * 20];
 #endif
+    __shared__ uint32_t gring[GH ? NTSC_GHOST_RING * 64 : 1];
     const int lane = threadIdx.x;
     const int rho = blockIdx.x * 64 + lane;
     const int rc = rho < P.R ? rho : P.R - 1;
@@ -246,10 +290,12 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
 #pragma unroll
     for (int q = 0; q < 4; q++) { S.Yd[q] = 0; S.Ir[q] = 0; S.Qr[q] = 0; }
     S.fI[0] = S.fI[1] = 0;
+    GhostRing<GH> gh;
+    gh.begin(P, gring, lane);
 
     // ---------------- row start: pixels 0..3 fill the 4-sample look-ahead of the Q low-pass
     int t = 0;
-    for (; t < 4; t++) edge_step<RT, PRE>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < 4; t++) edge_step<RT, PRE, GH>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t, gh);
     // ---------------- steady state: 16-pixel chunks strictly inside the row
     if (t + 16 <= W) {
 #ifndef NTSC_ENC_NOCOOP
@@ -285,7 +331,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
                 rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
-                const int Y = step<J, RT, PRE, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]);          \
+                const int Y = gh.emit(t - 4 + J, step<J, RT, PRE, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J])); \
                 __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, NTSC_COMP_STORE_AUX);          \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
@@ -325,7 +371,7 @@ DEV void encode_fast_body(const DevParams &P, const FieldDev *__restrict__ field
         for (int q = 0; q < 4; q++) { S.Ir[q] = (int)IdT[q]; S.Qr[q] = (int)QdT[q]; }
     }
     // ---------------- row end + drain
-    for (; t < W + 4; t++) edge_step<RT, PRE>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < W + 4; t++) edge_step<RT, PRE, GH>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t, gh);
 }
 
 template <class RT>
@@ -335,6 +381,16 @@ __global__ __launch_bounds__(64) void k_encode_fast(DevParams P, const FieldDev 
                                                     int *__restrict__ comp)
 {
     encode_fast_body<RT, false>(P, fields, rs_luma, n0_luma, comp);
+}
+
+// the same with the ghosting extension folded in (GT = 2 or 4 taps, delays <= 63): stores the ghosted plane, no k_ghost pass
+template <class RT, int GT>
+__global__ __launch_bounds__(64) void k_encode_fast_gh(DevParams P, const FieldDev *__restrict__ fields,
+                                                       const uint32_t *__restrict__ rs_luma,
+                                                       const int *__restrict__ n0_luma,
+                                                       int *__restrict__ comp)
+{
+    encode_fast_body<RT, false, false, GT>(P, fields, rs_luma, n0_luma, comp);
 }
 
 // the same for scanline phases of either parity (-comp-phase 90 / 270, odd -comp-phase-offset)

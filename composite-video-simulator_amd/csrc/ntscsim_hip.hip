@@ -163,6 +163,7 @@ struct ntscsim_ctx {
     bool split_vhs = false;          // debug / A-B: VCR half + TV half in two launches instead of k_decode_fast<true>
     bool no_fast_decode = false;     // debug: keep the PRESET template kernels (A/B against k_decode_fast)
     bool no_stream422 = false;       // debug: the YUV422P preset kernel as four sweeps instead of A + one streamed pass
+    bool no_ghost_fuse = false;      // debug / A-B: the ghosting extension as its own pass (k_ghost) for every delay
     int mode = NTSCSIM_MODE_EXACT;
     SubmitEngine *sub = nullptr;     // ntscsim_submit() / ntscsim_wait(): created on first use
     Host422Engine *h422 = nullptr;   // ntscsim_field422() / ntscsim_submit422(): created on first use
@@ -380,6 +381,7 @@ extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx *
     if (const char *e = std::getenv("NTSCSIM_DEBUG_DECODE")) {
         const int v = std::atoi(e);
         c->no_fast_decode = (v & 1) != 0; c->split_vhs = (v & 2) != 0; c->no_stream422 = (v & 4) != 0;
+        c->no_ghost_fuse = (v & 8) != 0;
     }
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -479,7 +481,7 @@ extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
 
 extern "C" void ntscsim_debug_no_fast_decode(ntscsim_ctx *c, int on)
 {
-    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; c->no_stream422 = (on & 4) != 0; }
+    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; c->no_stream422 = (on & 4) != 0; c->no_ghost_fuse = (on & 8) != 0; }
 }
 
 extern "C" int ntscsim_debug_last_kernels(const ntscsim_ctx *c, char *out, size_t cap)
@@ -668,7 +670,22 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     const bool small_plane = fast_plane_ok((size_t)D.Rpad, W, hs_mode);
     // the same with composite pre-emphasis (the -comp-catv* presets): k_encode_fast_pre<RT>
     const bool enc_preset_pre = !c->force_generic && D.in_lp && D.pre_on && D.noise_k != 0 && D.amp == 50;
-    if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
+    // extension: ghosting.  Folded into the hand-tuned encoder when every delay fits its 64-sample ring
+    // (k_encode_fast_gh), a pass of its own between encoder and decoder otherwise (k_ghost).
+    bool ghost_fused = D.ghost_taps > 0 && !c->no_ghost_fuse;
+    for (int k = 0; k < D.ghost_taps; k++) ghost_fused = ghost_fused && D.ghost_delay[k] < NTSC_GHOST_RING;
+    ghost_fused = ghost_fused && enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 &&
+                  D.noise_k <= (1 << 20);
+    if (ghost_fused) {
+        const bool two = D.ghost_taps <= 2;
+        note_kernel(c, (std::string("k_encode_fast_gh<") + (fast ? "float," : "double,") + (two ? "2>" : "4>")).c_str());
+#define NTSC_LAUNCH_GH(RT, GT)                                                                  \
+        hipLaunchKernelGGL((k_encode_fast_gh<RT, GT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D, \
+                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p)
+        if (fast) { if (two) NTSC_LAUNCH_GH(float, 2); else NTSC_LAUNCH_GH(float, 4); }
+        else { if (two) NTSC_LAUNCH_GH(double, 2); else NTSC_LAUNCH_GH(double, 4); }
+#undef NTSC_LAUNCH_GH
+    } else if (enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16) {
         // hand-tuned encoder of the presets (ntsc_encode_fast.hip)
         note_kernel(c, fast ? "k_encode_fast<float>" : "k_encode_fast<double>");
         if (fast) hipLaunchKernelGGL((k_encode_fast<float>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,
@@ -693,7 +710,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
 #undef NTSC_LAUNCH_ENCODE
     // extension: ghosting between encoder and decoder (reads the raw plane, writes a second one)
     const int *dec_in = c->comp.p;
-    if (D.ghost_taps > 0) {
+    if (D.ghost_taps > 0 && !ghost_fused) {
         note_kernel(c, "k_ghost");
         HIPCHK(c, c->comp_ghost.ensure((size_t)D.Rpad * W));
         hipLaunchKernelGGL(k_ghost, dim3((D.R + 255) / 256, (unsigned)W), dim3(256), 0, st, D,

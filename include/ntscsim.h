@@ -96,7 +96,9 @@ typedef struct ntscsim_params {
      * composite signal, between the luma-noise stage (:1644) and head switching (:1647):
      *   Y'[x] = Y[x] + ( sum_k ghost_gain[k] * Y[x - ghost_delay[k]] ) / 256      (Y[<0] = 0)
      * taps read the un-ghosted signal (FIR), C integer arithmetic.  ghost_taps = 0 (default)
-     * disables it and leaves the output bit-identical to the reference.  BGRA path only. */
+     * disables it and leaves the output bit-identical to the reference.  BGRA path only.
+     * (Speed: while every delay is at most 63 samples the taps are folded into the encoder
+     * kernel; a longer delay costs a pass over the composite plane) */
     int32_t  ghost_taps;                  /* 0..NTSCSIM_MAX_GHOST_TAPS                           */
     int32_t  ghost_delay[4];              /* samples, 1..4096                                    */
     int32_t  ghost_gain[4];               /* 1/256 units, -256..256                              */

@@ -146,6 +146,91 @@ def test_full_size_ghosting_extension(w, h, nf):
         ["k_encode_fast<double>", "k_ghost", "k_decode_fast<true,double>"], ran
 
 
+def _ghost_params(flags, taps):
+    p = L.make_params(flags)
+    p.ghost_taps = len(taps)
+    for k, (d, g) in enumerate(taps):
+        p.ghost_delay[k] = d
+        p.ghost_gain[k] = g
+    return p
+
+
+_GHOST_FUSED = [((12, 64),), ((12, 64), (31, -32)), ((1, 256), (63, -256)), ((7, 64), (19, -32), (40, 12)),
+                ((1, -256), (2, 256), (62, 100), (63, -7)), ((5, 90), (5, 90), (33, -120), (33, 17))]
+
+
+@pytest.mark.parametrize("flags", [[], ["-vhs"]], ids=["default", "vhs"])
+@pytest.mark.parametrize("taps", _GHOST_FUSED, ids=lambda t: "-".join("%dx%d" % dg for dg in t))
+def test_ghosting_folded_into_the_encoder(flags, taps):
+    """Delays up to 63 samples: the encoder keeps the last 64 raw samples of every scanline in LDS and stores the
+    ghosted plane itself (k_encode_fast_gh<RT, 2 | 4>), no k_ghost pass.  HIP == oracle; the same bytes with the
+    fold switched off (ntscsim_debug_no_fast_decode bit 8: k_ghost for every delay); in FAST32 mode the two
+    forms agree with each other (the ghost sum is integer work in both)."""
+    w, h, n = 112, 40, 6        # 112 = 4 + 6 * 16 + 12: chunks, row start and row end all emit through the ring
+    p = _ghost_params(flags, taps)
+    srcs = [L.noise_frame(w, h, 301 + j) for j in range(3)]
+    jobs = cases.case_jobs(n)
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    form = "2" if len(taps) <= 2 else "4"
+    for mode, rt in ((_capi.MODE_EXACT, "double"), (_capi.MODE_FAST32, "float")):
+        outs = []
+        for fold in (True, False):
+            sim = ntscsim.FieldSimulator(params=p)
+            sim.set_mode(mode)
+            if not fold:
+                sim.debug_no_fast_decode(8)
+            outs.append(run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim))
+            ran = [k for k in sim.last_kernels() if k.startswith(("k_encode", "k_ghost"))]
+            sim.close()
+            assert ran == (["k_encode_fast_gh<%s,%s>" % (rt, form)] if fold else ["k_encode_fast<%s>" % rt, "k_ghost"]), ran
+        assert np.array_equal(outs[0], outs[1]), rt
+        if mode == _capi.MODE_EXACT:
+            assert np.array_equal(outs[0], exp)
+
+
+def test_ghosting_fold_preconditions():
+    """A delay of 64 or more, an odd scanline phase, pre-emphasis: the pass of its own (k_ghost), same oracle."""
+    w, h, n = 96, 32, 4
+    for flags, taps in (([], ((12, 64), (64, -32))), (["-comp-phase", "90"], ((12, 64),)),
+                        (["-comp-catv"], ((12, 64),))):
+        p = _ghost_params(flags, taps)
+        srcs = [L.noise_frame(w, h, 61 + j) for j in range(2)]
+        jobs = cases.case_jobs(n)
+        o = L.OracleStream(p)
+        exp = np.zeros((n, h, w, 4), np.uint8)
+        for k, (si, field, fieldno) in enumerate(jobs):
+            o.field(exp[k], srcs[si], field, fieldno)
+        sim = ntscsim.FieldSimulator(params=p)
+        got = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+        ran = sim.last_kernels()
+        sim.close()
+        assert np.array_equal(got, exp), flags
+        assert "k_ghost" in ran and not any(k.startswith("k_encode_fast_gh") for k in ran), ran
+
+
+@pytest.mark.parametrize("w,h,nf", [(720, 486, 6), (3840, 2160, 4)])
+def test_full_size_ghosting_folded(w, h, nf):
+    """The ghosting extension at BASELINE's sizes with the taps bench_side.py's vhs_ghost2 leg uses (12 and 31
+    samples): folded into the encoder, HIP == oracle."""
+    p = _ghost_params(["-vhs"], ((12, 64), (31, -32)))
+    srcs = [L.bars(w, h, j) if j % 2 == 0 else L.noise_frame(w, h, 177 + j) for j in range((nf + 1) // 2)]
+    jobs = cases.case_jobs(nf)
+    o = L.OracleStream(p)
+    exp = np.zeros((nf, h, w, 4), np.uint8)
+    for k, (si, field, fieldno) in enumerate(jobs):
+        o.field(exp[k], srcs[si], field, fieldno)
+    sim = ntscsim.FieldSimulator(params=p)
+    got = run_hip(p, srcs, jobs, h, w, per_field_dst=True, sim=sim)
+    ran = sim.last_kernels()
+    sim.close()
+    assert np.array_equal(got, exp)
+    assert [k for k in ran if not k.startswith(("k_field", "k_row"))] == \
+        ["k_encode_fast_gh<double,2>", "k_decode_fast<true,double>"], ran
+
+
 @pytest.mark.parametrize("c", FULL, ids=lambda c: "%dx%d%s" % (c["w"], c["h"], "".join(c["flags"])))
 def test_full_size_reference_hashes(c):
     """Hashes recorded from the reference extract at the BASELINE sizes (incl. 3840x2160)."""
