@@ -223,6 +223,13 @@ def lib():
         raise RuntimeError(
             "%s is missing -- build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
             "(or `make -C composite-video-simulator_amd/csrc`)" % PRODUCT_SO)
+    # torch carries its own copy of the HIP runtime; loaded AFTER libntscsim.so (which links /opt/rocm's) it finds no
+    # device (torch.cuda.is_available() == False, seen on the GPU box).  The device-tensor half of this package needs
+    # torch anyway, so let it load first whatever order the caller imports in: one runtime for both.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(PRODUCT_SO)
     L.ntscsim_params_init.argtypes = [C.POINTER(Params)]
     L.ntscsim_params_init.restype = None
