@@ -1028,19 +1028,32 @@ __global__ __launch_bounds__(64, (VHS && COMPOUT) ? NTSC_DEC_WAVES_VHS : NTSC_DE
 
 // =============================================================================== k_ghost
 // EXTENSION (not in the reference, default off): multipath ghosting of the composite signal,
-// out[x] = in[x] + (sum_k gain_k * in[x - delay_k]) / 256.  Pointwise over the transposed plane:
-// one thread per (x, row), coalesced along rows.
-__global__ void k_ghost(DevParams P, const int *__restrict__ in, int *__restrict__ out)
+// out[x] = in[x] + (sum_k gain_k * in[x - delay_k]) / 256, as a pass of its own -- the form for a delay of 64 samples
+// or more (shorter ones are folded into the encoder: k_encode_fast_gh, ntsc_encode_fast.hip).  Pointwise over the
+// transposed plane: a thread owns four neighbouring rows (one 16-byte piece of every plane row, Rpad is a multiple
+// of 64) and NTSC_GHOST_XT consecutive positions; both planes are streamed (nt): each is far larger than the L2
+// and next touched by another kernel.  A tap's piece was this pass's own in[x] delay positions earlier -- for a
+// delay of a few hundred samples still in the Infinity Cache.
+#define NTSC_GHOST_XT 8
+__global__ __launch_bounds__(256) void k_ghost(DevParams P, const int *__restrict__ in, int *__restrict__ out)
 {
-    const int rho = blockIdx.x * blockDim.x + threadIdx.x;
-    const int x = blockIdx.y;
+    const int rho = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (rho >= P.R) return;
-    int acc = 0;
-    for (int k = 0; k < P.ghost_taps; k++) {
-        const int xs = x - P.ghost_delay[k];
-        if (xs >= 0) acc += P.ghost_gain[k] * in[(size_t)xs * P.Rpad + rho];
+    const int x0 = blockIdx.y * NTSC_GHOST_XT;
+    const int taps = P.ghost_taps;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < NTSC_GHOST_XT; i++) {
+        const int x = x0 + i;
+        if (x >= P.W) break;
+        v4i acc = {0, 0, 0, 0};
+        for (int k = 0; k < taps; k++) {
+            const int xs = x - P.ghost_delay[k];
+            if (xs >= 0) acc += P.ghost_gain[k] * __builtin_nontemporal_load((const v4i *)(in + (size_t)xs * P.Rpad + rho));
+        }
+        const v4i v = __builtin_nontemporal_load((const v4i *)(in + (size_t)x * P.Rpad + rho));
+        __builtin_nontemporal_store(v + acc / 256, (v4i *)(out + (size_t)x * P.Rpad + rho));
     }
-    out[(size_t)x * P.Rpad + rho] = in[(size_t)x * P.Rpad + rho] + acc / 256;
 }
 
 // =============================================================================== k_bob

@@ -713,7 +713,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     if (D.ghost_taps > 0 && !ghost_fused) {
         note_kernel(c, "k_ghost");
         HIPCHK(c, c->comp_ghost.ensure((size_t)D.Rpad * W));
-        hipLaunchKernelGGL(k_ghost, dim3((D.R + 255) / 256, (unsigned)W), dim3(256), 0, st, D,
+        hipLaunchKernelGGL(k_ghost, dim3((D.R + 1023) / 1024, (unsigned)(W + NTSC_GHOST_XT - 1) / NTSC_GHOST_XT), dim3(256), 0, st, D,
                            c->comp.p, c->comp_ghost.p);
         dec_in = c->comp_ghost.p;
     }
