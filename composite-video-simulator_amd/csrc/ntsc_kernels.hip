@@ -191,15 +191,12 @@ DEV int field_rows(const DevParams &P, unsigned field) { return (P.H - (int)fiel
 // =============================================================================== k_field_setup
 // Per field: the draws that are not per-pixel.  Order of draws inside one composite_layer call
 // (SURVEY A.10): [W*L luma] [4 head switch] [2*W*L chroma] [L phase noise] [L dropout].
-__global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
-                                                    const FieldDev *__restrict__ fields,
-                                                    int *__restrict__ hs_shift,
-                                                    int *__restrict__ pn_noise,
-                                                    int *__restrict__ dropout)
+DEV void field_setup_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
+                          int *__restrict__ hs_shift, int *__restrict__ pn_noise, int *__restrict__ dropout,
+                          uint32_t *ring, int block)
 {
-    __shared__ uint32_t ring[31 * 64];
     const int lane = threadIdx.x;
-    const int f = blockIdx.x * 64 + lane;
+    const int f = block * 64 + lane;
     if (f >= P.nfields) return;
     const FieldDev &fd = fields[f];
     const unsigned field = fd.field & 1u;
@@ -210,6 +207,8 @@ __global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
 
     // VHS head switching geometry, ffmpeg_ntsc.cpp:1647-1713
     if (P.hs) {
+        // (every row of the field's slot, also the ones the switch does not reach: no fill of the plane before this kernel)
+        for (int k = 0; k < P.Lslot; k++) hs_row[k] = 0;
         const unsigned twidth = (unsigned)P.W + ((unsigned)P.W / 10u);
         double noise = 0;
         if (P.hs_noise_on) {
@@ -264,6 +263,16 @@ __global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
     }
 }
 
+__global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
+                                                    const FieldDev *__restrict__ fields,
+                                                    int *__restrict__ hs_shift,
+                                                    int *__restrict__ pn_noise,
+                                                    int *__restrict__ dropout)
+{
+    __shared__ uint32_t ring[31 * 64];
+    field_setup_body(P, G, fields, hs_shift, pn_noise, dropout, ring, (int)blockIdx.x);
+}
+
 // =============================================================================== k_row_states
 // rand() state and noise accumulator(s) at the first pixel of every scanline.
 // The accumulators are carried across rows in the reference (noise = (noise + d - k) / 2, C
@@ -271,17 +280,13 @@ __global__ __launch_bounds__(64) void k_field_setup(DevParams P, GeomDev G,
 // both extremes (-k and +k) over a short warm-up pins the exact value as soon as the two
 // trajectories meet.  If they have not met after the warm-up (probability ~2^-warm) the lane
 // recomputes serially from the start of the field -- exact by construction either way.
-__global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
-                                                   const FieldDev *__restrict__ fields,
-                                                   uint32_t *__restrict__ rs_luma,
-                                                   int *__restrict__ n0_luma,
-                                                   uint32_t *__restrict__ rs_chroma,
-                                                   int *__restrict__ n0_u, int *__restrict__ n0_v)
+DEV void row_states_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
+                         uint32_t *__restrict__ rs_luma, int *__restrict__ n0_luma,
+                         uint32_t *__restrict__ rs_chroma, int *__restrict__ n0_u, int *__restrict__ n0_v,
+                         uint32_t *ring, int block, int stream)
 {
-    __shared__ uint32_t ring[31 * 64];
     const int lane = threadIdx.x;
-    const int rho = blockIdx.x * 64 + lane;
-    const int stream = blockIdx.y;                 // 0 luma, 1 chroma
+    const int rho = block * 64 + lane;             // stream: 0 luma, 1 chroma
     if (rho >= P.R) return;
     if (stream == 0 ? !P.noise_k : !P.cnoise_k) return;
     const int f = rho / P.Lslot, k = rho - f * P.Lslot;
@@ -342,6 +347,35 @@ __global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
     }
     if (stream == 0) n0_luma[rho] = lo0;
     else { n0_u[rho] = lo0; n0_v[rho] = lo1; }
+}
+
+__global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
+                                                   const FieldDev *__restrict__ fields,
+                                                   uint32_t *__restrict__ rs_luma,
+                                                   int *__restrict__ n0_luma,
+                                                   uint32_t *__restrict__ rs_chroma,
+                                                   int *__restrict__ n0_u, int *__restrict__ n0_v)
+{
+    __shared__ uint32_t ring[31 * 64];
+    row_states_body(P, G, fields, rs_luma, n0_luma, rs_chroma, n0_u, n0_v, ring, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Both in ONE launch, for the short batches of the host-frame calls (ntscsim_field(): one field; a submit lane: `depth`
+// fields): the two are independent of each other, and with a handful of fields k_field_setup is a single wavefront
+// walking its rows one draw at a time (36 us for one field) -- as blocks of the same grid that walk overlaps the row
+// states instead of preceding them.  Blocks [0, nfs) do the field setup (first: they run longest), the rest the row states.
+__global__ __launch_bounds__(64) void k_field_row_setup(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
+                                                        int *__restrict__ hs_shift, int *__restrict__ pn_noise,
+                                                        int *__restrict__ dropout,
+                                                        uint32_t *__restrict__ rs_luma, int *__restrict__ n0_luma,
+                                                        uint32_t *__restrict__ rs_chroma,
+                                                        int *__restrict__ n0_u, int *__restrict__ n0_v, int nfs, int nrs)
+{
+    __shared__ uint32_t ring[31 * 64];
+    const int b = (int)blockIdx.x;
+    if (b < nfs) { field_setup_body(P, G, fields, hs_shift, pn_noise, dropout, ring, b); return; }
+    const int q = b - nfs;
+    row_states_body(P, G, fields, rs_luma, n0_luma, rs_chroma, n0_u, n0_v, ring, q % nrs, q / nrs);
 }
 
 // =============================================================================== k_encode

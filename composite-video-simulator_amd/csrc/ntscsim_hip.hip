@@ -164,6 +164,7 @@ struct ntscsim_ctx {
     bool no_fast_decode = false;     // debug: keep the PRESET template kernels (A/B against k_decode_fast)
     bool no_stream422 = false;       // debug: the YUV422P preset kernel as four sweeps instead of A + one streamed pass
     bool no_ghost_fuse = false;      // debug / A-B: the ghosting extension as its own pass (k_ghost) for every delay
+    bool no_setup_merge = false;     // debug / A-B: k_field_setup and k_row_states as two launches for short batches too
     int mode = NTSCSIM_MODE_EXACT;
     SubmitEngine *sub = nullptr;     // ntscsim_submit() / ntscsim_wait(): created on first use
     Host422Engine *h422 = nullptr;   // ntscsim_field422() / ntscsim_submit422(): created on first use
@@ -381,7 +382,7 @@ extern "C" int ntscsim_create(const ntscsim_params *p, int device, ntscsim_ctx *
     if (const char *e = std::getenv("NTSCSIM_DEBUG_DECODE")) {
         const int v = std::atoi(e);
         c->no_fast_decode = (v & 1) != 0; c->split_vhs = (v & 2) != 0; c->no_stream422 = (v & 4) != 0;
-        c->no_ghost_fuse = (v & 8) != 0;
+        c->no_ghost_fuse = (v & 8) != 0; c->no_setup_merge = (v & 16) != 0;
     }
     if (hipSetDevice(device) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -481,7 +482,7 @@ extern "C" void ntscsim_debug_force_generic(ntscsim_ctx *c, int on)
 
 extern "C" void ntscsim_debug_no_fast_decode(ntscsim_ctx *c, int on)
 {
-    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; c->no_stream422 = (on & 4) != 0; c->no_ghost_fuse = (on & 8) != 0; }
+    if (c) { c->no_fast_decode = (on & 1) != 0; c->split_vhs = (on & 2) != 0; c->no_stream422 = (on & 4) != 0; c->no_ghost_fuse = (on & 8) != 0; c->no_setup_merge = (on & 16) != 0; }
 }
 
 extern "C" int ntscsim_debug_last_kernels(const ntscsim_ctx *c, char *out, size_t cap)
@@ -502,6 +503,35 @@ extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chr
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (Geometry *e : c->geoms) e->valid = false;
+}
+
+// The draws that are not per-pixel (k_field_setup) and the rand() / noise state of every row start (k_row_states):
+// two launches for the long batches, one (k_field_row_setup: the field setup overlaps the row states) for short ones.
+#ifndef NTSC_SETUP_MERGE_MAX
+#define NTSC_SETUP_MERGE_MAX 64      /* fields; 0 = always two launches (A/B) */
+#endif
+static void launch_setup(ntscsim_ctx *c, const DevParams &D, const GeomDev &G, const FieldDev *fields_dev, int n, hipStream_t st)
+{
+    const bool fs = D.hs || D.pnoise_k || D.loss, rs = D.noise_k || D.cnoise_k;
+    if (fs && rs && n <= NTSC_SETUP_MERGE_MAX && !c->no_setup_merge) {
+        const int nfs = (n + 63) / 64, nrs = (D.R + 63) / 64;
+        note_kernel(c, "k_field_row_setup");
+        hipLaunchKernelGGL(k_field_row_setup, dim3((unsigned)(nfs + 2 * nrs)), dim3(64), 0, st, D, G, fields_dev,
+                           c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p,
+                           c->n0_u.p, c->n0_v.p, nfs, nrs);
+        return;
+    }
+    if (fs) {
+        note_kernel(c, "k_field_setup");
+        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
+                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
+    }
+    if (rs) {
+        note_kernel(c, "k_row_states");
+        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
+                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
+                           c->n0_v.p);
+    }
 }
 
 // ---- step 1: descriptors -> device records.  The rand() window of every field is computed on
@@ -643,18 +673,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     G.jwarm = c->geom_cur->jwarm.p; G.sstart = c->geom_cur->sstart.p; G.ptab = c->ptab.p;
 
     c->kernels.clear();
-    if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
-    if (D.hs || D.pnoise_k || D.loss) {
-        note_kernel(c, "k_field_setup");
-        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
-                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
-    }
-    if (D.noise_k || D.cnoise_k) {
-        note_kernel(c, "k_row_states");
-        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
-                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
-                           c->n0_v.p);
-    }
+    launch_setup(c, D, G, fields_dev, n, st);
     if (evs) HIPCHK(c, hipEventRecord(evs->e[1], st));
     // PRESET kernels (options folded at compile time) when the parameters match the default
     // preset or the full -vhs preset exactly; otherwise the GENERIC kernels.  Same results.
@@ -1158,18 +1177,7 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     if (any_flt)
         hipLaunchKernelGGL(k422_bkey, dim3((unsigned)((W2 + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
                            dim3(256), 0, st, D, fields422_dev, p.black_key_level_feedback);
-    if (D.hs) HIPCHK(c, hipMemsetAsync(c->hs_shift.p, 0, (size_t)D.R * sizeof(int), st));
-    if (D.hs || D.pnoise_k || D.loss) {
-        note_kernel(c, "k_field_setup");
-        hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
-                           c->hs_shift.p, c->pn_noise.p, c->dropout.p);
-    }
-    if (D.noise_k || D.cnoise_k) {
-        note_kernel(c, "k_row_states");
-        hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
-                           fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
-                           c->n0_v.p);
-    }
+    launch_setup(c, D, G, fields_dev, n, st);
     // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
     // empty, "decode" = the one kernel that does composite_video_process)
     if (evs) { HIPCHK(c, hipEventRecord(evs->e[1], st)); HIPCHK(c, hipEventRecord(evs->e[2], st)); }

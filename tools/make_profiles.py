@@ -171,7 +171,7 @@ rd += "| `r04_fuzz_sweep.txt` | `tools/fuzz_r04.sh` | one-off parity sweeps on t
 rd += "| `r03_decode_experiments.txt`, `r03_clock_under_load.txt`, `r03_composite_range.txt`, `r03_variant_sweeps.txt` | (round 3) | A/B experiments on the dominant kernel; shader clock under load (2.31-2.32 GHz); value range of the composite plane; wave-clock share of the YUV422P kernel's sweeps |\n"
 rd += "| `%s_raw28_front_pmc.txt` | `tools/pmc_raw28.sh`, `tools/follow_probe.hip` | counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront |\n" % tag
 rd += "| `%s_host422_loop_probe.txt` | `tools/host422_loop_probe.sh` (`host/field_loop422.cpp`) | (round 5) the YUV422P tool's loop on host frames, `ntscsim_field422()` / `ntscsim_submit422()`: byte identity (FNV-1a of every encoder frame) across sync / submit / staging rings / page-owned planes for six switch sets, fields/s by switch set, depth and frame allocation, host time inside the calls |\n" % tag
-rd += "| `%s_sync_call_stats.csv`, `%s_sync_call_notes.txt` | `rocprofv3 --kernel-trace --memory-copy-trace --stats -- field_loop -vhs --mode sync`; `tools/gpu_r05_5.sh` | (round 5) where the 0.54 ms of one synchronous `ntscsim_field()` call go, kernel by kernel; the same loop alone and beside a process that keeps the GPU busy (same rate: not a clock effect) |\n" % (tag, tag)
+rd += "| `%s_sync_call_stats.csv`, `%s_sync_call_notes.txt` | `rocprofv3 --kernel-trace --memory-copy-trace --stats -- field_loop -vhs --mode sync`; `tools/gpu_r05_5.sh` | (round 5) where the 0.51 ms of one synchronous `ntscsim_field()` call go, kernel by kernel; the same loop alone and beside a process that keeps the GPU busy (same rate: not a clock effect) |\n" % (tag, tag)
 rd += "| `%s_rank_bench.json` | `rank_bench -vhs --spawn 1 --frames 300 --steps 40 --warmup 8` | (round 5) the C++ rank-per-GPU harness over `rccl.h` with the one rank this box has |\n" % tag
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
@@ -237,7 +237,7 @@ k = d["roofline"]["kernel_ms_all"]
 for nm, key, ev in (("`k_decode_fast<true,double>`", "k_decode_fast<true", k["decode"]), ("`k_encode_fast<double>`", "k_encode_fast", k["encode"])):
     x, y = pick(b, key), pick(a, key)
     rd += "| %s | %.1f | %.1f | %.1f / %.1f / %.1f |\n" % (nm, ev * 1e3, x[1], y[2], y[1], y[3])
-rd += "| `k_row_states` + `k_field_setup` (+ memset) | %.1f (\"setup\") | %.1f + %.1f | |\n\n" % (
+rd += "| `k_row_states` + `k_field_setup` | %.1f (\"setup\") | %.1f + %.1f | |\n\n" % (
     k["setup"] * 1e3, pick(b, "k_row_states")[1], pick(b, "k_field_setup")[1])
 rd += "## Where the time goes\n\n"
 cd = cen["k_decode"]
