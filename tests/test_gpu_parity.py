@@ -618,6 +618,42 @@ def test_many_small_fields_in_one_batch():
     sim.close()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 130])
+def test_setup_kernels_one_launch_or_two(n):
+    """Batches of up to 64 fields run the per-field draws and the row states as ONE launch (k_field_row_setup: the
+    field setup's lone wavefront overlaps the row states -- the synchronous call's latency), longer ones as two;
+    either way the head-switch plane is cleared by the kernel (no fill).  Same bytes as the oracle at every size, the
+    form asserted by name, and the two-launch form forced for the short ones (ntscsim_debug_no_fast_decode bit 16).
+    A second batch on the same context with head switching at another point must not see the first one's shifts."""
+    torch = torch_mod()
+    w, h = 48, 18
+    frames = np.stack([L.noise_frame(w, h, 900 + j) for j in range((n + 1) // 2)])
+    src = torch.from_numpy(frames).cuda()
+    jobs = [(k // 2, k, (k & 1) ^ 1, k) for k in range(n)]
+    for forced in (False, True):
+        sim = None
+        for flags in (["-vhs", "-vhs-head-switching-point", "0.12", "-vhs-head-switching-phase", "0.3"], ["-vhs"]):
+            p = L.make_params(flags)
+            o = L.OracleStream(p)
+            exp = np.zeros((n, h, w, 4), np.uint8)
+            for k in range(n):
+                o.field(exp[k], frames[k // 2], (k & 1) ^ 1, k)
+            if sim is not None:
+                sim.close()
+            sim = ntscsim.FieldSimulator(params=p)
+            if forced:
+                sim.debug_no_fast_decode(16)
+            for rep in range(2):       # the second run reuses the context's planes
+                dst = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+                sim.rng_pos = 0
+                sim.fields(src, dst, jobs)
+                sim.sync()
+                assert np.array_equal(dst.cpu().numpy(), exp), (flags, forced, rep)
+            ran = [k for k in sim.last_kernels() if k.startswith(("k_field", "k_row"))]
+            assert ran == (["k_field_row_setup"] if n <= 64 and not forced else ["k_field_setup", "k_row_states"]), ran
+        sim.close()
+
+
 def test_frames_host_streaming_equals_field_loop():
     """ntscsim_frames_host: pipelined H2D | kernels | D2H over several chunks == the reference's
     field loop (composite_layer + bob into zeroed frames), rand() stream carried across calls."""
