@@ -1507,8 +1507,24 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     const size_t pitch = (((size_t)W * 4 + 255) / 256) * 256;
     HIPCHK(c, c->fsrc.ensure(pitch * H));
     HIPCHK(c, c->fdst.ensure(pitch * H));
-    HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p, pitch, src, (size_t)src_ls, (size_t)W * 4, (size_t)H,
-                               hipMemcpyHostToDevice, c->stream));
+    // Only the source rows this field reads go up: row min(y + opposite, H - 1) for y = field, field + 2, ...
+    // (ffmpeg_ntsc.cpp:1585-1588, :1599) -- every second row from `first`, plus row H - 1 when the last one is clamped
+    // onto it.  They land at their own place in the device frame; the rows in between are never read.
+    static const bool full_upload = std::getenv("NTSCSIM_FIELD_FULL_UPLOAD") != nullptr;      // A/B
+    const int opposite = src_interlaced ? (src_tff ? 1 : 0) : 0;
+    const int first = (int)field + opposite, Lf = (H - (int)field + 1) / 2;
+    const int direct = first <= H - 1 ? (H - 1 - first) / 2 + 1 : 0;      // rows first, first + 2, ... <= H - 1
+    if (full_upload || Lf <= 0) {
+        HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p, pitch, src, (size_t)src_ls, (size_t)W * 4, (size_t)H,
+                                   hipMemcpyHostToDevice, c->stream));
+    } else {
+        if (direct > 0)
+            HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p + pitch * first, pitch * 2, src + (size_t)src_ls * first, (size_t)src_ls * 2,
+                                       (size_t)W * 4, (size_t)(direct < Lf ? direct : Lf), hipMemcpyHostToDevice, c->stream));
+        if (direct < Lf)      // the clamped last row
+            HIPCHK(c, hipMemcpyAsync(c->fsrc.p + pitch * (H - 1), src + (size_t)src_ls * (H - 1), (size_t)W * 4,
+                                     hipMemcpyHostToDevice, c->stream));
+    }
     ntscsim_field_desc d;
     std::memset(&d, 0, sizeof(d));
     d.src_dev = c->fsrc.p; d.dst_dev = c->fdst.p;

@@ -271,6 +271,36 @@ def test_host_frame_dropin_sequence():
     sim.close()
 
 
+@pytest.mark.parametrize("h", [2, 3, 32, 33])
+@pytest.mark.parametrize("il,tff", [(0, 0), (1, 0), (1, 1)])
+def test_host_frame_dropin_uploads_the_rows_it_reads(h, il, tff):
+    """ntscsim_field() sends up only the source rows the field reads -- row min(y + opposite, H - 1) for the field's y
+    (ffmpeg_ntsc.cpp:1585-1588, :1599) -- incl. the last row clamped onto H - 1 (odd / even heights, interlaced
+    sources of either field order).  The product never reads the rows in between: they are poisoned in the frame it
+    gets, the oracle runs on the clean one."""
+    w = 64
+    p = L.make_params(["-vhs"])
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    dst = np.full((h, w, 4), 0x5A, np.uint8)
+    exp = np.full((h, w, 4), 0x5A, np.uint8)
+    for k in range(6):
+        s = L.noise_frame(w, h, 140 + k)
+        field = (k & 1) ^ 1
+        o.field(exp, s, field, k, interlaced=il, tff=tff)
+        # rows this field does not read: poisoned for the product
+        opposite = (1 if tff else 0) if il else 0
+        read = {min(y + opposite, h - 1) for y in range(field, h, 2)}
+        sp = s.copy()
+        for y in range(h):
+            if y not in read:
+                sp[y] = 0xA7
+        sim.field_host(dst, sp, field, k, interlaced=il, tff=tff)
+        assert np.array_equal(dst, exp), "call %d" % k
+        assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
 def test_batch_split_and_order_invariance():
     """Size-independent property at the BASELINE size: a 64-field batch == 64 single-field
     calls == two half batches issued in reverse order (explicit rand() positions)."""
