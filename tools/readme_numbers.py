@@ -46,7 +46,7 @@ mgpu = ("  One process per GPU with the C++ host over `rccl.h` (`host/rank_bench
         % round(mg["value"] / 1e3)) if mg.get("value") else ""
 new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` preset, exact mode; every figure is\n"
        "a key of `profiles/%s_bench.json`, the line `python bench.py` prints; `profiles/README.md` maps the\n"
-       "rest; box-to-box spread ≈ ±4 %%: `value` 764-805k over the boxes this round saw, the isolated kernels take the same time on all of them):\n"
+       "rest; box-to-box spread ≈ ±4 %%: `value` 764-813k over the boxes this round saw, the isolated kernels take the same time on all of them):\n"
        "`value_sustained` **%dk fields/s** (the same 600-field step repeated for %.2f s, four steps in flight) and `value` **%dk** over the %d\n"
        "timed steps that follow it (`config.pre_roll`: the sustained leg runs BEFORE the W warm-up steps, so the timed steps see a GPU at its\n"
        "working clocks; rounds 1 and 2 were measured without it and read 4-6 %% lower for that reason alone).  With the driver's own\n"
