@@ -36,7 +36,7 @@ VALU_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 at 2.4 G
 N_SIMD = 256 * 4
 
 
-from bench_side import (device_rate, device_stream_rate, extras, make_bars_clip, time_steps,  # noqa: E402,F401
+from bench_side import (device_rate, device_stream_rate, emit, extras, make_bars_clip, time_steps,  # noqa: E402,F401
                         variant_contexts)
 from bench_variant import main_to_composite  # noqa: E402
 
@@ -543,8 +543,8 @@ def main():
                 "unit": "frames/s",
                 "cores": 1,
                 "kind": kind,
-                "sample": "first %d fields of the same clip, %s; %d fields compared byte-for-byte "
-                          "with the HIP output" % (ncpu, what, ok_ref),
+                "sample": "first %d fields of the same clip, 1 thread; %d fields byte-compared with the HIP output" % (ncpu, ok_ref),
+                "engine": what,
                 "host_cpus": os.cpu_count(),
                 "port_1core": port_fps,
             }
@@ -558,7 +558,7 @@ def main():
                               "the cgroup CPU quota) x %d fields of the port, rand() positions by "
                               "jump-ahead, released together" % (nw, args.cpu_mt_fields)}
                 out["speedup_vs_cpu_all_cores"] = value / mt_fps
-        print(json.dumps(out), flush=True)
+        emit(out)
     for sm, plans, _, _ in ctxs:
         for pl in plans:
             sm.free_prepared(pl)

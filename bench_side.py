@@ -487,3 +487,115 @@ def extras(torch, ntscsim, dev, local_rank, args):
         except Exception as e:
             out["presets"][name] = {"error": repr(e)}
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The contract line.  bench.py / bench_variant.py build one big dictionary (every side leg with its workload notes);
+# the driver wants ONE short JSON line as the last line of stdout.  emit() writes the whole dictionary to
+# bench_extras.json (beside bench.py, and into gpurun_out/ when that directory exists) and prints the contract
+# object only: the keys the driver reads, `roofline`, `cpu_baseline` and one number per side leg.  No prose.
+LINE_LIMIT = 4096
+
+
+def _r(x, sig=6):
+    """Floats to `sig` significant digits (the line is for reading; the extras file keeps every digit)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def _num(d, *path):
+    """d[path...] when it is a number, else None (side legs may have failed or been skipped)."""
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d if isinstance(d, (int, float)) and not isinstance(d, bool) else None
+
+
+def compact_line(out, extras_file):
+    """The contract object of `out`: <= LINE_LIMIT bytes of JSON, numbers and short identifiers only."""
+    cfg = out.get("config", {})
+    pre = cfg.get("pre_roll") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfg[k] for k in ("workload", "tool", "fields_per_step_per_gpu", "steps_in_flight",
+                                          "mode", "rank_checksums_verified") if k in cfg and cfg[k] is not None}
+    if pre:
+        line["config"]["pre_roll_s"] = pre.get("seconds")
+    rf = out.get("roofline") or {}
+    line["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                           "algorithmic_bytes_per_launch", "kernel_ms", "kernel_ms_all",
+                                           "path_achieved", "live_fields") if k in rf}
+    if rf.get("traffic") is not None:
+        line["roofline"]["traffic_source"] = "replayed:profiles/traffic.json"
+    valu = rf.get("valu") or {}
+    vs = {k: valu[k] for k in ("path_frac_nominal", "k_decode_frac_nominal", "hbm_frac_ceiling_exact_mode") if k in valu}
+    if vs:
+        line["roofline"]["valu"] = vs
+    cb = out.get("cpu_baseline")
+    if cb:
+        c2 = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "port_1core") if k in cb}
+        if isinstance(cb.get("port_all_cores"), dict):
+            c2["port_all_cores"] = {"value": cb["port_all_cores"].get("value"), "cores": cb["port_all_cores"].get("cores")}
+        line["cpu_baseline"] = c2
+    for k in ("value_sustained", "speedup_vs_cpu_1core", "speedup_vs_cpu_all_cores", "extras_error"):
+        if k in out:
+            line[k] = out[k]
+    side = {
+        "variant422": _num(out, "variant422", "value"),
+        "raw28": _num(out, "raw28", "value"),
+        "device_stream": _num(out, "device_stream", "value"),
+        "sizes": {k: _num(v, "value") for k, v in (out.get("sizes") or {}).items()} or None,
+        "field_call": _num(out, "end_to_end", "field_call"),
+        "field_submit": _num(out, "end_to_end", "field_submit"),
+        "field_submit422": _num(out, "end_to_end", "field_submit422"),
+        "frames_host_bgra_pinned": _num(out, "end_to_end", "bgra_pinned"),
+        "cli": _num(out, "end_to_end", "cli"),
+        "multi_gpu_cpp_host": _num(out, "multi_gpu_cpp_host", "value"),
+        "presets": {k: _num(v, "value") for k, v in (out.get("presets") or {}).items()} or None,
+        "fast": _num(out, "fast", "value"),
+        "fast_frac": _num(out, "fast", "roofline_frac"),
+    }
+    side = {k: v for k, v in side.items() if v is not None}
+    if side:
+        side["unit"] = "frames/s"
+        line["side"] = side
+    line["extras_file"] = extras_file
+    line = _r(line)
+    # never lose the line to its own length: drop the optional parts, largest first
+    for drop in ("presets", "sizes", None):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        if drop is None:
+            line.pop("side", None)
+        elif "side" in line:
+            line["side"].pop(drop, None)
+    return line
+
+
+def emit(out, name="bench_extras.json"):
+    """Full dictionary -> bench_extras.json (and gpurun_out/ when present); contract object -> the last stdout line."""
+    paths = [os.path.join(ROOT, name)]
+    god = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(god):
+        paths.append(os.path.join(god, name))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f, indent=1)
+                f.write("\n")
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    line = compact_line(out, written)
+    txt = json.dumps(line)
+    assert len(txt) < LINE_LIMIT, len(txt)
+    sys.stdout.flush()
+    print(txt, flush=True)
+    return line

@@ -6,7 +6,7 @@ import os
 import sys
 import time
 
-from bench_side import HBM_PEAK_GBS, ROOT, variant_contexts
+from bench_side import HBM_PEAK_GBS, ROOT, emit, variant_contexts
 
 
 def main_to_composite(args):
@@ -193,7 +193,7 @@ def main_to_composite(args):
                                              % (ncpu, "composite_video_process() of the reference (oracle/_ref)"
                                                 if have_ref else "oracle/tocomp_oracle.c", ok)}
             out["speedup_vs_cpu_1core"] = value / cpu_fps
-        print(json.dumps(out), flush=True)
+        emit(out, "bench_extras_to_composite.json")
     for sm in sims:
         sm.close()
     if dist is not None:

@@ -12,14 +12,39 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline")
 
 
-def _run(extra):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-           "--frames", "12", "--sustain-seconds", "0.05"] + extra
-    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+def _run(extra, base=("--gpus", "1", "--steps", "3", "--warmup", "1", "--frames", "12", "--sustain-seconds", "0.05")):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + list(base) + extra
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
-    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    text = out.stdout.decode()
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text[-2000:]
+    # the contract object is the LAST line of stdout and short enough for any log tail (the 20 KB
+    # line of round 5 did not parse in the driver)
+    assert text.rstrip("\n").splitlines()[-1] == lines[0]
+    assert len(lines[0]) < 4096, len(lines[0])
     return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_line_of_the_drivers_exact_command():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- every side leg included, nothing skipped: the last stdout
+    line is the contract object alone (< 4 KB, json.loads), carries roofline.frac and cpu_baseline.value, one number
+    per side leg, and names the file the rest went to."""
+    d = _run([], base=("--gpus", "1", "--steps", "20", "--warmup", "5"))
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["value"] > 0
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel_ms"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    assert "extras_error" not in d, d.get("extras_error")
+    side = d["side"]
+    for k in ("variant422", "raw28", "device_stream", "sizes", "field_call", "field_submit", "field_submit422"):
+        assert k in side, k
+    full = json.load(open(os.path.join(ROOT, d["extras_file"])))
+    assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "end_to_end" in full
+    for v in d.values():          # no prose: every string of the line is short
+        assert not isinstance(v, str) or len(v) < 200
 
 
 @pytest.mark.gpu
