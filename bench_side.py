@@ -282,9 +282,9 @@ def extras(torch, ntscsim, dev, local_rank, args):
     if os.path.exists(floop):
         import json as _json
         import subprocess
-        def run_loop(*extra):
+        def run_loop(*extra, best_of=1):
             best = None
-            for _ in range(2):
+            for _ in range(best_of):
                 pr = subprocess.run([floop] + args.preset.split() + ["--height", str(h), "-width", str(w)] + list(extra),
                                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
                 try:
@@ -296,25 +296,21 @@ def extras(torch, ntscsim, dev, local_rank, args):
             return best
         big = ["--fields", "20000", "--warmup", "2000"]
         sync = run_loop("--mode", "sync", "--fields", "1500", "--warmup", "100")
-        sub = run_loop("--mode", "submit", "--depth", "32", "--rewrite-src", "1", *big)
+        sub = run_loop("--mode", "submit", "--depth", "32", "--rewrite-src", "1", "--alloc", "pinned", *big, best_of=2)
         e2e["field_submit"] = sub.get("fields_per_s", 0.0)
         e2e["field_submit_detail"] = {
             "loop_sync_fields_per_s": sync.get("fields_per_s"),
             "depth32_in_rgb_rewritten": sub,
-            "depth32_decoder_frames": run_loop("--mode", "submit", "--depth", "32", *big),
-            "depth32_bob": run_loop("--mode", "submit", "--depth", "32", "--bob", "1", *big),
-            "depth128": run_loop("--mode", "submit", "--depth", "128", *big),
-            "depth32_src_stable": run_loop("--mode", "submit", "--depth", "32", "--src-stable", "1", *big),
-            "depth32_staging_ring": run_loop("--mode", "submit", "--depth", "32", "--pin", "0", "--rewrite-src", "1", *big),
-            "note": "host/field_loop.cpp: the loop of ffmpeg_ntsc.cpp:2202-2282 on AVFrame-shaped pageable frames "
-                    "(posix_memalign, linesize rounded to 64) with composite_layer() :2229 replaced by "
-                    "ntscsim_submit_avframe() and the frame consumed behind ntscsim_wait() 4 * depth fields later; "
-                    "field_submit = depth 32, ONE source frame (in.rgb) rewritten by a memcpy for every new frame "
-                    "(the stand-in for sws_scale :603), snapshot semantics (submit returns after the DMA read "
-                    "it); decoder_frames = the source is re-pointed at one of 8 frames instead (no host copy); "
-                    "src_stable = the caller promises not to touch the source until the wait; staging_ring = "
-                    "pin_caller_buffers 0 (one host memcpy each way); loop_sync = the same loop with "
-                    "ntscsim_field_avframe() (= field_call from C++)"}
+            "depth32_decoder_frames": run_loop("--mode", "submit", "--depth", "32", "--alloc", "pinned", *big),
+            "depth32_bob": run_loop("--mode", "submit", "--depth", "32", "--bob", "1", "--alloc", "pinned", *big),
+            "depth128": run_loop("--mode", "submit", "--depth", "128", "--alloc", "pinned", *big),
+            "depth32_src_stable": run_loop("--mode", "submit", "--depth", "32", "--src-stable", "1", "--alloc", "pinned", *big),
+            "depth32_declared_pool": run_loop("--mode", "submit", "--depth", "32", "--rewrite-src", "1", "--alloc", "pool", *big),
+            "depth32_malloc_frames_staged": run_loop("--mode", "submit", "--depth", "32", "--rewrite-src", "1", "--alloc", "malloc", *big),
+            "depth32_malloc_frames_policy2": run_loop("--mode", "submit", "--depth", "32", "--rewrite-src", "1", "--alloc", "malloc", "--pin", "2", *big),
+            "note": "host/field_loop.cpp (ffmpeg_ntsc.cpp:2202-2282, :2229 replaced), 720x486 -vhs, consumed 4*depth fields behind; "
+                    "field_submit = frames from ntscsim_host_frame_alloc (the get_buffer helper), in.rgb rewritten per frame; "
+                    "declared_pool = ntscsim_host_pin; malloc_frames_staged = unpatched allocation, staging rings + copy threads"}
     # ---- the YUV422P tool's loop on host frames (ffmpeg_to_composite.cpp:1783-1800 with its four calls replaced by
     # one): host/field_loop422.cpp, synchronous and with iterations in flight
     floop422 = os.path.join(ROOT, "composite-video-simulator_amd", "field_loop422")
@@ -322,9 +318,9 @@ def extras(torch, ntscsim, dev, local_rank, args):
         import json as _json
         import subprocess
 
-        def run_loop422(*extra):
+        def run_loop422(*extra, best_of=1):
             best = None
-            for _ in range(2):
+            for _ in range(best_of):
                 pr = subprocess.run([floop422] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
                 try:
                     r = _json.loads(pr.stdout.decode().strip().splitlines()[-1])
@@ -334,31 +330,24 @@ def extras(torch, ntscsim, dev, local_rank, args):
                     best = r
             return best
         big = ["--fields", "6000", "--warmup", "600"]
-        sub422 = run_loop422("-vhs", "--mode", "submit", "--depth", "32", *big)
+        sub422 = run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--alloc", "pinned", *big, best_of=2)
         e2e["field_submit422"] = sub422.get("fields_per_s", 0.0)
         e2e["field_submit422_detail"] = {
             "loop_sync_fields_per_s": run_loop422("-vhs", "--mode", "sync", "--fields", "600", "--warmup", "100").get("fields_per_s"),
             "depth32_vhs": sub422,
-            "depth32_default_preset": run_loop422("--mode", "submit", "--depth", "32", *big),
-            "depth32_vhs_422_interlaced": run_loop422("-vhs", "-vi", "-422", "--mode", "submit", "--depth", "32", *big),
-            "depth64_vhs": run_loop422("-vhs", "--mode", "submit", "--depth", "64", *big),
-            "depth64_vhs_422": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "64", *big),
-            "depth32_vhs_heap_planes": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--mmap-threshold", "0", *big),
-            "depth32_vhs_page_frames": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
-            "depth32_vhs_422_page_frames": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "32", "--page-frames", "1", *big),
-            "tight_rows_704_one_at_a_time": run_loop422("-vhs", "-width", "704", "--mode", "submit", "--fields", "600", "--warmup", "100"),
-            "note": "host/field_loop422.cpp: the loop of ffmpeg_to_composite.cpp:1783-1800 (720x480, the tool's default "
-                    "geometry) on AVFrame-shaped pageable frames (linesize = width rounded up to 32, like "
-                    "av_frame_get_buffer) with render_field / black_key_feedback / composite_video_process / output_frame's "
-                    "copy replaced by ONE ntscsim_submit422_avframe() and the encoder frame consumed behind ntscsim_wait() "
-                    "2 * depth fields later; the input frame is rewritten by a memcpy per source frame (the stand-in for "
-                    "sws_scale :1770-1778).  The loop's first statement is mallopt(M_MMAP_THRESHOLD, 64 KiB) (INTEGRATION.md 5b): glibc then "
-                    "gives every frame plane a mapping of its own and the engine pins it in place (DMA uploads, delivery kernels); "
-                    "heap_planes = without it (--mmap-threshold 0): once the GPU runtime's start-up has raised glibc's dynamic "
-                    "threshold, 353 / 177 KiB planes are blocks inside the heap "
-                    "and go through the staging rings (one memcpy each way on the caller's thread); page_frames = every plane allocated by "
-                    "mmap (a get_buffer2 callback over page-aligned memory).  loop_sync = the same loop with ntscsim_field422_avframe(); tight rows "
-                    "(linesize == width) run one iteration at a time on a device mirror (include/ntscsim.h)"}
+            "depth32_default_preset": run_loop422("--mode", "submit", "--depth", "32", "--alloc", "pinned", *big),
+            "depth32_vhs_422_interlaced": run_loop422("-vhs", "-vi", "-422", "--mode", "submit", "--depth", "32", "--alloc", "pinned", *big),
+            "depth64_vhs": run_loop422("-vhs", "--mode", "submit", "--depth", "64", "--alloc", "pinned", *big),
+            "depth64_vhs_422": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "64", "--alloc", "pinned", *big),
+            "depth32_vhs_heap_planes": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--alloc", "malloc", *big),
+            "depth32_vhs_declared_pool": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--alloc", "pool", *big),
+            "depth32_vhs_page_frames": run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--alloc", "mmap", *big),
+            "depth32_vhs_422_pinned": run_loop422("-vhs", "-422", "--mode", "submit", "--depth", "32", "--alloc", "pinned", *big),
+            "tight_rows_704": run_loop422("-vhs", "-width", "704", "--mode", "submit", "--alloc", "pinned", *big),
+            "note": "host/field_loop422.cpp (ffmpeg_to_composite.cpp:1783-1800, four calls replaced by one), 720x480, consumed "
+                    "2*depth fields behind; field_submit422 = planes from ntscsim_host_frame_alloc (the get_buffer helper); "
+                    "heap_planes = unpatched posix_memalign planes, no mallopt: staging rings + copy threads; declared_pool = "
+                    "ntscsim_host_pin; tight_rows = linesize == width"}
     # ---- one process per GPU with the C++ host and rccl.h (host/rank_bench.cpp): here with the one rank this box has
     rb = os.path.join(ROOT, "composite-video-simulator_amd", "rank_bench")
     if os.path.exists(rb) and (w, h) == (720, 486):

@@ -92,6 +92,7 @@ struct Geometry {
 
 struct SubmitEngine;      // ntscsim_submit.hip (included at the end of this file)
 struct Host422Engine;     // ntscsim_host422.hip (likewise)
+struct PinCache;          // ntscsim_submit.hip: registrations of caller memory
 
 struct ntscsim_ctx {
     ntscsim_params prm;
@@ -168,7 +169,10 @@ struct ntscsim_ctx {
     int mode = NTSCSIM_MODE_EXACT;
     SubmitEngine *sub = nullptr;     // ntscsim_submit() / ntscsim_wait(): created on first use
     Host422Engine *h422 = nullptr;   // ntscsim_field422() / ntscsim_submit422(): created on first use
+    PinCache *declared = nullptr;    // ntscsim_host_pin(): memory the caller declared its own to pin
+    int pin_policy = 1;              // ntscsim_set_pin_policy()
 };
+static void declared_pins_destroy(ntscsim_ctx *c);
 static void submit_engine_destroy(ntscsim_ctx *c);
 static int sub_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
 static void host422_engine_destroy(ntscsim_ctx *c);
@@ -402,6 +406,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     (void)hipDeviceSynchronize();
     submit_engine_destroy(c);
     host422_engine_destroy(c);
+    declared_pins_destroy(c);
     for (Geometry *e : c->geoms) {
         e->lskip.release(); e->pskip.release(); e->jrow.release(); e->sstart.release(); e->jwarm.release();
         delete e;

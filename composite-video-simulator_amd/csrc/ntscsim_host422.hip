@@ -66,7 +66,9 @@ __global__ void k422_pad(const PadRec422 *__restrict__ recs)
 } // namespace
 
 struct Host422Engine {
-    int depth = 32, nslots = 128;
+    int depth = 32, nslots = 128;     // configured: iterations per launch, iterations that may be in flight
+    int ring_want = 0;                // the request the rings were sized for (ring may be smaller: the byte budget)
+    int ring = 0;                     // slots the rings were allocated with (<= nslots: lazily, and capped by a byte budget)
     // geometry of the rings
     int W = 0, H = 0, L = 0;
     int lsd[3] = {0, 0, 0};
@@ -115,8 +117,10 @@ struct Host422Engine {
         std::vector<Item> items;
         int rc = NTSCSIM_OK;
         bool launched_ok = false;
+        bool posted = false;              // staged results: handed to the copy threads (Delivery), id = `last`
     };
     std::deque<Batch> inflight;
+    Delivery dlv;                         // staging ring -> caller frames, off the caller's thread
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev_up = nullptr;
     uint64_t next_ticket = 1, done_ticket = 0;
@@ -134,8 +138,8 @@ static Host422Engine *h422_get(ntscsim_ctx *c)
     if (!c->h422) {
         c->h422 = new (std::nothrow) Host422Engine();
         if (c->h422) {
-            const char *ev = std::getenv("NTSCSIM_SUBMIT422_PIN");
-            c->h422->pins.enabled = !(ev && ev[0] == '0');
+            const char *ev = std::getenv("NTSCSIM_SUBMIT422_PIN");      // developer A/B: 0 / 1 / 2 = the pin policy
+            c->h422->pins.policy = (ev && ev[0] >= '0' && ev[0] <= '2') ? ev[0] - '0' : c->pin_policy;
             c->h422->pins.min_bytes = 64u << 10;        // (the floor of pin_lookup: a 4:2:0 chroma plane of 720x480 is 86 KiB)
         }
     }
@@ -144,9 +148,10 @@ static Host422Engine *h422_get(ntscsim_ctx *c)
 
 // all three planes of a caller frame pinned in place?  (`rows_c` chroma rows; one plane that cannot be pinned sends
 // the whole frame through the staging ring)
-static bool h422_pin_frame(Host422Engine *e, const ntscsim_frame422 &f, int W, int H, int rows_c, uint8_t *dev[3])
+static bool h422_pin_frame(ntscsim_ctx *c, Host422Engine *e, const ntscsim_frame422 &f, int W, int H, int rows_c, uint8_t *dev[3])
 {
     if (!f.data[0]) return false;
+    e->pins.declared = c->declared;
     for (int k = 0; k < 3; k++) {
         const size_t rb = k ? (size_t)W / 2 : (size_t)W, rows = k ? (size_t)rows_c : (size_t)H;
         dev[k] = pin_lookup(e->pins, f.data[k], (size_t)f.linesize[k] * (rows - 1) + rb);
@@ -165,7 +170,7 @@ static void h422_release_rings(Host422Engine *e)
     if (e->orec) (void)hipHostFree(e->orec);
     if (e->pads) (void)hipHostFree(e->pads);
     e->hsrc = e->hdn = e->pads = nullptr; e->prec = nullptr; e->crec = nullptr; e->orec = nullptr;
-    e->W = e->H = 0; e->sbytes = 0;
+    e->W = e->H = 0; e->sbytes = 0; e->ring = 0; e->ring_want = 0;
     e->src_cur = -1;
     e->src_last_ticket.clear();
 }
@@ -176,6 +181,7 @@ static void host422_engine_destroy(ntscsim_ctx *c)
     if (!e) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    e->dlv.stop();
     for (auto &b : e->inflight) if (b.done) (void)hipEventDestroy(b.done);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto *m : e->mirrors) { m->dev.release(); delete m; }
@@ -191,15 +197,31 @@ static void host422_engine_destroy(ntscsim_ctx *c)
 
 static size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
-// rings for this geometry; `src_need` = bytes of the largest source frame seen so far
-static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, size_t src_need)
+// bytes the rings may take, device and pinned host each (NTSCSIM_SUBMIT422_RING_MB overrides the default of 8 GiB)
+static size_t h422_ring_budget()
 {
-    if (e->W == W && e->H == H && e->sbytes >= src_need) return NTSCSIM_OK;
+    static const size_t b = [] {
+        const char *ev = std::getenv("NTSCSIM_SUBMIT422_RING_MB");
+        const long long mb = ev ? std::atoll(ev) : 0;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)8 << 30;
+    }();
+    return b;
+}
+
+// rings for this geometry; `src_need` = bytes of the largest source frame seen so far; `want` = slots the caller
+// needs (the synchronous call: 2; a submit: the configured `nslots`).  The rings grow lazily -- a tool that only ever
+// calls ntscsim_field422() never pays for 128 slots -- and never past the byte budget: a geometry of which not even
+// two slots fit is refused with NTSCSIM_E_SIZE, a large one runs with fewer iterations in flight.
+static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, size_t src_need, int want)
+{
+    if (want > e->nslots) want = e->nslots;
+    if (e->W == W && e->H == H && e->sbytes >= src_need && e->ring > 0 && e->ring_want >= want) return NTSCSIM_OK;
     int rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
     if (rc != NTSCSIM_OK) return rc;
     const size_t keep_src = e->sbytes > src_need ? e->sbytes : src_need;
+    if (e->W == W && e->H == H && e->ring_want > want) want = e->ring_want;     // (a larger source keeps the slots it had)
     h422_release_rings(e);
-    const int ns = e->nslots, L = (H + 1) / 2, W2 = W / 2;
+    const int L = (H + 1) / 2, W2 = W / 2;
     e->lsd[0] = (W + 16 + 63) / 64 * 64;
     e->lsd[1] = e->lsd[2] = (W2 + 8 + 31) / 32 * 32;
     e->foff[0] = 0;
@@ -215,6 +237,15 @@ static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, siz
     e->dn_flt = e->dn_out + up256((size_t)H * W + 2 * (size_t)(H + 1) * W2);
     e->dbytes = e->dn_flt + up256((size_t)L * W * 2);
     e->sbytes = up256(keep_src);
+    int ns = want;
+    {
+        const size_t per_dev = e->fbytes + e->sbytes + e->dbytes, per_host = e->sbytes + e->dbytes + (size_t)2 * L;
+        const size_t per = per_dev > per_host ? per_dev : per_host;
+        const size_t fit = h422_ring_budget() / per;
+        if (fit < 2) { c->err = "ntscsim_submit422: two ring slots of this geometry exceed the ring budget"; e->ring = 0; return NTSCSIM_E_SIZE; }
+        if ((size_t)ns > fit) ns = (int)fit;
+    }
+    e->ring = 0;
     HIPCHK(c, e->dfrm.ensure(e->fbytes * (size_t)ns));
     HIPCHK(c, e->dsrc.ensure(e->sbytes * (size_t)ns));
     HIPCHK(c, e->ddn.ensure(e->dbytes * (size_t)ns));
@@ -231,7 +262,7 @@ static int h422_ensure_rings(ntscsim_ctx *c, Host422Engine *e, int W, int H, siz
     if (!e->s_dn) HIPCHK(c, hipStreamCreateWithFlags(&e->s_dn, hipStreamNonBlocking));
     if (!e->ev_up) HIPCHK(c, hipEventCreateWithFlags(&e->ev_up, hipEventDisableTiming));
     if (!e->ev_k) HIPCHK(c, hipEventCreateWithFlags(&e->ev_k, hipEventDisableTiming));
-    e->W = W; e->H = H; e->L = L;
+    e->W = W; e->H = H; e->L = L; e->ring = ns; e->ring_want = want;
     e->src_last_ticket.assign((size_t)ns, 0);
     e->src_ring_pos = 0;
     e->src_cur = -1;
@@ -248,7 +279,9 @@ static int h422_out_chroma_rows(int H, uint32_t mode) { return (mode == NTSCSIM_
 static int h422_out_chroma_alloc(int H, uint32_t mode) { return h422_out_chroma_rows(H, mode) + 1; }
 static size_t h422_out_bytes(int W, int H, uint32_t mode) { return (size_t)W * H + 2 * (size_t)(W / 2) * (size_t)h422_out_chroma_alloc(H, mode); }
 
-static Host422Engine::Mirror *h422_mirror(ntscsim_ctx *c, Host422Engine *e, const ntscsim_frame422 &f, int H)
+// (`keep`: a mirror the caller already holds for the same iteration -- it survives the eviction below)
+static Host422Engine::Mirror *h422_mirror(ntscsim_ctx *c, Host422Engine *e, const ntscsim_frame422 &f, int H,
+                                          Host422Engine::Mirror *keep = nullptr)
 {
     for (auto *m : e->mirrors)
         if (m->host[0] == f.data[0] && m->host[1] == f.data[1] && m->host[2] == f.data[2] && m->ls[0] == f.linesize[0] &&
@@ -256,8 +289,9 @@ static Host422Engine::Mirror *h422_mirror(ntscsim_ctx *c, Host422Engine *e, cons
     if (e->mirrors.size() >= 64) {           // (a tool has one frame and one filter frame; keep the table bounded)
         if (h422_wait_ticket(c, NTSCSIM_TICKET_ALL) != NTSCSIM_OK) return nullptr;
         (void)hipStreamSynchronize(c->stream);
-        for (auto *m : e->mirrors) { m->dev.release(); delete m; }
+        for (auto *m : e->mirrors) if (m != keep) { m->dev.release(); delete m; }
         e->mirrors.clear();
+        if (keep) e->mirrors.push_back(keep);
     }
     auto *m = new (std::nothrow) Host422Engine::Mirror();
     if (!m) return nullptr;
@@ -300,42 +334,50 @@ static int h422_refresh_mirror(ntscsim_ctx *c, Host422Engine *e, Host422Engine::
     return NTSCSIM_OK;
 }
 
+// what the copy threads do for one launch: the staged results of its iterations, staging record -> caller planes
+static void h422_delivery_ops(const Host422Engine *e, const Host422Engine::Batch &b, std::vector<CopyOp> &ops)
+{
+    const int W = e->W, H = e->H, W2 = W / 2;
+    for (const auto &it : b.items) {
+        const uint8_t *st = e->hdn + e->dbytes * (size_t)it.slot;
+        const int n = h422_field_rows(H, it.it.field);
+        auto rows_out = [&](const ntscsim_frame422 &f, const uint8_t *s) {
+            for (int k = 0; k < 3; k++) {
+                const size_t rb = k ? (size_t)W2 : (size_t)W;
+                if (n > 0) ops.push_back({f.data[k] + (size_t)f.linesize[k] * it.it.field, s, 2 * (size_t)f.linesize[k], rb, rb, n});
+                s += rb * (size_t)n;
+            }
+        };
+        if (it.frm_how == 0) rows_out(it.it.frame, st + e->dn_frm);
+        if (it.serial && it.mflt && it.flt_how == 0) rows_out(it.it.filter, st + e->dn_flt);
+        if (it.it.out.data[0] && it.out_how == 0) {
+            const uint8_t *s = st + e->dn_out;
+            const int ch = h422_out_chroma_rows(H, it.it.out_mode);
+            for (int k = 0; k < 3; k++) {
+                const size_t rb = k ? (size_t)W2 : (size_t)W;
+                const int nr = k ? ch : H;
+                // (luma in two halves: the ops of a launch are the unit the copy threads share out)
+                if (k == 0 && nr >= 64) {
+                    const int h0 = nr / 2;
+                    ops.push_back({it.it.out.data[0], s, (size_t)it.it.out.linesize[0], rb, rb, h0});
+                    ops.push_back({it.it.out.data[0] + (size_t)it.it.out.linesize[0] * h0, s + rb * (size_t)h0, (size_t)it.it.out.linesize[0], rb, rb, nr - h0});
+                } else
+                    ops.push_back({it.it.out.data[k], s, (size_t)it.it.out.linesize[k], rb, rb, nr});
+                s += rb * (size_t)(k ? h422_out_chroma_alloc(H, it.it.out_mode) : H);
+            }
+        }
+    }
+}
+
 static int h422_retire_front(ntscsim_ctx *c, Host422Engine *e)
 {
     Host422Engine::Batch &b = e->inflight.front();
     int rc = b.rc;
     if (b.launched_ok) {
-        const hipError_t er = hipEventSynchronize(b.done);
-        if (er != hipSuccess) { c->err = std::string("hipEventSynchronize: ") + hipGetErrorString(er); rc = NTSCSIM_E_HIP; }
-        else {
-            const int W = e->W, H = e->H, W2 = W / 2;
-            for (const auto &it : b.items) {
-                const uint8_t *st = e->hdn + e->dbytes * (size_t)it.slot;
-                const int n = h422_field_rows(H, it.it.field);
-                auto rows_out = [&](const ntscsim_frame422 &f, const uint8_t *s) {
-                    for (int k = 0; k < 3; k++) {
-                        const size_t rb = k ? (size_t)W2 : (size_t)W;
-                        for (int r = 0; r < n; r++)
-                            std::memcpy(f.data[k] + (size_t)f.linesize[k] * (size_t)(it.it.field + 2 * r), s + rb * (size_t)r, rb);
-                        s += rb * (size_t)n;
-                    }
-                };
-                if (it.frm_how == 0) rows_out(it.it.frame, st + e->dn_frm);
-                if (it.serial && it.mflt && it.flt_how == 0) rows_out(it.it.filter, st + e->dn_flt);
-                if (it.it.out.data[0] && it.out_how == 0) {
-                    const uint8_t *s = st + e->dn_out;
-                    const int ch = h422_out_chroma_rows(H, it.it.out_mode);
-                    for (int k = 0; k < 3; k++) {
-                        const size_t rb = k ? (size_t)W2 : (size_t)W;
-                        const int nr = k ? ch : H;
-                        if ((size_t)it.it.out.linesize[k] == rb) std::memcpy(it.it.out.data[k], s, rb * (size_t)nr);
-                        else for (int r = 0; r < nr; r++)
-                            std::memcpy(it.it.out.data[k] + (size_t)it.it.out.linesize[k] * (size_t)r, s + rb * (size_t)r, rb);
-                        s += rb * (size_t)(k ? h422_out_chroma_alloc(H, it.it.out_mode) : H);
-                    }
-                }
-            }
-        }
+        bool ok;
+        if (b.posted) ok = e->dlv.wait(b.last);          // (the copy threads synchronised on the event)
+        else ok = hipEventSynchronize(b.done) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); c->err = "submit422: a launch failed on the device (hipEventSynchronize)"; rc = NTSCSIM_E_HIP; }
     }
     e->done_ticket = b.last;
     if (b.done) e->ev_pool.push_back(b.done);
@@ -401,9 +443,10 @@ static int h422_launch(ntscsim_ctx *c)
         Host422Engine::Item &a = b.items[(size_t)i];
         for (int j = i + 1; j < n; j++) {
             const Host422Engine::Item &z = b.items[(size_t)j];
-            if (a.frm_how == 1 && z.frm_dev[0] && z.it.frame.data[0] == a.it.frame.data[0] && z.it.field == a.it.field) a.frm_how = 2;
-            if (a.flt_how == 1 && z.flt_dev[0] && z.it.filter.data[0] == a.it.filter.data[0] && z.it.field == a.it.field) a.flt_how = 2;
-            if (a.out_how == 1 && z.out_dev[0] && z.it.out.data[0] == a.it.out.data[0]) a.out_how = 2;
+            // (pinned or staged alike: a frame is one or the other as a whole)
+            if (a.frm_how != 2 && z.it.frame.data[0] == a.it.frame.data[0] && z.it.field == a.it.field) a.frm_how = 2;
+            if (a.flt_how != 2 && a.it.filter.data[0] && z.it.filter.data[0] == a.it.filter.data[0] && z.it.field == a.it.field) a.flt_how = 2;
+            if (a.out_how != 2 && a.it.out.data[0] && z.it.out.data[0] == a.it.out.data[0]) a.out_how = 2;
         }
     }
     for (int i = 0; i < n; i++) {
@@ -496,7 +539,7 @@ static int h422_launch(ntscsim_ctx *c)
     }
     // slot runs: tickets are consecutive, slots = ticket mod nslots -> at most two runs
     const int s0 = b.items.front().slot;
-    const int run0 = s0 + n <= e->nslots ? n : e->nslots - s0;
+    const int run0 = s0 + n <= e->ring ? n : e->ring - s0;
     if (any_pad) {
         hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, st, e->prec + s0);
         if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, st, e->prec);
@@ -537,6 +580,12 @@ static int h422_launch(ntscsim_ctx *c)
     if (er != hipSuccess) { c->err = std::string("submit422 D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;
     e->stats[1]++;
+    if (any_staged) {
+        std::vector<CopyOp> ops;
+        h422_delivery_ops(e, b, ops);
+        e->dlv.post(c->device, b.done, std::move(ops), b.last);
+        b.posted = true;
+    }
     return finish(NTSCSIM_OK);
 }
 
@@ -572,7 +621,7 @@ static int h422_validate(const ntscsim_ctx *c, const ntscsim_loop422 *L)
     return NTSCSIM_OK;
 }
 
-extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags, uint64_t *ticket)
+static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags, uint64_t *ticket, bool sync_call)
 {
     int rc = h422_validate(c, L);
     if (rc != NTSCSIM_OK) return rc;
@@ -585,7 +634,7 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
     const bool c420 = (L->flags & NTSCSIM_422_SRC420) != 0;
     const size_t src_crows = c420 ? ((size_t)L->src_height + 1) / 2 : (size_t)L->src_height;
     const size_t src_bytes = have_src ? (size_t)W * L->src_height + 2 * (size_t)W2 * src_crows : 0;
-    rc = h422_ensure_rings(c, e, W, H, src_bytes);
+    rc = h422_ensure_rings(c, e, W, H, src_bytes, sync_call ? 2 : e->nslots);
     if (rc != NTSCSIM_OK) return rc;
 
     if (flags & NTSCSIM_SUBMIT422_DIRTY) {
@@ -597,15 +646,15 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
     }
     // ring space: ticket t uses slot t mod nslots; its previous user and that one's pair partner must have retired
     const uint64_t t = e->next_ticket;
-    if (t + 1 > (uint64_t)e->nslots && e->done_ticket < t + 1 - (uint64_t)e->nslots) {
+    if (t + 1 > (uint64_t)e->ring && e->done_ticket < t + 1 - (uint64_t)e->ring) {
         e->stats[7]++;
-        rc = h422_wait_ticket(c, t + 1 - (uint64_t)e->nslots);
+        rc = h422_wait_ticket(c, t + 1 - (uint64_t)e->ring);
         if (rc != NTSCSIM_OK) return rc;
     }
     const bool bkey = c->prm.black_key_level_feedback >= 0 && L->filter.data[0] != nullptr;
     // ---- FAST or SERIAL (see the head of this file)
     bool serial = !have_src || bkey || L->frame.linesize[0] < W + 2;
-    int fslot = (int)(t % (uint64_t)e->nslots);
+    int fslot = (int)(t % (uint64_t)e->ring);
     bool paired = false;
     if (!serial && !e->pending.empty()) {
         const Host422Engine::Item &pv = e->pending.back();
@@ -624,14 +673,14 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
 
     Host422Engine::Item it;
     it.ticket = t;
-    it.slot = (int)(t % (uint64_t)e->nslots);
+    it.slot = (int)(t % (uint64_t)e->ring);
     it.fslot = fslot;
     it.serial = serial;
     it.it = *L;
     // pinned caller frames: results are written in place by the delivery kernels
-    (void)h422_pin_frame(e, L->frame, W, H, H, it.frm_dev);
-    if (bkey) (void)h422_pin_frame(e, L->filter, W, H, H, it.flt_dev);
-    if (L->out.data[0]) (void)h422_pin_frame(e, L->out, W, H, h422_out_chroma_rows(H, L->out_mode), it.out_dev);
+    (void)h422_pin_frame(c, e, L->frame, W, H, H, it.frm_dev);
+    if (bkey) (void)h422_pin_frame(c, e, L->filter, W, H, H, it.flt_dev);
+    if (L->out.data[0]) (void)h422_pin_frame(c, e, L->out, W, H, h422_out_chroma_rows(H, L->out_mode), it.out_dev);
     if (serial) {
         // in order, alone: what is pending goes first
         rc = h422_launch(c);
@@ -641,7 +690,7 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
         rc = h422_refresh_mirror(c, e, it.mfrm, W);
         if (rc != NTSCSIM_OK) return rc;
         if (bkey) {
-            it.mflt = h422_mirror(c, e, L->filter, H);
+            it.mflt = h422_mirror(c, e, L->filter, H, it.mfrm);
             if (!it.mflt) return NTSCSIM_E_NOMEM;
             rc = h422_refresh_mirror(c, e, it.mflt, W);
             if (rc != NTSCSIM_OK) return rc;
@@ -661,7 +710,7 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
     if (have_src) {
         int sslot = e->src_cur;
         if (!(flags & NTSCSIM_SUBMIT_SAME_SRC) || sslot < 0) {
-            sslot = (int)(e->src_ring_pos % (uint64_t)e->nslots);
+            sslot = (int)(e->src_ring_pos % (uint64_t)e->ring);
             const uint64_t last = e->src_last_ticket[(size_t)sslot];
             if (last > e->done_ticket) {
                 rc = h422_wait_ticket(c, last);
@@ -673,7 +722,7 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
             // pinned caller planes, which the call then has to WAIT for (three plane copies + a stream synchronisation:
             // 46-50 us measured, and the engine's launches are no faster for it: profiles/r05_host422_loop_probe.txt)
             static const bool src_dma = std::getenv("NTSCSIM_SUBMIT422_SRCDMA") && std::getenv("NTSCSIM_SUBMIT422_SRCDMA")[0] == '1';
-            if (src_dma && h422_pin_frame(e, L->src, W, L->src_height, (int)src_crows, sdev)) {
+            if (src_dma && h422_pin_frame(c, e, L->src, W, L->src_height, (int)src_crows, sdev)) {
                 uint8_t *o = e->dsrc.p + e->sbytes * (size_t)sslot;
                 for (int k = 0; k < 3; k++) {
                     const size_t rb = k ? (size_t)W2 : (size_t)W, nr = k ? src_crows : (size_t)L->src_height;
@@ -712,15 +761,22 @@ extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint3
     if (serial) return h422_launch(c);
     // a launch at `depth` iterations -- but not between the two fields of a pair (the second one shares the first
     // one's device frame while that is still pending)
+    // (rings smaller than configured -- the byte budget -- hold fewer iterations: a launch and its successor must fit)
     const size_t np = e->pending.size();
-    if ((int)np >= e->depth && (L->field == 0 || (int)np > e->depth)) return h422_launch(c);
+    const int depth = e->depth <= (e->ring - 2) / 2 ? e->depth : ((e->ring - 2) / 2 > 0 ? (e->ring - 2) / 2 : 1);
+    if ((int)np >= depth && (L->field == 0 || (int)np > depth)) return h422_launch(c);
     return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_submit422(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags, uint64_t *ticket)
+{
+    return h422_submit(c, L, flags, ticket, false);
 }
 
 extern "C" int ntscsim_field422(ntscsim_ctx *c, const ntscsim_loop422 *L)
 {
     uint64_t t = 0;
-    int rc = ntscsim_submit422(c, L, 0, &t);
+    int rc = h422_submit(c, L, 0, &t, true);
     if (rc != NTSCSIM_OK) return rc;
     return h422_wait_ticket(c, t);
 }
@@ -759,4 +815,16 @@ static int h422_host_unpin(ntscsim_ctx *c, const void *base)
     else (void)pin_release(e->pins, base);
     e->src_cur = -1;
     return rc;
+}
+
+static bool h422_pins_overlap(ntscsim_ctx *c, uintptr_t p0, uintptr_t p1)
+{
+    if (!c->h422) return false;
+    for (auto &r : c->h422->pins.regs) if (p0 < r.p1 && r.p0 < p1) return true;
+    return false;
+}
+
+static void h422_set_pin_policy(ntscsim_ctx *c, int policy)
+{
+    if (c->h422) c->h422->pins.policy = policy;
 }

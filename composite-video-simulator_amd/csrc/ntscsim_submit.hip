@@ -16,7 +16,11 @@
 // Lanes exist because a launch of 32 fields is ~125 wavefronts on a chip with 2,048 slots and takes the same
 // ~0.5 ms as one of 600: three launches side by side hide that latency.  Fields carry explicit rand()
 // positions, so it does not matter which lane runs which launch.
+#include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
+#include <thread>
 #include <unistd.h>
 
 namespace {
@@ -56,12 +60,140 @@ __global__ void k_deliver(const DeliverRec *__restrict__ recs, int row_bytes, in
 
 } // namespace
 
+// ---- delivery of STAGED results (frames that are not pinned): the rows travel device -> pinned staging ring by DMA and
+// from there into the caller's frames by memcpy.  That memcpy used to run on the caller's thread inside ntscsim_wait()
+// (1.1 MB per 720x480 4:2:2 iteration: the whole budget of a 30k fields/s loop); it now runs on threads of the engine as
+// soon as the launch's event has fired, i.e. usually long before the caller asks.  One lead thread takes the launches in
+// order (hipEventSynchronize, then the copies, split over itself and `helpers` more threads); ntscsim_wait() only waits
+// for the launch's id.  Copies of one launch never overlap each other (the engines drop all but the last writer of a
+// row at launch time), launches are delivered one after the other: the caller's frames end up as the in-order loop
+// leaves them.
+struct CopyOp { uint8_t *dst; const uint8_t *src; size_t dstep, sstep, rb; int rows; };
+
+class Delivery {
+public:
+    ~Delivery() { stop(); }
+    // everything posted before is delivered in post order; `done` must have been recorded
+    void post(int device, hipEvent_t done, std::vector<CopyOp> &&ops, uint64_t id)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (!started_) start(device);
+        q_.push_back(Job{done, std::move(ops), id});
+        posted_ = id;
+        cv_.notify_all();
+    }
+    // true once launch `id` is in the caller's frames; false: its event failed (the rows are lost)
+    bool wait(uint64_t id)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return delivered_ >= id; });
+        return failed_.empty() || std::find(failed_.begin(), failed_.end(), id) == failed_.end();
+    }
+    void drain() { std::unique_lock<std::mutex> lk(m_); cv_done_.wait(lk, [&] { return delivered_ >= posted_; }); }
+    void stop()
+    {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            if (!started_) return;
+            cv_done_.wait(lk, [&] { return delivered_ >= posted_; });
+            quit_ = true;
+            cv_.notify_all();
+        }
+        for (auto &t : threads_) t.join();
+        threads_.clear();
+        started_ = false; quit_ = false;
+    }
+
+private:
+    struct Job { hipEvent_t done; std::vector<CopyOp> ops; uint64_t id; };
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    std::deque<Job> q_;
+    std::vector<std::thread> threads_;
+    std::vector<uint64_t> failed_;
+    uint64_t posted_ = 0, delivered_ = 0;
+    bool started_ = false, quit_ = false;
+    // the launch being copied: helpers pull ops by index
+    const std::vector<CopyOp> *cur_ = nullptr;
+    std::atomic<size_t> next_{0};
+    uint64_t gen_ = 0;
+    int busy_ = 0;
+
+    static void run_op(const CopyOp &o)
+    {
+        if (o.dstep == o.rb && o.sstep == o.rb) { std::memcpy(o.dst, o.src, o.rb * (size_t)o.rows); return; }
+        for (int r = 0; r < o.rows; r++) std::memcpy(o.dst + o.dstep * (size_t)r, o.src + o.sstep * (size_t)r, o.rb);
+    }
+    void pull()
+    {
+        const std::vector<CopyOp> &ops = *cur_;
+        for (size_t i = next_.fetch_add(1); i < ops.size(); i = next_.fetch_add(1)) run_op(ops[i]);
+    }
+    void helper()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return quit_ || (cur_ && gen_ != seen); });
+            if (quit_) return;
+            seen = gen_;
+            lk.unlock();
+            pull();
+            lk.lock();
+            if (--busy_ == 0) cv_done_.notify_all();
+        }
+    }
+    void lead(int device)
+    {
+        (void)hipSetDevice(device);
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [&] { return quit_ || !q_.empty(); });
+            if (q_.empty()) return;          // quit_ and nothing left
+            Job j = std::move(q_.front());
+            q_.pop_front();
+            lk.unlock();
+            const bool ok = hipEventSynchronize(j.done) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            lk.lock();
+            if (ok && !j.ops.empty()) {
+                cur_ = &j.ops; next_.store(0); gen_++;
+                busy_ = (int)threads_.size() - 1;
+                cv_.notify_all();
+                lk.unlock();
+                pull();
+                lk.lock();
+                cv_done_.wait(lk, [&] { return busy_ == 0; });
+                cur_ = nullptr;
+            }
+            if (!ok) failed_.push_back(j.id);
+            delivered_ = j.id;
+            cv_done_.notify_all();
+        }
+    }
+    void start(int device)          // m_ held
+    {
+        const char *ev = std::getenv("NTSCSIM_COPY_THREADS");
+        int n = ev ? std::atoi(ev) : 4;
+        if (n < 1) n = 1;
+        if (n > 16) n = 16;
+        threads_.emplace_back([this, device] { lead(device); });
+        for (int i = 1; i < n; i++) threads_.emplace_back([this] { helper(); });
+        started_ = true;
+    }
+};
+
 // registrations of caller memory (hipHostRegister in place), cached: a tool recycles a handful of frame buffers
+// policy: 0 = never (everything is staged); 1 (default) = memory that IS pinned already -- declared with
+// ntscsim_host_pin(), allocated with ntscsim_host_alloc() / hipHostMalloc, registered by the caller -- plus buffers
+// that start on a page boundary; 2 = additionally blocks that carry glibc's header of a chunk with a mapping of its
+// own (a peek at the allocator's internals: opt-in, glibc only)
 struct PinCache {
     struct Reg { uintptr_t p0, p1; uint8_t *dev; bool owned; };
     std::vector<Reg> regs;
-    bool enabled = true;
+    int policy = 1;
     size_t min_bytes = 256u << 10;
+    const PinCache *declared = nullptr;      // the ctx's explicit registrations (ntscsim_host_pin)
 };
 static void pin_release_all(PinCache &pc)      // everything that uses the registrations must have completed
 {
@@ -80,6 +212,14 @@ static bool pin_release(PinCache &pc, const void *base)
             return true;
         }
     return false;
+}
+
+static void declared_pins_destroy(ntscsim_ctx *c)
+{
+    if (!c->declared) return;
+    pin_release_all(*c->declared);
+    delete c->declared;
+    c->declared = nullptr;
 }
 
 struct SubmitEngine {
@@ -119,8 +259,10 @@ struct SubmitEngine {
         std::vector<Item> items;
         int rc = NTSCSIM_OK;
         bool launched_ok = false;
+        bool posted = false;              // staged fields: handed to the copy threads (Delivery), id = `last`
     };
     std::deque<Batch> inflight;
+    Delivery dlv;                         // staging ring -> caller frames, off the caller's thread
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     uint64_t next_ticket = 1;         // next to issue
     uint64_t done_ticket = 0;         // everything <= this has been delivered
@@ -154,7 +296,7 @@ static SubmitEngine *sub_get(ntscsim_ctx *c)
 {
     if (!c->sub) {
         c->sub = new (std::nothrow) SubmitEngine();
-        if (c->sub) ntscsim_submit_opts_init(&c->sub->o);
+        if (c->sub) { ntscsim_submit_opts_init(&c->sub->o); c->sub->o.pin_caller_buffers = c->pin_policy; }
     }
     return c->sub;
 }
@@ -180,6 +322,7 @@ static void submit_engine_destroy(ntscsim_ctx *c)
     if (!e) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    e->dlv.stop();
     for (auto &b : e->inflight) { if (b.up) (void)hipEventDestroy(b.up); if (b.done) (void)hipEventDestroy(b.done); }
     for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (ntscsim_ctx *l : e->lanes) ntscsim_destroy(l);
@@ -241,89 +384,195 @@ static int sub_ensure_staging(ntscsim_ctx *c, SubmitEngine *e, bool src)
 }
 
 // Device-visible address of caller memory [p, p+span), pinning it in place on first sight.  NULL = not pinned
-// (too small, shares a page with another registration, registration refused): the staging ring is used.
+// (policy, too small, shares a page with another registration, registration refused): the staging ring is used.
 static uint8_t *pin_lookup(PinCache &pc, const void *p, size_t span)
 {
-    if (!pc.enabled || span < pc.min_bytes) return nullptr;
+    if (pc.policy <= 0 || span == 0) return nullptr;
     const uintptr_t a0 = (uintptr_t)p, a1 = a0 + span;
-    // Registration is page-wise, so the frame's first and last page get pinned whole.  That is only harmless when
-    // nothing else lives in them: a foreign heap block that starts in a pinned page and runs on into pageable memory
-    // can no longer be the source of a hipMemcpy.  Frames from av_frame_get_buffer / posix_memalign / a large malloc
-    // are mmap'ed chunks of their own -- page-aligned plus the allocator's header and alignment padding, their tail
-    // page theirs as well; a frame that starts deeper than 128 bytes into a page is a block inside a shared heap and
-    // goes through the staging ring instead.
-    if ((a0 & 4095u) > 128u) return nullptr;
-    // ... and never memory of the brk heap, whatever it looks like: the allocator trims and recycles those pages under a
-    // registration (seen as aborts inside later, unrelated hipMemcpy calls once such a registration had been dropped and
-    // the pages reused).  Blocks with a mapping of their own (what malloc / posix_memalign hand out for frame-sized
-    // requests unless the process has raised the mmap threshold) live far above the program break.
-    if (span < (64u << 10) || a0 < (uintptr_t)sbrk(0)) return nullptr;
+    // (1) declared by the caller, or seen before
+    if (pc.declared)
+        for (auto &r : pc.declared->regs)
+            if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
     for (auto &r : pc.regs)
         if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
-    // ... nor a block inside one of glibc's non-main arenas or a pool of the caller's (they sit above the break too and
-    // can start near a page boundary by chance): a block that does not start ON a page boundary must carry the header
-    // of a chunk with a mapping of its own -- glibc keeps IS_MMAPPED (bit 1) in the size word in front of the pointer
-    // malloc / posix_memalign returned, for aligned blocks as well.  (Page-aligned buffers own their first page by
-    // construction.)  Anything that fails the test is staged, which is always safe.
-    if ((a0 & 4095u) >= sizeof(size_t)) {
+    if (pc.regs.size() >= 1024) return nullptr;
+    // (2) pinned already -- ntscsim_host_alloc() / hipHostMalloc / the caller's own hipHostRegister: the runtime knows, no
+    // guess about who owns the pages is needed.  First and last byte must belong to one registration (same offset).
+    {
+        hipPointerAttribute_t at0, at1;
+        const bool ok0 = hipPointerGetAttributes(&at0, (const void *)a0) == hipSuccess && at0.type == hipMemoryTypeHost && at0.devicePointer;
+        if (!ok0) (void)hipGetLastError();
+        else {
+            const bool ok1 = hipPointerGetAttributes(&at1, (const void *)(a1 - 1)) == hipSuccess && at1.type == hipMemoryTypeHost &&
+                             at1.devicePointer == (void *)((uint8_t *)at0.devicePointer + (span - 1));
+            if (!ok1) { (void)hipGetLastError(); return nullptr; }      // pinned in part: leave it alone, stage
+            pc.regs.push_back({a0, a1, (uint8_t *)at0.devicePointer, false});
+            return (uint8_t *)at0.devicePointer;
+        }
+    }
+    if (span < pc.min_bytes) return nullptr;
+    // (3) pin in place.  Registration is page-wise, so the buffer's first and last page get pinned whole.  That is only
+    // harmless when nothing else lives in them: a foreign heap block that starts in a pinned page and runs on into
+    // pageable memory can no longer be the source of a hipMemcpy.  Never memory of the brk heap (the allocator trims
+    // and recycles those pages under a registration), never small blocks.
+    if (span < (64u << 10) || a0 < (uintptr_t)sbrk(0)) return nullptr;
+    if (a0 & 4095u) {
+        // not on a page boundary: policy 1 stages it.  Policy 2 accepts a block that starts within the allocator's
+        // header + alignment padding of a page AND carries glibc's IS_MMAPPED bit (bit 1 of the size word in front
+        // of the pointer malloc / posix_memalign returned) with a chunk size that covers the span -- an allocation
+        // with a mapping of its own, whose edge pages are its own.
+#if defined(__GLIBC__)
+        if (pc.policy < 2 || (a0 & 4095u) > 128u) return nullptr;
         size_t hdr;
         std::memcpy(&hdr, (const void *)(a0 - sizeof(size_t)), sizeof(hdr));
-        if (!(hdr & 2u)) return nullptr;
-    } else if (a0 & 4095u) return nullptr;
+        if (!(hdr & 2u) || (hdr & ~(size_t)7) < span) return nullptr;
+#else
+        return nullptr;
+#endif
+    }
     const uintptr_t PG = 4096;
     const uintptr_t p0 = a0 & ~(PG - 1), p1 = (a1 + PG - 1) & ~(PG - 1);
     for (auto &r : pc.regs)
         if (p0 < r.p1 && r.p0 < p1) return nullptr;          // partial overlap with a live registration
-    if (pc.regs.size() >= 1024) return nullptr;
+    if (pc.declared)
+        for (auto &r : pc.declared->regs)
+            if (p0 < r.p1 && r.p0 < p1) return nullptr;
     hipError_t er = hipHostRegister((void *)p0, p1 - p0, hipHostRegisterDefault);
-    bool owned = true;
-    if (er == hipErrorHostMemoryAlreadyRegistered) { owned = false; er = hipSuccess; }   // pinned by the caller
     (void)hipGetLastError();
     if (er != hipSuccess) return nullptr;
     void *dev = nullptr;
     if (hipHostGetDevicePointer(&dev, (void *)p0, 0) != hipSuccess || !dev) {
         (void)hipGetLastError();
-        if (owned) (void)hipHostUnregister((void *)p0);
+        (void)hipHostUnregister((void *)p0);
         return nullptr;
     }
-    if (!owned) {
-        // pinned by the caller: trust it only if its registration is seen to cover the frame's last page as well, at the
-        // same offset
-        void *dev_last = nullptr;
-        if (hipHostGetDevicePointer(&dev_last, (void *)(p1 - PG), 0) != hipSuccess || dev_last != (uint8_t *)dev + (p1 - PG - p0)) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-    }
-    pc.regs.push_back({p0, p1, (uint8_t *)dev, owned});
+    pc.regs.push_back({p0, p1, (uint8_t *)dev, true});
     return (uint8_t *)dev + (a0 - p0);
 }
 
 static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_t span)
 {
-    (void)c;
-    e->pins.enabled = e->o.pin_caller_buffers != 0;
+    e->pins.policy = e->o.pin_caller_buffers < 0 ? 0 : (e->o.pin_caller_buffers > 2 ? 2 : e->o.pin_caller_buffers);
     e->pins.min_bytes = e->o.min_pin_bytes;
+    e->pins.declared = c->declared;
     uint8_t *d = pin_lookup(e->pins, p, span);
     e->stats[6] = e->pins.regs.size();
     return d;
 }
 
 static int h422_host_unpin(ntscsim_ctx *c, const void *base);      // ntscsim_host422.hip
+static bool h422_pins_overlap(ntscsim_ctx *c, uintptr_t p0, uintptr_t p1);
+static void h422_set_pin_policy(ntscsim_ctx *c, int policy);
 extern "C" int ntscsim_host_unpin(ntscsim_ctx *c, const void *base)
 {
     if (!c) return NTSCSIM_E_ARG;
-    if (c->h422) { const int r = h422_host_unpin(c, base); if (r != NTSCSIM_OK || !c->sub) return r; }
-    SubmitEngine *e = c->sub;
-    if (!e) return NTSCSIM_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
-    HIPCHK(c, hipStreamSynchronize(e->s_up ? e->s_up : c->stream));
-    if (!base) sub_unpin_all(e);
-    else (void)pin_release(e->pins, base);
-    e->stats[6] = e->pins.regs.size();
-    e->src_cur = -1;
+    int rc = NTSCSIM_OK;
+    if (c->h422) rc = h422_host_unpin(c, base);
+    if (SubmitEngine *e = c->sub) {
+        const int r = sub_wait_ticket(c, NTSCSIM_TICKET_ALL);
+        if (rc == NTSCSIM_OK) rc = r;
+        HIPCHK(c, hipStreamSynchronize(e->s_up ? e->s_up : c->stream));
+        if (!base) sub_unpin_all(e);
+        else (void)pin_release(e->pins, base);
+        e->stats[6] = e->pins.regs.size();
+        e->src_cur = -1;
+    }
+    if (c->declared) {           // ... and the caller's own declaration (ntscsim_host_pin) last: nothing uses it any more
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!base) pin_release_all(*c->declared);
+        else (void)pin_release(*c->declared, base);
+    }
     return rc;
+}
+
+// ---- explicit contract: the caller says which memory is its own to pin ----------
+extern "C" int ntscsim_host_pin(ntscsim_ctx *c, const void *base, size_t len)
+{
+    if (!c || !base || len == 0) return NTSCSIM_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->declared) c->declared = new (std::nothrow) PinCache();
+    if (!c->declared) return NTSCSIM_E_NOMEM;
+    const uintptr_t PG = 4096, a0 = (uintptr_t)base, a1 = a0 + len;
+    const uintptr_t p0 = a0 & ~(PG - 1), p1 = (a1 + PG - 1) & ~(PG - 1);
+    for (auto &r : c->declared->regs)
+        if (p0 >= r.p0 && p1 <= r.p1) return NTSCSIM_OK;                 // declared before
+    // registrations the engines made on their own for these pages go first (everything in flight is delivered)
+    auto overlaps = [&](const PinCache &pc) { for (auto &r : pc.regs) if (p0 < r.p1 && r.p0 < p1) return true; return false; };
+    if ((c->sub && overlaps(c->sub->pins)) || (c->h422 && h422_pins_overlap(c, p0, p1)) || overlaps(*c->declared)) {
+        int rc = NTSCSIM_OK;
+        for (uintptr_t a = p0; a < p1 && rc == NTSCSIM_OK; a += PG) {
+            bool hit = false;
+            if (c->sub) for (auto &r : c->sub->pins.regs) if (a >= r.p0 && a < r.p1) hit = true;
+            if (c->h422 && h422_pins_overlap(c, a, a + 1)) hit = true;
+            for (auto &r : c->declared->regs) if (a >= r.p0 && a < r.p1) hit = true;
+            if (hit) rc = ntscsim_host_unpin(c, (const void *)a);
+        }
+        if (rc != NTSCSIM_OK) return rc;
+    }
+    hipError_t er = hipHostRegister((void *)p0, p1 - p0, hipHostRegisterDefault);
+    bool owned = true;
+    if (er == hipErrorHostMemoryAlreadyRegistered) { owned = false; er = hipSuccess; }      // e.g. ntscsim_host_alloc() memory
+    (void)hipGetLastError();
+    if (er != hipSuccess) { c->err = std::string("hipHostRegister: ") + hipGetErrorString(er); return NTSCSIM_E_HIP; }
+    void *dev = nullptr, *dev_last = nullptr;
+    if (hipHostGetDevicePointer(&dev, (void *)a0, 0) != hipSuccess || !dev ||
+        hipHostGetDevicePointer(&dev_last, (void *)(a1 - 1), 0) != hipSuccess || dev_last != (uint8_t *)dev + (len - 1)) {
+        (void)hipGetLastError();
+        if (owned) (void)hipHostUnregister((void *)p0);
+        c->err = "ntscsim_host_pin: the range is not one registration";
+        return NTSCSIM_E_HIP;
+    }
+    if (owned) c->declared->regs.push_back({p0, p1, (uint8_t *)dev - (a0 - p0), true});
+    else c->declared->regs.push_back({a0, a1, (uint8_t *)dev, false});
+    return NTSCSIM_OK;
+}
+
+extern "C" void *ntscsim_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+extern "C" void ntscsim_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+// Planes like av_frame_get_buffer(frame, align) lays them out -- linesize = row bytes rounded up to `align`, every
+// plane start aligned, 32 spare rows' worth of padding dropped in favour of `align` + 64 spare bytes per plane -- in
+// ONE pinned allocation.
+extern "C" int ntscsim_host_frame_alloc(int n_planes, const int *row_bytes, const int *rows, int align,
+                                        uint8_t **data, int *linesize, void **base, size_t *bytes)
+{
+    if (n_planes < 1 || n_planes > 8 || !row_bytes || !rows || !data || !linesize || !base) return NTSCSIM_E_ARG;
+    if (align < 1) align = 1;
+    if (align & (align - 1)) return NTSCSIM_E_ARG;
+    const size_t A = (size_t)(align < 64 ? 64 : align);
+    size_t off[8], total = 0;
+    for (int k = 0; k < n_planes; k++) {
+        if (row_bytes[k] < 1 || rows[k] < 1) return NTSCSIM_E_ARG;
+        linesize[k] = (int)(((size_t)row_bytes[k] + (size_t)align - 1) / (size_t)align * (size_t)align);
+        off[k] = total;
+        total += ((size_t)linesize[k] * (size_t)rows[k] + 64 + A - 1) / A * A;
+    }
+    uint8_t *p = (uint8_t *)ntscsim_host_alloc(total);
+    if (!p) return NTSCSIM_E_NOMEM;
+    for (int k = 0; k < n_planes; k++) data[k] = p + off[k];
+    *base = p;
+    if (bytes) *bytes = total;
+    return NTSCSIM_OK;
+}
+
+extern "C" int ntscsim_set_pin_policy(ntscsim_ctx *c, int policy)
+{
+    if (!c || policy < 0 || policy > 2) return NTSCSIM_E_ARG;
+    c->pin_policy = policy;
+    if (c->sub) c->sub->o.pin_caller_buffers = policy;
+    h422_set_pin_policy(c, policy);
+    return NTSCSIM_OK;
 }
 
 extern "C" void ntscsim_submit_stats(const ntscsim_ctx *c, uint64_t out[8])
@@ -364,22 +613,10 @@ static int sub_retire_front(ntscsim_ctx *c, SubmitEngine *e)
     SubmitEngine::Batch &b = e->inflight.front();
     int rc = b.rc;
     if (b.launched_ok) {
-        hipError_t er = hipEventSynchronize(b.done);
-        if (er != hipSuccess) { c->err = std::string("hipEventSynchronize: ") + hipGetErrorString(er); rc = NTSCSIM_E_HIP; }
-        else
-            for (const auto &it : b.items) {
-                if (it.host_dst_dev) continue;
-                int row0, step, n;
-                sub_rows(e->H, it.field, (it.flags & NTSCSIM_DESC_BOB) != 0, row0, step, n);
-                const uint8_t *s = e->hdst + e->fbytes * (size_t)it.dst_slot;
-                const size_t rb = (size_t)e->W * 4;
-                const bool bob = (it.flags & NTSCSIM_DESC_BOB) != 0;
-                for (int k = 0; k < n; k++) {
-                    const size_t y = (size_t)row0 + (size_t)k * step;
-                    const size_t ys = !bob ? y : (it.field ? (y | 1) : ((y + 1) & ~(size_t)1));      // :2233-2257
-                    std::memcpy(it.host_dst + y * (size_t)it.dst_ls, s + ys * e->pitch, rb);
-                }
-            }
+        bool ok;
+        if (b.posted) ok = e->dlv.wait(b.last);          // (the copy threads synchronised on the event and moved the rows)
+        else ok = hipEventSynchronize(b.done) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); c->err = "submit: a launch failed on the device (hipEventSynchronize)"; rc = NTSCSIM_E_HIP; }
     }
     if (e->timing && b.t0 && b.t1) {
         float a = 0, z = 0;
@@ -544,6 +781,36 @@ static int sub_launch(ntscsim_ctx *c)
     if (er != hipSuccess) { c->err = std::string("hipEventRecord: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;
     e->stats[1]++;
+    if (any_staged) {
+        // the copy threads move the staged rows into the caller's frames as soon as the event fires.  (Fields of one launch
+        // never write the same rows: ntscsim_submit() launches before it accepts a field that clashes with a pending one.)
+        std::vector<CopyOp> ops;
+        const size_t rb = (size_t)e->W * 4;
+        for (const auto &it : b.items) {
+            if (it.host_dst_dev) continue;
+            int row0, step, nr;
+            sub_rows(e->H, it.field, (it.flags & NTSCSIM_DESC_BOB) != 0, row0, step, nr);
+            const uint8_t *s = e->hdst + e->fbytes * (size_t)it.dst_slot;
+            if (!(it.flags & NTSCSIM_DESC_BOB)) {
+                // rows field, field + 2, ...: in two halves (the ops of a launch are what the threads share out)
+                const int h0 = nr / 2;
+                if (h0 > 0) ops.push_back({it.host_dst + (size_t)row0 * (size_t)it.dst_ls, s + (size_t)row0 * e->pitch, 2 * (size_t)it.dst_ls, 2 * e->pitch, rb, h0});
+                if (nr - h0 > 0) ops.push_back({it.host_dst + (size_t)(row0 + 2 * h0) * (size_t)it.dst_ls, s + (size_t)(row0 + 2 * h0) * e->pitch, 2 * (size_t)it.dst_ls, 2 * e->pitch, rb, nr - h0});
+            } else {
+                // line doubling :2233-2257: destination row y takes the field's row beside it -- two strided passes
+                // (even destination rows, odd destination rows), each reading every second source row
+                for (int par = 0; par < 2; par++) {
+                    const int cnt = (nr - par + 1) / 2;           // destination rows par, par + 2, ... < nr
+                    if (cnt <= 0) continue;
+                    const size_t y0 = (size_t)par;
+                    const size_t ys0 = it.field ? (y0 | 1) : ((y0 + 1) & ~(size_t)1);
+                    ops.push_back({it.host_dst + y0 * (size_t)it.dst_ls, s + ys0 * e->pitch, 2 * (size_t)it.dst_ls, 2 * e->pitch, rb, cnt});
+                }
+            }
+        }
+        e->dlv.post(c->device, b.done, std::move(ops), b.last);
+        b.posted = true;
+    }
     return finish(NTSCSIM_OK);
 }
 

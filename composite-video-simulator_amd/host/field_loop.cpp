@@ -3,8 +3,8 @@
 // ntscsim_field_avframe) and section 1b (asynchronous: ntscsim_submit_avframe + ntscsim_wait `lag` fields later).
 //
 //   field_loop [reference switches] [--mode sync|submit] [--fields N] [--depth K] [--lanes L] [--lag G]
-//              [--ring R] [--bob 0|1] [--pin 0|1] [--rewrite-src 0|1] [--src-stable 0|1] [--warmup N] [--hash 0|1]
-//              [--height H]
+//              [--ring R] [--bob 0|1] [--pin 0|1|2] [--alloc malloc|pinned|pool] [--rewrite-src 0|1] [--src-stable 0|1]
+//              [--warmup N] [--hash 0|1] [--height H]
 //
 // The loop owns, like the tool: ONE source frame per input (in.rgb, av_frame_get_buffer(..., 64) :556: linesize
 // = width*4 rounded up to 64, posix_memalign'ed), a ring of output frames (:2070-2092; `--ring`, at least lag+1 so
@@ -13,8 +13,15 @@
 // for sws_scale :603; 0: in.rgb is re-pointed at one of 8 pre-generated frames, no host copy), composite_layer
 // (:2229) -> the GPU, then -- `lag` fields later in submit mode -- the frame is consumed (--hash 1: FNV-1a over the
 // frame, the stand-in for bob / sws_scale / output_frame :2233-2280; with --bob 1 the line doubling is the GPU's).
+// Frame memory (include/ntscsim.h "Host buffers"): --alloc malloc = posix_memalign like av_malloc's (the tool unpatched:
+// heap blocks -> the engine's staging rings and copy threads); --alloc pinned = ntscsim_host_frame_alloc(), what
+// ntscsim_av_frame_get_buffer() backs an AVFrame with (DMA uploads, the GPU writes the rows into the frame); --alloc pool
+// = one mmap'ed pool of the caller's, 64-byte aligned blocks, declared with ntscsim_host_pin().  --pin = the pin policy
+// (0 stage everything, 1 default, 2 + glibc chunk-header peek: round 5's behaviour for malloc'ed frames).
 // Prints one JSON line: fields/s over the timed fields, the FNV of all consumed frames (equal between the two modes
 // = byte-identical frames in the same order), the engine's counters.
+#include <sys/mman.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +40,11 @@ struct Frame {           // the six AVFrame members the hot path reads (ffmpeg_n
 
 namespace {
 
+enum { ALLOC_MALLOC = 0, ALLOC_PINNED, ALLOC_POOL };
+int g_alloc = ALLOC_MALLOC;
+uint8_t *g_pool = nullptr;
+size_t g_pool_len = 0, g_pool_used = 0;
+
 Frame *frame_alloc(int W, int H)            // av_frame_alloc + av_frame_get_buffer(f, 64)
 {
     Frame *f = new Frame();
@@ -40,7 +52,17 @@ Frame *frame_alloc(int W, int H)            // av_frame_alloc + av_frame_get_buf
     f->width = W; f->height = H;
     f->linesize[0] = ((W * 4 + 63) / 64) * 64;
     void *p = nullptr;
-    if (posix_memalign(&p, 64, (size_t)f->linesize[0] * H + 64) != 0) return nullptr;
+    if (g_alloc == ALLOC_PINNED) {
+        const int rb = W * 4;
+        void *base = nullptr;
+        if (ntscsim_host_frame_alloc(1, &rb, &H, 64, f->data, f->linesize, &base, nullptr) != NTSCSIM_OK) return nullptr;
+        p = f->data[0];
+    } else if (g_alloc == ALLOC_POOL) {
+        const size_t need = ((size_t)f->linesize[0] * H + 128 + 63) / 64 * 64;
+        if (g_pool_used + need > g_pool_len) return nullptr;
+        p = g_pool + g_pool_used + 64;          // 64 bytes of "allocator header" in front of every block
+        g_pool_used += need;
+    } else if (posix_memalign(&p, 64, (size_t)f->linesize[0] * H + 64) != 0) return nullptr;
     f->data[0] = (uint8_t *)p;
     std::memset(p, 0, (size_t)f->linesize[0] * H);
     return f;
@@ -96,6 +118,7 @@ int main(int argc, char **argv)
         if (opt("--ring")) { ring = std::atoi(argv[++i]); continue; }
         if (opt("--bob")) { do_bob = std::atoi(argv[++i]); continue; }
         if (opt("--pin")) { pin = std::atoi(argv[++i]); continue; }
+        if (opt("--alloc")) { const std::string a = argv[++i]; g_alloc = a == "pinned" ? ALLOC_PINNED : a == "pool" ? ALLOC_POOL : ALLOC_MALLOC; continue; }
         if (opt("--rewrite-src")) { rewrite = std::atoi(argv[++i]); continue; }
         if (opt("--src-stable")) { src_stable = std::atoi(argv[++i]); continue; }
         if (opt("--hash")) { do_hash = std::atoi(argv[++i]); continue; }
@@ -126,6 +149,15 @@ int main(int argc, char **argv)
         if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_submit_configure: %s\n", ntscsim_strerror(rc)); return 1; }
     }
 
+    if (!async && ntscsim_set_pin_policy(sim, pin) != NTSCSIM_OK) return 1;
+    if (g_alloc == ALLOC_POOL) {
+        g_pool_len = ((((size_t)W * 4 + 64) * H + 256) * (size_t)(8 + 1 + ring) + 4095) / 4096 * 4096;
+        void *pm = mmap(nullptr, g_pool_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (pm == MAP_FAILED) { std::fprintf(stderr, "mmap of the frame pool failed\n"); return 1; }
+        g_pool = (uint8_t *)pm;
+        rc = ntscsim_host_pin(sim, g_pool, g_pool_len);
+        if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_host_pin: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim)); return 1; }
+    }
     // "decoded" frames, the tool's in.rgb, the output frame ring
     std::vector<Frame *> decoded;
     for (int k = 0; k < 8; k++) { decoded.push_back(frame_alloc(W, H)); make_bars(decoded.back(), k); }
@@ -193,12 +225,13 @@ int main(int argc, char **argv)
     uint64_t st[8];
     ntscsim_submit_stats(sim, st);
     std::printf("{\"mode\": \"%s\", \"fields\": %ld, \"seconds\": %.6f, \"fields_per_s\": %.1f, \"width\": %d, \"height\": %d, "
-                "\"depth\": %d, \"lanes\": %d, \"lag\": %d, \"ring\": %d, \"bob\": %d, \"pin\": %d, \"rewrite_src\": %d, \"src_stable\": %d, "
+                "\"depth\": %d, \"lanes\": %d, \"lag\": %d, \"ring\": %d, \"bob\": %d, \"pin\": %d, \"alloc\": \"%s\", \"rewrite_src\": %d, \"src_stable\": %d, "
                 "\"host_us_per_call\": {\"new_frame\": %.1f, \"same_frame\": %.1f, \"wait\": %.1f}, "
                 "\"fnv1a\": \"%016llx\", \"rng_pos\": %llu, \"stats\": {\"submitted\": %llu, \"launches\": %llu, \"uploads\": %llu, "
                 "\"uploads_staged\": %llu, \"delivered_direct\": %llu, \"delivered_staged\": %llu, \"registrations\": %llu, "
                 "\"ring_full_waits\": %llu}}\n",
-                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, depth, lanes, lag, ring, do_bob, pin, rewrite, src_stable && !rewrite,
+                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, depth, lanes, lag, ring, do_bob, pin,
+                g_alloc == ALLOC_PINNED ? "pinned" : g_alloc == ALLOC_POOL ? "pool" : "malloc", rewrite, src_stable && !rewrite,
                 n_new ? us_new / n_new : 0.0, n_same ? us_same / n_same : 0.0, n_wait ? us_wait / n_wait : 0.0,
                 (unsigned long long)(do_hash ? hash : 0), (unsigned long long)ntscsim_get_rng_pos(sim),
                 (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],

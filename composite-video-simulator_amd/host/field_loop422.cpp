@@ -3,7 +3,8 @@
 // ntscsim_field422_avframe) and section 5b (asynchronous: ntscsim_submit422_avframe + ntscsim_wait `lag` fields later).
 //
 //   field_loop422 [ffmpeg_to_composite switches] [--mode sync|submit] [--fields N] [--depth K] [--lag G] [--warmup N]
-//                 [--hash 0|1] [--height H] [--align A] [--page-frames 0|1] [--mmap-threshold BYTES]
+//                 [--hash 0|1] [--height H] [--align A] [--alloc malloc|pinned|pool|mmap] [--pin-policy 0|1|2]
+//                 [--mmap-threshold BYTES]
 //
 // The loop owns, like the tool: ONE decoded-and-scaled input frame (output_avstream_video_input_frame, rewritten by a
 // memcpy per source frame -- the stand-in for sws_scale :1770-1778), ONE persistent processing frame
@@ -12,14 +13,18 @@
 // fields behind the submits (--hash 1: FNV-1a over each, the stand-in for the encoder).  Frames are allocated like
 // av_frame_get_buffer(f, A) does: linesize = width rounded up to A (default 32), so 720 -> 736 (padded rows: the
 // batched path) and 704 -> 704 (tight rows: one iteration at a time).  -vi / -422 as in the tool (:1792-1797, :1158).
-// Plane memory comes from posix_memalign like av_malloc's.  Whether such a block is an allocation with a mapping of its own
-// (which the engine pins in place: DMA uploads, delivery kernels, no copy on the caller's thread) or a block inside the C
-// library's heap (which it must stage: pinning the edge pages of a heap block would pin its neighbours' bytes) is glibc's
-// decision: blocks above M_MMAP_THRESHOLD get a mapping, and that threshold starts at 128 KiB but RISES whenever a larger
-// mapped block is freed -- which the GPU runtime's start-up does.  The one-line remedy INTEGRATION.md recommends is the first
-// statement here: mallopt(M_MMAP_THRESHOLD, 64 KiB) pins the threshold (--mmap-threshold 0 leaves glibc's dynamic default,
-// i.e. the staging rings for 353 / 177 KiB planes).  --page-frames 1 allocates every plane by mmap instead (what a
-// get_buffer2 callback over page-aligned memory gives).
+// Where the plane memory comes from decides how the pixels travel (include/ntscsim.h "Host buffers"; nothing here is a
+// guess about the allocator):
+//   --alloc malloc   posix_memalign like av_malloc's (the tool unpatched): ordinary heap blocks -> the engine's pinned staging
+//                    rings, one memcpy each way, the delivery side on the engine's copy threads.  The default.
+//   --alloc pinned   ntscsim_host_frame_alloc() -- what ntscsim_av_frame_get_buffer() (ntscsim_avframe.h) backs an AVFrame
+//                    with: pinned memory, DMA uploads, the GPU writes the results straight into the frames.
+//   --alloc pool     ONE mmap'ed pool the loop carves all its planes from (64-byte aligned, NOT page aligned), declared
+//                    with ntscsim_host_pin(pool, len): the explicit contract for callers with their own allocator.
+//   --alloc mmap     every plane a mapping of its own (page-aligned buffers are pinned in place on first sight).
+//   --alloc fakehdr  test: the pool NOT declared, every block behind a word that reads like glibc's IS_MMAPPED header.
+// --pin-policy 2 with --alloc malloc and --mmap-threshold 65536 is round 5's arrangement (glibc chunk-header peek +
+// mallopt); kept for A/B, no longer what INTEGRATION.md recommends.
 // Prints one JSON line: fields/s over the timed fields, the FNV of all consumed frames (equal between the two modes =
 // byte-identical frames in the same order), the rand() position, the engine's counters.
 #include <malloc.h>
@@ -44,21 +49,40 @@ struct Frame {           // the AVFrame members the four calls read (ffmpeg_to_c
 
 namespace {
 
-bool g_page_frames = false;
+enum { ALLOC_MALLOC = 0, ALLOC_PINNED, ALLOC_POOL, ALLOC_MMAP, ALLOC_FAKEHDR };
+int g_alloc = ALLOC_MALLOC;
+uint8_t *g_pool = nullptr;          // --alloc pool
+size_t g_pool_len = 0, g_pool_used = 0;
 
 Frame *frame_alloc(int W, int H, bool c420, int align, int fill)      // av_frame_alloc + av_frame_get_buffer(f, align)
 {
     Frame *f = new Frame();
     std::memset(f, 0, sizeof(*f));
     f->width = W; f->height = H;
+    if (g_alloc == ALLOC_PINNED) {        // av_frame_get_buffer's layout in ONE pinned block
+        int rb[3], rows[3];
+        for (int k = 0; k < 3; k++) { rb[k] = k ? W / 2 : W; rows[k] = (k && c420) ? (H + 1) / 2 : H; }
+        void *base = nullptr;
+        if (ntscsim_host_frame_alloc(3, rb, rows, align, f->data, f->linesize, &base, nullptr) != NTSCSIM_OK) return nullptr;
+        for (int k = 0; k < 3; k++) std::memset(f->data[k], k ? 128 : fill, (size_t)f->linesize[k] * rows[k] + 64);
+        return f;
+    }
     for (int k = 0; k < 3; k++) {
         const int w = k ? W / 2 : W, rows = (k && c420) ? (H + 1) / 2 : H;
         f->linesize[k] = ((w + align - 1) / align) * align;
         void *p = nullptr;
         const size_t bytes = (size_t)f->linesize[k] * rows + 64;
-        if (g_page_frames) {
+        if (g_alloc == ALLOC_MMAP) {
             p = mmap(nullptr, (bytes + 4095) / 4096 * 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (p == MAP_FAILED) return nullptr;
+        } else if (g_alloc == ALLOC_POOL || g_alloc == ALLOC_FAKEHDR) {
+            const size_t need = (bytes + 128 + 63) / 64 * 64;         // 64 bytes of "allocator header" between blocks
+            if (g_pool_used + need > g_pool_len) return nullptr;
+            p = g_pool + g_pool_used + 64;
+            if (!((uintptr_t)p & 4095)) p = (uint8_t *)p + 64;        // (never on a page boundary: that is --alloc mmap's case)
+            g_pool_used += need;
+            // a foreign allocator's header: the word in front of the block reads like glibc's "mmapped chunk, huge size"
+            if (g_alloc == ALLOC_FAKEHDR) { const size_t hdr = ~(size_t)0 - 5; std::memcpy((uint8_t *)p - sizeof(size_t), &hdr, sizeof(hdr)); }
         } else if (posix_memalign(&p, 64, bytes) != 0) return nullptr;
         f->data[k] = (uint8_t *)p;
         std::memset(p, k ? 128 : fill, (size_t)f->linesize[k] * rows + 64);
@@ -102,7 +126,8 @@ int main(int argc, char **argv)
     std::string mode = "submit";
     long fields = 2000, warmup = 200;
     int depth = 32, lag = -1, do_hash = 0, height = 0, align = 32;
-    long mmap_threshold = 64 << 10;
+    long mmap_threshold = 0;
+    int pin_policy = -1;
     std::vector<const char *> av;
     av.push_back(argv[0]);
     for (int i = 1; i < argc; i++) {
@@ -115,11 +140,17 @@ int main(int argc, char **argv)
         if (opt("--hash")) { do_hash = std::atoi(argv[++i]); continue; }
         if (opt("--height")) { height = std::atoi(argv[++i]); continue; }
         if (opt("--align")) { align = std::atoi(argv[++i]); continue; }
-        if (opt("--page-frames")) { g_page_frames = std::atoi(argv[++i]) != 0; continue; }
+        if (opt("--page-frames")) { if (std::atoi(argv[++i]) != 0) g_alloc = ALLOC_MMAP; continue; }
+        if (opt("--alloc")) {
+            const std::string a = argv[++i];
+            g_alloc = a == "pinned" ? ALLOC_PINNED : a == "pool" ? ALLOC_POOL : a == "mmap" ? ALLOC_MMAP : a == "fakehdr" ? ALLOC_FAKEHDR : ALLOC_MALLOC;
+            continue;
+        }
+        if (opt("--pin-policy")) { pin_policy = std::atoi(argv[++i]); continue; }
         if (opt("--mmap-threshold")) { mmap_threshold = std::atol(argv[++i]); continue; }
         av.push_back(argv[i]);
     }
-    if (mmap_threshold > 0) mallopt(M_MMAP_THRESHOLD, (int)mmap_threshold);     // frame planes keep mappings of their own
+    if (mmap_threshold > 0) mallopt(M_MMAP_THRESHOLD, (int)mmap_threshold);     // (round 5's arrangement, with --pin-policy 2)
     av.push_back("-i"); av.push_back("unused"); av.push_back("-o"); av.push_back("unused");   // (the parser insists, :1634)
     const bool async = mode == "submit";
     if (!async && mode != "sync") { std::fprintf(stderr, "--mode sync|submit\n"); return 1; }
@@ -147,6 +178,19 @@ int main(int argc, char **argv)
     if (async) {
         rc = ntscsim_submit422_configure(sim, depth, lag + 2 * depth + 2 > 4 * depth ? lag + 2 * depth + 2 : 4 * depth);
         if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_submit422_configure: %s\n", ntscsim_strerror(rc)); return 1; }
+    }
+    if (pin_policy >= 0 && ntscsim_set_pin_policy(sim, pin_policy) != NTSCSIM_OK) { std::fprintf(stderr, "--pin-policy 0|1|2\n"); return 1; }
+    if (g_alloc == ALLOC_POOL || g_alloc == ALLOC_FAKEHDR) {
+        // the caller's own allocator: one mapping for every plane of the run, declared once
+        const size_t per_frame = 2 * ((size_t)(W + align) * H + 256) + 1024;
+        g_pool_len = (per_frame * (size_t)(8 + 3 + lag + 1) + 4095) / 4096 * 4096;
+        void *pm = mmap(nullptr, g_pool_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (pm == MAP_FAILED) { std::fprintf(stderr, "mmap of the frame pool failed\n"); return 1; }
+        g_pool = (uint8_t *)pm;
+        // (--alloc fakehdr: the same pool NOT declared, every block behind a header word that looks like glibc's
+        //  IS_MMAPPED chunk -- the engine must not take that for permission: tests/test_host422.py)
+        rc = g_alloc == ALLOC_POOL ? ntscsim_host_pin(sim, g_pool, g_pool_len) : NTSCSIM_OK;
+        if (rc != NTSCSIM_OK) { std::fprintf(stderr, "ntscsim_host_pin: %s (%s)\n", ntscsim_strerror(rc), ntscsim_last_error(sim)); return 1; }
     }
     // "decoded" frames, the tool's three frames, the encoder frame ring
     std::vector<Frame *> decoded;
@@ -214,11 +258,12 @@ int main(int argc, char **argv)
     uint64_t st[8];
     ntscsim_submit422_stats(sim, st);
     std::printf("{\"mode\": \"%s\", \"fields\": %ld, \"seconds\": %.6f, \"fields_per_s\": %.1f, \"width\": %d, \"height\": %d, "
-                "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, \"page_frames\": %d, \"mmap_threshold\": %ld, "
+                "\"linesize\": %d, \"depth\": %d, \"lag\": %d, \"out_mode\": %u, \"interlaced_out\": %d, \"alloc\": \"%s\", \"mmap_threshold\": %ld, "
                 "\"host_us_per_call\": {\"new_frame\": %.1f, \"same_frame\": %.1f, \"wait\": %.1f}, "
                 "\"fnv1a\": \"%016llx\", \"rng_pos\": %llu, \"stats\": {\"submitted\": %llu, \"launches\": %llu, \"uploads\": %llu, "
                 "\"batched\": %llu, \"one_at_a_time\": %llu, \"frame_uploads\": %llu, \"delivered_direct\": %llu, \"ring_full_waits\": %llu}}\n",
-                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0, g_page_frames ? 1 : 0, mmap_threshold,
+                mode.c_str(), fields, dt, dt > 0 ? fields / dt : 0.0, W, H, frame->linesize[0], depth, lag, out_mode, interlaced_out ? 1 : 0,
+                g_alloc == ALLOC_PINNED ? "pinned" : g_alloc == ALLOC_POOL ? "pool" : g_alloc == ALLOC_MMAP ? "mmap" : g_alloc == ALLOC_FAKEHDR ? "fakehdr" : "malloc", mmap_threshold,
                 n_new ? us_new / n_new : 0.0, n_same ? us_same / n_same : 0.0, n_wait ? us_wait / n_wait : 0.0,
                 (unsigned long long)(do_hash ? hash : 0), (unsigned long long)ntscsim_get_rng_pos(sim),
                 (unsigned long long)st[0], (unsigned long long)st[1], (unsigned long long)st[2], (unsigned long long)st[3],

@@ -6,6 +6,11 @@ torch is used only for device memory, streams and torch.distributed plumbing.
 """
 import ctypes as C
 
+try:                # before libntscsim.so is loaded: one HIP runtime for torch and the library (_capi.lib)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 from . import _capi
 from ._capi import (DESC_BOB, DESC_INTERLACED, DESC_TFF, RNG_AUTO, Field422Desc, FieldDesc,
                     NtscsimError, Out422Desc, YuvDesc, ScaleDesc, HostSource, Params, lib, make_params,
@@ -115,6 +120,13 @@ class FieldSimulator:
     def host_unpin(self, array=None):
         self._chk(self._lib.ntscsim_host_unpin(self._h, None if array is None else array.ctypes.data),
                   "ntscsim_host_unpin")
+
+    def host_pin(self, array):
+        """ntscsim_host_pin(): declare a numpy array's memory as the caller's own to pin."""
+        self._chk(self._lib.ntscsim_host_pin(self._h, array.ctypes.data, array.nbytes), "ntscsim_host_pin")
+
+    def set_pin_policy(self, policy):
+        self._chk(self._lib.ntscsim_set_pin_policy(self._h, int(policy)), "ntscsim_set_pin_policy")
 
     def submit_stats(self):
         out = (C.c_uint64 * 8)()
@@ -519,3 +531,26 @@ class Raw28Decoder:
         if rc != _capi.OK:
             raise NtscsimError(rc, "ntscsim_raw28_debug_read_front")
         return out
+
+
+_host_blocks = {}
+
+
+def host_alloc_array(shape, align_offset=0):
+    """A uint8 array of `shape` in pinned memory from ntscsim_host_alloc(), starting `align_offset` bytes into the
+    block (tests: frames that do not start on a page boundary).  Free with host_free_array()."""
+    import numpy as np
+    n = int(np.prod(shape))
+    p = lib().ntscsim_host_alloc(n + int(align_offset))
+    if not p:
+        raise MemoryError("ntscsim_host_alloc(%d)" % n)
+    buf = (C.c_uint8 * (n + int(align_offset))).from_address(p)
+    a = np.frombuffer(buf, dtype=np.uint8)[int(align_offset):].reshape(shape)
+    _host_blocks[a.ctypes.data] = p
+    return a
+
+
+def host_free_array(a):
+    p = _host_blocks.pop(a.ctypes.data, None)
+    if p:
+        lib().ntscsim_host_free(p)

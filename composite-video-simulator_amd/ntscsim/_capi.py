@@ -41,6 +41,7 @@ EXPORTS = (
     "ntscsim_raw28_debug_read_front",
     "ntscsim_submit_opts_init", "ntscsim_submit_configure", "ntscsim_submit", "ntscsim_flush", "ntscsim_wait",
     "ntscsim_host_unpin", "ntscsim_submit_stats",
+    "ntscsim_host_pin", "ntscsim_host_alloc", "ntscsim_host_free", "ntscsim_host_frame_alloc", "ntscsim_set_pin_policy",
     "ntscsim_field422", "ntscsim_submit422", "ntscsim_submit422_configure", "ntscsim_submit422_stats",
     "ntscsim_pool_create", "ntscsim_pool_destroy", "ntscsim_pool_size", "ntscsim_pool_ctx", "ntscsim_pool_set_block",
     "ntscsim_pool_get_rng_pos", "ntscsim_pool_set_rng_pos", "ntscsim_pool_last_error", "ntscsim_pool_frames_host",
@@ -223,13 +224,9 @@ def lib():
         raise RuntimeError(
             "%s is missing -- build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
             "(or `make -C composite-video-simulator_amd/csrc`)" % PRODUCT_SO)
-    # torch carries its own copy of the HIP runtime; loaded AFTER libntscsim.so (which links /opt/rocm's) it finds no
-    # device (torch.cuda.is_available() == False, seen on the GPU box).  The device-tensor half of this package needs
-    # torch anyway, so let it load first whatever order the caller imports in: one runtime for both.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # Load order: torch carries its own copy of the HIP runtime; imported AFTER libntscsim.so (which links /opt/rocm's)
+    # it finds no device.  The package's __init__ (the half that hands torch tensors to this library) therefore imports
+    # torch before anything here runs; a program that uses _capi alone and torch later must import torch first itself.
     L = C.CDLL(PRODUCT_SO)
     L.ntscsim_params_init.argtypes = [C.POINTER(Params)]
     L.ntscsim_params_init.restype = None
@@ -368,6 +365,17 @@ def lib():
     L.ntscsim_host_unpin.restype = C.c_int
     L.ntscsim_submit_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.ntscsim_submit_stats.restype = None
+    L.ntscsim_host_pin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.ntscsim_host_pin.restype = C.c_int
+    L.ntscsim_host_alloc.argtypes = [C.c_size_t]
+    L.ntscsim_host_alloc.restype = C.c_void_p
+    L.ntscsim_host_free.argtypes = [C.c_void_p]
+    L.ntscsim_host_free.restype = None
+    L.ntscsim_host_frame_alloc.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.ntscsim_host_frame_alloc.restype = C.c_int
+    L.ntscsim_set_pin_policy.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_set_pin_policy.restype = C.c_int
     L.ntscsim_field422.argtypes = [C.c_void_p, C.POINTER(Loop422)]
     L.ntscsim_field422.restype = C.c_int
     L.ntscsim_submit422.argtypes = [C.c_void_p, C.POINTER(Loop422), C.c_uint32, C.POINTER(C.c_uint64)]

@@ -241,14 +241,22 @@ int ntscsim_field(ntscsim_ctx *ctx,
  *     ntscsim_wait(ctx, NTSCSIM_TICKET_ALL).
  *   - a launch happens when `depth` fields are pending, on ntscsim_flush(), or when a wait needs it; a
  *     change of width/height flushes first.
- * Host buffers: by default the engine pins the caller's frames IN PLACE the first time it sees them
- * (hipHostRegister, whole pages, cached per ctx: AVFrame pools recycle a handful of buffers) and moves the
- * pixels with DMA uploads and a GPU delivery kernel that writes the field rows straight into the caller's
- * frame -- no host memcpy.  Buffers smaller than min_pin_bytes (and never smaller than 64 KiB), memory of the brk heap
- * (below sbrk(0): the allocator trims and recycles those pages), buffers that start more than 128 bytes into a page
- * (a block inside a shared heap rather than an allocation of its own: pinning its edge pages would pin its
- * neighbours' bytes), buffers that share a page with another registration, or pin_caller_buffers = 0 go through a
- * pinned staging ring instead (one memcpy each way).
+ * Host buffers (the same rules for ntscsim_submit() and ntscsim_submit422()): frames in PINNED memory are served
+ * without a host memcpy -- DMA uploads, and the GPU writes the field rows straight into the caller's frame.  What
+ * counts as pinned is deterministic (pin policy 1, the default):
+ *   - memory the caller DECLARED with ntscsim_host_pin(ctx, base, len);
+ *   - memory that is pinned already: ntscsim_host_alloc() / ntscsim_host_frame_alloc() (what the
+ *     ntscsim_av_frame_get_buffer() helper of ntscsim_avframe.h backs an AVFrame with), hipHostMalloc, or the
+ *     caller's own hipHostRegister -- the HIP runtime is asked (hipPointerGetAttributes), nothing is guessed;
+ *   - buffers of at least min_pin_bytes (never below 64 KiB) that START ON A PAGE BOUNDARY and lie above the program
+ *     break: registered in place on first sight (hipHostRegister, whole pages, cached per ctx).
+ * Everything else -- ordinary malloc / av_malloc blocks, whatever the allocator (glibc, jemalloc, tcmalloc, a pool) --
+ * goes through pinned staging rings: one memcpy each way, the delivery side on the engine's own copy threads.  Same
+ * bytes either way.  Policy 2 (opt-in, glibc only: pin_caller_buffers = 2 / ntscsim_set_pin_policy) additionally
+ * registers blocks that carry glibc's header of a chunk with a mapping of its own (IS_MMAPPED and a chunk size that
+ * covers the frame) -- what av_frame_get_buffer() planes are while glibc's mmap threshold is below their size; it reads
+ * the allocator's private word in front of the pointer and must not be used with another allocator.  Policy 0 stages
+ * everything.
  * A pinned buffer must stay allocated until ntscsim_host_unpin() / ntscsim_destroy(): free()ing registered
  * memory while the registration lives is undefined (HIP).
  */
@@ -261,7 +269,7 @@ typedef struct ntscsim_submit_opts {
                                       the submits keeps uploads, kernels and deliveries of neighbouring
                                       launches overlapped (2*depth: ~10 % slower)                           */
     int32_t  lanes;                /* launches in flight side by side (own stream + scratch), 1..8; def. 3 */
-    int32_t  pin_caller_buffers;   /* default 1                                                           */
+    int32_t  pin_caller_buffers;   /* pin policy 0 | 1 | 2 (above); default 1                             */
     int32_t  _pad;
     size_t   min_pin_bytes;        /* default 256 KiB                                                     */
 } ntscsim_submit_opts;
@@ -286,9 +294,28 @@ int ntscsim_flush(ntscsim_ctx *ctx);
 /* Block until `ticket` (and every earlier one) has been delivered.  Returns the first error of the
  * launches it had to complete (their fields are then lost), NTSCSIM_E_ARG for a ticket never issued. */
 int ntscsim_wait(ntscsim_ctx *ctx, uint64_t ticket);
-/* Drop the cached registration that covers `base` (NULL: all of them) after waiting for everything in
- * flight: call before free()ing a frame buffer the engine has seen while the ctx lives on. */
+/* Declare [base, base + len) as the caller's own memory to pin: the pages it touches are registered with the GPU now
+ * (hipHostRegister; memory that is pinned already is just noted) and every frame inside the range takes the
+ * no-copy path from then on, wherever it starts.  The caller vouches that those pages hold nothing that is freed or
+ * recycled while the declaration lives (an allocation of its own: a mmap, a large malloc block incl. its header page,
+ * a frame pool).  NTSCSIM_OK, NTSCSIM_E_ARG, NTSCSIM_E_HIP (registration refused; nothing changed). */
+int ntscsim_host_pin(ntscsim_ctx *ctx, const void *base, size_t len);
+/* Drop the registration that covers `base` (NULL: all of them) -- declared or made by the engine on its own --
+ * after waiting for everything in flight: call before free()ing a frame buffer the engine has seen while the ctx
+ * lives on. */
 int ntscsim_host_unpin(ntscsim_ctx *ctx, const void *base);
+/* Pinned host memory (hipHostMalloc, visible to every GPU of the process), page-aligned; NULL when it cannot be had.
+ * No ctx needed: usable as the allocator behind av_buffer_create() (ntscsim_avframe.h). */
+void *ntscsim_host_alloc(size_t bytes);
+void  ntscsim_host_free(void *p);
+/* The planes of one frame, laid out like av_frame_get_buffer(frame, align) does (linesize[k] = row_bytes[k] rounded
+ * up to `align`, a power of two; every plane 64-byte aligned with 64 spare bytes), in ONE ntscsim_host_alloc()
+ * block: data[k] / linesize[k] receive the planes, *base the block to hand to ntscsim_host_free(), *bytes (may be
+ * NULL) its size. */
+int   ntscsim_host_frame_alloc(int n_planes, const int *row_bytes, const int *rows, int align,
+                               uint8_t **data, int *linesize, void **base, size_t *bytes);
+/* Pin policy of this ctx's host-frame engines (0 | 1 | 2, see "Host buffers" above; default 1). */
+int   ntscsim_set_pin_policy(ntscsim_ctx *ctx, int policy);
 /* Counters since ntscsim_create(): [0] fields submitted, [1] launches, [2] source uploads, [3] uploads that
  * went through the staging ring, [4] fields delivered by the GPU into pinned caller frames, [5] fields
  * delivered through the staging ring, [6] live registrations, [7] submits that blocked on a full ring. */
@@ -523,11 +550,11 @@ void ntscsim_batch422_destroy(ntscsim_batch422 *batch);
  *   - ntscsim_sync() delivers everything in flight first; the device-pointer entry points
  *     (ntscsim_fields422_device() ...) must not be mixed in without ntscsim_wait(ctx, NTSCSIM_TICKET_ALL).
  *     ntscsim_host_unpin(ctx, base) drops the engine's registration of a frame the caller is about to free.
- * Host buffers: planes that are allocations of their own -- at least 64 KiB, starting on a page boundary or carrying
- * glibc's header of a chunk with a mapping of its own -- are pinned in place (hipHostRegister, cached) and the results
- * are written into them by the delivery kernels (the source is snapshotted by one memcpy into a pinned ring: cheaper for
- * the calling thread than waiting for a DMA out of its planes).  Everything else (small planes, blocks inside the C library's heap, NTSCSIM_SUBMIT422_PIN=0 in the
- * environment) goes through pinned staging rings with one memcpy each way on the calling thread.  Same bytes either way.
+ * Host buffers: the rules of ntscsim_submit() above ("Host buffers"; the floor for pinning in place is 64 KiB per
+ * plane here).  Results are written into pinned planes by the delivery kernels (the source is snapshotted by one memcpy
+ * into a pinned ring: cheaper for the calling thread than waiting for a DMA out of its planes); planes that are not
+ * pinned are filled from the staging ring by the engine's copy threads before ntscsim_wait() returns.  Same bytes
+ * either way.
  * Errors: as ntscsim_fields422_device(); a refused call consumes no ticket and no rand() draws.
  */
 typedef struct ntscsim_frame422 {    /* AVFrame::data[0..2] / linesize[0..2] of a planar YUV frame in host memory */

@@ -298,3 +298,32 @@ def test_submit_opts_defaults_without_a_gpu():
     assert lib.ntscsim_submit(None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, None) == _capi.E_ARG
     assert lib.ntscsim_wait(None, 1) == _capi.E_ARG
     assert lib.ntscsim_flush(None) == _capi.E_ARG
+
+
+# ---- the C++ host of INTEGRATION.md section 1 / 1b: the reference's loop with the call at :2229 replaced ------------
+import json          # noqa: E402
+import os            # noqa: E402
+import subprocess    # noqa: E402
+
+FIELD_LOOP = os.path.join(L.PKG, "field_loop")
+
+
+def _run_field_loop(mode, extra=()):
+    r = subprocess.run([FIELD_LOOP, "-vhs", "--mode", mode, "--fields", "80", "--warmup", "0", "--hash", "1", "--depth", "8",
+                        "--rewrite-src", "1"] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bob", ["0", "1"])
+def test_cpp_field_loop_allocators_pinned_pool_and_plain_malloc(bob):
+    """VERDICT r05 item 2 for the BGRA tool: frames from ntscsim_host_frame_alloc() and frames carved from a pool that
+    was declared with ntscsim_host_pin() take the no-copy path; posix_memalign'ed frames are staged (copy threads) under
+    the default policy and pinned in place only under the opt-in glibc policy.  Same frames in the same order."""
+    a = _run_field_loop("sync", ["--bob", bob])
+    for alloc, pin, direct in (("malloc", "1", False), ("pinned", "1", True), ("pool", "1", True), ("malloc", "0", False)):
+        b = _run_field_loop("submit", ["--bob", bob, "--alloc", alloc, "--pin", pin])
+        assert b["fnv1a"] == a["fnv1a"] != "0000000000000000" and b["rng_pos"] == a["rng_pos"], (alloc, pin)
+        assert (b["stats"]["delivered_direct"] > 0) == direct, (alloc, pin, b["stats"])
+        assert (b["stats"]["delivered_staged"] > 0) == (not direct), (alloc, pin, b["stats"])
