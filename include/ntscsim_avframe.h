@@ -23,7 +23,10 @@
 
 #ifndef NTSCSIM_AVFRAME_T
 #include <libavutil/frame.h>
+#include <libavutil/buffer.h>
+#include <libavutil/imgutils.h>
 #define NTSCSIM_AVFRAME_T AVFrame
+#define NTSCSIM_AVFRAME_HAVE_LIBAV 1
 #endif
 
 #ifdef __cplusplus
@@ -134,6 +137,56 @@ static inline int ntscsim_submit422_avframe(ntscsim_ctx *ctx, NTSCSIM_AVFRAME_T 
                                                  out_mode, out_field, nocomp, field, fieldno);
     return rc != NTSCSIM_OK ? rc : ntscsim_submit422(ctx, &it, submit_flags, ticket);
 }
+
+/* ---- frames the engine can serve without a host copy --------------------------------------------------------
+ * The tools allocate their frames with av_frame_get_buffer(frame, 64) (ffmpeg_ntsc.cpp:351 in.rgb, :2082 the
+ * frame-delay ring; ffmpeg_to_composite.cpp: output_avstream_video_frame / _input_frame / _bob_frame) -- av_malloc
+ * blocks, which ntscsim_submit*() must stage (include/ntscsim.h "Host buffers").  ntscsim_av_frame_get_buffer() is
+ * the one-token replacement: same arguments, same result (width / height / format must be set; data[], linesize[],
+ * buf[0], extended_data are filled; av_frame_free() / av_frame_unref() release it), but the planes live in ONE block
+ * of pinned host memory (ntscsim_host_alloc) wrapped by av_buffer_create(): DMA reads it, the GPU writes the field
+ * rows straight into it.  Layout as libavutil's get_video_buffer(): linesizes from av_image_fill_linesizes() with the width
+ * padded until linesize[0] is a multiple of `align`, each rounded up to `align`, height padded to a multiple of 32 rows, planes placed by
+ * av_image_fill_pointers(), `align` spare bytes in front (none needed: the block is page aligned) and 64 behind.
+ * Returns 0 or a negative AVERROR, like av_frame_get_buffer().
+ *
+ * Compiled only against FFmpeg's headers; a unit that defines NTSCSIM_AVFRAME_T itself may define
+ * NTSCSIM_AVFRAME_HAVE_LIBAV as well if it provides av_image_fill_linesizes / av_image_fill_pointers /
+ * av_buffer_create / FFALIGN / AVERROR with libavutil's signatures (tests/test_params_capi.py does, to compile
+ * and run this function without libav). */
+#ifdef NTSCSIM_AVFRAME_HAVE_LIBAV
+static void ntscsim_av_buffer_free_(void *opaque, uint8_t *data)
+{
+    (void)opaque;
+    ntscsim_host_free(data);
+}
+
+static inline int ntscsim_av_frame_get_buffer(NTSCSIM_AVFRAME_T *frame, int align)
+{
+    int i, ret, padded_height, total;
+    uint8_t *block;
+    if (frame == 0 || frame->width <= 0 || frame->height <= 0 || frame->format < 0) return AVERROR(EINVAL);
+    if (align <= 0) align = 32;
+    /* (libavutil's search: the smallest width alignment that makes linesize[0] a multiple of `align`) */
+    for (i = 1; i <= align; i += i) {
+        ret = av_image_fill_linesizes(frame->linesize, (enum AVPixelFormat)frame->format, FFALIGN(frame->width, i));
+        if (ret < 0) return ret;
+        if (!(frame->linesize[0] & (align - 1))) break;
+    }
+    for (i = 0; i < 4 && frame->linesize[i]; i++) frame->linesize[i] = FFALIGN(frame->linesize[i], align);
+    padded_height = FFALIGN(frame->height, 32);
+    total = av_image_fill_pointers(frame->data, (enum AVPixelFormat)frame->format, padded_height, 0, frame->linesize);
+    if (total < 0) return total;
+    block = (uint8_t *)ntscsim_host_alloc((size_t)total + 64);
+    if (block == 0) return AVERROR(ENOMEM);
+    frame->buf[0] = av_buffer_create(block, total + 64, ntscsim_av_buffer_free_, 0, 0);
+    if (frame->buf[0] == 0) { ntscsim_host_free(block); return AVERROR(ENOMEM); }
+    ret = av_image_fill_pointers(frame->data, (enum AVPixelFormat)frame->format, padded_height, block, frame->linesize);
+    if (ret < 0) { av_buffer_unref(&frame->buf[0]); return ret; }
+    frame->extended_data = frame->data;
+    return 0;
+}
+#endif /* NTSCSIM_AVFRAME_HAVE_LIBAV */
 
 #ifdef __cplusplus
 }

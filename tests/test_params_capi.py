@@ -285,3 +285,75 @@ def test_fast_kernel_plane_predicate_covers_the_displaced_range():
     for a, b in ((0, 1), (1, 2)):
         assert any(lib.ntscsim_debug_fast_plane_ok(n, W, H, a) and not lib.ntscsim_debug_fast_plane_ok(n, W, H, b)
                    for n in range(2500, 6200, 7)), (a, b)
+
+
+_GETBUF_SRC = r'''
+/* compile-and-run check of ntscsim_av_frame_get_buffer() WITHOUT libav: the four libavutil entry points it uses are
+ * given local definitions with libavutil's signatures for planar YUV 4:2:2 / BGRA only (a test double of our header's
+ * dependencies, not a libav build) */
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+enum AVPixelFormat { AV_PIX_FMT_YUV422P = 4, AV_PIX_FMT_BGRA = 28 };
+typedef struct AVBufferRef { uint8_t *data; int size; void (*free_)(void *, uint8_t *); void *opaque; } AVBufferRef;
+struct my_frame { uint8_t *data[8]; int linesize[8]; uint8_t **extended_data; int width, height; int format;
+                  int interlaced_frame, top_field_first; AVBufferRef *buf[8]; };
+#define FFALIGN(x, a) (((x) + (a) - 1) & ~((a) - 1))
+#define AVERROR(e) (-(e))
+static int av_image_fill_linesizes(int ls[4], enum AVPixelFormat f, int w)
+{ ls[0] = f == AV_PIX_FMT_BGRA ? 4 * w : w; ls[1] = ls[2] = f == AV_PIX_FMT_BGRA ? 0 : (w + 1) / 2; ls[3] = 0; return 0; }
+static int av_image_fill_pointers(uint8_t *d[4], enum AVPixelFormat f, int h, uint8_t *p, const int ls[4])
+{ int i, off = 0; (void)f; for (i = 0; i < 4; i++) { d[i] = (p && ls[i]) ? p + off : 0; off += ls[i] * h; } return off; }
+static AVBufferRef *av_buffer_create(uint8_t *data, int size, void (*fr)(void *, uint8_t *), void *opaque, int flags)
+{ AVBufferRef *b = (AVBufferRef *)malloc(sizeof(*b)); (void)flags; b->data = data; b->size = size; b->free_ = fr; b->opaque = opaque; return b; }
+static void av_buffer_unref(AVBufferRef **b) { if (*b) { (*b)->free_((*b)->opaque, (*b)->data); free(*b); *b = 0; } }
+#define NTSCSIM_AVFRAME_T struct my_frame
+#define NTSCSIM_AVFRAME_HAVE_LIBAV 1
+#include "ntscsim_avframe.h"
+int main(void) {
+    struct my_frame f = {{0}}, g = {{0}};
+    int r1, r2;
+    f.width = 720; f.height = 480; f.format = AV_PIX_FMT_YUV422P;
+    g.width = 720; g.height = 486; g.format = AV_PIX_FMT_BGRA;
+    r1 = ntscsim_av_frame_get_buffer(&f, 32);
+    r2 = ntscsim_av_frame_get_buffer(&g, 64);
+    printf("%d %d %d %d %d %ld %ld %d %d\n", r1, r2, f.linesize[0], f.linesize[1], g.linesize[0],
+           r1 ? 0L : (long)(f.data[1] - f.data[0]), r1 ? 0L : (long)(f.data[2] - f.data[1]),
+           r1 ? 0 : (int)((uintptr_t)f.data[0] & 4095), r1 ? 0 : (f.extended_data == f.data && f.buf[0]->data == f.data[0]));
+    if (!r1) av_buffer_unref(&f.buf[0]);
+    if (!r2) av_buffer_unref(&g.buf[0]);
+    return 0;
+}
+'''
+
+
+def _run_getbuf(tmp_path):
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "getbuf.c"
+    src.write_text(_GETBUF_SRC)
+    exe = tmp_path / "getbuf"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(L.ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", L.PKG, "-lntscsim", "-Wl,-rpath," + L.PKG])
+    return [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+
+
+def test_av_frame_get_buffer_helper_compiles_and_fails_cleanly_without_a_gpu(tmp_path):
+    """ntscsim_av_frame_get_buffer() (include/ntscsim_avframe.h): the one-token replacement for av_frame_get_buffer() at
+    ffmpeg_ntsc.cpp:351 / :2082.  Without a GPU pinned memory cannot be had: AVERROR(ENOMEM), nothing leaked; with one
+    (the -m gpu twin below) the layout is libavutil's."""
+    out = _run_getbuf(tmp_path)
+    assert out[0] in (0, -12) and out[1] in (0, -12)
+    assert out[2:5] == [736, 384, 2880]          # linesizes are filled either way (720 -> 736 at align 32; 360 -> 384; 4*720)
+
+
+@pytest.mark.gpu
+def test_av_frame_get_buffer_helper_layout_on_pinned_memory(tmp_path):
+    out = _run_getbuf(tmp_path)
+    assert out[:2] == [0, 0]
+    assert out[2:5] == [736, 384, 2880]
+    assert out[5] == 736 * 480 and out[6] == 384 * 480          # planes back to back, height padded to 32 rows (480 is)
+    assert out[7] == 0 and out[8] == 1                          # page aligned, buf[0] owns the block

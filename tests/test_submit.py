@@ -310,7 +310,7 @@ FIELD_LOOP = os.path.join(L.PKG, "field_loop")
 
 def _run_field_loop(mode, extra=()):
     r = subprocess.run([FIELD_LOOP, "-vhs", "--mode", mode, "--fields", "80", "--warmup", "0", "--hash", "1", "--depth", "8",
-                        "--rewrite-src", "1"] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                        "--rewrite-src", "1", "--ring", "40"] + list(extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()[-1500:]
     return json.loads(r.stdout.decode().strip().splitlines()[-1])
 
@@ -320,7 +320,9 @@ def _run_field_loop(mode, extra=()):
 def test_cpp_field_loop_allocators_pinned_pool_and_plain_malloc(bob):
     """VERDICT r05 item 2 for the BGRA tool: frames from ntscsim_host_frame_alloc() and frames carved from a pool that
     was declared with ntscsim_host_pin() take the no-copy path; posix_memalign'ed frames are staged (copy threads) under
-    the default policy and pinned in place only under the opt-in glibc policy.  Same frames in the same order."""
+    the default policy and pinned in place only under the opt-in glibc policy.  Same frames in the same order (the same
+    ring of 40 output frames in both modes: without the line doubling a frame keeps the other field's rows of its
+    previous use, and the hash covers whole frames)."""
     a = _run_field_loop("sync", ["--bob", bob])
     for alloc, pin, direct in (("malloc", "1", False), ("pinned", "1", True), ("pool", "1", True), ("malloc", "0", False)):
         b = _run_field_loop("submit", ["--bob", bob, "--alloc", alloc, "--pin", pin])
