@@ -33,8 +33,12 @@ struct CopyRec422 {               // rows src -> dst on the device side of the l
 };
 struct PadRec422 {                // the two bytes behind every row of the field (k422_pad)
     uint8_t *y;                   // luma plane of the device frame
-    const uint8_t *pad;           // [nrows][2], pinned host memory
+    const uint8_t *pad;           // [nrows][2], pinned host memory: the bytes as snapshotted at submit
+    const uint8_t *chain;         // TIGHT rows (linesize == width): luma plane of the device frame that holds the OTHER field as
+                                  // the previous iteration left it -- the two bytes behind row y are pixels 0, 1 of row y + 1
+                                  // (16 behind the frame's last row); NULL: take `pad`
     int32_t ls, W, field, nrows;
+    int32_t chain_ls, H;
 };
 
 // grid (row chunks, records): copy nrows rows of rowbytes bytes; records with nrows == 0 are skipped
@@ -57,9 +61,15 @@ __global__ void k422_pad(const PadRec422 *__restrict__ recs)
 {
     const PadRec422 r = recs[blockIdx.x];
     for (int k = threadIdx.x; k < r.nrows; k += blockDim.x) {
-        uint8_t *row = r.y + (size_t)r.ls * (size_t)(r.field + 2 * k);
-        row[r.W] = r.pad[2 * k];
-        row[r.W + 1] = r.pad[2 * k + 1];
+        const int y = r.field + 2 * k;
+        uint8_t *row = r.y + (size_t)r.ls * (size_t)y;
+        uint8_t a = r.pad[2 * k], b = r.pad[2 * k + 1];
+        if (r.chain) {
+            if (y + 1 < r.H) { const uint8_t *nx = r.chain + (size_t)r.chain_ls * (size_t)(y + 1); a = nx[0]; b = nx[1]; }
+            else { a = 16; b = 16; }
+        }
+        row[r.W] = a;
+        row[r.W + 1] = b;
     }
 }
 
@@ -99,6 +109,9 @@ struct Host422Engine {
         uint64_t ticket = 0;
         int slot = 0, fslot = 0, sslot = -1;
         bool serial = false;
+        bool tight = false;               // batched although linesize[0] < width + 2: the pad bytes are chained on the device
+        int chain_fslot = -1;             // device frame that holds the other field as the previous iteration left it (-1: none, snapshot)
+        uint64_t chain_ticket = 0;        // ... and the ticket of the iteration that wrote it
         ntscsim_loop422 it;
         Mirror *mfrm = nullptr, *mflt = nullptr;
         uint64_t rng_pos = 0;
@@ -111,6 +124,9 @@ struct Host422Engine {
         int frm_how = 0, flt_how = 0, out_how = 0;
     };
     std::vector<Item> pending;
+    // TIGHT rows: who wrote each field of a caller frame last, and into which device frame (see h422_submit)
+    struct Writer { const uint8_t *frame; uint64_t ticket[2]; int fslot[2]; };
+    std::vector<Writer> writers;
     struct Batch {
         uint64_t first = 0, last = 0;
         hipEvent_t done = nullptr;
@@ -127,6 +143,7 @@ struct Host422Engine {
     int src_cur = -1;
     uint64_t src_ring_pos = 0;
     std::vector<uint64_t> src_last_ticket;
+    uint64_t stats_two_pass = 0;           // launches that ran twice (TIGHT rows chained inside the launch)
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [0] submitted [1] launches [2] uploads [3] FAST [4] SERIAL [5] mirror uploads [6] iterations with a result written by the delivery kernels into pinned caller planes
 };
 
@@ -455,6 +472,13 @@ static int h422_launch(ntscsim_ctx *c)
     }
     std::vector<ntscsim_field422_desc> descs((size_t)n);
     bool any_pad = false, any_out = false;
+    // TIGHT rows whose other field is written by an iteration of THIS launch: the bytes behind their rows -- pixels 0, 1 of
+    // the neighbouring rows -- exist only after that iteration has run.  Nothing an iteration computes for pixels 0, 1
+    // of a row depends on the bytes behind ANY row (the separator's read :496 reaches the last positions of a row only;
+    // every later stage is causal in x up to the filters' few samples of delay), so: run the launch once, copy the bytes,
+    // run it again -- the second pass sees exactly what the in-order loop sees.  The GPU has the time (a launch is
+    // ~0.1 ms of kernels against ~1 ms of link traffic).
+    bool two_pass = false;
     bool al4 = (W2 & 3) == 0;
     size_t dn_need = e->dn_out;                      // bytes at the head of every delivery record that this launch fills
     bool any_staged = false, flt_staged = false;     // anything for the staging ring at all?
@@ -488,6 +512,9 @@ static int h422_launch(ntscsim_ctx *c)
         // caller's; the bytes were snapshotted at submit)
         PadRec422 &p = e->prec[it.slot];
         p.y = frm[0]; p.pad = e->pads + (size_t)2 * e->L * (size_t)it.slot; p.ls = fls[0]; p.W = W;
+        p.chain = (it.tight && it.chain_fslot >= 0) ? e->dfrm.p + e->fbytes * (size_t)it.chain_fslot + e->foff[0] : nullptr;
+        p.chain_ls = e->lsd[0]; p.H = H;
+        if (it.tight && it.chain_fslot >= 0 && it.chain_ticket >= b.first) two_pass = true;
         p.field = (int32_t)L.field; p.nrows = it.serial ? 0 : nr;
         any_pad = any_pad || !it.serial;
         // delivery: the field's rows of the frame (and of the filter frame) -> the delivery record
@@ -548,6 +575,14 @@ static int h422_launch(ntscsim_ctx *c)
     int rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
     c->rng_pos = keep_pos;
     if (rc != NTSCSIM_OK) return finish(rc);
+    if (two_pass) {
+        hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, st, e->prec + s0);
+        if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, st, e->prec);
+        rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
+        c->rng_pos = keep_pos;
+        if (rc != NTSCSIM_OK) return finish(rc);
+        e->stats_two_pass++;
+    }
     // Delivery -- output_frame's copy, the rows of the field, the download of what is staged -- runs on a stream of its own
     // behind the batch's kernels: the NEXT launch's kernels do not wait for it (batched iterations own their device frames
     // and delivery records).  An iteration on a mirror is different: the next one modifies the rows this one delivers from,
@@ -653,7 +688,13 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
     }
     const bool bkey = c->prm.black_key_level_feedback >= 0 && L->filter.data[0] != nullptr;
     // ---- FAST or SERIAL (see the head of this file)
-    bool serial = !have_src || bkey || L->frame.linesize[0] < W + 2;
+    // TIGHT rows (linesize[0] < width + 2: av_frame_get_buffer(f, 32) gives them to every width that is a multiple of 32):
+    // batched like padded ones, the two bytes behind each row chained on the device (h422_launch).  Narrow frames keep
+    // the in-order path: the argument that pixels 0, 1 of a row never depend on the bytes behind a row wants the filter
+    // delays (a dozen samples per Y/C pass) to be small against the width.
+    const bool tight = L->frame.linesize[0] < W + 2;
+    const bool chain_ok = tight && have_src && !bkey && W >= 128 && !(std::getenv("NTSCSIM_SUBMIT422_NOCHAIN"));
+    bool serial = !have_src || bkey || (tight && !chain_ok);
     int fslot = (int)(t % (uint64_t)e->ring);
     bool paired = false;
     if (!serial && !e->pending.empty()) {
@@ -676,7 +717,35 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
     it.slot = (int)(t % (uint64_t)e->ring);
     it.fslot = fslot;
     it.serial = serial;
+    it.tight = tight && !serial;
     it.it = *L;
+    {
+        // who wrote each field of this caller frame last (TIGHT rows chain on it; any iteration updates it)
+        Host422Engine::Writer *wr = nullptr;
+        for (auto &x : e->writers) if (x.frame == L->frame.data[0]) { wr = &x; break; }
+        if (!wr) {
+            if (e->writers.size() >= 64) e->writers.erase(e->writers.begin());
+            e->writers.push_back({L->frame.data[0], {0, 0}, {-1, -1}});
+            wr = &e->writers.back();
+        }
+        if (flags & NTSCSIM_SUBMIT422_DIRTY) { wr->ticket[0] = wr->ticket[1] = 0; }
+        const unsigned other = L->field ^ 1u;
+        if (it.tight) {
+            // the other field's rows as the in-order loop has them now: written by iteration wr->ticket[other] into device
+            // frame wr->fslot[other] -- still there while fewer than ring - 2 iterations have passed -- or, when this
+            // engine has not written them (first iterations, after a one-at-a-time iteration or a DIRTY), the caller's
+            // own bytes, snapshotted below
+            if (wr->ticket[other] != 0 && t - wr->ticket[other] + 2 < (uint64_t)e->ring) { it.chain_fslot = wr->fslot[other]; it.chain_ticket = wr->ticket[other]; }
+            else if (e->next_ticket - 1 > e->done_ticket) {
+                // snapshot of the caller's bytes: whatever is in flight lands in them first (start of a stream, after a
+                // one-at-a-time iteration; with alternating fields the chain never breaks afterwards)
+                rc = h422_wait_ticket(c, NTSCSIM_TICKET_ALL);
+                if (rc != NTSCSIM_OK) return rc;
+            }
+        }
+        if (serial) { wr->ticket[0] = wr->ticket[1] = 0; }      // the frame moves on in the caller's memory (mirror path)
+        else { wr->ticket[L->field] = t; wr->fslot[L->field] = fslot; }
+    }
     // pinned caller frames: results are written in place by the delivery kernels
     (void)h422_pin_frame(c, e, L->frame, W, H, H, it.frm_dev);
     if (bkey) (void)h422_pin_frame(c, e, L->filter, W, H, H, it.flt_dev);
@@ -702,8 +771,11 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
         uint8_t *pad = e->pads + (size_t)2 * e->L * (size_t)it.slot;
         const int nr = h422_field_rows(H, L->field);
         for (int k = 0; k < nr; k++) {
-            const uint8_t *row = L->frame.data[0] + (size_t)L->frame.linesize[0] * (size_t)(L->field + 2 * k);
-            pad[2 * k] = row[W]; pad[2 * k + 1] = row[W + 1];
+            const int y = (int)L->field + 2 * k;
+            const uint8_t *row = L->frame.data[0] + (size_t)L->frame.linesize[0] * (size_t)y;
+            // (behind the last row of a TIGHT plane lies nothing of the caller's: the contract's value 16)
+            const bool inside = !it.tight || (size_t)L->frame.linesize[0] * (size_t)y + (size_t)W + 1 < (size_t)L->frame.linesize[0] * (size_t)H;
+            pad[2 * k] = inside ? row[W] : 16; pad[2 * k + 1] = inside ? row[W + 1] : 16;
         }
     }
     // ---- source snapshot

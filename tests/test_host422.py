@@ -269,6 +269,53 @@ def test_tight_rows_run_in_order_on_a_mirror(mode):
     assert st[4] == 10 and st[3] == 0 and st[5] == 1          # serial; the frame went up once
 
 
+@pytest.mark.parametrize("mode,depth,lag", [("sync", 8, None), ("submit", 8, None), ("submit", 3, None), ("submit", 8, 0), ("submit", 5, 2)])
+@pytest.mark.parametrize("flags,w,h,out_mode,il", [
+    (["-vhs"], 256, 36, OUT_BOB420, False),
+    (["-vhs", "-vhs-speed", "ep"], 128, 35, OUT_BOB422, False),
+    ([], 160, 36, OUT_BOB420, False),                       # the tool's default preset
+    (["-vhs", "-yc-recomb", "2"], 256, 34, OUT_BOB422, False),
+    (["-vhs"], 256, 36, OUT_INT420, True),                  # -vi: the repack reads both fields of the shared device frame
+    (["-vhs", "-tvstd", "pal"], 192, 40, OUT_BOB420, False),
+])
+def test_tight_rows_are_batched_with_the_pad_bytes_chained_on_the_device(flags, w, h, out_mode, il, mode, depth, lag):
+    """linesize == width at a width of >= 128: the two bytes behind each row are pixels 0, 1 of the NEXT row -- the other
+    field's, as the previous iteration left them (:496) -- and that iteration may be in the same launch.  The engine
+    runs such a launch twice with the bytes copied in between (pixels 0, 1 of a row never depend on the bytes behind a
+    row); whole buffers equal the oracle's in-order loop, whatever the depth and wherever the waits fall."""
+    p = L.make_params_tocomp(flags + ["-width", str(w)], output_height=h)
+    st = run_loop(p, w, h, 0, 7, out_mode, mode, depth=depth, interlaced_out=il, lag=lag)
+    if mode == "submit" and lag is None:
+        assert st[3] == 14 and st[4] == 0, st               # batched, none one at a time
+        assert st[1] <= 14 // depth + 2
+
+
+def test_tight_rows_chain_survives_a_dirty_frame_and_a_one_at_a_time_iteration():
+    """the chain of pad bytes breaks where the caller rewrites the frame (DIRTY) or an iteration without a source runs in
+    order on the mirror -- the next tight iteration snapshots the caller's own bytes again"""
+    w, h = 256, 36
+    p = L.make_params_tocomp(["-vhs", "-width", str(w)], output_height=h)
+    srcs = sources(6, w, h)
+    frame_o = L.yuv_noise(w, h, 9, 0)
+    frame_g = frame_o.copy()
+    o = L.TocompOracleStream(p, oob=L.OOB_PLANE)
+    ctx = Ctx(p, depth=4)
+    for vf in range(12):
+        field = (vf & 1) ^ 1
+        s_ = srcs[vf // 2] if vf != 7 else None              # iteration 7: no source -> in order on the mirror
+        if vf == 4:
+            ctx.wait()
+            for fr in (frame_o, frame_g):
+                fr.pix(0)[3:9, 0:40] = 77
+        oracle_iteration(o, p, frame_o, s_, field, vf, F_SECOND if vf & 1 else 0, None, None, 0, field)
+        ctx.submit(ctx.loop(frame_g, s_, field, vf, F_SECOND if vf & 1 else 0), _capi.SUBMIT422_DIRTY if vf == 4 else 0)
+    ctx.wait()
+    st = ctx.stats()
+    assert ctx.rng_pos == o.rng_pos and st[4] == 1 and st[3] == 11, st
+    ctx.close()
+    same_frames(frame_g, frame_o, "frame")
+
+
 @pytest.mark.parametrize("mode", ["sync", "submit"])
 def test_black_key_feedback_recurrence(mode):
     w, h = 96, 36
@@ -437,7 +484,8 @@ def run_cpp(mode, flags, fields=60, depth=8, extra=(), env=None):
     (["-vhs", "-vi"], [], True),                            # interlaced 4:2:0 repack after every pair
     (["-vhs", "-vi", "-422"], [], True),                    # the frame itself (:1158) as NTSCSIM_OUT422_FRAME
     ([], ["--height", "120"], True),                        # the tool's default preset
-    (["-vhs", "-width", "704"], ["--height", "96"], False),  # linesize == width: in order, on the mirror
+    (["-vhs", "-width", "704"], ["--height", "96"], True),  # linesize == width: batched, pad bytes chained on the device
+    (["-vhs", "-width", "96"], ["--height", "96"], False),  # ... narrow and tight: in order, on the mirror
     (["-422", "-bkey-feedback", "40"], ["--height", "96"], False),
 ])
 def test_cpp_loop_submit_equals_sync(flags, extra, batched):
