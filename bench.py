@@ -221,9 +221,10 @@ def main():
     ap.add_argument("--tool", default="ntsc", choices=["ntsc", "to_composite"],
                     help="ntsc = ffmpeg_ntsc's composite_layer on BGRA (BASELINE's metric, default); "
                          "to_composite = the 8-bit YUV422P sibling (ffmpeg_to_composite)")
-    ap.add_argument("--mode", default="exact", choices=["exact", "fast32"],
-                    help="exact = bit-identical to the reference (fp64, default); fast32 = fp32 "
-                         "filters within the tolerance of tests/test_gpu_fast_mode.py")
+    ap.add_argument("--mode", default="exact", choices=["exact", "fast32", "float"],
+                    help="exact = bit-identical to the reference (fp64, default); fast32 = the exact kernels with fp32 "
+                         "filter states; float = the all-float pipeline (csrc/ntsc_float.hip); both within the "
+                         "tolerance of tests/test_gpu_fast_mode.py")
     ap.add_argument("--dist-backend", default="nccl",
                     help="torch.distributed backend (nccl = RCCL; gloo only for dry runs of the "
                          "multi-rank path on a box with fewer GPUs than ranks)")
@@ -293,8 +294,8 @@ def main():
         ctxs = []
         for q in range(nq):
             sm = ntscsim.FieldSimulator(params=params, device=local_rank)
-            if args.mode == "fast32":
-                sm.set_mode(ntscsim._capi.MODE_FAST32)
+            if args.mode != "exact":
+                sm.set_mode(ntscsim._capi.MODE_FAST32 if args.mode == "fast32" else ntscsim._capi.MODE_FLOAT)
             plans, dsts = [], []
             for (first, stride, nloc, jobs) in clips:
                 src = build.src.setdefault((first, stride, nloc), make_bars_clip(torch, nloc, w, h, first, stride, dev))
@@ -476,11 +477,12 @@ def main():
                     "rank's share on its own GPU after the timed region and got the same sums",
                 "mode": "exact (bit-identical to the reference: fp64, no FMA contraction)"
                         if args.mode == "exact" else
-                        "fast32 (fp32 filters; <= 1 LSB per 8-bit channel vs the reference)",
+                        ("fast32 (fp32 filters; <= 1 LSB per 8-bit channel vs the reference)" if args.mode == "fast32" else
+                         "float (all-float pipeline; <= 1 LSB per 8-bit channel vs the reference)"),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_decode",
+                "kernel": "k_decode" if args.mode != "float" else "k_decode_fp",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

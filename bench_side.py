@@ -436,6 +436,44 @@ def extras(torch, ntscsim, dev, local_rank, args):
                         "threads; 48 steps, best of 2" % (w, h, args.preset, 2 * args.frames, args.inflight)}
     except Exception as e:
         out["device_stream"] = {"error": repr(e)}
+    # ---- the tolerance modes on the headline workload (never the default): the all-float pipeline and FAST32
+    try:
+        from ntscsim import shard as _sh, _capi as _cc
+        def mode_rate(mode):
+            jobs = _sh.jobs_for_rank(params, w, h, 2 * args.frames, 0, 1)
+            srcm = make_bars_clip(torch, args.frames, w, h, 0, 1, dev)
+            locm = [(cur // 2, cur // 2, field, fieldno) for (cur, field, fieldno, _) in jobs]
+            sims, plans, keep, streams = [], [], [], []
+            for _ in range(args.inflight):
+                sm = ntscsim.FieldSimulator(params=params, device=local_rank)
+                sm.set_mode(mode)
+                d = torch.zeros((args.frames, h, w, 4), dtype=torch.uint8, device=dev)
+                plans.append(sm.prepare(sm.build_descs(srcm, d, locm, rng_pos=[j[3] for j in jobs]), w, h))
+                sims.append(sm); keep.append(d); streams.append(torch.cuda.Stream(dev))
+            def stepm(i):
+                q = i % args.inflight
+                sims[q].run_prepared(plans[q], stream=streams[q].cuda_stream)
+            for i in range(4 * args.inflight):
+                stepm(i)
+            dtm = time_steps(torch, dev, stepm, 60)
+            sims[0].set_profiling(True)
+            for _ in range(5):
+                sims[0].run_prepared(plans[0], stream=streams[0].cuda_stream)
+            torch.cuda.synchronize(dev)
+            tmm = sims[0].timings_ms()
+            kern = sims[0].last_kernels()
+            for sm, pl in zip(sims, plans):
+                sm.free_prepared(pl); sm.close()
+            dec_ms = tmm["decode"] / max(1, tmm["calls"])
+            algb = 8.0 * w * ((ntscsim.field_rows(h, 0) + ntscsim.field_rows(h, 1)) / 2.0) * len(jobs)
+            return {"value": len(jobs) / dtm, "unit": "frames/s", "ms_per_step": dtm * 1e3, "decode_kernel_ms": dec_ms,
+                    "roofline_frac": algb / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dec_ms > 0 else None,
+                    "kernels": [k_ for k_ in kern if k_.startswith(("k_enc", "k_dec"))]}
+        out["fast"] = mode_rate(_cc.MODE_FLOAT)
+        out["fast"]["mode"] = "float (all-float pipeline, <= 1 LSB; tests/test_gpu_fast_mode.py)"
+        out["fast32"] = mode_rate(_cc.MODE_FAST32)
+    except Exception as e:
+        out["fast"] = {"error": repr(e)}
     # ---- other sizes / presets on the BGRA path
     out["sizes"] = {
         "1920x1080": {"value": device_rate(torch, ntscsim, dev, local_rank, args.preset.split(), 1920, 1080, 136, 8, args.inflight),

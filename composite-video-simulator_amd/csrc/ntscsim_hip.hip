@@ -24,6 +24,7 @@
 #include "ntsc422_kernels.hip"
 #include "ntsc422_fused.hip"
 #include "ntsc_scale.hip"
+#include "ntsc_float.hpp"       // NTSCSIM_MODE_FLOAT: its kernels are a translation unit of their own
 
 using namespace ntscsim;
 
@@ -153,6 +154,11 @@ struct ntscsim_ctx {
                       hipEvent_t up = nullptr, done = nullptr, down = nullptr; };
     HostSlot hslot[2];
     hipStream_t s_up = nullptr, s_dn = nullptr;
+    // ntscsim_field(): the source rows go up on s_up while the setup kernel (which does not read pixels) runs on the ctx's
+    // stream; the encoder waits for `ev_src` (launch_records)
+    hipEvent_t ev_src = nullptr;
+    bool src_pending = false;
+    hipEvent_t ev_role[3] = {nullptr, nullptr, nullptr};      // NTSCSIM_ROLE_PROBE (timing probe, see launch_records)
 
     // profiling: five events per call (start | setup done | encode done | decode done | end),
     // recorded on the launch stream; summed and recycled by ntscsim_get_timings_ms()
@@ -422,6 +428,8 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
         if (h.done) (void)hipEventDestroy(h.done);
         if (h.down) (void)hipEventDestroy(h.down);
     }
+    if (c->ev_src) (void)hipEventDestroy(c->ev_src);
+    for (auto &e_ : c->ev_role) if (e_) (void)hipEventDestroy(e_);
     if (c->s_up) (void)hipStreamDestroy(c->s_up);
     if (c->s_dn) (void)hipStreamDestroy(c->s_dn);
     for (int i = 0; i < 2; i++) {
@@ -475,7 +483,7 @@ extern "C" int ntscsim_get_timings_ms(ntscsim_ctx *c, float out_ms[4], int *n_ca
 
 extern "C" int ntscsim_set_mode(ntscsim_ctx *c, int mode)
 {
-    if (!c || (mode != NTSCSIM_MODE_EXACT && mode != NTSCSIM_MODE_FAST32)) return NTSCSIM_E_ARG;
+    if (!c || (mode != NTSCSIM_MODE_EXACT && mode != NTSCSIM_MODE_FAST32 && mode != NTSCSIM_MODE_FLOAT)) return NTSCSIM_E_ARG;
     c->mode = mode;
     return NTSCSIM_OK;
 }
@@ -679,11 +687,20 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
 
     c->kernels.clear();
     launch_setup(c, D, G, fields_dev, n, st);
+    if (c->src_pending) {          // ntscsim_field(): the pixels were uploaded beside the setup kernel
+        c->src_pending = false;
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_src, 0));
+    }
     if (evs) HIPCHK(c, hipEventRecord(evs->e[1], st));
+    // NTSCSIM_ROLE_PROBE=1 (developer timing probe, WRONG pixels): with the two-launch VHS form selected
+    // (ntscsim_debug_no_fast_decode bit 1) the three roles of a field -- encoder, VCR half, TV half -- are launched side
+    // by side on three streams with no dependency between them: the time of a call is then what a perfectly pipelined
+    // three-role workgroup could reach at best (tools/role_probe.py, profiles/r06_role_probe.txt)
+    static const bool role_probe = std::getenv("NTSCSIM_ROLE_PROBE") && std::getenv("NTSCSIM_ROLE_PROBE")[0] == '1';
     // PRESET kernels (options folded at compile time) when the parameters match the default
     // preset or the full -vhs preset exactly; otherwise the GENERIC kernels.  Same results.
     const bool enc_preset = !c->force_generic && D.in_lp && !D.pre_on && D.noise_k != 0 && D.amp == 50;
-    const bool fast = c->mode == NTSCSIM_MODE_FAST32;
+    const bool fast = c->mode != NTSCSIM_MODE_EXACT;          // float filter states (FAST32; FLOAT's fallback for other switch sets)
 #define NTSC_LAUNCH_ENCODE(F, RT)                                                               \
     do { note_kernel(c, ("k_encode<" + std::to_string((unsigned)(F)) + "u," #RT ">").c_str());  \
     hipLaunchKernelGGL((k_encode<F, RT>), dim3((D.R + 63) / 64), dim3(64), 0, st, D,             \
@@ -700,7 +717,16 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     for (int k = 0; k < D.ghost_taps; k++) ghost_fused = ghost_fused && D.ghost_delay[k] < NTSC_GHOST_RING;
     ghost_fused = ghost_fused && enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 &&
                   D.noise_k <= (1 << 20);
-    if (ghost_fused) {
+    // NTSCSIM_MODE_FLOAT: the all-float pipeline (ntsc_float.hip) for the default preset and the -vhs family with its
+    // standard switches -- encoder AND decoder (the plane between them holds floats); anything else runs the FAST32 forms
+    const bool fp = c->mode == NTSCSIM_MODE_FLOAT && enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 &&
+                    D.ghost_taps == 0 && !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small &&
+                    !c->split_vhs &&
+                    ((D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) || (!D.vhs && !D.cnoise_k && !D.pnoise_k));
+    if (fp) {
+        note_kernel(c, "k_encode_fp");
+        launch_encode_fp(st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
+    } else if (ghost_fused) {
         const bool two = D.ghost_taps <= 2;
         note_kernel(c, (std::string("k_encode_fast_gh<") + (fast ? "float," : "double,") + (two ? "2>" : "4>")).c_str());
 #define NTSC_LAUNCH_GH(RT, GT)                                                                  \
@@ -777,26 +803,44 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_decode_fast<true, RT, true>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
-    if (dec_fast && back50 && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
+    if (fp) {
+        note_kernel(c, D.vhs ? "k_decode_fp<true>" : "k_decode_fp<false>");
+        static const int fpv = std::getenv("NTSCSIM_FP_VARIANT") ? std::atoi(std::getenv("NTSCSIM_FP_VARIANT")) : 0;    // developer A/B switch
+        launch_decode_fp(st, D, G, fields_dev, dec_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
+                         c->dropout.p, c->tails.p, fpv);
+    } else if (dec_fast && back50 && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {
         // VCR half -> second composite plane -> TV half (= the non-VHS decoder without head switching)
         HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
         note_kernel(c, fast ? "k_vcr_front<float>" : "k_vcr_front<double>");
         note_kernel(c, fast ? "k_decode_fast<false,float>" : "k_decode_fast<false,double>");
-        if (fast) hipLaunchKernelGGL((k_vcr_front<float>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+        hipStream_t sv = st, stv = st;
+        if (role_probe) {
+            // the encoder is on `st` already; the two decoder halves start when the setup kernel has finished, beside it
+            if (!c->s_up) HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+            if (!c->s_dn) HIPCHK(c, hipStreamCreateWithFlags(&c->s_dn, hipStreamNonBlocking));
+            for (auto &e_ : c->ev_role) if (!e_) HIPCHK(c, hipEventCreateWithFlags(&e_, hipEventDisableTiming));
+            sv = c->s_up; stv = c->s_dn;
+            if (evs) { HIPCHK(c, hipStreamWaitEvent(sv, evs->e[1], 0)); HIPCHK(c, hipStreamWaitEvent(stv, evs->e[1], 0)); }
+        }
+        if (fast) hipLaunchKernelGGL((k_vcr_front<float>), dgrid, dim3(64), 0, sv, D, G, fields_dev, dec_in,
                                      c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                      c->pn_noise.p, c->tails.p);
-        else hipLaunchKernelGGL((k_vcr_front<double>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in,
+        else hipLaunchKernelGGL((k_vcr_front<double>), dgrid, dim3(64), 0, sv, D, G, fields_dev, dec_in,
                                 c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                 c->pn_noise.p, c->tails.p);
         DevParams D2 = D;
         D2.hs = 0;
         const int *tv_in = c->comp_vcr.p;
-        if (fast) hipLaunchKernelGGL((k_decode_fast<false, float>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
+        if (fast) hipLaunchKernelGGL((k_decode_fast<false, float>), dgrid, dim3(64), 0, stv, D2, G, fields_dev,
                                      tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                      c->pn_noise.p, c->dropout.p, c->tails.p);
-        else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, st, D2, G, fields_dev,
+        else hipLaunchKernelGGL((k_decode_fast<false, double>), dgrid, dim3(64), 0, stv, D2, G, fields_dev,
                                 tv_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,
                                 c->pn_noise.p, c->dropout.p, c->tails.p);
+        if (role_probe) {
+            HIPCHK(c, hipEventRecord(c->ev_role[0], sv)); HIPCHK(c, hipEventRecord(c->ev_role[1], stv));
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_role[0], 0)); HIPCHK(c, hipStreamWaitEvent(st, c->ev_role[1], 0));
+        }
     } else if (!c->force_generic && !D.nocolor && D.out_lp == 2 && D.amp == 50 && back50 && !c->no_fast_decode && D.dst_al16 &&
                even_phase && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0)) {
         // the -vhs family with the FULL output chroma low-pass
@@ -1519,17 +1563,24 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     const int opposite = src_interlaced ? (src_tff ? 1 : 0) : 0;
     const int first = (int)field + opposite, Lf = (H - (int)field + 1) / 2;
     const int direct = first <= H - 1 ? (H - 1 - first) / 2 + 1 : 0;      // rows first, first + 2, ... <= H - 1
+    // The rows travel on a copy stream of their own: the first kernel of the chain (rand() states, head-switch geometry)
+    // does not read pixels and runs beside the upload; the encoder waits for `ev_src` (launch_records).
+    if (!c->s_up) HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
+    if (!c->ev_src) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
+    const hipStream_t su = c->s_up;
     if (full_upload || Lf <= 0) {
         HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p, pitch, src, (size_t)src_ls, (size_t)W * 4, (size_t)H,
-                                   hipMemcpyHostToDevice, c->stream));
+                                   hipMemcpyHostToDevice, su));
     } else {
         if (direct > 0)
             HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p + pitch * first, pitch * 2, src + (size_t)src_ls * first, (size_t)src_ls * 2,
-                                       (size_t)W * 4, (size_t)(direct < Lf ? direct : Lf), hipMemcpyHostToDevice, c->stream));
+                                       (size_t)W * 4, (size_t)(direct < Lf ? direct : Lf), hipMemcpyHostToDevice, su));
         if (direct < Lf)      // the clamped last row
             HIPCHK(c, hipMemcpyAsync(c->fsrc.p + pitch * (H - 1), src + (size_t)src_ls * (H - 1), (size_t)W * 4,
-                                     hipMemcpyHostToDevice, c->stream));
+                                     hipMemcpyHostToDevice, su));
     }
+    HIPCHK(c, hipEventRecord(c->ev_src, su));
+    c->src_pending = true;
     ntscsim_field_desc d;
     std::memset(&d, 0, sizeof(d));
     d.src_dev = c->fsrc.p; d.dst_dev = c->fdst.p;
@@ -1539,7 +1590,7 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     d.fieldno = fieldno;
     d.rng_pos = NTSCSIM_RNG_AUTO;
     int rc = ntscsim_fields_device(c, &d, 1, W, H, c->stream);
-    if (rc != NTSCSIM_OK) return rc;
+    if (rc != NTSCSIM_OK) { c->src_pending = false; (void)hipStreamSynchronize(su); return rc; }
     // only the rows of this field are written back (:1910-1916)
     const int L = (H - (int)field + 1) / 2;
     if (L > 0)

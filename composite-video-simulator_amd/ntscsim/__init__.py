@@ -64,7 +64,7 @@ class FieldSimulator:
             raise NtscsimError(rc, "%s: %s" % (what, self._lib.ntscsim_last_error(self._h).decode()))
 
     def set_mode(self, mode):
-        """_capi.MODE_EXACT (default, bit-identical to the reference) or _capi.MODE_FAST32."""
+        """_capi.MODE_EXACT (default, bit-identical to the reference), _capi.MODE_FAST32 or _capi.MODE_FLOAT."""
         self._chk(self._lib.ntscsim_set_mode(self._h, int(mode)), "ntscsim_set_mode")
 
     # ---- rand() stream position -----------------------------------------------------------

@@ -14,7 +14,7 @@ PRODUCT_SO = os.environ.get("NTSCSIM_LIB") or os.path.join(PKG_DIR, "libntscsim.
 OK, E_ARG, E_SIZE, E_NODEV, E_HIP, E_NOMEM, E_PARAM, E_FLAG, E_HELP, E_INTERNAL = \
     0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 RNG_AUTO = 0xFFFFFFFFFFFFFFFF
-MODE_EXACT, MODE_FAST32 = 0, 1
+MODE_EXACT, MODE_FAST32, MODE_FLOAT = 0, 1, 2
 DESC_INTERLACED, DESC_TFF, DESC_BOB = 1, 2, 0x100
 SUBMIT_SAME_SRC, SUBMIT_SRC_STABLE = 0x10000, 0x20000
 TICKET_ALL = 0xFFFFFFFFFFFFFFFF

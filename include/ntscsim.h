@@ -185,8 +185,15 @@ const char *ntscsim_last_error(const ntscsim_ctx *ctx); /* text of the last HIP 
  *                       the colour matrices and the phase rotation in fp32 (FMA allowed).  Output
  *                       differs from the reference by at most 1 LSB per 8-bit channel on a small
  *                       fraction of pixels (bounds in tests/test_gpu_fast_mode.py).
+ *   NTSCSIM_MODE_FLOAT:  the tolerance mode as a pipeline of its own (csrc/ntsc_float.hip): Y / I / Q and the composite
+ *                       sample are fp32 from RGB -> YIQ to YIQ -> RGB -- no inter-stage (int), no int <-> float
+ *                       conversion of the signal, FMA contraction on -- while the rand() stream, the noise accumulators,
+ *                       head-switch geometry, phase-noise table and dropout stay the exact mode's integers.  Same stated
+ *                       tolerance as FAST32 (at most 1 LSB per 8-bit channel; bounds and the measured share of exact
+ *                       pixels in tests/test_gpu_fast_mode.py).  Default preset and the -vhs family with its standard
+ *                       switches; other switch sets run the FAST32 forms in this mode.
  */
-enum { NTSCSIM_MODE_EXACT = 0, NTSCSIM_MODE_FAST32 = 1 };
+enum { NTSCSIM_MODE_EXACT = 0, NTSCSIM_MODE_FAST32 = 1, NTSCSIM_MODE_FLOAT = 2 };
 int ntscsim_set_mode(ntscsim_ctx *ctx, int mode);
 
 /* Stream position of the next field processed through ntscsim_field() (starts at 0, advances

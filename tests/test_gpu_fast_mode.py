@@ -56,6 +56,106 @@ def test_fast32_within_stated_tolerance(flags, w, h, n, kind):
     sim.close()
 
 
+# ---- NTSCSIM_MODE_FLOAT: the all-float pipeline (csrc/ntsc_float.hip) ------------------------------------------------
+# Stated tolerance: every channel of every pixel within +-1 LSB, on every input.  How many pixels differ at all depends on
+# the input: every dropped `(int)` is worth a uniform +-1/2 of 1/256 of an output step on natural / noisy pictures (mean
+# compensated: measured mean signed difference < 0.002 LSB per channel) -- 0.5 % of the channels, 1.5 % of the pixels --
+# but FLAT colour (bars) is the reference's worst case for truncation: its filters converge towards integers from one
+# side, so `(int)` takes a whole unit off for hundreds of samples where the float pipeline keeps the fraction.
+# Measured (tools/float_err.py, profiles/r06_float_err.txt): noise 1.2-1.5 % of the pixels, ramps 2.6 %, -vhs bars
+# 2.7-4 %, default-preset bars 7 %.  rand() stream, noise accumulators, head-switch geometry, dropout rows: identical.
+FLOAT_MAX_FRACTION = {"noise": 0.02, "ramp": 0.035, "bars": 0.08}
+
+
+def _ramp(w, h):
+    x = np.arange(w)[None, :]
+    y = np.arange(h)[:, None]
+    fr = np.zeros((h, w, 4), np.uint8)
+    fr[..., 0] = x * 255 // max(1, w - 1)
+    fr[..., 1] = y * 255 // max(1, h - 1)
+    fr[..., 2] = (x + y) * 255 // (w + h - 2)
+    return fr
+
+
+@pytest.mark.parametrize("flags,w,h,n,kind,fp", [
+    ([], 720, 486, 4, "bars", True), ([], 720, 486, 2, "noise", True),
+    (["-vhs"], 720, 486, 4, "bars", True), (["-vhs"], 720, 486, 4, "noise", True), (["-vhs"], 720, 486, 2, "ramp", True),
+    (["-vhs", "-vhs-speed", "ep"], 720, 480, 2, "noise", True), (["-vhs", "-vhs-speed", "lp"], 704, 480, 2, "noise", True),
+    (["-vhs"], 1920, 1080, 2, "noise", True), (["-vhs"], 3840, 2160, 2, "noise", True),
+    # geometries whose rows are all row start / row end (the guarded steps), the head switch inside the frame
+    (["-vhs"], 36, 17, 4, "noise", True), (["-vhs"], 100, 31, 4, "noise", True), ([], 20, 9, 4, "noise", True),
+    (["-vhs"], 33, 17, 4, "noise", False),            # rows that are not 16-byte aligned: the FAST32 forms
+    (["-vhs", "-vhs-head-switching-point", "0.8"], 360, 244, 4, "noise", True),
+    # switch sets outside the float forms run the FAST32 kernels in this mode
+    (["-vhs", "-vhs-svideo", "1"], 360, 240, 2, "noise", False), (["-vhs", "-comp-phase", "90"], 360, 240, 2, "noise", False),
+])
+def test_float_pipeline_within_stated_tolerance(flags, w, h, n, kind, fp):
+    import torch
+    p = L.make_params(flags)
+    srcs = [L.noise_frame(w, h, 5 + j) if kind == "noise" else (L.bars(w, h, j) if kind == "bars" else _ramp(w, h))
+            for j in range((n + 1) // 2)]
+    o = L.OracleStream(p)
+    exp = np.full((n, h, w, 4), 0x77, np.uint8)
+    for k in range(n):
+        o.field(exp[k], srcs[k // 2], (k & 1) ^ 1, k)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.set_mode(_capi.MODE_FLOAT)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.full((n, h, w, 4), 0x77, dtype=torch.uint8, device="cuda")
+    sim.fields(src, dst, [(k // 2, k, (k & 1) ^ 1, k) for k in range(n)])
+    sim.sync()
+    assert sim.rng_pos == o.rng_pos
+    kern = sim.last_kernels()
+    if fp:
+        assert "k_encode_fp" in kern and ("k_decode_fp<true>" if "-vhs" in flags else "k_decode_fp<false>") in kern, kern
+    else:
+        assert not any(k_.endswith("_fp") or "_fp<" in k_ for k_ in kern), kern
+    got = dst.cpu().numpy()
+    d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+    assert d.max() <= MAX_ABS
+    limit = FLOAT_MAX_FRACTION[kind] if fp else MAX_FRACTION_DIFFERENT
+    if w < 64:
+        limit = 0.06            # (a handful of pixels per row: the share is noisy)
+    for k in range(n):
+        field = (k & 1) ^ 1
+        assert (got[k][1 - field::2] == 0x77).all()           # other field's rows untouched
+        assert not got[k][field::2, :, 3].any()                # alpha 0
+        frac = (d[k][field::2].max(axis=-1) > 0).mean()
+        assert frac <= limit, (k, frac)
+        # the compensated luma bias: no channel is off on average
+        sd = (got[k][field::2, :, :3].astype(np.int16) - exp[k][field::2, :, :3].astype(np.int16))
+        if kind != "bars" and w >= 360:
+            assert abs(sd.mean()) < 0.004, sd.mean()
+    sim.close()
+
+
+def test_float_mode_through_the_host_call_and_the_submit_engine():
+    """the mode is the ctx's: ntscsim_field() and ntscsim_submit() lanes run the float pipeline too, same bytes as the
+    device-resident batch"""
+    import torch
+    w, h = 720, 486
+    p = L.make_params(["-vhs"])
+    srcs = [L.noise_frame(w, h, 40 + j) for j in range(2)]
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.set_mode(_capi.MODE_FLOAT)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.zeros((4, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, dst, [(k // 2, k, (k & 1) ^ 1, k) for k in range(4)])
+    sim.sync()
+    ref = dst.cpu().numpy()
+    sim.rng_pos = 0
+    one = np.zeros((4, h, w, 4), np.uint8)
+    for k in range(4):
+        sim.field_host(one[k], srcs[k // 2], (k & 1) ^ 1, k)
+    assert np.array_equal(one, ref)
+    sim.rng_pos = 0
+    two = np.zeros((4, h, w, 4), np.uint8)
+    ts = [sim.submit(two[k], srcs[k // 2], (k & 1) ^ 1, k) for k in range(4)]
+    sim.wait(ts[-1])
+    assert np.array_equal(two, ref)
+    sim.close()
+
+
 def test_mode_switch_roundtrip():
     """EXACT after FAST32 on the same ctx is bit-exact again."""
     import torch
@@ -68,6 +168,8 @@ def test_mode_switch_roundtrip():
     src = torch.from_numpy(s[None]).cuda()
     dst = torch.zeros((1, h, w, 4), dtype=torch.uint8, device="cuda")
     sim.set_mode(_capi.MODE_FAST32)
+    sim.fields(src, dst, [(0, 0, 1, 0)], rng_pos=[0])
+    sim.set_mode(_capi.MODE_FLOAT)
     sim.fields(src, dst, [(0, 0, 1, 0)], rng_pos=[0])
     sim.set_mode(_capi.MODE_EXACT)
     dst.zero_()
