@@ -835,6 +835,296 @@ __global__ __launch_bounds__(64, VHS ? WAVES : 4) void k_decode_fp(DevParams P, 
     }
 }
 
+// ================================================================================================ k_decode_fp2
+// The -vhs decoder as a TWO-ROLE workgroup: wave 0 runs the VCR half of its 63 rows (+ halo), wave 1 the TV half of the
+// same rows, and the VCR's composite output travels through an LDS ring instead of living in one wave's registers.
+// Why: the one-wave form needs ~196 VGPRs (two waves per SIMD) and its waves spend most of their cycles stalled on their
+// own dependency chains (profiles/r06_float_pmc.txt); the two roles need ~half the registers each, so twice as many
+// waves fit a SIMD, and a field's rows are worked on by two instruction streams instead of one.
+//   ring slot of sample x2: (x2 & (NSLOT - 1)), one column per lane;
+//   sync[0] = samples published by the VCR role, sync[1] = samples consumed by the TV role (both monotonic);
+//   the VCR role publishes after every group of samples behind a workgroup-scope release (LDS operations of one wave
+//   are performed in order; the fence keeps the compiler from moving the counter store in front of the samples) and
+//   waits while the ring is full; the TV role waits until what it is about to read has been published.
+namespace fpipe {
+
+constexpr int NSLOT = 32;
+
+DEV int lds_peek(const volatile uint32_t *p) { return __builtin_amdgcn_readfirstlane((int)*p); }
+DEV void lds_wait_ge(const volatile uint32_t *p, int v, int &cached)
+{
+    if (cached >= v) return;
+    int seen = lds_peek(p);
+    while (seen < v) { __builtin_amdgcn_s_sleep(2); seen = lds_peek(p); }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    cached = seen;
+}
+DEV void lds_publish(volatile uint32_t *p, int v)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    *p = (uint32_t)v;
+}
+
+// ---- wave 0: the VCR half (vcr_edge / vcr_step as in the one-wave form), output x2 = t - (7 + d) into the ring
+template <int DPH>
+DEV int vcr_steady(const DevParams &P, State<true> &S, const Const &C, uint32_t *ring, uint32_t *c2col, volatile uint32_t *sync,
+                   int &cons_seen, int t, int SK1)
+{
+    const int t_end = C.W - (C.d > 7 ? C.d - 7 : 0);
+    const int LOFF = C.LOFF, lane = C.lane;
+    if (t + 4 > t_end || (S.rng.pos & 7)) return t;
+    Steady T;
+    T.D1.from(S.D1, (DPH & 1) != 0);
+    T.D2.from(S.D2, true);          // (unused by this role)
+    T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
+    int sbase = S.rng.pos;
+    float pc[4], pl[4], nc[4], nl[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        pc[j] = cs_load(C, t + j); pl[j] = cs_load<NTSC_COMP_LOAD2_AUX>(C, t + j - LOFF);
+        nc[j] = cs_load(C, t + 4 + j); nl[j] = cs_load<NTSC_COMP_LOAD2_AUX>(C, t + 4 + j - LOFF);
+    }
+    for (; t + 4 <= t_end; t += 4) {
+        float fc[4], fl[4], c2[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { fc[j] = cs_load(C, t + 8 + j); fl[j] = cs_load<NTSC_COMP_LOAD2_AUX>(C, t + 8 + j - LOFF); }
+        T.rb = ring + sbase * 64 + lane;
+        T.rb0 = sbase == 0;
+        sbase = (sbase + 8) & 31;
+        c2[0] = vcr_step<DPH, 0>(P, S, T, C, pc[0], pl[0]); __builtin_amdgcn_sched_barrier(0);
+        c2[1] = vcr_step<DPH, 1>(P, S, T, C, pc[1], pl[1]); __builtin_amdgcn_sched_barrier(0);
+        c2[2] = vcr_step<DPH, 2>(P, S, T, C, pc[2], pl[2]); __builtin_amdgcn_sched_barrier(0);
+        c2[3] = vcr_step<DPH, 3>(P, S, T, C, pc[3], pl[3]); __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { pc[j] = nc[j]; pl[j] = nl[j]; nc[j] = fc[j]; nl[j] = fl[j]; }
+        const int x2 = t - SK1;                    // multiple of 4 (the steady loop starts on x2 = 0 (mod 4), see the kernel)
+        lds_wait_ge(sync + 1, x2 + 4 - NSLOT, cons_seen);
+        const int sl = x2 & (NSLOT - 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) c2col[(sl + j) * 64] = (uint32_t)as_i(c2[j]);
+        lds_publish(sync, x2 + 4);
+    }
+    {
+        const float d1c1 = T.D1.pA - T.D1.c1, lc2 = T.lpA - T.lc1;
+        T.D1.to(S.D1, (DPH & 1) != 0, d1c1, T.D1.pB - d1c1);
+        S.l2 = T.lc1; S.l1 = lc2; S.l0 = T.lpB - lc2;
+    }
+    S.rng.pos = sbase;
+    return t;
+}
+
+DEV void vcr_role(const DevParams &P, State<true> &S, const Const &C, uint32_t *ring, uint32_t *c2ring, volatile uint32_t *sync)
+{
+    const int W = C.W, SK1 = 7 + C.d, total = W + SK1;
+    uint32_t *c2col = c2ring + C.lane;
+    int cons_seen = 0;
+    int t = 0;
+    for (; t < SK1 && t < total; t++) (void)vcr_edge(P, S, C, ring, t);          // pipeline fill: x2 < 0
+    switch (C.d & 3) {
+        case 0: t = vcr_steady<0>(P, S, C, ring, c2col, sync, cons_seen, t, SK1); break;
+        case 1: t = vcr_steady<1>(P, S, C, ring, c2col, sync, cons_seen, t, SK1); break;
+        case 2: t = vcr_steady<2>(P, S, C, ring, c2col, sync, cons_seen, t, SK1); break;
+        default: t = vcr_steady<3>(P, S, C, ring, c2col, sync, cons_seen, t, SK1); break;
+    }
+    for (; t < total; t++) {
+        const float c2 = vcr_edge(P, S, C, ring, t);
+        const int x2 = t - SK1;
+        lds_wait_ge(sync + 1, x2 + 1 - NSLOT, cons_seen);
+        c2col[(x2 & (NSLOT - 1)) * 64] = (uint32_t)as_i(c2);
+        lds_publish(sync, x2 + 1);
+    }
+}
+
+// ---- wave 1: the TV half = the one-separator decoder on the samples of the ring (position u = the VCR's x2)
+DEV void tv_role(const DevParams &P, State<false> &S, const Const &C, uint32_t *c2ring, volatile uint32_t *sync, uint32_t *ostage,
+                 const unsigned long long *orow, uint32_t *drow, bool is_out)
+{
+    const int W = C.W, lane = C.lane, SKT = 8, total = W + SKT;
+    const uint32_t *c2col = c2ring + lane;
+    int prod_seen = 0;
+    uint32_t *nouse = nullptr;
+    int u = 0;
+    auto guarded = [&](int uu, uint32_t &px, int &xo) -> bool {
+        float Y, U, V;
+        float pc = 0.0f;
+        if (uu < W) {
+            lds_wait_ge(sync, uu + 1, prod_seen);
+            pc = as_f((int)c2col[(uu & (NSLOT - 1)) * 64]);
+            lds_publish(sync + 1, uu + 1);
+        }
+        S.D1.push_edge(pc, uu, C.hi, W, C.xe, Y, U, V);
+        const int x3 = uu - 7;
+        if (x3 < 0 || x3 > W) return false;
+        const bool in3 = x3 < W;
+        if (!in3) { U = 0; V = 0; Y = 0; }
+        U *= C.dmf; V *= C.dmf;
+        float fUd = 0, fVd = 0;
+        if (in3) { fUd = S.oU.push(U, C.a_tv); fVd = S.oV.push(V, C.a_tv); }
+        xo = x3 - 1;
+        const float Yo = S.Yprev, Ur = S.Uraw, Vr = S.Vraw;
+        S.Yprev = Y; S.Uraw = U; S.Vraw = V;
+        if (xo < 0) return false;
+        if (xo >= W - 1) { fUd = Ur; fVd = Vr; }
+        px = yiq_to_bgra(C, Yo, fUd, fVd);
+        return true;
+    };
+    (void)nouse;
+    for (; u < SKT && u < total; u++) { uint32_t px; int xo; (void)guarded(u, px, xo); }
+    // steady: every sample inside the row, 4 per iteration, the next iteration's samples read one iteration ahead
+    if (u + 4 <= W) {
+        Steady T;
+        T.D1.from(S.D1, true);
+        T.D2.from(S.D2, true);
+        T.D1.ieP *= C.dmf; T.D1.qeP *= C.dmf; T.D1.ieN *= C.dmf; T.D1.qeN *= C.dmf;
+        float pc[4], nc[4];
+        lds_wait_ge(sync, u + 4, prod_seen);
+#pragma unroll
+        for (int j = 0; j < 4; j++) pc[j] = as_f((int)c2col[((u + j) & (NSLOT - 1)) * 64]);
+        int pend_x = -1;
+        for (; u + 4 <= W; u += 4) {
+            const bool more = u + 8 <= W;
+            if (more) {
+                lds_wait_ge(sync, u + 8, prod_seen);
+#pragma unroll
+                for (int j = 0; j < 4; j++) nc[j] = as_f((int)c2col[((u + 4 + j) & (NSLOT - 1)) * 64]);
+            }
+            // (everything up to u + 4, or u + 8, is in registers: the VCR role may reuse those slots)
+            lds_publish(sync + 1, more ? u + 8 : u + 4);
+            uint32_t o[4];
+            State<false> &Sx = S;
+            o[0] = step<false, 0, 0>(P, Sx, T, C, pc[0], 0.0f);
+            o[1] = step<false, 0, 1>(P, Sx, T, C, pc[1], 0.0f);
+            o[2] = step<false, 0, 2>(P, Sx, T, C, pc[2], 0.0f);
+            o[3] = step<false, 0, 3>(P, Sx, T, C, pc[3], 0.0f);
+#pragma unroll
+            for (int j = 0; j < 4; j++) pc[j] = nc[j];
+            const int xo0 = u - SKT;
+            const int sub = (xo0 >> 2) & 3;
+            *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) = make_uint4(o[0], o[1], o[2], o[3]);
+            if (sub == 3) {
+                pend_x = xo0 - 12;
+                unsigned long long rp[4];
+                uint4 fv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = 16 * k + (lane >> 2);
+                    rp[k] = orow[r];
+                    fv[k] = *reinterpret_cast<const uint4 *>(&ostage[r * 20 + (lane & 3) * 4]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (rp[k]) __builtin_nontemporal_store(to_v4u(fv[k]), (g_v4u_ptr)(rp[k] + 4ull * (unsigned)(pend_x + (lane & 3) * 4)));
+            }
+        }
+        const float d1c1 = T.D1.pA - T.D1.c1;
+        T.D1.to(S.D1, true, d1c1, T.D1.pB - d1c1);
+        S.Uraw = 0; S.Vraw = 0;
+    }
+    for (; u < total; u++) {
+        uint32_t px; int xo;
+        if (!guarded(u, px, xo)) continue;
+        ostage[lane * 20 + (xo & 15)] = px;
+        if ((xo & 15) == 15) {
+            if (is_out) {
+                const uint4 *sp = reinterpret_cast<const uint4 *>(&ostage[lane * 20]);
+                g_v4u_ptr dp = (g_v4u_ptr)(drow + (xo - 15));
+                const uint4 a = sp[0], b = sp[1], c4 = sp[2], d4 = sp[3];
+                dp[0] = to_v4u(a); dp[1] = to_v4u(b); dp[2] = to_v4u(c4); dp[3] = to_v4u(d4);
+            }
+        } else if (xo == W - 1 && is_out) {
+            const int xb = xo & ~15;
+            for (int q = xb; q <= xo; q++) ((g_u32_ptr)drow)[q] = ostage[lane * 20 + (q - xb)];
+        }
+    }
+}
+
+} // namespace fpipe
+
+template <int WAVES>
+__global__ __launch_bounds__(128, WAVES) void k_decode_fp2(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
+                                                           const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
+                                                           const int *__restrict__ n0_u, const int *__restrict__ n0_v,
+                                                           const int *__restrict__ hs_shift, const int *__restrict__ pn_noise,
+                                                           const int *__restrict__ dropout, int *__restrict__ tails)
+{
+    using namespace fpipe;
+    __shared__ uint32_t ring[33 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
+    __shared__ unsigned long long orow[64];
+    __shared__ uint32_t c2ring[NSLOT * 64];
+    __shared__ uint32_t sync[2];
+
+    const int role = threadIdx.x >> 6;            // 0: VCR half, 1: TV half
+    const int lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok;
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const int W = P.W;
+    uint32_t *drow = reinterpret_cast<uint32_t *>(fd.dst + (size_t)fd.dst_ls * y);
+    if (role == 1) orow[lane] = is_out ? (unsigned long long)drow : 0ull;
+    if (threadIdx.x < 2) sync[threadIdx.x] = 0u;
+    __syncthreads();
+
+    Const C;
+    C.xi = scan_phase(P, y, fd.fieldno);
+    C.hi = (C.xi & 2u) != 0;
+    C.W = W;
+    C.xe = (W & 1) ? W - 1 : W - 2;
+    C.lane = lane;
+    C.d = P.cdelay;
+    C.SKT = 15 + C.d;
+    C.LOFF = 5 + C.d;
+    C.sg0 = C.hi ? -1.0f : 1.0f;
+    C.sg2 = -C.sg0;
+    const bool vb = P.vblend && P.ntsc;
+    C.bA = (vb && k >= 2) ? 1.0f : 0.0f;
+    C.bS = (vb && k >= 1) ? 0.5f : 1.0f;
+    C.dmf = (P.loss && dropout[rc] != 0) ? 0.0f : 1.0f;
+    {
+        int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+        C.cosv = (float)G.ptab[2 * n]; C.sinv = (float)G.ptab[2 * n + 1];
+    }
+    C.a_vc = (float)P.a_vc; C.a_vl = (float)P.a_vl; C.a_sh = (float)P.a_sh; C.a_tv = (float)P.a_tv;
+    C.sharp2 = (float)(P.sharpen * 2);
+    C.ybias = NTSC_FP_LUMA_BIAS_VHS * (1.0f / 256.0f);
+    C.tailU = tails + (size_t)blockIdx.x * 64 + lane;
+    C.rstride = (size_t)gridDim.x * 64;
+    C.rowbytes = P.Rpad * 4;
+    const int hs = P.hs ? hs_shift[rc] : 0;
+    C.vbase = (int)((unsigned)rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
+    C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
+
+    if (role == 0) {
+        State<true> S;
+        S.D1.init(); S.D2.init();
+        S.l0 = S.l1 = S.l2 = 0;
+        S.vl.reset(16); S.vpre.reset(16); S.vcU.reset(0); S.vcV.reset(0);
+        S.sh.reset(0);
+        S.oU.reset(0); S.oV.reset(0);
+        S.Yprev = S.Uraw = S.Vraw = 0;
+        // the fill draws twice per step from x1 = 0 on (t = 7 .. SK1 - 1 = 6 + d): the steady loop's first draw on a slot
+        // that is a multiple of 8
+        S.rng.init(ring, rs_chroma + rc, P.Rpad, lane, (-(31 + 2 * C.d)) & 7);
+        S.nU = n0_u[rc]; S.nV = n0_v[rc];
+        vcr_role(P, S, C, ring, c2ring, sync);
+    } else {
+        State<false> S;
+        S.D1.init(); S.D2.init();
+        S.l0 = S.l1 = S.l2 = 0;
+        S.vl.reset(0); S.vpre.reset(0); S.vcU.reset(0); S.vcV.reset(0); S.sh.reset(0);
+        S.oU.reset(0); S.oV.reset(0);
+        S.Yprev = S.Uraw = S.Vraw = 0;
+        S.nU = S.nV = 0;
+        tv_role(P, S, C, c2ring, sync, ostage, orow, drow, is_out);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 void launch_encode_fp(hipStream_t st, const DevParams &D, const FieldDev *fields, const uint32_t *rs_luma, const int *n0_luma,
                       int *comp)
@@ -850,10 +1140,22 @@ void launch_decode_fp(hipStream_t st, const DevParams &D, const GeomDev &G, cons
 #define NTSC_FPV(VHS, VAR, WV) hipLaunchKernelGGL((k_decode_fp<VHS, VAR, WV>), grid, dim3(64), 0, st, D, G, fields, comp, rs_chroma, \
                                                   n0_u, n0_v, hs_shift, pn_noise, dropout, tails)
     if (!D.vhs) { NTSC_FPV(false, 0, 2); return; }
-    switch (variant) {
+    // Two forms of the -vhs decoder.  One wave per 63 rows (k_decode_fp<true>): the form of long batches -- with tens of
+    // thousands of rows in flight the chip's VALU issue is what bounds the step (measured 0.70 of it), and this form
+    // issues least.  Two-role workgroup (k_decode_fp2): a field's rows are worked on by two instruction streams, so a
+    // SHORT batch -- the synchronous one-field call, a launch of the submit engine -- finishes sooner (isolated 600-field
+    // launch 0.48 against 0.52 ms; tools/fp_probe.sh).  variant: -1 = by batch size; 0 / 1 = two roles (4 / 3 waves per
+    // SIMD); 10.. = one wave (developer A/B, NTSCSIM_FP_VARIANT).
+    if (variant < 0) variant = D.nfields <= 128 ? 0 : 10;
+    if (variant < 10) {
+        if (variant == 1) hipLaunchKernelGGL((k_decode_fp2<3>), grid, dim3(128), 0, st, D, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift,
+                                             pn_noise, dropout, tails);
+        else hipLaunchKernelGGL((k_decode_fp2<4>), grid, dim3(128), 0, st, D, G, fields, comp, rs_chroma, n0_u, n0_v, hs_shift,
+                                pn_noise, dropout, tails);
+        return;
+    }
+    switch (variant - 10) {
         case 1: NTSC_FPV(true, 1, 2); break;
-        case 2: NTSC_FPV(true, 0, 3); break;
-        case 3: NTSC_FPV(true, 1, 3); break;
         default: NTSC_FPV(true, 0, 2); break;
     }
 #undef NTSC_FPV

@@ -804,8 +804,9 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
     if (fp) {
-        note_kernel(c, D.vhs ? "k_decode_fp<true>" : "k_decode_fp<false>");
-        static const int fpv = std::getenv("NTSCSIM_FP_VARIANT") ? std::atoi(std::getenv("NTSCSIM_FP_VARIANT")) : 0;    // developer A/B switch
+        static const int fpv_env = std::getenv("NTSCSIM_FP_VARIANT") ? std::atoi(std::getenv("NTSCSIM_FP_VARIANT")) : -1;    // developer A/B switch
+        const int fpv = fpv_env >= 0 ? fpv_env : (n <= 128 ? 0 : 10);      // (launch_decode_fp's own rule, for the kernel's name)
+        note_kernel(c, D.vhs ? (fpv < 10 ? "k_decode_fp2" : "k_decode_fp<true>") : "k_decode_fp<false>");
         launch_decode_fp(st, D, G, fields_dev, dec_in, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,
                          c->dropout.p, c->tails.p, fpv);
     } else if (dec_fast && back50 && hs_small && D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k && c->split_vhs) {

@@ -30,7 +30,6 @@
 #include "ntscsim.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -580,29 +579,73 @@ __device__ __forceinline__ void run_masks(const uint8_t *__restrict__ h, size_t 
     // a run still open at the end of the capture ends at N: bit `nvalid` (position N)
     if (s0 + nvalid == N && ((m >> (nvalid - 1)) & 1u)) ends |= 1u << nvalid;
 }
+// Prefix sums of the run counts (two 32-bit counters packed in one u64: starts low, ends high -- neither can carry into
+// the other: at most one start and one end per sample, N < 2^32).  Own code, no library: an inclusive scan across the 64
+// lanes of a wave by six shuffle-and-add steps, the waves of a block chained through LDS.
+__device__ __forceinline__ unsigned long long wave_scan_incl_u64(unsigned long long v)
+{
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned lo = (unsigned)__shfl_up((int)(unsigned)(v & 0xFFFFFFFFull), d), hi = (unsigned)__shfl_up((int)(unsigned)(v >> 32), d);
+        if (lane >= d) v += ((unsigned long long)hi << 32) | lo;
+    }
+    return v;
+}
+// exclusive prefix of `mine` over the T threads of the block (T a multiple of 64, at most 1024); *total = the block's sum
+template <int T>
+__device__ __forceinline__ unsigned long long block_scan_excl_u64(unsigned long long mine, unsigned long long *wsum /* [T / 64] LDS */,
+                                                                  unsigned long long *total)
+{
+    const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const unsigned long long incl = wave_scan_incl_u64(mine);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < T / 64; k++) { const unsigned long long s = wsum[k]; if (k < w) base += s; tot += s; }
+    __syncthreads();                 // (wsum may be reused by the caller's next round)
+    if (total) *total = tot;
+    return base + incl - mine;
+}
+
 __global__ __launch_bounds__(RUN_T) void k_raw28_run_count(const uint8_t *__restrict__ h, size_t N, int thr,
                                                            unsigned long long *__restrict__ cnt)
 {
-    typedef hipcub::BlockReduce<unsigned long long, RUN_T> Red;
-    __shared__ typename Red::TempStorage tmp;
+    __shared__ unsigned long long wsum[RUN_T / 64];
     uint32_t st, en;
     run_masks(h, N, thr, ((size_t)blockIdx.x * RUN_T + threadIdx.x) * RUN_PER, st, en);
     const unsigned long long mine = (unsigned long long)__popc(st) | ((unsigned long long)__popc(en) << 32);
-    const unsigned long long tot = Red(tmp).Sum(mine);
+    unsigned long long tot;
+    (void)block_scan_excl_u64<RUN_T>(mine, wsum, &tot);
     if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+
+// exclusive scan of n counters in place of a library's device-wide scan: n is the number of 4,096-sample blocks of the
+// buffer (~70,000 for a ten-second capture), so ONE workgroup does it -- every thread sums its own contiguous slice,
+// the slice sums are scanned across the block, every thread writes its slice's prefixes
+constexpr int SCAN_T = 1024;
+__global__ __launch_bounds__(SCAN_T) void k_raw28_scan_counts(const unsigned long long *__restrict__ in,
+                                                              unsigned long long *__restrict__ out, size_t n)
+{
+    __shared__ unsigned long long wsum[SCAN_T / 64];
+    const size_t per = (n + SCAN_T - 1) / SCAN_T;
+    const size_t a = (size_t)threadIdx.x * per, b = a + per < n ? a + per : n;
+    unsigned long long sum = 0;
+    for (size_t i = a; i < b; i++) sum += in[i];
+    unsigned long long run = block_scan_excl_u64<SCAN_T>(sum, wsum, nullptr);
+    for (size_t i = a; i < b; i++) { const unsigned long long v = in[i]; out[i] = run; run += v; }
 }
 __global__ __launch_bounds__(RUN_T) void k_raw28_run_scatter(const uint8_t *__restrict__ h, size_t N, int thr,
                                                              const unsigned long long *__restrict__ off,
                                                              uint32_t *__restrict__ rstart, uint32_t *__restrict__ rend)
 {
-    typedef hipcub::BlockScan<unsigned long long, RUN_T> Scan;
-    __shared__ typename Scan::TempStorage tmp;
+    __shared__ unsigned long long wsum[RUN_T / 64];
     const size_t s0 = ((size_t)blockIdx.x * RUN_T + threadIdx.x) * RUN_PER;
     uint32_t st, en;
     run_masks(h, N, thr, s0, st, en);
     const unsigned long long mine = (unsigned long long)__popc(st) | ((unsigned long long)__popc(en) << 32);
-    unsigned long long before;
-    Scan(tmp).ExclusiveSum(mine, before);
+    unsigned long long before = block_scan_excl_u64<RUN_T>(mine, wsum, nullptr);
     before += off[blockIdx.x];
     uint32_t os = (uint32_t)(before & 0xFFFFFFFFull), oe = (uint32_t)(before >> 32);
     while (st) { const int k = __ffs(st) - 1; st &= st - 1; rstart[os++] = (uint32_t)(s0 + k); }
@@ -1355,10 +1398,7 @@ static int raw28_stream_push_impl(ntscsim_raw28 *d, const void *samples, bool on
         R28CHK(d, d->segoff.ensure(nseg + 1));
         hipLaunchKernelGGL(k_raw28_run_count, dim3((unsigned)nseg), dim3(RUN_T), 0, st, d->h.p, N, d->K.thr, d->segcnt.p);
         R28CHK(d, hipMemsetAsync(d->segcnt.p + nseg, 0, sizeof(unsigned long long), st));
-        size_t tmp_bytes = 0;
-        R28CHK(d, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d->segcnt.p, d->segoff.p, (int)(nseg + 1), st));
-        R28CHK(d, d->tmp.ensure(tmp_bytes + 16));
-        R28CHK(d, hipcub::DeviceScan::ExclusiveSum(d->tmp.p, tmp_bytes, d->segcnt.p, d->segoff.p, (int)(nseg + 1), st));
+        hipLaunchKernelGGL(k_raw28_scan_counts, dim3(1), dim3(SCAN_T), 0, st, d->segcnt.p, d->segoff.p, nseg + 1);
         unsigned long long total = 0;
         R28CHK(d, hipMemcpyAsync(&total, d->segoff.p + nseg, sizeof(total), hipMemcpyDeviceToHost, st));
         R28CHK(d, hipStreamSynchronize(st));

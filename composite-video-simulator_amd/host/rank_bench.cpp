@@ -5,7 +5,12 @@
 //
 //   rank_bench [reference switches] [--spawn N | (RANK / WORLD_SIZE / LOCAL_RANK from the environment, e.g. torchrun)]
 //              [--frames F] [--steps K] [--warmup W] [--scaling weak|strong] [--verify 0|1] [--width W --height H]
-//              [--one-device 0|1] [--inflight Q]
+//              [--size WxH] [--streams S] [--one-device 0|1] [--inflight Q]
+//
+// BASELINE's two multi-GPU configurations have a leg each:
+//   configs[3]  --streams 8                  eight independent 300-frame 720x486 streams, stream s on rank s % N (every
+//                                            stream its own fieldno / rand() sequence from 0, like eight runs of the tool)
+//   configs[4]  --size 3840x2160 --frames 600   the 60 fps long-form clip (600 frames = 10 s), frame-round-robin
 //
 // Every rank owns the frames g = rank, rank + N, ... of the clip (weak: the clip has N x F frames, strong: F), keeps
 // its source and destination frames in ITS GPU's HBM and runs ONE prepared batch per step (ntscsim_batch_run: the
@@ -17,9 +22,13 @@
 // so the union of the ranks' outputs is the one-GPU run byte for byte, and no data moves between GPUs.
 // Rank 0 prints one JSON line: whole-job fields/s (fields of all ranks / MAX elapsed), per-rank checksums (sum of
 // all destination bytes), and with --verify 1 whether rank 0 could reproduce every rank's checksum on its own GPU.
-// The ncclUniqueId travels through a file ($NTSCSIM_RCCL_ID_FILE, default /tmp/ntscsim_rccl_id.<MASTER_PORT|ppid>).
+// The ncclUniqueId travels through a file ($NTSCSIM_RCCL_ID_FILE, default /tmp/ntscsim_rccl_id.<MASTER_PORT|ppid>): rank 0
+// creates it exclusively (O_EXCL | O_NOFOLLOW under a temporary name, then rename) with a run nonce in front -- the
+// launcher's pid, MASTER_PORT and TORCHELASTIC_RUN_ID hashed -- and the other ranks only accept a file that carries
+// THIS run's nonce, so a file left behind by an earlier run on the same port is never taken for the id.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -71,14 +80,22 @@ struct Share {                       // one rank's frames, resident on one GPU
     size_t nframes = 0, fbytes = 0;
 };
 
-static int build_share(Share &S, const ntscsim_params &prm, int device, int W, int H, int rank, int world, long total_frames)
+// `streams` > 0: BASELINE configs[3] -- this rank owns the streams s = rank, rank + world, ... (< streams), each a clip of
+// `total_frames` frames of its own (bars rotated by 37 s + j, fieldno and rand() position from 0); otherwise the frames
+// g = rank, rank + world, ... of ONE clip of `total_frames` frames
+static int build_share(Share &S, const ntscsim_params &prm, int device, int W, int H, int rank, int world, long total_frames,
+                       int streams = 0)
 {
     HIPOK(hipSetDevice(device));
     int rc = ntscsim_create(&prm, device, &S.sim);
     if (rc != NTSCSIM_OK) { std::fprintf(stderr, "[rank %d] ntscsim_create: %s\n", g_rank, ntscsim_strerror(rc)); return 1; }
     S.fbytes = (size_t)W * 4 * H;
-    std::vector<long> mine;
-    for (long g = rank; g < total_frames; g += world) mine.push_back(g);
+    std::vector<long> mine, rot;        // global frame number within its clip (-> fieldno, rand() position); bar rotation
+    if (streams > 0) {
+        for (int sidx = rank; sidx < streams; sidx += world)
+            for (long j = 0; j < total_frames; j++) { mine.push_back(j); rot.push_back(37L * sidx + j); }
+    } else
+        for (long g = rank; g < total_frames; g += world) { mine.push_back(g); rot.push_back(g); }
     S.nframes = mine.size();
     HIPOK(hipMalloc((void **)&S.src, S.fbytes * (S.nframes ? S.nframes : 1)));
     HIPOK(hipMalloc((void **)&S.dst, S.fbytes * (S.nframes ? S.nframes : 1)));
@@ -88,7 +105,7 @@ static int build_share(Share &S, const ntscsim_params &prm, int device, int W, i
     const uint64_t c1 = ntscsim_rng_calls_per_field(&prm, W, H, 1), c0 = ntscsim_rng_calls_per_field(&prm, W, H, 0);
     std::vector<ntscsim_field_desc> descs;
     for (size_t j = 0; j < S.nframes; j++) {
-        make_bars(host.data(), W, H, mine[j]);
+        make_bars(host.data(), W, H, rot[j]);
         HIPOK(hipMemcpy(S.src + S.fbytes * j, host.data(), S.fbytes, hipMemcpyHostToDevice));
         for (int sub = 0; sub < 2; sub++) {
             const uint64_t k = 2 * (uint64_t)mine[j] + (uint64_t)sub;
@@ -134,7 +151,7 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
 {
     g_rank = rank;
     long frames = 300, steps = 20, warmup = 5;
-    int verify = 1, width = 0, height = 486, one_device = 0, inflight = 4;
+    int verify = 1, width = 0, height = 486, one_device = 0, inflight = 4, streams = 0;
     std::string scaling = "weak";
     std::vector<const char *> av;
     av.push_back(argv[0]);
@@ -148,6 +165,8 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
         if (opt("--verify")) { verify = std::atoi(argv[++i]); continue; }
         if (opt("--width")) { width = std::atoi(argv[++i]); continue; }
         if (opt("--height")) { height = std::atoi(argv[++i]); continue; }
+        if (opt("--size")) { if (std::sscanf(argv[++i], "%dx%d", &width, &height) != 2) { std::fprintf(stderr, "--size WxH\n"); return 1; } continue; }
+        if (opt("--streams")) { streams = std::atoi(argv[++i]); continue; }
         if (opt("--one-device")) { one_device = std::atoi(argv[++i]); continue; }
         if (opt("--inflight")) { inflight = std::atoi(argv[++i]); continue; }
         av.push_back(argv[i]);
@@ -166,24 +185,38 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
     HIPOK(hipSetDevice(device));
 
     // ---- the communicator: rank 0 makes the id, everybody reads it from the file
+    struct IdRecord { unsigned long long magic, nonce; ncclUniqueId id; } recid;
+    unsigned long long nonce = 1469598103934665603ull;
+    {
+        auto mix = [&](const char *t) { for (; t && *t; t++) { nonce ^= (unsigned char)*t; nonce *= 1099511628211ull; } };
+        mix(std::to_string((long)getppid()).c_str());            // torchrun's agent / the --spawn parent: the same for every local rank
+        mix(std::getenv("MASTER_PORT"));
+        mix(std::getenv("TORCHELASTIC_RUN_ID"));
+        mix(std::getenv("NTSCSIM_RCCL_NONCE"));                  // (several nodes: give every rank the same value)
+    }
     ncclUniqueId id;
     if (rank == 0) {
         NCCLOK(ncclGetUniqueId(&id));
-        const std::string tmp = id_file + ".tmp";
-        FILE *f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
-        std::fclose(f);
-        std::rename(tmp.c_str(), id_file.c_str());
+        recid.magic = 0x4e54534352434c31ull; recid.nonce = nonce; recid.id = id;
+        const std::string tmp = id_file + ".tmp." + std::to_string((long)getpid());
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        if (fd < 0 || write(fd, &recid, sizeof(recid)) != (ssize_t)sizeof(recid)) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+        close(fd);
+        if (std::rename(tmp.c_str(), id_file.c_str()) != 0) { std::fprintf(stderr, "cannot publish %s\n", id_file.c_str()); return 1; }
     } else {
         bool got = false;
-        for (int tries = 0; tries < 3000 && !got; tries++) {
-            struct stat sb;            // (a file left behind by a run that died is not this run's id)
-            if (stat(id_file.c_str(), &sb) == 0 && std::time(nullptr) - sb.st_mtime > 120) { std::this_thread::sleep_for(std::chrono::milliseconds(10)); continue; }
-            FILE *f = std::fopen(id_file.c_str(), "rb");
-            if (f) { got = std::fread(&id, sizeof(id), 1, f) == 1; std::fclose(f); }
+        for (int tries = 0; tries < 6000 && !got; tries++) {
+            const int fd = open(id_file.c_str(), O_RDONLY | O_NOFOLLOW);
+            if (fd >= 0) {
+                // (a file of another run -- an earlier one on the same port that died -- carries another nonce: keep waiting)
+                got = read(fd, &recid, sizeof(recid)) == (ssize_t)sizeof(recid) && recid.magic == 0x4e54534352434c31ull && recid.nonce == nonce;
+                close(fd);
+            }
             if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
-        if (!got) { std::fprintf(stderr, "[rank %d] no id file %s\n", rank, id_file.c_str()); return 1; }
+        if (!got) { std::fprintf(stderr, "[rank %d] no id file %s of this run\n", rank, id_file.c_str()); return 1; }
+        id = recid.id;
     }
     ncclComm_t comm;
     NCCLOK(ncclCommInitRank(&comm, world, id, rank));
@@ -199,11 +232,11 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
         return 0;
     };
 
-    const long total_frames = scaling == "strong" ? frames : frames * world;
+    const long total_frames = streams > 0 ? frames : (scaling == "strong" ? frames : frames * world);
     if (inflight < 1) inflight = 1;
     if (inflight > 16) inflight = 16;
     std::vector<Share> Q((size_t)inflight);
-    for (auto &q : Q) if (build_share(q, prm, device, W, H, rank, world, total_frames)) return 1;
+    for (auto &q : Q) if (build_share(q, prm, device, W, H, rank, world, total_frames, streams)) return 1;
     Share &S = Q[0];
     for (auto &q : Q) { rc = run_share(q); if (rc != NTSCSIM_OK) return 1; }          // first-call allocations of every context
     for (long i = 0; i < warmup; i++) { rc = run_share(Q[(size_t)(i % inflight)]); if (rc != NTSCSIM_OK) return 1; }
@@ -248,7 +281,7 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
                 if (r == 0) { if (checksum_share(S, &cs_r)) return 1; }
                 else {
                     Share T;
-                    if (build_share(T, prm, device, W, H, r, world, total_frames)) return 1;
+                    if (build_share(T, prm, device, W, H, r, world, total_frames, streams)) return 1;
                     if (run_share(T) != NTSCSIM_OK) return 1;
                     HIPOK(hipDeviceSynchronize());
                     if (checksum_share(T, &cs_r)) return 1;
@@ -259,11 +292,11 @@ static int rank_main(int rank, int world, int local_rank, int argc, char **argv,
         }
         std::printf("{\"metric\": \"frames/sec (output frames = fields; %dx%d, C++ host, one process per GPU, RCCL barrier / max / all-gather)\", "
                     "\"value\": %.1f, \"unit\": \"frames/s\", \"n_gpus\": %d, \"steps\": %ld, \"warmup\": %ld, \"ms_per_step\": %.4f, "
-                    "\"higher_is_better\": true, \"scaling\": \"%s\", \"dtype\": \"f64\", \"data\": \"synthetic\", \"steps_in_flight\": %d, "
+                    "\"higher_is_better\": true, \"scaling\": \"%s\", \"streams\": %d, \"dtype\": \"f64\", \"data\": \"synthetic\", \"steps_in_flight\": %d, "
                     "\"fields_per_step\": %llu, \"collectives\": [\"ncclAllReduce(sum) x2 as barriers\", \"ncclAllReduce(max) of the elapsed time\", "
                     "\"ncclAllGather of {checksum, fields, elapsed}\"], \"rank_checksums_verified\": %s, \"ranks\": [",
                     W, H, max_s > 0 ? (double)fields_per_step * steps / max_s : 0.0, world, steps, warmup, max_s / steps * 1e3,
-                    scaling.c_str(), inflight, fields_per_step, verified < 0 ? "null" : (verified ? "true" : "false"));
+                    streams > 0 ? "weak" : scaling.c_str(), streams, inflight, fields_per_step, verified < 0 ? "null" : (verified ? "true" : "false"));
         for (int r = 0; r < world; r++) {
             double el; std::memcpy(&el, &all[(size_t)3 * r + 2], sizeof(double));
             std::printf("%s{\"rank\": %d, \"checksum\": %llu, \"fields_per_step\": %llu, \"seconds\": %.6f}", r ? ", " : "", r,
@@ -305,6 +338,5 @@ int main(int argc, char **argv)
     const int rank = std::getenv("RANK") ? std::atoi(std::getenv("RANK")) : 0;
     const int world = std::getenv("WORLD_SIZE") ? std::atoi(std::getenv("WORLD_SIZE")) : 1;
     const int local = std::getenv("LOCAL_RANK") ? std::atoi(std::getenv("LOCAL_RANK")) : rank;
-    if (rank == 0) std::remove(id_file.c_str());
     return rank_main(rank, world, local, argc, argv, id_file);
 }

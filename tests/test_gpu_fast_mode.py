@@ -107,7 +107,7 @@ def test_float_pipeline_within_stated_tolerance(flags, w, h, n, kind, fp):
     assert sim.rng_pos == o.rng_pos
     kern = sim.last_kernels()
     if fp:
-        assert "k_encode_fp" in kern and ("k_decode_fp<true>" if "-vhs" in flags else "k_decode_fp<false>") in kern, kern
+        assert "k_encode_fp" in kern and ("k_decode_fp2" if "-vhs" in flags else "k_decode_fp<false>") in kern, kern      # (short batch: the two-role form)
     else:
         assert not any(k_.endswith("_fp") or "_fp<" in k_ for k_ in kern), kern
     got = dst.cpu().numpy()
@@ -126,6 +126,31 @@ def test_float_pipeline_within_stated_tolerance(flags, w, h, n, kind, fp):
         sd = (got[k][field::2, :, :3].astype(np.int16) - exp[k][field::2, :, :3].astype(np.int16))
         if kind != "bars" and w >= 360:
             assert abs(sd.mean()) < 0.004, sd.mean()
+    sim.close()
+
+
+def test_float_long_batches_take_the_one_wave_form_and_equal_the_two_role_form():
+    """more than 128 fields per launch: k_decode_fp<true> (one wave per 63 rows); same bytes as the two-role workgroup
+    form the short batches take"""
+    import torch
+    w, h, n = 360, 120, 160
+    p = L.make_params(["-vhs"])
+    srcs = [L.noise_frame(w, h, 70 + j) for j in range(4)]
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    jobs = [(k % 4, k, (k & 1) ^ 1, k) for k in range(n)]
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.set_mode(_capi.MODE_FLOAT)
+    a = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, a, jobs)
+    sim.sync()
+    assert "k_decode_fp<true>" in sim.last_kernels()
+    sim.rng_pos = 0
+    b = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+    for i in range(0, n, 40):
+        sim.fields(src, b[i:i + 40], [(k % 4, k - i, (k & 1) ^ 1, k) for k in range(i, i + 40)])
+    sim.sync()
+    assert "k_decode_fp2" in sim.last_kernels()
+    assert torch.equal(a, b)
     sim.close()
 
 

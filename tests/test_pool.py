@@ -120,6 +120,41 @@ def test_rank_bench_runs_through_rccl_with_one_rank_and_matches_one_context():
     sim.close()
 
 
+@pytest.mark.gpu
+def test_rank_bench_legs_of_the_two_multi_gpu_configs():
+    """BASELINE configs[3] (--streams: independent clips, each with its own fieldno / rand() sequence from 0) and
+    configs[4] (--size 3840x2160) through the C++ host with the one rank this box has: checksums verified by rank 0's
+    re-computation; two streams give twice the byte sum pattern of... no: each stream is its own clip, so the share holds
+    streams x frames frames and the line says so."""
+    import json
+    import subprocess
+    exe = os.path.join(L.PKG, "rank_bench")
+    r = subprocess.run([exe, "-vhs", "--spawn", "1", "--streams", "3", "--frames", "4", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["streams"] == 3 and line["fields_per_step"] == 3 * 2 * 4 and line["rank_checksums_verified"] is True
+    # stream s = the tool run on its own clip (bars rotated by 37 s + j): the byte sum of the three clips through the veneer
+    import torch
+    w, h = 720, 486
+    p = L.make_params(["-vhs"])
+    total = 0
+    for sidx in range(3):
+        sim = ntscsim.FieldSimulator(params=p)
+        src = torch.from_numpy(np.stack([L.bars(w, h, 37 * sidx + j) for j in range(4)])).cuda()
+        dst = torch.zeros((4, h, w, 4), dtype=torch.uint8, device="cuda")
+        sim.fields(src, dst, [(k // 2, k // 2, (k & 1) ^ 1, k) for k in range(8)])
+        sim.sync()
+        total += int(dst.to(torch.int64).sum().item())
+        sim.close()
+    assert total == line["ranks"][0]["checksum"]
+    r = subprocess.run([exe, "-vhs", "--spawn", "1", "--size", "3840x2160", "--frames", "2", "--steps", "2", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert "3840x2160" in line["metric"] and line["rank_checksums_verified"] is True and line["fields_per_step"] == 4
+
+
 def test_rank_bench_closed_form_positions_are_the_serial_stream():
     """rank_bench.cpp's closed form pos(k) = (k / 2) (draws(parity 1) + draws(parity 0)) + (k & 1) draws(parity 1) -- what lets
     rank r of N start at frame r without its predecessors -- against the serial walk of the loop (field k has parity

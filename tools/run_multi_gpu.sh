@@ -28,9 +28,14 @@ print(b)
 PY
 )
 done
-# ... and the same deal with the C++ host (host/rank_bench.cpp: rccl.h directly, no torch): one JSON line per N
+# ... and the same deal with the C++ host (host/rank_bench.cpp: rccl.h directly, no torch): one JSON line per N and leg --
+# BASELINE configs[1] (the clip frame-round-robin), configs[3] (8 independent streams) and configs[4] (3840x2160, 600 frames)
+rb=composite-video-simulator_amd/rank_bench
 for n in 1 2 4 8; do
   [ "$n" -le "$max" ] || break
-  composite-video-simulator_amd/rank_bench -vhs --spawn "$n" --frames 300 --steps 20 --warmup 5 2> /tmp/rank_bench_$n.err | grep '^{' | tail -1 \
-    || { echo "rank_bench N=$n FAILED (see /tmp/rank_bench_$n.err)"; tail -3 /tmp/rank_bench_$n.err; }
+  for leg in "--frames 300" "--streams 8 --frames 300" "--size 3840x2160 --frames 64 --steps 6 --warmup 2"; do
+    echo "rank_bench N=$n $leg" >&2
+    $rb -vhs --spawn "$n" --steps 20 --warmup 5 $leg 2> /tmp/rank_bench_$n.err | grep '^{' | tail -1 \
+      || { echo "rank_bench N=$n $leg FAILED (see /tmp/rank_bench_$n.err)"; tail -3 /tmp/rank_bench_$n.err; }
+  done
 done
