@@ -54,10 +54,10 @@ def test_bench_line_primary_tool():
         assert k in d, k
     assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["dtype"] == "f64" and d["data"] == "synthetic"
-    assert d["value"] > 0 and abs(d["value"] - 24 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-6
+    assert d["value"] > 0 and abs(d["value"] - 24 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-4     # (the line carries 6 significant digits)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"]
     assert r["algorithmic_bytes_per_launch"] == 8 * 720 * 243 * 24
     cb = d["cpu_baseline"]
     assert cb["cores"] == 1 and cb["kind"] in ("reference", "port") and cb["value"] > 0

@@ -228,7 +228,7 @@ def test_no_product_kernel_uses_scratch_memory():
     import shutil
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    objs = [os.path.join(root, "composite-video-simulator_amd", "csrc", n) for n in ("ntscsim_hip.o", "raw28_decode.o")]
+    objs = [os.path.join(root, "composite-video-simulator_amd", "csrc", n) for n in ("ntscsim_hip.o", "ntsc_float.o", "raw28_decode.o")]
     tool = os.path.join(root, "tools", "kres.sh")
     if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") \
             or shutil.which("c++filt") is None:
