@@ -560,13 +560,15 @@ def main():
                               "the cgroup CPU quota) x %d fields of the port, rand() positions by "
                               "jump-ahead, released together" % (nw, args.cpu_mt_fields)}
                 out["speedup_vs_cpu_all_cores"] = value / mt_fps
-        emit(out)
     for sm, plans, _, _ in ctxs:
         for pl in plans:
             sm.free_prepared(pl)
         sm.close()
     if dist is not None:
         dist.destroy_process_group()
+    # (after the teardown: the contract object is the last thing this process writes to stdout)
+    if out is not None:
+        emit(out)
 
 
 if __name__ == "__main__":

@@ -527,6 +527,8 @@ LINE_LIMIT = 4096
 def _r(x, sig=6):
     """Floats to `sig` significant digits (the line is for reading; the extras file keeps every digit)."""
     if isinstance(x, float):
+        if x == int(x) and abs(x) < 2 ** 53:
+            return int(x)                   # byte and field counts stay exact
         return float("%.*g" % (sig, x))
     if isinstance(x, dict):
         return {k: _r(v, sig) for k, v in x.items()}
@@ -551,7 +553,7 @@ def compact_line(out, extras_file):
     line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = {k: cfg[k] for k in ("workload", "tool", "fields_per_step_per_gpu", "steps_in_flight",
-                                          "mode", "rank_checksums_verified") if k in cfg and cfg[k] is not None}
+                                          "mode", "rank_checksums", "rank_checksums_verified") if k in cfg and cfg[k] is not None}
     if pre:
         line["config"]["pre_roll_s"] = pre.get("seconds")
     rf = out.get("roofline") or {}
@@ -623,6 +625,13 @@ def emit(out, name="bench_extras.json"):
     line = compact_line(out, written)
     txt = json.dumps(line)
     assert len(txt) < LINE_LIMIT, len(txt)
+    # (RCCL writes its version banner through C stdio, which holds it in a buffer until the process exits when stdout
+    #  is a pipe: flush the C side first, so that the contract object really is the last line)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     sys.stdout.flush()
     print(txt, flush=True)
     return line

@@ -72,6 +72,7 @@ def main_to_composite(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    out = None
     if rank == 0:
         import ctypes as C
         import _libs as L
@@ -193,8 +194,9 @@ def main_to_composite(args):
                                              % (ncpu, "composite_video_process() of the reference (oracle/_ref)"
                                                 if have_ref else "oracle/tocomp_oracle.c", ok)}
             out["speedup_vs_cpu_1core"] = value / cpu_fps
-        emit(out, "bench_extras_to_composite.json")
     for sm in sims:
         sm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and out is not None:
+        emit(out, "bench_extras_to_composite.json")

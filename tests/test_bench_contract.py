@@ -21,7 +21,7 @@ def _run(extra, base=("--gpus", "1", "--steps", "3", "--warmup", "1", "--frames"
     assert len(lines) == 1, text[-2000:]
     # the contract object is the LAST line of stdout and short enough for any log tail (the 20 KB
     # line of round 5 did not parse in the driver)
-    assert text.rstrip("\n").splitlines()[-1] == lines[0]
+    assert text.rstrip("\n").splitlines()[-1] == lines[0]      # (also behind RCCL's banner: bench_side.emit flushes C stdio first)
     assert len(lines[0]) < 4096, len(lines[0])
     return json.loads(lines[0])
 

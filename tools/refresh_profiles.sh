@@ -15,8 +15,20 @@ if [ "$mode" = gpu ]; then
   timeout 120 tools/bin/chain_probe > gpurun_out/chain_probe_$tag.txt 2>&1
   timeout 900 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
   timeout 200 python bench.py --mode fast32 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_fast32.json 2>> gpurun_out/bench_$tag.err
-  # the command the driver runs at round end (its own K / W)
-  timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_driver_cmd.json 2>> gpurun_out/bench_$tag.err
+  # the command the driver runs at round end, exactly (its own K / W, every side leg): the contract line and what it left in
+  # bench_extras.json
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_${tag}_driver_cmd.json 2>> gpurun_out/bench_$tag.err
+  cp bench_extras.json gpurun_out/bench_extras_$tag.json 2> /dev/null
+  # NTSCSIM_MODE_FLOAT (round 6): bench line, kernel stats, error against the oracle, stall counters of its forms, HBM bytes
+  timeout 200 python bench.py --mode float --cpu-fields 0 --no-extras > gpurun_out/bench_${tag}_float.json 2>> gpurun_out/bench_$tag.err
+  timeout 250 tools/kstats.sh ks_${tag}_float --mode float --inflight 1 --steps 20 --no-extras --sustain-seconds 0 > /dev/null
+  timeout 600 python tools/float_err.py --mode float > gpurun_out/float_err_$tag.txt 2>&1
+  timeout 400 bash tools/fp_probe.sh fp_$tag "10 0" "10 0" > gpurun_out/float_pmc_$tag.txt 2>&1
+  ( export TMPDIR=/tmp; R=$PWD; cd /tmp; for grp in FETCH_SIZE WRITE_SIZE; do
+      timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/fp_$tag/$grp -o pmc -- python $R/bench.py --mode float --steps 2 --warmup 1 --cpu-fields 0 --inflight 1 --no-extras --sustain-seconds 0 > $R/gpurun_out/fp_$tag/$grp.log 2>&1 < /dev/null; done )
+  python tools/pmc_summary.py gpurun_out/fp_$tag > gpurun_out/float_traffic_$tag.txt 2>&1
+  # the synchronous call: shipped chain, two-launch form, the three roles side by side (ceiling of a pipelined form), float
+  timeout 300 python tools/role_probe.py > gpurun_out/role_probe_$tag.txt 2>&1
   timeout 500 bash tools/pmc422.sh pmc422_$tag > /dev/null 2>&1
   timeout 250 tools/kstats.sh ks_${tag}_tocomp --tool to_composite --inflight 1 --steps 20 --sustain-seconds 0 > /dev/null
   timeout 600 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
@@ -58,6 +70,12 @@ else
   [ -s gpurun_out/host422_loop_probe.txt ] && cp gpurun_out/host422_loop_probe.txt profiles/${tag}_host422_loop_probe.txt
   [ -s gpurun_out/ks_${tag}_sync/kernel_stats.csv ] && { cat gpurun_out/ks_${tag}_sync/kernel_stats.csv; echo; cat gpurun_out/ks_${tag}_sync/memory_copy_stats.csv; } > profiles/${tag}_sync_call_stats.csv
   [ -s gpurun_out/rank_bench_$tag.txt ] && grep '^{' gpurun_out/rank_bench_$tag.txt > profiles/${tag}_rank_bench.json
+  [ -s gpurun_out/bench_extras_$tag.json ] && cp gpurun_out/bench_extras_$tag.json profiles/${tag}_bench_extras.json
+  [ -s gpurun_out/bench_${tag}_float.json ] && cp gpurun_out/bench_${tag}_float.json profiles/${tag}_bench_float.json
+  [ -s gpurun_out/ks_${tag}_float/kernel_stats.csv ] && cp gpurun_out/ks_${tag}_float/kernel_stats.csv profiles/${tag}_kernel_stats_float.csv
+  [ -s gpurun_out/float_err_$tag.txt ] && cp gpurun_out/float_err_$tag.txt profiles/${tag}_float_err.txt
+  [ -s gpurun_out/float_pmc_$tag.txt ] && { cat gpurun_out/float_pmc_$tag.txt; echo; echo "== FETCH_SIZE / WRITE_SIZE (KiB, raw counters; calibration factors: profiles/r04_fetch_calibration.txt)"; cat gpurun_out/float_traffic_$tag.txt; } > profiles/${tag}_float_pmc.txt
+  [ -s gpurun_out/role_probe_$tag.txt ] && cp gpurun_out/role_probe_$tag.txt profiles/${tag}_role_probe.txt
   # opcode histograms of the hand-tuned decoder forms' steady loops (the per-stage census: profiles/${tag}_decode_census.txt)
   { for k in 'k_decode_fastILb1EdLb0EE' 'k_decode_fast_xiIdE' 'k_decode_fast_foIdE' 'k_decode_fast_svIdE'; do
       echo "== $k"; (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s "$k" --hist | awk 'NR % 2 == 1 || 1' | cut -c1-1400 | grep -A1 "VALU [67][0-9][0-9] " | head -2); done; } > profiles/${tag}_loop_histograms.txt 2>/dev/null
