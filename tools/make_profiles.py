@@ -150,7 +150,8 @@ e2e = d.get("end_to_end", {})
 rd = "# profiles/ -- round %s (MI355X, gfx950, ROCm 7.2)\n\n" % tag[1:]
 rd += "Everything here comes from `python bench.py` (BASELINE configs[1]: 720x486, 600 fields per step, `-vhs`) and the probes in `tools/`; `tools/refresh_profiles.sh` shows the commands, `tools/make_profiles.py` assembles this directory.  Files of earlier rounds (`r01_*` … `r03_*`) are kept for comparison.\n\n"
 rd += "| file | command | what |\n|---|---|---|\n"
-rd += "| `%s_bench.json` | `python bench.py` | the bench line: value, value_sustained, roofline (+ cycle-weighted `valu`, calibrated `traffic`), cpu_baseline, device_stream, end_to_end (incl. `field_submit`, `field_submit422`), multi_gpu_cpp_host, variant422, raw28, sizes, presets |\n" % tag
+rd += "| `%s_bench_driver_cmd.json`, `%s_bench_line_default_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command, nothing skipped); `python bench.py` | what bench.py PRINTS since round 6: the contract object alone (< 4 KB: contract keys, `roofline`, `cpu_baseline`, `side` = one number per side leg); everything else goes to `bench_extras.json` = the next row |\n" % (tag, tag)
+rd += "| `%s_bench.json` | the same driver-command run | the FULL dictionary of that run (`bench_extras.json`): value, value_sustained, roofline (+ cycle-weighted `valu`, calibrated `traffic`), cpu_baseline, device_stream, end_to_end (incl. `field_submit`, `field_submit422`), multi_gpu_cpp_host, variant422, raw28, sizes, presets |\n" % tag
 rd += "| `%s_kernel_stats_default_cmd.csv` | `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-fields 0 --no-extras` | 4 steps in flight: kernels of different steps share the GPU, wall durations stretch; **Min** = un-shared duration |\n" % tag
 rd += "| `%s_kernel_stats_inflight1.csv` | `... --inflight 1` | one step at a time: per-kernel durations without overlap |\n" % tag
 rd += "| `%s_pmc_summary.txt` | `tools/pmc.sh` (4 separate `--pmc` passes, `--inflight 1`) | FETCH_SIZE, WRITE_SIZE, SQ counters per kernel (mean per launch) |\n" % tag
@@ -159,7 +160,8 @@ rd += "| `%s_chain_probe.txt` | `tools/chain_probe.hip` | cost of dependent fp64
 rd += "| `%s_isa_cost.json` | `tools/isa_cost.py` | cycle-weighted instruction census of each kernel's steady loop |\n" % tag
 rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_pmc_summary_to_composite.txt` | `python bench.py --tool to_composite`, `tools/kstats.sh ... --tool to_composite --inflight 1`, `tools/pmc422.sh` | the same three for the YUV422P tool |\n" % (tag, tag, tag)
 rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- python tools/raw28_probe.py` | kernels of the raw-composite decoder on a 600-field capture (4 calls) |\n" % tag
-rd += "| `%s_bench_driver_cmd.json` | `python bench.py --gpus 1 --steps 20 --warmup 5 ...` | the driver's own window |\n" % tag
+rd += "| `%s_bench_float.json`, `%s_kernel_stats_float.csv`, `%s_float_err.txt`, `%s_float_pmc.txt` | `python bench.py --mode float`, `tools/kstats.sh ... --mode float --inflight 1`, `tools/float_err.py`, `tools/fp_probe.sh` + FETCH_SIZE / WRITE_SIZE passes | (round 6) NTSCSIM_MODE_FLOAT, the all-float pipeline: bench line, kernel durations, error against the oracle per input class (max, share of pixels / channels that differ, mean signed difference, histogram), stall counters of its decoder forms (one wave: variant 10; two-role workgroup: variant 0) and its HBM bytes |\n" % (tag, tag, tag, tag)
+rd += "| `%s_role_probe.txt` | `tools/role_probe.py` | (round 6) the synchronous one-field call: shipped chain, two-launch decoder, encoder + VCR half + TV half launched side by side with no dependency (`NTSCSIM_ROLE_PROBE=1`: the ceiling of a stage-pipelined form), and the float pipeline |\n" % tag
 rd += "| `r04_decode_census.txt`, `%s_loop_histograms.txt` | `tools/loop_census.py --hist` on `hipcc -S`; source accounting | where the VALU instructions of `k_decode_fast` go, stage by stage; what the round-4 diet removed; what was measured and not done (noise pre-pass, LDS luma ring, packed fp32) -- the kernel is unchanged since; opcode histograms of the steady loops of the hand-tuned decoder forms on this round's build |\n" % tag
 rd += "| `r04_fetch_calibration.txt` | `tools/fetch_calibrate.sh` (`tools/fetch_probe.hip`) | FETCH_SIZE / WRITE_SIZE against known byte counts for this library's access shapes: the factors `traffic.json` applies |\n"
 rd += "| `%s_submit_probe.txt` | `tools/submit_probe.sh` (`host/field_loop.cpp`, `tools/link_probe.hip`) | `ntscsim_submit()` / `ntscsim_wait()` against the synchronous call: byte identity (FNV-1a of every consumed frame), fields/s by depth / lanes / line doubling / source handling / delivery path / lag, GPU spans of consecutive launches, the host link's rates |\n" % tag
@@ -172,7 +174,7 @@ rd += "| `r04_fuzz_sweep.txt` | `tools/fuzz_r04.sh` | one-off parity sweeps on t
 rd += "| `r03_decode_experiments.txt`, `r03_clock_under_load.txt`, `r03_composite_range.txt`, `r03_variant_sweeps.txt` | (round 3) | A/B experiments on the dominant kernel; shader clock under load (2.31-2.32 GHz); value range of the composite plane; wave-clock share of the YUV422P kernel's sweeps |\n"
 rd += "| `%s_raw28_front_pmc.txt` | `tools/pmc_raw28.sh`, `tools/follow_probe.hip` | counters of the raw-composite decoder's two front-end sweeps and the cost of one follower step for a lone wavefront |\n" % tag
 rd += "| `%s_host422_loop_probe.txt` | `tools/host422_loop_probe.sh` (`host/field_loop422.cpp`) | (round 5) the YUV422P tool's loop on host frames, `ntscsim_field422()` / `ntscsim_submit422()`: byte identity (FNV-1a of every encoder frame) across sync / submit / staging rings / page-owned planes for six switch sets, fields/s by switch set, depth and frame allocation, host time inside the calls |\n" % tag
-rd += "| `%s_sync_call_stats.csv`, `%s_sync_call_notes.txt` | `rocprofv3 --kernel-trace --memory-copy-trace --stats -- field_loop -vhs --mode sync`; `tools/gpu_r05_5.sh` | (round 5) where the 0.51 ms of one synchronous `ntscsim_field()` call go, kernel by kernel; the same loop alone and beside a process that keeps the GPU busy (same rate: not a clock effect) |\n" % (tag, tag)
+rd += "| `%s_sync_call_stats.csv`, `r05_sync_call_notes.txt` | `rocprofv3 --kernel-trace --memory-copy-trace --stats -- field_loop -vhs --mode sync` | where the ~0.5 ms of one synchronous `ntscsim_field()` call go, kernel by kernel; (round 5) the same loop alone and beside a process that keeps the GPU busy (same rate: not a clock effect) |\n" % tag
 rd += "| `%s_rank_bench.json` | `rank_bench -vhs --spawn 1 --frames 300 --steps 40 --warmup 8` | (round 5) the C++ rank-per-GPU harness over `rccl.h` with the one rank this box has |\n" % tag
 rd += "| `traffic.json` | derived (`tools/make_profiles.py`) | HBM bytes and VALU work per launch that `bench.py` turns into `roofline.traffic` / `roofline.valu` |\n\n"
 rd += "## Bench line\n\n"
@@ -201,21 +203,22 @@ if e2e:
         rd += "One field per `ntscsim_field()` call (the 1:1 drop-in, synchronous, pageable host frames): %.0f fields/s.  " % e2e["field_call"]
     if e2e.get("field_submit"):
         fsd = e2e.get("field_submit_detail", {})
-        rd += ("The same loop with `ntscsim_submit()` / `ntscsim_wait()` (`host/field_loop.cpp`, depth 32, pageable AVFrame-shaped buffers pinned in place): %.0f fields/s with one source frame "
-               "rewritten per decoded frame (`end_to_end.field_submit`), %.0f with the source re-pointed at decoded frames, %.0f with the line doubling delivered as well, %.0f at depth 128, "
-               "%.0f through the staging ring.  " % (e2e["field_submit"], (fsd.get("depth32_decoder_frames") or {}).get("fields_per_s", 0),
-                                                     (fsd.get("depth32_bob") or {}).get("fields_per_s", 0), (fsd.get("depth128") or {}).get("fields_per_s", 0),
-                                                     (fsd.get("depth32_staging_ring") or {}).get("fields_per_s", 0)))
+        rd += ("The same loop with `ntscsim_submit()` / `ntscsim_wait()` (`host/field_loop.cpp`, depth 32): %.0f fields/s with one source frame "
+               "rewritten per decoded frame (`end_to_end.field_submit`: frames from ntscsim_host_frame_alloc), %.0f with the source re-pointed at decoded frames, %.0f with the line doubling delivered as well, %.0f at depth 128, "
+               "%.0f with the frames in a pool declared by ntscsim_host_pin, %.0f with plain posix_memalign frames (staged: pinned rings + the engine's copy threads).  " % (
+                   e2e["field_submit"], (fsd.get("depth32_decoder_frames") or {}).get("fields_per_s", 0),
+                   (fsd.get("depth32_bob") or {}).get("fields_per_s", 0), (fsd.get("depth128") or {}).get("fields_per_s", 0),
+                   (fsd.get("depth32_declared_pool") or {}).get("fields_per_s", 0), (fsd.get("depth32_malloc_frames_staged") or {}).get("fields_per_s", 0)))
     if e2e.get("cli"):
         rd += "`ntsc_cli -vhs -i bars:3000 -o null:` %.0f fields/s (`end_to_end.cli`).  " % e2e["cli"]
 if e2e.get("field_submit422"):
     f4 = e2e.get("field_submit422_detail", {})
     g = lambda k_: (f4.get(k_) or {}).get("fields_per_s", 0) if isinstance(f4.get(k_), dict) else (f4.get(k_) or 0)
     rd += ("\n\nThe YUV422P tool's loop on host frames (`host/field_loop422.cpp`, 720x480, depth 32; `end_to_end.field_submit422*`): %.0f fields/s with `-vhs` "
-           "(posix_memalign'ed planes under mallopt(M_MMAP_THRESHOLD, 64 KiB): pinned in place), %.0f without the mallopt (heap blocks: staging rings), %.0f with `-vhs -422` on page-owned planes, %.0f with the default preset, "
-           "%.0f one iteration at a time (tight rows, 704 wide), %.0f for the synchronous `ntscsim_field422()`.  " % (
-               e2e["field_submit422"], g("depth32_vhs_heap_planes"), g("depth32_vhs_422_page_frames"), g("depth32_default_preset"),
-               g("tight_rows_704_one_at_a_time"), g("loop_sync_fields_per_s")))
+           "(planes from ntscsim_host_frame_alloc: pinned by construction), %.0f with a declared pool, %.0f with plain posix_memalign planes and no mallopt (staging rings + copy threads), "
+           "%.0f with `-vhs -422`, %.0f with the default preset, %.0f with tight rows (704 wide: batched, pad bytes chained on the device), %.0f for the synchronous `ntscsim_field422()`.  " % (
+               e2e["field_submit422"], g("depth32_vhs_declared_pool"), g("depth32_vhs_heap_planes"), g("depth32_vhs_422_pinned"), g("depth32_default_preset"),
+               g("tight_rows_704"), g("loop_sync_fields_per_s")))
 mg = d.get("multi_gpu_cpp_host") or {}
 if mg.get("value"):
     rd += "`rank_bench --spawn 1` (C++ host, `rccl.h`): %.0f fields/s, checksums verified: %s.  " % (mg["value"], mg.get("rank_checksums_verified"))
@@ -231,7 +234,11 @@ if "raw28" in d:
 if "sizes" in d:
     rd += "1920x1080: %.0f, 3840x2160: %.0f frames/s.  " % (d["sizes"]["1920x1080"]["value"], d["sizes"]["3840x2160"]["value"])
 if "presets" in d:
-    rd += "Default preset at 720x486: %.0f frames/s.\n\n" % d["presets"]["default"]["value"]
+    rd += "Default preset at 720x486: %.0f frames/s.  " % d["presets"]["default"]["value"]
+if isinstance(d.get("fast"), dict) and d["fast"].get("value"):
+    rd += ("Tolerance modes (never the default; `fast`, `fast32`): NTSCSIM_MODE_FLOAT %.0f frames/s (decoder `roofline_frac` %.3f, kernels %s), NTSCSIM_MODE_FAST32 %.0f.  " % (
+        d["fast"]["value"], d["fast"].get("roofline_frac") or 0, ", ".join(d["fast"].get("kernels", [])), (d.get("fast32") or {}).get("value", 0)))
+rd += "\n\n"
 rd += "## Kernel durations (us): hipEvents in bench.py vs rocprofv3\n\n"
 rd += "| kernel | bench.py hipEvents (isolated pass) | rocprofv3 inflight 1 avg | rocprofv3 default cmd min / avg / max |\n|---|---|---|---|\n"
 k = d["roofline"]["kernel_ms_all"]

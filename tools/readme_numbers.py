@@ -1,88 +1,68 @@
 #!/usr/bin/env python3
-"""Rewrites the "Round-N numbers" paragraph of README.md from the tracked bench lines under
-profiles/ (run after tools/refresh_profiles.sh local <tag>):  python tools/readme_numbers.py r03"""
+"""Rewrites the numbers table of README.md (between the markers `<!-- numbers:begin -->` / `<!-- numbers:end -->`) from
+the tracked bench files under profiles/ (run after tools/refresh_profiles.sh local <tag>):
+    python tools/readme_numbers.py r06"""
 import json
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-d = json.load(open("profiles/%s_bench.json" % tag))
-t = json.load(open("profiles/%s_bench_to_composite.json" % tag))
-f = json.load(open("profiles/%s_bench_fast32.json" % tag))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+P = "profiles/%s_" % tag
+line = json.load(open(P + "bench_driver_cmd.json"))          # what the driver's command printed
+full = json.load(open(P + "bench.json"))                     # bench_extras.json of the same run
+flt = json.load(open(P + "bench_float.json"))
+f32 = json.load(open(P + "bench_fast32.json"))
+toc = json.load(open(P + "bench_to_composite.json"))
+try:
+    dflt = json.load(open(P + "bench_line_default_cmd.json"))
+except Exception:
+    dflt = None
+e = full.get("end_to_end", {})
+fs, f4 = e.get("field_submit_detail", {}), e.get("field_submit422_detail", {})
+
+
+def rate(d, k):
+    x = d.get(k)
+    return (x.get("fields_per_s") if isinstance(x, dict) else x) or 0
+
+
+def k(v):
+    return "%.0fk" % (v / 1e3) if v >= 10000 else "%.2fk" % (v / 1e3)
+
+
+cb = line["cpu_baseline"]
+rows = [
+    ("**headline, driver's window** (`python bench.py --gpus 1 --steps 20 --warmup 5`): 600-field `-vhs` clip resident in HBM, exact mode, four steps in flight",
+     "**%s fields/s** (`value`), %s sustained over 0.5 s" % (k(line["value"]), k(line["value_sustained"])), "`%sbench_driver_cmd.json`" % P),
+    ("the same with `bench.py`'s own defaults (100 timed steps after 40 warm-up steps)",
+     "%s fields/s" % k(dflt["value"]) if dflt else "-", "`%sbench_line_default_cmd.json`" % P),
+    ("`roofline` of the dominant kernel (`k_decode_fast<true,double>`, algorithmic 8·W·L bytes per field ÷ its duration ÷ 8 TB/s)",
+     "`frac` **%.3f** (%.0f GB/s); the kernel moves %.2f × those bytes over HBM (encoder + decoder: %.2f ×, the composite plane between them); the bound that applies is VALU issue: %.2f of its nominal capacity for the whole path" % (
+         line["roofline"]["frac"], line["roofline"]["achieved"], (full["roofline"].get("traffic") or 0) / full["roofline"]["algorithmic_bytes_per_launch"],
+         json.load(open("profiles/traffic.json"))["720x486 -vhs"]["path_over_algorithmic"], line["roofline"]["valu"]["path_frac_nominal"]), "DESIGN.md §5, `profiles/traffic.json`"),
+    ("CPU beside it on the GPU box's host: the reference's own `composite_layer()` text, 1 thread like the tool",
+     "%.1f fields/s (our C port: %.0f on 1 core, %.0f on %d cores)" % (cb["value"], cb["port_1core"], cb["port_all_cores"]["value"], cb["port_all_cores"]["cores"]),
+     "`cpu_baseline`"),
+    ("device-resident STREAM of fresh batches (descriptor validation, `rand()` windows, record upload inside the clock)", "%s fields/s" % k(line["side"]["device_stream"]), "`side.device_stream`"),
+    ("other sizes, `-vhs`: 1920×1080 / 3840×2160", "%s / %s fields/s" % (k(line["side"]["sizes"]["1920x1080"]), k(line["side"]["sizes"]["3840x2160"])), "`side.sizes`"),
+    ("default preset (BASELINE configs[0] on the GPU)", "%s fields/s" % k(line["side"]["presets"]["default"]), "`side.presets`"),
+    ("the YUV422P tool (`ffmpeg_to_composite`), `-vhs`, device resident", "%s frames/s (sustained %s)" % (k(toc["value"]), k(toc.get("value_sustained", 0))), "`%sbench_to_composite.json`" % P),
+    ("the raw-composite decoder (`ffmpeg_raw28ntsc`), 600-field capture resident in HBM", "%s fields/s" % k(line["side"]["raw28"]), "`side.raw28`"),
+    ("**tolerance mode `NTSCSIM_MODE_FLOAT`** (all-float pipeline, ≤ 1 LSB, never the default)",
+     "**%s fields/s**, decoder `roofline.frac` %.3f (FAST32, the exact kernels with float states: %s)" % (k(flt["value"]), flt["roofline"]["frac"], k(f32["value"])),
+     "`%sbench_float.json`, DESIGN.md §3b" % P),
+    ("drop-in on HOST frames, synchronous: one `ntscsim_field()` per `composite_layer()` call", "%s fields/s (%.0f × the reference on one core)" % (k(e.get("field_call", 0)), e.get("field_call", 0) / cb["value"]), "`side.field_call`"),
+    ("... asynchronous, `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`): frames from `ntscsim_host_frame_alloc()` / a pool declared with `ntscsim_host_pin()` / plain `posix_memalign` frames (staged)",
+     "%s / %s / %s fields/s" % (k(e.get("field_submit", 0)), k(rate(fs, "depth32_declared_pool")), k(rate(fs, "depth32_malloc_frames_staged"))), "`end_to_end.field_submit*`"),
+    ("the YUV422P tool's loop on host frames, depth 32 (`host/field_loop422.cpp`): pinned planes / plain heap planes, no `mallopt` / tight rows (704 wide) / synchronous",
+     "%s / %s / %s / %s fields/s" % (k(e.get("field_submit422", 0)), k(rate(f4, "depth32_vhs_heap_planes")), k(rate(f4, "tight_rows_704")), k(rate(f4, "loop_sync_fields_per_s"))),
+     "`end_to_end.field_submit422*`"),
+    ("whole clips from host memory (`ntscsim_frames_host`): BGRA out / YUV420P out / YUV420P in and out", "%s / %s / %s fields/s" % (
+        k(e.get("bgra_pinned", 0)), k(e.get("yuv420p_pinned", 0)), k(e.get("yuv420p_in_yuv420p_out_pinned", 0))), "`end_to_end.*_pinned`"),
+    ("one process per GPU, C++ host over `rccl.h` (`host/rank_bench.cpp`), with the one rank this box has", "%s fields/s, checksums verified" % k(line["side"]["multi_gpu_cpp_host"]), "`side.multi_gpu_cpp_host`"),
+]
+tbl = "| what (1× MI355X, 720×486 unless said otherwise) | measured | where |\n|---|---|---|\n" + "\n".join("| %s | %s | %s |" % r for r in rows)
 s = open("README.md").read()
-import re
-a, b = re.search(r"Round-\d numbers", s).start(), s.index("Build: `python -c")
-v = d["roofline"]["valu"]
-p_ = d.get("presets", {})
-cb, e = d["cpu_baseline"], d["end_to_end"]
-r28 = d.get("raw28")
-raw28 = ("  The raw-composite decoder (`ffmpeg_raw28ntsc`, `raw28`): a 600-field capture resident in HBM decodes at "
-         "%.1fk fields/s (the reference text on one host core: %.0f)." % (r28["value"] / 1e3, r28["cpu_1core"]["value"])) if r28 else ""
-fcall = ("  One field per synchronous `ntscsim_field()` call (the 1:1 drop-in on host frames): %.0f fields/s." % e["field_call"]) if e.get("field_call") else ""
-cli = ("  The raw-file CLI `ntsc_cli -vhs -i bars:3000 -o null:` runs at %.0fk fields/s (`end_to_end.cli`)." % (e["cli"] / 1e3)) if e.get("cli") else ""
-ds = d.get("device_stream", {})
-fs = e.get("field_submit_detail", {})
-def fps(k):
-    x = fs.get(k) or {}
-    return (x.get("fields_per_s") or 0) / 1e3
-pre = (d["config"].get("pre_roll") or {})
-f4 = e.get("field_submit422_detail") or {}
-def f4ps(k):
-    x = f4.get(k)
-    return ((x.get("fields_per_s") or 0) if isinstance(x, dict) else (x or 0)) / 1e3
-tp = t.get("presets") or {}
-v422 = ""
-if e.get("field_submit422"):
-    v422 = ("  The YUV422P tool on HOST frames (`ntscsim_field422()` / `ntscsim_submit422()`, `host/field_loop422.cpp`: the loop of "
-            "ffmpeg_to_composite.cpp:1783-1800 with its four calls replaced by one, 720×480, depth 32): %.0fk fields/s with `-vhs` "
-            "(frame planes pinned in place), %.0fk through the staging rings (heap-block planes: no `mallopt`), %.1fk one iteration at a time "
-            "(tight rows), %.1fk synchronous (`end_to_end.field_submit422*`)." % (
-                e["field_submit422"] / 1e3, f4ps("depth32_vhs_heap_planes"), f4ps("tight_rows_704_one_at_a_time"), f4ps("loop_sync_fields_per_s")))
-    if tp.get("default", {}).get("value"):
-        v422 += ("  Its switch-set families on the device (`bench.py --tool to_composite` → `presets`): default preset %dk frames/s (`%s`), "
-                 "`-vhs -vhs-svideo 1` %dk (`%s`)." % (round(tp["default"]["value"] / 1e3), ", ".join(tp["default"].get("kernels", [])),
-                                                     round(tp.get("vhs_svideo", {}).get("value", 0) / 1e3), ", ".join(tp.get("vhs_svideo", {}).get("kernels", []))))
-mg = d.get("multi_gpu_cpp_host") or {}
-mgpu = ("  One process per GPU with the C++ host over `rccl.h` (`host/rank_bench.cpp`, here with the one rank this box has): %dk fields/s, checksums verified."
-        % round(mg["value"] / 1e3)) if mg.get("value") else ""
-new = ("Round-%s numbers (1× MI355X, 720×486, 600-field clip, full `-vhs` preset, exact mode; every figure is\n"
-       "a key of `profiles/%s_bench.json`, the line `python bench.py` prints; `profiles/README.md` maps the\n"
-       "rest; box-to-box spread ≈ ±4 %%: `value` 764-813k over the boxes this round saw, the isolated kernels take the same time on all of them):\n"
-       "`value_sustained` **%dk fields/s** (the same 600-field step repeated for %.2f s, four steps in flight) and `value` **%dk** over the %d\n"
-       "timed steps that follow it (`config.pre_roll`: the sustained leg runs BEFORE the W warm-up steps, so the timed steps see a GPU at its\n"
-       "working clocks; rounds 1 and 2 were measured without it and read 4-6 %% lower for that reason alone).  With the driver's own\n"
-       "window (`--steps 20 --warmup 5`): %dk (`profiles/%s_bench_driver_cmd.json`).  A device-resident STREAM of fresh batches -- every step the next\n"
-       "600 fields, descriptor validation, `rand()` windows and record upload inside the clock -- runs at %dk (`device_stream`, %.2f × `value`).\n"
-       "CPU beside it on the GPU box's host: the reference's own `composite_layer()`\n"
-       "(`oracle/_ref`, single-threaded like the tool) %.0f fields/s, our C port %.0f fields/s on one core and\n"
-       "%d fields/s on the %d CPUs the box's cgroup allows.  `sizes`: 1920×1080 %.1fk, 3840×2160 %.1fk\n"
-       "fields/s; `presets.default`: %dk fields/s; other switch sets, each on a hand-tuned form of its own, as a fraction of the `-vhs` preset measured the same way (`presets.*.frac_of_preset`): %s;\n"
-       "the YUV422P tool (`python bench.py --tool to_composite`,\n"
-       "`profiles/%s_bench_to_composite.json`): **%dk frames/s** sustained, %dk over the timed steps.  The path is VALU-issue\n"
-       "bound, not HBM bound: `roofline.frac` (HBM, algorithmic bytes) = %.3f, and %.2f is the most a kernel chain with the\n"
-       "reference's fp64 arithmetic could reach (`roofline.valu.hbm_frac_ceiling_exact_mode`); `roofline.valu.path_frac_nominal` =\n"
-       "%.2f of the VALU issue capacity at the pipe's nominal 4 / 2 cycles per instruction (%.2f at the measured slowest-wave\n"
-       "costs; PMC instruction counts × each kernel's instruction mix ÷ measured time) — see `profiles/README.md`, `profiles/r04_decode_census.txt` and DESIGN.md §5 for what\n"
-       "was measured and what is derived.  The drop-in on HOST frames: one synchronous `ntscsim_field()` per `composite_layer()` call %.1fk fields/s; the\n"
-       "same loop with `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`, pageable AVFrame-shaped buffers pinned in place) **%.0fk** with ONE\n"
-       "source frame rewritten per decoded frame, %.0fk with the source re-pointed at decoded frames, %.0fk with the line doubling delivered too, %.0fk at depth 128\n"
-       "(`end_to_end.field_submit*`; %.0f × the reference on one core; these are the host link's rates, not the GPU's -- 0.7 MB up and 0.7 MB down per field, "
-       "1.4 MB down with the line doubling: DESIGN.md §1b).  Whole clips from host memory (`ntscsim_frames_host`): %.0fk\n"
-       "fields/s BGRA out, %.0fk with YUV420P made on the GPU, %.0fk with YUV420P in as well.%s%s%s%s  Not a headline: the optional\n"
-       "`NTSCSIM_MODE_FAST32` (the same kernels with fp32 filter states, ≤1 LSB, not bit-exact) runs %dk fields/s (`profiles/%s_bench_fast32.json`).\n\n" % (
-           tag[1:].lstrip("0"), tag, round(d["value_sustained"] / 1e3), (d.get("sustained") or {}).get("seconds", 0.5), round(d["value"] / 1e3), d["steps"],
-           round(json.load(open("profiles/%s_bench_driver_cmd.json" % tag))["value"] / 1e3), tag,
-           round(ds.get("value", 0) / 1e3), ds.get("value", 0) / d["value"],
-           cb["value"], cb["port_1core"],
-           round(cb["port_all_cores"]["value"]), cb["port_all_cores"]["cores"],
-           d["sizes"]["1920x1080"]["value"] / 1e3, d["sizes"]["3840x2160"]["value"] / 1e3,
-           round(d["presets"]["default"]["value"] / 1e3),
-           ", ".join("%s %dk (%.2f)" % (k[4:], round(x["value"] / 1e3), x.get("frac_of_preset") or 0) for k, x in p_.items() if k.startswith("vhs_") and "value" in x),
-           tag, round(t["value_sustained"] / 1e3), round(t["value"] / 1e3), d["roofline"]["frac"], v["hbm_frac_ceiling_exact_mode"],
-           v["path_frac_nominal"], v["path_frac"], e["field_call"] / 1e3,
-           e.get("field_submit", 0) / 1e3, fps("depth32_decoder_frames"), fps("depth32_bob"), fps("depth128"),
-           e.get("field_submit", 0) / cb["value"],
-           e["bgra_pinned"] / 1e3, e["yuv420p_pinned"] / 1e3,
-           e.get("yuv420p_in_yuv420p_out_pinned", 0) / 1e3, cli, raw28, v422, mgpu,
-           round(f["value"] / 1e3), tag))
-open("README.md", "w").write(s[:a] + new + s[b:])
-print(new)
+a, b = s.index("<!-- numbers:begin -->"), s.index("<!-- numbers:end -->")
+s = s[:a] + "<!-- numbers:begin -->\n" + tbl + "\n" + s[b:]
+open("README.md", "w").write(s)
+print(tbl)

@@ -58,7 +58,10 @@ else
   done
   (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s 'k422_fusedILb1ELb1E' --mean > /tmp/census_$tag/k422_fused.json)
   [ -s gpurun_out/fetch_calibration.txt ] && cp gpurun_out/fetch_calibration.txt profiles/r04_fetch_calibration.txt
-  python tools/make_profiles.py $tag gpurun_out/bench_$tag.json gpurun_out/ks_${tag}_default gpurun_out/ks_${tag}_if1 \
+  # (since round 6 bench.py prints the contract object only: the full dictionary make_profiles.py reads is the driver-command
+  #  run's bench_extras.json; the printed lines are kept beside it)
+  [ -s gpurun_out/bench_$tag.json ] && cp gpurun_out/bench_$tag.json profiles/${tag}_bench_line_default_cmd.json
+  python tools/make_profiles.py $tag gpurun_out/bench_extras_$tag.json gpurun_out/ks_${tag}_default gpurun_out/ks_${tag}_if1 \
       gpurun_out/pmc_$tag gpurun_out/valu_rates_$tag.txt gpurun_out/chain_probe_$tag.txt /tmp/census_$tag \
       gpurun_out/bench_${tag}_fast32.json gpurun_out/bench_${tag}_tocomp.json gpurun_out/ks_${tag}_tocomp \
       gpurun_out/pmc422_$tag > /dev/null && echo "profiles/ assembled"
