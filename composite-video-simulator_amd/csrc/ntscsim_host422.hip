@@ -39,6 +39,8 @@ struct PadRec422 {                // the two bytes behind every row of the field
                                   // (16 behind the frame's last row); NULL: take `pad`
     int32_t ls, W, field, nrows;
     int32_t chain_ls, H;
+    int32_t host_ls, _pad;        // the caller's linesize: byte W + j of a row is the row's own padding while W + j < host_ls
+                                  // (nobody writes it: the snapshot), pixel W + j - host_ls of the NEXT row otherwise
 };
 
 // grid (row chunks, records): copy nrows rows of rowbytes bytes; records with nrows == 0 are skipped
@@ -65,8 +67,9 @@ __global__ void k422_pad(const PadRec422 *__restrict__ recs)
         uint8_t *row = r.y + (size_t)r.ls * (size_t)y;
         uint8_t a = r.pad[2 * k], b = r.pad[2 * k + 1];
         if (r.chain) {
-            if (y + 1 < r.H) { const uint8_t *nx = r.chain + (size_t)r.chain_ls * (size_t)(y + 1); a = nx[0]; b = nx[1]; }
-            else { a = 16; b = 16; }
+            const uint8_t *nx = r.chain + (size_t)r.chain_ls * (size_t)(y + 1);
+            if (r.W >= r.host_ls) a = y + 1 < r.H ? nx[r.W - r.host_ls] : (uint8_t)16;
+            if (r.W + 1 >= r.host_ls) b = y + 1 < r.H ? nx[r.W + 1 - r.host_ls] : (uint8_t)16;
         }
         row[r.W] = a;
         row[r.W + 1] = b;
@@ -513,7 +516,7 @@ static int h422_launch(ntscsim_ctx *c)
         PadRec422 &p = e->prec[it.slot];
         p.y = frm[0]; p.pad = e->pads + (size_t)2 * e->L * (size_t)it.slot; p.ls = fls[0]; p.W = W;
         p.chain = (it.tight && it.chain_fslot >= 0) ? e->dfrm.p + e->fbytes * (size_t)it.chain_fslot + e->foff[0] : nullptr;
-        p.chain_ls = e->lsd[0]; p.H = H;
+        p.chain_ls = e->lsd[0]; p.H = H; p.host_ls = L.frame.linesize[0]; p._pad = 0;
         if (it.tight && it.chain_fslot >= 0 && it.chain_ticket >= b.first) two_pass = true;
         p.field = (int32_t)L.field; p.nrows = it.serial ? 0 : nr;
         any_pad = any_pad || !it.serial;
@@ -773,9 +776,11 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
         for (int k = 0; k < nr; k++) {
             const int y = (int)L->field + 2 * k;
             const uint8_t *row = L->frame.data[0] + (size_t)L->frame.linesize[0] * (size_t)y;
-            // (behind the last row of a TIGHT plane lies nothing of the caller's: the contract's value 16)
-            const bool inside = !it.tight || (size_t)L->frame.linesize[0] * (size_t)y + (size_t)W + 1 < (size_t)L->frame.linesize[0] * (size_t)H;
-            pad[2 * k] = inside ? row[W] : 16; pad[2 * k + 1] = inside ? row[W + 1] : 16;
+            // (behind the last row of a TIGHT plane lies nothing of the caller's: the contract's value 16 -- byte by byte: with
+            //  linesize = width + 1 the first of the two is still the row's own padding)
+            const size_t plane = (size_t)L->frame.linesize[0] * (size_t)H, at = (size_t)L->frame.linesize[0] * (size_t)y + (size_t)W;
+            pad[2 * k] = (!it.tight || at < plane) ? row[W] : 16;
+            pad[2 * k + 1] = (!it.tight || at + 1 < plane) ? row[W + 1] : 16;
         }
     }
     // ---- source snapshot

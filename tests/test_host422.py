@@ -288,6 +288,9 @@ def test_tight_rows_are_batched_with_the_pad_bytes_chained_on_the_device(flags, 
     if mode == "submit" and lag is None:
         assert st[3] == 14 and st[4] == 0, st               # batched, none one at a time
         assert st[1] <= 14 // depth + 2
+    # linesize = width + 1: the first byte behind a row is the row's own padding (the caller's, noise here), the second
+    # one pixel 0 of the next row (tools/fuzz_host422.py found the first build of the chain taking both from the next row)
+    run_loop(p, w, h, 1, 5, out_mode, mode, depth=depth, interlaced_out=il, lag=lag)
 
 
 def test_tight_rows_chain_survives_a_dirty_frame_and_a_one_at_a_time_iteration():

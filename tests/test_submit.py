@@ -329,3 +329,54 @@ def test_cpp_field_loop_allocators_pinned_pool_and_plain_malloc(bob):
         assert b["fnv1a"] == a["fnv1a"] != "0000000000000000" and b["rng_pos"] == a["rng_pos"], (alloc, pin)
         assert (b["stats"]["delivered_direct"] > 0) == direct, (alloc, pin, b["stats"])
         assert (b["stats"]["delivered_staged"] > 0) == (not direct), (alloc, pin, b["stats"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["declared", "host_alloc", "neither"])
+def test_frames_that_are_not_page_aligned_need_a_declaration_or_pinned_memory(how):
+    """The pin rules of include/ntscsim.h ("Host buffers") through the Python veneer: frames that start 80 bytes into a
+    block (what an allocator's header + alignment gives) are written by the GPU in place when the block was DECLARED with
+    ntscsim_host_pin() or IS pinned memory (ntscsim_host_alloc: the runtime is asked), and are staged -- nothing
+    registered, no header word read -- when they are neither.  Same frames every way."""
+    w, h, n = 192, 96, 12
+    p = L.make_params(["-vhs"], output_height=h)
+    frames = [L.noise_frame(w, h, 900 + j) for j in range(n // 2)]
+    exp, exp_pos = reference_loop(p, frames, n, w, h, n, False)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.submit_configure(depth=4, slots=16, lanes=2, min_pin_bytes=0)
+    nbytes = h * w * 4
+    blocks = []
+    if how == "host_alloc":
+        views = []
+        for _ in range(n + 1):
+            a = ntscsim.host_alloc_array((nbytes + 4096,), align_offset=0)
+            blocks.append(a)
+            views.append(a[80:80 + nbytes].reshape(h, w, 4))
+    else:
+        import mmap
+        m = mmap.mmap(-1, (n + 1) * (nbytes + 4096))
+        pool = np.frombuffer(m, np.uint8)
+        views = [pool[i * (nbytes + 4096) + 80: i * (nbytes + 4096) + 80 + nbytes].reshape(h, w, 4) for i in range(n + 1)]
+        if how == "declared":
+            sim.host_pin(pool)
+    src, bufs = views[0], views[1:]
+    for b in bufs:
+        b[:] = 0x5A
+    tickets = []
+    for k in range(n):
+        if (k & 1) == 0:
+            src[:] = frames[k // 2]
+        tickets.append(sim.submit(bufs[k], src, (k & 1) ^ 1, k, same_src=(k & 1) == 1))
+    sim.wait()
+    for k in range(n):
+        assert np.array_equal(bufs[k], exp[k]), (how, k)
+    assert sim.rng_pos == exp_pos
+    st = sim.submit_stats()
+    if how == "neither":
+        assert st["delivered_direct"] == 0 and st["delivered_staged"] == n and st["registrations"] == 0, st
+    else:
+        assert st["delivered_direct"] == n and st["uploads_staged"] == 0, st
+    sim.host_unpin()
+    sim.close()
+    for a in blocks:
+        ntscsim.host_free_array(a)
