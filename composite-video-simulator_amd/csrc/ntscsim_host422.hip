@@ -201,7 +201,7 @@ static void host422_engine_destroy(ntscsim_ctx *c)
     if (!e) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    e->dlv.stop();
+    e->dlv.stop(true);
     for (auto &b : e->inflight) if (b.done) (void)hipEventDestroy(b.done);
     for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
     for (auto *m : e->mirrors) { m->dev.release(); delete m; }

@@ -90,18 +90,21 @@ public:
         return failed_.empty() || std::find(failed_.begin(), failed_.end(), id) == failed_.end();
     }
     void drain() { std::unique_lock<std::mutex> lk(m_); cv_done_.wait(lk, [&] { return delivered_ >= posted_; }); }
-    void stop()
+    // cancel: what has not been delivered yet is dropped, not copied (ntscsim_destroy() with fields in flight: the caller
+    // never waited for them, its frames may be gone)
+    void stop(bool cancel = false)
     {
         {
             std::unique_lock<std::mutex> lk(m_);
             if (!started_) return;
+            cancel_ = cancel;
             cv_done_.wait(lk, [&] { return delivered_ >= posted_; });
             quit_ = true;
             cv_.notify_all();
         }
         for (auto &t : threads_) t.join();
         threads_.clear();
-        started_ = false; quit_ = false;
+        started_ = false; quit_ = false; cancel_ = false;
     }
 
 private:
@@ -112,7 +115,7 @@ private:
     std::vector<std::thread> threads_;
     std::vector<uint64_t> failed_;
     uint64_t posted_ = 0, delivered_ = 0;
-    bool started_ = false, quit_ = false;
+    bool started_ = false, quit_ = false, cancel_ = false;
     // the launch being copied: helpers pull ops by index
     const std::vector<CopyOp> *cur_ = nullptr;
     std::atomic<size_t> next_{0};
@@ -156,7 +159,7 @@ private:
             const bool ok = hipEventSynchronize(j.done) == hipSuccess;
             if (!ok) (void)hipGetLastError();
             lk.lock();
-            if (ok && !j.ops.empty()) {
+            if (ok && !cancel_ && !j.ops.empty()) {
                 cur_ = &j.ops; next_.store(0); gen_++;
                 busy_ = (int)threads_.size() - 1;
                 cv_.notify_all();
@@ -322,7 +325,7 @@ static void submit_engine_destroy(ntscsim_ctx *c)
     if (!e) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    e->dlv.stop();
+    e->dlv.stop(true);
     for (auto &b : e->inflight) { if (b.up) (void)hipEventDestroy(b.up); if (b.done) (void)hipEventDestroy(b.done); }
     for (auto &p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (ntscsim_ctx *l : e->lanes) ntscsim_destroy(l);

@@ -380,3 +380,26 @@ def test_frames_that_are_not_page_aligned_need_a_declaration_or_pinned_memory(ho
     sim.close()
     for a in blocks:
         ntscsim.host_free_array(a)
+
+
+@pytest.mark.gpu
+def test_destroy_with_staged_fields_in_flight_drops_them():
+    """ntscsim_destroy() with submitted-but-never-waited fields whose frames are staged: the copy threads drop what they have
+    not delivered yet instead of writing into frames the caller may have freed; nothing hangs, a new ctx works."""
+    w, h = 192, 96
+    p = L.make_params(["-vhs"], output_height=h)
+    src = L.noise_frame(w, h, 5)
+    for _ in range(3):
+        sim = ntscsim.FieldSimulator(params=p)
+        sim.submit_configure(depth=4, slots=16, lanes=2, pin=0)
+        bufs = [np.zeros((h, w, 4), np.uint8) for _ in range(10)]
+        for k in range(10):
+            sim.submit(bufs[k], src, (k & 1) ^ 1, k)
+        sim.close()
+        del bufs
+    sim = ntscsim.FieldSimulator(params=p)
+    a, b = np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 4), np.uint8)
+    sim.field_host(a, src, 1, 0)
+    L.OracleStream(p).field(b, src, 1, 0)
+    assert np.array_equal(a, b)
+    sim.close()
