@@ -168,7 +168,7 @@ rd += "| `%s_submit_probe.txt` | `tools/submit_probe.sh` (`host/field_loop.cpp`,
 rd += "| `%s_dryrun_two_ranks.txt` | `tools/dryrun_two_ranks_one_gpu.sh` | `bench.py` with two ranks on the one GPU: RCCL refuses two ranks on one device, the same run with gloo verifies every rank's checksum |\n" % tag
 rd += "| `r04_nt_probe.txt` | `tools/nt_probe.sh`, `tools/nt422_probe.sh` | A/B builds on one box: streaming (nt) stores / loads on the path's planes -- fields/s, kernel times, raw FETCH_SIZE / WRITE_SIZE per launch (shipped: output pixels, composite plane, the luma path's re-read; not shipped: the encoder's source loads, the YUV422P burst writer) |\n"
 rd += "| `r04_raw28_sweep.txt`, `r04_raw28_noise.txt` | `tools/raw28_sweep_r04.sh`, `tools/raw28_noise_probe.py` (`tools/follow_guess_probe.c` for the CPU side) | the raw-composite decoder against the switches of its second sweep (exact scanlines behind the closed-form warm-up, chunks per wavefront, the fall-back when lanes are out of step, the run-based form that was dropped) and against the capture's noise level (links left to the repair rounds, warm-up lengths that close them) |\n"
-rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_%s.sh` | (round 5) one-off parity sweeps of this round's new code on the final build: 3,000 random switch sets through the YUV422P tool's short forms with a census of the forms that ran, 3,000 random loops through `ntscsim_field422()` / `ntscsim_submit422()` against the oracle on byte-identical buffers (every byte compared), 2,000 random loops through `ntscsim_submit()` / `ntscsim_wait()` (half of them with rings of 1-3 frames shared by the fields in flight: delivery in submit order), 5,000 random ghosting cases (taps, delays either side of the fold's 63-sample limit, switch sets, geometries; census of the forms that ran), 1,500 + 400 random switch sets of both tools |\n" % (tag, tag)
+rd += "| `%s_fuzz_sweep.txt` | `tools/fuzz_%s.sh` | one-off parity sweeps of this round's new code on the final build (round 6: 3,000 random loops through `ntscsim_field422()` / `ntscsim_submit422()` incl. tight rows chained on the device and staged delivery on the copy threads, 2,000 through `ntscsim_submit()`, 1,500 random switch sets / geometries in `NTSCSIM_MODE_FLOAT` with the census of decoder forms, 1,000 + 300 full-size switch sets of both tools, 200 raw captures): 0 failures; `r05_fuzz_sweep.txt`: round 5's |\n" % (tag, tag)
 rd += "| `%s_ghost_probe.txt` | `tools/ghost_probe.py` (and with `NTSCSIM_DEBUG_DECODE=8`) | (round 5) the ghosting extension: rates of `-vhs` with 0 / 2 / 4 taps folded into the encoder (`k_encode_fast_gh`) against the same taps as a pass of `k_ghost`, and a delay too long to fold, one run on one box |\n" % tag
 rd += "| `r04_fuzz_sweep.txt` | `tools/fuzz_r04.sh` | one-off parity sweeps on the final build (random switch sets of both tools, full size, the any-phase / full-output-low-pass / pre-emphasis / S-Video families at full size with the kernel forms listed; the raw-composite decoder on random captures / streams / speculation settings); the kernels those sweeps cover are unchanged since |\n"
 rd += "| `r03_decode_experiments.txt`, `r03_clock_under_load.txt`, `r03_composite_range.txt`, `r03_variant_sweeps.txt` | (round 3) | A/B experiments on the dominant kernel; shader clock under load (2.31-2.32 GHz); value range of the composite plane; wave-clock share of the YUV422P kernel's sweeps |\n"
