@@ -21,6 +21,7 @@
 #include "ntsc_kernels.hip"
 #include "ntsc_decode_fast.hip"
 #include "ntsc_encode_fast.hip"
+#include "ntsc_pipe.hip"
 #include "ntsc422_kernels.hip"
 #include "ntsc422_fused.hip"
 #include "ntsc_scale.hip"
@@ -177,6 +178,9 @@ struct ntscsim_ctx {
     Host422Engine *h422 = nullptr;   // ntscsim_field422() / ntscsim_submit422(): created on first use
     PinCache *declared = nullptr;    // ntscsim_host_pin(): memory the caller declared its own to pin
     int pin_policy = 1;              // ntscsim_set_pin_policy()
+    // the host-frame entry points (ntscsim_field(), the submit engine's lanes) ask for the LATENCY form of short launches
+    // (k_field_pipe, ntsc_pipe.hip); the device-pointer entry points keep the kernels their callers (and tests) name
+    bool latency_form = false;
 };
 static void declared_pins_destroy(ntscsim_ctx *c);
 static void submit_engine_destroy(ntscsim_ctx *c);
@@ -723,7 +727,21 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                     D.ghost_taps == 0 && !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small &&
                     !c->split_vhs &&
                     ((D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) || (!D.vhs && !D.cnoise_k && !D.pnoise_k));
-    if (fp) {
+    // the latency form: encoder, VCR half and TV half as three wavefronts of one workgroup (ntsc_pipe.hip) -- short launches
+    // from the host-frame entry points, the -vhs preset family of the hand-tuned kernels.  NTSCSIM_PIPE=0: A/B switch.
+    static const bool pipe_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
+    const bool pipe_form = c->latency_form && pipe_env && n <= NTSC_PIPE_MAX_FIELDS && c->mode != NTSCSIM_MODE_FLOAT &&
+                           enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
+                           !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->split_vhs &&
+                           D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k;
+    if (pipe_form) {
+        HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
+        note_kernel(c, fast ? "k_field_pipe<float>" : "k_field_pipe<double>");
+        if (fast) hipLaunchKernelGGL((k_field_pipe<float>), dgrid, dim3(192), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
+                                     c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p);
+        else hipLaunchKernelGGL((k_field_pipe<double>), dgrid, dim3(192), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
+                                c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p);
+    } else if (fp) {
         note_kernel(c, "k_encode_fp");
         launch_encode_fp(st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
     } else if (ghost_fused) {
@@ -803,7 +821,9 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_decode_fast<true, RT, true>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
-    if (fp) {
+    if (pipe_form) {
+        // (encoder and decoder ran as one launch above)
+    } else if (fp) {
         static const int fpv_env = std::getenv("NTSCSIM_FP_VARIANT") ? std::atoi(std::getenv("NTSCSIM_FP_VARIANT")) : -1;    // developer A/B switch
         const int fpv = fpv_env >= 0 ? fpv_env : (n <= 128 ? 0 : 10);      // (launch_decode_fp's own rule, for the kernel's name)
         note_kernel(c, D.vhs ? (fpv < 10 ? "k_decode_fp2" : "k_decode_fp<true>") : "k_decode_fp<false>");
@@ -1590,7 +1610,9 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     d.flags = (src_interlaced ? NTSCSIM_DESC_INTERLACED : 0u) | (src_tff ? NTSCSIM_DESC_TFF : 0u);
     d.fieldno = fieldno;
     d.rng_pos = NTSCSIM_RNG_AUTO;
+    c->latency_form = true;
     int rc = ntscsim_fields_device(c, &d, 1, W, H, c->stream);
+    c->latency_form = false;
     if (rc != NTSCSIM_OK) { c->src_pending = false; (void)hipStreamSynchronize(su); return rc; }
     // only the rows of this field are written back (:1910-1916)
     const int L = (H - (int)field + 1) / 2;

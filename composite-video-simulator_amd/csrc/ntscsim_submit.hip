@@ -727,7 +727,9 @@ static int sub_launch(ntscsim_ctx *c)
         (void)hipEventRecord(b.t0, lane->stream);
     }
     if (er != hipSuccess) { c->err = std::string("submit launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    lane->latency_form = true;         // (short launches take the three-role workgroup form: ntsc_pipe.hip)
     int rc = ntscsim_fields_device(lane, descs.data(), n, e->W, e->H, lane->stream);
+    lane->latency_form = false;
     if (rc != NTSCSIM_OK) { c->err = lane->err; return finish(rc); }
     c->kernels = lane->kernels;
     // delivery

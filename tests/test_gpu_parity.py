@@ -271,6 +271,38 @@ def test_host_frame_dropin_sequence():
     sim.close()
 
 
+@pytest.mark.parametrize("flags,w,h,piped", [
+    (["-vhs"], 720, 486, True), (["-vhs"], 720, 480, True), (["-vhs", "-vhs-speed", "lp"], 360, 243, True),
+    (["-vhs", "-vhs-speed", "ep"], 1920, 1080, True), (["-vhs"], 3840, 2160, True),
+    (["-vhs"], 16, 4, True), (["-vhs"], 20, 9, True), (["-vhs"], 36, 130, True), (["-vhs"], 100, 7, True),
+    (["-vhs", "-vhs-head-switching-point", "0.8"], 360, 244, True), (["-vhs", "-chroma-dropout", "30000"], 256, 100, True),
+    (["-vhs", "-vhs-chroma-vblend", "0"], 256, 100, True), (["-vhs", "-noise", "40", "-chroma-noise", "70"], 256, 100, True),
+    (["-vhs", "-tvstd", "pal"], 720, 576, False),           # PAL: head-switch displacement beyond W/10 -> the one-launch forms
+    (["-vhs", "-vhs-svideo", "1"], 256, 100, False), (["-vhs", "-comp-phase", "90"], 256, 100, False), ([], 256, 100, False),
+    (["-vhs"], 33, 17, True),                               # (tight host rows: the device frames have aligned rows of their own)
+])
+def test_synchronous_call_takes_the_three_role_form_and_equals_the_oracle(flags, w, h, piped):
+    """ntscsim_field(): launches of up to 64 fields from the host-frame entry points run encoder, VCR half and TV half
+    as three wavefronts of one workgroup (k_field_pipe, csrc/ntsc_pipe.hip) for the -vhs preset family -- same step
+    functions as the other forms, samples handed over through the planes behind two LDS counters -- bit for bit the
+    oracle's, call after call (the rand() stream carried like the reference's); other switch sets keep their forms."""
+    p = L.make_params(flags, output_height=h)
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    got = np.full((h, w, 4), 0x5A, np.uint8)
+    exp = np.full((h, w, 4), 0x5A, np.uint8)
+    for k in range(4):
+        s = L.noise_frame(w, h, 90 + k // 2)
+        field = (k & 1) ^ 1
+        sim.field_host(got, s, field, k)
+        o.field(exp, s, field, k)
+        assert np.array_equal(got, exp), "call %d" % k
+        assert sim.rng_pos == o.rng_pos
+        kern = sim.last_kernels()
+        assert (("k_field_pipe<double>" in kern) == piped), kern
+    sim.close()
+
+
 @pytest.mark.parametrize("h", [2, 3, 32, 33])
 @pytest.mark.parametrize("il,tff", [(0, 0), (1, 0), (1, 1)])
 def test_host_frame_dropin_uploads_the_rows_it_reads(h, il, tff):

@@ -126,7 +126,7 @@ def test_submit_at_the_baseline_size_default_options():
     got = run_submit_loop(sim, frames, n, w, h, ring, True, lag)
     st = sim.submit_stats()
     assert st["delivered_direct"] == n and st["uploads_staged"] == 0, st
-    assert "k_decode_fast<true,double>" in sim.last_kernels()
+    assert "k_field_pipe<double>" in sim.last_kernels()      # launches of <= 64 fields: the three-role workgroup form
     pos_async = sim.rng_pos
     sim.close()
     # the synchronous loop on the product

@@ -9,6 +9,8 @@ Measures the call (720x486 -vhs, pageable host frames, one field per call) in th
                them (wrong pixels, right instructions): each role is a lone wavefront per 63 rows and runs at the issue
                rate of a lone wavefront, so the call takes max(role) instead of sum(roles) -- the CEILING of any
                three-role pipeline, before it pays a cycle for its hand-offs.
+  pipe         the three roles as three wavefronts of ONE workgroup with the hand-offs in place (k_field_pipe,
+               csrc/ntsc_pipe.hip; the other arrangements run with NTSCSIM_PIPE=0) -- right pixels
 and the float pipeline (NTSCSIM_MODE_FLOAT) in the shipped arrangement.  Prints one line each and a JSON summary."""
 import json
 import os
@@ -31,7 +33,7 @@ p = L.make_params(["-vhs"])
 sim = ntscsim.FieldSimulator(params=p)
 if mode == "float":
     sim.set_mode(_capi.MODE_FLOAT)
-if arr != "one_launch":
+if arr not in ("one_launch", "pipe"):
     sim.debug_no_fast_decode(2)
 src = L.bars(w, h, 0)
 dst = np.zeros((h, w, 4), np.uint8)
@@ -52,6 +54,8 @@ def run(arr, mode="exact"):
     env = dict(os.environ)
     if arr == "side_by_side":
         env["NTSCSIM_ROLE_PROBE"] = "1"
+    if arr != "pipe":
+        env["NTSCSIM_PIPE"] = "0"
     r = subprocess.run([sys.executable, "-c", WORKER, arr, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     if r.returncode != 0:
         return {"arrangement": arr, "mode": mode, "error": r.stderr.decode()[-400:]}
@@ -59,7 +63,7 @@ def run(arr, mode="exact"):
 
 
 def main():
-    out = [run("one_launch"), run("two_launch"), run("side_by_side"), run("one_launch", "float")]
+    out = [run("one_launch"), run("two_launch"), run("side_by_side"), run("pipe"), run("one_launch", "float")]
     for o in out:
         if "error" in o:
             print(o)
