@@ -1,36 +1,48 @@
-// ntsc_pipe.hip -- the LATENCY form of the -vhs chain for short batches: one workgroup of three
+// ntsc_pipe.hip -- the LATENCY form of the -vhs chain for short batches: one workgroup of FIVE
 // wavefronts per 63 scanlines (+ the halo row above), each wavefront one ROLE of the same rows, running side by side:
 //
-//     wave 0  encoder    BGRA -> composite samples            (the loop of encode_fast_body, ntsc_encode_fast.hip)
-//     wave 1  VCR half   composite -> the VCR's composite out  (the loop of k_vcr_front, ntsc_decode_fast.hip)
-//     wave 2  TV half    the VCR's output -> BGRA              (the loop of decode_fast_body<false>)
+//     ENC   encoder              BGRA -> composite samples               (the loop of encode_fast_body, ntsc_encode_fast.hip)
+//     SEP   VCR, chroma front    composite -> raw chroma + chroma noise  (first separator, :1497-1567, :1719-1735)
+//     CHR   VCR, chroma back     phase noise, VHS chroma low-pass, vertical blend, carrier sign (:1736-1762, :1814-1863)
+//     LUM   VCR luma + TV front  VHS luma low-pass / emphasis / sharpen, re-modulation, second separator
+//                                (:1793-1812, :1866-1888, :1497-1567, dropout :1891-1901)
+//     OUT   TV back              TV chroma low-pass, YIQ -> RGB, pixel stores  (:1399-1427, :1385-1396)
 //
 // A field is four lone wavefronts whichever way it is cut, and a lone wavefront issues one VALU instruction per ~5
-// cycles: the one-launch chain walks a row's 235 instructions per pixel one after the other (0.43 ms of kernels per
-// field), three roles walk 58 / 110 / 65 of them concurrently.  tools/role_probe.py measured the ceiling of this form
-// BEFORE it was built (the three roles as independent launches: 386 us per call against 573 us); this kernel is that
-// arrangement with the hand-offs in place.  It is only worth it while every wavefront has a SIMD to itself, so only the
-// synchronous call and launches of at most NTSC_PIPE_MAX_FIELDS fields take it; long batches fill the chip with the
-// one-wave-per-63-rows kernels, which issue less.
+// cycles: the one-launch chain walks a row's ~235 instructions per pixel one after the other (encoder 97 us, VCR half
+// 209 us, TV half 107 us as lone kernels on one field: profiles/r06_sync_roles.txt); here five wavefronts walk
+// ~58 / 45 / 40 / 55 / 50 of them concurrently on the four SIMDs of one CU (SEP and CHR, the two lightest, share one).
+// It is only worth it while every workgroup has a CU to itself, so only the synchronous call and launches of at most
+// NTSC_PIPE_MAX_FIELDS fields from the host-frame entry points take it; long batches fill the chip with the
+// one-wave-per-63-rows kernels, which issue less in total.
 //
-// The ARITHMETIC is not restated here: every sample goes through the same step functions as in the two-launch form
-// (fastenc::step / edge_step, fastdec::vcr_step / vcr_edge, fastdec::step<false> / edge_step<false>), so the bits are
-// the same by construction; this file is the three loops around them plus the flow control.
+// The ARITHMETIC of a position is the one of the one-launch kernels, cut at three places where only integers cross:
+// every role runs the same stream positions t = 0 .. W + 15 + d as k_decode_fast<true> (fill: guarded steps, steady:
+// 4 positions per iteration, drain: guarded steps) with ITS part of fastdec::vcr_step / step / vcr_edge / edge_step,
+// written out below next to the statement of the original it is (same operations on the same operands: same bits;
+// tests/test_gpu_parity.py::test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle).
 //
-// Hand-offs.  The samples travel through the same transposed planes in global memory as in the two-launch form
-// (comp[x][row]: encoder -> VCR half, comp_vcr[x][row]: VCR half -> TV half) -- the head switch needs random access in x
-// and the luma path re-reads a sample 5 + d positions later -- and every role writes the columns its own lanes' rows read
-// (a lane of the next workgroup's halo re-computes the same values: identical stores).  Flow control is two monotonic
-// counters in LDS: `sync[0]` = composite columns the encoder has made visible, `sync[1]` = columns of the VCR's output.
-// A producer publishes a column only when its stores have been acknowledged by the L2 (s_waitcnt vmcnt(N) with N = the
-// memory operations it has issued since: one group behind, so it never stalls on its newest stores) behind a
-// workgroup-scope release; a consumer waits (s_sleep poll, acquire) until the highest column it is about to request has
-// been published, and requests composite samples with streaming (nt) loads, which bypass the CU's L1: what it reads is
-// what the L2 holds.
+// Hand-offs.
+//   ENC -> SEP, LUM: the composite samples travel through the transposed plane in global memory (comp[x][row]) -- the
+//       head switch needs random access in x.  ENC publishes a column count (flag F_ENC) once its stores have been
+//       acknowledged by the L2 (s_waitcnt vmcnt(N), N = the memory operations issued since: one chunk behind, so it never
+//       stalls on its newest stores); the readers request samples with streaming (nt) loads, which always miss the
+//       CU's L1: what they read is what the L2 holds (two workgroups of one launch may share a CU, and a 128-byte line
+//       of a column holds rows of two workgroups).
+//   SEP -> CHR -> LUM -> OUT: rings of RING stream positions in LDS (2 / 1 / 3 integers per lane and position), each
+//       with a `produced` and a `consumed` position count.  A producer writes a position only when the slot's previous
+//       tenant has been consumed and publishes it behind a workgroup-scope release (s_waitcnt lgkmcnt(0)), in the
+//       steady loop one step late, when the stores have long landed; a consumer polls (s_sleep) only when the count it
+//       remembers is not enough.
 #pragma clang fp contract(off)
 
 #ifndef NTSC_PIPE_MAX_FIELDS
 #define NTSC_PIPE_MAX_FIELDS 64
+#endif
+// wavefront w of the workgroup takes role (NTSC_PIPE_ORDER >> 4w) & 15: 0 ENC, 1 SEP, 2 CHR, 3 LUM, 4 OUT.  Wavefronts 0 and 4
+// land on the same SIMD (round-robin placement): the two lightest roles.
+#ifndef NTSC_PIPE_ORDER
+#define NTSC_PIPE_ORDER 0x24301u
 #endif
 
 namespace ntscsim {
@@ -38,16 +50,27 @@ namespace pipe {
 
 using namespace fastdec;
 
-DEV int lds_peek(const volatile uint32_t *p) { return __builtin_amdgcn_readfirstlane((int)*p); }
-DEV void wait_ge(const volatile uint32_t *p, int v, int &cached)
+constexpr int RING = 16;          // stream positions per LDS ring (four steady iterations)
+enum { F_ENC = 0, F_AB_P, F_AB_C, F_BC_P, F_BC_C, F_CD_P, F_CD_C, F_COUNT = 8 };
+
+typedef __attribute__((address_space(3))) volatile uint32_t *lds_flag;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) uint32_t *lds_x1;
+typedef __attribute__((address_space(3))) u32x2 *lds_x2;
+typedef __attribute__((address_space(3))) u32x4 *lds_x4;
+
+DEV int flag_peek(lds_flag p) { return __builtin_amdgcn_readfirstlane((int)*p); }
+// wait until the count at p is at least v (wave-uniform); `cached`: the last value this wavefront saw
+DEV void wait_ge(lds_flag p, int v, int &cached)
 {
     if (cached >= v) return;
-    int seen = lds_peek(p);
-    while (seen < v) { __builtin_amdgcn_s_sleep(2); seen = lds_peek(p); }
+    int seen = flag_peek(p);
+    while (seen < v) { __builtin_amdgcn_s_sleep(1); seen = flag_peek(p); }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     cached = seen;
 }
-DEV void publish(volatile uint32_t *p, int v)
+DEV void publish(lds_flag p, int v)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     *p = (uint32_t)v;
@@ -55,7 +78,7 @@ DEV void publish(volatile uint32_t *p, int v)
 // s_waitcnt vmcnt(N), everything else untouched (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0], expcnt imm[6:4], lgkmcnt imm[11:8])
 #define NTSC_PIPE_VMCNT(N) __builtin_amdgcn_s_waitcnt((((N) >> 4) << 14) | 0x0F70 | ((N) & 15))
 
-// what the three roles share about their lane's row
+// what the roles share about their lane's row
 struct Row {
     int lane, rc, k;
     unsigned field, y;
@@ -63,10 +86,14 @@ struct Row {
     const FieldDev *fd;
 };
 
-// ------------------------------------------------------------------------------------------------ wave 0: encoder
+// slot of stream position t in a ring: the steady loop's first position (t = SKT) sits on slot 0, so the four
+// positions of an iteration are four consecutive slots
+DEV int slot_of(int t, int SKT) { return (t - SKT) & (RING - 1); }
+
+// ------------------------------------------------------------------------------------------------ ENC: encoder
 template <class RT>
 DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
-                      int *__restrict__ comp, uint32_t *ring, uint32_t *ltile, volatile uint32_t *sync)
+                      int *__restrict__ comp, uint32_t *ring, uint32_t *ltile, lds_flag fl)
 {
     using namespace fastenc;
     const int lane = R.lane, W = P.W;
@@ -139,6 +166,11 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
             NTSC_PIPE_ENC_STEP(5, Yn[1], F[3])
             NTSC_PIPE_ENC_STEP(6, Yn[2], F[4])
             NTSC_PIPE_ENC_STEP(7, Yn[3], F[5])
+            // the chunk before this one is in the L2 once at most this chunk's memory operations are still in flight (its
+            // 8 stores so far, and the 4 row requests when there is a next chunk; vmcnt counts in issue order): published
+            // in the middle of the chunk, half a chunk earlier than at its end
+            if (more) NTSC_PIPE_VMCNT(12); else NTSC_PIPE_VMCNT(8);
+            publish(fl + F_ENC, t - 4);            // columns < t - 4: everything the previous chunks stored
             NTSC_PIPE_ENC_STEP(8, Yn[4], F[6])
             NTSC_PIPE_ENC_STEP(9, Yn[5], F[7])
             NTSC_PIPE_ENC_STEP(10, Yn[6], F[8])
@@ -150,10 +182,6 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
 #undef NTSC_PIPE_ENC_STEP
             Y0 = Yn[12]; Y1 = Yn[13]; Y2 = Yn[14]; Y3 = Yn[15];
             I0 = F[14]; I1 = F[15];
-            // the chunk before this one is in the L2 once at most THIS chunk's memory operations are still in flight: its 16
-            // stores, and the 4 row requests when there is a next chunk (vmcnt counts in issue order)
-            if (more) NTSC_PIPE_VMCNT(20); else NTSC_PIPE_VMCNT(16);
-            publish(sync, t - 4);                  // columns < t - 4: everything the previous chunks stored
             if (more) L.deliver(nq, cur);
         }
         S.rng.pos = sbase;
@@ -161,35 +189,29 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
         S.fI[0] = I0; S.fI[1] = I1;
 #pragma unroll
         for (int q = 0; q < 4; q++) { S.Ir[q] = (int)IdT[q]; S.Qr[q] = (int)QdT[q]; }
+        NTSC_PIPE_VMCNT(0);
+        publish(fl + F_ENC, t - 4);
     }
     for (; t < W + 4; t++) edge_step<RT, false, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
     NTSC_PIPE_VMCNT(0);
-    publish(sync, W);
+    publish(fl + F_ENC, W);
 }
 
-// ------------------------------------------------------------------------------------------------ wave 1: VCR half
-// columns of the composite plane a step at stream position t may request: its own loads reach t + 7 (two iterations of
-// look-ahead minus one) and a head-switched lane reads up to W/10 + 1 columns further (k_field_setup; the launcher takes
-// this form only for displacements within W/10)
+// ------------------------------------------------------------------------------------------------ the decoder roles
+// per-lane constants of the four decoder roles (every role fills what it reads; the rest is dead code)
 template <class RT>
-DEV void vcr_role(const DevParams &P, const GeomDev &G, const Row &R, const int *__restrict__ comp, int *__restrict__ comp_out,
-                  const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u, const int *__restrict__ n0_v,
-                  const int *__restrict__ hs_shift, const int *__restrict__ pn_noise, int *__restrict__ tails, uint32_t *ring,
-                  volatile uint32_t *sync)
+DEV void dec_const(Const<RT, false> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift)
 {
-    const int lane = R.lane, W = P.W;
-    const FieldDev &fd = *R.fd;
-    typedef Const<RT, false> CT;
-    CT C;
+    const int W = P.W;
     C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
     C.bmul = 0; C.bshift = 0; C.odd = false; C.mo = 0;
-    C.xi = scan_phase(P, R.y, fd.fieldno);
+    C.xi = scan_phase(P, R.y, R.fd->fieldno);
     C.hi = (C.xi & 2u) != 0;
     C.W = W;
     C.xe = (W & 1) ? W - 1 : W - 2;
-    C.lane = lane;
+    C.lane = R.lane;
     C.d = P.cdelay;
-    C.SKT = 7 + C.d;
+    C.SKT = 15 + C.d;                  // the depth of the whole decoder: every role runs k_decode_fast<true>'s positions
     C.LOFF = 5 + C.d;
     C.mL = opaque_v(C.hi ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
@@ -197,203 +219,332 @@ DEV void vcr_role(const DevParams &P, const GeomDev &G, const Row &R, const int 
     C.bA = opaque_v((vb && R.k >= 2) ? -1 : 0);
     C.bC = opaque_v((vb && R.k >= 1) ? 1 : 0);
     C.dm = -1;
+    C.cosv = 1; C.sinv = 0;
+    C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
+    C.a_oi = (RT)P.a_in_i; C.a_oq = (RT)P.a_in_q;
+    C.sharp2 = (RT)(P.sharpen * 2);
+    C.tailU = nullptr; C.rstride = 0; C.xs = nullptr;
+    C.rowbytes = P.Rpad * 4;
+    const int hs = (P.hs && hs_shift) ? hs_shift[R.rc] : 0;
+    C.vbase = (int)((unsigned)R.rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
+    C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
+}
+// the steady loop exists iff one iteration fits (every role decides alike: the positions are the same for all)
+DEV bool has_steady(int W, int d) { return 15 + d + 4 <= W - (d > 7 ? d - 7 : 0); }
+
+// ------------------------------------------------------------------------------------------------ SEP: VCR, chroma front
+// vcr_step / vcr_edge up to the chroma noise: first separator at x1 = t - 7 (no luma out), U / V += noise, two draws
+template <class RT>
+DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
+                  const int *__restrict__ n0_u, const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
+                  uint32_t *ring, lds_x2 ab, lds_flag fl)
+{
+    typedef Const<RT, false> CT;
+    CT C;
+    dec_const<RT>(C, P, R, comp, hs_shift);
+    const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
+    DemodR D1;
+    D1.init();
+    LaneRand32 rng;
+    rng.init(ring, rs_chroma + R.rc, P.Rpad, lane, (-(31 + 2 * (SKT - 7))) & 7);      // (as decode_fast_body)
+    int nU = n0_u[R.rc], nV = n0_v[R.rc];
+    // columns of the composite plane a step at stream position t may request: its own column t and, on a head-switched
+    // lane, up to W/10 + 1 columns further (k_field_setup; the launcher takes this form only for displacements within W/10)
+    const int reach = W / 10 + 2;
+    int enc_seen = 0, cons_seen = 0;
+    auto need_enc = [&](int c) { wait_ge(fl + F_ENC, c < W ? c : W, enc_seen); };
+    auto edge = [&](int t) {
+        need_enc(t + reach);
+        wait_ge(fl + F_AB_C, t + 1 - RING, cons_seen);
+        const int pc = t < W ? cs_load<2>(C, t) : 0;
+        int Y, U, V;
+        D1.template push_edge<false, false>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+        const int x1 = t - 7;
+        if (x1 >= 0 && x1 < W) {
+            U += nU; V += nV;                                                       // chroma noise :1719-1735
+            nU = sdiv2(nU + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+            nV = sdiv2(nV + (int)umod31(rng.next(ring, lane), P.m_cnoise) - P.cnoise_k);
+        }
+        ab[slot_of(t, SKT) * 64 + lane] = u32x2{(uint32_t)U, (uint32_t)V};
+        publish(fl + F_AB_P, t + 1);
+    };
+    int t = 0;
+    for (; t < SKT && t < total; t++) edge(t);
+    const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
+    if (has_steady(W, C.d) && !(rng.pos & 7)) {
+        DemodS S1;
+        S1.from(D1, (C.d & 1) != 0);              // x1 = t - 7 = d (mod 4) at the loop's first position
+        int sbase = rng.pos;
+        int pc[4];
+        need_enc(t + 4 + reach);
+#pragma unroll
+        for (int j = 0; j < 4; j++) pc[j] = cs_load<2>(C, t + j);
+#define NTSC_PIPE_SEP_STEP(DPH, J)                                                                \
+        {                                                                                         \
+            constexpr bool pick1 = (((DPH) + (J)) & 1) != 0, neg1 = (((DPH) + (J)) & 3) == 3;     \
+            int Yd, U, V;                                                                         \
+            S1.template push<pick1, neg1, false, false, false, false>(pc[J], C.hi, -1, Yd, U, V); \
+            pc[J] = cs_load<2>(C, t + 4 + (J));       /* (past the row end: the buffer's bounds check, 0) */ \
+            U += nU; V += nV;                                                                     \
+            nU = sdiv2(nU + (int)umod31(rng.template draw<2 * (J)>(rb, rb0), P.m_cnoise) - P.cnoise_k);     \
+            nV = sdiv2(nV + (int)umod31(rng.template draw<2 * (J) + 1>(rb, rb0), P.m_cnoise) - P.cnoise_k); \
+            o[(J) * 64] = u32x2{(uint32_t)U, (uint32_t)V};                                        \
+            NTSC_STEP_SCHED_BARRIER();                                                            \
+        }
+#define NTSC_PIPE_SEP_ITER(DPH)                                                                   \
+        for (; t + 4 <= t_end; t += 4) {                                                          \
+            need_enc(t + 8 + reach);                                                              \
+            wait_ge(fl + F_AB_C, t + 4 - RING, cons_seen);                                        \
+            uint32_t *const rb = ring + sbase * 64 + lane;                                        \
+            const bool rb0 = sbase == 0;                                                          \
+            sbase = (sbase + 8) & 31;                                                             \
+            const lds_x2 o = ab + slot_of(t, SKT) * 64 + lane;                                    \
+            NTSC_PIPE_SEP_STEP(DPH, 0)                                                            \
+            publish(fl + F_AB_P, t);              /* the iteration before this one */             \
+            NTSC_PIPE_SEP_STEP(DPH, 1) NTSC_PIPE_SEP_STEP(DPH, 2) NTSC_PIPE_SEP_STEP(DPH, 3)      \
+        }
+        switch (C.d & 3) {
+            case 0: NTSC_PIPE_SEP_ITER(0) break;
+            case 1: NTSC_PIPE_SEP_ITER(1) break;
+            case 2: NTSC_PIPE_SEP_ITER(2) break;
+            default: NTSC_PIPE_SEP_ITER(3) break;
+        }
+#undef NTSC_PIPE_SEP_ITER
+#undef NTSC_PIPE_SEP_STEP
+        publish(fl + F_AB_P, t);
+        S1.to(D1, (C.d & 1) != 0);
+        rng.pos = sbase;
+    }
+    for (; t < total; t++) edge(t);
+}
+
+// ------------------------------------------------------------------------------------------------ CHR: VCR, chroma back
+// vcr_step / vcr_edge from the phase noise to the sign of the re-modulated chroma: what comes out is the term the
+// composite sample at x2 = t - 7 - d adds to its luma
+template <class RT>
+DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const int *__restrict__ pn_noise,
+                     int *__restrict__ tails, lds_x2 ab, lds_x1 bc, lds_flag fl)
+{
+    typedef Const<RT, false> CT;
+    CT C;
+    dec_const<RT>(C, P, R, nullptr, nullptr);
+    const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     {
         int n = (R.rowok ? pn_noise[R.rc] : 0) + P.pnoise_k;
         n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
         C.cosv = (RT)G.ptab[2 * n]; C.sinv = (RT)G.ptab[2 * n + 1];
     }
-    C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
-    C.sharp2 = (RT)(P.sharpen * 2);
-    C.tailU = tails + (size_t)blockIdx.x * 64 + lane;
-    C.rstride = (size_t)gridDim.x * 64;
-    C.rowbytes = P.Rpad * 4;
-    const int hs = P.hs ? hs_shift[R.rc] : 0;
-    C.vbase = (int)((unsigned)R.rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
-    C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(comp_out, 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
-    // The column this lane's TV role reads -- for the lanes that own a row.  The halo lane and the lanes past the last row
-    // compute a NEIGHBOUR's row with another row above it (the vertical blend), i.e. other values: like k_vcr_front they
-    // write to padding columns (R <= column < Rpad), and their TV lanes, whose pixels nobody stores, read whatever the
-    // row's owner wrote.
-    const int gidx = (int)blockIdx.x * 63 + lane - 1;
-    const int vout = (lane >= 1 && gidx < P.R ? gidx : P.R + lane) * 4;
-
-    State<true, RT> S;
-    S.D1.init(); S.D2.init();
-    S.l0 = S.l1 = S.l2 = S.lsum = 0;
-    S.vl.reset(16, C.a_vl); S.vpre.reset(16, C.a_vl); S.vcU.reset(0, C.a_vc); S.vcV.reset(0, C.a_vc);
-    S.sh.reset(0, C.a_sh); S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv);
-    S.Yprev = S.Uraw = S.Vraw = 0;
-    S.Uf2[0] = S.Uf2[1] = 0;
-    S.rng.init(ring, rs_chroma + R.rc, P.Rpad, lane, (-(31 + 2 * (C.SKT - 7))) & 7);
-    S.nU = n0_u[R.rc]; S.nV = n0_v[R.rc];
-
-    const int SK1 = C.SKT, LOFF = C.LOFF;
-    const int total = W + SK1;
-    const unsigned rb = (unsigned)C.rowbytes;
-    const int reach = W / 10 + 2;          // head-switch displacement of the farthest lane, + 1
-    int enc_seen = 0;
-    int t = 0;
-    int yv_, uv_, vv_;
-    // a guarded step at t loads column t (+ displacement) and column t - LOFF
-    auto need_edge = [&](int tt) { const int c = tt + reach; wait_ge(sync, c < W ? c : W, enc_seen); };
-    for (; t < SK1 && t < total; t++) { need_edge(t); (void)vcr_edge<RT, CT>(P, S, C, ring, t, yv_, uv_, vv_); }
-    {
-        const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
-        if (t + 4 <= t_end && !(S.rng.pos & 7)) {
-            Steady T;
-            T.D1.from(S.D1, (C.d & 1) != 0);
-            T.D2.from(S.D2, true);
-            T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
-            int sbase = S.rng.pos;
-            int pc[4], pl[4];
-            { const int c = t + 4 + reach; wait_ge(sync, c < W ? c : W, enc_seen); }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { pc[j] = cs_load<2>(C, t + j); pl[j] = cs_load<2>(C, t + j - LOFF); }
-            unsigned soff = (unsigned)(t - SK1) * rb;
-#define NTSC_PIPE_VCR_STEP(DPV, J)                                                                \
-            {                                                                                     \
-                const int c2 = vcr_step<DPV, J, RT, CT>(P, S, T, C, pc[J], pl[J], yv_, uv_, vv_); \
-                pc[J] = cs_load<2>(C, t + 4 + J);                                                 \
-                pl[J] = cs_load<2>(C, t + 4 + J - LOFF);                                          \
-                __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)soff, 0);               \
-                soff += rb;                                                                       \
-                NTSC_STEP_SCHED_BARRIER();                                                        \
+    int *const tailU = tails + (size_t)blockIdx.x * 64 + lane;
+    const size_t rstride = (size_t)gridDim.x * 64;
+    Casc3<RT> vcU, vcV;
+    vcU.reset(0, C.a_vc); vcV.reset(0, C.a_vc);
+    int in_seen = 0, cons_seen = 0;
+    auto edge = [&](int t) {
+        wait_ge(fl + F_AB_P, t + 1, in_seen);
+        wait_ge(fl + F_BC_C, t + 1 - RING, cons_seen);
+        const u32x2 uv = ab[slot_of(t, SKT) * 64 + lane];
+        const int x1 = t - 7;
+        int fU = 0, fV = 0;
+        if (x1 >= 0 && x1 < W) {
+            const RT u = (RT)(int)uv.x, v = (RT)(int)uv.y;
+            const int U = (int)((u * C.cosv) - (v * C.sinv));                       // chroma phase noise :1748-1762
+            const int V = (int)((u * C.sinv) + (v * C.cosv));
+            fU = (int)vcU.push((RT)U, C.a_vc);                                      // VHS chroma low-pass :1814-1836
+            fV = (int)vcV.push((RT)V, C.a_vc);
+            if (x1 >= W - C.d) {                  // raw tail of the chroma low-pass :1830
+                tailU[(size_t)(x1 & 15) * rstride] = U;
+                tailU[(size_t)(16 + (x1 & 15)) * rstride] = V;
             }
-#define NTSC_PIPE_VCR_ITER(DPV)                                                                   \
-            for (; t + 4 <= t_end; t += 4) {                                                      \
-                { const int c = t + 8 + reach; wait_ge(sync, c < W ? c : W, enc_seen); }          \
-                T.rb = ring + sbase * 64 + lane; T.rb0 = sbase == 0; sbase = (sbase + 8) & 31;    \
-                NTSC_PIPE_VCR_STEP(DPV, 0) NTSC_PIPE_VCR_STEP(DPV, 1) NTSC_PIPE_VCR_STEP(DPV, 2) NTSC_PIPE_VCR_STEP(DPV, 3) \
-                /* the iteration before this one is in the L2 once at most this one's 8 loads + 4 stores are in flight */ \
-                NTSC_PIPE_VMCNT(12);                                                              \
-                publish(sync + 1, t - SK1);                                                       \
-            }
-            switch (C.d & 3) {
-                case 0: NTSC_PIPE_VCR_ITER(0) break;
-                case 1: NTSC_PIPE_VCR_ITER(1) break;
-                case 2: NTSC_PIPE_VCR_ITER(2) break;
-                default: NTSC_PIPE_VCR_ITER(3) break;
-            }
-#undef NTSC_PIPE_VCR_ITER
-#undef NTSC_PIPE_VCR_STEP
-            T.D1.to(S.D1, (C.d & 1) != 0);
-            S.l2 = T.lc1; S.l1 = T.lpA - T.lc1; S.l0 = T.lpB - S.l1; S.lsum = S.l0 + S.l1 + S.l2;
-            S.rng.pos = sbase;
         }
+        const int x2 = x1 - C.d;
+        const bool in2 = x2 >= 0 && x2 < W;
+        if (in2 && x2 >= W - C.d) {
+            fU = tailU[(size_t)(x2 & 15) * rstride];
+            fV = tailU[(size_t)(16 + (x2 & 15)) * rstride];
+        }
+        const int U = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;                   // vertical blend :1843-1863
+        const int V = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;
+        int ch = 0;
+        if (in2) {
+            const unsigned s = (C.xi + (unsigned)x2) & 3u;
+            ch = (s & 1u) ? V : U;
+            if (s & 2u) ch = -ch;
+        }
+        bc[slot_of(t, SKT) * 64 + lane] = (uint32_t)ch;
+        publish(fl + F_BC_P, t + 1);
+        *(fl + F_AB_C) = (uint32_t)(t + 1);
+    };
+    int t = 0;
+    for (; t < SKT && t < total; t++) edge(t);
+    const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
+    if (has_steady(W, C.d)) {
+#define NTSC_PIPE_CHR_STEP(J)                                                                     \
+        {                                                                                         \
+            const RT u = (RT)(int)in[J].x, v = (RT)(int)in[J].y;                                  \
+            const RT Ud = rtrunc<RT>((u * C.cosv) - (v * C.sinv));                                \
+            const RT Vd = rtrunc<RT>((u * C.sinv) + (v * C.cosv));                                \
+            const int fU = (int)vcU.push(Ud, C.a_vc);                                             \
+            const int fV = (int)vcV.push(Vd, C.a_vc);                                             \
+            /* x2 = J (mod 4): U for even J, sign by J & 2 (vcr_step); only the component that is modulated is blended */ \
+            const int f = ((J) & 1) ? fV : fU;                                                    \
+            const int chroma = ((wave_up(f) & C.bA) + f + C.bC) >> C.bC;                          \
+            const int mm = ((J) & 2) ? C.mNL : C.mL;                                              \
+            o[(J) * 64] = (uint32_t)((chroma ^ mm) - mm);                                         \
+            NTSC_STEP_SCHED_BARRIER();                                                            \
+        }
+        for (; t + 4 <= t_end; t += 4) {
+            wait_ge(fl + F_AB_P, t + 4, in_seen);
+            wait_ge(fl + F_BC_C, t + 4 - RING, cons_seen);
+            const lds_x2 ip = ab + slot_of(t, SKT) * 64 + lane;
+            const lds_x1 o = bc + slot_of(t, SKT) * 64 + lane;
+            u32x2 in[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
+            NTSC_PIPE_CHR_STEP(0)
+            publish(fl + F_BC_P, t);              // the iteration before this one: written, and its inputs read
+            *(fl + F_AB_C) = (uint32_t)t;
+            NTSC_PIPE_CHR_STEP(1) NTSC_PIPE_CHR_STEP(2) NTSC_PIPE_CHR_STEP(3)
+        }
+#undef NTSC_PIPE_CHR_STEP
+        publish(fl + F_BC_P, t);
+        *(fl + F_AB_C) = (uint32_t)t;
     }
-    for (; t < total; t++) {
-        need_edge(t);
-        const int c2 = vcr_edge<RT, CT>(P, S, C, ring, t, yv_, uv_, vv_);
-        const int x2 = t - SK1;
-        if (x2 >= 0) __builtin_amdgcn_raw_buffer_store_b32(c2, out, vout, (int)((unsigned)x2 * rb), 0);
-    }
-    NTSC_PIPE_VMCNT(0);
-    publish(sync + 1, W);
+    for (; t < total; t++) edge(t);
 }
 
-// ------------------------------------------------------------------------------------------------ wave 2: TV half
+// ------------------------------------------------------------------------------------------------ LUM: VCR luma + TV front
+// the luma path of vcr_step / vcr_edge (box at x2, VHS low-pass + emphasis, sharpen), the VCR's composite sample
+// c2 = Y + chroma term, and the TV's separator on it (step<true> / edge_step<true>: x3 = x2 - 7, dropout as the and-mask)
 template <class RT>
-DEV void tv_role(const DevParams &P, const Row &R, const int *__restrict__ comp_vcr, const int *__restrict__ dropout,
-                 uint32_t *ostage, const unsigned long long *orow, uint32_t *drow, volatile uint32_t *sync)
+DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const int *__restrict__ hs_shift,
+                   const int *__restrict__ dropout, lds_x1 bc, lds_x4 cd, lds_flag fl)
 {
-    const int lane = R.lane, W = P.W;
-    const FieldDev &fd = *R.fd;
     typedef Const<RT, false> CT;
     CT C;
-    C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
-    C.bmul = P.m_amp_back.mul; C.bshift = P.m_amp_back.shift; C.odd = false; C.mo = 0;
-    C.xi = scan_phase(P, R.y, fd.fieldno);
-    C.hi = (C.xi & 2u) != 0;
-    C.W = W;
-    C.xe = (W & 1) ? W - 1 : W - 2;
-    C.lane = lane;
-    C.d = 0;
-    C.SKT = 8;
-    C.LOFF = 5;
-    C.mL = opaque_v(C.hi ? -1 : 0);
-    C.mNL = opaque_v(~C.mL);
-    C.bA = 0; C.bC = 0;
+    dec_const<RT>(C, P, R, comp, hs_shift);
     C.dm = opaque_v((P.loss && dropout[R.rc] != 0) ? 0 : -1);
-    C.cosv = 1; C.sinv = 0;
-    C.a_vc = (RT)P.a_vc; C.a_vl = (RT)P.a_vl; C.a_sh = (RT)P.a_sh; C.a_tv = (RT)P.a_tv;
-    C.a_oi = (RT)P.a_in_i; C.a_oq = (RT)P.a_in_q;
-    C.sharp2 = (RT)(P.sharpen * 2);
-    C.tailU = nullptr; C.rstride = 0;
-    C.xs = nullptr;
-    C.rowbytes = P.Rpad * 4;
-    C.vbase = (int)((unsigned)R.rc * 4u);                  // the VCR's output carries the head switch already
-    C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp_vcr), 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
-
-    State<false, RT> S;
-    S.D1.init(); S.D2.init();
-    S.l0 = S.l1 = S.l2 = S.lsum = 0;
-    S.vl.reset(16, C.a_vl); S.vpre.reset(16, C.a_vl); S.vcU.reset(0, C.a_vc); S.vcV.reset(0, C.a_vc);
-    S.sh.reset(0, C.a_sh);
-    S.oU.reset(0, C.a_tv); S.oV.reset(0, C.a_tv);
-    S.Yprev = S.Uraw = S.Vraw = 0;
-    S.Uf2[0] = S.Uf2[1] = 0;
-    S.nU = S.nV = 0;
-
-    const int SKT = C.SKT, total = W + SKT;
-    int vcr_seen = 0;
-    int t = 0;
-    auto need = [&](int cols) { wait_ge(sync + 1, cols < W ? cols : W, vcr_seen); };
-    // (the guarded steps of the one-separator decoder load with cs_load's plain policy; the columns they ask for were
-    //  never in this CU's L1 before -- each is requested exactly once, after it was published)
-    for (; t < SKT && t < total; t++) {
-        uint32_t px; int xo;
-        need(t + 1);
-        (void)edge_step<false, RT, CT>(P, S, C, nullptr, t, px, xo);
-    }
-    // steady: 4 positions per iteration, the next iteration's samples requested at the top of the current one
-    {
-        const int t_end = W;
-        if (t + 4 <= t_end) {
-            Steady T;
-            T.D1.from(S.D1, true);
-            T.D2.from(S.D2, true);
-            T.lc1 = S.l2; T.lpA = S.l2 + S.l1; T.lpB = S.l1 + S.l0;
-            T.D1.ieP &= C.dm; T.D1.qeP &= C.dm; T.D1.ieN &= C.dm; T.D1.qeN &= C.dm;
-            int pc[4];
-            need(t + 4);
-#pragma unroll
-            for (int j = 0; j < 4; j++) pc[j] = cs_load<2>(C, t + j);
-            int pend_x = -1;
-            for (; t + 4 <= t_end; t += 4) {
-                uint32_t o[4];
-                int nc[4] = {0, 0, 0, 0};
-                need(t + 8);
-#pragma unroll
-                for (int j = 0; j < 4; j++) nc[j] = cs_load<2>(C, t + 4 + j);      // (past the row end: the buffer's bounds check, 0)
-                o[0] = step<false, 0, 0, RT, CT>(P, S, T, C, pc[0], 0);
-                o[1] = step<false, 0, 1, RT, CT>(P, S, T, C, pc[1], 0);
-                o[2] = step<false, 0, 2, RT, CT>(P, S, T, C, pc[2], 0);
-                o[3] = step<false, 0, 3, RT, CT>(P, S, T, C, pc[3], 0);
-#pragma unroll
-                for (int j = 0; j < 4; j++) pc[j] = nc[j];
-                const int xo0 = t - SKT;
-                const int sub = (xo0 >> 2) & 3;
-                *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) = make_uint4(o[0], o[1], o[2], o[3]);
-                if (sub == 3) {
-                    pend_x = xo0 - 12;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int r = 16 * k + (lane >> 2);
-                        const unsigned long long rp = orow[r];
-                        const uint4 v = *reinterpret_cast<const uint4 *>(&ostage[r * 20 + (lane & 3) * 4]);
-                        if (rp) NTSC_OUT_STORE((g_v4u_ptr)(rp + 4ull * (unsigned)(pend_x + (lane & 3) * 4)), to_v4u(v));
-                    }
-                }
-            }
-            T.D1.to(S.D1, true);
-            S.Uraw = 0; S.Vraw = 0;
+    const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT, LOFF = C.LOFF;
+    DemodR D2;
+    D2.init();
+    int l0 = 0, l1 = 0, l2 = 0;
+    Casc3<RT> vl, sh;
+    PoleHp<RT> vpre;
+    vl.reset(16, C.a_vl); vpre.reset(16, C.a_vl); sh.reset(0, C.a_sh);
+    const int reach = W / 10 + 2;
+    int enc_seen = 0, in_seen = 0, cons_seen = 0;
+    auto need_enc = [&](int c) { wait_ge(fl + F_ENC, c < W ? c : W, enc_seen); };
+    auto edge = [&](int t) {
+        wait_ge(fl + F_BC_P, t + 1, in_seen);
+        wait_ge(fl + F_CD_C, t + 1 - RING, cons_seen);
+        const int xl = t - LOFF;
+        if (xl >= 0) need_enc(xl + reach);
+        const int pl = (xl >= 0 && xl < W) ? cs_load<2>(C, xl) : 0;
+        const int ch = (int)bc[slot_of(t, SKT) * 64 + lane];
+        const int yb = sdiv4(l0 + l1 + l2 + pl);
+        l0 = l1; l1 = l2; l2 = pl;
+        const int x2 = t - 7 - C.d;
+        int c2 = 0;
+        if (x2 >= 0 && x2 < W) {
+            RT m2;
+            RT s = vl.push((RT)yb, C.a_vl, m2);                                     // :1793-1812
+            s += vpre.hp(s, m2, C.a_vl) * RT(1.6);
+            const RT s0 = rtrunc<RT>(s);
+            const RT ts = sh.push(s0, C.a_sh);                                      // :1866-1883
+            const int Y = (int)(s0 + ((s0 - ts) * C.sharp2));
+            c2 = Y + ch;                                                            // :1885-1888
         }
+        int Y, U, V;
+        D2.template push_edge<false, false>(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
+        if (x2 - 7 >= W) { U = 0; V = 0; Y = 0; }
+        U &= C.dm; V &= C.dm;                                                       // :1891-1901
+        cd[slot_of(t, SKT) * 64 + lane] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};
+        publish(fl + F_CD_P, t + 1);
+        *(fl + F_BC_C) = (uint32_t)(t + 1);
+    };
+    int t = 0;
+    for (; t < SKT && t < total; t++) edge(t);
+    const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
+    if (has_steady(W, C.d)) {
+        DemodS S2;
+        S2.from(D2, true);                        // x3 = 1 (mod 4) at the loop's first position: a pick
+        S2.ieP &= C.dm; S2.qeP &= C.dm; S2.ieN &= C.dm; S2.qeN &= C.dm;     // (as steady(): the guarded steps mask their outputs)
+        int lc1 = l2, lpA = l2 + l1, lpB = l1 + l0;
+        int pl[4];
+        need_enc(t + 4 - LOFF + reach);
+#pragma unroll
+        for (int j = 0; j < 4; j++) pl[j] = cs_load<2>(C, t + j - LOFF);
+#define NTSC_PIPE_LUM_STEP(J)                                                                     \
+        {                                                                                         \
+            const int lp = pl[J] + lc1;                                                           \
+            const int yb = sdiv4s(lp + lpB);                                                      \
+            lc1 = pl[J]; lpB = lpA; lpA = lp;                                                     \
+            pl[J] = cs_load<2>(C, t + 4 + (J) - LOFF);                                            \
+            RT m2;                                                                                \
+            RT s = vl.push((RT)yb, C.a_vl, m2);                                                   \
+            s += vpre.hp(s, m2, C.a_vl) * RT(1.6);                                                \
+            const RT s0 = rtrunc<RT>(s);                                                          \
+            const RT ts = sh.push(s0, C.a_sh);                                                    \
+            const int c2 = (int)(s0 + ((s0 - ts) * C.sharp2)) + (int)in[J];                       \
+            constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;             \
+            int Y, U, V;                                                                          \
+            S2.template push<pick3, neg3, true, false, true, false>(c2, C.hi, C.dm, Y, U, V);     \
+            o[(J) * 64] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};                       \
+            NTSC_STEP_SCHED_BARRIER();                                                            \
+        }
+        for (; t + 4 <= t_end; t += 4) {
+            need_enc(t + 8 - LOFF + reach);
+            wait_ge(fl + F_BC_P, t + 4, in_seen);
+            wait_ge(fl + F_CD_C, t + 4 - RING, cons_seen);
+            const lds_x1 ip = bc + slot_of(t, SKT) * 64 + lane;
+            const lds_x4 o = cd + slot_of(t, SKT) * 64 + lane;
+            uint32_t in[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
+            NTSC_PIPE_LUM_STEP(0)
+            publish(fl + F_CD_P, t);
+            *(fl + F_BC_C) = (uint32_t)t;
+            NTSC_PIPE_LUM_STEP(1) NTSC_PIPE_LUM_STEP(2) NTSC_PIPE_LUM_STEP(3)
+        }
+#undef NTSC_PIPE_LUM_STEP
+        publish(fl + F_CD_P, t);
+        *(fl + F_BC_C) = (uint32_t)t;
+        S2.to(D2, true);
+        l2 = lc1; l1 = lpA - lc1; l0 = lpB - l1;
     }
-    for (; t < total; t++) {
-        uint32_t px; int xo;
-        need(t + 1);
-        if (!edge_step<false, RT, CT>(P, S, C, nullptr, t, px, xo)) continue;
+    for (; t < total; t++) edge(t);
+}
+
+// ------------------------------------------------------------------------------------------------ OUT: TV back
+// the output stage of step<true> / edge_step<true>: composite_lowpass_tv (delay 1), YIQ -> RGB for the previous position,
+// 16 pixels of 64 rows staged in LDS and stored as 64-byte bursts (steady()'s cooperative flush)
+template <class RT>
+DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const unsigned long long *orow, uint32_t *drow,
+                     lds_x4 cd, lds_flag fl)
+{
+    const int lane = R.lane, W = P.W, d = P.cdelay, SKT = 15 + d, total = W + SKT;
+    const RT a_tv = (RT)P.a_tv;
+    Casc3<RT> oU, oV;
+    oU.reset(0, a_tv); oV.reset(0, a_tv);
+    int Yprev = 0, Uraw = 0, Vraw = 0;
+    int in_seen = 0;
+    auto edge = [&](int t) {
+        wait_ge(fl + F_CD_P, t + 1, in_seen);
+        const u32x4 yuv = cd[slot_of(t, SKT) * 64 + lane];
+        publish(fl + F_CD_C, t + 1);              // (behind the release: the slot has been read)
+        const int x3 = t - 14 - d;
+        if (x3 < 0 || x3 > W) return;
+        const int Y = (int)yuv.x, U = (int)yuv.y, V = (int)yuv.z;
+        RT fUd = 0, fVd = 0;
+        if (x3 < W) {
+            fUd = rtrunc<RT>(oU.push((RT)U, a_tv));
+            fVd = rtrunc<RT>(oV.push((RT)V, a_tv));
+        }
+        const int xo = x3 - 1;
+        const int Yo = Yprev, Ur = Uraw, Vr = Vraw;
+        Yprev = Y; Uraw = U; Vraw = V;
+        if (xo < 0) return;
+        if (xo >= W - 1) { fUd = (RT)Ur; fVd = (RT)Vr; }      // last sample keeps its input :1419-1424
+        const uint32_t px = yiq_to_bgra<RT>(Yo, fUd, fVd);
         ostage[lane * 20 + (xo & 15)] = px;
         if ((xo & 15) == 15) {
             if (R.is_out) {
@@ -406,33 +557,73 @@ DEV void tv_role(const DevParams &P, const Row &R, const int *__restrict__ comp_
             const int xb = xo & ~15;
             for (int q = xb; q <= xo; q++) ((g_u32_ptr)drow)[q] = ostage[lane * 20 + (q - xb)];
         }
+    };
+    int t = 0;
+    for (; t < SKT && t < total; t++) edge(t);
+    const int t_end = W - (d > 7 ? d - 7 : 0);
+    if (has_steady(W, d)) {
+        for (; t + 4 <= t_end; t += 4) {
+            wait_ge(fl + F_CD_P, t + 4, in_seen);
+            const lds_x4 ip = cd + slot_of(t, SKT) * 64 + lane;
+            u32x4 in[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const RT fUd = rtrunc<RT>(oU.push((RT)(int)in[j].y, a_tv));
+                const RT fVd = rtrunc<RT>(oV.push((RT)(int)in[j].z, a_tv));
+                o[j] = yiq_to_bgra<RT>(Yprev, fUd, fVd);
+                Yprev = (int)in[j].x;
+                if (j == 0) publish(fl + F_CD_C, t + 4);      // the four slots are in registers
+                NTSC_STEP_SCHED_BARRIER();
+            }
+            const int xo0 = t - SKT;                   // multiple of 4
+            const int sub = (xo0 >> 2) & 3;
+            *reinterpret_cast<uint4 *>(&ostage[lane * 20 + sub * 4]) = make_uint4(o[0], o[1], o[2], o[3]);
+            if (sub == 3) {
+                const int pend_x = xo0 - 12;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = 16 * k + (lane >> 2);
+                    const unsigned long long rp = orow[r];
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&ostage[r * 20 + (lane & 3) * 4]);
+                    if (rp) NTSC_OUT_STORE((g_v4u_ptr)(rp + 4ull * (unsigned)(pend_x + (lane & 3) * 4)), to_v4u(v));
+                }
+            }
+        }
+        Uraw = 0; Vraw = 0;        // (only the row's last sample reads them, every guarded step rewrites them)
     }
+    for (; t < total; t++) edge(t);
 }
 
 } // namespace pipe
 
-// One workgroup = 63 rows + the halo row above, three wavefronts = three roles (see the head of this file).
+// One workgroup = 63 rows + the halo row above, five wavefronts = five roles (see the head of this file).
 // Preconditions (launcher): the -vhs preset family of the hand-tuned kernels (input chroma low-pass on, no pre-emphasis, luma /
 // chroma / phase noise on, amplitudes 50 / 50, even scanline phase, output low-pass "lite", composite out), head-switch
 // displacement within W/10, 16-byte aligned rows, planes below 4 GiB, no ghosting.
 template <class RT>
-__global__ __launch_bounds__(192) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
+__global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
                                                     const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
-                                                    int *__restrict__ comp, int *__restrict__ comp_vcr,
+                                                    int *__restrict__ comp,
                                                     const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
                                                     const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                                                     const int *__restrict__ pn_noise, const int *__restrict__ dropout,
-                                                    int *__restrict__ tails)
+                                                    int *__restrict__ tails, unsigned order)
 {
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];                                   // the encoder's rand() ring
     __shared__ __attribute__((aligned(16))) uint32_t ltile[64 * 20];       // its cooperative row loads
-    __shared__ uint32_t ring_v[33 * 64];                                   // the VCR half's rand() ring
-    __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];      // the TV half's pixel staging
+    __shared__ uint32_t ring_v[33 * 64];                                   // the chroma noise's rand() ring
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];      // the pixel staging
     __shared__ unsigned long long orow[64];
-    __shared__ uint32_t sync[2];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_ab[RING * 64 * 2];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_bc[RING * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_cd[RING * 64 * 4];
+    __shared__ uint32_t flags[F_COUNT];
 
-    const int role = threadIdx.x >> 6;
+    const int role = (int)((order >> (4 * (threadIdx.x >> 6))) & 15u);
     Row R;
     R.lane = threadIdx.x & 63;
     const int gidx = blockIdx.x * 63 + R.lane - 1;          // lane 0 = halo (row above)
@@ -445,12 +636,18 @@ __global__ __launch_bounds__(192) void k_field_pipe(DevParams P, GeomDev G, cons
     R.is_out = R.lane >= 1 && gidx < P.R && R.rowok;
     R.y = R.rowok ? R.field + 2u * (unsigned)R.k : R.field;
     uint32_t *drow = reinterpret_cast<uint32_t *>(R.fd->dst + (size_t)R.fd->dst_ls * R.y);
-    if (role == 2) orow[R.lane] = R.is_out ? (unsigned long long)drow : 0ull;
-    if (threadIdx.x < 2) sync[threadIdx.x] = 0u;
+    if (threadIdx.x < 64) orow[R.lane] = R.is_out ? (unsigned long long)drow : 0ull;
+    if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0u;
     __syncthreads();
-    if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, sync);
-    else if (role == 1) vcr_role<RT>(P, G, R, comp, comp_vcr, rs_chroma, n0_u, n0_v, hs_shift, pn_noise, tails, ring_v, sync);
-    else tv_role<RT>(P, R, comp_vcr, dropout, ostage, orow, drow, sync);
+    const lds_flag fl = (lds_flag)flags;
+    const lds_x2 ab = (lds_x2)ring_ab;
+    const lds_x1 bc = (lds_x1)ring_bc;
+    const lds_x4 cd = (lds_x4)ring_cd;
+    if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    else if (role == 1) sep_role<RT>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
+    else if (role == 2) chroma_role<RT>(P, G, R, pn_noise, tails, ab, bc, fl);
+    else if (role == 3) luma_role<RT>(P, R, comp, hs_shift, dropout, bc, cd, fl);
+    else output_role<RT>(P, R, ostage, orow, drow, cd, fl);
 }
 
 } // namespace ntscsim

@@ -727,7 +727,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                     D.ghost_taps == 0 && !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small &&
                     !c->split_vhs &&
                     ((D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) || (!D.vhs && !D.cnoise_k && !D.pnoise_k));
-    // the latency form: encoder, VCR half and TV half as three wavefronts of one workgroup (ntsc_pipe.hip) -- short launches
+    // the latency form: the chain as five wavefronts (roles) of one workgroup (ntsc_pipe.hip) -- short launches
     // from the host-frame entry points, the -vhs preset family of the hand-tuned kernels.  NTSCSIM_PIPE=0: A/B switch.
     static const bool pipe_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
     const bool pipe_form = c->latency_form && pipe_env && n <= NTSC_PIPE_MAX_FIELDS && c->mode != NTSCSIM_MODE_FLOAT &&
@@ -735,12 +735,14 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                            !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->split_vhs &&
                            D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k;
     if (pipe_form) {
-        HIPCHK(c, c->comp_vcr.ensure((size_t)D.Rpad * W));
+        // (developer switch: which wavefront of the workgroup takes which role, one hex digit per wavefront -- ntsc_pipe.hip)
+        static const unsigned order = std::getenv("NTSCSIM_PIPE_ORDER") ? (unsigned)std::strtoul(std::getenv("NTSCSIM_PIPE_ORDER"), nullptr, 16)
+                                                                        : NTSC_PIPE_ORDER;
         note_kernel(c, fast ? "k_field_pipe<float>" : "k_field_pipe<double>");
-        if (fast) hipLaunchKernelGGL((k_field_pipe<float>), dgrid, dim3(192), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                     c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p);
-        else hipLaunchKernelGGL((k_field_pipe<double>), dgrid, dim3(192), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                c->comp_vcr.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p);
+        if (fast) hipLaunchKernelGGL((k_field_pipe<float>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
+                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order);
+        else hipLaunchKernelGGL((k_field_pipe<double>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
+                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order);
     } else if (fp) {
         note_kernel(c, "k_encode_fp");
         launch_encode_fp(st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);

@@ -281,7 +281,7 @@ def test_host_frame_dropin_sequence():
     (["-vhs", "-vhs-svideo", "1"], 256, 100, False), (["-vhs", "-comp-phase", "90"], 256, 100, False), ([], 256, 100, False),
     (["-vhs"], 33, 17, True),                               # (tight host rows: the device frames have aligned rows of their own)
 ])
-def test_synchronous_call_takes_the_three_role_form_and_equals_the_oracle(flags, w, h, piped):
+def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, w, h, piped):
     """ntscsim_field(): launches of up to 64 fields from the host-frame entry points run encoder, VCR half and TV half
     as three wavefronts of one workgroup (k_field_pipe, csrc/ntsc_pipe.hip) for the -vhs preset family -- same step
     functions as the other forms, samples handed over through the planes behind two LDS counters -- bit for bit the
