@@ -360,10 +360,87 @@ __global__ __launch_bounds__(64) void k_row_states(DevParams P, GeomDev G,
     row_states_body(P, G, fields, rs_luma, n0_luma, rs_chroma, n0_u, n0_v, ring, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// One PART of a field's setup by one block (the short batches of the host-frame calls: k_field_row_setup): part 0 the head
+// switch, 1 the phase-noise walk, 2 the dropout walk.  field_setup_body does the three one after the other in one lane (a
+// lane per field: right for hundreds of fields, 36 us for one); here the three walks of a field run side by side, and
+// the jump to a walk's first draw -- 31 dot products of 31 terms, ~8 us in one lane -- is one dot product per lane.
+DEV void field_part_body(const DevParams &P, const GeomDev &G, const FieldDev *__restrict__ fields,
+                         int *__restrict__ hs_shift, int *__restrict__ pn_noise, int *__restrict__ dropout,
+                         uint32_t *ring, int f, int part)
+{
+    const int lane = threadIdx.x;
+    const FieldDev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const int L = field_rows(P, field);
+    const bool on = part == 0 ? P.hs != 0 : (part == 1 ? P.pnoise_k != 0 : P.loss != 0);
+    if (!on) return;
+    int *hs_row = hs_shift + (size_t)f * P.Lslot;
+    if (part == 0)      // (every row of the field's slot, also the ones the switch does not reach)
+        for (int k = lane; k < P.Lslot; k += 64) hs_row[k] = 0;
+    if (part == 0) __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the zeros have landed before lane 0 writes its rows
+    if (part != 0 || P.hs_noise_on) {
+        // part 2 starts behind the phase-noise draws: the second half of the pskip table (build_geometry)
+        const uint32_t *c = (part == 0 ? G.lskip : G.pskip + (part == 2 ? 62 : 0)) + field * 31;
+        if (lane < 31) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 31; k++) acc += c[k] * fd.rng[lane + k];
+            ring[lane * 64] = acc;
+        }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    SetupRand g;
+    g.p3 = ring[28 * 64]; g.p2 = ring[29 * 64]; g.p1 = ring[30 * 64];
+    g.slot = 0;
+    if (part == 0) {
+        // VHS head switching geometry, ffmpeg_ntsc.cpp:1647-1713 (as field_setup_body)
+        const unsigned twidth = (unsigned)P.W + ((unsigned)P.W / 10u);
+        double noise = 0;
+        if (P.hs_noise_on) {
+            unsigned u = g.next(ring, 0);
+            u *= g.next(ring, 0); u *= g.next(ring, 0); u *= g.next(ring, 0);
+            u %= 2000000000U;
+            noise = ((double)u / 1000000000U) - 1.0;
+            noise *= P.hs_pn;
+        }
+        const double t = P.ntsc ? twidth * 262.5 : twidth * 312.5;
+        double a = (P.variant ? P.hs_phase : P.hs_point) + noise;
+        unsigned pp = (unsigned)((a - trunc(a)) * t);
+        int y = (int)((pp / twidth) * 2u) + (int)field;
+        a = P.hs_phase + noise;
+        pp = (unsigned)((a - trunc(a)) * t);
+        const unsigned hx = pp % twidth;
+        y -= P.ntsc ? (262 - 240) * 2 : (312 - 288) * 2;
+        const int ishif = (hx >= twidth / 2) ? (int)(hx - twidth) : (int)hx;
+        int shif = 0;
+        unsigned shy = 0;
+        while (y < P.H) {
+            if (y >= 0 && shif != 0) hs_row[(y - (int)field) >> 1] = shif;
+            shif = (shy == 0) ? ishif : (shif * 7) / 8;
+            y += 2;
+            shy++;
+        }
+    } else if (part == 1) {
+        // chroma phase noise accumulator, one draw per row, carried down the field (:1736-1746)
+        int n = 0;
+        for (int k = 0; k < L; k++) {
+            n += (int)umod31(g.next(ring, 0), P.m_pnoise) - P.pnoise_k;
+            n = sdiv2(n);
+            pn_noise[(size_t)f * P.Lslot + k] = n;
+        }
+    } else {
+        // chroma dropout, one draw per row (:1891-1901)
+        for (int k = 0; k < L; k++)
+            dropout[(size_t)f * P.Lslot + k] = (g.next(ring, 0) % 100000U) < (unsigned)P.loss;
+    }
+}
+
 // Both in ONE launch, for the short batches of the host-frame calls (ntscsim_field(): one field; a submit lane: `depth`
 // fields): the two are independent of each other, and with a handful of fields k_field_setup is a single wavefront
 // walking its rows one draw at a time (36 us for one field) -- as blocks of the same grid that walk overlaps the row
-// states instead of preceding them.  Blocks [0, nfs) do the field setup (first: they run longest), the rest the row states.
+// states instead of preceding them.  Blocks [0, nfs) do the field setup, one block per field and part (first: they run
+// longest), the rest the row states.
 __global__ __launch_bounds__(64) void k_field_row_setup(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
                                                         int *__restrict__ hs_shift, int *__restrict__ pn_noise,
                                                         int *__restrict__ dropout,
@@ -373,7 +450,7 @@ __global__ __launch_bounds__(64) void k_field_row_setup(DevParams P, GeomDev G, 
 {
     __shared__ uint32_t ring[31 * 64];
     const int b = (int)blockIdx.x;
-    if (b < nfs) { field_setup_body(P, G, fields, hs_shift, pn_noise, dropout, ring, b); return; }
+    if (b < nfs) { field_part_body(P, G, fields, hs_shift, pn_noise, dropout, ring, b / 3, b % 3); return; }
     const int q = b - nfs;
     row_states_body(P, G, fields, rs_luma, n0_luma, rs_chroma, n0_u, n0_v, ring, q % nrs, q / nrs);
 }

@@ -60,13 +60,19 @@ typedef __attribute__((address_space(3))) uint32_t *lds_x1;
 typedef __attribute__((address_space(3))) u32x2 *lds_x2;
 typedef __attribute__((address_space(3))) u32x4 *lds_x4;
 
+__shared__ unsigned g_waited[8];
 DEV int flag_peek(lds_flag p) { return __builtin_amdgcn_readfirstlane((int)*p); }
 // wait until the count at p is at least v (wave-uniform); `cached`: the last value this wavefront saw
 DEV void wait_ge(lds_flag p, int v, int &cached)
 {
     if (cached >= v) return;
     int seen = flag_peek(p);
-    while (seen < v) { __builtin_amdgcn_s_sleep(1); seen = flag_peek(p); }
+    if (seen < v) {
+        // (developer timing, NTSCSIM_PIPE_TIMING: 100 MHz ticks this wavefront spent polling, summed per wavefront behind the flags)
+        const unsigned t0 = (unsigned)wall_clock64();
+        do { __builtin_amdgcn_s_sleep(1); seen = flag_peek(p); } while (seen < v);
+        g_waited[threadIdx.x >> 6] += (unsigned)wall_clock64() - t0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     cached = seen;
 }
@@ -279,7 +285,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
         need_enc(t + 4 + reach);
 #pragma unroll
         for (int j = 0; j < 4; j++) pc[j] = cs_load<2>(C, t + j);
-#define NTSC_PIPE_SEP_STEP(DPH, J)                                                                \
+#define NTSC_PIPE_SEP_STEP(DPH, J, PRE)                                                           \
         {                                                                                         \
             constexpr bool pick1 = (((DPH) + (J)) & 1) != 0, neg1 = (((DPH) + (J)) & 3) == 3;     \
             int Yd, U, V;                                                                         \
@@ -288,6 +294,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
             U += nU; V += nV;                                                                     \
             nU = sdiv2(nU + (int)umod31(rng.template draw<2 * (J)>(rb, rb0), P.m_cnoise) - P.cnoise_k);     \
             nV = sdiv2(nV + (int)umod31(rng.template draw<2 * (J) + 1>(rb, rb0), P.m_cnoise) - P.cnoise_k); \
+            PRE;                                                                                  \
             o[(J) * 64] = u32x2{(uint32_t)U, (uint32_t)V};                                        \
             NTSC_STEP_SCHED_BARRIER();                                                            \
         }
@@ -299,9 +306,10 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
             const bool rb0 = sbase == 0;                                                          \
             sbase = (sbase + 8) & 31;                                                             \
             const lds_x2 o = ab + slot_of(t, SKT) * 64 + lane;                                    \
-            NTSC_PIPE_SEP_STEP(DPH, 0)                                                            \
-            publish(fl + F_AB_P, t);              /* the iteration before this one */             \
-            NTSC_PIPE_SEP_STEP(DPH, 1) NTSC_PIPE_SEP_STEP(DPH, 2) NTSC_PIPE_SEP_STEP(DPH, 3)      \
+            /* the iteration before this one is published between the arithmetic of step 0 and its store: the release's    \
+               s_waitcnt lgkmcnt(0) then finds the earlier stores long landed and nothing new in flight */                 \
+            NTSC_PIPE_SEP_STEP(DPH, 0, publish(fl + F_AB_P, t))                                   \
+            NTSC_PIPE_SEP_STEP(DPH, 1, (void)0) NTSC_PIPE_SEP_STEP(DPH, 2, (void)0) NTSC_PIPE_SEP_STEP(DPH, 3, (void)0) \
         }
         switch (C.d & 3) {
             case 0: NTSC_PIPE_SEP_ITER(0) break;
@@ -378,7 +386,7 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
     for (; t < SKT && t < total; t++) edge(t);
     const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
     if (has_steady(W, C.d)) {
-#define NTSC_PIPE_CHR_STEP(J)                                                                     \
+#define NTSC_PIPE_CHR_STEP(J, PRE)                                                                \
         {                                                                                         \
             const RT u = (RT)(int)in[J].x, v = (RT)(int)in[J].y;                                  \
             const RT Ud = rtrunc<RT>((u * C.cosv) - (v * C.sinv));                                \
@@ -389,7 +397,9 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
             const int f = ((J) & 1) ? fV : fU;                                                    \
             const int chroma = ((wave_up(f) & C.bA) + f + C.bC) >> C.bC;                          \
             const int mm = ((J) & 2) ? C.mNL : C.mL;                                              \
-            o[(J) * 64] = (uint32_t)((chroma ^ mm) - mm);                                         \
+            const uint32_t outv = (uint32_t)((chroma ^ mm) - mm);                                 \
+            PRE;                                                                                  \
+            o[(J) * 64] = outv;                                                                   \
             NTSC_STEP_SCHED_BARRIER();                                                            \
         }
         for (; t + 4 <= t_end; t += 4) {
@@ -400,10 +410,9 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
             u32x2 in[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
-            NTSC_PIPE_CHR_STEP(0)
-            publish(fl + F_BC_P, t);              // the iteration before this one: written, and its inputs read
-            *(fl + F_AB_C) = (uint32_t)t;
-            NTSC_PIPE_CHR_STEP(1) NTSC_PIPE_CHR_STEP(2) NTSC_PIPE_CHR_STEP(3)
+            // (the iteration before this one: written, and its inputs read -- published as in SEP)
+            NTSC_PIPE_CHR_STEP(0, (publish(fl + F_BC_P, t), (void)(*(fl + F_AB_C) = (uint32_t)t)))
+            NTSC_PIPE_CHR_STEP(1, (void)0) NTSC_PIPE_CHR_STEP(2, (void)0) NTSC_PIPE_CHR_STEP(3, (void)0)
         }
 #undef NTSC_PIPE_CHR_STEP
         publish(fl + F_BC_P, t);
@@ -473,7 +482,7 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
         need_enc(t + 4 - LOFF + reach);
 #pragma unroll
         for (int j = 0; j < 4; j++) pl[j] = cs_load<2>(C, t + j - LOFF);
-#define NTSC_PIPE_LUM_STEP(J)                                                                     \
+#define NTSC_PIPE_LUM_STEP(J, PRE)                                                                \
         {                                                                                         \
             const int lp = pl[J] + lc1;                                                           \
             const int yb = sdiv4s(lp + lpB);                                                      \
@@ -488,6 +497,7 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;             \
             int Y, U, V;                                                                          \
             S2.template push<pick3, neg3, true, false, true, false>(c2, C.hi, C.dm, Y, U, V);     \
+            PRE;                                                                                  \
             o[(J) * 64] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};                       \
             NTSC_STEP_SCHED_BARRIER();                                                            \
         }
@@ -500,10 +510,8 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             uint32_t in[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
-            NTSC_PIPE_LUM_STEP(0)
-            publish(fl + F_CD_P, t);
-            *(fl + F_BC_C) = (uint32_t)t;
-            NTSC_PIPE_LUM_STEP(1) NTSC_PIPE_LUM_STEP(2) NTSC_PIPE_LUM_STEP(3)
+            NTSC_PIPE_LUM_STEP(0, (publish(fl + F_CD_P, t), (void)(*(fl + F_BC_C) = (uint32_t)t)))
+            NTSC_PIPE_LUM_STEP(1, (void)0) NTSC_PIPE_LUM_STEP(2, (void)0) NTSC_PIPE_LUM_STEP(3, (void)0)
         }
 #undef NTSC_PIPE_LUM_STEP
         publish(fl + F_CD_P, t);
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
                                                     const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
                                                     const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                                                     const int *__restrict__ pn_noise, const int *__restrict__ dropout,
-                                                    int *__restrict__ tails, unsigned order)
+                                                    int *__restrict__ tails, unsigned order, unsigned long long *dbg)
 {
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];                                   // the encoder's rand() ring
@@ -637,8 +645,9 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     R.y = R.rowok ? R.field + 2u * (unsigned)R.k : R.field;
     uint32_t *drow = reinterpret_cast<uint32_t *>(R.fd->dst + (size_t)R.fd->dst_ls * R.y);
     if (threadIdx.x < 64) orow[R.lane] = R.is_out ? (unsigned long long)drow : 0ull;
-    if (threadIdx.x < F_COUNT) flags[threadIdx.x] = 0u;
+    if (threadIdx.x < F_COUNT) { flags[threadIdx.x] = 0u; g_waited[threadIdx.x] = 0u; }
     __syncthreads();
+    const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     const lds_flag fl = (lds_flag)flags;
     const lds_x2 ab = (lds_x2)ring_ab;
     const lds_x1 bc = (lds_x1)ring_bc;
@@ -648,6 +657,11 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     else if (role == 2) chroma_role<RT>(P, G, R, pn_noise, tails, ab, bc, fl);
     else if (role == 3) luma_role<RT>(P, R, comp, hs_shift, dropout, bc, cd, fl);
     else output_role<RT>(P, R, ostage, orow, drow, cd, fl);
+    if (dbg && R.lane == 0) {      // NTSCSIM_PIPE_TIMING: start, end, ticks spent polling -- per workgroup and role
+        unsigned long long *o = dbg + ((size_t)blockIdx.x * 5 + role) * 3;
+        o[0] = t_start; o[1] = wall_clock64();
+        o[2] = g_waited[threadIdx.x >> 6] | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);      // HW_ID: SIMD, CU
+    }
 }
 
 } // namespace ntscsim

@@ -312,7 +312,7 @@ static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
     const uint64_t cdraws = D.variant ? 2ull * (uint64_t)(W / 2) : 2ull * (uint64_t)W;
     const int Lslot = (H + 1) / 2;
     const int Lp[2] = {(H + 1) / 2, H / 2};
-    std::vector<uint32_t> lskip(2 * 31), pskip(2 * 31), sstart(4 * 31), jrow((size_t)4 * Lslot * 31);
+    std::vector<uint32_t> lskip(2 * 31), pskip(4 * 31), sstart(4 * 31), jrow((size_t)4 * Lslot * 31);
     std::vector<int32_t> jwarm((size_t)4 * Lslot);
     const RandPoly xW = rand_poly_pow((uint64_t)W), x2W = rand_poly_pow(cdraws);
     for (int par = 0; par < 2; par++) {
@@ -324,6 +324,9 @@ static int build_geometry(ntscsim_ctx *c, int W, int H, const DevParams &D)
         const RandPoly b = rand_poly_pow(off_pn);
         std::memcpy(&lskip[par * 31], a.c, sizeof(a.c));
         std::memcpy(&pskip[par * 31], b.c, sizeof(b.c));
+        // ... and before the per-row dropout draws, which follow the phase-noise ones (k_field_row_setup walks the two in parallel)
+        const RandPoly bd = rand_poly_pow(off_pn + (c->prm.video_chroma_phase_noise != 0 ? (uint64_t)Lp[par] : 0));
+        std::memcpy(&pskip[(2 + par) * 31], bd.c, sizeof(bd.c));
         g.calls[par] = D.variant ? ntscsim_rng_calls_per_field_422(&c->prm, W, H, (unsigned)par)
                                  : ntscsim_rng_calls_per_field(&c->prm, W, H, (unsigned)par);
         for (int s = 0; s < 2; s++) {
@@ -531,7 +534,7 @@ static void launch_setup(ntscsim_ctx *c, const DevParams &D, const GeomDev &G, c
 {
     const bool fs = D.hs || D.pnoise_k || D.loss, rs = D.noise_k || D.cnoise_k;
     if (fs && rs && n <= NTSC_SETUP_MERGE_MAX && !c->no_setup_merge) {
-        const int nfs = (n + 63) / 64, nrs = (D.R + 63) / 64;
+        const int nfs = 3 * n, nrs = (D.R + 63) / 64;      // (one block per field and part: head switch | phase noise | dropout)
         note_kernel(c, "k_field_row_setup");
         hipLaunchKernelGGL(k_field_row_setup, dim3((unsigned)(nfs + 2 * nrs)), dim3(64), 0, st, D, G, fields_dev,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p,
@@ -738,11 +741,34 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         // (developer switch: which wavefront of the workgroup takes which role, one hex digit per wavefront -- ntsc_pipe.hip)
         static const unsigned order = std::getenv("NTSCSIM_PIPE_ORDER") ? (unsigned)std::strtoul(std::getenv("NTSCSIM_PIPE_ORDER"), nullptr, 16)
                                                                         : NTSC_PIPE_ORDER;
+        // NTSCSIM_PIPE_TIMING=1 (developer probe): every role's start / end / polling time of the first workgroups, on stderr
+        static const bool pipe_timing = std::getenv("NTSCSIM_PIPE_TIMING") != nullptr;
+        static unsigned long long *dbg = nullptr;
+        if (pipe_timing && !dbg) { HIPCHK(c, hipMalloc((void **)&dbg, (size_t)4096 * 15 * sizeof(unsigned long long))); }
         note_kernel(c, fast ? "k_field_pipe<float>" : "k_field_pipe<double>");
         if (fast) hipLaunchKernelGGL((k_field_pipe<float>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order);
+                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg);
         else hipLaunchKernelGGL((k_field_pipe<double>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order);
+                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg);
+        if (pipe_timing && dgrid.x <= 4096) {
+            static int shown = 0;
+            std::vector<unsigned long long> h((size_t)dgrid.x * 15);
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (shown++ % 100 == 20) {
+                static const char *const names[5] = {"ENC", "SEP", "CHR", "LUM", "OUT"};
+                unsigned long long t0 = ~0ull;
+                for (size_t i = 0; i < h.size(); i += 3) t0 = h[i] < t0 ? h[i] : t0;
+                for (unsigned b = 0; b < dgrid.x && b < 4; b++)
+                    for (int r = 0; r < 5; r++) {
+                        const unsigned long long *o = &h[((size_t)b * 5 + r) * 3];
+                        const unsigned hw = (unsigned)(o[2] >> 32);
+                        std::fprintf(stderr, "pipe_timing wg %u %s start %.2f us end %.2f us polling %.2f us  simd %u cu %u se %u\n", b, names[r],
+                                     (double)(o[0] - t0) / 100.0, (double)(o[1] - t0) / 100.0, (double)(o[2] & 0xffffffffu) / 100.0,
+                                     (hw >> 4) & 3u, (hw >> 8) & 15u, (hw >> 13) & 7u);
+                    }
+            }
+        }
     } else if (fp) {
         note_kernel(c, "k_encode_fp");
         launch_encode_fp(st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p);
