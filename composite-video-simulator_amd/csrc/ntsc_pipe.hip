@@ -290,7 +290,6 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
             constexpr bool pick1 = (((DPH) + (J)) & 1) != 0, neg1 = (((DPH) + (J)) & 3) == 3;     \
             int Yd, U, V;                                                                         \
             S1.template push<pick1, neg1, false, false, false, false>(pc[J], C.hi, -1, Yd, U, V); \
-            pc[J] = cs_load<2>(C, t + 4 + (J));       /* (past the row end: the buffer's bounds check, 0) */ \
             U += nU; V += nV;                                                                     \
             nU = sdiv2(nU + (int)umod31(rng.template draw<2 * (J)>(rb, rb0), P.m_cnoise) - P.cnoise_k);     \
             nV = sdiv2(nV + (int)umod31(rng.template draw<2 * (J) + 1>(rb, rb0), P.m_cnoise) - P.cnoise_k); \
@@ -306,10 +305,15 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
             const bool rb0 = sbase == 0;                                                          \
             sbase = (sbase + 8) & 31;                                                             \
             const lds_x2 o = ab + slot_of(t, SKT) * 64 + lane;                                    \
+            /* the next iteration's samples are requested here and taken over at the bottom: a whole iteration of       \
+               arithmetic (~0.5 us) covers the L2 round trip (past the row end: the buffer's bounds check, 0) */         \
+            int nc[4];                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) nc[j] = cs_load<2>(C, t + 4 + j);       \
             /* the iteration before this one is published between the arithmetic of step 0 and its store: the release's    \
                s_waitcnt lgkmcnt(0) then finds the earlier stores long landed and nothing new in flight */                 \
             NTSC_PIPE_SEP_STEP(DPH, 0, publish(fl + F_AB_P, t))                                   \
             NTSC_PIPE_SEP_STEP(DPH, 1, (void)0) NTSC_PIPE_SEP_STEP(DPH, 2, (void)0) NTSC_PIPE_SEP_STEP(DPH, 3, (void)0) \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) pc[j] = nc[j];                          \
         }
         switch (C.d & 3) {
             case 0: NTSC_PIPE_SEP_ITER(0) break;
@@ -487,7 +491,6 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             const int lp = pl[J] + lc1;                                                           \
             const int yb = sdiv4s(lp + lpB);                                                      \
             lc1 = pl[J]; lpB = lpA; lpA = lp;                                                     \
-            pl[J] = cs_load<2>(C, t + 4 + (J) - LOFF);                                            \
             RT m2;                                                                                \
             RT s = vl.push((RT)yb, C.a_vl, m2);                                                   \
             s += vpre.hp(s, m2, C.a_vl) * RT(1.6);                                                \
@@ -508,10 +511,15 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             const lds_x1 ip = bc + slot_of(t, SKT) * 64 + lane;
             const lds_x4 o = cd + slot_of(t, SKT) * 64 + lane;
             uint32_t in[4];
+            int nl[4];                                // (the next iteration's samples: as in SEP)
+#pragma unroll
+            for (int j = 0; j < 4; j++) nl[j] = cs_load<2>(C, t + 4 + j - LOFF);
 #pragma unroll
             for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
             NTSC_PIPE_LUM_STEP(0, (publish(fl + F_CD_P, t), (void)(*(fl + F_BC_C) = (uint32_t)t)))
             NTSC_PIPE_LUM_STEP(1, (void)0) NTSC_PIPE_LUM_STEP(2, (void)0) NTSC_PIPE_LUM_STEP(3, (void)0)
+#pragma unroll
+            for (int j = 0; j < 4; j++) pl[j] = nl[j];
         }
 #undef NTSC_PIPE_LUM_STEP
         publish(fl + F_CD_P, t);
