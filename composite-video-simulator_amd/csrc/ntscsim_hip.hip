@@ -183,6 +183,7 @@ struct ntscsim_ctx {
     bool latency_form = false;
 };
 static void declared_pins_destroy(ntscsim_ctx *c);
+static uint8_t *pinned_device_ptr(ntscsim_ctx *c, const void *p, size_t span);      // ntscsim_submit.hip
 static void submit_engine_destroy(ntscsim_ctx *c);
 static int sub_wait_ticket(ntscsim_ctx *c, uint64_t ticket);
 static void host422_engine_destroy(ntscsim_ctx *c);
@@ -1604,7 +1605,16 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     }
     const size_t pitch = (((size_t)W * 4 + 255) / 256) * 256;
     HIPCHK(c, c->fsrc.ensure(pitch * H));
-    HIPCHK(c, c->fdst.ensure(pitch * H));
+    // A destination frame the GPU can address -- memory the caller declared (ntscsim_host_pin) or that is pinned already
+    // (ntscsim_host_frame_alloc / ntscsim_av_frame_get_buffer / hipHostMalloc; asked of the runtime at every call, nothing
+    // is registered or remembered here) -- with 16-byte aligned rows is written by the kernels themselves: no device copy
+    // of the frame, no download behind the chain.  NTSCSIM_FIELD_DIRECT=0: A/B switch.
+    static const bool direct_env = !(std::getenv("NTSCSIM_FIELD_DIRECT") && std::getenv("NTSCSIM_FIELD_DIRECT")[0] == '0');
+    uint8_t *dst_dev = nullptr;
+    if (direct_env && c->pin_policy > 0 && !(((uintptr_t)dst | (uintptr_t)dst_ls) & 15u))
+        dst_dev = pinned_device_ptr(c, dst, (size_t)dst_ls * (size_t)(H - 1) + (size_t)W * 4);
+    if (dst_dev && ((uintptr_t)dst_dev & 15u)) dst_dev = nullptr;
+    if (!dst_dev) HIPCHK(c, c->fdst.ensure(pitch * H));
     // Only the source rows this field reads go up: row min(y + opposite, H - 1) for y = field, field + 2, ...
     // (ffmpeg_ntsc.cpp:1585-1588, :1599) -- every second row from `first`, plus row H - 1 when the last one is clamped
     // onto it.  They land at their own place in the device frame; the rows in between are never read.
@@ -1632,8 +1642,8 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     c->src_pending = true;
     ntscsim_field_desc d;
     std::memset(&d, 0, sizeof(d));
-    d.src_dev = c->fsrc.p; d.dst_dev = c->fdst.p;
-    d.src_linesize = (int)pitch; d.dst_linesize = (int)pitch;
+    d.src_dev = c->fsrc.p; d.dst_dev = dst_dev ? dst_dev : c->fdst.p;
+    d.src_linesize = (int)pitch; d.dst_linesize = dst_dev ? dst_ls : (int)pitch;
     d.field = field;
     d.flags = (src_interlaced ? NTSCSIM_DESC_INTERLACED : 0u) | (src_tff ? NTSCSIM_DESC_TFF : 0u);
     d.fieldno = fieldno;
@@ -1644,7 +1654,7 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     if (rc != NTSCSIM_OK) { c->src_pending = false; (void)hipStreamSynchronize(su); return rc; }
     // only the rows of this field are written back (:1910-1916)
     const int L = (H - (int)field + 1) / 2;
-    if (L > 0)
+    if (L > 0 && !dst_dev)
         HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)dst_ls * field, (size_t)dst_ls * 2,
                                    c->fdst.p + pitch * field, pitch * 2, (size_t)W * 4, (size_t)L,
                                    hipMemcpyDeviceToHost, c->stream));

@@ -453,6 +453,29 @@ static uint8_t *pin_lookup(PinCache &pc, const void *p, size_t span)
     return (uint8_t *)dev + (a0 - p0);
 }
 
+// ntscsim_field(): the device-visible address of a caller frame that is the GPU's to address ALREADY -- declared through
+// ntscsim_host_pin(), or pinned memory the runtime knows (first and last byte of one registration) -- else NULL.  Registers
+// nothing and remembers nothing: the synchronous call must not outlive the caller's allocation with a cache entry.
+static uint8_t *pinned_device_ptr(ntscsim_ctx *c, const void *p, size_t span)
+{
+    if (!span) return nullptr;
+    const uintptr_t a0 = (uintptr_t)p, a1 = a0 + span;
+    if (c->declared)
+        for (auto &r : c->declared->regs)
+            if (a0 >= r.p0 && a1 <= r.p1) return r.dev + (a0 - r.p0);
+    hipPointerAttribute_t at0, at1;
+    if (hipPointerGetAttributes(&at0, (const void *)a0) != hipSuccess || at0.type != hipMemoryTypeHost || !at0.devicePointer) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipPointerGetAttributes(&at1, (const void *)(a1 - 1)) != hipSuccess || at1.type != hipMemoryTypeHost ||
+        at1.devicePointer != (void *)((uint8_t *)at0.devicePointer + (span - 1))) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (uint8_t *)at0.devicePointer;
+}
+
 static uint8_t *sub_pinned(ntscsim_ctx *c, SubmitEngine *e, const void *p, size_t span)
 {
     e->pins.policy = e->o.pin_caller_buffers < 0 ? 0 : (e->o.pin_caller_buffers > 2 ? 2 : e->o.pin_caller_buffers);

@@ -303,6 +303,45 @@ def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, 
     sim.close()
 
 
+@pytest.mark.parametrize("flags,w,h,off", [(["-vhs"], 720, 486, 0), (["-vhs"], 720, 486, 4), (["-vhs"], 100, 37, 0),
+                                           ([], 256, 100, 0), (["-vhs", "-vhs-svideo", "1"], 360, 243, 16)])
+def test_synchronous_call_writes_pinned_destination_frames_in_place(flags, w, h, off):
+    """ntscsim_field() on a destination frame the GPU can address (ntscsim_host_alloc / ntscsim_host_pin; 16-byte aligned
+    rows): the kernels store the field's rows into the caller's frame themselves -- no device copy, no download.  Same
+    bytes as the oracle, the other field's rows and the bytes around the frame untouched; frames that are pinned but
+    not 16-byte aligned (off = 4) go through the device copy."""
+    from ntscsim import host_alloc_array, host_free_array
+    p = L.make_params(flags, output_height=h)
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    block = host_alloc_array((h * w * 4 + 64 + off,))
+    block[:] = 0xA7
+    got = block[32 + off:32 + off + h * w * 4].reshape(h, w, 4)
+    got[:] = 0x5A
+    exp = np.full((h, w, 4), 0x5A, np.uint8)
+    for k in range(4):
+        s = L.noise_frame(w, h, 40 + k // 2)
+        field = (k & 1) ^ 1
+        sim.field_host(got, s, field, k)
+        o.field(exp, s, field, k)
+        assert np.array_equal(got, exp), "call %d" % k
+        assert sim.rng_pos == o.rng_pos
+    assert (block[:32 + off] == 0xA7).all() and (block[32 + off + h * w * 4:] == 0xA7).all()
+    # declared memory (ntscsim_host_pin) takes the same path
+    frame = np.zeros((h * w * 4 + 8192,), np.uint8)
+    a0 = (-frame.ctypes.data) % 4096
+    got2 = frame[a0:a0 + h * w * 4].reshape(h, w, 4)
+    sim.host_pin(frame[a0:a0 + ((h * w * 4 + 4095) // 4096) * 4096])
+    exp2 = np.zeros((h, w, 4), np.uint8)
+    for k in range(4, 6):
+        s = L.noise_frame(w, h, 40 + k // 2)
+        sim.field_host(got2, s, (k & 1) ^ 1, k)
+        o.field(exp2, s, (k & 1) ^ 1, k)
+        assert np.array_equal(got2, exp2), "declared, call %d" % k
+    sim.close()
+    host_free_array(block)
+
+
 @pytest.mark.parametrize("h", [2, 3, 32, 33])
 @pytest.mark.parametrize("il,tff", [(0, 0), (1, 0), (1, 1)])
 def test_host_frame_dropin_uploads_the_rows_it_reads(h, il, tff):
