@@ -184,6 +184,30 @@ def test_float_mode_through_the_host_call_and_the_submit_engine():
     sim.close()
 
 
+@pytest.mark.parametrize("w,h", [(720, 486), (100, 37)])
+def test_fast32_through_the_host_call_takes_the_pipelined_form_and_equals_the_batch(w, h):
+    """FAST32 is the exact kernels with float filter states: ntscsim_field() runs it as k_field_pipe<float> (five roles of
+    one workgroup), same bytes as the device-resident batch (k_encode_fast<float> | k_decode_fast<true,float>)"""
+    import torch
+    p = L.make_params(["-vhs"], output_height=h)
+    srcs = [L.noise_frame(w, h, 50 + j) for j in range(2)]
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.set_mode(_capi.MODE_FAST32)
+    src = torch.from_numpy(np.stack(srcs)).cuda()
+    dst = torch.zeros((4, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src, dst, [(k // 2, k, (k & 1) ^ 1, k) for k in range(4)])
+    sim.sync()
+    assert "k_field_pipe<float>" not in sim.last_kernels()
+    ref = dst.cpu().numpy()
+    sim.rng_pos = 0
+    one = np.zeros((4, h, w, 4), np.uint8)
+    for k in range(4):
+        sim.field_host(one[k], srcs[k // 2], (k & 1) ^ 1, k)
+        assert "k_field_pipe<float>" in sim.last_kernels()
+    assert np.array_equal(one, ref)
+    sim.close()
+
+
 def test_mode_switch_roundtrip():
     """EXACT after FAST32 on the same ctx is bit-exact again."""
     import torch
