@@ -236,7 +236,8 @@ DEV void dec_const(Const<RT, false> &C, const DevParams &P, const Row &R, const 
     C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
 }
 // the steady loop exists iff one iteration fits (every role decides alike: the positions are the same for all)
-DEV bool has_steady(int W, int d) { return 15 + d + 4 <= W - (d > 7 ? d - 7 : 0); }
+DEV bool has_steady(int W, int d, int SKT) { return SKT + 4 <= W - (d > 7 ? d - 7 : 0); }
+DEV bool has_steady(int W, int d) { return has_steady(W, d, 15 + d); }
 
 // ------------------------------------------------------------------------------------------------ SEP: VCR, chroma front
 // vcr_step / vcr_edge up to the chroma noise: first separator at x1 = t - 7 (no luma out), U / V += noise, two draws
@@ -530,14 +531,82 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
     for (; t < total; t++) edge(t);
 }
 
+// ------------------------------------------------------------------------------------------------ TVF: TV front, default preset
+// the decoder of the default preset (no VCR) up to its separator: step<false> / edge_step<false> of k_decode_fast<false>
+// without the output stage -- composite sample (head switching, if switched on without the VCR) -> Y, U, V at x3 = t - 7
+template <class RT>
+DEV void tvfront_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const int *__restrict__ hs_shift,
+                      const int *__restrict__ dropout, lds_x4 cd, lds_flag fl)
+{
+    typedef Const<RT, false> CT;
+    CT C;
+    dec_const<RT>(C, P, R, comp, hs_shift);
+    C.d = 0; C.SKT = 8;
+    C.dm = opaque_v((P.loss && dropout[R.rc] != 0) ? 0 : -1);
+    const int lane = R.lane, W = P.W, SKT = 8, total = W + SKT;
+    DemodR D1;
+    D1.init();
+    const int reach = P.hs ? W / 10 + 2 : 1;
+    int enc_seen = 0, cons_seen = 0;
+    auto need_enc = [&](int c) { wait_ge(fl + F_ENC, c < W ? c : W, enc_seen); };
+    auto edge = [&](int t) {
+        need_enc(t + reach);
+        wait_ge(fl + F_CD_C, t + 1 - RING, cons_seen);
+        const int pc = t < W ? cs_load<2>(C, t) : 0;
+        int Y, U, V;
+        D1.template push_edge<false, false>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+        if (t - 7 >= W) { U = 0; V = 0; Y = 0; }
+        U &= C.dm; V &= C.dm;                                                       // :1891-1901
+        cd[slot_of(t, SKT) * 64 + lane] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};
+        publish(fl + F_CD_P, t + 1);
+    };
+    int t = 0;
+    for (; t < SKT && t < total; t++) edge(t);
+    if (has_steady(W, 0, SKT)) {
+        DemodS S1;
+        S1.from(D1, true);                        // x3 = 1 (mod 4) at the loop's first position: a pick
+        S1.ieP &= C.dm; S1.qeP &= C.dm; S1.ieN &= C.dm; S1.qeN &= C.dm;
+        int pc[4];
+        need_enc(t + 4 + reach);
+#pragma unroll
+        for (int j = 0; j < 4; j++) pc[j] = cs_load<2>(C, t + j);
+#define NTSC_PIPE_TVF_STEP(J, PRE)                                                                \
+        {                                                                                         \
+            constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;             \
+            int Y, U, V;                                                                          \
+            S1.template push<pick3, neg3, true, false, true, false>(pc[J], C.hi, C.dm, Y, U, V);  \
+            PRE;                                                                                  \
+            o[(J) * 64] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};                       \
+            NTSC_STEP_SCHED_BARRIER();                                                            \
+        }
+        for (; t + 4 <= W; t += 4) {
+            need_enc(t + 8 + reach);
+            wait_ge(fl + F_CD_C, t + 4 - RING, cons_seen);
+            const lds_x4 o = cd + slot_of(t, SKT) * 64 + lane;
+            int nc[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) nc[j] = cs_load<2>(C, t + 4 + j);      // (past the row end: the buffer's bounds check, 0)
+            NTSC_PIPE_TVF_STEP(0, publish(fl + F_CD_P, t))
+            NTSC_PIPE_TVF_STEP(1, (void)0) NTSC_PIPE_TVF_STEP(2, (void)0) NTSC_PIPE_TVF_STEP(3, (void)0)
+#pragma unroll
+            for (int j = 0; j < 4; j++) pc[j] = nc[j];
+        }
+#undef NTSC_PIPE_TVF_STEP
+        publish(fl + F_CD_P, t);
+        S1.to(D1, true);
+    }
+    for (; t < total; t++) edge(t);
+}
+
 // ------------------------------------------------------------------------------------------------ OUT: TV back
 // the output stage of step<true> / edge_step<true>: composite_lowpass_tv (delay 1), YIQ -> RGB for the previous position,
 // 16 pixels of 64 rows staged in LDS and stored as 64-byte bursts (steady()'s cooperative flush)
-template <class RT>
+template <class RT, bool VHS = true>
 DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const unsigned long long *orow, uint32_t *drow,
                      lds_x4 cd, lds_flag fl)
 {
-    const int lane = R.lane, W = P.W, d = P.cdelay, SKT = 15 + d, total = W + SKT;
+    // (the positions of the decoder in front: k_decode_fast<true> -- SKT = 15 + d -- or, default preset, k_decode_fast<false>: 8)
+    const int lane = R.lane, W = P.W, d = VHS ? P.cdelay : 0, SKT = VHS ? 15 + d : 8, total = W + SKT;
     const RT a_tv = (RT)P.a_tv;
     Casc3<RT> oU, oV;
     oU.reset(0, a_tv); oV.reset(0, a_tv);
@@ -547,7 +616,7 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
         wait_ge(fl + F_CD_P, t + 1, in_seen);
         const u32x4 yuv = cd[slot_of(t, SKT) * 64 + lane];
         publish(fl + F_CD_C, t + 1);              // (behind the release: the slot has been read)
-        const int x3 = t - 14 - d;
+        const int x3 = t - (SKT - 1);
         if (x3 < 0 || x3 > W) return;
         const int Y = (int)yuv.x, U = (int)yuv.y, V = (int)yuv.z;
         RT fUd = 0, fVd = 0;
@@ -577,7 +646,7 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
     int t = 0;
     for (; t < SKT && t < total; t++) edge(t);
     const int t_end = W - (d > 7 ? d - 7 : 0);
-    if (has_steady(W, d)) {
+    if (has_steady(W, d, SKT)) {
         for (; t + 4 <= t_end; t += 4) {
             wait_ge(fl + F_CD_P, t + 4, in_seen);
             const lds_x4 ip = cd + slot_of(t, SKT) * 64 + lane;
@@ -670,6 +739,45 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
         o[0] = t_start; o[1] = wall_clock64();
         o[2] = g_waited[threadIdx.x >> 6] | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);      // HW_ID: SIMD, CU
     }
+}
+
+// The default preset (no VCR) as three roles: ENC | TVF | OUT (same workgroup shape, same hand-offs; the launcher's
+// preconditions are those of k_encode_fast / k_decode_fast<false>).
+template <class RT>
+__global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldDev *__restrict__ fields,
+                                                       const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
+                                                       int *__restrict__ comp, const int *__restrict__ hs_shift,
+                                                       const int *__restrict__ dropout)
+{
+    using namespace pipe;
+    __shared__ uint32_t ring_e[33 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t ltile[64 * 20];
+    __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
+    __shared__ unsigned long long orow[64];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_cd[RING * 64 * 4];
+    __shared__ uint32_t flags[F_COUNT];
+
+    const int role = (int)(threadIdx.x >> 6);
+    Row R;
+    R.lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * 63 + R.lane - 1;          // lane 0 = halo (row above)
+    R.rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = R.rc / P.Lslot;
+    R.k = R.rc - f * P.Lslot;
+    R.fd = &fields[f];
+    R.field = R.fd->field & 1u;
+    R.rowok = (int)(R.field + 2u * R.k) < P.H;
+    R.is_out = R.lane >= 1 && gidx < P.R && R.rowok;
+    R.y = R.rowok ? R.field + 2u * (unsigned)R.k : R.field;
+    uint32_t *drow = reinterpret_cast<uint32_t *>(R.fd->dst + (size_t)R.fd->dst_ls * R.y);
+    if (threadIdx.x < 64) orow[R.lane] = R.is_out ? (unsigned long long)drow : 0ull;
+    if (threadIdx.x < F_COUNT) { flags[threadIdx.x] = 0u; g_waited[threadIdx.x] = 0u; }
+    __syncthreads();
+    const lds_flag fl = (lds_flag)flags;
+    const lds_x4 cd = (lds_x4)ring_cd;
+    if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    else if (role == 1) tvfront_role<RT>(P, R, comp, hs_shift, dropout, cd, fl);
+    else output_role<RT, false>(P, R, ostage, orow, drow, cd, fl);
 }
 
 } // namespace ntscsim

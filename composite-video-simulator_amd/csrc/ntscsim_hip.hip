@@ -738,7 +738,18 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                            enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                            !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->split_vhs &&
                            D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k;
-    if (pipe_form) {
+    // ... and the default preset (no VCR) as three roles: encoder | TV front | TV back
+    const bool pipe_tv = c->latency_form && pipe_env && n <= NTSC_PIPE_MAX_FIELDS && c->mode != NTSCSIM_MODE_FLOAT &&
+                         enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
+                         !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->force_generic &&
+                         !D.vhs && !D.cnoise_k && !D.pnoise_k;
+    if (pipe_tv) {
+        note_kernel(c, fast ? "k_field_pipe_tv<float>" : "k_field_pipe_tv<double>");
+        if (fast) hipLaunchKernelGGL((k_field_pipe_tv<float>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
+                                     c->hs_shift.p, c->dropout.p);
+        else hipLaunchKernelGGL((k_field_pipe_tv<double>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
+                                c->hs_shift.p, c->dropout.p);
+    } else if (pipe_form) {
         // (developer switch: which wavefront of the workgroup takes which role, one hex digit per wavefront -- ntsc_pipe.hip)
         static const unsigned order = std::getenv("NTSCSIM_PIPE_ORDER") ? (unsigned)std::strtoul(std::getenv("NTSCSIM_PIPE_ORDER"), nullptr, 16)
                                                                         : NTSC_PIPE_ORDER;
@@ -850,7 +861,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_decode_fast<true, RT, true>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
-    if (pipe_form) {
+    if (pipe_form || pipe_tv) {
         // (encoder and decoder ran as one launch above)
     } else if (fp) {
         static const int fpv_env = std::getenv("NTSCSIM_FP_VARIANT") ? std::atoi(std::getenv("NTSCSIM_FP_VARIANT")) : -1;    // developer A/B switch

@@ -271,21 +271,30 @@ def test_host_frame_dropin_sequence():
     sim.close()
 
 
+_PIPE5, _PIPE3 = "k_field_pipe<double>", "k_field_pipe_tv<double>"
+
+
 @pytest.mark.parametrize("flags,w,h,piped", [
-    (["-vhs"], 720, 486, True), (["-vhs"], 720, 480, True), (["-vhs", "-vhs-speed", "lp"], 360, 243, True),
-    (["-vhs", "-vhs-speed", "ep"], 1920, 1080, True), (["-vhs"], 3840, 2160, True),
-    (["-vhs"], 16, 4, True), (["-vhs"], 20, 9, True), (["-vhs"], 36, 130, True), (["-vhs"], 100, 7, True),
-    (["-vhs", "-vhs-head-switching-point", "0.8"], 360, 244, True), (["-vhs", "-chroma-dropout", "30000"], 256, 100, True),
-    (["-vhs", "-vhs-chroma-vblend", "0"], 256, 100, True), (["-vhs", "-noise", "40", "-chroma-noise", "70"], 256, 100, True),
-    (["-vhs", "-tvstd", "pal"], 720, 576, False),           # PAL: head-switch displacement beyond W/10 -> the one-launch forms
-    (["-vhs", "-vhs-svideo", "1"], 256, 100, False), (["-vhs", "-comp-phase", "90"], 256, 100, False), ([], 256, 100, False),
-    (["-vhs"], 33, 17, True),                               # (tight host rows: the device frames have aligned rows of their own)
+    (["-vhs"], 720, 486, _PIPE5), (["-vhs"], 720, 480, _PIPE5), (["-vhs", "-vhs-speed", "lp"], 360, 243, _PIPE5),
+    (["-vhs", "-vhs-speed", "ep"], 1920, 1080, _PIPE5), (["-vhs"], 3840, 2160, _PIPE5),
+    (["-vhs"], 16, 4, _PIPE5), (["-vhs"], 20, 9, _PIPE5), (["-vhs"], 36, 130, _PIPE5), (["-vhs"], 100, 7, _PIPE5),
+    (["-vhs", "-vhs-head-switching-point", "0.8"], 360, 244, _PIPE5), (["-vhs", "-chroma-dropout", "30000"], 256, 100, _PIPE5),
+    (["-vhs", "-vhs-chroma-vblend", "0"], 256, 100, _PIPE5), (["-vhs", "-noise", "40", "-chroma-noise", "70"], 256, 100, _PIPE5),
+    (["-vhs"], 33, 17, _PIPE5),                             # (tight host rows: the device frames have aligned rows of their own)
+    # the default preset (no VCR): three roles
+    ([], 720, 486, _PIPE3), ([], 256, 100, _PIPE3), ([], 16, 4, _PIPE3), ([], 21, 9, _PIPE3), ([], 1920, 1080, _PIPE3),
+    (["-noise", "30", "-chroma-dropout", "20000"], 360, 243, _PIPE3), (["-tvstd", "pal"], 720, 576, _PIPE3),
+    (["-vhs-head-switching", "1"], 256, 100, _PIPE3),       # the head switch without the VCR: displaced loads in the TV front
+    (["-vhs", "-tvstd", "pal"], 720, 576, None),            # PAL: head-switch displacement beyond W/10 -> the one-launch forms
+    (["-vhs", "-vhs-svideo", "1"], 256, 100, None), (["-vhs", "-comp-phase", "90"], 256, 100, None),
+    (["-comp-catv"], 256, 100, None),
 ])
 def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, w, h, piped):
-    """ntscsim_field(): launches of up to 64 fields from the host-frame entry points run encoder, VCR half and TV half
-    as three wavefronts of one workgroup (k_field_pipe, csrc/ntsc_pipe.hip) for the -vhs preset family -- same step
-    functions as the other forms, samples handed over through the planes behind two LDS counters -- bit for bit the
-    oracle's, call after call (the rand() stream carried like the reference's); other switch sets keep their forms."""
+    """ntscsim_field(): launches of up to 64 fields from the host-frame entry points run the chain as ROLES of one
+    workgroup (csrc/ntsc_pipe.hip): five wavefronts for the -vhs preset family (k_field_pipe: encoder | VCR chroma front |
+    VCR chroma back | VCR luma + TV separator | TV output), three for the default preset (k_field_pipe_tv) -- the
+    arithmetic of the one-launch kernels cut where only integers cross, handed over through LDS rings -- bit for bit
+    the oracle's, call after call (the rand() stream carried like the reference's); other switch sets keep their forms."""
     p = L.make_params(flags, output_height=h)
     sim = ntscsim.FieldSimulator(params=p)
     o = L.OracleStream(p)
@@ -299,7 +308,7 @@ def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, 
         assert np.array_equal(got, exp), "call %d" % k
         assert sim.rng_pos == o.rng_pos
         kern = sim.last_kernels()
-        assert (("k_field_pipe<double>" in kern) == piped), kern
+        assert [x for x in kern if x.startswith("k_field_pipe")] == ([piped] if piped else []), kern
     sim.close()
 
 

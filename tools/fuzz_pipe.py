@@ -26,6 +26,7 @@ for seed in range(s0, s0 + n):
     if r.random() < 0.4: flags += ["-vhs-head-switching-point", "%.4f" % r.uniform(0.6, 1.0)]
     if r.random() < 0.3: flags += ["-vhs-head-switching-phase", "%.4f" % r.uniform(0.0, 0.2)]
     if r.random() < 0.2: flags += ["-vhs-head-switching", "0"]
+    if r.random() < 0.15: flags.remove("-vhs")           # the default preset family: three roles
     if r.random() < 0.3: flags += ["-chroma-dropout", str(r.choice([100, 3000, 30000, 90000]))]
     if r.random() < 0.2: flags += ["-vhs-chroma-vblend", "0"]
     if r.random() < 0.15: flags += ["-tvstd", "pal"]
