@@ -1008,11 +1008,19 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         if (rc != NTSCSIM_OK) return rc;
         HIPCHK(c, hipEventRecord(evs.e[0], st));
     }
-    HIPCHK(c, hipMemcpyAsync(c->fields.p, c->stage[si], (size_t)n * sizeof(FieldDev),
-                             hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
+    // Short launches of the host-frame entry points read their records where the host wrote them: the pinned staging
+    // buffer is the GPU's to address, a handful of 288-byte records is not worth a copy kernel and the dependency behind it
+    // (the staging slot is then busy until the kernels have run: the event follows them).  NTSCSIM_RECORDS_INPLACE=0: A/B.
+    static const bool inplace_env = !(std::getenv("NTSCSIM_RECORDS_INPLACE") && std::getenv("NTSCSIM_RECORDS_INPLACE")[0] == '0');
+    const bool inplace = inplace_env && c->latency_form && n <= NTSC_PIPE_MAX_FIELDS;
+    if (!inplace) {
+        HIPCHK(c, hipMemcpyAsync(c->fields.p, c->stage[si], (size_t)n * sizeof(FieldDev),
+                                 hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
+    }
     c->stage_used[si] = true;
-    rc = launch_records(c, D, c->fields.p, any_bob, st, prof ? &evs : nullptr);
+    rc = launch_records(c, D, inplace ? c->stage[si] : c->fields.p, any_bob, st, prof ? &evs : nullptr);
+    if (inplace) HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
     if (rc != NTSCSIM_OK) return rc;
     if (prof) c->ev_live.push_back(evs);
     c->rng_pos = rng_end;

@@ -1,5 +1,4 @@
 R=$PWD
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "pipelined or pinned_destination" 2>&1 | tail -5
-for a in malloc pinned; do $R/composite-video-simulator_amd/field_loop --mode sync --fields 600 --warmup 50 --alloc $a 2>&1 | cut -c1-90; done
-NTSCSIM_PIPE=0 $R/composite-video-simulator_amd/field_loop --mode sync --fields 600 --warmup 50 --alloc malloc 2>&1 | cut -c1-90
-timeout 600 python tools/fuzz_pipe.py 3000 1500 2>&1 | tail -14
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_submit.py -m gpu -x -q 2>&1 | tail -3
+for e in 1 0; do for a in malloc pinned; do echo -n "inplace=$e $a: "; NTSCSIM_RECORDS_INPLACE=$e $R/composite-video-simulator_amd/field_loop -vhs --mode sync --fields 1000 --warmup 50 --alloc $a 2>&1 | cut -c1-90; done; done
+for e in 1 0; do for d in 4 16; do echo -n "inplace=$e depth $d: "; NTSCSIM_RECORDS_INPLACE=$e $R/composite-video-simulator_amd/field_loop -vhs --mode submit --depth $d --lag $d --ring $((d*2+2)) --fields 3000 --warmup 200 --alloc pinned 2>&1 | cut -c1-90; done; done
