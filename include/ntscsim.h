@@ -208,6 +208,11 @@ void     ntscsim_set_rng_pos(ntscsim_ctx *ctx, uint64_t pos);
  *   dst_bgra/dst_linesize/width/height           = dstframe->data[0], ->linesize[0], ->width, ->height
  * Only rows y = field, field+2, ... of dst are written (alpha byte 0, :1914); other rows are
  * untouched.  Synchronous.  Uses and advances the ctx's rand() stream position.
+ * A dst frame the GPU can address -- memory declared with ntscsim_host_pin(), or pinned memory (ntscsim_host_frame_alloc /
+ * ntscsim_av_frame_get_buffer of ntscsim_avframe.h / hipHostMalloc; the runtime is asked at every call, nothing is
+ * registered or remembered) -- whose rows are 16-byte aligned is written by the kernels themselves; any other frame goes
+ * through a device copy and a download.  Same bytes either way.  (The call runs encoder and decoder as wavefront ROLES of
+ * one workgroup per 63 rows for the -vhs family and the default preset: DESIGN.md 1c; 4.8-5.8k calls per second at 720x486.)
  */
 int ntscsim_field(ntscsim_ctx *ctx,
                   const uint8_t *src_bgra, int src_linesize, int src_interlaced, int src_tff,
@@ -219,8 +224,8 @@ int ntscsim_field(ntscsim_ctx *ctx,
  *
  * The reference's loop calls composite_layer(ring[idx], in.rgb, in, (current&1)^1, current) at
  * ffmpeg_ntsc.cpp:2229, then line-doubles (:2233-2257), converts (:2266) and encodes the frame before it
- * composites the next field.  One synchronous field per call leaves the GPU 99 % idle (a field is four
- * wavefronts of work).  ntscsim_submit() takes the same arguments, returns at once with a ticket, and the
+ * composites the next field.  One synchronous field per call leaves the GPU 98 % idle (a field is four
+ * workgroups of work).  ntscsim_submit() takes the same arguments, returns at once with a ticket, and the
  * ctx coalesces submitted fields into launches of `depth` fields; ntscsim_wait(ticket) returns when that
  * field's rows are in the caller's dst frame.  The caller moves everything it does with the frame after
  * composite_layer() (bob, sws_scale, output_frame :2233-2280) behind a wait issued `depth` fields later

@@ -50,7 +50,9 @@ rows = [
     ("**tolerance mode `NTSCSIM_MODE_FLOAT`** (all-float pipeline, ≤ 1 LSB, never the default)",
      "**%s fields/s**, decoder `roofline.frac` %.3f (FAST32, the exact kernels with float states: %s)" % (k(flt["value"]), flt["roofline"]["frac"], k(f32["value"])),
      "`%sbench_float.json`, DESIGN.md §3b" % P),
-    ("drop-in on HOST frames, synchronous: one `ntscsim_field()` per `composite_layer()` call", "%s fields/s (%.0f × the reference on one core)" % (k(e.get("field_call", 0)), e.get("field_call", 0) / cb["value"]), "`side.field_call`"),
+    ("drop-in on HOST frames, synchronous: one `ntscsim_field()` per `composite_layer()` call (`host/field_loop.cpp --mode sync`; a pipeline of wavefront roles, DESIGN §1c): `posix_memalign` frames / pinned frames / from Python",
+     "%s / %s / %s fields/s (%.0f / %.0f × the reference on one core)" % (k(e.get("field_call_cpp", 0)), k(e.get("field_call_cpp_pinned", 0)), k(e.get("field_call", 0)),
+                                                                       e.get("field_call_cpp", 0) / cb["value"], e.get("field_call_cpp_pinned", 0) / cb["value"]), "`side.field_call`, `side.field_call_pinned`, `side.field_call_python`"),
     ("... asynchronous, `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`): frames from `ntscsim_host_frame_alloc()` / a pool declared with `ntscsim_host_pin()` / plain `posix_memalign` frames (staged)",
      "%s / %s / %s fields/s" % (k(e.get("field_submit", 0)), k(rate(fs, "depth32_declared_pool")), k(rate(fs, "depth32_malloc_frames_staged"))), "`end_to_end.field_submit*`"),
     ("the YUV422P tool's loop on host frames, depth 32 (`host/field_loop422.cpp`): pinned planes / plain heap planes, no `mallopt` / tight rows (704 wide) / synchronous",
