@@ -61,6 +61,14 @@ typedef __attribute__((address_space(3))) u32x2 *lds_x2;
 typedef __attribute__((address_space(3))) u32x4 *lds_x4;
 
 __shared__ unsigned g_waited[8];
+// A hand-off that never comes (a count two roles disagree about -- a bug, not a data condition) must not hang the GPU: a poll
+// gives up after NTSC_PIPE_SPIN_LIMIT rounds (~0.3 s, five orders of magnitude above any real wait), raises g_fault in LDS --
+// every later wait of the workgroup then falls through at once -- and the kernel reports it in a pinned word the host
+// checks behind the launch (NTSCSIM_E_HIP "k_field_pipe: hand-off timed out"; pixels of that launch are garbage).
+#ifndef NTSC_PIPE_SPIN_LIMIT
+#define NTSC_PIPE_SPIN_LIMIT (1 << 22)
+#endif
+__shared__ unsigned g_fault;
 DEV int flag_peek(lds_flag p) { return __builtin_amdgcn_readfirstlane((int)*p); }
 // wait until the count at p is at least v (wave-uniform); `cached`: the last value this wavefront saw
 DEV void wait_ge(lds_flag p, int v, int &cached)
@@ -70,7 +78,12 @@ DEV void wait_ge(lds_flag p, int v, int &cached)
     if (seen < v) {
         // (developer timing, NTSCSIM_PIPE_TIMING: 100 MHz ticks this wavefront spent polling, summed per wavefront behind the flags)
         const unsigned t0 = (unsigned)wall_clock64();
-        do { __builtin_amdgcn_s_sleep(1); seen = flag_peek(p); } while (seen < v);
+        int spins = 0;
+        do {
+            __builtin_amdgcn_s_sleep(1);
+            seen = flag_peek(p);
+            if (++spins > NTSC_PIPE_SPIN_LIMIT || (spins > 64 && *(lds_flag)&g_fault)) { *(lds_flag)&g_fault = 1u; seen = 0x3FFFFFFF; }
+        } while (seen < v);
         g_waited[threadIdx.x >> 6] += (unsigned)wall_clock64() - t0;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -695,7 +708,8 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
                                                     const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
                                                     const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                                                     const int *__restrict__ pn_noise, const int *__restrict__ dropout,
-                                                    int *__restrict__ tails, unsigned order, unsigned long long *dbg)
+                                                    int *__restrict__ tails, unsigned order, unsigned long long *dbg,
+                                                    unsigned *__restrict__ fault)
 {
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];                                   // the encoder's rand() ring
@@ -723,6 +737,7 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     uint32_t *drow = reinterpret_cast<uint32_t *>(R.fd->dst + (size_t)R.fd->dst_ls * R.y);
     if (threadIdx.x < 64) orow[R.lane] = R.is_out ? (unsigned long long)drow : 0ull;
     if (threadIdx.x < F_COUNT) { flags[threadIdx.x] = 0u; g_waited[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0) g_fault = 0u;
     __syncthreads();
     const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     const lds_flag fl = (lds_flag)flags;
@@ -734,6 +749,7 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     else if (role == 2) chroma_role<RT>(P, G, R, pn_noise, tails, ab, bc, fl);
     else if (role == 3) luma_role<RT>(P, R, comp, hs_shift, dropout, bc, cd, fl);
     else output_role<RT>(P, R, ostage, orow, drow, cd, fl);
+    if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;
     if (dbg && R.lane == 0) {      // NTSCSIM_PIPE_TIMING: start, end, ticks spent polling -- per workgroup and role
         unsigned long long *o = dbg + ((size_t)blockIdx.x * 5 + role) * 3;
         o[0] = t_start; o[1] = wall_clock64();
@@ -747,7 +763,7 @@ template <class RT>
 __global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldDev *__restrict__ fields,
                                                        const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                        int *__restrict__ comp, const int *__restrict__ hs_shift,
-                                                       const int *__restrict__ dropout)
+                                                       const int *__restrict__ dropout, unsigned *__restrict__ fault)
 {
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];
@@ -772,12 +788,14 @@ __global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldD
     uint32_t *drow = reinterpret_cast<uint32_t *>(R.fd->dst + (size_t)R.fd->dst_ls * R.y);
     if (threadIdx.x < 64) orow[R.lane] = R.is_out ? (unsigned long long)drow : 0ull;
     if (threadIdx.x < F_COUNT) { flags[threadIdx.x] = 0u; g_waited[threadIdx.x] = 0u; }
+    if (threadIdx.x == 0) g_fault = 0u;
     __syncthreads();
     const lds_flag fl = (lds_flag)flags;
     const lds_x4 cd = (lds_x4)ring_cd;
     if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
     else if (role == 1) tvfront_role<RT>(P, R, comp, hs_shift, dropout, cd, fl);
     else output_role<RT, false>(P, R, ostage, orow, drow, cd, fl);
+    if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;
 }
 
 } // namespace ntscsim

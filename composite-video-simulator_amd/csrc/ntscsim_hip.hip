@@ -181,6 +181,7 @@ struct ntscsim_ctx {
     // the host-frame entry points (ntscsim_field(), the submit engine's lanes) ask for the LATENCY form of short launches
     // (k_field_pipe, ntsc_pipe.hip); the device-pointer entry points keep the kernels their callers (and tests) name
     bool latency_form = false;
+    unsigned *pipe_fault = nullptr;  // pinned word the role kernels raise when a hand-off timed out (ntsc_pipe.hip); checked behind launches
 };
 static void declared_pins_destroy(ntscsim_ctx *c);
 static uint8_t *pinned_device_ptr(ntscsim_ctx *c, const void *p, size_t span);      // ntscsim_submit.hip
@@ -442,6 +443,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     if (c->s_dn) (void)hipStreamDestroy(c->s_dn);
     for (int i = 0; i < 2; i++) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+        if (i == 0 && c->pipe_fault) { (void)hipHostFree(c->pipe_fault); c->pipe_fault = nullptr; }
         if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]);
         if (c->stage422[i]) (void)hipHostFree(c->stage422[i]);
         if (c->stage422_ev[i]) (void)hipEventDestroy(c->stage422_ev[i]);
@@ -743,12 +745,16 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                          enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                          !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->force_generic &&
                          !D.vhs && !D.cnoise_k && !D.pnoise_k;
+    if ((pipe_tv || pipe_form) && !c->pipe_fault) {
+        HIPCHK(c, hipHostMalloc((void **)&c->pipe_fault, 64, hipHostMallocDefault));
+        *c->pipe_fault = 0u;
+    }
     if (pipe_tv) {
         note_kernel(c, fast ? "k_field_pipe_tv<float>" : "k_field_pipe_tv<double>");
         if (fast) hipLaunchKernelGGL((k_field_pipe_tv<float>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                     c->hs_shift.p, c->dropout.p);
+                                     c->hs_shift.p, c->dropout.p, c->pipe_fault);
         else hipLaunchKernelGGL((k_field_pipe_tv<double>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                c->hs_shift.p, c->dropout.p);
+                                c->hs_shift.p, c->dropout.p, c->pipe_fault);
     } else if (pipe_form) {
         // (developer switch: which wavefront of the workgroup takes which role, one hex digit per wavefront -- ntsc_pipe.hip)
         static const unsigned order = std::getenv("NTSCSIM_PIPE_ORDER") ? (unsigned)std::strtoul(std::getenv("NTSCSIM_PIPE_ORDER"), nullptr, 16)
@@ -759,9 +765,9 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         if (pipe_timing && !dbg) { HIPCHK(c, hipMalloc((void **)&dbg, (size_t)4096 * 15 * sizeof(unsigned long long))); }
         note_kernel(c, fast ? "k_field_pipe<float>" : "k_field_pipe<double>");
         if (fast) hipLaunchKernelGGL((k_field_pipe<float>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg);
+                                     c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg, c->pipe_fault);
         else hipLaunchKernelGGL((k_field_pipe<double>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg);
+                                c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg, c->pipe_fault);
         if (pipe_timing && dgrid.x <= 4096) {
             static int shown = 0;
             std::vector<unsigned long long> h((size_t)dgrid.x * 15);
@@ -983,6 +989,11 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
 
+    if (c->pipe_fault && *c->pipe_fault) {      // raised by an earlier launch of this ctx (ntsc_pipe.hip: a hand-off timed out)
+        c->err = "k_field_pipe: hand-off timed out in workgroup " + std::to_string(*c->pipe_fault - 1u);
+        *c->pipe_fault = 0u;
+        return NTSCSIM_E_HIP;
+    }
     // pinned staging for the records, double-buffered against the asynchronous upload
     const int si = c->stage_idx;
     c->stage_idx ^= 1;
@@ -1678,6 +1689,11 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
                                    c->fdst.p + pitch * field, pitch * 2, (size_t)W * 4, (size_t)L,
                                    hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->pipe_fault && *c->pipe_fault) {
+        c->err = "k_field_pipe: hand-off timed out in workgroup " + std::to_string(*c->pipe_fault - 1u);
+        *c->pipe_fault = 0u;
+        return NTSCSIM_E_HIP;
+    }
     return NTSCSIM_OK;
 }
 

@@ -312,6 +312,29 @@ def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, 
     sim.close()
 
 
+def test_a_hand_off_that_never_comes_is_an_error_not_a_hang():
+    """The role kernels poll each other's counts in LDS.  A wait that can never be satisfied (here: the developer switch
+    NTSCSIM_PIPE_ORDER leaves the chroma-back role out, so its ring is never drained) gives up after a bounded number of
+    rounds, the workgroup's other waits fall through, and the call returns NTSCSIM_E_HIP instead of hanging the GPU."""
+    import subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, _libs as L, ntscsim\n"
+        "p = L.make_params(['-vhs'], output_height=100)\n"
+        "sim = ntscsim.FieldSimulator(params=p)\n"
+        "s = L.noise_frame(256, 100, 1); d = np.zeros((100, 256, 4), np.uint8)\n"
+        "try:\n"
+        "    sim.field_host(d, s, 1, 0)\n"
+        "    print('NO ERROR')\n"
+        "except ntscsim.NtscsimError as e:\n"
+        "    print('ERROR', e)\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "composite-video-simulator_amd"))
+    env = dict(os.environ, NTSCSIM_PIPE_ORDER="24001")      # wavefront 2 runs a second encoder instead of the chroma-back role
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    out = r.stdout.decode()
+    assert "ERROR" in out and "hand-off timed out" in out, (out, r.stderr.decode()[-400:])
+
+
 @pytest.mark.parametrize("flags,w,h,off", [(["-vhs"], 720, 486, 0), (["-vhs"], 720, 486, 4), (["-vhs"], 100, 37, 0),
                                            ([], 256, 100, 0), (["-vhs", "-vhs-svideo", "1"], 360, 243, 16)])
 def test_synchronous_call_writes_pinned_destination_frames_in_place(flags, w, h, off):
