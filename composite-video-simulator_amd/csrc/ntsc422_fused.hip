@@ -1030,6 +1030,7 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
     uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
     uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
     uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    halo_redirect(Sc, lane, fy, fu, fv);
     // the two bytes the reference's Y/C separator reads past the row (:496), see ntsc422_kernels.hip
     int oob0 = 16, oob1 = 16;
     {
@@ -1221,6 +1222,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
     uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
     uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
     uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    halo_redirect(Sc, lane, fy, fu, fv);
     int oob0 = 16, oob1 = 16;                             // the separator's two bytes past the row (:496)
     {
         const size_t off = (size_t)fd.dst_ls[0] * y + (size_t)W, end = (size_t)fd.dst_ls[0] * (size_t)P.H;

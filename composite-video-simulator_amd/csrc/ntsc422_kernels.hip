@@ -42,7 +42,24 @@ enum : uint32_t {
 struct Scratch422 {
     uint32_t *Y, *T, *U, *V;       // words of 4 samples: [ceil(W/4)][S] x2, [ceil(W/8)][S] x2
     size_t S;                      // slots = waves * 64
+    uint8_t *halo;                 // [workgroup][3 planes][halo_pitch]: the INPUT of the row above every workgroup (k422_halo)
+    uint32_t halo_pitch;
 };
+
+// The halo lane (lane 0 of every workgroup but the first) re-computes the row ABOVE the workgroup's rows for the vertical
+// blend -- a row that the neighbouring workgroup rewrites IN PLACE.  A workgroup dispatched after its neighbour has got
+// that far (a launch of more workgroups than the chip holds at once, or one that shares the chip with other streams) would
+// read output where it needs input: tools/halo_race_probe.py (1,600 fields in one launch: the first row of workgroup 2,048
+// differed from the same fields in launches of 8).  So the rows in question are copied aside by k422_halo BEFORE the
+// process kernel starts, and the halo lane reads the copy (64-byte aligned, as long as the frame's linesize + the two
+// bytes the separator reads past the row :496).
+DEV void halo_redirect(const Scratch422 &Sc, int lane, uint8_t *&fy, uint8_t *&fu, uint8_t *&fv)
+{
+    if (lane == 0 && blockIdx.x > 0 && Sc.halo) {
+        uint8_t *b = Sc.halo + (size_t)blockIdx.x * 3u * Sc.halo_pitch;
+        fy = b; fu = b + Sc.halo_pitch; fv = b + 2u * (size_t)Sc.halo_pitch;
+    }
+}
 
 // scanline phase of the 8-bit tool (:449-460 / :508-522): phase 0 ignores the offset, PAL differs
 DEV unsigned scan_phase422(const DevParams &P, unsigned y, uint64_t fieldno)
@@ -55,6 +72,32 @@ DEV unsigned scan_phase422(const DevParams &P, unsigned y, uint64_t fieldno)
         return 0;
     }
     return (unsigned)((fieldno + y) & 3);
+}
+
+// ------------------------------------------------------------------------------ halo rows (see halo_redirect)
+// block b copies the input of the row above workgroup b + 1 (row rc = 63 (b + 1) - 1 of the batch's row space): linesize
+// bytes of each plane, + 2 of the luma plane (the separator's bytes past the row), never past the end of a plane
+__global__ __launch_bounds__(256) void k422_halo(DevParams P, const Field422Dev *__restrict__ fields, Scratch422 Sc)
+{
+    const int wg = (int)blockIdx.x + 1;
+    const int rc = wg * 63 - 1;
+    if (rc >= P.R) return;
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const Field422Dev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;       // (the process kernels' row of that lane)
+    uint8_t *out = Sc.halo + (size_t)wg * 3u * Sc.halo_pitch;
+    for (int pl = 0; pl < 3; pl++) {
+        const size_t ls = (size_t)fd.dst_ls[pl];
+        const uint8_t *src = fd.dst[pl] + ls * y;
+        size_t n = ls + (pl == 0 ? 2u : 0u);
+        const size_t left = ls * (size_t)(P.H - (int)y);               // bytes from the row's start to the end of the plane
+        if (n > left) n = left;
+        if (n > Sc.halo_pitch) n = Sc.halo_pitch;
+        uint8_t *dst = out + (size_t)pl * Sc.halo_pitch;
+        for (size_t t = threadIdx.x; t < n; t += blockDim.x) dst[t] = src[t];
+    }
 }
 
 // ------------------------------------------------------------------------------ render_field
@@ -463,6 +506,7 @@ __global__ __launch_bounds__(64) void k422_process(DevParams P, GeomDev G,
     uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
     uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
     uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    halo_redirect(Sc, lane, fy, fu, fv);
     // the two bytes the reference's Y/C separator reads past the row (:496): inside the luma plane
     // they are the caller's own bytes, outside it (last row, linesize < W + 2) the defined value 16
     int oob0 = 16, oob1 = 16;

@@ -124,6 +124,7 @@ struct ntscsim_ctx {
     DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, comp_ghost, comp_vcr, tails;
     DevBuf<Field422Dev> fields422;
     DevBuf<uint32_t> scratch422;
+    DevBuf<uint8_t> halo422;         // k422_halo: the input rows the halo lanes read (ntsc422_kernels.hip: halo_redirect)
     std::vector<Out422Dev> host_out422;
     DevBuf<Out422Dev> out422;
     std::vector<YuvDev> host_yuv;
@@ -429,7 +430,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geoms.clear();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scale.release(); c->scratch422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scale.release(); c->scratch422.release(); c->halo422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (auto &h : c->hslot) {
         h.dsrc.release(); h.ddst.release(); h.dyuv.release(); h.yrec.release(); h.draw.release(); h.srec.release();
@@ -1117,6 +1118,7 @@ struct Prep422 {
     double a_hp_i = 0, a_hp_q = 0, a_sh_c = 0;
     uint64_t rng_end = 0;          // in: position of the first descriptor with NTSCSIM_RNG_AUTO; out: after the last
     int n = 0, W = 0, H = 0;
+    int max_ls = 0;                // largest destination linesize of the batch (the pitch of the halo-row copies)
 };
 static int prepare422(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n, int W, int H, Prep422 &P,
                       FieldDev *host_fields, Field422Dev *host_fields422)
@@ -1171,6 +1173,7 @@ static int prepare422(ntscsim_ctx *c, const ntscsim_field422_desc *descs, int n,
             const int need = k == 0 ? W : W / 2;
             if (d.dst_linesize[k] < need) return NTSCSIM_E_SIZE;
             o.dst[k] = (uint8_t *)d.dst_dev[k]; o.dst_ls[k] = d.dst_linesize[k];
+            if (d.dst_linesize[k] > P.max_ls) P.max_ls = d.dst_linesize[k];
             if (d.src_dev[0]) {
                 if (!d.src_dev[k] || d.src_linesize[k] < need) return NTSCSIM_E_SIZE;
                 o.src[k] = (const uint8_t *)d.src_dev[k]; o.src_ls[k] = d.src_linesize[k];
@@ -1296,6 +1299,13 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     Sc.T = Sc.Y + S * Wq;
     Sc.U = Sc.T + S * Wq;
     Sc.V = Sc.U + S * W2q;
+    // the rows above the workgroups, copied aside before the in-place kernel starts (halo_redirect)
+    Sc.halo_pitch = (uint32_t)((((size_t)P.max_ls + 2 + 63) / 64) * 64);
+    Sc.halo = nullptr;
+    if (pgrid.x > 1) {
+        HIPCHK(c, c->halo422.ensure((size_t)pgrid.x * 3 * Sc.halo_pitch + 256));
+        Sc.halo = c->halo422.p;
+    }
 
     c->kernels.clear();
     if (any_render) note_kernel(c, "k422_render");
@@ -1306,6 +1316,8 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     if (any_flt)
         hipLaunchKernelGGL(k422_bkey, dim3((unsigned)((W2 + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
                            dim3(256), 0, st, D, fields422_dev, p.black_key_level_feedback);
+    if (Sc.halo)
+        hipLaunchKernelGGL(k422_halo, dim3(pgrid.x - 1), dim3(256), 0, st, D, fields422_dev, Sc);
     launch_setup(c, D, G, fields_dev, n, st);
     // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
     // empty, "decode" = the one kernel that does composite_video_process)

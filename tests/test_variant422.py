@@ -595,6 +595,41 @@ def test_hip_batch_of_fields_full_size():
 
 
 @pytest.mark.gpu
+def test_a_launch_of_more_workgroups_than_the_chip_holds_equals_small_launches():
+    """composite_video_process() runs IN PLACE, and a workgroup's halo lane re-computes the row above -- a row of its
+    neighbour's.  With more workgroups than the chip holds at once (here 2,667 for 2,048 slots) a workgroup starts after its
+    neighbour has rewritten that row; the halo lanes therefore read copies taken before the kernel starts (k422_halo).
+    700 fields in ONE launch == the same fields in launches of 50, byte for byte (before the fix: the first row of
+    workgroup 2,048 -- field 537, row 288 -- differed; tools/halo_race_probe.py)."""
+    import torch
+    w, h, n = 720, 480, 700
+    p = L.make_params_tocomp(["-vhs"])
+    lib = L.product()
+    srcs = [L.yuv_noise(w, h, 70 + j) for j in range(4)]
+    base = [[torch.from_numpy(np.ascontiguousarray(s.plane(i))).cuda() for i in range(3)] for s in srcs]
+
+    def run(batch):
+        devs = [[t.clone() for t in base[(k // 2) % 4]] for k in range(n)]
+        jobs, pos = [], 0
+        for k in range(n):
+            field = (k & 1) ^ 1
+            jobs.append({"dst": devs[k], "field": field, "fieldno": k, "rng_pos": pos})
+            pos += lib.ntscsim_rng_calls_per_field_422(C.byref(p), w, h, field)
+        sim = ntscsim.FieldSimulator(params=p)
+        for a in range(0, n, batch):
+            sim.fields422(jobs[a:a + batch], w, h)
+        sim.sync()
+        sim.close()
+        return devs
+
+    small = run(50)
+    for _ in range(2):
+        big = run(n)
+        bad = [(k, i) for k in range(n) for i in range(3) if not torch.equal(big[k][i], small[k][i])]
+        assert not bad, bad[:5]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("is420,il,tff,second,sh", [(0, 0, 0, 0, 50), (1, 0, 0, 0, 48), (0, 1, 1, 1, 48),
                                                      (1, 1, 0, 1, 64)])
 def test_hip_render_field_and_black_key(is420, il, tff, second, sh):
