@@ -11,9 +11,10 @@ import ntscsim
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
 w, h = 720, 480
-p = L.make_params_tocomp(["-vhs"])
+FLAGS = [["-vhs"], [], ["-vhs", "-vhs-svideo", "1"], ["-vhs", "-vhs-speed", "ep", "-tvstd", "pal"], ["-vhs", "-yc-recomb", "1"]]
 lib = L.product()
 srcs = [L.yuv_noise(w, h, 70 + j) for j in range(4)]
+p = None
 base = [[torch.from_numpy(np.ascontiguousarray(s.plane(i))).cuda() for i in range(3)] for s in srcs]
 def run(batch):
     devs = [[t.clone() for t in base[(k // 2) % 4]] for k in range(n)]
@@ -29,8 +30,11 @@ def run(batch):
     kern = sim.last_kernels()
     sim.close()
     return devs, kern
-small, _ = run(8)
-for trial in range(3):
+for flags in FLAGS:
+  p = L.make_params_tocomp(flags)
+  print("==", " ".join(flags) or "default")
+  small, _ = run(8)
+  for trial in range(2):
     big, kern = run(n)
     bad = 0
     first = None
@@ -41,4 +45,5 @@ for trial in range(3):
                 if first is None:
                     d = (big[k][i] != small[k][i]).nonzero()
                     first = (k, i, d[0].tolist(), int(d.shape[0]))
+    del big
     print("trial %d: %d fields in ONE batch (%s) vs batches of 8: %d planes differ%s" % (trial, n, ",".join(kern), bad, "" if first is None else "  first: field %d plane %d at %s (%d bytes)" % first))
