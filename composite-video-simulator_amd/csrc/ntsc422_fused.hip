@@ -345,10 +345,13 @@ struct ChromaLpFull {
 // (:470) and the modulation sign (:463-466: bit 1 of xi + x) as a per-lane mask chosen by the unrolled
 // position -- the same results as the general body, which still runs the first and the last block(s).
 // ALROWS (the streamed forms): rows aligned to 16 / 8 bytes, linesizes lsy / lsc known: branch-free loads.
-template <bool NTSC, bool ALIGNED, bool FAST = false, bool ALROWS = false>
+struct NoPub422 { DEV void operator()(int) const {} };
+// PUB: called at the end of every group of 32 chroma inputs with the group's first index g0 (k422_pipe: the sweep as a
+// ROLE that publishes how far the composite bytes have got)
+template <bool NTSC, bool ALIGNED, bool FAST = false, bool ALROWS = false, class PUB = NoPub422>
 DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const uint8_t *fu, const uint8_t *fv,
                  int W, unsigned xi, LumaPost422 &post, double a_hp_i, double a_hp_q, int lsy = 0, int lsu = 0, int lsv = 0,
-                 uint32_t *tile = nullptr)
+                 uint32_t *tile = nullptr, PUB pub = PUB())
 {
     constexpr int D = NTSC ? 4 : 2, DU = 2, DV = NTSC ? 4 : 2;
     const int W2 = W / 2;
@@ -509,6 +512,7 @@ DEV void sweep_a(const DevParams &P, const Row422 &R, const uint8_t *fy, const u
           gu[b][0] = nu[b][0]; gu[b][1] = nu[b][1]; gv[b][0] = nv[b][0]; gv[b][1] = nv[b][1];
         }
       }
+      pub(g0);
     }
     oy.finish(W);
 }
@@ -1170,6 +1174,175 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
         demod<true>(P, R, W, xi, P.m_amp, oob0, oob1, nocp, nolv, sink);
     }
     F422_STAMP(4);
+}
+
+// ---------------------------------------------------------------------------------- the latency form (round 6)
+// k422_fused's streamed form as three ROLES of one workgroup (the BGRA tool's k_field_pipe, ntsc_pipe.hip: a lone wavefront
+// gets one instruction through per ~5 cycles, so a launch of a few fields is bound by the length of one row's instruction
+// stream): wavefront 0 runs sweep A, wavefront 1 the head-switch gather (only in workgroups that hold a switched row),
+// wavefront 2 the streamed B pass -- the SAME code as the one-wave form (sweep_a, StreamB), so the same bytes; what is new is
+// that B starts while A is still writing.  Hand-offs: the composite bytes travel through the scratch planes as before
+// (plane Y: A -> G, B; plane T: G -> B), behind byte counts in LDS: A publishes a group of 64 bytes once the group BEHIND
+// it has been stored (its loads of the next group, issued before those stores, have returned: vmcnt is one in-order counter),
+// G one step of 16 bytes behind its stores; the readers use streaming loads (always from the L2) and wait for the highest
+// byte they are about to request.  A leads B by construction, and B's frame bursts only cover bytes A has consumed long
+// before (A reads the frame a group ahead of the bytes it emits), so running in place stays safe.
+// Launcher: the streamed forms' preconditions, head-switch displacement within W/10, launches of the host-frame engine.
+template <bool SPEC, int DD = 4, bool SVID = false>
+__global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const Field422Dev *__restrict__ fields, Scratch422 Sc,
+                                                 const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
+                                                 const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
+                                                 const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
+                                                 const int *__restrict__ pn_noise, const int *__restrict__ dropout,
+                                                 double a_hp_i, double a_hp_q, double a_sh_c, double sharpen_c,
+                                                 unsigned *__restrict__ fault)
+{
+    using namespace fused422;
+    using pipe::lds_flag;
+    __shared__ uint32_t ring_a[31 * 64];                                   // A: luma noise
+    __shared__ uint32_t ring_b[31 * 64];                                   // B: chroma noise
+    __shared__ __attribute__((aligned(16))) uint32_t tile_a[64 * 44];      // A: cooperative frame-row loads (CoopRows)
+    __shared__ __attribute__((aligned(16))) uint32_t fstage[64 * 16 * 3];  // B: frame bursts
+    __shared__ uint32_t flags[4];                                          // [0] bytes of plane Y, [1] bytes of plane T
+    const int role = (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const Field422Dev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok && !(fd.flags & F422_NOCOMP);
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const unsigned xi = scan_phase422(P, y, fd.fieldno);
+    const int W = P.W;
+    const size_t slot = (size_t)blockIdx.x * 64 + lane;
+    Row422 R;
+    R.Y.p = Sc.Y + slot; R.T.p = Sc.T + slot; R.U.p = Sc.U + slot; R.V.p = Sc.V + slot;
+    R.Y.S = R.T.S = R.U.S = R.V.S = Sc.S;
+    uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
+    uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
+    uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    halo_redirect(Sc, lane, fy, fu, fv);
+    int oob0 = 16, oob1 = 16;
+    {
+        const size_t off = (size_t)fd.dst_ls[0] * y + (size_t)W, end = (size_t)fd.dst_ls[0] * (size_t)P.H;
+        if (off < end) oob0 = fy[W];
+        if (off + 1 < end) oob1 = fy[W + 1];
+    }
+    const int hs = P.hs ? hs_shift[rc] : 0;
+    const bool gather = P.hs && __any(hs != 0);          // (the same 64 rows in every role: the same answer)
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    if (threadIdx.x < 8) pipe::g_waited[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) pipe::g_fault = 0u;
+    __syncthreads();
+    const lds_flag fl = (lds_flag)flags;
+    typedef __attribute__((address_space(1))) const uint32_t *g_cw;
+
+    if (role == 0) {
+        // ---- A: frame row -> composite bytes (plane Y)
+        constexpr int D = 4;                               // (NTSC; PAL: 2 -- the count below only has to be a lower bound)
+        LumaPost422 lp_;
+        lp_.pre_on = SPEC ? false : P.pre_on != 0; lp_.noise_on = SPEC ? true : P.noise_k != 0;
+        lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring_a; lp_.lane = lane;
+        if (lp_.noise_on) { lp_.rng.init(ring_a, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
+        // group g0 emits the bytes of chroma samples g0 - D .. g0 + 31 - D; when its hook runs, the group before it is in
+        // memory (at most this group's 16 word stores are still in flight)
+        auto pub = [&](int g0) {
+            const int done = 2 * (g0 - D);
+            if (done > 0) { NTSC_PIPE_VMCNT(16); pipe::publish(fl, done < W ? done : W); }
+        };
+        if (SPEC || P.ntsc) sweep_a<true, SPEC, SPEC, true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q,
+                                                            fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2], tile_a, pub);
+        else sweep_a<false, SPEC, false, true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q, fd.dst_ls[0], fd.dst_ls[1],
+                                               fd.dst_ls[2], tile_a, pub);
+        NTSC_PIPE_VMCNT(0);
+        pipe::publish(fl, W);
+    } else if (role == 1) {
+        // ---- G: head switching :669-732 (displaced copy Y -> T, fill value 16), 16 samples per step
+        if (gather) {
+            const int tw = W + W / 10, reach = W / 10 + 2;
+            int seen = 0;
+            Packer422 o; o.begin(R.T);
+            constexpr int HB = 16;
+            for (int x0 = 0; x0 < W; x0 += HB) {
+                { const int c = x0 + HB + reach; pipe::wait_ge(fl, c < W ? c : W, seen); }
+                int v[HB], ix[HB];
+#pragma unroll
+                for (int j = 0; j < HB; j++) {
+                    int idx = x0 + j + hs;
+                    idx += (idx >> 31) & tw;
+                    idx -= (idx >= tw) ? tw : 0;
+                    ix[j] = idx;
+                    const int xr = idx < W ? idx : W - 1;
+                    const uint32_t wv = __builtin_nontemporal_load((g_cw)(R.Y.p + (size_t)(xr >> 2) * R.Y.S));
+                    v[j] = (int)((wv >> (8 * (xr & 3))) & 0xFFu);
+                }
+#pragma unroll
+                for (int j = 0; j < HB; j++)
+                    if (x0 + j < W) o.put(x0 + j, ix[j] < W ? v[j] : 16);
+                // (this step's 4 word stores may still be in flight; everything before them has landed)
+                NTSC_PIPE_VMCNT(4);
+                pipe::publish(fl + 1, x0);
+            }
+            o.finish(W);
+            NTSC_PIPE_VMCNT(0);
+            pipe::publish(fl + 1, W);
+        }
+    } else {
+        // ---- B: B1 + B2 + B3 in one streamed pass over plane Y (T where the workgroup gathered)
+        const Plane422 IN = gather ? R.T : R.Y;
+        const lds_flag fin = gather ? fl + 1 : fl;
+        int seen = 0;
+        StreamB<DD> B;
+        B.begin(P, W, xi, k, oob0, oob1, a_sh_c, sharpen_c);
+        B.cp.noise_on = SPEC ? true : P.cnoise_k != 0; B.cp.phase_on = SPEC ? true : P.pnoise_k != 0;
+        B.cp.nU = B.cp.nV = 0; B.cp.cosv = 1; B.cp.sinv = 0; B.cp.ring = ring_b; B.cp.lane = lane;
+        if (B.cp.noise_on) { B.cp.rng.init(ring_b, rs_chroma + rc, P.Rpad, lane); B.cp.nU = n0_u[rc]; B.cp.nV = n0_v[rc]; }
+        if (B.cp.phase_on) {
+            int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+            n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+            B.cp.cosv = G.ptab[2 * n]; B.cp.sinv = G.ptab[2 * n + 1];
+        }
+        B.sink.begin(P, true, SPEC ? 2 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        B.sink.wy.st = fstage + lane * 16; B.sink.wu.st = fstage + (64 + lane) * 16; B.sink.wv.st = fstage + (128 + lane) * 16;
+        if constexpr (SPEC) B.begin_fast(P.loss && dropout[rc] != 0);
+        const int W2 = W / 2, NIT = W2 + DD + 2;
+        auto need = [&](int bytes) { pipe::wait_ge(fin, bytes < W ? bytes : W, seen); };
+        auto ldw = [&](int q) -> uint32_t { return __builtin_nontemporal_load((g_cw)(IN.p + (size_t)q * IN.S)); };
+        auto in_byte = [&](int x) -> int {
+            if (x >= W) return x == W ? oob0 : (x == W + 1 ? oob1 : 0);
+            need(x + 1);
+            return (int)((ldw(x >> 2) >> (8 * (x & 3))) & 0xFFu);
+        };
+        int i = 0;
+        for (; i < 8 && i < NIT; i++) B.template iter<true, SVID>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        if (i == 8 && i + 3 <= W2 - 2 - DD) {
+            need(4 * ((i >> 1) + 2));
+            uint32_t w0 = ldw(i >> 1), w1 = ldw((i >> 1) + 1);
+            for (; i + 3 <= W2 - 2 - DD; i += 4) {
+                // the next two words are requested before this pair is worked on (clamped at the row end)
+                const int qn = (i >> 1) + 2, qmax = (W - 1) >> 2;
+                need(4 * (qn + 2));
+                const uint32_t n0 = ldw(qn <= qmax ? qn : qmax), n1 = ldw(qn + 1 <= qmax ? qn + 1 : qmax);
+                if constexpr (SPEC) {
+                    B.template iter_fast<0>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                    B.template iter_fast<1>(P, i, byte_of(w0, 2), byte_of(w0, 3));
+                    B.template iter_fast<2>(P, i, byte_of(w1, 0), byte_of(w1, 1));
+                    B.template iter_fast<3>(P, i, byte_of(w1, 2), byte_of(w1, 3));
+                } else {
+                    B.template iter<false, SVID>(P, i, byte_of(w0, 0), byte_of(w0, 1));
+                    B.template iter<false, SVID>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
+                    B.template iter<false, SVID>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
+                    B.template iter<false, SVID>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
+                }
+                w0 = n0; w1 = n1;
+            }
+        }
+        for (; i < NIT; i++) B.template iter<true, SVID>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        B.sink.finish(W);
+    }
+    if (lane == 0 && *(lds_flag)&pipe::g_fault) *fault = 1u + blockIdx.x;
 }
 
 // ---------------------------------------------------------------------------------- the short form

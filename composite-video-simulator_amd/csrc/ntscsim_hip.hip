@@ -1348,6 +1348,14 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
                        D.src_al16 && D.dst_al16;
     // the VCR with S-Video out: the streamed pass without its re-modulation (aligned rows), else the twelve sweeps
     const bool stream_sv = fused_sv && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 && D.cdelay >= 4 && D.cdelay <= 6;
+    static const bool pipe422_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
+    const bool pipe422 = c->latency_form && pipe422_env && n <= NTSC_PIPE_MAX_FIELDS && head_switch_is_small(D, W) &&
+                         ((fused && stream) || stream_gen || stream_sv);
+    if (pipe422)
+        note_kernel(c, (fused && stream) ? "k422_pipe<true,4>"
+                       : stream_sv ? (D.cdelay == 4 ? "k422_pipe_sv<4>" : D.cdelay == 5 ? "k422_pipe_sv<5>" : "k422_pipe_sv<6>")
+                                   : (D.cdelay == 4 ? "k422_pipe<false,4>" : D.cdelay == 5 ? "k422_pipe<false,5>" : "k422_pipe<false,6>"));
+    else
     note_kernel(c, direct ? (fasta ? "k422_direct_fast" : "k422_direct")
                           : stream_sv ? (D.cdelay == 4 ? "k422_fused_sv<4>" : D.cdelay == 5 ? "k422_fused_sv<5>" : "k422_fused_sv<6>")
                           : !fused ? "k422_process"
@@ -1358,6 +1366,23 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     hipLaunchKernelGGL((k422_fused<__VA_ARGS__>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma)
+    // the latency form of the streamed kernels: sweep A | head-switch gather | streamed B pass as three wavefronts of one
+    // workgroup (k422_pipe) -- short launches of the host-frame engine (ntscsim_field422 / the lanes of ntscsim_submit422)
+#define NTSC_LAUNCH_422_PIPE(...)                                                                             \
+    hipLaunchKernelGGL((k422_pipe<__VA_ARGS__>), pgrid, dim3(192), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
+                       c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
+                       c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma, c->pipe_fault)
+    if (pipe422) {
+        if (!c->pipe_fault) { HIPCHK(c, hipHostMalloc((void **)&c->pipe_fault, 64, hipHostMallocDefault)); *c->pipe_fault = 0u; }
+        if (fused && stream) NTSC_LAUNCH_422_PIPE(true, 4);
+        else if (stream_sv && D.cdelay == 4) NTSC_LAUNCH_422_PIPE(false, 4, true);
+        else if (stream_sv && D.cdelay == 5) NTSC_LAUNCH_422_PIPE(false, 5, true);
+        else if (stream_sv) NTSC_LAUNCH_422_PIPE(false, 6, true);
+        else if (D.cdelay == 4) NTSC_LAUNCH_422_PIPE(false, 4);
+        else if (D.cdelay == 5) NTSC_LAUNCH_422_PIPE(false, 5);
+        else NTSC_LAUNCH_422_PIPE(false, 6);
+    } else
+#undef NTSC_LAUNCH_422_PIPE
     if (direct) {
         if (fasta)
             hipLaunchKernelGGL(k422_short<true>, pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p,
@@ -1405,6 +1430,11 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     if (n < 0) return NTSCSIM_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->pipe_fault && *c->pipe_fault) {      // raised by an earlier launch of this ctx (k422_pipe: a hand-off timed out)
+        c->err = "k422_pipe: hand-off timed out in workgroup " + std::to_string(*c->pipe_fault - 1u);
+        *c->pipe_fault = 0u;
+        return NTSCSIM_E_HIP;
+    }
     // pinned staging for the records, double-buffered against the asynchronous upload
     const int si = c->stage422_idx;
     c->stage422_idx ^= 1;

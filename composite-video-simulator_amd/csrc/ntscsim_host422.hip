@@ -575,13 +575,17 @@ static int h422_launch(ntscsim_ctx *c)
         if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, st, e->prec);
     }
     const uint64_t keep_pos = c->rng_pos;           // the stream advanced at submit; descriptors carry positions
+    c->latency_form = true;             // (short launches take the role form of the streamed kernels: k422_pipe)
     int rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
+    c->latency_form = false;
     c->rng_pos = keep_pos;
     if (rc != NTSCSIM_OK) return finish(rc);
     if (two_pass) {
         hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, st, e->prec + s0);
         if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, st, e->prec);
+        c->latency_form = true;
         rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
+        c->latency_form = false;
         c->rng_pos = keep_pos;
         if (rc != NTSCSIM_OK) return finish(rc);
         e->stats_two_pass++;
