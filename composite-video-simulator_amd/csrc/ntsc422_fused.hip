@@ -800,13 +800,25 @@ struct StreamB {
     // SV (S-Video out of the VCR, -vhs-svideo 1, :926: no re-modulation and no second separation): the VCR's luma and
     // chroma of sample m2 go to the frame sink as they are -- luma 2 m2, 2 m2 + 1 out of the delay line, chroma m2.
     template <bool EDGE, bool SV = false>
-    DEV void iter(const DevParams &P, int i, int c0, int c1)
+    DEV void iter(const DevParams &P, int i, int c0, int c1) { uint32_t none = 0; iter_part<EDGE, SV, 0>(P, i, c0, c1, none, 0u, 0u); }
+    // PART (k422_pipe: the pass as two ROLES): 0 the whole iteration; 1 its FRONT -- separation 1, chroma / phase noise, the
+    // VCR luma chain -- whose products leave as one packed word (luma 2i-2, luma 2i-1, U1, V1: four bytes, zero where the
+    // guarded form has nothing); 2 its BACK -- VCR chroma low-pass, blend, sharpen, re-modulation, separation 2, the sink --
+    // fed with this iteration's word (chroma) and the word of iteration i - D (the luma the delay line would hand over).
+    template <bool EDGE, bool SV, int PART>
+    DEV void iter_part(const DevParams &P, int i, int c0, int c1, uint32_t &xf_out, uint32_t xf_now, uint32_t xf_del)
     {
         // ---- main stream: separation 1 at x = 2i, 2i+1
         int yb_[2] = {0, 0};
         bool yok[2] = {false, false};
         int U1 = 0, V1 = 0;
         bool pair = false;
+        if constexpr (PART == 2) {
+            U1 = (int)((xf_now >> 16) & 0xFFu); V1 = (int)(xf_now >> 24);
+            pair = !EDGE || (i >= 1 && 2 * i + 1 <= W + 1);      // (what the loop below would have found)
+        }
+        const int yd0 = PART == 2 ? (int)(xf_del & 0xFFu) : yq[0], yd1 = PART == 2 ? (int)((xf_del >> 8) & 0xFFu) : yq[1];
+        if constexpr (PART != 2) {
 #pragma unroll
         for (int sx = 0; sx < 2; sx++) {
             const int x = 2 * i + sx;
@@ -830,6 +842,8 @@ struct StreamB {
                 pair = true;
             }
         }
+        }
+        if constexpr (PART != 1) {
         // ---- VCR chroma: input m1 = i - 1, output m2 = i - 1 - D
         int fU = 0, fV = 0;
         if (!EDGE || pair) {
@@ -857,8 +871,8 @@ struct StreamB {
             ts = sV.push(s, a_sh_c);
             v = clampu8((int)(s + ((s - ts) * sharpen_c)));
             if constexpr (SV) {
-                sink.luma(2 * m2, yq[0]);
-                sink.luma(2 * m2 + 1, yq[1]);
+                sink.luma(2 * m2, yd0);
+                sink.luma(2 * m2 + 1, yd1);
                 if (EDGE) sink.chroma(m2, u, v);
                 else {
                     if (sink.drop) { u = 128; v = 128; }
@@ -872,20 +886,29 @@ struct StreamB {
                 const unsigned ph = (xi + (unsigned)lx) & 3u;
                 int chroma = ((ph & 1u) ? v - 128 : u - 128) * P.amp;
                 if (ph & 2u) chroma = -chroma;
-                sep2<EDGE>(P, lx, clampu8(yq[sx] + chroma / 50));
+                sep2<EDGE>(P, lx, clampu8((sx ? yd1 : yd0) + chroma / 50));
             }
             }
         } else if (EDGE && !SV) {
             // lanes must stay in step for the wave shift of the blend: nothing to shift here (m2 is wave-uniform)
             if (m2 == W2) { sep2<true>(P, W, oob0); sep2<true>(P, W + 1, oob1); }   // Y[x+2] past the row :496
         }
+        }
         // ---- VCR luma of positions 2i-2, 2i-1 enters the delay line (a dummy while outside the row)
+        if constexpr (PART != 2) {
+            int y1_[2];
 #pragma unroll
         for (int sx = 0; sx < 2; sx++) {
             const int y1 = (!EDGE || yok[sx]) ? lv.run(yb_[sx]) : 0;
+            y1_[sx] = y1;
+            if constexpr (PART == 0) {
 #pragma unroll
             for (int q = 0; q < 2 * D - 1; q++) yq[q] = yq[q + 1];
             yq[2 * D - 1] = y1;
+            }
+        }
+            if constexpr (PART == 1)
+                xf_out = (uint32_t)y1_[0] | ((uint32_t)y1_[1] << 8) | ((uint32_t)U1 << 16) | ((uint32_t)V1 << 24);
         }
     }
 
@@ -929,13 +952,19 @@ struct StreamB {
         }
     }
     template <int J>
-    DEV void iter_fast(const DevParams &P, int ib, int c0, int c1)
+    DEV void iter_fast(const DevParams &P, int ib, int c0, int c1) { uint32_t none = 0; iter_fast_part<J, 0>(P, ib, c0, c1, none, 0u, 0u); }
+    template <int J, int PART>                   // PART: as iter_part
+    DEV void iter_fast_part(const DevParams &P, int ib, int c0, int c1, uint32_t &xf_out, uint32_t xf_now, uint32_t xf_del)
     {
         static_assert(D == 4, "the preset form: SP tape speed");
         const int i = ib + J;                     // ib is a multiple of 4
         // ---- main stream: separation 1 at x = 2i, 2i+1 (xo = 2i-2 even, 2i-1 odd; xo & 2 = (2J - 2) & 2)
         constexpr int XO2A = (2 * J + 2) & 2;
-        int yb_[2];
+        int yb_[2] = {0, 0};
+        int U1 = 0, V1 = 0;
+        if constexpr (PART == 2) { U1 = (int)((xf_now >> 16) & 0xFFu); V1 = (int)(xf_now >> 24); }
+        const int yd0 = PART == 2 ? (int)(xf_del & 0xFFu) : yq[0], yd1 = PART == 2 ? (int)((xf_del >> 8) & 0xFFu) : yq[1];
+        if constexpr (PART != 2) {
         {
             const unsigned c = (unsigned)c0;
             asum -= a0; a0 = a1; a1 = a2; a2 = a3; a3 = c; asum += c;
@@ -943,7 +972,6 @@ struct StreamB {
             yb_[0] = (int)yb;
             ev1 = clampu8((int)c + 128 - (int)yb) ^ (XO2A ? fm1 : fm0);
         }
-        int U1, V1;
         {
             const unsigned c = (unsigned)c1;
             asum -= a0; a0 = a1; a1 = a2; a2 = a3; a3 = c; asum += c;
@@ -953,6 +981,8 @@ struct StreamB {
             U1 = 255 - ev1; V1 = 255 - ch;
             chroma_post422(P, cp, U1, V1);
         }
+        }
+        if constexpr (PART != 1) {
         // ---- VCR chroma: input m1 = i - 1, output m2 = i - 5 (strictly inside the row: filtered value)
         int u = clampu8((int)lU.push((double)U1, a_vc));
         int v = clampu8((int)lV.push((double)V1, a_vc));
@@ -969,15 +999,24 @@ struct StreamB {
         constexpr int LX2 = (2 * J + 2) & 2, XO2B = (2 * J) & 2;
         const int sm = LX2 ? sm1 : sm0;
         const int lx = 2 * i - 10;
-        sep2_fast<XO2B>(lx - 2, false, clampu8(yq[0] + (((u - 128) ^ sm) - sm)));
-        sep2_fast<XO2B>(lx - 1, true, clampu8(yq[1] + (((v - 128) ^ sm) - sm)));
+        sep2_fast<XO2B>(lx - 2, false, clampu8(yd0 + (((u - 128) ^ sm) - sm)));
+        sep2_fast<XO2B>(lx - 1, true, clampu8(yd1 + (((v - 128) ^ sm) - sm)));
+        }
         // ---- VCR luma of positions 2i-2, 2i-1 enters the delay line
+        if constexpr (PART != 2) {
+            int y1_[2];
 #pragma unroll
         for (int sx = 0; sx < 2; sx++) {
             const int y1 = lv.run(yb_[sx]);
+            y1_[sx] = y1;
+            if constexpr (PART == 0) {
 #pragma unroll
             for (int q = 0; q < 7; q++) yq[q] = yq[q + 1];
             yq[7] = y1;
+            }
+        }
+            if constexpr (PART == 1)
+                xf_out = (uint32_t)y1_[0] | ((uint32_t)y1_[1] << 8) | ((uint32_t)U1 << 16) | ((uint32_t)V1 << 24);
         }
     }
 };
@@ -1177,19 +1216,23 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
 }
 
 // ---------------------------------------------------------------------------------- the latency form (round 6)
-// k422_fused's streamed form as three ROLES of one workgroup (the BGRA tool's k_field_pipe, ntsc_pipe.hip: a lone wavefront
+// k422_fused's streamed form as four ROLES of one workgroup (the BGRA tool's k_field_pipe, ntsc_pipe.hip: a lone wavefront
 // gets one instruction through per ~5 cycles, so a launch of a few fields is bound by the length of one row's instruction
-// stream): wavefront 0 runs sweep A, wavefront 1 the head-switch gather (only in workgroups that hold a switched row),
-// wavefront 2 the streamed B pass -- the SAME code as the one-wave form (sweep_a, StreamB), so the same bytes; what is new is
-// that B starts while A is still writing.  Hand-offs: the composite bytes travel through the scratch planes as before
-// (plane Y: A -> G, B; plane T: G -> B), behind byte counts in LDS: A publishes a group of 64 bytes once the group BEHIND
-// it has been stored (its loads of the next group, issued before those stores, have returned: vmcnt is one in-order counter),
-// G one step of 16 bytes behind its stores; the readers use streaming loads (always from the L2) and wait for the highest
-// byte they are about to request.  A leads B by construction, and B's frame bursts only cover bytes A has consumed long
-// before (A reads the frame a group ahead of the bytes it emits), so running in place stays safe.
+// stream): wavefront 0 runs sweep A; wavefront 1 the head-switch gather (only in workgroups that hold a switched row);
+// wavefront 2 the FRONT of the streamed B pass -- separation 1, chroma and phase noise, the VCR luma chain --; wavefront 3
+// its BACK -- VCR chroma low-pass, blend, sharpen, re-modulation, second separation, dropout, output low-pass, the frame.
+// The SAME code as the one-wave form (sweep_a; StreamB's iterations cut where only bytes cross: iter_part / iter_fast_part),
+// so the same bytes; what is new is that the stages of a row run side by side.  Hand-offs: the composite bytes travel
+// through the scratch planes as before (plane Y: A -> G, F; plane T: G -> F), behind byte counts in LDS: A publishes a group
+// of 64 bytes once the group BEHIND it has been stored (its loads of the next group, issued before those stores, have
+// returned: vmcnt is one in-order counter), G one step of 16 bytes behind its stores; the readers use streaming loads
+// (always from the L2) and wait for the highest byte they are about to request.  F -> K: one packed word per lane and
+// iteration (luma 2i-2, luma 2i-1, U1, V1) in a ring of 32 iterations in LDS; K reads word i for the chroma and word i - D
+// for the luma (the delay line of the one-wave form).  A leads K by construction, and K's frame bursts only cover bytes
+// A has consumed long before (A reads the frame a group ahead of the bytes it emits), so running in place stays safe.
 // Launcher: the streamed forms' preconditions, head-switch displacement within W/10, launches of the host-frame engine.
 template <bool SPEC, int DD = 4, bool SVID = false>
-__global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const Field422Dev *__restrict__ fields, Scratch422 Sc,
+__global__ __launch_bounds__(256) void k422_pipe(DevParams P, GeomDev G, const Field422Dev *__restrict__ fields, Scratch422 Sc,
                                                  const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                  const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
                                                  const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
@@ -1203,7 +1246,11 @@ __global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const F
     __shared__ uint32_t ring_b[31 * 64];                                   // B: chroma noise
     __shared__ __attribute__((aligned(16))) uint32_t tile_a[64 * 44];      // A: cooperative frame-row loads (CoopRows)
     __shared__ __attribute__((aligned(16))) uint32_t fstage[64 * 16 * 3];  // B: frame bursts
-    __shared__ uint32_t flags[4];                                          // [0] bytes of plane Y, [1] bytes of plane T
+    constexpr int XR = 32;                                                 // iterations the front may run ahead of the back
+    __shared__ uint32_t xring[XR * 64];                                    // F -> K: one packed word per lane and iteration
+    __shared__ uint32_t flags[4];      // [0] bytes of plane Y, [1] bytes of plane T, [2] iterations F has produced, [3] K has finished
+    typedef __attribute__((address_space(3))) uint32_t *lds_w;
+    const lds_w xr = (lds_w)xring;
     const int role = (int)(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int gidx = blockIdx.x * 63 + lane - 1;          // lane 0 = halo (row above)
@@ -1289,11 +1336,12 @@ __global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const F
             NTSC_PIPE_VMCNT(0);
             pipe::publish(fl + 1, W);
         }
-    } else {
-        // ---- B: B1 + B2 + B3 in one streamed pass over plane Y (T where the workgroup gathered)
+    } else if (role == 2) {
+        // ---- F: the FRONT of the streamed B pass (StreamB::iter_part<.., 1>): separation 1, chroma / phase noise, VCR luma
+        // chain over plane Y (T where the workgroup gathered) -> one packed word per iteration in the LDS ring
         const Plane422 IN = gather ? R.T : R.Y;
         const lds_flag fin = gather ? fl + 1 : fl;
-        int seen = 0;
+        int seen = 0, kseen = 0;
         StreamB<DD> B;
         B.begin(P, W, xi, k, oob0, oob1, a_sh_c, sharpen_c);
         B.cp.noise_on = SPEC ? true : P.cnoise_k != 0; B.cp.phase_on = SPEC ? true : P.pnoise_k != 0;
@@ -1304,9 +1352,7 @@ __global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const F
             n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
             B.cp.cosv = G.ptab[2 * n]; B.cp.sinv = G.ptab[2 * n + 1];
         }
-        B.sink.begin(P, true, SPEC ? 2 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
-        B.sink.wy.st = fstage + lane * 16; B.sink.wu.st = fstage + (64 + lane) * 16; B.sink.wv.st = fstage + (128 + lane) * 16;
-        if constexpr (SPEC) B.begin_fast(P.loss && dropout[rc] != 0);
+        if constexpr (SPEC) B.begin_fast(false);
         const int W2 = W / 2, NIT = W2 + DD + 2;
         auto need = [&](int bytes) { pipe::wait_ge(fin, bytes < W ? bytes : W, seen); };
         auto ldw = [&](int q) -> uint32_t { return __builtin_nontemporal_load((g_cw)(IN.p + (size_t)q * IN.S)); };
@@ -1315,8 +1361,18 @@ __global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const F
             need(x + 1);
             return (int)((ldw(x >> 2) >> (8 * (x & 3))) & 0xFFu);
         };
+        // iteration w may be written once the back has finished iteration w - XR + DD (it reads words i and i - DD)
+        auto room = [&](int w) { pipe::wait_ge(fl + 3, w - XR + 1 + DD, kseen); };
+        auto edge = [&](int i) {
+            uint32_t xf = 0;
+            const int c0 = in_byte(2 * i), c1 = in_byte(2 * i + 1);
+            B.template iter_part<true, SVID, 1>(P, i, c0, c1, xf, 0u, 0u);
+            room(i);
+            xr[(i & (XR - 1)) * 64 + lane] = xf;
+            pipe::publish(fl + 2, i + 1);
+        };
         int i = 0;
-        for (; i < 8 && i < NIT; i++) B.template iter<true, SVID>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        for (; i < 8 && i < NIT; i++) edge(i);
         if (i == 8 && i + 3 <= W2 - 2 - DD) {
             need(4 * ((i >> 1) + 2));
             uint32_t w0 = ldw(i >> 1), w1 = ldw((i >> 1) + 1);
@@ -1325,21 +1381,68 @@ __global__ __launch_bounds__(192) void k422_pipe(DevParams P, GeomDev G, const F
                 const int qn = (i >> 1) + 2, qmax = (W - 1) >> 2;
                 need(4 * (qn + 2));
                 const uint32_t n0 = ldw(qn <= qmax ? qn : qmax), n1 = ldw(qn + 1 <= qmax ? qn + 1 : qmax);
+                uint32_t xf[4];
                 if constexpr (SPEC) {
-                    B.template iter_fast<0>(P, i, byte_of(w0, 0), byte_of(w0, 1));
-                    B.template iter_fast<1>(P, i, byte_of(w0, 2), byte_of(w0, 3));
-                    B.template iter_fast<2>(P, i, byte_of(w1, 0), byte_of(w1, 1));
-                    B.template iter_fast<3>(P, i, byte_of(w1, 2), byte_of(w1, 3));
+                    B.template iter_fast_part<0, 1>(P, i, byte_of(w0, 0), byte_of(w0, 1), xf[0], 0u, 0u);
+                    B.template iter_fast_part<1, 1>(P, i, byte_of(w0, 2), byte_of(w0, 3), xf[1], 0u, 0u);
+                    B.template iter_fast_part<2, 1>(P, i, byte_of(w1, 0), byte_of(w1, 1), xf[2], 0u, 0u);
+                    B.template iter_fast_part<3, 1>(P, i, byte_of(w1, 2), byte_of(w1, 3), xf[3], 0u, 0u);
                 } else {
-                    B.template iter<false, SVID>(P, i, byte_of(w0, 0), byte_of(w0, 1));
-                    B.template iter<false, SVID>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3));
-                    B.template iter<false, SVID>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1));
-                    B.template iter<false, SVID>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3));
+                    B.template iter_part<false, SVID, 1>(P, i, byte_of(w0, 0), byte_of(w0, 1), xf[0], 0u, 0u);
+                    B.template iter_part<false, SVID, 1>(P, i + 1, byte_of(w0, 2), byte_of(w0, 3), xf[1], 0u, 0u);
+                    B.template iter_part<false, SVID, 1>(P, i + 2, byte_of(w1, 0), byte_of(w1, 1), xf[2], 0u, 0u);
+                    B.template iter_part<false, SVID, 1>(P, i + 3, byte_of(w1, 2), byte_of(w1, 3), xf[3], 0u, 0u);
                 }
+                room(i + 3);
+#pragma unroll
+                for (int j = 0; j < 4; j++) xr[((i + j) & (XR - 1)) * 64 + lane] = xf[j];
+                pipe::publish(fl + 2, i + 4);
                 w0 = n0; w1 = n1;
             }
         }
-        for (; i < NIT; i++) B.template iter<true, SVID>(P, i, in_byte(2 * i), in_byte(2 * i + 1));
+        for (; i < NIT; i++) edge(i);
+    } else {
+        // ---- K: the BACK of the pass (iter_part<.., 2>): VCR chroma low-pass, blend, sharpen, re-modulation, second
+        // separation, dropout, output low-pass -> frame bursts
+        int fseen = 0;
+        StreamB<DD> B;
+        B.begin(P, W, xi, k, oob0, oob1, a_sh_c, sharpen_c);
+        B.cp.noise_on = false; B.cp.phase_on = false;
+        B.sink.begin(P, true, SPEC ? 2 : P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        B.sink.wy.st = fstage + lane * 16; B.sink.wu.st = fstage + (64 + lane) * 16; B.sink.wv.st = fstage + (128 + lane) * 16;
+        if constexpr (SPEC) B.begin_fast(P.loss && dropout[rc] != 0);
+        const int W2 = W / 2, NIT = W2 + DD + 2;
+        auto word = [&](int it) -> uint32_t { return it >= 0 ? xr[(it & (XR - 1)) * 64 + lane] : 0u; };
+        auto edge = [&](int i) {
+            pipe::wait_ge(fl + 2, i + 1, fseen);
+            uint32_t none = 0;
+            const uint32_t now = word(i), del = word(i - DD);
+            B.template iter_part<true, SVID, 2>(P, i, 0, 0, none, now, del);
+            pipe::publish(fl + 3, i + 1);
+        };
+        int i = 0;
+        for (; i < 8 && i < NIT; i++) edge(i);
+        if (i == 8 && i + 3 <= W2 - 2 - DD) {
+            for (; i + 3 <= W2 - 2 - DD; i += 4) {
+                pipe::wait_ge(fl + 2, i + 4, fseen);
+                uint32_t now[4], del[4], none = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { now[j] = word(i + j); del[j] = word(i + j - DD); }
+                if constexpr (SPEC) {
+                    B.template iter_fast_part<0, 2>(P, i, 0, 0, none, now[0], del[0]);
+                    B.template iter_fast_part<1, 2>(P, i, 0, 0, none, now[1], del[1]);
+                    B.template iter_fast_part<2, 2>(P, i, 0, 0, none, now[2], del[2]);
+                    B.template iter_fast_part<3, 2>(P, i, 0, 0, none, now[3], del[3]);
+                } else {
+                    B.template iter_part<false, SVID, 2>(P, i, 0, 0, none, now[0], del[0]);
+                    B.template iter_part<false, SVID, 2>(P, i + 1, 0, 0, none, now[1], del[1]);
+                    B.template iter_part<false, SVID, 2>(P, i + 2, 0, 0, none, now[2], del[2]);
+                    B.template iter_part<false, SVID, 2>(P, i + 3, 0, 0, none, now[3], del[3]);
+                }
+                pipe::publish(fl + 3, i + 4);
+            }
+        }
+        for (; i < NIT; i++) edge(i);
         B.sink.finish(W);
     }
     if (lane == 0 && *(lds_flag)&pipe::g_fault) *fault = 1u + blockIdx.x;

@@ -1366,10 +1366,10 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     hipLaunchKernelGGL((k422_fused<__VA_ARGS__>), pgrid, dim3(64), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma)
-    // the latency form of the streamed kernels: sweep A | head-switch gather | streamed B pass as three wavefronts of one
+    // the latency form of the streamed kernels: sweep A | head-switch gather | front and back of the streamed pass as four wavefronts of one
     // workgroup (k422_pipe) -- short launches of the host-frame engine (ntscsim_field422 / the lanes of ntscsim_submit422)
 #define NTSC_LAUNCH_422_PIPE(...)                                                                             \
-    hipLaunchKernelGGL((k422_pipe<__VA_ARGS__>), pgrid, dim3(192), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
+    hipLaunchKernelGGL((k422_pipe<__VA_ARGS__>), pgrid, dim3(256), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma, c->pipe_fault)
     if (pipe422) {
