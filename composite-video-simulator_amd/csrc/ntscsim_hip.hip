@@ -1467,6 +1467,8 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
                              hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->stage422_ev[si], st));
     c->stage422_used[si] = true;
+    // (reading the records in the pinned staging buffer, as ntscsim_fields_device does for short launches, was measured
+    //  SLOWER here -- 3.21k against 3.39k calls/s: seven kernels read them, not two)
 
     rc = launch422(c, P, c->fields.p, c->fields422.p, st, prof ? &evs : nullptr);
     if (rc != NTSCSIM_OK) return rc;
