@@ -337,8 +337,13 @@ def extras(torch, ntscsim, dev, local_rank, args):
         big = ["--fields", "6000", "--warmup", "600"]
         sub422 = run_loop422("-vhs", "--mode", "submit", "--depth", "32", "--alloc", "pinned", *big, best_of=2)
         e2e["field_submit422"] = sub422.get("fields_per_s", 0.0)
+        # the synchronous iteration ntscsim_field422() (round 6: its streamed kernels as four wavefront roles, k422_pipe)
+        sync422 = run_loop422("-vhs", "--mode", "sync", "--fields", "1000", "--warmup", "100", best_of=2)
+        sync422p = run_loop422("-vhs", "--mode", "sync", "--fields", "1000", "--warmup", "100", "--alloc", "pinned", best_of=2)
+        e2e["field_call422"] = sync422.get("fields_per_s", 0.0)
+        e2e["field_call422_pinned"] = sync422p.get("fields_per_s", 0.0)
         e2e["field_submit422_detail"] = {
-            "loop_sync_fields_per_s": run_loop422("-vhs", "--mode", "sync", "--fields", "600", "--warmup", "100").get("fields_per_s"),
+            "loop_sync_fields_per_s": sync422.get("fields_per_s"),
             "depth32_vhs": sub422,
             "depth32_default_preset": run_loop422("--mode", "submit", "--depth", "32", "--alloc", "pinned", *big),
             "depth32_vhs_422_interlaced": run_loop422("-vhs", "-vi", "-422", "--mode", "submit", "--depth", "32", "--alloc", "pinned", *big),
@@ -590,6 +595,8 @@ def compact_line(out, extras_file):
         "field_call_python": _num(out, "end_to_end", "field_call"),
         "field_submit": _num(out, "end_to_end", "field_submit"),
         "field_submit422": _num(out, "end_to_end", "field_submit422"),
+        "field_call422": _num(out, "end_to_end", "field_call422"),
+        "field_call422_pinned": _num(out, "end_to_end", "field_call422_pinned"),
         "frames_host_bgra_pinned": _num(out, "end_to_end", "bgra_pinned"),
         "cli": _num(out, "end_to_end", "cli"),
         "multi_gpu_cpp_host": _num(out, "multi_gpu_cpp_host", "value"),

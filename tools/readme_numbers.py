@@ -55,9 +55,11 @@ rows = [
                                                                        e.get("field_call_cpp", 0) / cb["value"], e.get("field_call_cpp_pinned", 0) / cb["value"]), "`side.field_call`, `side.field_call_pinned`, `side.field_call_python`"),
     ("... asynchronous, `ntscsim_submit()` / `ntscsim_wait()` at depth 32 (`host/field_loop.cpp`): frames from `ntscsim_host_frame_alloc()` / a pool declared with `ntscsim_host_pin()` / plain `posix_memalign` frames (staged)",
      "%s / %s / %s fields/s" % (k(e.get("field_submit", 0)), k(rate(fs, "depth32_declared_pool")), k(rate(fs, "depth32_malloc_frames_staged"))), "`end_to_end.field_submit*`"),
-    ("the YUV422P tool's loop on host frames, depth 32 (`host/field_loop422.cpp`): pinned planes / plain heap planes, no `mallopt` / tight rows (704 wide) / synchronous",
-     "%s / %s / %s / %s fields/s" % (k(e.get("field_submit422", 0)), k(rate(f4, "depth32_vhs_heap_planes")), k(rate(f4, "tight_rows_704")), k(rate(f4, "loop_sync_fields_per_s"))),
+    ("the YUV422P tool's loop on host frames, depth 32 (`host/field_loop422.cpp`): pinned planes / plain heap planes, no `mallopt` / tight rows (704 wide)",
+     "%s / %s / %s fields/s" % (k(e.get("field_submit422", 0)), k(rate(f4, "depth32_vhs_heap_planes")), k(rate(f4, "tight_rows_704"))),
      "`end_to_end.field_submit422*`"),
+    ("... synchronous: one `ntscsim_field422()` per loop iteration (four wavefront roles, `k422_pipe`, DESIGN §7c): heap planes / pinned planes",
+     "%s / %s fields/s" % (k(e.get("field_call422", 0) or rate(f4, "loop_sync_fields_per_s")), k(e.get("field_call422_pinned", 0))), "`side.field_call422`, `side.field_call422_pinned`"),
     ("whole clips from host memory (`ntscsim_frames_host`): BGRA out / YUV420P out / YUV420P in and out", "%s / %s / %s fields/s" % (
         k(e.get("bgra_pinned", 0)), k(e.get("yuv420p_pinned", 0)), k(e.get("yuv420p_in_yuv420p_out_pinned", 0))), "`end_to_end.*_pinned`"),
     ("one process per GPU, C++ host over `rccl.h` (`host/rank_bench.cpp`), with the one rank this box has", "%s fields/s, checksums verified" % k(line["side"]["multi_gpu_cpp_host"]), "`side.multi_gpu_cpp_host`"),
