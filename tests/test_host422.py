@@ -108,6 +108,12 @@ class Ctx:
     def unpin(self):
         assert self.lib.ntscsim_host_unpin(self.h, None) == 0
 
+    def last_kernels(self):
+        buf = C.create_string_buffer(1024)
+        n = self.lib.ntscsim_debug_last_kernels(self.h, buf, len(buf))
+        assert n >= 0, n
+        return [k for k in buf.value.decode().split(";") if k]
+
 
 def enc_frame(w, h, mode, fill=0):
     """the encoder's frame: YUV422P, or YUV420P in a Yuv422-shaped buffer of which (h + 1) // 2 chroma rows count"""
@@ -257,6 +263,44 @@ def test_loop_on_padded_frames_batches_and_equals_the_tool(flags, out_mode, pad,
     st = run_loop(p, w, h, pad, 9, out_mode, mode, depth=8)
     if mode == "submit":
         assert st[3] == 18 and st[4] == 0 and st[1] <= 4      # batched: 18 iterations in a few launches
+
+
+@pytest.mark.parametrize("flags,form", [
+    (["-vhs"], "k422_pipe<true,4>"),
+    (["-vhs", "-vhs-speed", "lp"], "k422_pipe<false,5>"),
+    (["-vhs", "-vhs-speed", "ep", "-chroma-dropout", "30000"], "k422_pipe<false,6>"),
+    (["-vhs", "-vhs-svideo", "1"], "k422_pipe_sv<4>"),
+    (["-vhs", "-vhs-head-switching-point", "0.85", "-noise", "9"], "k422_pipe<false,4>"),
+    (["-vhs", "-tvstd", "pal"], "k422_fused<false,true,4>"),      # PAL: head-switch displacement beyond W/10 -> the one-wave form
+    ([], "k422_direct_fast"),                                     # no VCR: the two-sweep form (no role form yet)
+])
+def test_synchronous_iteration_takes_the_role_form_and_equals_the_tool(flags, form):
+    """ntscsim_field422(): the streamed kernels of the -vhs family run as four wavefront ROLES of one workgroup (k422_pipe:
+    sweep A | head-switch gather | front | back of the streamed pass -- the one-wave form's own code cut where only bytes
+    cross) for short launches of the host-frame engine; whole-buffer equality with the oracle's loop, form asserted by name."""
+    w, h = 720, 122
+    p = L.make_params_tocomp(flags + ["-width", str(w)], output_height=h)
+    srcs = sources(3, w, h)
+    frame_o = L.yuv_noise(w, h, 5, 16)
+    random_padding(frame_o, 6)
+    frame_g = frame_o.copy()
+    o = L.TocompOracleStream(p, oob=L.OOB_PLANE)
+    ctx = Ctx(p)
+    vf = 0
+    for s in srcs:
+        for sub in (0, 1):
+            field = (vf & 1) ^ 1
+            fl = F_SECOND if sub else 0
+            eo, go = enc_frame(w, h, OUT_BOB422, fill=7), enc_frame(w, h, OUT_BOB422, fill=7)
+            oracle_iteration(o, p, frame_o, s, field, vf, fl, None, eo, OUT_BOB422, field)
+            ctx.field(ctx.loop(frame_g, s, field, vf, fl, None, go, OUT_BOB422, field, sh=h))
+            kern = ctx.last_kernels()
+            assert form in kern, kern
+            same_frames(frame_g, frame_o, "frame, iteration %d" % vf)
+            same_out(go, eo, h, OUT_BOB422, "encoder frame %d" % vf)
+            vf += 1
+    assert ctx.rng_pos == o.rng_pos
+    ctx.close()
 
 
 @pytest.mark.parametrize("mode", ["sync", "submit"])
