@@ -155,19 +155,35 @@ struct BurstWriter {
 // the block size a compile-time constant.  Whole blocks run without any bounds test; the ragged
 // last block is a second copy of the body.  The next block's words are requested before the
 // current block is worked on.
-template <int NWB, class F>
-DEV void sweep_blocks(const Plane422 &pl, int N, F body)
+// NEED (the sweep as a ROLE of k422_direct_pipe): need(bytes) returns once the plane's first `bytes` samples may be read;
+// such a reader loads with the streaming policy (always from the L2).
+struct NoNeed422 { static constexpr bool nt = false; DEV void operator()(int) const {} };
+struct Need422 {
+    static constexpr bool nt = true;
+    pipe::lds_flag f;
+    int W;
+    int *seen;
+    DEV void operator()(int bytes) const { pipe::wait_ge(f, bytes < W ? bytes : W, *seen); }
+};
+template <int NWB, class F, class NEED = NoNeed422>
+DEV void sweep_blocks(const Plane422 &pl, int N, F body, NEED need = NEED())
 {
     constexpr int B = 4 * NWB;
     const int nwords = (N + 3) >> 2;
     uint32_t c[NWB], n[NWB];
+    auto ldw = [&](int q) -> uint32_t {
+        if constexpr (NEED::nt) return __builtin_nontemporal_load((__attribute__((address_space(1))) const uint32_t *)(pl.p + (size_t)q * pl.S));
+        else return pl.word(q);
+    };
+    need(4 * NWB);
 #pragma unroll
-    for (int i = 0; i < NWB; i++) c[i] = i < nwords ? pl.word(i) : 0u;
+    for (int i = 0; i < NWB; i++) c[i] = i < nwords ? ldw(i) : 0u;
     int x0 = 0;
     for (; x0 + B <= N; x0 += B) {
         const int q = (x0 >> 2) + NWB;
+        need(4 * (q + NWB));
 #pragma unroll
-        for (int i = 0; i < NWB; i++) n[i] = q + i < nwords ? pl.word(q + i) : 0u;
+        for (int i = 0; i < NWB; i++) n[i] = q + i < nwords ? ldw(q + i) : 0u;
 #pragma unroll
         for (int j = 0; j < B; j++) body(x0 + j, j, (int)((c[j >> 2] >> (8 * (j & 3))) & 0xFFu));
 #pragma unroll
@@ -607,9 +623,9 @@ typedef FrameSinkT<BurstWriter<4, 16>, BurstWriter<2, 16>> FrameSinkBurst;
 // the separated luma goes through the VHS luma chain and back to R.Y, chroma to R.U / R.V.  SINK:
 // everything goes to the frame through `sink`.  POST: the chroma pair passes the chroma / phase noise on its way
 // (the first separation of the path; SINK + POST = the whole decode side of a switch set WITHOUT the VCR, k422_direct).
-template <bool SINK, bool POST = !SINK, class SINKT = FrameSink>
+template <bool SINK, bool POST = !SINK, class SINKT = FrameSink, class NEED = NoNeed422>
 DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Magic31 &mA, int oob0, int oob1,
-               ChromaPost422 &cpost_in, LumaVhs &lv_in, SINKT &sink_in)
+               ChromaPost422 &cpost_in, LumaVhs &lv_in, SINKT &sink_in, NEED need = NEED())
 {
     // private copies: the states live in registers for the whole sweep
     ChromaPost422 cpost = cpost_in;
@@ -646,7 +662,7 @@ DEV void demod(const DevParams &P, const Row422 &R, int W, unsigned xi, const Ma
                 else { ou.put(xo >> 1, u); ov.put(xo >> 1, v); }
             }
         }
-    });
+    }, need);
     if (!SINK) { oy.finish(W); ou.finish(W2); ov.finish(W2); }
     else sink.finish(W);
 }
@@ -1565,6 +1581,120 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
         demod<true, true>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, sink);
     }
     (void)a_sh_c; (void)sharpen_c;
+}
+
+// The no-VCR form's latency form: sweep A | head-switch gather | the decode sweep as three wavefronts of one workgroup
+// (k422_pipe's arrangement and hand-off protocol; `demod` reads the composite bytes behind A's byte count through the NEED
+// hook of sweep_blocks).  FASTA preconditions (the tool's default preset qualifies), displacement within W/10.
+__global__ __launch_bounds__(192) void k422_short_pipe(DevParams P, GeomDev G, const Field422Dev *__restrict__ fields, Scratch422 Sc,
+                                                       const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
+                                                       const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
+                                                       const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
+                                                       const int *__restrict__ pn_noise, const int *__restrict__ dropout,
+                                                       double a_hp_i, double a_hp_q, unsigned *__restrict__ fault)
+{
+    using namespace fused422;
+    using pipe::lds_flag;
+    __shared__ uint32_t ring_a[31 * 64];
+    __shared__ uint32_t ring_b[31 * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t tile_a[64 * 44];
+    __shared__ __attribute__((aligned(16))) uint32_t fstage[64 * 16 * 3];
+    __shared__ uint32_t flags[4];
+    const int role = (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int gidx = blockIdx.x * 63 + lane - 1;
+    const int rc = gidx < 0 ? 0 : (gidx < P.R ? gidx : P.R - 1);
+    const int f = rc / P.Lslot, k = rc - f * P.Lslot;
+    const Field422Dev &fd = fields[f];
+    const unsigned field = fd.field & 1u;
+    const bool rowok = (int)(field + 2u * k) < P.H;
+    const bool is_out = lane >= 1 && gidx < P.R && rowok && !(fd.flags & F422_NOCOMP);
+    const unsigned y = rowok ? field + 2u * (unsigned)k : field;
+    const unsigned xi = scan_phase422(P, y, fd.fieldno);
+    const int W = P.W;
+    const size_t slot = (size_t)blockIdx.x * 64 + lane;
+    Row422 R;
+    R.Y.p = Sc.Y + slot; R.T.p = Sc.T + slot; R.U.p = Sc.U + slot; R.V.p = Sc.V + slot;
+    R.Y.S = R.T.S = R.U.S = R.V.S = Sc.S;
+    uint8_t *fy = fd.dst[0] + (size_t)fd.dst_ls[0] * y;
+    uint8_t *fu = fd.dst[1] + (size_t)fd.dst_ls[1] * y;
+    uint8_t *fv = fd.dst[2] + (size_t)fd.dst_ls[2] * y;
+    halo_redirect(Sc, lane, fy, fu, fv);
+    int oob0 = 16, oob1 = 16;
+    {
+        const size_t off = (size_t)fd.dst_ls[0] * y + (size_t)W, end = (size_t)fd.dst_ls[0] * (size_t)P.H;
+        if (off < end) oob0 = fy[W];
+        if (off + 1 < end) oob1 = fy[W + 1];
+    }
+    const int hs = P.hs ? hs_shift[rc] : 0;
+    const bool gather = P.hs && __any(hs != 0);
+    if (threadIdx.x < 4) flags[threadIdx.x] = 0u;
+    if (threadIdx.x < 8) pipe::g_waited[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) pipe::g_fault = 0u;
+    __syncthreads();
+    const lds_flag fl = (lds_flag)flags;
+    typedef __attribute__((address_space(1))) const uint32_t *g_cw;
+    if (role == 0) {
+        LumaPost422 lp_;
+        lp_.pre_on = P.pre_on != 0; lp_.noise_on = P.noise_k != 0;
+        lp_.pre.p = 16; lp_.noise = 0; lp_.ring = ring_a; lp_.lane = lane;
+        if (lp_.noise_on) { lp_.rng.init(ring_a, rs_luma + rc, P.Rpad, lane); lp_.noise = n0_luma[rc]; }
+        auto pub = [&](int g0) {
+            const int done = 2 * (g0 - 4);
+            if (done > 0) { NTSC_PIPE_VMCNT(16); pipe::publish(fl, done < W ? done : W); }
+        };
+        sweep_a<true, true, true, true>(P, R, fy, fu, fv, W, xi, lp_, a_hp_i, a_hp_q, fd.dst_ls[0], fd.dst_ls[1], fd.dst_ls[2], tile_a, pub);
+        NTSC_PIPE_VMCNT(0);
+        pipe::publish(fl, W);
+    } else if (role == 1) {
+        if (gather) {
+            const int tw = W + W / 10, reach = W / 10 + 2;
+            int seen = 0;
+            Packer422 o; o.begin(R.T);
+            constexpr int HB = 16;
+            for (int x0 = 0; x0 < W; x0 += HB) {
+                { const int c = x0 + HB + reach; pipe::wait_ge(fl, c < W ? c : W, seen); }
+                int v[HB], ix[HB];
+#pragma unroll
+                for (int j = 0; j < HB; j++) {
+                    int idx = x0 + j + hs;
+                    idx += (idx >> 31) & tw;
+                    idx -= (idx >= tw) ? tw : 0;
+                    ix[j] = idx;
+                    const int xr = idx < W ? idx : W - 1;
+                    const uint32_t wv = __builtin_nontemporal_load((g_cw)(R.Y.p + (size_t)(xr >> 2) * R.Y.S));
+                    v[j] = (int)((wv >> (8 * (xr & 3))) & 0xFFu);
+                }
+#pragma unroll
+                for (int j = 0; j < HB; j++)
+                    if (x0 + j < W) o.put(x0 + j, ix[j] < W ? v[j] : 16);
+                NTSC_PIPE_VMCNT(4);
+                pipe::publish(fl + 1, x0);
+            }
+            o.finish(W);
+            NTSC_PIPE_VMCNT(0);
+            pipe::publish(fl + 1, W);
+        }
+    } else {
+        if (gather) R.Y = R.T;
+        int seen = 0;
+        Need422 need{gather ? fl + 1 : fl, W, &seen};
+        ChromaPost422 cp_;
+        cp_.noise_on = P.cnoise_k != 0; cp_.phase_on = P.pnoise_k != 0;
+        cp_.nU = cp_.nV = 0; cp_.cosv = 1; cp_.sinv = 0; cp_.ring = ring_b; cp_.lane = lane;
+        if (cp_.noise_on) { cp_.rng.init(ring_b, rs_chroma + rc, P.Rpad, lane); cp_.nU = n0_u[rc]; cp_.nV = n0_v[rc]; }
+        if (cp_.phase_on) {
+            int n = (rowok ? pn_noise[rc] : 0) + P.pnoise_k;
+            n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+            cp_.cosv = G.ptab[2 * n]; cp_.sinv = G.ptab[2 * n + 1];
+        }
+        FrameSinkBurst bs;
+        bs.begin(P, true, P.out_lp, fy, fu, fv, is_out, P.loss && dropout[rc] != 0, a_hp_i, a_hp_q, W);
+        bs.wy.st = fstage + lane * 16; bs.wu.st = fstage + (64 + lane) * 16; bs.wv.st = fstage + (128 + lane) * 16;
+        LumaVhs nolv;
+        demod<true, true, FrameSinkBurst, Need422>(P, R, W, xi, P.m_amp_back, oob0, oob1, cp_, nolv, bs, need);
+    }
+    if (lane == 0 && *(lds_flag)&pipe::g_fault) *fault = 1u + blockIdx.x;
 }
 
 } // namespace ntscsim

@@ -1351,7 +1351,9 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     static const bool pipe422_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
     const bool pipe422 = c->latency_form && pipe422_env && n <= NTSC_PIPE_MAX_FIELDS && head_switch_is_small(D, W) &&
                          ((fused && stream) || stream_gen || stream_sv);
-    if (pipe422)
+    const bool pipe422_direct = c->latency_form && pipe422_env && n <= NTSC_PIPE_MAX_FIELDS && head_switch_is_small(D, W) && direct && fasta;
+    if (pipe422_direct) note_kernel(c, "k422_direct_pipe");
+    else if (pipe422)
         note_kernel(c, (fused && stream) ? "k422_pipe<true,4>"
                        : stream_sv ? (D.cdelay == 4 ? "k422_pipe_sv<4>" : D.cdelay == 5 ? "k422_pipe_sv<5>" : "k422_pipe_sv<6>")
                                    : (D.cdelay == 4 ? "k422_pipe<false,4>" : D.cdelay == 5 ? "k422_pipe<false,5>" : "k422_pipe<false,6>"));
@@ -1372,8 +1374,11 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     hipLaunchKernelGGL((k422_pipe<__VA_ARGS__>), pgrid, dim3(256), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, \
                        c->n0_luma.p, c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p,                      \
                        c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, a_sh_c, p.vhs_out_sharpen_chroma, c->pipe_fault)
-    if (pipe422) {
-        if (!c->pipe_fault) { HIPCHK(c, hipHostMalloc((void **)&c->pipe_fault, 64, hipHostMallocDefault)); *c->pipe_fault = 0u; }
+    if ((pipe422 || pipe422_direct) && !c->pipe_fault) { HIPCHK(c, hipHostMalloc((void **)&c->pipe_fault, 64, hipHostMallocDefault)); *c->pipe_fault = 0u; }
+    if (pipe422_direct) {
+        hipLaunchKernelGGL(k422_short_pipe, pgrid, dim3(192), 0, st, D, G, fields422_dev, Sc, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p,
+                           c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, a_hp_i, a_hp_q, c->pipe_fault);
+    } else if (pipe422) {
         if (fused && stream) NTSC_LAUNCH_422_PIPE(true, 4);
         else if (stream_sv && D.cdelay == 4) NTSC_LAUNCH_422_PIPE(false, 4, true);
         else if (stream_sv && D.cdelay == 5) NTSC_LAUNCH_422_PIPE(false, 5, true);

@@ -270,9 +270,10 @@ def test_loop_on_padded_frames_batches_and_equals_the_tool(flags, out_mode, pad,
     (["-vhs", "-vhs-speed", "lp"], "k422_pipe<false,5>"),
     (["-vhs", "-vhs-speed", "ep", "-chroma-dropout", "30000"], "k422_pipe<false,6>"),
     (["-vhs", "-vhs-svideo", "1"], "k422_pipe_sv<4>"),
-    (["-vhs", "-vhs-head-switching-point", "0.85", "-noise", "9"], "k422_pipe<false,4>"),
+    (["-vhs", "-noise", "0", "-chroma-noise", "40"], "k422_pipe<false,4>"),
+    (["-vhs", "-vhs-head-switching-point", "0.85", "-noise", "9"], "k422_fused<true,true,4>"),   # a displacement beyond W/10: one wave
     (["-vhs", "-tvstd", "pal"], "k422_fused<false,true,4>"),      # PAL: head-switch displacement beyond W/10 -> the one-wave form
-    ([], "k422_direct_fast"),                                     # no VCR: the two-sweep form (no role form yet)
+    ([], "k422_direct_pipe"),                                     # no VCR: sweep A | gather | the decode sweep
 ])
 def test_synchronous_iteration_takes_the_role_form_and_equals_the_tool(flags, form):
     """ntscsim_field422(): the streamed kernels of the -vhs family run as four wavefront ROLES of one workgroup (k422_pipe:
