@@ -203,6 +203,14 @@ static int h422_launch(ntscsim_ctx *c);
 
 // which kernel form a launch site chose (read back by ntscsim_debug_last_kernels; the parity tests
 // assert on it, so that a specialised form cannot silently stop being the one that runs)
+// launches of at most this many fields from the host-frame entry points take the role kernels (ntsc_pipe.hip, k422_pipe);
+// NTSCSIM_PIPE_MAX: developer switch for the crossover measurement (tools/sync_trace.sh)
+static int pipe_max_fields()
+{
+    static const int v = std::getenv("NTSCSIM_PIPE_MAX") ? std::atoi(std::getenv("NTSCSIM_PIPE_MAX")) : NTSC_PIPE_MAX_FIELDS;
+    return v;
+}
+
 static void note_kernel(ntscsim_ctx *c, const char *name)
 {
     if (!c->kernels.empty()) c->kernels += ';';
@@ -737,12 +745,12 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     // the latency form: the chain as five wavefronts (roles) of one workgroup (ntsc_pipe.hip) -- short launches
     // from the host-frame entry points, the -vhs preset family of the hand-tuned kernels.  NTSCSIM_PIPE=0: A/B switch.
     static const bool pipe_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
-    const bool pipe_form = c->latency_form && pipe_env && n <= NTSC_PIPE_MAX_FIELDS && c->mode != NTSCSIM_MODE_FLOAT &&
+    const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() && c->mode != NTSCSIM_MODE_FLOAT &&
                            enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                            !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->split_vhs &&
                            D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k;
     // ... and the default preset (no VCR) as three roles: encoder | TV front | TV back
-    const bool pipe_tv = c->latency_form && pipe_env && n <= NTSC_PIPE_MAX_FIELDS && c->mode != NTSCSIM_MODE_FLOAT &&
+    const bool pipe_tv = c->latency_form && pipe_env && n <= pipe_max_fields() && c->mode != NTSCSIM_MODE_FLOAT &&
                          enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                          !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->force_generic &&
                          !D.vhs && !D.cnoise_k && !D.pnoise_k;
@@ -1024,7 +1032,7 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     // buffer is the GPU's to address, a handful of 288-byte records is not worth a copy kernel and the dependency behind it
     // (the staging slot is then busy until the kernels have run: the event follows them).  NTSCSIM_RECORDS_INPLACE=0: A/B.
     static const bool inplace_env = !(std::getenv("NTSCSIM_RECORDS_INPLACE") && std::getenv("NTSCSIM_RECORDS_INPLACE")[0] == '0');
-    const bool inplace = inplace_env && c->latency_form && n <= NTSC_PIPE_MAX_FIELDS;
+    const bool inplace = inplace_env && c->latency_form && n <= pipe_max_fields();
     if (!inplace) {
         HIPCHK(c, hipMemcpyAsync(c->fields.p, c->stage[si], (size_t)n * sizeof(FieldDev),
                                  hipMemcpyHostToDevice, st));
@@ -1349,9 +1357,9 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // the VCR with S-Video out: the streamed pass without its re-modulation (aligned rows), else the twelve sweeps
     const bool stream_sv = fused_sv && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 && D.cdelay >= 4 && D.cdelay <= 6;
     static const bool pipe422_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
-    const bool pipe422 = c->latency_form && pipe422_env && n <= NTSC_PIPE_MAX_FIELDS && head_switch_is_small(D, W) &&
+    const bool pipe422 = c->latency_form && pipe422_env && n <= pipe_max_fields() && head_switch_is_small(D, W) &&
                          ((fused && stream) || stream_gen || stream_sv);
-    const bool pipe422_direct = c->latency_form && pipe422_env && n <= NTSC_PIPE_MAX_FIELDS && head_switch_is_small(D, W) && direct && fasta;
+    const bool pipe422_direct = c->latency_form && pipe422_env && n <= pipe_max_fields() && head_switch_is_small(D, W) && direct && fasta;
     if (pipe422_direct) note_kernel(c, "k422_direct_pipe");
     else if (pipe422)
         note_kernel(c, (fused && stream) ? "k422_pipe<true,4>"
