@@ -742,15 +742,18 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                     D.ghost_taps == 0 && !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small &&
                     !c->split_vhs &&
                     ((D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k) || (!D.vhs && !D.cnoise_k && !D.pnoise_k));
+    // (NTSCSIM_MODE_FLOAT: its short host-frame launches take the role kernels with float filter states -- the FAST32
+    //  arithmetic, inside the mode's stated tolerance like every other FAST32 fallback of that mode -- because the float
+    //  pipeline's own two-role decoder makes 2.3k calls per second where these make 4.8k)
     // the latency form: the chain as five wavefronts (roles) of one workgroup (ntsc_pipe.hip) -- short launches
     // from the host-frame entry points, the -vhs preset family of the hand-tuned kernels.  NTSCSIM_PIPE=0: A/B switch.
     static const bool pipe_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
-    const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() && c->mode != NTSCSIM_MODE_FLOAT &&
+    const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() &&
                            enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                            !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->split_vhs &&
                            D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k;
     // ... and the default preset (no VCR) as three roles: encoder | TV front | TV back
-    const bool pipe_tv = c->latency_form && pipe_env && n <= pipe_max_fields() && c->mode != NTSCSIM_MODE_FLOAT &&
+    const bool pipe_tv = c->latency_form && pipe_env && n <= pipe_max_fields() &&
                          enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                          !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->force_generic &&
                          !D.vhs && !D.cnoise_k && !D.pnoise_k;

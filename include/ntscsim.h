@@ -191,7 +191,8 @@ const char *ntscsim_last_error(const ntscsim_ctx *ctx); /* text of the last HIP 
  *                       head-switch geometry, phase-noise table and dropout stay the exact mode's integers.  Same stated
  *                       tolerance as FAST32 (at most 1 LSB per 8-bit channel; bounds and the measured share of exact
  *                       pixels in tests/test_gpu_fast_mode.py).  Default preset and the -vhs family with its standard
- *                       switches; other switch sets run the FAST32 forms in this mode.
+ *                       switches; other switch sets -- and the short launches of ntscsim_field() / ntscsim_submit() -- run
+ *                       the FAST32 forms in this mode.
  */
 enum { NTSCSIM_MODE_EXACT = 0, NTSCSIM_MODE_FAST32 = 1, NTSCSIM_MODE_FLOAT = 2 };
 int ntscsim_set_mode(ntscsim_ctx *ctx, int mode);

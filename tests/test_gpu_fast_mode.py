@@ -158,29 +158,39 @@ def test_float_long_batches_take_the_one_wave_form_and_agree_with_the_two_role_f
 
 
 def test_float_mode_through_the_host_call_and_the_submit_engine():
-    """the mode is the ctx's: ntscsim_field() and ntscsim_submit() lanes run the float pipeline too, same bytes as the
-    device-resident batch"""
-    import torch
+    """the mode is the ctx's: ntscsim_field() and ntscsim_submit() lanes run in the tolerance mode too -- their short launches
+    as the role kernels with float filter states (k_field_pipe<float>: 4.8k calls per second against 2.3k for the float
+    pipeline's own short-batch form) -- inside the mode's stated tolerance against the oracle, same rand() stream"""
     w, h = 720, 486
     p = L.make_params(["-vhs"])
     srcs = [L.noise_frame(w, h, 40 + j) for j in range(2)]
+    o = L.OracleStream(p)
+    exp = np.zeros((4, h, w, 4), np.uint8)
+    for k in range(4):
+        o.field(exp[k], srcs[k // 2], (k & 1) ^ 1, k)
     sim = ntscsim.FieldSimulator(params=p)
     sim.set_mode(_capi.MODE_FLOAT)
-    src = torch.from_numpy(np.stack(srcs)).cuda()
-    dst = torch.zeros((4, h, w, 4), dtype=torch.uint8, device="cuda")
-    sim.fields(src, dst, [(k // 2, k, (k & 1) ^ 1, k) for k in range(4)])
-    sim.sync()
-    ref = dst.cpu().numpy()
-    sim.rng_pos = 0
+
+    def check(got, what):
+        d = np.abs(got.astype(np.int16) - exp.astype(np.int16))
+        assert d.max() <= MAX_ABS, what
+        for k in range(4):
+            field = (k & 1) ^ 1
+            assert not got[k][1 - field::2].any(), what              # the other field's rows untouched
+            assert (d[k][field::2].max(axis=-1) > 0).mean() <= MAX_FRACTION_DIFFERENT, what
+
     one = np.zeros((4, h, w, 4), np.uint8)
     for k in range(4):
         sim.field_host(one[k], srcs[k // 2], (k & 1) ^ 1, k)
-    assert np.array_equal(one, ref)
+        assert "k_field_pipe<float>" in sim.last_kernels()
+    assert sim.rng_pos == o.rng_pos
+    check(one, "ntscsim_field")
     sim.rng_pos = 0
     two = np.zeros((4, h, w, 4), np.uint8)
     ts = [sim.submit(two[k], srcs[k // 2], (k & 1) ^ 1, k) for k in range(4)]
     sim.wait(ts[-1])
-    assert np.array_equal(two, ref)
+    check(two, "ntscsim_submit")
+    assert np.array_equal(one, two)
     sim.close()
 
 

@@ -63,7 +63,7 @@ def run(arr, mode="exact"):
 
 
 def main():
-    out = [run("one_launch"), run("two_launch"), run("side_by_side"), run("pipe"), run("one_launch", "float")]
+    out = [run("one_launch"), run("two_launch"), run("side_by_side"), run("pipe"), run("one_launch", "float"), run("pipe", "float")]
     for o in out:
         if "error" in o:
             print(o)
