@@ -218,8 +218,8 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
 
 // ------------------------------------------------------------------------------------------------ the decoder roles
 // per-lane constants of the four decoder roles (every role fills what it reads; the rest is dead code)
-template <class RT>
-DEV void dec_const(Const<RT, false> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift)
+template <class RT, bool WR = false>
+DEV void dec_const(Const<RT, WR> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift)
 {
     const int W = P.W;
     C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
@@ -246,22 +246,48 @@ DEV void dec_const(Const<RT, false> &C, const DevParams &P, const Row &R, const 
     C.rowbytes = P.Rpad * 4;
     const int hs = (P.hs && hs_shift) ? hs_shift[R.rc] : 0;
     C.vbase = (int)((unsigned)R.rc * 4u + (unsigned)hs * (unsigned)C.rowbytes);
+    if constexpr (WR) {       // displacements that wrap around the 1.1 W window (decode_fast_body, cs_load)
+        const int tw = W + W / 10;
+        C.wrapoff = (int)((unsigned)(hs > 0 ? -tw : tw) * (unsigned)C.rowbytes);
+        C.wrapA = hs > 0 ? tw - hs - 1 : (hs < 0 ? -hs - 1 : 0x3FFFFFFF);
+        C.wrapS = opaque_v(hs < 0 ? -1 : 0);
+    }
     C.comp = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(comp), 0, (int)((unsigned)W * (unsigned)C.rowbytes), 0x00020000);
 }
 // the steady loop exists iff one iteration fits (every role decides alike: the positions are the same for all)
 DEV bool has_steady(int W, int d, int SKT) { return SKT + 4 <= W - (d > 7 ? d - 7 : 0); }
 DEV bool has_steady(int W, int d) { return has_steady(W, d, 15 + d); }
+// How far ahead of its own position a reader of the composite plane may ask: the head-switch displacement of its farthest
+// lane, + 2.  Displacements within W/10 (the launcher's head_switch_is_small): W/10 + 2 covers them.  WR (any displacement,
+// e.g. PAL's default switching point: the sample is row[(x + shift) mod 1.1 W]): the workgroup's largest forward
+// displacement -- and the WHOLE row when a lane's backward displacement exceeds W/10, because the row's first samples
+// then come from its end (that workgroup, the one that holds the switched rows, runs its encoder first and the rest behind).
+template <bool WR>
+DEV int wg_reach(const DevParams &P, const int *hs_shift, int rc)
+{
+    const int W = P.W;
+    if (!WR || !P.hs) return W / 10 + 2;
+    int hs = hs_shift[rc], mx = hs, mn = hs;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int a = __shfl_xor(mx, o), b = __shfl_xor(mn, o);
+        mx = a > mx ? a : mx; mn = b < mn ? b : mn;
+    }
+    mx = __builtin_amdgcn_readfirstlane(mx); mn = __builtin_amdgcn_readfirstlane(mn);
+    if (mn < -(W / 10)) return W;
+    return (mx > 0 ? mx : 0) + 2;
+}
 
 // ------------------------------------------------------------------------------------------------ SEP: VCR, chroma front
 // vcr_step / vcr_edge up to the chroma noise: first separator at x1 = t - 7 (no luma out), U / V += noise, two draws
-template <class RT>
+template <class RT, bool WR>
 DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                   const int *__restrict__ n0_u, const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                   uint32_t *ring, lds_x2 ab, lds_flag fl)
 {
-    typedef Const<RT, false> CT;
+    typedef Const<RT, WR> CT;
     CT C;
-    dec_const<RT>(C, P, R, comp, hs_shift);
+    dec_const<RT, WR>(C, P, R, comp, hs_shift);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     DemodR D1;
     D1.init();
@@ -270,7 +296,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
     int nU = n0_u[R.rc], nV = n0_v[R.rc];
     // columns of the composite plane a step at stream position t may request: its own column t and, on a head-switched
     // lane, up to W/10 + 1 columns further (k_field_setup; the launcher takes this form only for displacements within W/10)
-    const int reach = W / 10 + 2;
+    const int reach = wg_reach<WR>(P, hs_shift, R.rc);
     int enc_seen = 0, cons_seen = 0;
     auto need_enc = [&](int c) { wait_ge(fl + F_ENC, c < W ? c : W, enc_seen); };
     auto edge = [&](int t) {
@@ -442,13 +468,13 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
 // ------------------------------------------------------------------------------------------------ LUM: VCR luma + TV front
 // the luma path of vcr_step / vcr_edge (box at x2, VHS low-pass + emphasis, sharpen), the VCR's composite sample
 // c2 = Y + chroma term, and the TV's separator on it (step<true> / edge_step<true>: x3 = x2 - 7, dropout as the and-mask)
-template <class RT>
+template <class RT, bool WR>
 DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const int *__restrict__ hs_shift,
                    const int *__restrict__ dropout, lds_x1 bc, lds_x4 cd, lds_flag fl)
 {
-    typedef Const<RT, false> CT;
+    typedef Const<RT, WR> CT;
     CT C;
-    dec_const<RT>(C, P, R, comp, hs_shift);
+    dec_const<RT, WR>(C, P, R, comp, hs_shift);
     C.dm = opaque_v((P.loss && dropout[R.rc] != 0) ? 0 : -1);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT, LOFF = C.LOFF;
     DemodR D2;
@@ -457,7 +483,7 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
     Casc3<RT> vl, sh;
     PoleHp<RT> vpre;
     vl.reset(16, C.a_vl); vpre.reset(16, C.a_vl); sh.reset(0, C.a_sh);
-    const int reach = W / 10 + 2;
+    const int reach = wg_reach<WR>(P, hs_shift, R.rc);
     int enc_seen = 0, in_seen = 0, cons_seen = 0;
     auto need_enc = [&](int c) { wait_ge(fl + F_ENC, c < W ? c : W, enc_seen); };
     auto edge = [&](int t) {
@@ -701,7 +727,8 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
 // Preconditions (launcher): the -vhs preset family of the hand-tuned kernels (input chroma low-pass on, no pre-emphasis, luma /
 // chroma / phase noise on, amplitudes 50 / 50, even scanline phase, output low-pass "lite", composite out), head-switch
 // displacement within W/10, 16-byte aligned rows, planes below 4 GiB, no ghosting.
-template <class RT>
+// WR: head-switch displacements of any size (wrap-around loads, wg_reach) -- e.g. PAL with its default switching point.
+template <class RT, bool WR = false>
 __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
                                                     const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                     int *__restrict__ comp,
@@ -745,9 +772,9 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     const lds_x1 bc = (lds_x1)ring_bc;
     const lds_x4 cd = (lds_x4)ring_cd;
     if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
-    else if (role == 1) sep_role<RT>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
+    else if (role == 1) sep_role<RT, WR>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
     else if (role == 2) chroma_role<RT>(P, G, R, pn_noise, tails, ab, bc, fl);
-    else if (role == 3) luma_role<RT>(P, R, comp, hs_shift, dropout, bc, cd, fl);
+    else if (role == 3) luma_role<RT, WR>(P, R, comp, hs_shift, dropout, bc, cd, fl);
     else output_role<RT>(P, R, ostage, orow, drow, cd, fl);
     if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;
     if (dbg && R.lane == 0) {      // NTSCSIM_PIPE_TIMING: start, end, ticks spent polling -- per workgroup and role

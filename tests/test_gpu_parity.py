@@ -271,7 +271,7 @@ def test_host_frame_dropin_sequence():
     sim.close()
 
 
-_PIPE5, _PIPE3 = "k_field_pipe<double>", "k_field_pipe_tv<double>"
+_PIPE5, _PIPE3, _PIPE5W = "k_field_pipe<double>", "k_field_pipe_tv<double>", "k_field_pipe<double,true>"
 
 
 @pytest.mark.parametrize("flags,w,h,piped", [
@@ -285,7 +285,11 @@ _PIPE5, _PIPE3 = "k_field_pipe<double>", "k_field_pipe_tv<double>"
     ([], 720, 486, _PIPE3), ([], 256, 100, _PIPE3), ([], 16, 4, _PIPE3), ([], 21, 9, _PIPE3), ([], 1920, 1080, _PIPE3),
     (["-noise", "30", "-chroma-dropout", "20000"], 360, 243, _PIPE3), (["-tvstd", "pal"], 720, 576, _PIPE3),
     (["-vhs-head-switching", "1"], 256, 100, _PIPE3),       # the head switch without the VCR: displaced loads in the TV front
-    (["-vhs", "-tvstd", "pal"], 720, 576, None),            # PAL: head-switch displacement beyond W/10 -> the one-launch forms
+    # head-switch displacements beyond W/10 (wrap-around loads; a workgroup whose rows reach back to the row's end runs
+    # its encoder first): PAL's default switching point, a large forward and a large backward displacement
+    (["-vhs", "-tvstd", "pal"], 720, 576, _PIPE5W),
+    (["-vhs", "-vhs-head-switching-phase", "0.001"], 720, 486, _PIPE5W),
+    (["-vhs", "-vhs-head-switching-phase", "0.003"], 720, 486, _PIPE5W), (["-vhs", "-vhs-head-switching-phase", "0.003"], 100, 60, _PIPE5W),
     (["-vhs", "-vhs-svideo", "1"], 256, 100, None), (["-vhs", "-comp-phase", "90"], 256, 100, None),
     (["-comp-catv"], 256, 100, None),
 ])
