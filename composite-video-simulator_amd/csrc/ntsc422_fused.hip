@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(64, STREAM ? 2 : F422_WAVES) void k422_fused(DevPar
 // iteration (luma 2i-2, luma 2i-1, U1, V1) in a ring of 32 iterations in LDS; K reads word i for the chroma and word i - D
 // for the luma (the delay line of the one-wave form).  A leads K by construction, and K's frame bursts only cover bytes
 // A has consumed long before (A reads the frame a group ahead of the bytes it emits), so running in place stays safe.
-// Launcher: the streamed forms' preconditions, head-switch displacement within W/10, launches of the host-frame engine.
+// Launcher: the streamed forms' preconditions, launches of the host-frame engine.
 template <bool SPEC, int DD = 4, bool SVID = false>
 __global__ __launch_bounds__(256) void k422_pipe(DevParams P, GeomDev G, const Field422Dev *__restrict__ fields, Scratch422 Sc,
                                                  const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
@@ -1324,7 +1324,20 @@ __global__ __launch_bounds__(256) void k422_pipe(DevParams P, GeomDev G, const F
     } else if (role == 1) {
         // ---- G: head switching :669-732 (displaced copy Y -> T, fill value 16), 16 samples per step
         if (gather) {
-            const int tw = W + W / 10, reach = W / 10 + 2;
+            const int tw = W + W / 10;
+            // how far ahead of x a lane may read: its forward displacement -- and the whole row when a backward displacement
+            // beyond W/10 makes the row's first samples come from its end (ntsc_pipe.hip: wg_reach)
+            int reach;
+            {
+                int mx = hs, mn = hs;
+#pragma unroll
+                for (int o_ = 32; o_ >= 1; o_ >>= 1) {
+                    const int a_ = __shfl_xor(mx, o_), b_ = __shfl_xor(mn, o_);
+                    mx = a_ > mx ? a_ : mx; mn = b_ < mn ? b_ : mn;
+                }
+                mx = __builtin_amdgcn_readfirstlane(mx); mn = __builtin_amdgcn_readfirstlane(mn);
+                reach = mn < -(W / 10) ? W : (mx > 0 ? mx : 0) + 2;
+            }
             int seen = 0;
             Packer422 o; o.begin(R.T);
             constexpr int HB = 16;
@@ -1585,7 +1598,7 @@ __global__ __launch_bounds__(64, F422_WAVES) void k422_short(DevParams P, GeomDe
 
 // The no-VCR form's latency form: sweep A | head-switch gather | the decode sweep as three wavefronts of one workgroup
 // (k422_pipe's arrangement and hand-off protocol; `demod` reads the composite bytes behind A's byte count through the NEED
-// hook of sweep_blocks).  FASTA preconditions (the tool's default preset qualifies), displacement within W/10.
+// hook of sweep_blocks).  FASTA preconditions (the tool's default preset qualifies).
 __global__ __launch_bounds__(192) void k422_short_pipe(DevParams P, GeomDev G, const Field422Dev *__restrict__ fields, Scratch422 Sc,
                                                        const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                        const uint32_t *__restrict__ rs_chroma, const int *__restrict__ n0_u,
@@ -1648,7 +1661,20 @@ __global__ __launch_bounds__(192) void k422_short_pipe(DevParams P, GeomDev G, c
         pipe::publish(fl, W);
     } else if (role == 1) {
         if (gather) {
-            const int tw = W + W / 10, reach = W / 10 + 2;
+            const int tw = W + W / 10;
+            // how far ahead of x a lane may read: its forward displacement -- and the whole row when a backward displacement
+            // beyond W/10 makes the row's first samples come from its end (ntsc_pipe.hip: wg_reach)
+            int reach;
+            {
+                int mx = hs, mn = hs;
+#pragma unroll
+                for (int o_ = 32; o_ >= 1; o_ >>= 1) {
+                    const int a_ = __shfl_xor(mx, o_), b_ = __shfl_xor(mn, o_);
+                    mx = a_ > mx ? a_ : mx; mn = b_ < mn ? b_ : mn;
+                }
+                mx = __builtin_amdgcn_readfirstlane(mx); mn = __builtin_amdgcn_readfirstlane(mn);
+                reach = mn < -(W / 10) ? W : (mx > 0 ? mx : 0) + 2;
+            }
             int seen = 0;
             Packer422 o; o.begin(R.T);
             constexpr int HB = 16;

@@ -1365,9 +1365,9 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     // the VCR with S-Video out: the streamed pass without its re-modulation (aligned rows), else the twelve sweeps
     const bool stream_sv = fused_sv && !c->no_stream422 && !c->split_vhs && D.src_al16 && D.dst_al16 && D.cdelay >= 4 && D.cdelay <= 6;
     static const bool pipe422_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
-    const bool pipe422 = c->latency_form && pipe422_env && n <= pipe_max_fields() && head_switch_is_small(D, W) &&
+    const bool pipe422 = c->latency_form && pipe422_env && n <= pipe_max_fields() &&
                          ((fused && stream) || stream_gen || stream_sv);
-    const bool pipe422_direct = c->latency_form && pipe422_env && n <= pipe_max_fields() && head_switch_is_small(D, W) && direct && fasta;
+    const bool pipe422_direct = c->latency_form && pipe422_env && n <= pipe_max_fields() && direct && fasta;
     if (pipe422_direct) note_kernel(c, "k422_direct_pipe");
     else if (pipe422)
         note_kernel(c, (fused && stream) ? "k422_pipe<true,4>"

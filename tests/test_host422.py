@@ -271,8 +271,8 @@ def test_loop_on_padded_frames_batches_and_equals_the_tool(flags, out_mode, pad,
     (["-vhs", "-vhs-speed", "ep", "-chroma-dropout", "30000"], "k422_pipe<false,6>"),
     (["-vhs", "-vhs-svideo", "1"], "k422_pipe_sv<4>"),
     (["-vhs", "-noise", "0", "-chroma-noise", "40"], "k422_pipe<false,4>"),
-    (["-vhs", "-vhs-head-switching-point", "0.85", "-noise", "9"], "k422_fused<true,true,4>"),   # a displacement beyond W/10: one wave
-    (["-vhs", "-tvstd", "pal"], "k422_fused<false,true,4>"),      # PAL: head-switch displacement beyond W/10 -> the one-wave form
+    (["-vhs", "-vhs-head-switching-point", "0.85", "-noise", "9"], "k422_pipe<true,4>"),   # a displacement beyond W/10: the gather's
+    (["-vhs", "-tvstd", "pal"], "k422_pipe<false,4>"),            # reach is the workgroup's own (up to the whole row)
     ([], "k422_direct_pipe"),                                     # no VCR: sweep A | gather | the decode sweep
 ])
 def test_synchronous_iteration_takes_the_role_form_and_equals_the_tool(flags, form):
