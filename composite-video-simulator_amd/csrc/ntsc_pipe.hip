@@ -726,7 +726,7 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
 // One workgroup = 63 rows + the halo row above, five wavefronts = five roles (see the head of this file).
 // Preconditions (launcher): the -vhs preset family of the hand-tuned kernels (input chroma low-pass on, no pre-emphasis, luma /
 // chroma / phase noise on, amplitudes 50 / 50, even scanline phase, output low-pass "lite", composite out), head-switch
-// displacement within W/10, 16-byte aligned rows, planes below 4 GiB, no ghosting.
+// displacement within W/10 (WR = false) or any (WR = true), 16-byte aligned rows, planes below 4 GiB, no ghosting.
 // WR: head-switch displacements of any size (wrap-around loads, wg_reach) -- e.g. PAL with its default switching point.
 template <class RT, bool WR = false>
 __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
