@@ -219,7 +219,7 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
 // ------------------------------------------------------------------------------------------------ the decoder roles
 // per-lane constants of the four decoder roles (every role fills what it reads; the rest is dead code)
 template <class RT, bool WR = false>
-DEV void dec_const(Const<RT, WR> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift)
+DEV void dec_const(Const<RT, WR> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift, bool sv = false)
 {
     const int W = P.W;
     C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
@@ -230,7 +230,8 @@ DEV void dec_const(Const<RT, WR> &C, const DevParams &P, const Row &R, const int
     C.xe = (W & 1) ? W - 1 : W - 2;
     C.lane = R.lane;
     C.d = P.cdelay;
-    C.SKT = 15 + C.d;                  // the depth of the whole decoder: every role runs k_decode_fast<true>'s positions
+    C.SKT = (sv ? 8 : 15) + C.d;       // the depth of the whole decoder: every role runs k_decode_fast<true>'s positions (S-Video out
+                                       // of the VCR, k_decode_fast_sv: no re-modulation / second separation, 7 stages fewer)
     C.LOFF = 5 + C.d;
     C.mL = opaque_v(C.hi ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
@@ -280,14 +281,14 @@ DEV int wg_reach(const DevParams &P, const int *hs_shift, int rc)
 
 // ------------------------------------------------------------------------------------------------ SEP: VCR, chroma front
 // vcr_step / vcr_edge up to the chroma noise: first separator at x1 = t - 7 (no luma out), U / V += noise, two draws
-template <class RT, bool WR>
+template <class RT, bool WR, bool SV = false>
 DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                   const int *__restrict__ n0_u, const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                   uint32_t *ring, lds_x2 ab, lds_flag fl)
 {
     typedef Const<RT, WR> CT;
     CT C;
-    dec_const<RT, WR>(C, P, R, comp, hs_shift);
+    dec_const<RT, WR>(C, P, R, comp, hs_shift, SV);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     DemodR D1;
     D1.init();
@@ -317,9 +318,9 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
     int t = 0;
     for (; t < SKT && t < total; t++) edge(t);
     const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
-    if (has_steady(W, C.d) && !(rng.pos & 7)) {
+    if (has_steady(W, C.d, SKT) && !(rng.pos & 7)) {
         DemodS S1;
-        S1.from(D1, (C.d & 1) != 0);              // x1 = t - 7 = d (mod 4) at the loop's first position
+        S1.from(D1, ((SKT - 7) & 1) != 0);        // x1 = t - 7 = SKT - 7 (mod 4) at the loop's first position
         int sbase = rng.pos;
         int pc[4];
         need_enc(t + 4 + reach);
@@ -355,7 +356,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
             NTSC_PIPE_SEP_STEP(DPH, 1, (void)0) NTSC_PIPE_SEP_STEP(DPH, 2, (void)0) NTSC_PIPE_SEP_STEP(DPH, 3, (void)0) \
             _Pragma("unroll") for (int j = 0; j < 4; j++) pc[j] = nc[j];                          \
         }
-        switch (C.d & 3) {
+        switch ((SKT - 7) & 3) {
             case 0: NTSC_PIPE_SEP_ITER(0) break;
             case 1: NTSC_PIPE_SEP_ITER(1) break;
             case 2: NTSC_PIPE_SEP_ITER(2) break;
@@ -364,7 +365,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
 #undef NTSC_PIPE_SEP_ITER
 #undef NTSC_PIPE_SEP_STEP
         publish(fl + F_AB_P, t);
-        S1.to(D1, (C.d & 1) != 0);
+        S1.to(D1, ((SKT - 7) & 1) != 0);
         rng.pos = sbase;
     }
     for (; t < total; t++) edge(t);
@@ -373,13 +374,14 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
 // ------------------------------------------------------------------------------------------------ CHR: VCR, chroma back
 // vcr_step / vcr_edge from the phase noise to the sign of the re-modulated chroma: what comes out is the term the
 // composite sample at x2 = t - 7 - d adds to its luma
-template <class RT>
+// SV (S-Video out of the VCR): no carrier -- both blended components go on, as they are (vcr_step's Uv, Vv)
+template <class RT, bool SV = false>
 DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const int *__restrict__ pn_noise,
-                     int *__restrict__ tails, lds_x2 ab, lds_x1 bc, lds_flag fl)
+                     int *__restrict__ tails, lds_x2 ab, lds_x2 bc, lds_flag fl)
 {
     typedef Const<RT, false> CT;
     CT C;
-    dec_const<RT>(C, P, R, nullptr, nullptr);
+    dec_const<RT>(C, P, R, nullptr, nullptr, SV);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     {
         int n = (R.rowok ? pn_noise[R.rc] : 0) + P.pnoise_k;
@@ -422,14 +424,14 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
             ch = (s & 1u) ? V : U;
             if (s & 2u) ch = -ch;
         }
-        bc[slot_of(t, SKT) * 64 + lane] = (uint32_t)ch;
+        bc[slot_of(t, SKT) * 64 + lane] = SV ? u32x2{(uint32_t)(in2 ? U : 0), (uint32_t)(in2 ? V : 0)} : u32x2{(uint32_t)ch, 0u};
         publish(fl + F_BC_P, t + 1);
         *(fl + F_AB_C) = (uint32_t)(t + 1);
     };
     int t = 0;
     for (; t < SKT && t < total; t++) edge(t);
     const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
-    if (has_steady(W, C.d)) {
+    if (has_steady(W, C.d, SKT)) {
 #define NTSC_PIPE_CHR_STEP(J, PRE)                                                                \
         {                                                                                         \
             const RT u = (RT)(int)in[J].x, v = (RT)(int)in[J].y;                                  \
@@ -438,10 +440,16 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
             const int fU = (int)vcU.push(Ud, C.a_vc);                                             \
             const int fV = (int)vcV.push(Vd, C.a_vc);                                             \
             /* x2 = J (mod 4): U for even J, sign by J & 2 (vcr_step); only the component that is modulated is blended */ \
-            const int f = ((J) & 1) ? fV : fU;                                                    \
-            const int chroma = ((wave_up(f) & C.bA) + f + C.bC) >> C.bC;                          \
-            const int mm = ((J) & 2) ? C.mNL : C.mL;                                              \
-            const uint32_t outv = (uint32_t)((chroma ^ mm) - mm);                                 \
+            u32x2 outv;                                                                           \
+            if constexpr (SV) {                                                                   \
+                outv = u32x2{(uint32_t)(((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC),              \
+                             (uint32_t)(((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC)};             \
+            } else {                                                                              \
+                const int f = ((J) & 1) ? fV : fU;                                                \
+                const int chroma = ((wave_up(f) & C.bA) + f + C.bC) >> C.bC;                      \
+                const int mm = ((J) & 2) ? C.mNL : C.mL;                                          \
+                outv = u32x2{(uint32_t)((chroma ^ mm) - mm), 0u};                                 \
+            }                                                                                     \
             PRE;                                                                                  \
             o[(J) * 64] = outv;                                                                   \
             NTSC_STEP_SCHED_BARRIER();                                                            \
@@ -450,7 +458,7 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
             wait_ge(fl + F_AB_P, t + 4, in_seen);
             wait_ge(fl + F_BC_C, t + 4 - RING, cons_seen);
             const lds_x2 ip = ab + slot_of(t, SKT) * 64 + lane;
-            const lds_x1 o = bc + slot_of(t, SKT) * 64 + lane;
+            const lds_x2 o = bc + slot_of(t, SKT) * 64 + lane;
             u32x2 in[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) in[j] = ip[j * 64];
@@ -468,13 +476,15 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
 // ------------------------------------------------------------------------------------------------ LUM: VCR luma + TV front
 // the luma path of vcr_step / vcr_edge (box at x2, VHS low-pass + emphasis, sharpen), the VCR's composite sample
 // c2 = Y + chroma term, and the TV's separator on it (step<true> / edge_step<true>: x3 = x2 - 7, dropout as the and-mask)
-template <class RT, bool WR>
+// SV: the VCR's luma and the blended chroma go to the TV's output stage as they are (x3 = x2: step<true> / edge_step<true>
+// with CT::svideo), dropout as the and-mask
+template <class RT, bool WR, bool SV = false>
 DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const int *__restrict__ hs_shift,
-                   const int *__restrict__ dropout, lds_x1 bc, lds_x4 cd, lds_flag fl)
+                   const int *__restrict__ dropout, lds_x2 bc, lds_x4 cd, lds_flag fl)
 {
     typedef Const<RT, WR> CT;
     CT C;
-    dec_const<RT, WR>(C, P, R, comp, hs_shift);
+    dec_const<RT, WR>(C, P, R, comp, hs_shift, SV);
     C.dm = opaque_v((P.loss && dropout[R.rc] != 0) ? 0 : -1);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT, LOFF = C.LOFF;
     DemodR D2;
@@ -492,11 +502,12 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
         const int xl = t - LOFF;
         if (xl >= 0) need_enc(xl + reach);
         const int pl = (xl >= 0 && xl < W) ? cs_load<2>(C, xl) : 0;
-        const int ch = (int)bc[slot_of(t, SKT) * 64 + lane];
+        const u32x2 chv = bc[slot_of(t, SKT) * 64 + lane];
+        const int ch = (int)chv.x;
         const int yb = sdiv4(l0 + l1 + l2 + pl);
         l0 = l1; l1 = l2; l2 = pl;
         const int x2 = t - 7 - C.d;
-        int c2 = 0;
+        int c2 = 0, Ysv = 0;
         if (x2 >= 0 && x2 < W) {
             RT m2;
             RT s = vl.push((RT)yb, C.a_vl, m2);                                     // :1793-1812
@@ -505,10 +516,17 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             const RT ts = sh.push(s0, C.a_sh);                                      // :1866-1883
             const int Y = (int)(s0 + ((s0 - ts) * C.sharp2));
             c2 = Y + ch;                                                            // :1885-1888
+            Ysv = Y;
         }
         int Y, U, V;
+        if constexpr (SV) {
+            // (vcr_edge hands Yv / Uv / Vv on, zero outside the row; the chroma role has zeroed its part)
+            Y = Ysv; U = (int)chv.x; V = (int)chv.y;
+            if (x2 >= W) { U = 0; V = 0; Y = 0; }
+        } else {
         D2.template push_edge<false, false>(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
         if (x2 - 7 >= W) { U = 0; V = 0; Y = 0; }
+        }
         U &= C.dm; V &= C.dm;                                                       // :1891-1901
         cd[slot_of(t, SKT) * 64 + lane] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};
         publish(fl + F_CD_P, t + 1);
@@ -517,7 +535,7 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
     int t = 0;
     for (; t < SKT && t < total; t++) edge(t);
     const int t_end = W - (C.d > 7 ? C.d - 7 : 0);
-    if (has_steady(W, C.d)) {
+    if (has_steady(W, C.d, SKT)) {
         DemodS S2;
         S2.from(D2, true);                        // x3 = 1 (mod 4) at the loop's first position: a pick
         S2.ieP &= C.dm; S2.qeP &= C.dm; S2.ieN &= C.dm; S2.qeN &= C.dm;     // (as steady(): the guarded steps mask their outputs)
@@ -536,10 +554,14 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             s += vpre.hp(s, m2, C.a_vl) * RT(1.6);                                                \
             const RT s0 = rtrunc<RT>(s);                                                          \
             const RT ts = sh.push(s0, C.a_sh);                                                    \
-            const int c2 = (int)(s0 + ((s0 - ts) * C.sharp2)) + (int)in[J];                       \
-            constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;             \
+            const int Yl = (int)(s0 + ((s0 - ts) * C.sharp2));                                    \
             int Y, U, V;                                                                          \
-            S2.template push<pick3, neg3, true, false, true, false>(c2, C.hi, C.dm, Y, U, V);     \
+            if constexpr (SV) { Y = Yl; U = (int)in[J].x & C.dm; V = (int)in[J].y & C.dm; }       \
+            else {                                                                                \
+                const int c2 = Yl + (int)in[J].x;                                                 \
+                constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;         \
+                S2.template push<pick3, neg3, true, false, true, false>(c2, C.hi, C.dm, Y, U, V); \
+            }                                                                                     \
             PRE;                                                                                  \
             o[(J) * 64] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};                       \
             NTSC_STEP_SCHED_BARRIER();                                                            \
@@ -548,9 +570,9 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             need_enc(t + 8 - LOFF + reach);
             wait_ge(fl + F_BC_P, t + 4, in_seen);
             wait_ge(fl + F_CD_C, t + 4 - RING, cons_seen);
-            const lds_x1 ip = bc + slot_of(t, SKT) * 64 + lane;
+            const lds_x2 ip = bc + slot_of(t, SKT) * 64 + lane;
             const lds_x4 o = cd + slot_of(t, SKT) * 64 + lane;
-            uint32_t in[4];
+            u32x2 in[4];
             int nl[4];                                // (the next iteration's samples: as in SEP)
 #pragma unroll
             for (int j = 0; j < 4; j++) nl[j] = cs_load<2>(C, t + 4 + j - LOFF);
@@ -640,12 +662,12 @@ DEV void tvfront_role(const DevParams &P, const Row &R, const int *__restrict__ 
 // ------------------------------------------------------------------------------------------------ OUT: TV back
 // the output stage of step<true> / edge_step<true>: composite_lowpass_tv (delay 1), YIQ -> RGB for the previous position,
 // 16 pixels of 64 rows staged in LDS and stored as 64-byte bursts (steady()'s cooperative flush)
-template <class RT, bool VHS = true>
+template <class RT, bool VHS = true, bool SV = false>
 DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const unsigned long long *orow, uint32_t *drow,
                      lds_x4 cd, lds_flag fl)
 {
     // (the positions of the decoder in front: k_decode_fast<true> -- SKT = 15 + d -- or, default preset, k_decode_fast<false>: 8)
-    const int lane = R.lane, W = P.W, d = VHS ? P.cdelay : 0, SKT = VHS ? 15 + d : 8, total = W + SKT;
+    const int lane = R.lane, W = P.W, d = VHS ? P.cdelay : 0, SKT = VHS ? (SV ? 8 : 15) + d : 8, total = W + SKT;
     const RT a_tv = (RT)P.a_tv;
     Casc3<RT> oU, oV;
     oU.reset(0, a_tv); oV.reset(0, a_tv);
@@ -728,7 +750,8 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
 // chroma / phase noise on, amplitudes 50 / 50, even scanline phase, output low-pass "lite", composite out), head-switch
 // displacement within W/10 (WR = false) or any (WR = true), 16-byte aligned rows, planes below 4 GiB, no ghosting.
 // WR: head-switch displacements of any size (wrap-around loads, wg_reach) -- e.g. PAL with its default switching point.
-template <class RT, bool WR = false>
+// SV: the -vhs preset with S-Video out of the VCR (-vhs-svideo 1): k_decode_fast_sv's positions (8 + d deep).
+template <class RT, bool WR = false, bool SV = false>
 __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
                                                     const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                     int *__restrict__ comp,
@@ -745,7 +768,7 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];      // the pixel staging
     __shared__ unsigned long long orow[64];
     __shared__ __attribute__((aligned(16))) uint32_t ring_ab[RING * 64 * 2];
-    __shared__ __attribute__((aligned(16))) uint32_t ring_bc[RING * 64];
+    __shared__ __attribute__((aligned(16))) uint32_t ring_bc[RING * 64 * 2];
     __shared__ __attribute__((aligned(16))) uint32_t ring_cd[RING * 64 * 4];
     __shared__ uint32_t flags[F_COUNT];
 
@@ -769,13 +792,13 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     const lds_flag fl = (lds_flag)flags;
     const lds_x2 ab = (lds_x2)ring_ab;
-    const lds_x1 bc = (lds_x1)ring_bc;
+    const lds_x2 bc = (lds_x2)ring_bc;
     const lds_x4 cd = (lds_x4)ring_cd;
     if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
-    else if (role == 1) sep_role<RT, WR>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
-    else if (role == 2) chroma_role<RT>(P, G, R, pn_noise, tails, ab, bc, fl);
-    else if (role == 3) luma_role<RT, WR>(P, R, comp, hs_shift, dropout, bc, cd, fl);
-    else output_role<RT>(P, R, ostage, orow, drow, cd, fl);
+    else if (role == 1) sep_role<RT, WR, SV>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
+    else if (role == 2) chroma_role<RT, SV>(P, G, R, pn_noise, tails, ab, bc, fl);
+    else if (role == 3) luma_role<RT, WR, SV>(P, R, comp, hs_shift, dropout, bc, cd, fl);
+    else output_role<RT, true, SV>(P, R, ostage, orow, drow, cd, fl);
     if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;
     if (dbg && R.lane == 0) {      // NTSCSIM_PIPE_TIMING: start, end, ticks spent polling -- per workgroup and role
         unsigned long long *o = dbg + ((size_t)blockIdx.x * 5 + role) * 3;

@@ -751,7 +751,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() &&
                            enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                            !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && !c->split_vhs &&
-                           D.vhs && !D.svideo && D.cnoise_k && D.pnoise_k;
+                           D.vhs && D.cnoise_k && D.pnoise_k;      // (S-Video out of the VCR: the SV instantiation)
     // (head-switch displacements beyond W/10 -- PAL's default switching point -- take its wrap-around form; small_plane
     //  has been computed for the displacement range at hand)
     const bool pipe_wr = pipe_form && !hs_small;
@@ -778,11 +778,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         static const bool pipe_timing = std::getenv("NTSCSIM_PIPE_TIMING") != nullptr;
         static unsigned long long *dbg = nullptr;
         if (pipe_timing && !dbg) { HIPCHK(c, hipMalloc((void **)&dbg, (size_t)4096 * 15 * sizeof(unsigned long long))); }
-        note_kernel(c, pipe_wr ? (fast ? "k_field_pipe<float,true>" : "k_field_pipe<double,true>") : (fast ? "k_field_pipe<float>" : "k_field_pipe<double>"));
-#define NTSC_LAUNCH_PIPE(RT, WR)                                                                                                 \
-        hipLaunchKernelGGL((k_field_pipe<RT, WR>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p, \
+        const bool pipe_sv = D.svideo != 0;
+        note_kernel(c, pipe_sv ? (fast ? "k_field_pipe_sv<float>" : "k_field_pipe_sv<double>")
+                               : pipe_wr ? (fast ? "k_field_pipe<float,true>" : "k_field_pipe<double,true>") : (fast ? "k_field_pipe<float>" : "k_field_pipe<double>"));
+#define NTSC_LAUNCH_PIPE(RT, ...)                                                                                                \
+        hipLaunchKernelGGL((k_field_pipe<RT, __VA_ARGS__>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p, \
                            c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg, c->pipe_fault)
-        if (pipe_wr) { if (fast) NTSC_LAUNCH_PIPE(float, true); else NTSC_LAUNCH_PIPE(double, true); }
+        if (pipe_sv && pipe_wr) { if (fast) NTSC_LAUNCH_PIPE(float, true, true); else NTSC_LAUNCH_PIPE(double, true, true); }
+        else if (pipe_sv) { if (fast) NTSC_LAUNCH_PIPE(float, false, true); else NTSC_LAUNCH_PIPE(double, false, true); }
+        else if (pipe_wr) { if (fast) NTSC_LAUNCH_PIPE(float, true); else NTSC_LAUNCH_PIPE(double, true); }
         else { if (fast) NTSC_LAUNCH_PIPE(float, false); else NTSC_LAUNCH_PIPE(double, false); }
 #undef NTSC_LAUNCH_PIPE
         if (pipe_timing && dgrid.x <= 4096) {

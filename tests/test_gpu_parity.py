@@ -271,7 +271,7 @@ def test_host_frame_dropin_sequence():
     sim.close()
 
 
-_PIPE5, _PIPE3, _PIPE5W = "k_field_pipe<double>", "k_field_pipe_tv<double>", "k_field_pipe<double,true>"
+_PIPE5, _PIPE3, _PIPE5W, _PIPE5S = "k_field_pipe<double>", "k_field_pipe_tv<double>", "k_field_pipe<double,true>", "k_field_pipe_sv<double>"
 
 
 @pytest.mark.parametrize("flags,w,h,piped", [
@@ -290,7 +290,11 @@ _PIPE5, _PIPE3, _PIPE5W = "k_field_pipe<double>", "k_field_pipe_tv<double>", "k_
     (["-vhs", "-tvstd", "pal"], 720, 576, _PIPE5W),
     (["-vhs", "-vhs-head-switching-phase", "0.001"], 720, 486, _PIPE5W),
     (["-vhs", "-vhs-head-switching-phase", "0.003"], 720, 486, _PIPE5W), (["-vhs", "-vhs-head-switching-phase", "0.003"], 100, 60, _PIPE5W),
-    (["-vhs", "-vhs-svideo", "1"], 256, 100, None), (["-vhs", "-comp-phase", "90"], 256, 100, None),
+    # S-Video out of the VCR: no re-modulation, no second separation, 7 positions less deep
+    (["-vhs", "-vhs-svideo", "1"], 256, 100, _PIPE5S), (["-vhs", "-vhs-svideo", "1"], 720, 486, _PIPE5S),
+    (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "ep", "-chroma-dropout", "30000"], 360, 243, _PIPE5S),
+    (["-vhs", "-vhs-svideo", "1", "-tvstd", "pal"], 720, 576, _PIPE5S), (["-vhs", "-vhs-svideo", "1"], 20, 9, _PIPE5S),
+    (["-vhs", "-comp-phase", "90"], 256, 100, None),
     (["-comp-catv"], 256, 100, None),
 ])
 def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, w, h, piped):
