@@ -8,10 +8,11 @@
 //                                (:1793-1812, :1866-1888, :1497-1567, dropout :1891-1901)
 //     OUT   TV back              TV chroma low-pass, YIQ -> RGB, pixel stores  (:1399-1427, :1385-1396)
 //
-// A field is four lone wavefronts whichever way it is cut, and a lone wavefront issues one VALU instruction per ~5
-// cycles: the one-launch chain walks a row's ~235 instructions per pixel one after the other (encoder 97 us, VCR half
-// 209 us, TV half 107 us as lone kernels on one field: profiles/r06_sync_roles.txt); here five wavefronts walk
-// ~58 / 45 / 40 / 55 / 50 of them concurrently on the four SIMDs of one CU (SEP and CHR, the two lightest, share one).
+// A field is four lone wavefronts whichever way it is cut, and a lone wavefront gets one instruction of any kind through
+// per ~5.3 cycles: the one-launch chain walks a row's ~235 VALU instructions per pixel one after the other (encoder 97 us,
+// VCR half 209 us, TV half 107 us as lone kernels on one field); here five wavefronts walk 63 / 58 / 52 / 70 / 65
+// instructions per pixel concurrently on the four SIMDs of one CU (SEP and CHR share one): 146 us, the roles' clocks in
+// profiles/r06_sync_pipe.txt, DESIGN.md 1c.
 // It is only worth it while every workgroup has a CU to itself, so only the synchronous call and launches of at most
 // NTSC_PIPE_MAX_FIELDS fields from the host-frame entry points take it; long batches fill the chip with the
 // one-wave-per-63-rows kernels, which issue less in total.
