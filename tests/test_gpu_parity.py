@@ -320,6 +320,27 @@ def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, 
     sim.close()
 
 
+def test_a_launch_of_more_workgroups_than_the_chip_holds_equals_small_launches():
+    """700 fields (2,700 workgroups for 2,048 two-wave slots) in ONE launch == the same fields in launches of 50, byte for
+    byte: a workgroup that starts after its neighbours have finished must not see anything of theirs (the YUV422P tool's
+    in-place kernels did, through the halo row: tests/test_variant422.py; the BGRA tool reads frames it never writes)."""
+    import torch
+    w, h, n = 720, 486, 700
+    p = L.make_params(["-vhs"])
+    src = torch.from_numpy(np.stack([L.noise_frame(w, h, 40 + j) for j in range(4)])).cuda()
+    jobs = [((k // 2) % 4, k, (k & 1) ^ 1, k) for k in range(n)]
+    outs = []
+    for batch in (50, n):
+        sim = ntscsim.FieldSimulator(params=p)
+        dst = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        for a in range(0, n, batch):
+            sim.fields(src, dst, jobs[a:a + batch])
+        sim.sync()
+        sim.close()
+        outs.append(dst)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_a_hand_off_that_never_comes_is_an_error_not_a_hang():
     """The role kernels poll each other's counts in LDS.  A wait that can never be satisfied (here: the developer switch
     NTSCSIM_PIPE_ORDER leaves the chroma-back role out, so its ring is never drained) gives up after a bounded number of
