@@ -42,7 +42,11 @@ for seed in range(s0, s0 + n):
     pad = r.choice([0, 0, 4, 12, 16, 64])
     kind = r.choice(["pageable", "pinned", "pinned", "declared"])
     il, tff = r.choice([(0, 0), (1, 0), (1, 1)])
-    sim = ntscsim.FieldSimulator(params=p)
+    try:
+        sim = ntscsim.FieldSimulator(params=p)
+    except ntscsim.NtscsimError:
+        census["rejected switches"] += 1      # (outside the supported domain: ntscsim_params_validate)
+        continue
     o = L.OracleStream(p)
     rowb = w * 4 + pad
     nbytes = rowb * h
