@@ -162,6 +162,8 @@ rd += "| `%s_bench_to_composite.json`, `%s_kernel_stats_to_composite.csv`, `%s_p
 rd += "| `%s_kernel_stats_raw28.csv` | `rocprofv3 --kernel-trace --stats -- python tools/raw28_probe.py` | kernels of the raw-composite decoder on a 600-field capture (4 calls) |\n" % tag
 rd += "| `%s_bench_float.json`, `%s_kernel_stats_float.csv`, `%s_float_err.txt`, `%s_float_pmc.txt` | `python bench.py --mode float`, `tools/kstats.sh ... --mode float --inflight 1`, `tools/float_err.py`, `tools/fp_probe.sh` + FETCH_SIZE / WRITE_SIZE passes | (round 6) NTSCSIM_MODE_FLOAT, the all-float pipeline: bench line, kernel durations, error against the oracle per input class (max, share of pixels / channels that differ, mean signed difference, histogram), stall counters of its decoder forms (one wave: variant 10; two-role workgroup: variant 0) and its HBM bytes |\n" % (tag, tag, tag, tag)
 rd += "| `%s_sync_pipe.txt`, `%s_fuzz_pipe.txt` | `tools/sync_trace.sh`, `tools/fuzz_pipe.py` | (round 6) the synchronous call as a pipeline of wavefront roles (`k_field_pipe`, `k_field_pipe_tv`: DESIGN 1c): rate per preset and frame memory kind against the one-launch chain, rocprofv3 kernel / copy averages, the roles' clocks inside one call, `ntscsim_submit()` at depths 1-64 with and without the roles; the random sweep against the oracle |\n" % (tag, tag)
+rd += "| `%s_pipe_census.txt` | `tools/pipe_census.py` (no GPU) | instruction census of the role kernels' loops by class (VALU f64 / int, SALU, LDS, VMEM, waits) from the built object: a lone wavefront's time per iteration is its total count x ~5.3 cycles |\n" % tag
+rd += "| `%s_fuzz_long.txt` | the fuzz tools with larger counts | the last build's longer sweeps (role kernels 30,000 cases, host422 12,000 loops, submit 5,000 loops, the batch-size / concurrency probes) |\n" % tag
 rd += "| `%s_role_probe.txt` | `tools/role_probe.py` | (round 6) the synchronous one-field call: shipped chain, two-launch decoder, encoder + VCR half + TV half launched side by side with no dependency (`NTSCSIM_ROLE_PROBE=1`: the ceiling of a stage-pipelined form), and the float pipeline |\n" % tag
 rd += "| `r04_decode_census.txt`, `%s_loop_histograms.txt` | `tools/loop_census.py --hist` on `hipcc -S`; source accounting | where the VALU instructions of `k_decode_fast` go, stage by stage; what the round-4 diet removed; what was measured and not done (noise pre-pass, LDS luma ring, packed fp32) -- the kernel is unchanged since; opcode histograms of the steady loops of the hand-tuned decoder forms on this round's build |\n" % tag
 rd += "| `r04_fetch_calibration.txt` | `tools/fetch_calibrate.sh` (`tools/fetch_probe.hip`) | FETCH_SIZE / WRITE_SIZE against known byte counts for this library's access shapes: the factors `traffic.json` applies |\n"
