@@ -111,7 +111,7 @@ struct Row {
 DEV int slot_of(int t, int SKT) { return (t - SKT) & (RING - 1); }
 
 // ------------------------------------------------------------------------------------------------ ENC: encoder
-template <class RT>
+template <class RT, bool XA = false>
 DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                       int *__restrict__ comp, uint32_t *ring, uint32_t *ltile, lds_flag fl)
 {
@@ -129,9 +129,9 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
     C.lane = lane;
     C.mL = opaque_v((C.xi & 2u) ? -1 : 0);
     C.mNL = opaque_v(~C.mL);
-    C.odd = false;
+    C.odd = XA && (C.xi & 1u) != 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) C.ms[j] = 0;
+    for (int j = 0; j < 4; j++) C.ms[j] = XA ? opaque_v(((C.xi + (unsigned)j) & 2u) ? -1 : 0) : 0;
     C.a_i = (RT)P.a_in_i; C.a_q = (RT)P.a_in_q;
     C.a_pre = (RT)P.a_pre; C.pre_gain = (RT)P.pre_gain;
     C.rowbytes = P.Rpad * 4;
@@ -174,7 +174,7 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
                 rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
-                const int Y = step<J, RT, false, false>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]); \
+                const int Y = step<J, RT, false, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]);    \
                 __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
@@ -219,14 +219,20 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
 
 // ------------------------------------------------------------------------------------------------ the decoder roles
 // per-lane constants of the four decoder roles (every role fills what it reads; the rest is dead code)
-template <class RT, bool WR = false>
-DEV void dec_const(Const<RT, WR> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift, bool sv = false)
+template <class RT, bool WR = false, bool XA = false>
+DEV void dec_const(Const<RT, WR, false, false, XA> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift, bool sv = false)
 {
     const int W = P.W;
     C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
     C.bmul = 0; C.bshift = 0; C.odd = false; C.mo = 0;
     C.xi = scan_phase(P, R.y, R.fd->fieldno);
     C.hi = (C.xi & 2u) != 0;
+    if constexpr (XA) {        // scanline phases of either parity (-comp-phase 90 / 270, odd offsets): per-lane picks and signs
+        C.odd = (C.xi & 1u) != 0;
+        C.mo = opaque_v(C.odd ? -1 : 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) C.ms[j] = opaque_v(((C.xi + (unsigned)j) & 2u) ? -1 : 0);
+    }
     C.W = W;
     C.xe = (W & 1) ? W - 1 : W - 2;
     C.lane = R.lane;
@@ -282,14 +288,14 @@ DEV int wg_reach(const DevParams &P, const int *hs_shift, int rc)
 
 // ------------------------------------------------------------------------------------------------ SEP: VCR, chroma front
 // vcr_step / vcr_edge up to the chroma noise: first separator at x1 = t - 7 (no luma out), U / V += noise, two draws
-template <class RT, bool WR, bool SV = false>
+template <class RT, bool WR, bool SV = false, bool XA = false>
 DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                   const int *__restrict__ n0_u, const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                   uint32_t *ring, lds_x2 ab, lds_flag fl)
 {
-    typedef Const<RT, WR> CT;
+    typedef Const<RT, WR, false, false, XA> CT;
     CT C;
-    dec_const<RT, WR>(C, P, R, comp, hs_shift, SV);
+    dec_const<RT, WR, XA>(C, P, R, comp, hs_shift, SV);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     DemodR D1;
     D1.init();
@@ -306,7 +312,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
         wait_ge(fl + F_AB_C, t + 1 - RING, cons_seen);
         const int pc = t < W ? cs_load<2>(C, t) : 0;
         int Y, U, V;
-        D1.template push_edge<false, false>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+        D1.template push_edge<false, XA>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
         const int x1 = t - 7;
         if (x1 >= 0 && x1 < W) {
             U += nU; V += nV;                                                       // chroma noise :1719-1735
@@ -331,7 +337,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
         {                                                                                         \
             constexpr bool pick1 = (((DPH) + (J)) & 1) != 0, neg1 = (((DPH) + (J)) & 3) == 3;     \
             int Yd, U, V;                                                                         \
-            S1.template push<pick1, neg1, false, false, false, false>(pc[J], C.hi, -1, Yd, U, V); \
+            S1.template push<pick1, neg1, false, false, false, XA>(pc[J], C.hi, -1, Yd, U, V, 0, 0, C.odd, C.mo); \
             U += nU; V += nV;                                                                     \
             nU = sdiv2(nU + (int)umod31(rng.template draw<2 * (J)>(rb, rb0), P.m_cnoise) - P.cnoise_k);     \
             nV = sdiv2(nV + (int)umod31(rng.template draw<2 * (J) + 1>(rb, rb0), P.m_cnoise) - P.cnoise_k); \
@@ -376,13 +382,14 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
 // vcr_step / vcr_edge from the phase noise to the sign of the re-modulated chroma: what comes out is the term the
 // composite sample at x2 = t - 7 - d adds to its luma
 // SV (S-Video out of the VCR): no carrier -- both blended components go on, as they are (vcr_step's Uv, Vv)
-template <class RT, bool SV = false>
+// XA: the carrier's U / V role swaps on lanes with an odd scanline phase, its sign is per lane (vcr_step, CT::anyxi)
+template <class RT, bool SV = false, bool XA = false>
 DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const int *__restrict__ pn_noise,
                      int *__restrict__ tails, lds_x2 ab, lds_x2 bc, lds_flag fl)
 {
-    typedef Const<RT, false> CT;
+    typedef Const<RT, false, false, false, XA> CT;
     CT C;
-    dec_const<RT>(C, P, R, nullptr, nullptr, SV);
+    dec_const<RT, false, XA>(C, P, R, nullptr, nullptr, SV);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     {
         int n = (R.rowok ? pn_noise[R.rc] : 0) + P.pnoise_k;
@@ -446,9 +453,16 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
                 outv = u32x2{(uint32_t)(((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC),              \
                              (uint32_t)(((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC)};             \
             } else {                                                                              \
-                const int f = ((J) & 1) ? fV : fU;                                                \
-                const int chroma = ((wave_up(f) & C.bA) + f + C.bC) >> C.bC;                      \
-                const int mm = ((J) & 2) ? C.mNL : C.mL;                                          \
+                int chroma;                                                                       \
+                if constexpr (XA) {       /* (rows of one wavefront differ in parity: blend both, then pick per lane) */ \
+                    const int bU = ((wave_up(fU) & C.bA) + fU + C.bC) >> C.bC;                    \
+                    const int bV = ((wave_up(fV) & C.bA) + fV + C.bC) >> C.bC;                    \
+                    chroma = ((J) & 1) ? (C.odd ? bU : bV) : (C.odd ? bV : bU);                   \
+                } else {                                                                          \
+                    const int f = ((J) & 1) ? fV : fU;                                            \
+                    chroma = ((wave_up(f) & C.bA) + f + C.bC) >> C.bC;                            \
+                }                                                                                 \
+                const int mm = XA ? C.ms[(J) & 3] : (((J) & 2) ? C.mNL : C.mL);                   \
                 outv = u32x2{(uint32_t)((chroma ^ mm) - mm), 0u};                                 \
             }                                                                                     \
             PRE;                                                                                  \
@@ -479,13 +493,13 @@ DEV void chroma_role(const DevParams &P, const GeomDev &G, const Row &R, const i
 // c2 = Y + chroma term, and the TV's separator on it (step<true> / edge_step<true>: x3 = x2 - 7, dropout as the and-mask)
 // SV: the VCR's luma and the blended chroma go to the TV's output stage as they are (x3 = x2: step<true> / edge_step<true>
 // with CT::svideo), dropout as the and-mask
-template <class RT, bool WR, bool SV = false>
+template <class RT, bool WR, bool SV = false, bool XA = false>
 DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const int *__restrict__ hs_shift,
                    const int *__restrict__ dropout, lds_x2 bc, lds_x4 cd, lds_flag fl)
 {
-    typedef Const<RT, WR> CT;
+    typedef Const<RT, WR, false, false, XA> CT;
     CT C;
-    dec_const<RT, WR>(C, P, R, comp, hs_shift, SV);
+    dec_const<RT, WR, XA>(C, P, R, comp, hs_shift, SV);
     C.dm = opaque_v((P.loss && dropout[R.rc] != 0) ? 0 : -1);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT, LOFF = C.LOFF;
     DemodR D2;
@@ -525,7 +539,7 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             Y = Ysv; U = (int)chv.x; V = (int)chv.y;
             if (x2 >= W) { U = 0; V = 0; Y = 0; }
         } else {
-        D2.template push_edge<false, false>(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
+        D2.template push_edge<false, XA>(c2, x2, C.xi, C.hi, W, C.xe, Y, U, V);
         if (x2 - 7 >= W) { U = 0; V = 0; Y = 0; }
         }
         U &= C.dm; V &= C.dm;                                                       // :1891-1901
@@ -561,7 +575,7 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
             else {                                                                                \
                 const int c2 = Yl + (int)in[J].x;                                                 \
                 constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;         \
-                S2.template push<pick3, neg3, true, false, true, false>(c2, C.hi, C.dm, Y, U, V); \
+                S2.template push<pick3, neg3, true, false, true, XA>(c2, C.hi, C.dm, Y, U, V, 0, 0, C.odd, C.mo); \
             }                                                                                     \
             PRE;                                                                                  \
             o[(J) * 64] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};                       \
@@ -752,7 +766,8 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
 // displacement within W/10 (WR = false) or any (WR = true), 16-byte aligned rows, planes below 4 GiB, no ghosting.
 // WR: head-switch displacements of any size (wrap-around loads, wg_reach) -- e.g. PAL with its default switching point.
 // SV: the -vhs preset with S-Video out of the VCR (-vhs-svideo 1): k_decode_fast_sv's positions (8 + d deep).
-template <class RT, bool WR = false, bool SV = false>
+// XA: scanline phases of either parity (-comp-phase 90 / 270, odd -comp-phase-offset): k_encode_fast_xi / k_decode_fast_xi's forms.
+template <class RT, bool WR = false, bool SV = false, bool XA = false>
 __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
                                                     const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                     int *__restrict__ comp,
@@ -795,10 +810,10 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     const lds_x2 ab = (lds_x2)ring_ab;
     const lds_x2 bc = (lds_x2)ring_bc;
     const lds_x4 cd = (lds_x4)ring_cd;
-    if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
-    else if (role == 1) sep_role<RT, WR, SV>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
-    else if (role == 2) chroma_role<RT, SV>(P, G, R, pn_noise, tails, ab, bc, fl);
-    else if (role == 3) luma_role<RT, WR, SV>(P, R, comp, hs_shift, dropout, bc, cd, fl);
+    if (role == 0) encoder_role<RT, XA>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    else if (role == 1) sep_role<RT, WR, SV, XA>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
+    else if (role == 2) chroma_role<RT, SV, XA>(P, G, R, pn_noise, tails, ab, bc, fl);
+    else if (role == 3) luma_role<RT, WR, SV, XA>(P, R, comp, hs_shift, dropout, bc, cd, fl);
     else output_role<RT, true, SV>(P, R, ostage, orow, drow, cd, fl);
     if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;
     if (dbg && R.lane == 0) {      // NTSCSIM_PIPE_TIMING: start, end, ticks spent polling -- per workgroup and role

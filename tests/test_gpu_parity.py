@@ -294,7 +294,11 @@ _PIPE5, _PIPE3, _PIPE5W, _PIPE5S = "k_field_pipe<double>", "k_field_pipe_tv<doub
     (["-vhs", "-vhs-svideo", "1"], 256, 100, _PIPE5S), (["-vhs", "-vhs-svideo", "1"], 720, 486, _PIPE5S),
     (["-vhs", "-vhs-svideo", "1", "-vhs-speed", "ep", "-chroma-dropout", "30000"], 360, 243, _PIPE5S),
     (["-vhs", "-vhs-svideo", "1", "-tvstd", "pal"], 720, 576, _PIPE5S), (["-vhs", "-vhs-svideo", "1"], 20, 9, _PIPE5S),
-    (["-vhs", "-comp-phase", "90"], 256, 100, None),
+    # scanline phases of either parity: per-lane picks / signs / carrier roles in every role
+    (["-vhs", "-comp-phase", "90"], 256, 100, "k_field_pipe_xi<double>"), (["-vhs", "-comp-phase", "270"], 720, 486, "k_field_pipe_xi<double>"),
+    (["-vhs", "-comp-phase-offset", "1"], 360, 243, "k_field_pipe_xi<double>"), (["-vhs", "-comp-phase", "90", "-tvstd", "pal"], 720, 576, "k_field_pipe_xi<double>"),
+    (["-vhs", "-comp-phase", "90"], 21, 9, "k_field_pipe_xi<double>"),
+    (["-vhs", "-comp-phase", "90", "-vhs-svideo", "1"], 256, 100, None),
     (["-comp-catv"], 256, 100, None),
 ])
 def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, w, h, piped):
