@@ -111,7 +111,7 @@ struct Row {
 DEV int slot_of(int t, int SKT) { return (t - SKT) & (RING - 1); }
 
 // ------------------------------------------------------------------------------------------------ ENC: encoder
-template <class RT, bool XA = false>
+template <class RT, bool XA = false, bool PRE = false>
 DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                       int *__restrict__ comp, uint32_t *ring, uint32_t *ltile, lds_flag fl)
 {
@@ -148,7 +148,7 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
     S.fI[0] = S.fI[1] = 0;
 
     int t = 0;
-    for (; t < 4; t++) edge_step<RT, false, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < 4; t++) edge_step<RT, PRE, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
     if (t + 16 <= W) {
         CoopLoader L;
         L.begin(srow, ltile, lane);
@@ -174,7 +174,7 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
                 rgb_to_yiq256<RT>(cur[J], dY, Id_, Qd_);                                          \
                 Yn[J] = (int)dY;                                                                  \
                 if (J >= 12) { IdT[J & 3] = Id_; QdT[J & 3] = Qd_; }                              \
-                const int Y = step<J, RT, false, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]);    \
+                const int Y = step<J, RT, PRE, XA>(P, S, C, rb, rb0, Id_, Qd_, YX, IX, F[J]);      \
                 __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)soff, 0);           \
                 soff += (unsigned)C.rowbytes;                                                     \
             }
@@ -212,19 +212,19 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
         NTSC_PIPE_VMCNT(0);
         publish(fl + F_ENC, t - 4);
     }
-    for (; t < W + 4; t++) edge_step<RT, false, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < W + 4; t++) edge_step<RT, PRE, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
     NTSC_PIPE_VMCNT(0);
     publish(fl + F_ENC, W);
 }
 
 // ------------------------------------------------------------------------------------------------ the decoder roles
 // per-lane constants of the four decoder roles (every role fills what it reads; the rest is dead code)
-template <class RT, bool WR = false, bool XA = false>
-DEV void dec_const(Const<RT, WR, false, false, XA> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift, bool sv = false)
+template <class RT, bool WR = false, bool XA = false, bool BK = false>
+DEV void dec_const(Const<RT, WR, BK, false, XA> &C, const DevParams &P, const Row &R, const int *comp, const int *hs_shift, bool sv = false)
 {
     const int W = P.W;
     C.wrapoff = 0; C.wrapA = 0x3FFFFFFF; C.wrapS = 0;
-    C.bmul = 0; C.bshift = 0; C.odd = false; C.mo = 0;
+    C.bmul = BK ? P.m_amp_back.mul : 0; C.bshift = BK ? P.m_amp_back.shift : 0; C.odd = false; C.mo = 0;
     C.xi = scan_phase(P, R.y, R.fd->fieldno);
     C.hi = (C.xi & 2u) != 0;
     if constexpr (XA) {        // scanline phases of either parity (-comp-phase 90 / 270, odd offsets): per-lane picks and signs
@@ -288,14 +288,15 @@ DEV int wg_reach(const DevParams &P, const int *hs_shift, int rc)
 
 // ------------------------------------------------------------------------------------------------ SEP: VCR, chroma front
 // vcr_step / vcr_edge up to the chroma noise: first separator at x1 = t - 7 (no luma out), U / V += noise, two draws
-template <class RT, bool WR, bool SV = false, bool XA = false>
+// BK: the separated chroma is scaled by 50 / subcarrier_amplitude_back (the pre-emphasis presets raise it: k_decode_fast_bk)
+template <class RT, bool WR, bool SV = false, bool XA = false, bool BK = false>
 DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const uint32_t *__restrict__ rs_chroma,
                   const int *__restrict__ n0_u, const int *__restrict__ n0_v, const int *__restrict__ hs_shift,
                   uint32_t *ring, lds_x2 ab, lds_flag fl)
 {
-    typedef Const<RT, WR, false, false, XA> CT;
+    typedef Const<RT, WR, BK, false, XA> CT;
     CT C;
-    dec_const<RT, WR, XA>(C, P, R, comp, hs_shift, SV);
+    dec_const<RT, WR, XA, BK>(C, P, R, comp, hs_shift, SV);
     const int lane = R.lane, W = P.W, SKT = C.SKT, total = W + SKT;
     DemodR D1;
     D1.init();
@@ -312,7 +313,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
         wait_ge(fl + F_AB_C, t + 1 - RING, cons_seen);
         const int pc = t < W ? cs_load<2>(C, t) : 0;
         int Y, U, V;
-        D1.template push_edge<false, XA>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+        D1.template push_edge<BK, XA>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
         const int x1 = t - 7;
         if (x1 >= 0 && x1 < W) {
             U += nU; V += nV;                                                       // chroma noise :1719-1735
@@ -337,7 +338,7 @@ DEV void sep_role(const DevParams &P, const Row &R, const int *__restrict__ comp
         {                                                                                         \
             constexpr bool pick1 = (((DPH) + (J)) & 1) != 0, neg1 = (((DPH) + (J)) & 3) == 3;     \
             int Yd, U, V;                                                                         \
-            S1.template push<pick1, neg1, false, false, false, XA>(pc[J], C.hi, -1, Yd, U, V, 0, 0, C.odd, C.mo); \
+            S1.template push<pick1, neg1, false, BK, false, XA>(pc[J], C.hi, -1, Yd, U, V, C.bmul, C.bshift, C.odd, C.mo); \
             U += nU; V += nV;                                                                     \
             nU = sdiv2(nU + (int)umod31(rng.template draw<2 * (J)>(rb, rb0), P.m_cnoise) - P.cnoise_k);     \
             nV = sdiv2(nV + (int)umod31(rng.template draw<2 * (J) + 1>(rb, rb0), P.m_cnoise) - P.cnoise_k); \
@@ -767,7 +768,9 @@ DEV void output_role(const DevParams &P, const Row &R, uint32_t *ostage, const u
 // WR: head-switch displacements of any size (wrap-around loads, wg_reach) -- e.g. PAL with its default switching point.
 // SV: the -vhs preset with S-Video out of the VCR (-vhs-svideo 1): k_decode_fast_sv's positions (8 + d deep).
 // XA: scanline phases of either parity (-comp-phase 90 / 270, odd -comp-phase-offset): k_encode_fast_xi / k_decode_fast_xi's forms.
-template <class RT, bool WR = false, bool SV = false, bool XA = false>
+// CATV: the pre-emphasis presets (-comp-catv, -comp-catv2/3/4): composite pre-emphasis in the encoder role, the first
+// separator's 50 / subcarrier_amplitude_back -- k_encode_fast_pre / k_decode_fast_bk's forms.
+template <class RT, bool WR = false, bool SV = false, bool XA = false, bool CATV = false>
 __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, const FieldDev *__restrict__ fields,
                                                     const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                     int *__restrict__ comp,
@@ -810,8 +813,8 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     const lds_x2 ab = (lds_x2)ring_ab;
     const lds_x2 bc = (lds_x2)ring_bc;
     const lds_x4 cd = (lds_x4)ring_cd;
-    if (role == 0) encoder_role<RT, XA>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
-    else if (role == 1) sep_role<RT, WR, SV, XA>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
+    if (role == 0) encoder_role<RT, XA, CATV>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    else if (role == 1) sep_role<RT, WR, SV, XA, CATV>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
     else if (role == 2) chroma_role<RT, SV, XA>(P, G, R, pn_noise, tails, ab, bc, fl);
     else if (role == 3) luma_role<RT, WR, SV, XA>(P, R, comp, hs_shift, dropout, bc, cd, fl);
     else output_role<RT, true, SV>(P, R, ostage, orow, drow, cd, fl);

@@ -750,10 +750,13 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     static const bool pipe_env = !(std::getenv("NTSCSIM_PIPE") && std::getenv("NTSCSIM_PIPE")[0] == '0');
     // (odd scanline phases -- -comp-phase 90 / 270, odd offsets --: the XA instantiation, wrap-around loads whatever the displacement)
     const bool pipe_xa = !even_phase && !D.svideo && fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0);
-    const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() &&
-                           enc_preset && !c->no_fast_decode && (even_phase ? small_plane : pipe_xa) && D.src_al16 && D.ghost_taps == 0 &&
-                           !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && !c->split_vhs &&
-                           D.vhs && D.cnoise_k && D.pnoise_k;      // (S-Video out of the VCR: the SV instantiation)
+    // (the pre-emphasis presets -- composite pre-emphasis on, subcarrier_amplitude_back raised --: the CATV instantiation)
+    const bool pipe_catv = enc_preset_pre && D.amp_back != 50 && D.amp_back >= 2 && even_phase && !D.svideo &&
+                           fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0);
+    const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() && !c->no_fast_decode && D.src_al16 && D.ghost_taps == 0 &&
+                           !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.dst_al16 && !c->split_vhs && D.vhs && D.cnoise_k && D.pnoise_k &&
+                           (pipe_catv || (enc_preset && D.amp_back == 50 && (even_phase ? small_plane : pipe_xa)));
+                           // (S-Video out of the VCR: the SV instantiation)
     // (head-switch displacements beyond W/10 -- PAL's default switching point -- take its wrap-around form; small_plane
     //  has been computed for the displacement range at hand)
     const bool pipe_wr = pipe_form && !hs_small;
@@ -781,13 +784,15 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
         static unsigned long long *dbg = nullptr;
         if (pipe_timing && !dbg) { HIPCHK(c, hipMalloc((void **)&dbg, (size_t)4096 * 15 * sizeof(unsigned long long))); }
         const bool pipe_sv = D.svideo != 0;
-        note_kernel(c, !even_phase ? (fast ? "k_field_pipe_xi<float>" : "k_field_pipe_xi<double>")
+        note_kernel(c, pipe_catv ? (fast ? "k_field_pipe_catv<float>" : "k_field_pipe_catv<double>")
+                       : !even_phase ? (fast ? "k_field_pipe_xi<float>" : "k_field_pipe_xi<double>")
                        : pipe_sv ? (fast ? "k_field_pipe_sv<float>" : "k_field_pipe_sv<double>")
                                : pipe_wr ? (fast ? "k_field_pipe<float,true>" : "k_field_pipe<double,true>") : (fast ? "k_field_pipe<float>" : "k_field_pipe<double>"));
 #define NTSC_LAUNCH_PIPE(RT, ...)                                                                                                \
         hipLaunchKernelGGL((k_field_pipe<RT, __VA_ARGS__>), dgrid, dim3(320), 0, st, D, G, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p, \
                            c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->tails.p, order, dbg, c->pipe_fault)
-        if (!even_phase) { if (fast) NTSC_LAUNCH_PIPE(float, true, false, true); else NTSC_LAUNCH_PIPE(double, true, false, true); }
+        if (pipe_catv) { if (fast) NTSC_LAUNCH_PIPE(float, true, false, false, true); else NTSC_LAUNCH_PIPE(double, true, false, false, true); }
+        else if (!even_phase) { if (fast) NTSC_LAUNCH_PIPE(float, true, false, true); else NTSC_LAUNCH_PIPE(double, true, false, true); }
         else if (pipe_sv && pipe_wr) { if (fast) NTSC_LAUNCH_PIPE(float, true, true); else NTSC_LAUNCH_PIPE(double, true, true); }
         else if (pipe_sv) { if (fast) NTSC_LAUNCH_PIPE(float, false, true); else NTSC_LAUNCH_PIPE(double, false, true); }
         else if (pipe_wr) { if (fast) NTSC_LAUNCH_PIPE(float, true); else NTSC_LAUNCH_PIPE(double, true); }

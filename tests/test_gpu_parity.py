@@ -299,6 +299,11 @@ _PIPE5, _PIPE3, _PIPE5W, _PIPE5S = "k_field_pipe<double>", "k_field_pipe_tv<doub
     (["-vhs", "-comp-phase-offset", "1"], 360, 243, "k_field_pipe_xi<double>"), (["-vhs", "-comp-phase", "90", "-tvstd", "pal"], 720, 576, "k_field_pipe_xi<double>"),
     (["-vhs", "-comp-phase", "90"], 21, 9, "k_field_pipe_xi<double>"),
     (["-vhs", "-comp-phase", "90", "-vhs-svideo", "1"], 256, 100, None),
+    # the pre-emphasis presets with the VCR: composite pre-emphasis in the encoder role, 50 / subcarrier_amplitude_back in
+    # the first separator (k_encode_fast_pre / k_decode_fast_bk's forms)
+    (["-vhs", "-comp-catv"], 256, 100, "k_field_pipe_catv<double>"), (["-vhs", "-comp-catv2"], 720, 486, "k_field_pipe_catv<double>"),
+    (["-vhs", "-comp-catv3", "-tvstd", "pal"], 720, 576, "k_field_pipe_catv<double>"), (["-vhs", "-comp-catv4"], 360, 243, "k_field_pipe_catv<double>"),
+    (["-vhs", "-comp-catv"], 21, 9, "k_field_pipe_catv<double>"),
     (["-comp-catv"], 256, 100, None),
 ])
 def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, w, h, piped):

@@ -32,6 +32,7 @@ for seed in range(s0, s0 + n):
     if r.random() < 0.15: flags += ["-tvstd", "pal"]
     if r.random() < 0.1: flags += ["-vhs-svideo", "1"]
     if r.random() < 0.1: flags += ["-comp-phase", r.choice(["0", "90", "180", "270"])]
+    if len(sys.argv) > 3 and sys.argv[3] == "catv" and r.random() < 0.6: flags += [r.choice(["-comp-catv", "-comp-catv2", "-comp-catv3", "-comp-catv4"])]
     w = r.choice([16, 17, 20, 33, 36, 64, 100, 180, 256, 333, 360, 640, 720, 800]) if r.random() < 0.7 else r.randrange(16, 801)
     h = r.choice([2, 3, 9, 63, 64, 65, 126, 127, 128, 243, 244, 300]) if r.random() < 0.7 else r.randrange(2, 301)
     try:
@@ -77,7 +78,7 @@ for seed in range(s0, s0 + n):
             if not np.array_equal(got, exp) or sim.rng_pos != o.rng_pos:
                 bad.append((seed, flags, w, h, pad, kind, il, tff, "call %d" % k)); ok = False; break
         kern = sim.last_kernels()
-        census["k_field_pipe" if any("k_field_pipe" in x for x in kern) else ",".join(x for x in kern if "setup" not in x)] += 1
+        census[next((x for x in kern if "k_field_pipe" in x), None) or ",".join(x for x in kern if "setup" not in x)] += 1
         if pad and ok:
             padv = np.lib.stride_tricks.as_strided(base[w * 4:], shape=(h - 1, pad), strides=(rowb, 1))
             if not (padv == 0x5A).all(): bad.append((seed, "row padding written", flags, w, h, pad, kind))
