@@ -753,7 +753,9 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     // (the pre-emphasis presets -- composite pre-emphasis on, subcarrier_amplitude_back raised --: the CATV instantiation)
     const bool pipe_catv = enc_preset_pre && D.amp_back != 50 && D.amp_back >= 2 && even_phase && !D.svideo &&
                            fast_plane_ok((size_t)D.Rpad, W, D.hs ? 2 : 0);
-    const bool pipe_form = c->latency_form && pipe_env && n <= pipe_max_fields() && !c->no_fast_decode && D.src_al16 && D.ghost_taps == 0 &&
+    // NTSCSIM_PIPE_ALWAYS=1 (developer A/B switch): device-resident batches of any length take the role kernels too
+    static const bool pipe_always = std::getenv("NTSCSIM_PIPE_ALWAYS") && std::getenv("NTSCSIM_PIPE_ALWAYS")[0] == '1';
+    const bool pipe_form = (c->latency_form || pipe_always) && pipe_env && (pipe_always || n <= pipe_max_fields()) && !c->no_fast_decode && D.src_al16 && D.ghost_taps == 0 &&
                            !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.dst_al16 && !c->split_vhs && D.vhs && D.cnoise_k && D.pnoise_k &&
                            (pipe_catv || (enc_preset && D.amp_back == 50 && (even_phase ? small_plane : pipe_xa)));
                            // (S-Video out of the VCR: the SV instantiation)
