@@ -611,15 +611,24 @@ DEV void luma_role(const DevParams &P, const Row &R, const int *__restrict__ com
 // ------------------------------------------------------------------------------------------------ TVF: TV front, default preset
 // the decoder of the default preset (no VCR) up to its separator: step<false> / edge_step<false> of k_decode_fast<false>
 // without the output stage -- composite sample (head switching, if switched on without the VCR) -> Y, U, V at x3 = t - 7
-template <class RT>
+// CATV (the pre-emphasis presets without the VCR: k_encode_fast_pre in front): the separated chroma is scaled by
+// 50 / subcarrier_amplitude_back, then rotated by the row's chroma phase noise (:1736-1764; the presets switch it on) --
+// a rotation by cos = 1, sin = 0 when the noise is off: (int)((u * 1.0) - (v * 0.0)) = u
+template <class RT, bool CATV = false>
 DEV void tvfront_role(const DevParams &P, const Row &R, const int *__restrict__ comp, const int *__restrict__ hs_shift,
-                      const int *__restrict__ dropout, lds_x4 cd, lds_flag fl)
+                      const int *__restrict__ dropout, const int *__restrict__ pn_noise, const double *__restrict__ ptab,
+                      lds_x4 cd, lds_flag fl)
 {
-    typedef Const<RT, false> CT;
+    typedef Const<RT, false, CATV> CT;
     CT C;
-    dec_const<RT>(C, P, R, comp, hs_shift);
+    dec_const<RT, false, false, CATV>(C, P, R, comp, hs_shift);
     C.d = 0; C.SKT = 8;
     C.dm = opaque_v((P.loss && dropout[R.rc] != 0) ? 0 : -1);
+    if (CATV && P.pnoise_k) {
+        int n = (R.rowok ? pn_noise[R.rc] : 0) + P.pnoise_k;
+        n = n < 0 ? 0 : (n > 2 * P.pnoise_k ? 2 * P.pnoise_k : n);
+        C.cosv = (RT)ptab[2 * n]; C.sinv = (RT)ptab[2 * n + 1];
+    }
     const int lane = R.lane, W = P.W, SKT = 8, total = W + SKT;
     DemodR D1;
     D1.init();
@@ -631,8 +640,13 @@ DEV void tvfront_role(const DevParams &P, const Row &R, const int *__restrict__ 
         wait_ge(fl + F_CD_C, t + 1 - RING, cons_seen);
         const int pc = t < W ? cs_load<2>(C, t) : 0;
         int Y, U, V;
-        D1.template push_edge<false, false>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V);
+        D1.template push_edge<CATV, false>(pc, t, C.xi, C.hi, W, C.xe, Y, U, V, C.bmul, C.bshift);
         if (t - 7 >= W) { U = 0; V = 0; Y = 0; }
+        if constexpr (CATV) {                                                       // chroma phase noise :1748-1762
+            const RT u = (RT)U, v = (RT)V;
+            U = (int)((u * C.cosv) - (v * C.sinv));
+            V = (int)((u * C.sinv) + (v * C.cosv));
+        }
         U &= C.dm; V &= C.dm;                                                       // :1891-1901
         cd[slot_of(t, SKT) * 64 + lane] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};
         publish(fl + F_CD_P, t + 1);
@@ -651,7 +665,12 @@ DEV void tvfront_role(const DevParams &P, const Row &R, const int *__restrict__ 
         {                                                                                         \
             constexpr bool pick3 = (((J) + 1) & 1) != 0, neg3 = (((J) + 1) & 3) == 3;             \
             int Y, U, V;                                                                          \
-            S1.template push<pick3, neg3, true, false, true, false>(pc[J], C.hi, C.dm, Y, U, V);  \
+            S1.template push<pick3, neg3, true, CATV, true, false>(pc[J], C.hi, C.dm, Y, U, V, C.bmul, C.bshift); \
+            if constexpr (CATV) {                                                                 \
+                const RT u = (RT)U, v = (RT)V;                                                    \
+                U = (int)((u * C.cosv) - (v * C.sinv));                                           \
+                V = (int)((u * C.sinv) + (v * C.cosv));                                           \
+            }                                                                                     \
             PRE;                                                                                  \
             o[(J) * 64] = u32x4{(uint32_t)Y, (uint32_t)U, (uint32_t)V, 0u};                       \
             NTSC_STEP_SCHED_BARRIER();                                                            \
@@ -828,11 +847,14 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
 
 // The default preset (no VCR) as three roles: ENC | TVF | OUT (same workgroup shape, same hand-offs; the launcher's
 // preconditions are those of k_encode_fast / k_decode_fast<false>).
-template <class RT>
+// CATV: the pre-emphasis presets without the VCR (-comp-catv ... -comp-catv4): ENC with k_encode_fast_pre's steps, TVF
+// with 50 / subcarrier_amplitude_back and the chroma phase noise of those presets.
+template <class RT, bool CATV = false>
 __global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldDev *__restrict__ fields,
                                                        const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
                                                        int *__restrict__ comp, const int *__restrict__ hs_shift,
-                                                       const int *__restrict__ dropout, unsigned *__restrict__ fault)
+                                                       const int *__restrict__ dropout, const int *__restrict__ pn_noise,
+                                                       const double *__restrict__ ptab, unsigned *__restrict__ fault)
 {
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];
@@ -861,8 +883,8 @@ __global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldD
     __syncthreads();
     const lds_flag fl = (lds_flag)flags;
     const lds_x4 cd = (lds_x4)ring_cd;
-    if (role == 0) encoder_role<RT>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
-    else if (role == 1) tvfront_role<RT>(P, R, comp, hs_shift, dropout, cd, fl);
+    if (role == 0) encoder_role<RT, false, CATV>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    else if (role == 1) tvfront_role<RT, CATV>(P, R, comp, hs_shift, dropout, pn_noise, ptab, cd, fl);
     else output_role<RT, false>(P, R, ostage, orow, drow, cd, fl);
     if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;
 }

@@ -767,16 +767,24 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
                          enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                          !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->force_generic &&
                          !D.vhs && !D.cnoise_k && !D.pnoise_k;
-    if ((pipe_tv || pipe_form) && !c->pipe_fault) {
+    // ... and the pre-emphasis presets without the VCR (-comp-catv ... -comp-catv4; chroma phase noise on or off)
+    const bool pipe_tv_catv = c->latency_form && pipe_env && n <= pipe_max_fields() &&
+                              enc_preset_pre && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
+                              !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back != 50 && D.amp_back >= 2 && D.dst_al16 && hs_small &&
+                              !D.vhs && !D.cnoise_k;
+    if ((pipe_tv || pipe_tv_catv || pipe_form) && !c->pipe_fault) {
         HIPCHK(c, hipHostMalloc((void **)&c->pipe_fault, 64, hipHostMallocDefault));
         *c->pipe_fault = 0u;
     }
-    if (pipe_tv) {
-        note_kernel(c, fast ? "k_field_pipe_tv<float>" : "k_field_pipe_tv<double>");
-        if (fast) hipLaunchKernelGGL((k_field_pipe_tv<float>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                     c->hs_shift.p, c->dropout.p, c->pipe_fault);
-        else hipLaunchKernelGGL((k_field_pipe_tv<double>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p,
-                                c->hs_shift.p, c->dropout.p, c->pipe_fault);
+    if (pipe_tv || pipe_tv_catv) {
+        note_kernel(c, pipe_tv_catv ? (fast ? "k_field_pipe_tv_catv<float>" : "k_field_pipe_tv_catv<double>")
+                                    : (fast ? "k_field_pipe_tv<float>" : "k_field_pipe_tv<double>"));
+#define NTSC_LAUNCH_PIPE_TV(RT, CATV)                                                                                            \
+        hipLaunchKernelGGL((k_field_pipe_tv<RT, CATV>), dgrid, dim3(192), 0, st, D, fields_dev, c->rs_luma.p, c->n0_luma.p, c->comp.p, \
+                           c->hs_shift.p, c->dropout.p, c->pn_noise.p, G.ptab, c->pipe_fault)
+        if (pipe_tv_catv) { if (fast) NTSC_LAUNCH_PIPE_TV(float, true); else NTSC_LAUNCH_PIPE_TV(double, true); }
+        else { if (fast) NTSC_LAUNCH_PIPE_TV(float, false); else NTSC_LAUNCH_PIPE_TV(double, false); }
+#undef NTSC_LAUNCH_PIPE_TV
     } else if (pipe_form) {
         // (developer switch: which wavefront of the workgroup takes which role, one hex digit per wavefront -- ntsc_pipe.hip)
         static const unsigned order = std::getenv("NTSCSIM_PIPE_ORDER") ? (unsigned)std::strtoul(std::getenv("NTSCSIM_PIPE_ORDER"), nullptr, 16)
@@ -899,7 +907,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     hipLaunchKernelGGL((k_decode_fast<true, RT, true>), dgrid, dim3(64), 0, st, D, G, fields_dev, dec_in, \
                        c->rs_chroma.p, c->n0_u.p, c->n0_v.p, c->hs_shift.p, c->pn_noise.p,       \
                        c->dropout.p, c->tails.p); } while (0)
-    if (pipe_form || pipe_tv) {
+    if (pipe_form || pipe_tv || pipe_tv_catv) {
         // (encoder and decoder ran as one launch above)
     } else if (fp) {
         static const int fpv_env = std::getenv("NTSCSIM_FP_VARIANT") ? std::atoi(std::getenv("NTSCSIM_FP_VARIANT")) : -1;    // developer A/B switch
