@@ -160,6 +160,9 @@ struct ntscsim_ctx {
     // stream; the encoder waits for `ev_src` (launch_records)
     hipEvent_t ev_src = nullptr;
     bool src_pending = false;
+    // ntscsim_field422() / ntscsim_submit422(): the same for the YUV422P tool -- the engine's upload event (not owned);
+    // launch422 runs the per-field / per-row draws first and waits for it in front of the first kernel that reads pixels
+    hipEvent_t wait422_ev = nullptr;
     hipEvent_t ev_role[3] = {nullptr, nullptr, nullptr};      // NTSCSIM_ROLE_PROBE (timing probe, see launch_records)
 
     // profiling: five events per call (start | setup done | encode done | decode done | end),
@@ -1349,6 +1352,12 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
     c->kernels.clear();
     if (any_render) note_kernel(c, "k422_render");
     if (any_flt) note_kernel(c, "k422_bkey");
+    // the draws read no pixels: they go first, beside the host-frame engine's upload of the source (ntscsim_host422.hip)
+    launch_setup(c, D, G, fields_dev, n, st);
+    if (c->wait422_ev) {
+        HIPCHK(c, hipStreamWaitEvent(st, c->wait422_ev, 0));
+        c->wait422_ev = nullptr;
+    }
     if (any_render)
         hipLaunchKernelGGL(k422_render, dim3((unsigned)((2 * W + 255) / 256), (unsigned)D.Lslot, (unsigned)n),
                            dim3(256), 0, st, D, fields422_dev);
@@ -1357,7 +1366,6 @@ static int launch422(ntscsim_ctx *c, const Prep422 &P, const FieldDev *fields_de
                            dim3(256), 0, st, D, fields422_dev, p.black_key_level_feedback);
     if (Sc.halo)
         hipLaunchKernelGGL(k422_halo, dim3(pgrid.x - 1), dim3(256), 0, st, D, fields422_dev, Sc);
-    launch_setup(c, D, G, fields_dev, n, st);
     // (profiling slots: "setup" = render, black key and the per-field / per-row draws, "encode" is
     // empty, "decode" = the one kernel that does composite_video_process)
     if (evs) { HIPCHK(c, hipEventRecord(evs->e[1], st)); HIPCHK(c, hipEventRecord(evs->e[2], st)); }

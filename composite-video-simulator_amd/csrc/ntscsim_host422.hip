@@ -94,6 +94,7 @@ struct Host422Engine {
     CopyRec422 *crec = nullptr;                         // 6 per slot
     Out422Dev *orec = nullptr;                          // 1 per slot
     uint8_t *pads = nullptr;                            // [nslots][2 * L]
+    bool launch_for_wait = false;                       // h422_launch called from h422_wait_ticket: delivery on the ctx's stream
     hipStream_t s_up = nullptr, s_dn = nullptr;
     hipEvent_t ev_k = nullptr;
     // caller frames pinned in place (hipHostRegister, cached): the rows of frame / filter / encoder frame are written by
@@ -414,7 +415,10 @@ static int h422_wait_ticket(ntscsim_ctx *c, uint64_t ticket)
     if (ticket >= e->next_ticket) return NTSCSIM_E_ARG;
     int rc = NTSCSIM_OK;
     if (!e->pending.empty() && ticket >= e->pending.front().ticket) {
+        static const bool own_stream = std::getenv("NTSCSIM_SUBMIT422_DLVSTREAM") && std::getenv("NTSCSIM_SUBMIT422_DLVSTREAM")[0] == '1';   // developer A/B
+        e->launch_for_wait = !own_stream;
         const int r = h422_launch(c);
+        e->launch_for_wait = false;
         if (r != NTSCSIM_OK) rc = r;
     }
     while (!e->inflight.empty() && e->inflight.front().first <= ticket) {
@@ -448,9 +452,15 @@ static int h422_launch(ntscsim_ctx *c)
     const int W = e->W, H = e->H, W2 = W / 2;
     hipStream_t st = c->stream;
     // uploads of this launch's sources have been enqueued on the copy stream
+    // (the ctx's stream waits for them in front of its first kernel that reads pixels -- launch422: the padding bytes, the
+    //  records and the per-field / per-row draws run beside the upload)
     hipError_t er = hipEventRecord(e->ev_up, e->s_up);
-    if (er == hipSuccess) er = hipStreamWaitEvent(st, e->ev_up, 0);
     if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    static const bool early_wait = std::getenv("NTSCSIM_SUBMIT422_EARLYWAIT") && std::getenv("NTSCSIM_SUBMIT422_EARLYWAIT")[0] == '1';   // developer A/B
+    if (early_wait) {
+        er = hipStreamWaitEvent(st, e->ev_up, 0);
+        if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    }
 
     // Delivery by the kernels into pinned caller frames.  The iterations of a launch run concurrently, so of several that
     // write the same rows of the same caller frame (ONE persistent frame: every second field) only the LAST delivers them
@@ -576,9 +586,14 @@ static int h422_launch(ntscsim_ctx *c)
     }
     const uint64_t keep_pos = c->rng_pos;           // the stream advanced at submit; descriptors carry positions
     c->latency_form = true;             // (short launches take the role form of the streamed kernels: k422_pipe)
+    c->wait422_ev = early_wait ? nullptr : e->ev_up;
     int rc = ntscsim_fields422_device(c, descs.data(), n, W, H, st);
     c->latency_form = false;
     c->rng_pos = keep_pos;
+    if (c->wait422_ev) {                // (the call failed before its launches: nothing later on this stream may overtake the upload)
+        c->wait422_ev = nullptr;
+        (void)hipStreamWaitEvent(st, e->ev_up, 0);
+    }
     if (rc != NTSCSIM_OK) return finish(rc);
     if (two_pass) {
         hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, st, e->prec + s0);
@@ -594,10 +609,14 @@ static int h422_launch(ntscsim_ctx *c)
     // behind the batch's kernels: the NEXT launch's kernels do not wait for it (batched iterations own their device frames
     // and delivery records).  An iteration on a mirror is different: the next one modifies the rows this one delivers from,
     // so the ctx's stream waits for its delivery (below).
-    hipStream_t sd = e->s_dn;
-    er = hipEventRecord(e->ev_k, st);
-    if (er == hipSuccess) er = hipStreamWaitEvent(sd, e->ev_k, 0);
-    if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    // (a launch made because the caller is about to wait for it -- the synchronous call, a wait on a pending ticket --
+    //  delivers on the ctx's stream itself: nothing comes behind it, and the hop between streams costs ~10 us)
+    hipStream_t sd = e->launch_for_wait ? st : e->s_dn;
+    if (sd != st) {
+        er = hipEventRecord(e->ev_k, st);
+        if (er == hipSuccess) er = hipStreamWaitEvent(sd, e->ev_k, 0);
+        if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    }
     DevParams D;
     std::memset(&D, 0, sizeof(D));
     D.W = W; D.H = H; D.variant = 1;
@@ -618,7 +637,7 @@ static int h422_launch(ntscsim_ctx *c)
     if (er == hipSuccess && run0 < n && dn_need)
         er = hipMemcpy2DAsync(e->hdn, e->dbytes, e->ddn.p, e->dbytes, dn_need, (size_t)(n - run0), hipMemcpyDeviceToHost, sd);
     if (er == hipSuccess) er = hipEventRecord(b.done, sd);
-    if (er == hipSuccess && b.items.front().serial) er = hipStreamWaitEvent(st, b.done, 0);
+    if (er == hipSuccess && b.items.front().serial && sd != st) er = hipStreamWaitEvent(st, b.done, 0);
     if (er != hipSuccess) { c->err = std::string("submit422 D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;
     e->stats[1]++;
@@ -839,7 +858,12 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
     e->stats[0]++;
     e->stats[serial ? 4 : 3]++;
     if (ticket) *ticket = t;
-    if (serial) return h422_launch(c);
+    if (serial) {
+        e->launch_for_wait = sync_call;     // (ntscsim_field422(): the caller waits for this launch next)
+        rc = h422_launch(c);
+        e->launch_for_wait = false;
+        return rc;
+    }
     // a launch at `depth` iterations -- but not between the two fields of a pair (the second one shares the first
     // one's device frame while that is still pending)
     // (rings smaller than configured -- the byte budget -- hold fewer iterations: a launch and its successor must fit)
