@@ -215,11 +215,11 @@ DEV void copy_row422(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, int
     }
 }
 
-__global__ void k422_output(DevParams P, const Out422Dev *__restrict__ outs, int al4)
+// one row of output_frame's copy (a workgroup per row)
+DEV void output422_row(const DevParams &P, const Out422Dev &o, const unsigned y, int al4)
 {
-    const Out422Dev &o = outs[blockIdx.y];
     if (o.mode > OUT422_FRAME) return;                             // (a record of the host engine's ring with no output_frame)
-    const unsigned y = blockIdx.x, H = (unsigned)P.H;
+    const unsigned H = (unsigned)P.H;
     unsigned sy;
     if (o.mode == OUT422_INTERLACED420 || o.mode == OUT422_FRAME) sy = y;     // :1202-1203; :1158 the frame as it is
     else if (o.field) sy = y | 1u;                                 // 1, 1, 3, 3, ...  :1181-1184
@@ -235,6 +235,11 @@ __global__ void k422_output(DevParams P, const Out422Dev *__restrict__ outs, int
         for (int p = 1; p <= 2; p++)
             copy_row422(o.bob[p] + (size_t)o.bob_ls[p] * cy, o.frame[p] + (size_t)o.frame_ls[p] * sy,
                         P.W / 2, al4);
+}
+
+__global__ void k422_output(DevParams P, const Out422Dev *__restrict__ outs, int al4)
+{
+    output422_row(P, outs[blockIdx.y], blockIdx.x, al4);
 }
 
 // ------------------------------------------------------------------------------ the field

@@ -123,6 +123,7 @@ struct ntscsim_ctx {
     DevBuf<FieldDev> fields;
     DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v, comp, comp_ghost, comp_vcr, tails;
     DevBuf<Field422Dev> fields422;
+    DevBuf<uint8_t> recs422;           // ntscsim_fields422_device: [n] FieldDev + [n] Field422Dev, one upload
     DevBuf<uint32_t> scratch422;
     DevBuf<uint8_t> halo422;         // k422_halo: the input rows the halo lanes read (ntsc422_kernels.hip: halo_redirect)
     std::vector<Out422Dev> host_out422;
@@ -441,7 +442,7 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     c->geoms.clear();
     c->ptab.release(); c->fields.release(); c->hs_shift.release(); c->pn_noise.release();
     c->dropout.release(); c->n0_luma.release(); c->n0_u.release(); c->n0_v.release();
-    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->out422.release(); c->yuv.release(); c->scale.release(); c->scratch422.release(); c->halo422.release(); c->rs_luma.release(); c->rs_chroma.release();
+    c->comp.release(); c->comp_ghost.release(); c->comp_vcr.release(); c->tails.release(); c->fields422.release(); c->recs422.release(); c->out422.release(); c->yuv.release(); c->scale.release(); c->scratch422.release(); c->halo422.release(); c->rs_luma.release(); c->rs_chroma.release();
     c->fsrc.release(); c->fdst.release();
     for (auto &h : c->hslot) {
         h.dsrc.release(); h.ddst.release(); h.dyuv.release(); h.yrec.release(); h.draw.release(); h.srec.release();
@@ -1505,8 +1506,11 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     P.rng_end = c->rng_pos;
     int rc = prepare422(c, descs, n, W, H, P, host_fields, host_fields422);
     if (rc != NTSCSIM_OK) return rc;
-    HIPCHK(c, c->fields.ensure((size_t)n));
-    HIPCHK(c, c->fields422.ensure((size_t)n));
+    // (both record arrays lie back to back in the staging buffer: one upload into one device buffer of the same layout)
+    static_assert(sizeof(FieldDev) % alignof(Field422Dev) == 0, "records back to back");
+    HIPCHK(c, c->recs422.ensure((size_t)n * rec_bytes));
+    FieldDev *const dev_fields = reinterpret_cast<FieldDev *>(c->recs422.p);
+    Field422Dev *const dev_fields422 = reinterpret_cast<Field422Dev *>(c->recs422.p + (size_t)n * sizeof(FieldDev));
     ntscsim_ctx::EvSet evs;
     const bool prof = c->profiling;
     if (prof) {
@@ -1514,15 +1518,13 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
         if (rc != NTSCSIM_OK) return rc;
         HIPCHK(c, hipEventRecord(evs.e[0], st));
     }
-    HIPCHK(c, hipMemcpyAsync(c->fields.p, host_fields, (size_t)n * sizeof(FieldDev), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->fields422.p, host_fields422, (size_t)n * sizeof(Field422Dev),
-                             hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->recs422.p, c->stage422[si], (size_t)n * rec_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipEventRecord(c->stage422_ev[si], st));
     c->stage422_used[si] = true;
     // (reading the records in the pinned staging buffer, as ntscsim_fields_device does for short launches, was measured
     //  SLOWER here -- 3.21k against 3.39k calls/s: seven kernels read them, not two)
 
-    rc = launch422(c, P, c->fields.p, c->fields422.p, st, prof ? &evs : nullptr);
+    rc = launch422(c, P, dev_fields, dev_fields422, st, prof ? &evs : nullptr);
     if (rc != NTSCSIM_OK) return rc;
     if (prof) c->ev_live.push_back(evs);
     c->rng_pos = P.rng_end;

@@ -43,11 +43,10 @@ struct PadRec422 {                // the two bytes behind every row of the field
                                   // (nobody writes it: the snapshot), pixel W + j - host_ls of the NEXT row otherwise
 };
 
-// grid (row chunks, records): copy nrows rows of rowbytes bytes; records with nrows == 0 are skipped
-__global__ void k422_rows(const CopyRec422 *__restrict__ recs)
+// copy nrows rows of rowbytes bytes, this workgroup the rows k0, k0 + step, ...; records with nrows == 0 are skipped
+__device__ __forceinline__ void rows422(const CopyRec422 r, int k0, int step)
 {
-    const CopyRec422 r = recs[blockIdx.y];
-    for (int k = blockIdx.x; k < r.nrows; k += gridDim.x) {
+    for (int k = k0; k < r.nrows; k += step) {
         const uint8_t *s = r.src + (size_t)k * (size_t)r.sp;
         uint8_t *d = r.dst + (size_t)k * (size_t)r.dp;
         if (!(((uintptr_t)s | (uintptr_t)d | (uintptr_t)r.rowbytes) & 3)) {
@@ -56,6 +55,24 @@ __global__ void k422_rows(const CopyRec422 *__restrict__ recs)
             for (int i = threadIdx.x; i < r.rowbytes / 4; i += blockDim.x) d4[i] = s4[i];
         } else
             for (int i = threadIdx.x; i < r.rowbytes; i += blockDim.x) d[i] = s[i];
+    }
+}
+
+// grid (row chunks, records)
+__global__ void k422_rows(const CopyRec422 *__restrict__ recs)
+{
+    rows422(recs[blockIdx.y], (int)blockIdx.x, (int)gridDim.x);
+}
+
+// output_frame's copy AND the rows of the field in one launch -- grid (H + 16 * 6, iterations): the first H workgroups of an
+// iteration take a row of k422_output each, the others are k422_rows' (16 row chunks x 6 records)
+__global__ void k422_deliver(ntscsim::DevParams P, const ntscsim::Out422Dev *__restrict__ outs, int al4, const CopyRec422 *__restrict__ recs)
+{
+    const unsigned H = (unsigned)P.H;
+    if (blockIdx.x < H) ntscsim::output422_row(P, outs[blockIdx.y], blockIdx.x, al4);
+    else {
+        const unsigned j = blockIdx.x - H;
+        rows422(recs[6u * blockIdx.y + (j >> 4)], (int)(j & 15u), 16);
     }
 }
 
@@ -122,6 +139,7 @@ struct Host422Engine {
         uint8_t *frm_dev[3] = {nullptr, nullptr, nullptr};    // device-visible addresses of the caller's planes when pinned
         uint8_t *flt_dev[3] = {nullptr, nullptr, nullptr};
         uint8_t *out_dev[3] = {nullptr, nullptr, nullptr};
+        uint8_t *src_dev[3] = {nullptr, nullptr, nullptr};    // ntscsim_field422(): pinned source planes, read in place (no snapshot)
         // set at launch -- how each of the three results reaches the caller: 0 through the staging record (copied at
         // ntscsim_wait), 1 written by the delivery kernels into the pinned frame, 2 not at all (a later iteration of the same
         // launch writes the same rows of the same pinned frame)
@@ -452,15 +470,10 @@ static int h422_launch(ntscsim_ctx *c)
     const int W = e->W, H = e->H, W2 = W / 2;
     hipStream_t st = c->stream;
     // uploads of this launch's sources have been enqueued on the copy stream
-    // (the ctx's stream waits for them in front of its first kernel that reads pixels -- launch422: the padding bytes, the
-    //  records and the per-field / per-row draws run beside the upload)
-    hipError_t er = hipEventRecord(e->ev_up, e->s_up);
-    if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    // (the ctx's stream waits for them in front of its first kernel that reads pixels -- launch422: the records and the
+    //  per-field / per-row draws run beside the upload; the event is recorded below, behind the padding bytes)
+    hipError_t er = hipSuccess;
     static const bool early_wait = std::getenv("NTSCSIM_SUBMIT422_EARLYWAIT") && std::getenv("NTSCSIM_SUBMIT422_EARLYWAIT")[0] == '1';   // developer A/B
-    if (early_wait) {
-        er = hipStreamWaitEvent(st, e->ev_up, 0);
-        if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
-    }
 
     // Delivery by the kernels into pinned caller frames.  The iterations of a launch run concurrently, so of several that
     // write the same rows of the same caller frame (ONE persistent frame: every second field) only the LAST delivers them
@@ -484,7 +497,7 @@ static int h422_launch(ntscsim_ctx *c)
         if (it.frm_how == 1 || it.out_how == 1 || it.flt_how == 1) e->stats[6]++;
     }
     std::vector<ntscsim_field422_desc> descs((size_t)n);
-    bool any_pad = false, any_out = false;
+    bool any_pad = false, any_out = false, any_chain = false;
     // TIGHT rows whose other field is written by an iteration of THIS launch: the bytes behind their rows -- pixels 0, 1 of
     // the neighbouring rows -- exist only after that iteration has run.  Nothing an iteration computes for pixels 0, 1
     // of a row depends on the bytes behind ANY row (the separator's read :496 reaches the last positions of a row only;
@@ -512,7 +525,7 @@ static int h422_launch(ntscsim_ctx *c)
                 uint8_t *s = e->dsrc.p + e->sbytes * (size_t)it.sslot;
                 d.src_dev[k] = k == 0 ? s : s + (size_t)W * L.src_height + (k == 2 ? (size_t)W2 * src_crows : 0);
                 d.src_linesize[k] = k ? W2 : W;
-            }
+            } else if (it.src_dev[0]) { d.src_dev[k] = it.src_dev[k]; d.src_linesize[k] = L.src.linesize[k]; }
             if (it.mflt) { d.flt_dev[k] = it.mflt->dev.p + it.mflt->off[k]; d.flt_linesize[k] = it.mflt->ls[k]; }
         }
         d.src_height = L.src_height;
@@ -528,6 +541,7 @@ static int h422_launch(ntscsim_ctx *c)
         p.chain = (it.tight && it.chain_fslot >= 0) ? e->dfrm.p + e->fbytes * (size_t)it.chain_fslot + e->foff[0] : nullptr;
         p.chain_ls = e->lsd[0]; p.H = H; p.host_ls = L.frame.linesize[0]; p._pad = 0;
         if (it.tight && it.chain_fslot >= 0 && it.chain_ticket >= b.first) two_pass = true;
+        any_chain = any_chain || p.chain != nullptr;
         p.field = (int32_t)L.field; p.nrows = it.serial ? 0 : nr;
         any_pad = any_pad || !it.serial;
         // delivery: the field's rows of the frame (and of the filter frame) -> the delivery record
@@ -580,7 +594,17 @@ static int h422_launch(ntscsim_ctx *c)
     // slot runs: tickets are consecutive, slots = ticket mod nslots -> at most two runs
     const int s0 = b.items.front().slot;
     const int run0 = s0 + n <= e->ring ? n : e->ring - s0;
-    if (any_pad) {
+    // The padding bytes come out of the submit-time snapshot (pinned host memory): on the UPLOAD stream, behind the source
+    // and beside the draws -- unless a record chains on a device frame that kernels of the ctx's stream write (TIGHT rows).
+    const bool pad_up = any_pad && !any_chain && !early_wait;
+    if (pad_up) {
+        hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, e->s_up, e->prec + s0);
+        if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, e->s_up, e->prec);
+    }
+    er = hipEventRecord(e->ev_up, e->s_up);
+    if (er == hipSuccess && early_wait) er = hipStreamWaitEvent(st, e->ev_up, 0);
+    if (er != hipSuccess) { c->err = std::string("submit422 launch: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
+    if (any_pad && !pad_up) {
         hipLaunchKernelGGL(k422_pad, dim3((unsigned)run0), dim3(256), 0, st, e->prec + s0);
         if (run0 < n) hipLaunchKernelGGL(k422_pad, dim3((unsigned)(n - run0)), dim3(256), 0, st, e->prec);
     }
@@ -620,12 +644,19 @@ static int h422_launch(ntscsim_ctx *c)
     DevParams D;
     std::memset(&D, 0, sizeof(D));
     D.W = W; D.H = H; D.variant = 1;
+    static const bool one_deliver = !(std::getenv("NTSCSIM_SUBMIT422_DELIVER1") && std::getenv("NTSCSIM_SUBMIT422_DELIVER1")[0] == '0');   // developer A/B
+    if (any_out && one_deliver) {
+        // (the two copies read the same device frame and write different caller frames: one launch, side by side)
+        hipLaunchKernelGGL(k422_deliver, dim3((unsigned)H + 96u, (unsigned)run0), dim3(256), 0, sd, D, e->orec + s0, al4 ? 1 : 0, e->crec + 6 * (size_t)s0);
+        if (run0 < n) hipLaunchKernelGGL(k422_deliver, dim3((unsigned)H + 96u, (unsigned)(n - run0)), dim3(256), 0, sd, D, e->orec, al4 ? 1 : 0, e->crec);
+    } else {
     if (any_out) {
         hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)run0), dim3(256), 0, sd, D, e->orec + s0, al4 ? 1 : 0);
         if (run0 < n) hipLaunchKernelGGL(k422_output, dim3((unsigned)H, (unsigned)(n - run0)), dim3(256), 0, sd, D, e->orec, al4 ? 1 : 0);
     }
     hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * run0)), dim3(256), 0, sd, e->crec + 6 * (size_t)s0);
     if (run0 < n) hipLaunchKernelGGL(k422_rows, dim3(16, (unsigned)(6 * (n - run0))), dim3(256), 0, sd, e->crec);
+    }
     er = hipGetLastError();
     if (er != hipSuccess) { c->err = std::string("submit422 kernels: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     if (flt_staged) { dn_need = e->dbytes; any_staged = true; }
@@ -807,7 +838,14 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
         }
     }
     // ---- source snapshot
+    // (the SYNCHRONOUS call returns when its iteration is done: pinned source planes need no snapshot -- k422_render reads
+    //  them where they are, 0.7 MB over the link instead of a memcpy on the calling thread + a DMA of the same bytes)
+    static const bool sync_direct = !(std::getenv("NTSCSIM_FIELD422_SRCDIRECT") && std::getenv("NTSCSIM_FIELD422_SRCDIRECT")[0] == '0');   // developer A/B
+    if (have_src && sync_call && sync_direct && h422_pin_frame(c, e, L->src, W, L->src_height, (int)src_crows, it.src_dev)) {
+        e->src_cur = -1;                  // (no device copy of this source: a later SAME_SRC submit takes its own)
+    } else
     if (have_src) {
+        for (int k = 0; k < 3; k++) it.src_dev[k] = nullptr;
         int sslot = e->src_cur;
         if (!(flags & NTSCSIM_SUBMIT_SAME_SRC) || sslot < 0) {
             sslot = (int)(e->src_ring_pos % (uint64_t)e->ring);
@@ -882,8 +920,10 @@ extern "C" int ntscsim_field422(ntscsim_ctx *c, const ntscsim_loop422 *L)
 {
     uint64_t t = 0;
     int rc = h422_submit(c, L, 0, &t, true);
-    if (rc != NTSCSIM_OK) return rc;
-    return h422_wait_ticket(c, t);
+    if (rc == NTSCSIM_OK) rc = h422_wait_ticket(c, t);
+    // (failed: a copy out of the caller's planes may still be in flight -- they are the caller's again when this returns)
+    if (rc != NTSCSIM_OK && c && c->h422 && c->h422->s_up) (void)hipStreamSynchronize(c->h422->s_up);
+    return rc;
 }
 
 extern "C" int ntscsim_submit422_configure(ntscsim_ctx *c, int depth, int slots)
