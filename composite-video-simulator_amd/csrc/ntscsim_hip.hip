@@ -161,6 +161,25 @@ struct ntscsim_ctx {
     // stream; the encoder waits for `ev_src` (launch_records)
     hipEvent_t ev_src = nullptr;
     bool src_pending = false;
+    // The SYNCHRONOUS calls (ntscsim_field / ntscsim_field422) run their NEXT call's setup kernel ahead of time: behind the
+    // event the caller waits for, while the host is on its way back into the library (speculate_setup).  What the kernel reads
+    // is the key; launch_setup skips its launch when the call that comes has exactly that key, and launches as ever otherwise.
+    struct SetupSpec {
+        bool have_last = false;          // D / G / field of the last latency-form launch of one field
+        DevParams D;
+        GeomDev G;
+        unsigned field = 0, field_before = 0;
+        bool armed = false, dry = false; // key below: launched ahead | only predicted (after misses)
+        hipStream_t st = nullptr;
+        const void *tab[8] = {};
+        unsigned kfield = 0;
+        uint32_t krng[61];
+        FieldDev *rec = nullptr;         // pinned: the record the early kernel reads
+        int misses = 0;
+        uint64_t hits = 0, launched = 0, seen = 0;
+    } spec;
+    const FieldDev *setup_host_rec = nullptr;   // host copy of record 0 of the launch being made (set by the entry points)
+    hipEvent_t ev_done = nullptr;               // ntscsim_field(): what the call waits for
     // ntscsim_field422() / ntscsim_submit422(): the same for the YUV422P tool -- the engine's upload event (not owned);
     // launch422 runs the per-field / per-row draws first and waits for it in front of the first kernel that reads pixels
     hipEvent_t wait422_ev = nullptr;
@@ -451,6 +470,11 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
         if (h.down) (void)hipEventDestroy(h.down);
     }
     if (c->ev_src) (void)hipEventDestroy(c->ev_src);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->spec.rec) (void)hipHostFree(c->spec.rec);
+    if (std::getenv("NTSCSIM_SETUP_AHEAD_STATS") && c->spec.seen)       // developer probe
+        std::fprintf(stderr, "setup ahead: %llu single-field launches, %llu early kernels, %llu used\n",
+                     (unsigned long long)c->spec.seen, (unsigned long long)c->spec.launched, (unsigned long long)c->spec.hits);
     for (auto &e_ : c->ev_role) if (e_) (void)hipEventDestroy(e_);
     if (c->s_up) (void)hipStreamDestroy(c->s_up);
     if (c->s_dn) (void)hipStreamDestroy(c->s_dn);
@@ -546,28 +570,96 @@ extern "C" void ntscsim_debug_set_warmup(ntscsim_ctx *c, int luma_draws, int chr
 #ifndef NTSC_SETUP_MERGE_MAX
 #define NTSC_SETUP_MERGE_MAX 64      /* fields; 0 = always two launches (A/B) */
 #endif
-static void launch_setup(ntscsim_ctx *c, const DevParams &D, const GeomDev &G, const FieldDev *fields_dev, int n, hipStream_t st)
+static void launch_setup_kernels(ntscsim_ctx *c, const DevParams &D, const GeomDev &G, const FieldDev *fields_dev, int n, hipStream_t st,
+                                 bool note, bool launch)
 {
     const bool fs = D.hs || D.pnoise_k || D.loss, rs = D.noise_k || D.cnoise_k;
     if (fs && rs && n <= NTSC_SETUP_MERGE_MAX && !c->no_setup_merge) {
         const int nfs = 3 * n, nrs = (D.R + 63) / 64;      // (one block per field and part: head switch | phase noise | dropout)
-        note_kernel(c, "k_field_row_setup");
+        if (note) note_kernel(c, "k_field_row_setup");
+        if (launch)
         hipLaunchKernelGGL(k_field_row_setup, dim3((unsigned)(nfs + 2 * nrs)), dim3(64), 0, st, D, G, fields_dev,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p,
                            c->n0_u.p, c->n0_v.p, nfs, nrs);
         return;
     }
     if (fs) {
-        note_kernel(c, "k_field_setup");
+        if (note) note_kernel(c, "k_field_setup");
+        if (launch)
         hipLaunchKernelGGL(k_field_setup, dim3((n + 63) / 64), dim3(64), 0, st, D, G, fields_dev,
                            c->hs_shift.p, c->pn_noise.p, c->dropout.p);
     }
     if (rs) {
-        note_kernel(c, "k_row_states");
+        if (note) note_kernel(c, "k_row_states");
+        if (launch)
         hipLaunchKernelGGL(k_row_states, dim3((D.R + 63) / 64, 2), dim3(64), 0, st, D, G,
                            fields_dev, c->rs_luma.p, c->n0_luma.p, c->rs_chroma.p, c->n0_u.p,
                            c->n0_v.p);
     }
+}
+
+static void setup_tables(const ntscsim_ctx *c, const void *t[8])
+{
+    t[0] = c->hs_shift.p; t[1] = c->pn_noise.p; t[2] = c->dropout.p; t[3] = c->rs_luma.p;
+    t[4] = c->n0_luma.p; t[5] = c->rs_chroma.p; t[6] = c->n0_u.p; t[7] = c->n0_v.p;
+}
+
+static void launch_setup(ntscsim_ctx *c, const DevParams &D, const GeomDev &G, const FieldDev *fields_dev, int n, hipStream_t st)
+{
+    ntscsim_ctx::SetupSpec &sp = c->spec;
+    const FieldDev *hr = c->setup_host_rec;
+    c->setup_host_rec = nullptr;
+    bool skip = false;
+    if (sp.armed || sp.dry) {
+        // the early launch's key against this call's: everything the setup kernels read, and where they write
+        const void *t[8];
+        setup_tables(c, t);
+        const bool same = hr && n == 1 && c->latency_form && st == sp.st && !std::memcmp(&D, &sp.D, sizeof(D)) &&
+                          !std::memcmp(&G, &sp.G, sizeof(G)) && !std::memcmp(t, sp.tab, sizeof(t)) &&
+                          (hr->field & 1u) == sp.kfield && !std::memcmp(hr->rng, sp.krng, sizeof(sp.krng));
+        if (same) { sp.misses = 0; if (sp.armed) { skip = true; sp.hits++; } }
+        else if (c->latency_form && n == 1) sp.misses++;
+        // (a launch on ANOTHER stream must not meet the early kernel in the tables)
+        if (sp.armed && st != sp.st) (void)hipStreamSynchronize(sp.st);
+        sp.armed = sp.dry = false;           // (whatever runs now rewrites the tables)
+    }
+    launch_setup_kernels(c, D, G, fields_dev, n, st, true, !skip);
+    sp.have_last = false;
+    if (hr && n == 1 && c->latency_form) {
+        sp.have_last = true;
+        sp.D = D; sp.G = G; sp.st = st;
+        sp.field_before = sp.field;
+        sp.field = hr->field & 1u;
+        sp.seen++;
+    }
+}
+
+// Behind a synchronous call's last operation (and the event its caller waits for): the setup kernel of the call that is
+// expected next -- same switches and geometry, the field parity continuing the pattern of the last two calls, the rand()
+// stream where this call left it.  NTSCSIM_SETUP_AHEAD=0: A/B switch.
+static void speculate_setup(ntscsim_ctx *c, hipStream_t st)
+{
+    static const bool on = !(std::getenv("NTSCSIM_SETUP_AHEAD") && std::getenv("NTSCSIM_SETUP_AHEAD")[0] == '0');
+    ntscsim_ctx::SetupSpec &sp = c->spec;
+    if (!on || !sp.have_last || st != sp.st || sp.armed) return;
+    sp.have_last = false;
+    if (!sp.rec && hipHostMalloc((void **)&sp.rec, sizeof(FieldDev), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); sp.rec = nullptr; return; }
+    FieldDev r;
+    std::memset(&r, 0, sizeof(r));
+    // the parity alternates if the last two calls' did (or there is one call only), repeats otherwise
+    r.field = (sp.seen < 2 || sp.field != sp.field_before) ? sp.field ^ 1u : sp.field;
+    const RandState s = ctx_state_at(c, c->rng_pos);
+    std::memcpy(r.rng, s.w, sizeof(s.w));
+    for (int j = 31; j < 61; j++) r.rng[j] = r.rng[j - 31] + r.rng[j - 3];
+    sp.kfield = r.field & 1u;
+    std::memcpy(sp.krng, r.rng, sizeof(sp.krng));
+    setup_tables(c, sp.tab);
+    if (sp.misses >= 2) { sp.dry = true; return; }      // (mispredicted twice: predict only, until a prediction holds again)
+    *sp.rec = r;
+    launch_setup_kernels(c, sp.D, sp.G, sp.rec, 1, st, false, true);
+    (void)hipGetLastError();
+    sp.armed = true;
+    sp.launched++;
 }
 
 // ---- step 1: descriptors -> device records.  The rand() window of every field is computed on
@@ -1074,7 +1166,9 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
         HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
     }
     c->stage_used[si] = true;
+    c->setup_host_rec = c->stage[si];
     rc = launch_records(c, D, inplace ? c->stage[si] : c->fields.p, any_bob, st, prof ? &evs : nullptr);
+    c->setup_host_rec = nullptr;
     if (inplace) HIPCHK(c, hipEventRecord(c->stage_ev[si], st));
     if (rc != NTSCSIM_OK) return rc;
     if (prof) c->ev_live.push_back(evs);
@@ -1524,7 +1618,9 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     // (reading the records in the pinned staging buffer, as ntscsim_fields_device does for short launches, was measured
     //  SLOWER here -- 3.21k against 3.39k calls/s: seven kernels read them, not two)
 
+    c->setup_host_rec = host_fields;
     rc = launch422(c, P, dev_fields, dev_fields422, st, prof ? &evs : nullptr);
+    c->setup_host_rec = nullptr;
     if (rc != NTSCSIM_OK) return rc;
     if (prof) c->ev_live.push_back(evs);
     c->rng_pos = P.rng_end;
@@ -1786,7 +1882,11 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
         HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)dst_ls * field, (size_t)dst_ls * 2,
                                    c->fdst.p + pitch * field, pitch * 2, (size_t)W * 4, (size_t)L,
                                    hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (the call waits for its own work only: the next call's setup kernel goes behind the event)
+    if (!c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ev_done, c->stream));
+    speculate_setup(c, c->stream);
+    HIPCHK(c, hipEventSynchronize(c->ev_done));
     if (c->pipe_fault && *c->pipe_fault) {
         c->err = "k_field_pipe: hand-off timed out in workgroup " + std::to_string(*c->pipe_fault - 1u);
         *c->pipe_fault = 0u;

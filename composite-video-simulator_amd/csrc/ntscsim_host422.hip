@@ -672,6 +672,8 @@ static int h422_launch(ntscsim_ctx *c)
     if (er != hipSuccess) { c->err = std::string("submit422 D2H: ") + hipGetErrorString(er); return finish(NTSCSIM_E_HIP); }
     b.launched_ok = true;
     e->stats[1]++;
+    // (the synchronous call: the next call's setup kernel behind the event this one waits for -- ntscsim_hip.hip)
+    if (e->launch_for_wait && n == 1 && sd == st) speculate_setup(c, st);
     if (any_staged) {
         std::vector<CopyOp> ops;
         h422_delivery_ops(e, b, ops);

@@ -333,6 +333,54 @@ def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, 
     sim.close()
 
 
+def test_the_setup_kernel_launched_ahead_is_used_only_by_the_call_it_was_made_for():
+    """ntscsim_field() launches the NEXT call's setup kernel behind its own work (speculate_setup: same switches and
+    geometry, the field parity continuing the pattern, the rand() stream where the call left it); the next call skips its
+    own launch only when everything that kernel read is what the call would hand it.  Sequences that break the
+    prediction -- the same field twice, a stream position set by the caller, a batch on the device entry point in between,
+    another geometry -- equal the oracle's call after call."""
+    import torch
+    w, h = 256, 100
+    p = L.make_params(["-vhs"])
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    got = np.full((h, w, 4), 0x5A, np.uint8)
+    exp = np.full((h, w, 4), 0x5A, np.uint8)
+    s = L.noise_frame(w, h, 7)
+
+    def call(field, k):
+        sim.field_host(got, s, field, k)
+        o.field(exp, s, field, k)
+        assert np.array_equal(got, exp), "call %d" % k
+        assert sim.rng_pos == o.rng_pos
+
+    k = 0
+    for field in (1, 0, 1, 0, 0, 0, 1, 1, 0, 1):                # alternating (predicted), repeats (mispredicted, then predicted)
+        call(field, k); k += 1
+    o.skip(12345); sim.rng_pos = sim.rng_pos + 12345           # the caller moves the stream: the early kernel's draws are stale
+    call(1, k); k += 1
+    call(0, k); k += 1
+    # a batch through the device entry point rewrites the tables between two synchronous calls
+    src_t = torch.from_numpy(np.stack([s])).cuda()
+    dst_t = torch.zeros((2, h, w, 4), dtype=torch.uint8, device="cuda")
+    sim.fields(src_t, dst_t, [(0, 0, 1, k), (0, 1, 0, k + 1)])
+    sim.sync()
+    e2 = np.zeros((2, h, w, 4), np.uint8)
+    o.field(e2[0], s, 1, k); o.field(e2[1], s, 0, k + 1)
+    assert np.array_equal(dst_t.cpu().numpy(), e2)
+    k += 2
+    call(1, k); k += 1
+    call(0, k); k += 1
+    # another geometry in between (other tables, other DevParams), then back
+    s2 = L.noise_frame(64, 40, 9)
+    g2 = np.zeros((40, 64, 4), np.uint8); x2 = np.zeros((40, 64, 4), np.uint8)
+    sim.field_host(g2, s2, 1, k); o.field(x2, s2, 1, k); k += 1
+    assert np.array_equal(g2, x2)
+    call(0, k); k += 1
+    call(1, k)
+    sim.close()
+
+
 def test_a_launch_of_more_workgroups_than_the_chip_holds_equals_small_launches():
     """700 fields (2,700 workgroups for 2,048 two-wave slots) in ONE launch == the same fields in launches of 50, byte for
     byte: a workgroup that starts after its neighbours have finished must not see anything of theirs (the YUV422P tool's
