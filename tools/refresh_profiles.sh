@@ -30,7 +30,8 @@ if [ "$mode" = gpu ]; then
   # the synchronous call: shipped chain, two-launch form, the three roles side by side (ceiling of a pipelined form), float
   timeout 300 python tools/role_probe.py > gpurun_out/role_probe_$tag.txt 2>&1
   # ... and the form that ships: the call as a pipeline of wavefront roles (rates, kernel trace, role clocks, submit by depth)
-  timeout 600 tools/sync_trace.sh $tag > /dev/null 2>&1             # -> gpurun_out/sync_$tag.txt
+  timeout 900 tools/sync_trace.sh $tag > /dev/null 2>&1             # -> gpurun_out/sync_$tag.txt
+  timeout 300 bash tools/sync422_trace.sh > /dev/null 2>&1          # -> gpurun_out/sync422_timeline.txt
   timeout 500 bash tools/pmc422.sh pmc422_$tag > /dev/null 2>&1
   timeout 250 tools/kstats.sh ks_${tag}_tocomp --tool to_composite --inflight 1 --steps 20 --sustain-seconds 0 > /dev/null
   timeout 600 python bench.py --tool to_composite --cpu-fields 200 > gpurun_out/bench_${tag}_tocomp.json 2>> gpurun_out/bench_$tag.err
@@ -82,6 +83,7 @@ else
   [ -s gpurun_out/float_pmc_$tag.txt ] && { cat gpurun_out/float_pmc_$tag.txt; echo; echo "== FETCH_SIZE / WRITE_SIZE (KiB, raw counters; calibration factors: profiles/r04_fetch_calibration.txt)"; cat gpurun_out/float_traffic_$tag.txt; } > profiles/${tag}_float_pmc.txt
   [ -s gpurun_out/role_probe_$tag.txt ] && cp gpurun_out/role_probe_$tag.txt profiles/${tag}_role_probe.txt
   [ -s gpurun_out/sync_$tag.txt ] && cp gpurun_out/sync_$tag.txt profiles/${tag}_sync_pipe.txt
+  [ -s gpurun_out/sync422_timeline.txt ] && cp gpurun_out/sync422_timeline.txt profiles/${tag}_sync422_timeline.txt
   # opcode histograms of the hand-tuned decoder forms' steady loops (the per-stage census: profiles/${tag}_decode_census.txt)
   { for k in 'k_decode_fastILb1EdLb0EE' 'k_decode_fast_xiIdE' 'k_decode_fast_foIdE' 'k_decode_fast_svIdE'; do
       echo "== $k"; (cd tools && python loop_census.py /tmp/census_$tag/ntscsim.s "$k" --hist | awk 'NR % 2 == 1 || 1' | cut -c1-1400 | grep -A1 "VALU [67][0-9][0-9] " | head -2); done; } > profiles/${tag}_loop_histograms.txt 2>/dev/null

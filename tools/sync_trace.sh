@@ -30,6 +30,25 @@ for k in ("kernel_stats", "memory_copy_stats"):
 PY
   done
 done
+echo "== the other switch sets on role kernels: fields/s, frames malloc | pinned, roles (one-launch chain)"
+for preset in "-vhs -tvstd pal" "-vhs -vhs-svideo 1" "-vhs -comp-phase 90" "-vhs -comp-catv" "-vhs -comp-catv3" "-comp-catv" "-comp-catv3"; do
+  line="   [$preset]"
+  for alloc in malloc pinned; do
+    a=$($FL $preset --mode sync --fields 1500 --warmup 100 --alloc $alloc 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
+    b=$(NTSCSIM_PIPE=0 $FL $preset --mode sync --fields 1500 --warmup 100 --alloc $alloc 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
+    line="$line  $alloc $a ($b)"
+  done
+  echo "$line"
+done
+echo "== the next call's setup kernel launched ahead of time (NTSCSIM_SETUP_AHEAD=0: off), -vhs, pinned frames: BGRA tool | YUV422P tool"
+FL4=$R/composite-video-simulator_amd/field_loop422
+for v in 1 0; do
+  a=$(NTSCSIM_SETUP_AHEAD=$v $FL -vhs --mode sync --fields 3000 --warmup 200 --alloc pinned 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
+  b=$(NTSCSIM_SETUP_AHEAD=$v $FL4 -vhs --mode sync --fields 3000 --warmup 200 --alloc pinned 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
+  echo "   ahead=$v: $a | $b"
+done
+NTSCSIM_SETUP_AHEAD_STATS=1 $FL -vhs --mode sync --fields 500 --warmup 20 2>&1 | grep "setup ahead" | sed 's/^/   BGRA tool: /'
+NTSCSIM_SETUP_AHEAD_STATS=1 $FL4 -vhs --mode sync --fields 500 --warmup 20 2>&1 | grep "setup ahead" | sed 's/^/   YUV422P tool: /'
 echo "== the roles' clocks inside one call (-vhs; 100 MHz wall clock from the workgroup's start; polling = time spent waiting for a hand-off)"
 NTSCSIM_PIPE_TIMING=1 $FL -vhs --mode sync --fields 150 --warmup 10 2>&1 | grep "pipe_timing wg" | head -20
 echo "== ntscsim_submit() at small depths, pinned frames, lag = depth: fields/s with the one-launch chain | with the roles"
