@@ -473,6 +473,8 @@ def test_pinned_planes_take_the_dma_and_kernel_delivery_paths(flags, out_mode, b
     st = ctx.stats()
     assert ctx.rng_pos == o.rng_pos
     assert st[6] >= 2 * n_src - (3 if mode == "submit" else 0)    # the delivery kernels wrote into the pinned planes
+    # the synchronous call reads pinned source planes where they are (no snapshot, no upload); the asynchronous one snapshots
+    assert st[2] == (0 if mode == "sync" else n_src)
     ctx.unpin()
     ctx.close()
     same_frames(frame_g, frame_o, "frame")
@@ -480,6 +482,42 @@ def test_pinned_planes_take_the_dma_and_kernel_delivery_paths(flags, out_mode, b
         same_frames(flt_g, flt_o, "filter frame")
     for i, (a, b) in enumerate(zip(got, exp)):
         same_out(a, b, h, out_mode, "encoder frame %d" % i)
+
+
+@pytest.mark.parametrize("src_flags,sh,spad", [(F_420, 486, 0), (F_IL | F_TFF, 480, 32), (0, 540, 16), (F_420 | F_IL, 480, 0)])
+def test_synchronous_call_reads_pinned_sources_of_other_shapes_in_place(src_flags, sh, spad):
+    """ntscsim_field422() on pinned source planes of the tool's other input shapes -- 4:2:0 chroma (half the rows),
+    interlaced sources, a source taller than the frame, padded source rows: k422_render reads them with the caller's own
+    linesizes (no snapshot, no upload: stats[2] stays 0), same bytes as the oracle's loop."""
+    w, h, n_src = 720, 480, 3
+    p = L.make_params_tocomp(["-vhs"])
+    srcs = [paged_noise(w, sh, 500 + j, spad) for j in range(n_src)]
+    for j, s_ in enumerate(srcs):
+        random_padding(s_, 40 + j)
+    frame_o = paged_noise(w, h, 5, 16)
+    random_padding(frame_o, 6)
+    frame_g = frame_o.copy()
+    o = L.TocompOracleStream(p, oob=L.OOB_PLANE)
+    ctx = Ctx(p)
+    exp, got = [], []
+    vf = 0
+    for s_ in srcs:
+        for sub in (0, 1):
+            field = (vf & 1) ^ 1
+            fl = src_flags | (F_SECOND if sub else 0)
+            eo, go = PagedYuv(w, h, 0, 7), PagedYuv(w, h, 0, 7)
+            oracle_iteration(o, p, frame_o, s_, field, vf, fl, None, eo, OUT_BOB422, field)
+            ctx.field(ctx.loop(frame_g, s_, field, vf, fl, None, go, OUT_BOB422, field, sh=sh))
+            exp.append(eo); got.append(go)
+            vf += 1
+    st = ctx.stats()
+    assert ctx.rng_pos == o.rng_pos
+    assert st[2] == 0, st
+    ctx.unpin()
+    ctx.close()
+    same_frames(frame_g, frame_o, "frame")
+    for i, (a, b) in enumerate(zip(got, exp)):
+        same_out(a, b, h, OUT_BOB422, "encoder frame %d" % i)
 
 
 def test_error_codes():
