@@ -10,6 +10,8 @@ echo '$ python tools/fuzz_float.py 90000 1500       # NTSCSIM_MODE_FLOAT: random
 timeout 1500 python tools/fuzz_float.py 90000 1500 2>&1 | grep -v amdgpu.ids | tail -8
 echo '$ python tools/fuzz_pipe.py 50000 6000      # ntscsim_field(): the five-role workgroup form (k_field_pipe) on random geometries / -vhs switch sets / frame memory kinds'
 timeout 900 python tools/fuzz_pipe.py 50000 6000 2>&1 | grep -v amdgpu.ids | head -8
+echo '$ python tools/fuzz_pipe.py 70000 4000 catv # the same with the pre-emphasis presets mixed in (k_field_pipe_catv, k_field_pipe_tv_catv)'
+timeout 900 python tools/fuzz_pipe.py 70000 4000 catv 2>&1 | grep -v amdgpu.ids | head -10
 echo '$ python tools/fuzz_more.py 150000 1000      # random switch sets / geometries / sources, both tools, exact mode'
 timeout 900 python tools/fuzz_more.py 150000 1000 2>&1 | grep -v amdgpu.ids | tail -3
 echo '$ python tools/fuzz_fullsize.py 19000 300    # 720x486 / 720x480, random switch sets, both tools, two fields each'
