@@ -859,7 +859,7 @@ static int launch_records(ntscsim_ctx *c, const DevParams &D, const FieldDev *fi
     //  has been computed for the displacement range at hand)
     const bool pipe_wr = pipe_form && !hs_small;
     // ... and the default preset (no VCR) as three roles: encoder | TV front | TV back
-    const bool pipe_tv = c->latency_form && pipe_env && n <= pipe_max_fields() &&
+    const bool pipe_tv = (c->latency_form || pipe_always) && pipe_env && (pipe_always || n <= pipe_max_fields()) &&
                          enc_preset && !c->no_fast_decode && even_phase && small_plane && D.src_al16 && D.ghost_taps == 0 &&
                          !D.nocolor && D.out_lp == 1 && D.amp == 50 && D.amp_back == 50 && D.dst_al16 && hs_small && !c->force_generic &&
                          !D.vhs && !D.cnoise_k && !D.pnoise_k;
