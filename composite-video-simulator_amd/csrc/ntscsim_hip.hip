@@ -174,7 +174,10 @@ struct ntscsim_ctx {
         const void *tab[8] = {};
         unsigned kfield = 0;
         uint32_t krng[61];
-        FieldDev *rec = nullptr;         // pinned: the record the early kernel reads
+        FieldDev *rec = nullptr;         // pinned, TWO records used in turn: the early kernel of the call before may still be
+                                         // reading its own while the host writes the next (it has finished once the call
+                                         // after it has been waited for -- the one before this one)
+        unsigned rec_idx = 0;
         int misses = 0;
         uint64_t hits = 0, launched = 0, seen = 0;
     } spec;
@@ -643,7 +646,7 @@ static void speculate_setup(ntscsim_ctx *c, hipStream_t st)
     ntscsim_ctx::SetupSpec &sp = c->spec;
     if (!on || !sp.have_last || st != sp.st || sp.armed) return;
     sp.have_last = false;
-    if (!sp.rec && hipHostMalloc((void **)&sp.rec, sizeof(FieldDev), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); sp.rec = nullptr; return; }
+    if (!sp.rec && hipHostMalloc((void **)&sp.rec, 2 * sizeof(FieldDev), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); sp.rec = nullptr; return; }
     FieldDev r;
     std::memset(&r, 0, sizeof(r));
     // the parity alternates if the last two calls' did (or there is one call only), repeats otherwise
@@ -655,8 +658,9 @@ static void speculate_setup(ntscsim_ctx *c, hipStream_t st)
     std::memcpy(sp.krng, r.rng, sizeof(sp.krng));
     setup_tables(c, sp.tab);
     if (sp.misses >= 2) { sp.dry = true; return; }      // (mispredicted twice: predict only, until a prediction holds again)
-    *sp.rec = r;
-    launch_setup_kernels(c, sp.D, sp.G, sp.rec, 1, st, false, true);
+    FieldDev *const slot = sp.rec + (sp.rec_idx ^= 1u);
+    *slot = r;
+    launch_setup_kernels(c, sp.D, sp.G, slot, 1, st, false, true);
     (void)hipGetLastError();
     sp.armed = true;
     sp.launched++;
