@@ -923,8 +923,11 @@ extern "C" int ntscsim_field422(ntscsim_ctx *c, const ntscsim_loop422 *L)
     uint64_t t = 0;
     int rc = h422_submit(c, L, 0, &t, true);
     if (rc == NTSCSIM_OK) rc = h422_wait_ticket(c, t);
-    // (failed: a copy out of the caller's planes may still be in flight -- they are the caller's again when this returns)
-    if (rc != NTSCSIM_OK && c && c->h422 && c->h422->s_up) (void)hipStreamSynchronize(c->h422->s_up);
+    // (failed: something that reads the caller's planes may still be in flight -- they are the caller's again when this returns)
+    if (rc != NTSCSIM_OK && c && c->h422 && c->h422->s_up) {
+        (void)hipStreamSynchronize(c->h422->s_up);
+        (void)hipStreamSynchronize(c->stream);       // (k422_render may have been queued on pinned source planes)
+    }
     return rc;
 }
 
