@@ -303,11 +303,12 @@ _PIPE5, _PIPE3, _PIPE5W, _PIPE5S = "k_field_pipe<double>", "k_field_pipe_tv<doub
     # the first separator (k_encode_fast_pre / k_decode_fast_bk's forms)
     (["-vhs", "-comp-catv"], 256, 100, "k_field_pipe_catv<double>"), (["-vhs", "-comp-catv2"], 720, 486, "k_field_pipe_catv<double>"),
     (["-vhs", "-comp-catv3", "-tvstd", "pal"], 720, 576, "k_field_pipe_catv<double>"), (["-vhs", "-comp-catv4"], 360, 243, "k_field_pipe_catv<double>"),
-    (["-vhs", "-comp-catv"], 21, 9, "k_field_pipe_catv<double>"),
+    (["-vhs", "-comp-catv"], 21, 9, "k_field_pipe_catv<double>"), (["-vhs", "-comp-catv3", "-vhs-speed", "ep"], 1920, 1080, "k_field_pipe_catv<double>"),
     # ... and without it: three roles, the TV front with the amplitude scale and the presets' chroma phase noise
     (["-comp-catv"], 256, 100, "k_field_pipe_tv_catv<double>"), (["-comp-catv2"], 720, 486, "k_field_pipe_tv_catv<double>"),
     (["-comp-catv3", "-tvstd", "pal"], 720, 576, "k_field_pipe_tv_catv<double>"), (["-comp-catv4", "-chroma-phase-noise", "0"], 360, 243, "k_field_pipe_tv_catv<double>"),
     (["-comp-catv", "-chroma-dropout", "20000", "-vhs-head-switching", "1"], 21, 9, "k_field_pipe_tv_catv<double>"),
+    (["-comp-catv2"], 1920, 1080, "k_field_pipe_tv_catv<double>"),
     (["-comp-catv", "-chroma-noise", "5"], 256, 100, None),
 ])
 def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, w, h, piped):
