@@ -208,6 +208,7 @@ struct ntscsim_ctx {
     // the host-frame entry points (ntscsim_field(), the submit engine's lanes) ask for the LATENCY form of short launches
     // (k_field_pipe, ntsc_pipe.hip); the device-pointer entry points keep the kernels their callers (and tests) name
     bool latency_form = false;
+    bool latency_pref = false;       // ntscsim_set_launch_form(): the device-pointer entry points' short launches take it too
     unsigned *pipe_fault = nullptr;  // pinned word the role kernels raise when a hand-off timed out (ntsc_pipe.hip); checked behind launches
 };
 static void declared_pins_destroy(ntscsim_ctx *c);
@@ -498,6 +499,13 @@ extern "C" const char *ntscsim_last_error(const ntscsim_ctx *c) { return c ? c->
 extern "C" uint64_t ntscsim_get_rng_pos(const ntscsim_ctx *c) { return c ? c->rng_pos : 0; }
 extern "C" void ntscsim_set_rng_pos(ntscsim_ctx *c, uint64_t pos) { if (c) c->rng_pos = pos; }
 extern "C" void ntscsim_set_profiling(ntscsim_ctx *c, int on) { if (c) c->profiling = on != 0; }
+
+extern "C" int ntscsim_set_launch_form(ntscsim_ctx *c, int form)
+{
+    if (!c || (form != NTSCSIM_FORM_THROUGHPUT && form != NTSCSIM_FORM_LATENCY)) return NTSCSIM_E_ARG;
+    c->latency_pref = form == NTSCSIM_FORM_LATENCY;
+    return NTSCSIM_OK;
+}
 
 extern "C" int ntscsim_sync(ntscsim_ctx *c)
 {
@@ -1163,6 +1171,12 @@ extern "C" int ntscsim_fields_device(ntscsim_ctx *c, const ntscsim_field_desc *d
     // buffer is the GPU's to address, a handful of 288-byte records is not worth a copy kernel and the dependency behind it
     // (the staging slot is then busy until the kernels have run: the event follows them).  NTSCSIM_RECORDS_INPLACE=0: A/B.
     static const bool inplace_env = !(std::getenv("NTSCSIM_RECORDS_INPLACE") && std::getenv("NTSCSIM_RECORDS_INPLACE")[0] == '0');
+    // (ntscsim_set_launch_form(NTSCSIM_FORM_LATENCY): a caller of this entry point asked for the role kernels)
+    struct FormGuard {      // (every return below restores the flag)
+        ntscsim_ctx *c; bool on;
+        FormGuard(ntscsim_ctx *c_, bool on_) : c(c_), on(on_) { if (on) c->latency_form = true; }
+        ~FormGuard() { if (on) c->latency_form = false; }
+    } form_guard(c, c->latency_pref && !c->latency_form && n <= pipe_max_fields());
     const bool inplace = inplace_env && c->latency_form && n <= pipe_max_fields();
     if (!inplace) {
         HIPCHK(c, hipMemcpyAsync(c->fields.p, c->stage[si], (size_t)n * sizeof(FieldDev),
@@ -1623,7 +1637,10 @@ extern "C" int ntscsim_fields422_device(ntscsim_ctx *c, const ntscsim_field422_d
     //  SLOWER here -- 3.21k against 3.39k calls/s: seven kernels read them, not two)
 
     c->setup_host_rec = host_fields;
+    const bool pref = c->latency_pref && !c->latency_form && n <= pipe_max_fields();      // (ntscsim_set_launch_form)
+    if (pref) c->latency_form = true;
     rc = launch422(c, P, dev_fields, dev_fields422, st, prof ? &evs : nullptr);
+    if (pref) c->latency_form = false;
     c->setup_host_rec = nullptr;
     if (rc != NTSCSIM_OK) return rc;
     if (prof) c->ev_live.push_back(evs);

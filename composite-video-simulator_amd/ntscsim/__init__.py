@@ -343,6 +343,10 @@ class FieldSimulator:
     def sync(self):
         self._chk(self._lib.ntscsim_sync(self._h), "ntscsim_sync")
 
+    def set_launch_form(self, latency=True):
+        """Device-resident launches of up to 64 fields as wavefront roles (ntscsim_set_launch_form: NTSCSIM_FORM_LATENCY)."""
+        self._chk(self._lib.ntscsim_set_launch_form(self._h, 1 if latency else 0), "ntscsim_set_launch_form")
+
     def set_profiling(self, on=True):
         self._lib.ntscsim_set_profiling(self._h, 1 if on else 0)
 

@@ -27,7 +27,7 @@ EXPORTS = (
     "ntscsim_set_mode", "ntscsim_get_rng_pos", "ntscsim_set_rng_pos", "ntscsim_field", "ntscsim_frames_host",
     "ntscsim_fields_device",
     "ntscsim_batch_create", "ntscsim_batch_run", "ntscsim_batch_destroy",
-    "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms",
+    "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms", "ntscsim_set_launch_form",
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
     "ntscsim_debug_force_generic", "ntscsim_debug_no_fast_decode", "ntscsim_debug_last_kernels", "ntscsim_debug_fast_plane_ok",
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
@@ -276,6 +276,8 @@ def lib():
     L.ntscsim_sync.restype = C.c_int
     L.ntscsim_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.ntscsim_set_profiling.restype = None
+    L.ntscsim_set_launch_form.argtypes = [C.c_void_p, C.c_int]
+    L.ntscsim_set_launch_form.restype = C.c_int
     L.ntscsim_get_timings_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.ntscsim_get_timings_ms.restype = C.c_int
     L.ntscsim_debug_read_composite.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_size_t]

@@ -660,6 +660,18 @@ uint64_t ntscsim_rng_calls_per_field_422(const ntscsim_params *p, int width, int
 /* Block until everything enqueued by this ctx has finished. */
 int ntscsim_sync(ntscsim_ctx *ctx);
 
+/* Which kernels a launch of DEVICE-RESIDENT fields takes (ntscsim_fields_device / ntscsim_fields422_device; the host-frame
+ * entry points -- ntscsim_field, ntscsim_submit, ntscsim_field422, ntscsim_submit422 -- decide for themselves):
+ *   NTSCSIM_FORM_THROUGHPUT (default)  the one-launch chain: one wavefront per 63 rows walks the whole pipeline -- what long
+ *                                      batches want (1.3 us per field at 600 fields, 0.42 ms for a launch of ANY length up to 32);
+ *   NTSCSIM_FORM_LATENCY               launches of up to 64 fields run the chain as wavefront ROLES of one workgroup per 63 rows
+ *                                      (csrc/ntsc_pipe.hip, k422_pipe): 0.17 ms for a launch of up to 32 fields -- a frame at a
+ *                                      time between a decoder and an encoder on the same GPU.  Same bytes either way; switch
+ *                                      sets the role kernels do not cover, and longer launches, keep the throughput form.
+ * NTSCSIM_OK, NTSCSIM_E_ARG. */
+enum { NTSCSIM_FORM_THROUGHPUT = 0, NTSCSIM_FORM_LATENCY = 1 };
+int ntscsim_set_launch_form(ntscsim_ctx *ctx, int form);
+
 /* Kernel timing from hipEvents recorded on the launch stream around each stage of every
  * ntscsim_fields_device() call made while profiling is on.  ntscsim_get_timings_ms() waits for
  * those calls, returns the SUMS since the previous query (index 0 setup kernels, 1 encode

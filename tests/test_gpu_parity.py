@@ -334,6 +334,38 @@ def test_synchronous_call_takes_the_pipelined_form_and_equals_the_oracle(flags, 
     sim.close()
 
 
+@pytest.mark.parametrize("flags,n,form", [(["-vhs"], 2, "k_field_pipe<double>"), (["-vhs"], 64, "k_field_pipe<double>"), ([], 6, "k_field_pipe_tv<double>"),
+                                          (["-vhs", "-comp-catv"], 4, "k_field_pipe_catv<double>"), (["-vhs"], 65, None),
+                                          (["-vhs", "-nocolor-subcarrier"], 4, None)])
+def test_device_resident_launches_take_the_latency_form_when_asked(flags, n, form):
+    """ntscsim_set_launch_form(NTSCSIM_FORM_LATENCY): ntscsim_fields_device() launches of up to 64 device-resident fields
+    run as wavefront roles (0.17 ms against 0.42 ms for a launch of up to 32 fields); longer launches and switch sets the
+    role kernels do not cover keep the throughput form; the default (NTSCSIM_FORM_THROUGHPUT) never takes them.  Same bytes
+    as the oracle in every case."""
+    import torch
+    w, h = 256, 100
+    p = L.make_params(flags)
+    srcs = np.stack([L.noise_frame(w, h, 60 + j) for j in range(3)])
+    src = torch.from_numpy(srcs).cuda()
+    jobs = [((k // 2) % 3, k, (k & 1) ^ 1, k) for k in range(n)]
+    o = L.OracleStream(p)
+    exp = np.zeros((n, h, w, 4), np.uint8)
+    for (si, di, field, fieldno) in jobs:
+        o.field(exp[di], srcs[si], field, fieldno)
+    for latency in (True, False):
+        sim = ntscsim.FieldSimulator(params=p)
+        if latency:
+            sim.set_launch_form(True)
+        dst = torch.zeros((n, h, w, 4), dtype=torch.uint8, device="cuda")
+        sim.fields(src, dst, jobs)
+        sim.sync()
+        ran = [x for x in sim.last_kernels() if x.startswith("k_field_pipe")]
+        assert ran == ([form] if (latency and form) else []), sim.last_kernels()
+        assert np.array_equal(dst.cpu().numpy(), exp)
+        assert sim.rng_pos == o.rng_pos
+        sim.close()
+
+
 def test_the_setup_kernel_launched_ahead_is_used_only_by_the_call_it_was_made_for():
     """ntscsim_field() launches the NEXT call's setup kernel behind its own work (speculate_setup: same switches and
     geometry, the field parity continuing the pattern, the rand() stream where the call left it); the next call skips its

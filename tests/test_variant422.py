@@ -344,6 +344,46 @@ _FORM_CASES = [
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags,form", [(["-vhs"], "k422_pipe<true,4>"), (["-vhs", "-vhs-speed", "ep"], "k422_pipe<false,6>"),
+                                        (["-vhs", "-vhs-svideo", "1"], "k422_pipe_sv<4>"), ([], "k422_direct_pipe"),
+                                        (["-yc-recomb", "1"], "k422_process")])
+def test_device_resident_launches_take_the_latency_form_when_asked(flags, form):
+    """ntscsim_set_launch_form(NTSCSIM_FORM_LATENCY): ntscsim_fields422_device() launches of up to 64 fields run the streamed
+    kernels as wavefront roles (k422_pipe / k422_direct_pipe) -- same bytes as the oracle; switch sets the roles do not cover
+    keep their form; back to NTSCSIM_FORM_THROUGHPUT the one-launch kernels return."""
+    import torch
+    w, h, n = 128, 38, 4
+    p = L.make_params_tocomp(flags)
+    srcs = [cases422.make_source422("noise" if j else "bars", w, h, j + 9, 0) for j in range(n // 2)]
+    o = L.TocompOracleStream(p, L.OOB_MEMORY)
+    frame = srcs[0].copy()
+    mask = last_row_margin_mask(frame, 0)
+    sim = ntscsim.FieldSimulator(params=p)
+    sim.set_launch_form(True)
+    whole, dev = to_dev_onebuf(torch, frame)
+    for k in range(n):
+        if k == n - 1:
+            sim.set_launch_form(False)
+        field = (k & 1) ^ 1
+        refresh(frame, srcs[k // 2], field)
+        o.process(frame, field, k)
+        _, srcd = to_dev_onebuf(torch, srcs[k // 2])
+        sim.fields422([{"dst": dev, "src": srcd, "src_height": h, "field": field, "fieldno": k}], w, h)
+        sim.sync()
+        ran = sim.last_kernels()
+        if k < n - 1:
+            assert form in ran, ran
+        else:
+            assert not any("pipe" in x for x in ran), ran
+        got = whole.cpu().numpy()
+        bad = (got != frame.buf) & mask
+        assert not bad.any(), "field %d: %d bytes differ, first at %d" % (k, int(bad.sum()), int(np.argmax(bad)))
+        frame.buf[~mask] = got[~mask]
+    assert sim.rng_pos == o.rng_pos
+    sim.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags,form", _FORM_CASES,
                          ids=["vhs", "vhs-lite0", "vhs-litelp", "vhs-nolp", "vhs-lp", "vhs-ep", "pal-vhs", "pal-vhs-ep", "vhs-catv",
                               "vhs-nonoise", "vhs-phase90-amp30", "vhs-dropout", "vhs-svideo", "vhs-svideo-lp-dropout", "vhs-svideo-phase90",
