@@ -151,12 +151,12 @@ struct GhostRing {
 };
 
 // One guarded step at any stream position t (wave-uniform): row start, row end, filter tails.
+// (edge_step_px: the pixel of position t -- 0 behind the row's end -- is handed in; edge_step loads it from the frame)
 template <class RT, bool PRE, int GH = 0>
-DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
-                   const uint32_t *srow, int t, const GhostRing<GH> &gh = GhostRing<GH>())
+DEV void edge_step_px(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
+                      const uint32_t px, int t, const GhostRing<GH> &gh = GhostRing<GH>())
 {
     const int W = C.W;
-    const uint32_t px = t < W ? ((fastdec::g_cu32_ptr)srow)[t] : 0u;
     RT dY, Id, Qd;
     rgb_to_yiq256<RT>(px, dY, Id, Qd);
     const int Yx = S.Yd[0], Ix = S.Ir[0], Qx = S.Qr[0];          // pixel t - 4
@@ -180,6 +180,14 @@ DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint3
     S.noise = sdiv2(S.noise + (int)umod31(S.rng.next(ring, C.lane), P.m_noise) - P.noise_k);
     Y = gh.emit(x, Y);
     __builtin_amdgcn_raw_buffer_store_b32(Y, C.comp, C.vcol, (int)((unsigned)x * (unsigned)C.rowbytes), NTSC_COMP_STORE_AUX);
+}
+
+template <class RT, bool PRE, int GH = 0>
+DEV void edge_step(const DevParams &P, EState<RT> &S, const EConst<RT> &C, uint32_t *ring,
+                   const uint32_t *srow, int t, const GhostRing<GH> &gh = GhostRing<GH>())
+{
+    const uint32_t px = t < C.W ? ((fastdec::g_cu32_ptr)srow)[t] : 0u;
+    edge_step_px<RT, PRE, GH>(P, S, C, ring, px, t, gh);
 }
 
 DEV void load_chunk(const uint8_t *srow, int t0, uint32_t (&px)[16])

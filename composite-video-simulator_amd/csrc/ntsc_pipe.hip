@@ -113,7 +113,7 @@ DEV int slot_of(int t, int SKT) { return (t - SKT) & (RING - 1); }
 // ------------------------------------------------------------------------------------------------ ENC: encoder
 template <class RT, bool XA = false, bool PRE = false>
 DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restrict__ rs_luma, const int *__restrict__ n0_luma,
-                      int *__restrict__ comp, uint32_t *ring, uint32_t *ltile, lds_flag fl)
+                      int *__restrict__ comp, uint32_t *ring, uint32_t *ltile, uint32_t *etail, lds_flag fl)
 {
     using namespace fastenc;
     const int lane = R.lane, W = P.W;
@@ -147,14 +147,31 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
     for (int q = 0; q < 4; q++) { S.Yd[q] = 0; S.Ir[q] = 0; S.Qr[q] = 0; }
     S.fI[0] = S.fI[1] = 0;
 
-    int t = 0;
-    for (; t < 4; t++) edge_step<RT, PRE, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
-    if (t + 16 <= W) {
-        CoopLoader L;
+    // The source frame may be the caller's own, in pinned HOST memory (ntscsim_field() on a frame the GPU can address: no
+    // upload): a load then takes a round trip over the link, so everything the row's guarded steps need -- its first four
+    // pixels, the up to 15 behind the last whole chunk -- and the first chunk are requested HERE, together; the pixels of the
+    // row's end wait in LDS (etail: [16][64]).
+    const fastdec::g_cu32_ptr gpx = (fastdec::g_cu32_ptr) reinterpret_cast<const uint32_t *>(srow);
+    const int t_e = 4 + 16 * ((W - 4) / 16);          // where the chunks end (W >= 16)
+    uint32_t hpx[4], tpx[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) hpx[j] = gpx[j];
+#pragma unroll
+    for (int j = 0; j < 16; j++) tpx[j] = t_e + j < W ? gpx[t_e + j] : 0u;
+    CoopLoader L;
+    v4u nq[4];
+    const bool chunks = 4 + 16 <= W;
+    if (chunks) {
         L.begin(srow, ltile, lane);
+        L.request(4, nq);
+    }
+    int t = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++, t++) edge_step_px<RT, PRE, 0>(P, S, C, ring, hpx[j], j);
+#pragma unroll
+    for (int j = 0; j < 16; j++) etail[j * 64 + lane] = tpx[j];
+    if (chunks) {
         uint32_t cur[16];
-        v4u nq[4];
-        L.request(t, nq);
         L.deliver(nq, cur);
         int Y0 = S.Yd[0], Y1 = S.Yd[1], Y2 = S.Yd[2], Y3 = S.Yd[3];
         int I0 = S.fI[0], I1 = S.fI[1];
@@ -212,7 +229,7 @@ DEV void encoder_role(const DevParams &P, const Row &R, const uint32_t *__restri
         NTSC_PIPE_VMCNT(0);
         publish(fl + F_ENC, t - 4);
     }
-    for (; t < W + 4; t++) edge_step<RT, PRE, 0>(P, S, C, ring, reinterpret_cast<const uint32_t *>(srow), t);
+    for (; t < W + 4; t++) edge_step_px<RT, PRE, 0>(P, S, C, ring, t < W ? etail[(t - t_e) * 64 + lane] : 0u, t);
     NTSC_PIPE_VMCNT(0);
     publish(fl + F_ENC, W);
 }
@@ -802,6 +819,7 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];                                   // the encoder's rand() ring
     __shared__ __attribute__((aligned(16))) uint32_t ltile[64 * 20];       // its cooperative row loads
+    __shared__ uint32_t etail[16 * 64];                                    // the pixels of its rows' ends, requested at the start
     __shared__ uint32_t ring_v[33 * 64];                                   // the chroma noise's rand() ring
     __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];      // the pixel staging
     __shared__ unsigned long long orow[64];
@@ -832,7 +850,7 @@ __global__ __launch_bounds__(320) void k_field_pipe(DevParams P, GeomDev G, cons
     const lds_x2 ab = (lds_x2)ring_ab;
     const lds_x2 bc = (lds_x2)ring_bc;
     const lds_x4 cd = (lds_x4)ring_cd;
-    if (role == 0) encoder_role<RT, XA, CATV>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    if (role == 0) encoder_role<RT, XA, CATV>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, etail, fl);
     else if (role == 1) sep_role<RT, WR, SV, XA, CATV>(P, R, comp, rs_chroma, n0_u, n0_v, hs_shift, ring_v, ab, fl);
     else if (role == 2) chroma_role<RT, SV, XA>(P, G, R, pn_noise, tails, ab, bc, fl);
     else if (role == 3) luma_role<RT, WR, SV, XA>(P, R, comp, hs_shift, dropout, bc, cd, fl);
@@ -859,6 +877,7 @@ __global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldD
     using namespace pipe;
     __shared__ uint32_t ring_e[33 * 64];
     __shared__ __attribute__((aligned(16))) uint32_t ltile[64 * 20];
+    __shared__ uint32_t etail[16 * 64];
     __shared__ __attribute__((aligned(16))) uint32_t ostage[64 * 20];
     __shared__ unsigned long long orow[64];
     __shared__ __attribute__((aligned(16))) uint32_t ring_cd[RING * 64 * 4];
@@ -883,7 +902,7 @@ __global__ __launch_bounds__(192) void k_field_pipe_tv(DevParams P, const FieldD
     __syncthreads();
     const lds_flag fl = (lds_flag)flags;
     const lds_x4 cd = (lds_x4)ring_cd;
-    if (role == 0) encoder_role<RT, false, CATV>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, fl);
+    if (role == 0) encoder_role<RT, false, CATV>(P, R, rs_luma, n0_luma, comp, ring_e, ltile, etail, fl);
     else if (role == 1) tvfront_role<RT, CATV>(P, R, comp, hs_shift, dropout, pn_noise, ptab, cd, fl);
     else output_role<RT, false>(P, R, ostage, orow, drow, cd, fl);
     if (R.lane == 0 && *(lds_flag)&g_fault) *fault = 1u + blockIdx.x;

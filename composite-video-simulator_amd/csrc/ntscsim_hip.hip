@@ -181,8 +181,15 @@ struct ntscsim_ctx {
         int misses = 0;
         uint64_t hits = 0, launched = 0, seen = 0;
     } spec;
+    // (the early kernel runs BESIDE the call's own kernels, on a stream of its own, into the OTHER of two sets of setup tables:
+    //  speculate_setup swaps the sets, so the next launch reads what the early kernel wrote while this call's kernels still
+    //  read theirs)
+    struct AltTables { DevBuf<int> hs_shift, pn_noise, dropout, n0_luma, n0_u, n0_v; DevBuf<uint32_t> rs_luma, rs_chroma; } alt;
+    hipStream_t s_spec = nullptr;
+    hipEvent_t ev_spec = nullptr;
     const FieldDev *setup_host_rec = nullptr;   // host copy of record 0 of the launch being made (set by the entry points)
     hipEvent_t ev_done = nullptr;               // ntscsim_field(): what the call waits for
+    uint64_t field_stats[3] = {0, 0, 0};        // ntscsim_debug_field_stats
     // ntscsim_field422() / ntscsim_submit422(): the same for the YUV422P tool -- the engine's upload event (not owned);
     // launch422 runs the per-field / per-row draws first and waits for it in front of the first kernel that reads pixels
     hipEvent_t wait422_ev = nullptr;
@@ -476,6 +483,10 @@ extern "C" void ntscsim_destroy(ntscsim_ctx *c)
     if (c->ev_src) (void)hipEventDestroy(c->ev_src);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->spec.rec) (void)hipHostFree(c->spec.rec);
+    c->alt.hs_shift.release(); c->alt.pn_noise.release(); c->alt.dropout.release(); c->alt.n0_luma.release();
+    c->alt.n0_u.release(); c->alt.n0_v.release(); c->alt.rs_luma.release(); c->alt.rs_chroma.release();
+    if (c->ev_spec) (void)hipEventDestroy(c->ev_spec);
+    if (c->s_spec) (void)hipStreamDestroy(c->s_spec);
     if (std::getenv("NTSCSIM_SETUP_AHEAD_STATS") && c->spec.seen)       // developer probe
         std::fprintf(stderr, "setup ahead: %llu single-field launches, %llu early kernels, %llu used\n",
                      (unsigned long long)c->spec.seen, (unsigned long long)c->spec.launched, (unsigned long long)c->spec.hits);
@@ -499,6 +510,13 @@ extern "C" const char *ntscsim_last_error(const ntscsim_ctx *c) { return c ? c->
 extern "C" uint64_t ntscsim_get_rng_pos(const ntscsim_ctx *c) { return c ? c->rng_pos : 0; }
 extern "C" void ntscsim_set_rng_pos(ntscsim_ctx *c, uint64_t pos) { if (c) c->rng_pos = pos; }
 extern "C" void ntscsim_set_profiling(ntscsim_ctx *c, int on) { if (c) c->profiling = on != 0; }
+
+extern "C" void ntscsim_debug_field_stats(const ntscsim_ctx *c, uint64_t out[4])
+{
+    if (!out) return;
+    for (int i = 0; i < 3; i++) out[i] = c ? c->field_stats[i] : 0;
+    out[3] = c ? c->spec.hits : 0;
+}
 
 extern "C" int ntscsim_set_launch_form(ntscsim_ctx *c, int form)
 {
@@ -630,8 +648,8 @@ static void launch_setup(ntscsim_ctx *c, const DevParams &D, const GeomDev &G, c
                           (hr->field & 1u) == sp.kfield && !std::memcmp(hr->rng, sp.krng, sizeof(sp.krng));
         if (same) { sp.misses = 0; if (sp.armed) { skip = true; sp.hits++; } }
         else if (c->latency_form && n == 1) sp.misses++;
-        // (a launch on ANOTHER stream must not meet the early kernel in the tables)
-        if (sp.armed && st != sp.st) (void)hipStreamSynchronize(sp.st);
+        // (the early kernel ran on its own stream: whatever reads or rewrites its tables comes behind it)
+        if (sp.armed) (void)hipStreamWaitEvent(st, c->ev_spec, 0);
         sp.armed = sp.dry = false;           // (whatever runs now rewrites the tables)
     }
     launch_setup_kernels(c, D, G, fields_dev, n, st, true, !skip);
@@ -655,6 +673,8 @@ static void speculate_setup(ntscsim_ctx *c, hipStream_t st)
     if (!on || !sp.have_last || st != sp.st || sp.armed) return;
     sp.have_last = false;
     if (!sp.rec && hipHostMalloc((void **)&sp.rec, 2 * sizeof(FieldDev), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); sp.rec = nullptr; return; }
+    if (!c->s_spec && hipStreamCreateWithFlags(&c->s_spec, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->s_spec = nullptr; return; }
+    if (!c->ev_spec && hipEventCreateWithFlags(&c->ev_spec, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->ev_spec = nullptr; return; }
     FieldDev r;
     std::memset(&r, 0, sizeof(r));
     // the parity alternates if the last two calls' did (or there is one call only), repeats otherwise
@@ -664,11 +684,30 @@ static void speculate_setup(ntscsim_ctx *c, hipStream_t st)
     for (int j = 31; j < 61; j++) r.rng[j] = r.rng[j - 31] + r.rng[j - 3];
     sp.kfield = r.field & 1u;
     std::memcpy(sp.krng, r.rng, sizeof(sp.krng));
+    if (sp.misses >= 2) { setup_tables(c, sp.tab); sp.dry = true; return; }      // (mispredicted twice: predict only, until a prediction holds again)
+    // the other set of tables, as large as the set in use (the kernels that read that one may still be running)
+    // (exactly as large: ensure() rounds up, and two sets that leapfrog each other would grow at every call)
+    auto match = [](auto &a, const auto &m) {
+        if (a.cap >= m.cap) return true;
+        a.release();
+        if (hipMalloc((void **)&a.p, m.cap * sizeof(*a.p)) != hipSuccess) { a.p = nullptr; return false; }
+        a.cap = m.cap;
+        return true;
+    };
+    if (!match(c->alt.hs_shift, c->hs_shift) || !match(c->alt.pn_noise, c->pn_noise) || !match(c->alt.dropout, c->dropout) ||
+        !match(c->alt.n0_luma, c->n0_luma) || !match(c->alt.n0_u, c->n0_u) || !match(c->alt.n0_v, c->n0_v) ||
+        !match(c->alt.rs_luma, c->rs_luma) || !match(c->alt.rs_chroma, c->rs_chroma)) {
+        (void)hipGetLastError();
+        return;
+    }
+    std::swap(c->hs_shift, c->alt.hs_shift); std::swap(c->pn_noise, c->alt.pn_noise); std::swap(c->dropout, c->alt.dropout);
+    std::swap(c->n0_luma, c->alt.n0_luma); std::swap(c->n0_u, c->alt.n0_u); std::swap(c->n0_v, c->alt.n0_v);
+    std::swap(c->rs_luma, c->alt.rs_luma); std::swap(c->rs_chroma, c->alt.rs_chroma);
     setup_tables(c, sp.tab);
-    if (sp.misses >= 2) { sp.dry = true; return; }      // (mispredicted twice: predict only, until a prediction holds again)
     FieldDev *const slot = sp.rec + (sp.rec_idx ^= 1u);
     *slot = r;
-    launch_setup_kernels(c, sp.D, sp.G, slot, 1, st, false, true);
+    launch_setup_kernels(c, sp.D, sp.G, slot, 1, c->s_spec, false, true);
+    (void)hipEventRecord(c->ev_spec, c->s_spec);
     (void)hipGetLastError();
     sp.armed = true;
     sp.launched++;
@@ -1872,6 +1911,21 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     if (!c->s_up) HIPCHK(c, hipStreamCreateWithFlags(&c->s_up, hipStreamNonBlocking));
     if (!c->ev_src) HIPCHK(c, hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
     const hipStream_t su = c->s_up;
+    // A SOURCE frame the GPU can address (pinned like the destination above) with 16-byte aligned rows is not uploaded at
+    // all: the call returns when the field is done, so the encoder role reads the rows where they are -- its loads are a
+    // chunk (2 us of its own work) ahead of their use, which covers the link's latency, and the pixels of its guarded steps
+    // are requested at the start (encoder_role).  NTSCSIM_FIELD_SRC_DIRECT=0: A/B switch.
+    static const bool src_direct_env = !(std::getenv("NTSCSIM_FIELD_SRC_DIRECT") && std::getenv("NTSCSIM_FIELD_SRC_DIRECT")[0] == '0');
+    const uint8_t *src_dev = nullptr;
+    if (src_direct_env && c->pin_policy > 0 && !(((uintptr_t)src | (uintptr_t)src_ls) & 15u))
+        src_dev = pinned_device_ptr(c, src, (size_t)src_ls * (size_t)(H - 1) + (size_t)W * 4);
+    if (src_dev && ((uintptr_t)src_dev & 15u)) src_dev = nullptr;
+    c->field_stats[0]++;
+    if (src_dev) c->field_stats[1]++;
+    if (dst_dev) c->field_stats[2]++;
+    if (src_dev) {
+        // (nothing to wait for)
+    } else
     if (full_upload || Lf <= 0) {
         HIPCHK(c, hipMemcpy2DAsync(c->fsrc.p, pitch, src, (size_t)src_ls, (size_t)W * 4, (size_t)H,
                                    hipMemcpyHostToDevice, su));
@@ -1883,12 +1937,14 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
             HIPCHK(c, hipMemcpyAsync(c->fsrc.p + pitch * (H - 1), src + (size_t)src_ls * (H - 1), (size_t)W * 4,
                                      hipMemcpyHostToDevice, su));
     }
-    HIPCHK(c, hipEventRecord(c->ev_src, su));
-    c->src_pending = true;
+    if (!src_dev) {
+        HIPCHK(c, hipEventRecord(c->ev_src, su));
+        c->src_pending = true;
+    }
     ntscsim_field_desc d;
     std::memset(&d, 0, sizeof(d));
-    d.src_dev = c->fsrc.p; d.dst_dev = dst_dev ? dst_dev : c->fdst.p;
-    d.src_linesize = (int)pitch; d.dst_linesize = dst_dev ? dst_ls : (int)pitch;
+    d.src_dev = src_dev ? (void *)src_dev : (void *)c->fsrc.p; d.dst_dev = dst_dev ? dst_dev : c->fdst.p;
+    d.src_linesize = src_dev ? src_ls : (int)pitch; d.dst_linesize = dst_dev ? dst_ls : (int)pitch;
     d.field = field;
     d.flags = (src_interlaced ? NTSCSIM_DESC_INTERLACED : 0u) | (src_tff ? NTSCSIM_DESC_TFF : 0u);
     d.fieldno = fieldno;

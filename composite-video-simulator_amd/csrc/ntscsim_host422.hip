@@ -909,7 +909,12 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
     // (rings smaller than configured -- the byte budget -- hold fewer iterations: a launch and its successor must fit)
     const size_t np = e->pending.size();
     const int depth = e->depth <= (e->ring - 2) / 2 ? e->depth : ((e->ring - 2) / 2 > 0 ? (e->ring - 2) / 2 : 1);
-    if ((int)np >= depth && (L->field == 0 || (int)np > depth)) return h422_launch(c);
+    if ((int)np >= depth && (L->field == 0 || (int)np > depth)) {
+        e->launch_for_wait = sync_call;     // (ntscsim_field422(): the caller waits for this launch next)
+        rc = h422_launch(c);
+        e->launch_for_wait = false;
+        return rc;
+    }
     return NTSCSIM_OK;
 }
 

@@ -343,6 +343,12 @@ class FieldSimulator:
     def sync(self):
         self._chk(self._lib.ntscsim_sync(self._h), "ntscsim_sync")
 
+    def debug_field_stats(self):
+        """[calls of ntscsim_field, sources read in place, destinations written in place, early setup kernels used]"""
+        a = (C.c_uint64 * 4)()
+        self._lib.ntscsim_debug_field_stats(self._h, a)
+        return list(a)
+
     def set_launch_form(self, latency=True):
         """Device-resident launches of up to 64 fields as wavefront roles (ntscsim_set_launch_form: NTSCSIM_FORM_LATENCY)."""
         self._chk(self._lib.ntscsim_set_launch_form(self._h, 1 if latency else 0), "ntscsim_set_launch_form")

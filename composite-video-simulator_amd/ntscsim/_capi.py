@@ -29,7 +29,7 @@ EXPORTS = (
     "ntscsim_batch_create", "ntscsim_batch_run", "ntscsim_batch_destroy",
     "ntscsim_sync", "ntscsim_set_profiling", "ntscsim_get_timings_ms", "ntscsim_set_launch_form",
     "ntscsim_debug_read_composite", "ntscsim_debug_set_warmup",
-    "ntscsim_debug_force_generic", "ntscsim_debug_no_fast_decode", "ntscsim_debug_last_kernels", "ntscsim_debug_fast_plane_ok",
+    "ntscsim_debug_force_generic", "ntscsim_debug_no_fast_decode", "ntscsim_debug_last_kernels", "ntscsim_debug_fast_plane_ok", "ntscsim_debug_field_stats",
     "ntscsim_params_init_to_composite", "ntscsim_params_parse_argv_to_composite",
     "ntscsim_fields422_device", "ntscsim_output422_device", "ntscsim_bgra_to_yuv_device", "ntscsim_rng_calls_per_field_422",
     "ntscsim_scale_to_bgra_device", "ntscsim_frames_host_scaled",
@@ -315,6 +315,8 @@ def lib():
     L.ntscsim_debug_last_kernels.restype = C.c_int
     L.ntscsim_debug_fast_plane_ok.argtypes = [C.c_int] * 4
     L.ntscsim_debug_fast_plane_ok.restype = C.c_int
+    L.ntscsim_debug_field_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.ntscsim_debug_field_stats.restype = None
     L.ntscsim_batch422_create.argtypes = [C.c_void_p, C.POINTER(Field422Desc), C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_void_p)]
     L.ntscsim_batch422_create.restype = C.c_int

@@ -717,6 +717,12 @@ int ntscsim_debug_last_kernels(const ntscsim_ctx *ctx, char *out, size_t cap);
  * 0 = the generic kernels run. */
 int ntscsim_debug_fast_plane_ok(int n_fields, int width, int height, int head_switching);
 
+/* Test hook: what the synchronous call ntscsim_field() did since the ctx was created -- [0] calls, [1] calls whose SOURCE
+ * frame was read where it is (pinned memory the GPU can address, 16-byte aligned rows: no upload), [2] calls whose
+ * DESTINATION frame was written where it is (no download), [3] calls (of either tool's synchronous entry point) that
+ * found their setup kernel already run, launched ahead of time by the call before. */
+void ntscsim_debug_field_stats(const ntscsim_ctx *ctx, uint64_t out[4]);
+
 /* ---- the raw-composite decoder: ffmpeg_raw28ntsc.cpp ---------------
  * The tool reads 8-bit composite video sampled at 8 x fsc (28.636 MHz, e.g. a cxadc capture) and
  * renders one grey-scale BGRA frame of (scanline_samples + 1 & ~1) x 262 per field:

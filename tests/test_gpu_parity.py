@@ -497,6 +497,45 @@ def test_synchronous_call_writes_pinned_destination_frames_in_place(flags, w, h,
     host_free_array(block)
 
 
+@pytest.mark.parametrize("flags,w,h,pad,off,il,tff,direct", [
+    (["-vhs"], 720, 486, 0, 0, 0, 0, True), ([], 256, 100, 64, 16, 1, 1, True), (["-vhs", "-comp-catv"], 100, 7, 16, 0, 1, 0, True),
+    (["-vhs"], 20, 9, 0, 0, 0, 0, True), (["-vhs"], 36, 130, 0, 32, 0, 0, True), (["-vhs", "-vhs-svideo", "1"], 333, 65, 8, 0, 0, 0, False),
+    (["-vhs"], 256, 100, 0, 4, 0, 0, False), (["-noise", "0"], 64, 40, 0, 0, 0, 0, True)])
+def test_synchronous_call_reads_pinned_source_frames_in_place(flags, w, h, pad, off, il, tff, direct):
+    """ntscsim_field() on a SOURCE frame the GPU can address (pinned, 16-byte aligned rows): nothing is uploaded -- the encoder
+    reads the caller's rows over the link, with the pixels of its guarded steps (the row's first four, the up to 15 behind
+    its last whole chunk) requested at the start; widths with every remainder, padded rows, interlaced sources.  Same bytes as
+    the oracle; rows that are not 16-byte aligned (pad = 8 at width 333, off = 4) take the upload.  The bytes of the frame are never
+    written."""
+    from ntscsim import host_alloc_array, host_free_array
+    p = L.make_params(flags, output_height=h)
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    rowb = w * 4 + pad
+    block = host_alloc_array((rowb * h + 64 + off,))
+    block[:] = 0xC3
+    base = block[off:off + rowb * h]
+    srcv = np.lib.stride_tricks.as_strided(base, shape=(h, w, 4), strides=(rowb, 4, 1))
+    got = np.full((h, w, 4), 0x5A, np.uint8)
+    exp = np.full((h, w, 4), 0x5A, np.uint8)
+    u8p = ntscsim.C.POINTER(ntscsim.C.c_uint8)
+    for k in range(4):
+        s = L.noise_frame(w, h, 70 + k // 2)
+        srcv[:] = s
+        keep = block.copy()
+        field = (k & 1) ^ 1
+        rc = sim._lib.ntscsim_field(sim._h, srcv.ctypes.data_as(u8p), rowb, il, tff, got.ctypes.data_as(u8p), w * 4, w, h, field, k)
+        sim._chk(rc, "ntscsim_field")
+        o.field(exp, s, field, k, interlaced=il, tff=tff)
+        assert np.array_equal(got, exp), "call %d" % k
+        assert sim.rng_pos == o.rng_pos
+        assert np.array_equal(block, keep), "the source frame was written"
+    st = sim.debug_field_stats()
+    assert st[0] == 4 and st[1] == (4 if direct else 0), st
+    sim.close()
+    host_free_array(block)
+
+
 @pytest.mark.parametrize("h", [2, 3, 32, 33])
 @pytest.mark.parametrize("il,tff", [(0, 0), (1, 0), (1, 1)])
 def test_host_frame_dropin_uploads_the_rows_it_reads(h, il, tff):

@@ -64,12 +64,19 @@ for seed in range(s0, s0 + n):
         base = np.zeros((nbytes + 64,), np.uint8)[r.choice([0, 4, 16]):][:nbytes]
     base[:] = 0x5A
     got = np.lib.stride_tricks.as_strided(base, shape=(h, w, 4), strides=(rowb, 4, 1))
+    sblk, src_pin = None, None
+    if r.random() < 0.5:
+        sblk = host_alloc_array((w * 4 * h + 64,))
+        src_pin = sblk[r.choice([0, 16, 32, 4]):][:w * 4 * h].reshape(h, w, 4)
     exp = np.full((h, w, 4), 0x5A, np.uint8)
     order = r.choice([(1, 0), (0, 1)])
     ok = True
     try:
         for k in range(r.choice([2, 4, 5])):
             s = L.noise_frame(w, h, seed * 5 + k // 2) if r.random() < 0.8 else L.bars(w, h, k)
+            if src_pin is not None:           # a pinned source frame: read in place by the encoder role
+                src_pin[:] = s
+                s = src_pin
             field = order[k & 1]
             rc = sim._lib.ntscsim_field(sim._h, s.ctypes.data_as(ntscsim.C.POINTER(ntscsim.C.c_uint8)), s.strides[0], il, tff,
                                         got.ctypes.data_as(ntscsim.C.POINTER(ntscsim.C.c_uint8)), rowb, w, h, field, k)
@@ -85,6 +92,7 @@ for seed in range(s0, s0 + n):
     finally:
         sim.close()
         if blk is not None: host_free_array(blk)
+        if sblk is not None: host_free_array(sblk)
 print("fuzz_pipe: %d cases from seed %d, %d failures, %.0f s" % (n, s0, len(bad), time.time() - t0))
 for k, v in census.most_common(): print("  %5d  %s" % (v, k))
 for b in bad[:20]: print("  FAIL", b)
