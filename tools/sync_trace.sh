@@ -47,6 +47,12 @@ for v in 1 0; do
   b=$(NTSCSIM_SETUP_AHEAD=$v $FL4 -vhs --mode sync --fields 3000 --warmup 200 --alloc pinned 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
   echo "   ahead=$v: $a | $b"
 done
+echo "== pinned source frames read in place by the encoder (NTSCSIM_FIELD_SRC_DIRECT=0: uploaded), pinned frames: -vhs | default preset"
+for v in 1 0; do
+  a=$(NTSCSIM_FIELD_SRC_DIRECT=$v $FL -vhs --mode sync --fields 3000 --warmup 200 --alloc pinned 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
+  b=$(NTSCSIM_FIELD_SRC_DIRECT=$v $FL --mode sync --fields 3000 --warmup 200 --alloc pinned 2>/dev/null | python3 -c "import sys,json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['fields_per_s'])")
+  echo "   in place=$v: $a | $b"
+done
 NTSCSIM_SETUP_AHEAD_STATS=1 $FL -vhs --mode sync --fields 500 --warmup 20 2>&1 | grep "setup ahead" | sed 's/^/   BGRA tool: /'
 NTSCSIM_SETUP_AHEAD_STATS=1 $FL4 -vhs --mode sync --fields 500 --warmup 20 2>&1 | grep "setup ahead" | sed 's/^/   YUV422P tool: /'
 echo "== the roles' clocks inside one call (-vhs; 100 MHz wall clock from the workgroup's start; polling = time spent waiting for a hand-off)"
