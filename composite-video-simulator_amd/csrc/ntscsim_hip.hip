@@ -1917,7 +1917,11 @@ extern "C" int ntscsim_field(ntscsim_ctx *c, const uint8_t *src, int src_ls, int
     // are requested at the start (encoder_role).  NTSCSIM_FIELD_SRC_DIRECT=0: A/B switch.
     static const bool src_direct_env = !(std::getenv("NTSCSIM_FIELD_SRC_DIRECT") && std::getenv("NTSCSIM_FIELD_SRC_DIRECT")[0] == '0');
     const uint8_t *src_dev = nullptr;
-    if (src_direct_env && c->pin_policy > 0 && !(((uintptr_t)src | (uintptr_t)src_ls) & 15u))
+    // (never a source that shares bytes with the destination: the upload is the snapshot such a caller relies on)
+    const uintptr_t s0_ = (uintptr_t)src, s1_ = s0_ + (size_t)src_ls * (size_t)(H - 1) + (size_t)W * 4;
+    const uintptr_t d0_ = (uintptr_t)dst, d1_ = d0_ + (size_t)dst_ls * (size_t)(H - 1) + (size_t)W * 4;
+    const bool apart = s1_ <= d0_ || d1_ <= s0_;
+    if (src_direct_env && apart && c->pin_policy > 0 && !(((uintptr_t)src | (uintptr_t)src_ls) & 15u))
         src_dev = pinned_device_ptr(c, src, (size_t)src_ls * (size_t)(H - 1) + (size_t)W * 4);
     if (src_dev && ((uintptr_t)src_dev & 15u)) src_dev = nullptr;
     c->field_stats[0]++;

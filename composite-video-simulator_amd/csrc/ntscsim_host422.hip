@@ -843,7 +843,19 @@ static int h422_submit(ntscsim_ctx *c, const ntscsim_loop422 *L, uint32_t flags,
     // (the SYNCHRONOUS call returns when its iteration is done: pinned source planes need no snapshot -- k422_render reads
     //  them where they are, 0.7 MB over the link instead of a memcpy on the calling thread + a DMA of the same bytes)
     static const bool sync_direct = !(std::getenv("NTSCSIM_FIELD422_SRCDIRECT") && std::getenv("NTSCSIM_FIELD422_SRCDIRECT")[0] == '0');   // developer A/B
-    if (have_src && sync_call && sync_direct && h422_pin_frame(c, e, L->src, W, L->src_height, (int)src_crows, it.src_dev)) {
+    // (never planes that share bytes with a frame the iteration writes: the snapshot is what such a caller relies on)
+    auto shares = [&](const ntscsim_frame422 &f, int rows_y, int rows_c) {
+        if (!f.data[0]) return false;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                const uintptr_t s0 = (uintptr_t)L->src.data[a], s1 = s0 + (size_t)L->src.linesize[a] * (a ? src_crows : (size_t)L->src_height);
+                const uintptr_t f0 = (uintptr_t)f.data[b], f1 = f0 + (size_t)f.linesize[b] * (size_t)(b ? rows_c : rows_y);
+                if (s0 < f1 && f0 < s1) return true;
+            }
+        return false;
+    };
+    const bool src_apart = have_src && !shares(L->frame, H, H) && !shares(L->filter, H, H) && !shares(L->out, H, H);
+    if (have_src && sync_call && sync_direct && src_apart && h422_pin_frame(c, e, L->src, W, L->src_height, (int)src_crows, it.src_dev)) {
         e->src_cur = -1;                  // (no device copy of this source: a later SAME_SRC submit takes its own)
     } else
     if (have_src) {

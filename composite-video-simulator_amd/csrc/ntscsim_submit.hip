@@ -521,6 +521,14 @@ extern "C" int ntscsim_host_pin(ntscsim_ctx *c, const void *base, size_t len)
     if (!c->declared) return NTSCSIM_E_NOMEM;
     const uintptr_t PG = 4096, a0 = (uintptr_t)base, a1 = a0 + len;
     const uintptr_t p0 = a0 & ~(PG - 1), p1 = (a1 + PG - 1) & ~(PG - 1);
+    // Never memory of the brk heap (small malloc blocks): the allocator trims and recycles those pages under a registration,
+    // and the GPU then faults on them -- in this call or in an unrelated later one (seen: sporadic aborts of the process,
+    // rocr's VMFaultHandler).  What can be declared is an allocation of its own: a mapping, a block above the mmap threshold,
+    // a pool.  (The engines' own pinning has always refused these addresses: pin_lookup.)
+    if (p0 < (uintptr_t)sbrk(0)) {
+        c->err = "ntscsim_host_pin: the range lies in the brk heap (a small malloc block); declare an allocation of its own";
+        return NTSCSIM_E_ARG;
+    }
     for (auto &r : c->declared->regs)
         if (p0 >= r.p0 && p1 <= r.p1) return NTSCSIM_OK;                 // declared before
     // registrations the engines made on their own for these pages go first (everything in flight is delivered)

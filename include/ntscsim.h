@@ -311,7 +311,9 @@ int ntscsim_wait(ntscsim_ctx *ctx, uint64_t ticket);
  * (hipHostRegister; memory that is pinned already is just noted) and every frame inside the range takes the
  * no-copy path from then on, wherever it starts.  The caller vouches that those pages hold nothing that is freed or
  * recycled while the declaration lives (an allocation of its own: a mmap, a large malloc block incl. its header page,
- * a frame pool).  NTSCSIM_OK, NTSCSIM_E_ARG, NTSCSIM_E_HIP (registration refused; nothing changed). */
+ * a frame pool).  Memory of the brk heap -- small malloc blocks, whose pages the allocator trims and recycles -- is refused
+ * (NTSCSIM_E_ARG): a registration there makes the GPU fault sooner or later.
+ * NTSCSIM_OK, NTSCSIM_E_ARG, NTSCSIM_E_HIP (registration refused; nothing changed). */
 int ntscsim_host_pin(ntscsim_ctx *ctx, const void *base, size_t len);
 /* Drop the registration that covers `base` (NULL: all of them) -- declared or made by the engine on its own --
  * after waiting for everything in flight: call before free()ing a frame buffer the engine has seen while the ctx

@@ -482,8 +482,17 @@ def test_synchronous_call_writes_pinned_destination_frames_in_place(flags, w, h,
         assert np.array_equal(got, exp), "call %d" % k
         assert sim.rng_pos == o.rng_pos
     assert (block[:32 + off] == 0xA7).all() and (block[32 + off + h * w * 4:] == 0xA7).all()
-    # declared memory (ntscsim_host_pin) takes the same path
-    frame = np.zeros((h * w * 4 + 8192,), np.uint8)
+    # declared memory (ntscsim_host_pin) takes the same path -- a mapping of its own: pages of the brk heap (what a small
+    # numpy array is made of) are refused, a registration there makes the GPU fault sooner or later
+    import mmap
+    libc = ntscsim.C.CDLL(None)
+    libc.sbrk.restype, libc.sbrk.argtypes = ntscsim.C.c_void_p, [ntscsim.C.c_long]
+    small = np.zeros((3000,), np.uint8)
+    if small.ctypes.data < libc.sbrk(0):          # (a small block of the brk heap, as expected of the allocator)
+        with pytest.raises(ntscsim.NtscsimError):
+            sim.host_pin(small)
+    mm = mmap.mmap(-1, h * w * 4 + 8192)
+    frame = np.frombuffer(mm, np.uint8)
     a0 = (-frame.ctypes.data) % 4096
     got2 = frame[a0:a0 + h * w * 4].reshape(h, w, 4)
     sim.host_pin(frame[a0:a0 + ((h * w * 4 + 4095) // 4096) * 4096])

@@ -56,7 +56,8 @@ for seed in range(s0, s0 + n):
         blk = host_alloc_array((nbytes + 64,))
         base = blk[r.choice([0, 16, 32, 4]):][:nbytes]
     elif kind == "declared":
-        raw = np.zeros((nbytes + 3 * 4096,), np.uint8)
+        import mmap            # (a mapping of its own: ntscsim_host_pin refuses pages of the brk heap)
+        raw = np.frombuffer(mmap.mmap(-1, nbytes + 3 * 4096), np.uint8)
         a0 = (-raw.ctypes.data) % 4096
         sim.host_pin(raw[a0:a0 + ((nbytes + 4095) // 4096) * 4096])
         base = raw[a0:a0 + nbytes]
