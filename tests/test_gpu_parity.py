@@ -545,6 +545,31 @@ def test_synchronous_call_reads_pinned_source_frames_in_place(flags, w, h, pad, 
     host_free_array(block)
 
 
+def test_synchronous_call_on_one_pinned_frame_as_source_and_destination():
+    """composite_layer() reads its whole field before it writes a pixel (:1585-1609), so the tool may be handed ONE frame as
+    source and destination.  A pinned frame would qualify for being read AND written in place at once -- the encoder would
+    meet the decoder's rows: frames that share bytes take the upload (the snapshot), and the result is the oracle's."""
+    from ntscsim import host_alloc_array, host_free_array
+    w, h = 256, 100
+    p = L.make_params(["-vhs"])
+    sim = ntscsim.FieldSimulator(params=p)
+    o = L.OracleStream(p)
+    block = host_alloc_array((h * w * 4,))
+    frame = block.reshape(h, w, 4)
+    frame[:] = L.noise_frame(w, h, 11)
+    exp = frame.copy()
+    for k in range(4):
+        field = (k & 1) ^ 1
+        src_copy = exp.copy()
+        o.field(exp, src_copy, field, k)
+        sim.field_host(frame, frame, field, k)
+        assert np.array_equal(frame, exp), "call %d" % k
+    st = sim.debug_field_stats()
+    assert st[1] == 0 and st[2] == 4, st
+    sim.close()
+    host_free_array(block)
+
+
 @pytest.mark.parametrize("h", [2, 3, 32, 33])
 @pytest.mark.parametrize("il,tff", [(0, 0), (1, 0), (1, 1)])
 def test_host_frame_dropin_uploads_the_rows_it_reads(h, il, tff):
